@@ -1,0 +1,101 @@
+// ORACLE (test infrastructure) command line: the reference module names and flag names
+// (mm/commons/Parameters.cpp:423-439,872-892; src/commons/LocalParameters.h:96-102) over the
+// CPU restatement.  Usage mirrors `plass <module> …`:
+//   plass_oracle kmermatcher <seqDB> <prefDB> [flags]
+//   plass_oracle rescorediagonal <qDB> <tDB> <prefDB> <alnDB> [flags]
+//   plass_oracle assembleresults|nuclassembleresults <seqDB> <alnDB> <outDB> [flags]
+#include "oracle.hpp"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace oracle;
+
+static bool multiParam(const std::string &v, const char *which, std::string &out) {
+    // "aa:13,nucl:5" or "13"
+    if (v.find(':') == std::string::npos) { out = v; return true; }
+    size_t p = 0;
+    while (p < v.size()) {
+        size_t c = v.find(',', p); if (c == std::string::npos) c = v.size();
+        std::string part = v.substr(p, c - p);
+        size_t col = part.find(':');
+        if (col != std::string::npos && part.substr(0, col) == which) { out = part.substr(col + 1); return true; }
+        p = c + 1;
+    }
+    return false;
+}
+
+static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<std::string> &pos) {
+    for (int i = from; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) {
+            if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); return 1; }
+            std::string v = argv[++i], t;
+            if (a == "-k") par.kmerSize = atoi(v.c_str());
+            else if (a == "--alph-size") { if (multiParam(v, "aa", t)) par.alphabetSizeAA = atoi(t.c_str()); }
+            else if (a == "--kmer-per-seq") par.kmersPerSequence = atoi(v.c_str());
+            else if (a == "--kmer-per-seq-scale") {
+                if (multiParam(v, "aa", t)) par.kmersPerSequenceScaleAA = strtof(t.c_str(), nullptr);
+                if (multiParam(v, "nucl", t)) par.kmersPerSequenceScaleNucl = strtof(t.c_str(), nullptr);
+            }
+            else if (a == "--hash-shift") par.hashShift = atoi(v.c_str());
+            else if (a == "--include-only-extendable") par.includeOnlyExtendable = atoi(v.c_str()) != 0;
+            else if (a == "--ignore-multi-kmer") par.ignoreMultiKmer = atoi(v.c_str()) != 0;
+            else if (a == "--cov-mode") par.covMode = atoi(v.c_str());
+            else if (a == "-c") par.covThr = strtof(v.c_str(), nullptr);
+            else if (a == "--rescore-mode") par.rescoreMode = atoi(v.c_str());
+            else if (a == "-e") par.evalThr = strtod(v.c_str(), nullptr);
+            else if (a == "--min-seq-id") par.seqIdThr = strtof(v.c_str(), nullptr);
+            else if (a == "--min-aln-len") par.alnLenThr = atoi(v.c_str());
+            else if (a == "--seq-id-mode") par.seqIdMode = atoi(v.c_str());
+            else if (a == "-a") par.addBacktrace = atoi(v.c_str()) != 0;
+            else if (a == "--add-self-matches") par.includeIdentity = atoi(v.c_str()) != 0;
+            else if (a == "--max-seq-len") par.maxSeqLen = (size_t) strtoull(v.c_str(), nullptr, 10);
+            else if (a == "--keep-target") par.keepTarget = atoi(v.c_str()) != 0;
+            else { /* accepted and ignored: --sub-mat --threads -v --compressed --mask … */ }
+        } else pos.push_back(a);
+    }
+    return 0;
+}
+
+static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv) {
+    if (argc < 2) { fprintf(stderr, "usage: plass_oracle <module> <dbs…> [flags]\n"); return 1; }
+    std::string mod = argv[1];
+    Params par; std::vector<std::string> pos; std::string err;
+    // module defaults: kmermatcher's setLinearFilterDefault sets covThr 0.8 (kmermatcher.cpp:566-573);
+    // the workflows always pass -c explicitly, and so do the tests.
+    if (parseFlags(argc, argv, 2, par, pos)) return 1;
+    if (mod == "kmermatcher") {
+        if (pos.size() != 2) { fprintf(stderr, "kmermatcher <seqDB> <prefDB>\n"); return 1; }
+        DB seq; if (!readDB(pos[0], seq, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        double t0 = now(); KmerStats st;
+        DB pref = kmermatcher(seq, par, &st);
+        double t1 = now();
+        fprintf(stderr, "oracle kmermatcher: %zu seqs, N_k=%zu N_m=%zu N_c=%zu, %.3f s\n", seq.size(), st.nKmerRecords, st.nGrouped, st.nCandidates, t1 - t0);
+        if (!writeDB(pos[1], pref, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "rescorediagonal") {
+        if (pos.size() != 4) { fprintf(stderr, "rescorediagonal <qDB> <tDB> <prefDB> <alnDB>\n"); return 1; }
+        DB q, t, pref;
+        if (!readDB(pos[0], q, err) || !readDB(pos[2], pref, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        bool same = pos[0] == pos[1];
+        if (!same && !readDB(pos[1], t, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        double t0 = now();
+        DB aln = rescorediagonal(q, same ? q : t, same, pref, par);
+        fprintf(stderr, "oracle rescorediagonal: %.3f s\n", now() - t0);
+        if (!writeDB(pos[3], aln, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "assembleresults" || mod == "nuclassembleresults") {
+        if (pos.size() != 3) { fprintf(stderr, "%s <seqDB> <alnDB> <outDB>\n", mod.c_str()); return 1; }
+        DB seq, aln;
+        if (!readDB(pos[0], seq, err) || !readDB(pos[1], aln, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        double t0 = now();
+        DB out = (mod == "assembleresults") ? assembleresults(seq, aln, par) : nuclassembleresults(seq, aln, par);
+        fprintf(stderr, "oracle %s: %.3f s\n", mod.c_str(), now() - t0);
+        if (!writeDB(pos[2], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else { fprintf(stderr, "unknown module %s\n", mod.c_str()); return 1; }
+    return 0;
+}
