@@ -1,0 +1,170 @@
+/* plasship — C-ABI of the MI355X-native Plass/PenguiN hot path
+ *   kmermatcher -> rescorediagonal -> assembleresults
+ *
+ * This is the drop-in boundary.  In the reference each of the three steps is an
+ * MMseqs2 "module" `int f(int argc, const char** argv, const Command&)` (mm/commons/Command.h:91-102)
+ * registered by name (src/plass.cpp:24-30, src/penguin.cpp:30-47) and run as a sub-process by
+ * data/assemble.sh:92,103,145; modules exchange DBReader/DBWriter databases on disk.  A derived tool
+ * overrides a module by registering the same name (mm/commons/Application.cpp:24-36).  The entry
+ * points below are what such an override binds: plain pointers and sizes, no C++
+ * or torch types.  Host buffers are owned by the caller, device buffers by the library.  All functions
+ * return 0 on success and a negative code on failure; plasship_last_error() gives the message (thread
+ * local).  One context per process/GPU; calls on one context are not re-entrant.  There is NO CPU
+ * fallback: if no gfx950 device is usable, plasship_ctx_create fails.
+ */
+#ifndef PLASSHIP_H
+#define PLASSHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plasship_ctx plasship_ctx;       /* one GPU + stream + scratch arenas              */
+typedef struct plasship_seqdb plasship_seqdb;   /* sequence DB resident in HBM                    */
+typedef struct plasship_cands plasship_cands;   /* prefilter result (candidate pairs) in HBM      */
+typedef struct plasship_alns plasship_alns;     /* alignment result (verified overlaps) in HBM    */
+
+#define PLASSHIP_OK 0
+#define PLASSHIP_ERR_ARG (-1)
+#define PLASSHIP_ERR_IO (-2)
+#define PLASSHIP_ERR_DEVICE (-3)
+#define PLASSHIP_ERR_UNSUPPORTED (-4)
+
+/* MMseqs2 dbtype codes (mm/commons/Parameters.h:65-84) */
+#define PLASSHIP_DBTYPE_AMINO_ACIDS 0
+#define PLASSHIP_DBTYPE_NUCLEOTIDES 1
+#define PLASSHIP_DBTYPE_ALIGNMENT_RES 5
+#define PLASSHIP_DBTYPE_PREFILTER_RES 7
+#define PLASSHIP_DBTYPE_PREFILTER_REV_RES 14
+
+const char *plasship_last_error(void);
+const char *plasship_version(void);
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* replaces: process start-up of a module (MMseqsMPI::init + Parameters singleton,
+ * mm/linclust/kmermatcher.cpp:780-785).  device_ordinal < 0 = use LOCAL_RANK or 0.            */
+int plasship_ctx_create(int device_ordinal, plasship_ctx **out);
+void plasship_ctx_destroy(plasship_ctx *ctx);
+int plasship_ctx_sync(plasship_ctx *ctx);
+/* raw hipStream_t of the context, so a caller can bracket work with its own events */
+void *plasship_ctx_stream(plasship_ctx *ctx);
+
+/* ---- sequence DB  (replaces DBReader<unsigned int>::open/getData/getSeqLen/getDbKey,
+ *      mm/commons/DBReader.cpp:150-215,548-589; DBReader.h:185-213) --------------------------- */
+/* data = concatenation of entries "SEQ\n\0"; off/elen index it (elen includes "\n\0");
+ * keys need not be sorted — ids are ranks in key order like DBReader::getId.                   */
+int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t data_bytes, const uint64_t *off,
+                          const uint32_t *elen, const uint32_t *key, size_t n, int dbtype,
+                          plasship_seqdb **out);
+int plasship_seqdb_read(plasship_ctx *ctx, const char *db_path, plasship_seqdb **out);
+/* replaces DBWriter::writeData/close for a sequence DB (mm/commons/DBWriter.cpp:362-419,522-614) */
+int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *db, const char *db_path);
+int plasship_seqdb_info(const plasship_seqdb *db, size_t *n, uint64_t *residues, uint32_t *max_entry_len,
+                        int *dbtype, uint64_t *data_bytes);
+/* download in key order; any pointer may be NULL */
+int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *db, char *data, uint64_t *off,
+                            uint32_t *elen, uint32_t *key);
+void plasship_seqdb_free(plasship_ctx *ctx, plasship_seqdb *db);
+
+/* ---- kmermatcher  (replaces int kmermatcher(int, const char**, const Command&),
+ *      mm/linclust/kmermatcher.cpp:780-807; flags of Parameters.cpp:872-892) ------------------- */
+typedef struct plasship_kmermatch_params {
+    int32_t kmer_size;               /* -k                       (14 plass / 22 penguin nucl)     */
+    int32_t alphabet_size;           /* --alph-size aa           (13; 21 = full)                  */
+    int32_t kmers_per_seq;           /* --kmer-per-seq           (60)                             */
+    float kmers_per_seq_scale;       /* --kmer-per-seq-scale for the DB's alphabet               */
+    int32_t hash_shift;              /* --hash-shift             (67, 68, 68, 69 …)               */
+    int32_t include_only_extendable; /* --include-only-extendable                                 */
+    int32_t ignore_multi_kmer;       /* --ignore-multi-kmer                                       */
+    int32_t cov_mode;                /* --cov-mode                                                */
+    float cov_thr;                   /* -c                                                        */
+} plasship_kmermatch_params;
+
+typedef struct plasship_kmermatch_stats {
+    uint64_t n_kmer_records;   /* N_k: records emitted by extraction (incl. identity records)    */
+    uint64_t n_grouped;        /* N_m: records after assignGroup                                 */
+    uint64_t n_candidates;     /* N_c: non-self prefilter lines                                  */
+    uint32_t record_bytes;     /* 16 (T=short) or 20 (T=int) in the reference layout             */
+    float ms_extract, ms_sort1, ms_group, ms_sort2, ms_reduce; /* HIP-event kernel times         */
+} plasship_kmermatch_stats;
+
+int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par,
+                       plasship_cands **out, plasship_kmermatch_stats *stats);
+
+/* prefilter DB <-> device candidate list (hit_t lines "seqId\tprefScore\tdiagonal\n",
+ * mm/prefiltering/QueryMatcher.h:35-51,81-126; back-fill of self-only entries kmermatcher.cpp:705-724) */
+int plasship_cands_write(plasship_ctx *ctx, const plasship_cands *c, const plasship_seqdb *db, const char *db_path);
+int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb, const plasship_seqdb *tdb,
+                        const char *db_path, plasship_cands **out);
+int plasship_cands_count(const plasship_cands *c, uint64_t *n_hits, int *reverse_capable);
+/* arrays of n_hits (non-self) entries in prefilter order (query key, then target key ascending);
+ * qdb/tdb are the DBs the list was built on (ids are mapped back to DB keys) */
+int plasship_cands_download(plasship_ctx *ctx, const plasship_cands *c, const plasship_seqdb *qdb,
+                            const plasship_seqdb *tdb, uint32_t *query_key, uint32_t *target_key,
+                            int32_t *pref_score, uint16_t *diagonal);
+void plasship_cands_free(plasship_ctx *ctx, plasship_cands *c);
+
+/* ---- rescorediagonal  (replaces int rescorediagonal(int, const char**, const Command&),
+ *      mm/alignment/rescorediagonal.cpp:381-431; flags of Parameters.cpp:423-439) -------------- */
+typedef struct plasship_rescore_params {
+    int32_t rescore_mode;     /* --rescore-mode: 2 local start/end, 3 end-to-end (default)        */
+    double eval_thr;          /* -e                                                               */
+    float seq_id_thr;         /* --min-seq-id                                                     */
+    int32_t cov_mode;         /* --cov-mode                                                       */
+    float cov_thr;            /* -c                                                               */
+    int32_t min_aln_len;      /* --min-aln-len                                                    */
+    int32_t seq_id_mode;      /* --seq-id-mode                                                    */
+    int32_t add_backtrace;    /* -a                                                               */
+    int32_t include_identity; /* --add-self-matches                                               */
+} plasship_rescore_params;
+
+typedef struct plasship_rescore_stats {
+    uint64_t n_scored;    /* candidate pairs scored (incl. the self hit of every query)          */
+    uint64_t n_accepted;  /* alignment lines kept                                                */
+    uint64_t overlap_residues; /* Σ diagonal overlap length over scored pairs                    */
+    float ms_kernel;
+} plasship_rescore_stats;
+
+/* qdb == tdb (same handle) is the plass case (sameQTDB, rescorediagonal.cpp:59-69) */
+int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, const plasship_seqdb *tdb,
+                     const plasship_cands *c, const plasship_rescore_params *par, plasship_alns **out,
+                     plasship_rescore_stats *stats);
+
+/* alignment DB <-> device (Matcher::resultToBuffer / parseAlignmentRecord, mm/alignment/Matcher.cpp:248-370) */
+int plasship_alns_write(plasship_ctx *ctx, const plasship_alns *a, const char *db_path);
+int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, const char *db_path, plasship_alns **out);
+int plasship_alns_count(const plasship_alns *a, uint64_t *n_lines);
+typedef struct plasship_aln_record {   /* one accepted alignment line, binary */
+    uint32_t query_key, target_key;
+    int32_t bit_score, raw_score;
+    float seq_id;              /* exact float before text truncation                              */
+    int32_t q_start, q_end, q_len, db_start, db_end, db_len, aln_len;
+    int32_t reversed;
+} plasship_aln_record;
+int plasship_alns_download(plasship_ctx *ctx, const plasship_alns *a, plasship_aln_record *out);
+void plasship_alns_free(plasship_ctx *ctx, plasship_alns *a);
+
+/* ---- assembleresults  (replaces int assembleresult(int, const char**, const Command&),
+ *      src/assembler/assembleresult.cpp:358-368; flags LocalParameters.h:96-102) --------------- */
+typedef struct plasship_assemble_params {
+    float seq_id_thr;       /* --min-seq-id                                                      */
+    uint64_t max_seq_len;   /* --max-seq-len                                                     */
+    int32_t keep_target;    /* --keep-target                                                     */
+    int32_t rescore_mode;   /* --rescore-mode                                                    */
+} plasship_assemble_params;
+
+typedef struct plasship_assemble_stats {
+    uint64_t n_extended;        /* queries that became (longer) contigs                          */
+    uint64_t n_rescored;        /* deferred hits re-scored on an extended query (A4)             */
+    uint64_t out_residues;
+    float ms_kernel;
+} plasship_assemble_stats;
+
+int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *a,
+                      const plasship_assemble_params *par, plasship_seqdb **out, plasship_assemble_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLASSHIP_H */

@@ -19,3 +19,7 @@ g++ -O3 -DNDEBUG -w -fsigned-char -march=native -std=c++1y -fopenmp -DENABLE_IPS
     $B/lib/mmseqs/lib/microtar/libmicrotar.a -lz
 "$OUT" dump | grep -v "^Reduced amino acid alphabet\|^Time for processing" > "$HERE/../ref_tables.h"
 echo "wrote $HERE/../ref_tables.h"
+# The product keeps its own copy of the same DATA (it must not include anything under oracle/).
+sed -e 's/REF_/PH_/g' -e '1s|.*|/* GENERATED DATA (oracle/tools/make_tables.sh): constant tables of the reference matrices. */|' \
+    "$HERE/../ref_tables.h" > "$HERE/../../plass_amd/csrc/tables_data.h"
+echo "wrote plass_amd/csrc/tables_data.h"

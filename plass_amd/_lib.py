@@ -1,0 +1,292 @@
+"""ctypes binding of include/plasship.h (no torch types cross the boundary)."""
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libplasship.so")
+
+
+class PlasshipError(RuntimeError):
+    pass
+
+
+class _KmermatchParams(C.Structure):
+    _fields_ = [("kmer_size", C.c_int32), ("alphabet_size", C.c_int32), ("kmers_per_seq", C.c_int32),
+                ("kmers_per_seq_scale", C.c_float), ("hash_shift", C.c_int32), ("include_only_extendable", C.c_int32),
+                ("ignore_multi_kmer", C.c_int32), ("cov_mode", C.c_int32), ("cov_thr", C.c_float)]
+
+
+class KmermatchStats(C.Structure):
+    _fields_ = [("n_kmer_records", C.c_uint64), ("n_grouped", C.c_uint64), ("n_candidates", C.c_uint64),
+                ("record_bytes", C.c_uint32), ("ms_extract", C.c_float), ("ms_sort1", C.c_float),
+                ("ms_group", C.c_float), ("ms_sort2", C.c_float), ("ms_reduce", C.c_float)]
+
+
+class _RescoreParams(C.Structure):
+    _fields_ = [("rescore_mode", C.c_int32), ("eval_thr", C.c_double), ("seq_id_thr", C.c_float), ("cov_mode", C.c_int32),
+                ("cov_thr", C.c_float), ("min_aln_len", C.c_int32), ("seq_id_mode", C.c_int32), ("add_backtrace", C.c_int32),
+                ("include_identity", C.c_int32)]
+
+
+class RescoreStats(C.Structure):
+    _fields_ = [("n_scored", C.c_uint64), ("n_accepted", C.c_uint64), ("overlap_residues", C.c_uint64), ("ms_kernel", C.c_float)]
+
+
+class _AssembleParams(C.Structure):
+    _fields_ = [("seq_id_thr", C.c_float), ("max_seq_len", C.c_uint64), ("keep_target", C.c_int32), ("rescore_mode", C.c_int32)]
+
+
+class AssembleStats(C.Structure):
+    _fields_ = [("n_extended", C.c_uint64), ("n_rescored", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float)]
+
+
+class AlnRecord(C.Structure):
+    _fields_ = [("query_key", C.c_uint32), ("target_key", C.c_uint32), ("bit_score", C.c_int32), ("raw_score", C.c_int32),
+                ("seq_id", C.c_float), ("q_start", C.c_int32), ("q_end", C.c_int32), ("q_len", C.c_int32),
+                ("db_start", C.c_int32), ("db_end", C.c_int32), ("db_len", C.c_int32), ("aln_len", C.c_int32), ("reversed", C.c_int32)]
+
+
+# every symbol include/plasship.h declares: (name, restype, argtypes)
+P = C.c_void_p
+SYMBOLS = [
+    ("plasship_last_error", C.c_char_p, []),
+    ("plasship_version", C.c_char_p, []),
+    ("plasship_ctx_create", C.c_int, [C.c_int, C.POINTER(P)]),
+    ("plasship_ctx_destroy", None, [P]),
+    ("plasship_ctx_sync", C.c_int, [P]),
+    ("plasship_ctx_stream", P, [P]),
+    ("plasship_seqdb_upload", C.c_int, [P, C.c_char_p, C.c_size_t, P, P, P, C.c_size_t, C.c_int, C.POINTER(P)]),
+    ("plasship_seqdb_read", C.c_int, [P, C.c_char_p, C.POINTER(P)]),
+    ("plasship_seqdb_write", C.c_int, [P, P, C.c_char_p]),
+    ("plasship_seqdb_info", C.c_int, [P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    ("plasship_seqdb_download", C.c_int, [P, P, P, P, P, P]),
+    ("plasship_seqdb_free", None, [P, P]),
+    ("plasship_kmermatch", C.c_int, [P, P, C.POINTER(_KmermatchParams), C.POINTER(P), C.POINTER(KmermatchStats)]),
+    ("plasship_cands_write", C.c_int, [P, P, P, C.c_char_p]),
+    ("plasship_cands_read", C.c_int, [P, P, P, C.c_char_p, C.POINTER(P)]),
+    ("plasship_cands_count", C.c_int, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_int)]),
+    ("plasship_cands_download", C.c_int, [P, P, P, P, P, P, P, P]),
+    ("plasship_cands_free", None, [P, P]),
+    ("plasship_rescore", C.c_int, [P, P, P, P, C.POINTER(_RescoreParams), C.POINTER(P), C.POINTER(RescoreStats)]),
+    ("plasship_alns_write", C.c_int, [P, P, C.c_char_p]),
+    ("plasship_alns_read", C.c_int, [P, P, C.c_char_p, C.POINTER(P)]),
+    ("plasship_alns_count", C.c_int, [P, C.POINTER(C.c_uint64)]),
+    ("plasship_alns_download", C.c_int, [P, P, P]),
+    ("plasship_alns_free", None, [P, P]),
+    ("plasship_assemble", C.c_int, [P, P, P, C.POINTER(_AssembleParams), C.POINTER(P), C.POINTER(AssembleStats)]),
+]
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree HIP library and bind every declared symbol; raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise PlasshipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(plass_amd has no CPU fallback)" % path)
+    lib = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().plasship_last_error()
+        raise PlasshipError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+@dataclass
+class KmermatchParams:
+    """kmermatcher flags (defaults = plass assemble, src/workflow/Assembler.cpp:10-27)."""
+    k: int = 14
+    alph_size: int = 13
+    kmer_per_seq: int = 60
+    kmer_per_seq_scale: float = 0.0
+    hash_shift: int = 67
+    include_only_extendable: bool = False
+    ignore_multi_kmer: bool = True
+    cov_mode: int = 0
+    c: float = 0.0
+
+    def _c(self):
+        return _KmermatchParams(self.k, self.alph_size, self.kmer_per_seq, self.kmer_per_seq_scale, self.hash_shift,
+                                int(self.include_only_extendable), int(self.ignore_multi_kmer), self.cov_mode, self.c)
+
+
+@dataclass
+class RescoreParams:
+    rescore_mode: int = 3
+    e: float = 1e-5
+    min_seq_id: float = 0.9
+    cov_mode: int = 0
+    c: float = 0.0
+    min_aln_len: int = 0
+    seq_id_mode: int = 0
+    a: bool = False
+    add_self_matches: bool = False
+
+    def _c(self):
+        return _RescoreParams(self.rescore_mode, self.e, self.min_seq_id, self.cov_mode, self.c, self.min_aln_len,
+                              self.seq_id_mode, int(self.a), int(self.add_self_matches))
+
+
+@dataclass
+class AssembleParams:
+    min_seq_id: float = 0.9
+    max_seq_len: int = 65535
+    keep_target: bool = True
+    rescore_mode: int = 3
+
+    def _c(self):
+        return _AssembleParams(self.min_seq_id, self.max_seq_len, int(self.keep_target), self.rescore_mode)
+
+
+class Context:
+    """One GPU (one process per GPU; LOCAL_RANK picks the device when ordinal < 0)."""
+
+    def __init__(self, device=-1):
+        self.lib = load_library()
+        self.h = P()
+        _check(self.lib.plasship_ctx_create(device, C.byref(self.h)), "plasship_ctx_create")
+
+    def close(self):
+        if self.h:
+            self.lib.plasship_ctx_destroy(self.h)
+            self.h = P()
+
+    def sync(self):
+        _check(self.lib.plasship_ctx_sync(self.h), "plasship_ctx_sync")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # ---- modules -------------------------------------------------------------------------------
+    def read_seqdb(self, path):
+        h = P()
+        _check(self.lib.plasship_seqdb_read(self.h, os.fsencode(path), C.byref(h)), "plasship_seqdb_read")
+        return SeqDB(self, h)
+
+    def upload_seqdb(self, data, off, elen, key, dbtype=0):
+        import numpy as np
+        data = bytes(data)
+        off = np.ascontiguousarray(off, dtype=np.uint64); elen = np.ascontiguousarray(elen, dtype=np.uint32)
+        key = np.ascontiguousarray(key, dtype=np.uint32)
+        h = P()
+        _check(self.lib.plasship_seqdb_upload(self.h, data, len(data), off.ctypes.data, elen.ctypes.data, key.ctypes.data,
+                                              len(key), dbtype, C.byref(h)), "plasship_seqdb_upload")
+        return SeqDB(self, h)
+
+    def kmermatcher(self, db, par=None):
+        par = par or KmermatchParams()
+        h = P(); st = KmermatchStats(); cp = par._c()
+        _check(self.lib.plasship_kmermatch(self.h, db.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_kmermatch")
+        return Candidates(self, h, db, db), st
+
+    def read_prefdb(self, qdb, tdb, path):
+        h = P()
+        _check(self.lib.plasship_cands_read(self.h, qdb.h, tdb.h, os.fsencode(path), C.byref(h)), "plasship_cands_read")
+        return Candidates(self, h, qdb, tdb)
+
+    def rescorediagonal(self, qdb, tdb, cands, par=None):
+        par = par or RescoreParams()
+        h = P(); st = RescoreStats(); cp = par._c()
+        _check(self.lib.plasship_rescore(self.h, qdb.h, tdb.h, cands.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_rescore")
+        return Alignments(self, h, qdb, tdb), st
+
+    def read_alndb(self, db, path):
+        h = P()
+        _check(self.lib.plasship_alns_read(self.h, db.h, os.fsencode(path), C.byref(h)), "plasship_alns_read")
+        return Alignments(self, h, db, db)
+
+    def assembleresults(self, db, alns, par=None):
+        par = par or AssembleParams()
+        h = P(); st = AssembleStats(); cp = par._c()
+        _check(self.lib.plasship_assemble(self.h, db.h, alns.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_assemble")
+        return SeqDB(self, h), st
+
+
+class SeqDB:
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def info(self):
+        n = C.c_size_t(); res = C.c_uint64(); mx = C.c_uint32(); ty = C.c_int(); nb = C.c_uint64()
+        _check(self.ctx.lib.plasship_seqdb_info(self.h, C.byref(n), C.byref(res), C.byref(mx), C.byref(ty), C.byref(nb)), "plasship_seqdb_info")
+        return dict(n=n.value, residues=res.value, max_entry_len=mx.value, dbtype=ty.value, data_bytes=nb.value)
+
+    def write(self, path):
+        _check(self.ctx.lib.plasship_seqdb_write(self.ctx.h, self.h, os.fsencode(path)), "plasship_seqdb_write")
+
+    def download(self):
+        import numpy as np
+        i = self.info()
+        data = C.create_string_buffer(max(i["data_bytes"], 1))
+        off = np.zeros(i["n"], dtype=np.uint64); elen = np.zeros(i["n"], dtype=np.uint32); key = np.zeros(i["n"], dtype=np.uint32)
+        _check(self.ctx.lib.plasship_seqdb_download(self.ctx.h, self.h, data, off.ctypes.data, elen.ctypes.data, key.ctypes.data), "plasship_seqdb_download")
+        return data.raw[:i["data_bytes"]], off, elen, key
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.plasship_seqdb_free(self.ctx.h, self.h); self.h = P()
+
+
+class Candidates:
+    def __init__(self, ctx, h, qdb, tdb):
+        self.ctx, self.h, self.qdb, self.tdb = ctx, h, qdb, tdb
+
+    def count(self):
+        n = C.c_uint64(); r = C.c_int()
+        _check(self.ctx.lib.plasship_cands_count(self.h, C.byref(n), C.byref(r)), "plasship_cands_count")
+        return n.value
+
+    def write(self, path):
+        _check(self.ctx.lib.plasship_cands_write(self.ctx.h, self.h, self.qdb.h, os.fsencode(path)), "plasship_cands_write")
+
+    def download(self):
+        import numpy as np
+        n = self.count()
+        q = np.zeros(n, dtype=np.uint32); t = np.zeros(n, dtype=np.uint32); s = np.zeros(n, dtype=np.int32); d = np.zeros(n, dtype=np.uint16)
+        _check(self.ctx.lib.plasship_cands_download(self.ctx.h, self.h, self.qdb.h, self.tdb.h, q.ctypes.data, t.ctypes.data, s.ctypes.data, d.ctypes.data), "plasship_cands_download")
+        return q, t, s, d
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.plasship_cands_free(self.ctx.h, self.h); self.h = P()
+
+
+class Alignments:
+    def __init__(self, ctx, h, qdb, tdb):
+        self.ctx, self.h, self.qdb, self.tdb = ctx, h, qdb, tdb   # keeps the DBs alive (ids -> keys)
+
+    def count(self):
+        n = C.c_uint64()
+        _check(self.ctx.lib.plasship_alns_count(self.h, C.byref(n)), "plasship_alns_count")
+        return n.value
+
+    def write(self, path):
+        _check(self.ctx.lib.plasship_alns_write(self.ctx.h, self.h, os.fsencode(path)), "plasship_alns_write")
+
+    def download(self):
+        n = self.count()
+        arr = (AlnRecord * max(n, 1))()
+        _check(self.ctx.lib.plasship_alns_download(self.ctx.h, self.h, arr), "plasship_alns_download")
+        return arr[:n]
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.plasship_alns_free(self.ctx.h, self.h); self.h = P()

@@ -1,0 +1,356 @@
+// plasship: assembleresults on gfx950 (rows A1–A5 of SURVEY.md §8a), protein variant.  Product code.
+//
+// Reference behaviour reproduced (file:line in /root/reference):
+//   src/assembler/assembleresult.cpp:19-36     CompareResultByScore (score, alnLength, smaller key) — strict
+//   src/assembler/assembleresult.cpp:40-57     selectFragmentToExtend: pop until an extendable non-self hit
+//   src/assembler/assembleresult.cpp:161-189   queue fill: raw score from bit score, score/seqId rescaling
+//   src/assembler/assembleresult.cpp:193-314   extension rounds, deferred hits re-scored on the new query
+//   src/assembler/assembleresult.cpp:70-108    updateAlignment (identity count end-EXCLUSIVE, exact chars)
+//   src/assembler/assembleresult.cpp:316-342   flags 0x20 (became contig) / 0x80 (consumed), carry-over pass
+//   lib/mmseqs/src/alignment/Matcher.cpp:248-320  the text round trip the reference reads its input through:
+//       seqId has 3 truncated decimals ("1.00" for 1.0), alnLength = max(|qE-qS|,|tE-tS|)+1, score = bit score
+//
+// Kernel design: one wavefront per query.  The greedy loop is control flow on a handful of integers
+// (wave-uniform); the data-parallel parts — arg-max over the remaining hits, fragment copies, ungapped
+// re-scoring — use all 64 lanes.  The growing query lives in an HBM arena sized by an exact upper bound
+// (query + every target that could ever be attached on either side), so no allocation happens in the loop.
+// Because the comparator is a strict total order, std::priority_queue's pop order is "max of what is in
+// the queue", which is what the wave arg-max computes.
+// The nucleotide variants (non-strict Bayesian comparator, heap-order dependent) stay on the host side.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "host_util.hpp"
+#include <algorithm>
+#include <cstring>
+
+namespace plasship {
+
+struct Item {             // one alignment of the current query (reference: Matcher::result_t in the queue)
+    uint32_t target; int32_t score; uint32_t alnLength; float seqId;
+    int32_t qStart, qEnd; uint32_t qLen; int32_t dbStart, dbEnd; uint32_t dbLen;
+    uint32_t state;       // 0 = in queue, 1 = deferred (tmpAlignments), 2 = gone
+    uint32_t pad;
+};
+
+struct AsmArgs {
+    SeqView s;
+    const uint64_t *qoff; const AlnRec *recs;   // CSR of accepted alignments
+    Item *items;                                // [nLines] scratch, same indexing as recs
+    const uint64_t *arenaOff;                   // [n+1] byte offsets into arena
+    const uint32_t *leftCap;                    // [n] bytes reserved left of the original query
+    char *arena;
+    uint32_t *flags;                            // [n] wasExtended bits (0x20, 0x80)
+    uint32_t *newLen;                           // [n] length of the extended query (valid if flag 0x20)
+    uint64_t *newStart;                         // [n] absolute arena offset of the extended query
+    const signed char *mat;
+    double lambda, logK, ln2;
+    float seqIdThr; uint64_t maxSeqLen; int rescoreMode;
+    unsigned long long *stats;                  // [0] extended, [1] rescored
+};
+
+// text round trip of seqId (Util.cpp:278-307 + strtod in Matcher.cpp:265)
+__device__ __forceinline__ float seqIdThroughText(float f) {
+    if (f == 1.0f) return 1.0f;
+    const int t = (int) (f * 1000);
+    int zeros = 0;
+    if ((double) f < 0.10) zeros++;
+    if ((double) f < 0.01) zeros++;
+    int digits = 1; for (int x = t; x >= 10; x /= 10) digits++;
+    double den = 1.0; for (int i = 0; i < digits + zeros; i++) den *= 10.0;
+    return (float) ((double) t / den);
+}
+
+// ungappedAlignmentByDiagonal, mode 3 (DistanceCalculator.h:115-175,204-220) + the counts updateAlignment needs
+struct Rescored { int startPos, endPos; unsigned score, diagonalLen; int idExcl; };
+__device__ __forceinline__ Rescored rescoreOnDiagonal(const char *q, unsigned qLen, const char *t, unsigned tLen, int diagonal,
+                                                      const signed char *smat) {
+    Rescored r; r.startPos = -1; r.endPos = -1; r.score = 0; r.diagonalLen = 0; r.idExcl = 0;
+    const unsigned dist = (unsigned) abs(diagonal);
+    unsigned qo, to, len;
+    if (diagonal >= 0 && dist < qLen) { qo = dist; to = 0; len = min(tLen, qLen - dist); }
+    else if (diagonal < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, qLen); }
+    else return r;
+    r.diagonalLen = len;
+    if (len == 0) return r;
+    unsigned first = (q[qo] == '*' || t[to] == '*') ? 1u : 0u;
+    unsigned last = len - 1;
+    if (last > 0 && (q[qo + len - 1] == '*' || t[to + len - 1] == '*')) last--;
+    int s = 0, ids = 0;
+    for (unsigned p = first + (unsigned) laneId(); p <= last; p += 64) {
+        const char a = q[qo + p], b = t[to + p];
+        s += (int) smat[(int) a * 123 + (int) b];
+        if (p < last) ids += (a == b) ? 1 : 0;          // [qStart, qEnd): the last aligned column is not counted
+    }
+    s = waveReduceSum(s); ids = waveReduceSum(ids);
+    r.score = (unsigned) max(s, 0); r.startPos = (int) first; r.endPos = (int) last; r.idExcl = ids;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void assembleKernel(AsmArgs a) {
+    __shared__ signed char smat[123 * 123 + 7];
+    for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    unsigned long long nExt = 0, nResc = 0;
+    for (uint32_t id = blockIdx.x; id < a.s.n; id += gridDim.x) {
+        const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
+        const uint32_t h = (uint32_t) (h1 - h0);
+        if (h == 0) continue;
+        const uint64_t aoff = a.arenaOff[id];
+        if (a.arenaOff[id + 1] == aoff) continue;          // no non-self hit: can never be extended
+        Item *it = a.items + h0;
+        const char *orig = a.s.data + a.s.off[id];
+        unsigned querySeqLen = a.s.len[id];
+        // ---- queue fill (assembleresult.cpp:161-189) ----
+        for (uint32_t i = lane; i < h; i += 64) {
+            const AlnRec r = a.recs[h0 + i];
+            Item x;
+            x.target = r.target;
+            const int aq = (r.qStart == -1) ? 0 : r.qStart, ad = (r.dbStart == -1) ? 0 : r.dbStart;
+            x.alnLength = (uint32_t) (max(abs(r.qEnd - aq), abs(r.dbEnd - ad)) + 1);           // Matcher::computeAlnLength
+            const int rawScore = (int) (fma((double) r.bitScore, a.ln2, a.logK) / a.lambda + 0.5);
+            const float scorePerCol = (float) rawScore / (float) ((double) x.alnLength + 0.5);
+            const float sid = r.fromText ? r.seqId : seqIdThroughText(r.seqId);
+            const float alnLen = (float) x.alnLength;
+            const float ids = sid * alnLen;
+            x.seqId = (float) ((double) ids / ((double) alnLen + 0.5));
+            x.score = (int) (scorePerCol * 100);
+            x.qStart = r.qStart; x.qEnd = r.qEnd; x.qLen = (uint32_t) r.qLen; x.dbStart = r.dbStart; x.dbEnd = r.dbEnd; x.dbLen = (uint32_t) r.dbLen;
+            x.state = 0; x.pad = 0;
+            it[i] = x;
+        }
+        // the query starts in the middle of its arena slice
+        char *buf = a.arena + aoff;
+        uint64_t curStart = a.leftCap[id];
+        for (uint32_t i = lane; i < querySeqLen; i += 64) buf[curStart + i] = orig[i];
+        uint64_t curLen = querySeqLen;
+        __syncthreads();
+        bool couldExtend = false;
+        uint32_t inQueue = h;
+        while (inQueue > 0) {
+            unsigned leftOff = 0, rightOff = 0;
+            bool brokeOut = false;
+            // deferred list of this round = items with state 1; clear leftovers of the previous round
+            for (uint32_t i = lane; i < h; i += 64) if (it[i].state == 1) it[i].state = 2;
+            __syncthreads();
+            for (;;) {
+                // ---- selectFragmentToExtend: pop the maximum until one is extendable ----
+                int bs = INT_MIN; uint32_t bl = 0, bt = 0xFFFFFFFFu, bi = 0xFFFFFFFFu;
+                for (uint32_t i = lane; i < h; i += 64) {
+                    const Item x = it[i];
+                    if (x.state != 0) continue;
+                    const bool better = (bi == 0xFFFFFFFFu) || (x.score > bs) || (x.score == bs && (x.alnLength > bl || (x.alnLength == bl && x.target < bt)));
+                    if (better) { bs = x.score; bl = x.alnLength; bt = x.target; bi = i; }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int os = __shfl_xor(bs, o, 64); const uint32_t ol = __shfl_xor(bl, o, 64), ot = __shfl_xor(bt, o, 64), oi = __shfl_xor(bi, o, 64);
+                    const bool better = (oi != 0xFFFFFFFFu) && ((bi == 0xFFFFFFFFu) || (os > bs) || (os == bs && (ol > bl || (ol == bl && ot < bt))));
+                    if (better) { bs = os; bl = ol; bt = ot; bi = oi; }
+                }
+                if (bi == 0xFFFFFFFFu) { inQueue = 0; break; }      // queue empty
+                Item best = it[bi];
+                __syncthreads();
+                if (lane == 0) it[bi].state = 2;                    // popped
+                inQueue--;
+                __syncthreads();
+                const bool notBoth = !(best.dbStart == 0 && best.qStart == 0);
+                const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
+                const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
+                const bool notIdentity = best.target != id;
+                if (!((rightStart || leftStart) && notBoth && notIdentity)) continue;    // discarded
+                const char *tSeq = a.s.data + a.s.off[best.target];
+                const unsigned tLen = a.s.len[best.target];
+                if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff) continue; }
+                else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff) continue; }
+                const unsigned dbStart = (unsigned) best.dbStart, dbEnd = (unsigned) best.dbEnd, qStart = (unsigned) best.qStart, qEnd = (unsigned) best.qEnd;
+                if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
+                    if (rightOff > 0) { if (lane == 0) it[bi].state = 1; __syncthreads(); continue; }
+                    const unsigned fragLen = tLen - (dbEnd + 1);
+                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + curLen + i] = tSeq[dbEnd + 1 + i];
+                    curLen += fragLen; rightOff += fragLen;
+                    if (lane == 0) atomicOr(&a.flags[best.target], 0x80u);
+                } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
+                    if (leftOff > 0) { if (lane == 0) it[bi].state = 1; __syncthreads(); continue; }
+                    const unsigned fragLen = dbStart;
+                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    curStart -= fragLen;
+                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + i] = tSeq[i];
+                    curLen += fragLen; leftOff += fragLen;
+                    if (lane == 0) atomicOr(&a.flags[best.target], 0x80u);
+                }
+                __syncthreads();
+            }
+            if (leftOff > 0 || rightOff > 0) couldExtend = true;
+            if (brokeOut && inQueue > 0) break;
+            // ---- re-score deferred hits on the extended query (assembleresult.cpp:288-313) ----
+            querySeqLen = (unsigned) curLen;
+            const char *qs = buf + curStart;
+            __syncthreads();
+            for (uint32_t i = 0; i < h; i++) {
+                if (it[i].state != 1) continue;                     // wave-uniform (same memory, after barrier)
+                Item x = it[i];
+                const char *tSeq = a.s.data + a.s.off[x.target];
+                const unsigned tLen = a.s.len[x.target];
+                const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
+                const Rescored rs = rescoreOnDiagonal(qs, querySeqLen, tSeq, tLen, diag, smat);
+                nResc++;
+                // updateAlignment
+                const int dist = abs(diag);
+                int qS, qE, dS, dE;
+                if (diag >= 0) { qS = rs.startPos + dist; qE = rs.endPos + dist; dS = rs.startPos; dE = rs.endPos; }
+                else { qS = rs.startPos; qE = rs.endPos; dS = rs.startPos + dist; dE = rs.endPos + dist; }
+                const float seqId = (float) rs.idExcl / ((float) qE - (float) qS);
+                x.seqId = seqId; x.qLen = querySeqLen; x.dbLen = tLen; x.alnLength = rs.diagonalLen;
+                const float spc = (float) rs.score / (float) ((double) x.alnLength + 0.5);
+                x.score = (int) (spc * 100);
+                x.qStart = qS; x.qEnd = qE; x.dbStart = dS; x.dbEnd = dE;
+                const bool requeue = seqId >= a.seqIdThr;
+                x.state = requeue ? 0u : 2u;
+                if (requeue) inQueue++;
+                __syncthreads();
+                if (lane == 0) it[i] = x;
+                __syncthreads();
+            }
+            // recount what is really queued (defensive: the loop condition must match the item states)
+            {
+                uint32_t c = 0;
+                for (uint32_t i = lane; i < h; i += 64) c += (it[i].state == 0) ? 1u : 0u;
+                inQueue = (uint32_t) waveReduceSum((int) c);
+            }
+        }
+        if (couldExtend) {
+            if (lane == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; }
+            nExt++;
+        }
+        __syncthreads();
+    }
+    if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); }
+}
+
+// arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
+__global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
+                                uint64_t *__restrict__ bytes) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
+        uint64_t sum = 0;
+        for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) { const AlnRec r = recs[i]; if (r.target != id) sum += (uint64_t) r.dbLen; }
+        leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
+        bytes[id] = sum ? (2 * sum + s.len[id] + 8) : 0;
+    }
+}
+
+__global__ void outLenKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen, int keepTarget,
+                             uint64_t *__restrict__ outBytes, uint32_t *__restrict__ keep) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
+        const uint32_t f = flags[id];
+        uint64_t b = 0; uint32_t k = 0;
+        if (f & 0x20u) { b = (uint64_t) newLen[id] + 2; k = 1; }
+        else if (keepTarget || !(f & 0x80u)) { b = (uint64_t) s.len[id] + 2; k = 1; }
+        outBytes[id] = b; keep[id] = k;
+    }
+}
+
+__global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen,
+                                                      const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
+                                                      const uint64_t *__restrict__ outOff, const uint32_t *__restrict__ keep,
+                                                      const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
+                                                      char *__restrict__ outData, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey) {
+    const int wavesPerBlock = 256 / 64;
+    for (uint32_t id = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); id < s.n; id += gridDim.x * wavesPerBlock) {
+        if (!keep[id]) continue;
+        const uint64_t o = outOff[id];
+        const bool ext = (flags[id] & 0x20u) != 0;
+        const uint32_t L = ext ? newLen[id] : s.len[id];
+        const char *src = ext ? (arena + newStart[id]) : (s.data + s.off[id]);
+        for (uint32_t i = laneId(); i < L; i += 64) outData[o + i] = src[i];
+        if (laneId() == 0) {
+            outData[o + L] = '\n'; outData[o + L + 1] = '\0';
+            const uint64_t j = keepPos[id];
+            outOffArr[j] = o; outLen[j] = L; outKey[j] = inKey[id];
+        }
+    }
+}
+__global__ void maxU32Kernel(const uint32_t *__restrict__ v, uint64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) m = max(m, v[i]);
+    m = (uint32_t) waveReduceMax((int) m);
+    if (laneId() == 0) atomicMax(out, m);
+}
+
+}  // namespace plasship
+using namespace plasship;
+
+extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al,
+                                 const plasship_assemble_params *par, plasship_seqdb **out, plasship_assemble_stats *stats) {
+    if (!ctx || !db || !al || !par || !out) { setError("plasship_assemble: bad argument"); return PLASSHIP_ERR_ARG; }
+    if (db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_assemble: only the protein variant (assembleresults) runs on the GPU path"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (par->rescore_mode != 3) { setError("plasship_assemble: only --rescore-mode 3"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (al->nQueries != db->n) { setError("plasship_assemble: alignment list does not belong to the DB"); return PLASSHIP_ERR_ARG; }
+    PH_CHECK(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t N = (uint32_t) db->n;
+    const uint64_t nLines = al->nLines;
+    DevBuf dLeftCap, dBytes, dArenaOff, dTmp, dItems, dFlags, dNewLen, dNewStart, dMat, dStats, dArena;
+    const size_t tmpBytes = exclusiveScanTmpBytes((size_t) N + 2);
+    if (dLeftCap.alloc(((size_t) N + 1) * 4) != hipSuccess || dBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dArenaOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
+        dTmp.alloc(tmpBytes) != hipSuccess || dItems.alloc(std::max<uint64_t>(nLines, 1) * sizeof(Item)) != hipSuccess || dFlags.alloc(((size_t) N + 1) * 4) != hipSuccess ||
+        dNewLen.alloc(((size_t) N + 1) * 4) != hipSuccess || dNewStart.alloc(((size_t) N + 1) * 8) != hipSuccess || dMat.alloc(123 * 123) != hipSuccess || dStats.alloc(16) != hipSuccess) {
+        setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    PH_CHECK(hipMemsetAsync(dFlags.p, 0, ((size_t) N + 1) * 4, st));
+    PH_CHECK(hipMemsetAsync(dNewLen.p, 0, ((size_t) N + 1) * 4, st));
+    PH_CHECK(hipMemsetAsync(dStats.p, 0, 16, st));
+    PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(false), 123 * 123, hipMemcpyHostToDevice, st));
+    const SeqView sv = db->view();
+    PH_CHECK(hipEventRecord(ctx->ev[0], st));
+    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>());
+    if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t arenaBytes = 0;
+    PH_CHECK(hipMemcpyAsync(&arenaBytes, dArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    if (dArena.alloc(arenaBytes + 64) != hipSuccess) { setError("plasship_assemble: out of device memory for the extension arena"); return PLASSHIP_ERR_DEVICE; }
+    HostEvaluer ev(false, db->residues);
+    AsmArgs a; memset(&a, 0, sizeof(a));
+    a.s = sv; a.qoff = al->d_qoff.as<uint64_t>(); a.recs = al->d_recs.as<AlnRec>(); a.items = dItems.as<Item>(); a.arenaOff = dArenaOff.as<uint64_t>();
+    a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
+    a.mat = dMat.as<signed char>(); a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.seqIdThr = par->seq_id_thr; a.maxSeqLen = par->max_seq_len; a.rescoreMode = par->rescore_mode;
+    a.stats = dStats.as<unsigned long long>();
+    if (N) hipLaunchKernelGGL(assembleKernel, dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, a);
+    // ---- output DB: extended queries + carried-over sequences, in key order ----
+    DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;
+    if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
+        dKeepPos.alloc(((size_t) N + 2) * 8) != hipSuccess || dMaxLen.alloc(4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (N) hipLaunchKernelGGL(outLenKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), par->keep_target, dOutBytes.as<uint64_t>(), dKeep.as<uint32_t>());
+    if (exclusiveScanU64(st, dOutBytes.as<uint64_t>(), dOutOff.as<uint64_t>(), N, dTmp.p, tmpBytes) ||
+        exclusiveScanU32(st, dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t outBytes = 0, outN = 0;
+    PH_CHECK(hipMemcpyAsync(&outBytes, dOutOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(&outN, dKeepPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    plasship_seqdb *o = new plasship_seqdb();
+    o->dbtype = db->dbtype; o->n = (size_t) outN; o->dataBytes = outBytes; o->residues = outBytes - 2 * outN; o->hostIndexValid = false;
+    if (o->d_data.alloc(outBytes + 64) != hipSuccess || o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
+        delete o; setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
+    }
+    PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
+    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 3) / 4, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, sv, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(),
+                              dNewStart.as<uint64_t>(), dArena.as<char>(), dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
+                              o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+    PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
+    PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
+    if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
+    uint32_t maxLen = 0; unsigned long long hs[2] = {0, 0};
+    PH_CHECK(hipEventRecord(ctx->ev[1], st));
+    PH_CHECK(hipMemcpyAsync(&maxLen, dMaxLen.p, 4, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hs, dStats.p, 16, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    o->maxEntryLen = maxLen + 2;
+    if (stats) {
+        stats->n_extended = hs[0]; stats->n_rescored = hs[1]; stats->out_residues = o->residues;
+        float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
+    }
+    *out = o;
+    return PLASSHIP_OK;
+}

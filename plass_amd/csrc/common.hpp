@@ -1,0 +1,103 @@
+// plasship internal declarations (product code; never includes anything from oracle/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstddef>
+#include <string>
+#include <vector>
+#include "../../include/plasship.h"
+
+namespace plasship {
+
+void setError(const std::string &msg);
+std::string hipErrStr(hipError_t e, const char *what, const char *file, int line);
+
+#define PH_CHECK(call)                                                                   \
+    do {                                                                                 \
+        hipError_t e_ = (call);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            plasship::setError(plasship::hipErrStr(e_, #call, __FILE__, __LINE__));     \
+            return PLASSHIP_ERR_DEVICE;                                                  \
+        }                                                                                \
+    } while (0)
+
+// RAII device buffer (untyped bytes)
+struct DevBuf {
+    void *p = nullptr; size_t bytes = 0;
+    DevBuf() {}
+    DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    hipError_t alloc(size_t n) { release(); bytes = n; if (n == 0) { p = nullptr; return hipSuccess; } return hipMalloc(&p, n); }
+    void release() { if (p) { (void) hipFree(p); p = nullptr; } bytes = 0; }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// ---- device-side views (POD, passed to kernels by value) --------------------------------------
+struct SeqView {
+    const char *data;          // entries "SEQ\n\0"
+    const uint64_t *off;       // [n] byte offset of entry i (id = rank in key order)
+    const uint32_t *len;       // [n] sequence length (entry length - 2)
+    uint32_t n;
+    int nucl;
+};
+
+// one candidate pair (query id implied by CSR)
+struct __attribute__((aligned(8))) CandHit { uint32_t target; int32_t prefScore; uint32_t diag16; uint32_t query; };
+
+// one scored/accepted alignment (device + host layout)
+struct AlnRec {
+    uint32_t query, target;    // ids (ranks)
+    int32_t bitScore, rawScore;
+    float seqId;               // exact float (or parsed text value if fromText)
+    int32_t qStart, qEnd, qLen, dbStart, dbEnd, dbLen, alnLen;
+    int32_t reversed;
+    int32_t accepted;
+    int32_t fromText;
+    int32_t pad;
+};
+
+}  // namespace plasship
+
+struct plasship_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    int numCU = 0;
+};
+
+struct plasship_seqdb {
+    int dbtype = 0;
+    size_t n = 0;
+    uint64_t dataBytes = 0, residues = 0;
+    uint32_t maxEntryLen = 0;
+    plasship::DevBuf d_data, d_off, d_len, d_key;
+    // host mirror of the index (lazily filled for device-produced DBs)
+    bool hostIndexValid = false;
+    std::vector<uint32_t> h_key, h_elen;
+    std::vector<uint64_t> h_off;
+    plasship::SeqView view() const {
+        plasship::SeqView v; v.data = d_data.as<char>(); v.off = d_off.as<uint64_t>(); v.len = d_len.as<uint32_t>();
+        v.n = (uint32_t) n; v.nucl = (dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES); return v;
+    }
+};
+
+struct plasship_cands {
+    bool reverseCapable = false;   // DBTYPE_PREFILTER_REV_RES
+    size_t nQueries = 0;           // == query DB size; every query has an entry
+    uint64_t nHits = 0;            // including the explicit self hits
+    uint64_t nNonSelf = 0;
+    plasship::DevBuf d_qoff;       // uint64 [nQueries+1]
+    plasship::DevBuf d_hits;       // CandHit [nHits], sorted by (query, target order of the reference)
+};
+
+struct plasship_alns {
+    size_t nQueries = 0;
+    uint64_t nLines = 0;
+    bool nucl = false;
+    bool addBacktrace = false;
+    uint64_t dbResidues = 0;       // of the target DB (E-value area)
+    plasship::DevBuf d_qoff;       // uint64 [nQueries+1]
+    plasship::DevBuf d_recs;       // AlnRec [nLines]
+    // DBs the list refers to (ids -> keys for text output); they must outlive this object
+    const plasship_seqdb *qdb = nullptr, *tdb = nullptr;
+};

@@ -1,0 +1,203 @@
+// plasship: context + sequence DB residency (C-ABI part 1).  Product code.
+//   replaces DBReader<unsigned int>::open/getData/getSeqLen/getDbKey for the hot modules
+//   (mm/commons/DBReader.cpp:150-215,548-589; DBReader.h:185-213) and DBWriter for sequence DBs.
+#include "common.hpp"
+#include "host_util.hpp"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+
+namespace plasship {
+static thread_local std::string g_err;
+void setError(const std::string &msg) { g_err = msg; }
+std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
+    return std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
+}
+}  // namespace plasship
+using namespace plasship;
+
+extern "C" const char *plasship_last_error(void) { return g_err.c_str(); }
+extern "C" const char *plasship_version(void) { return "plasship 0.1 (gfx950)"; }
+
+extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
+    if (!out) { setError("plasship_ctx_create: out is NULL"); return PLASSHIP_ERR_ARG; }
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        setError("plasship_ctx_create: no HIP device available (this library has no CPU fallback)");
+        return PLASSHIP_ERR_DEVICE;
+    }
+    if (device_ordinal < 0) {
+        const char *lr = getenv("LOCAL_RANK");
+        device_ordinal = lr ? atoi(lr) % count : 0;
+    }
+    if (device_ordinal >= count) { setError("plasship_ctx_create: device ordinal out of range"); return PLASSHIP_ERR_ARG; }
+    PH_CHECK(hipSetDevice(device_ordinal));
+    plasship_ctx *c = new plasship_ctx();
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    PH_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
+    c->numCU = prop.multiProcessorCount;
+    PH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    for (auto &ev : c->ev) PH_CHECK(hipEventCreate(&ev));
+    *out = c;
+    return PLASSHIP_OK;
+}
+
+extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int plasship_ctx_sync(plasship_ctx *ctx) {
+    if (!ctx) { setError("ctx is NULL"); return PLASSHIP_ERR_ARG; }
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    return PLASSHIP_OK;
+}
+extern "C" void *plasship_ctx_stream(plasship_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+// ---- sequence DB ---------------------------------------------------------------------------------
+extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t data_bytes, const uint64_t *off,
+                                     const uint32_t *elen, const uint32_t *key, size_t n, int dbtype,
+                                     plasship_seqdb **out) {
+    if (!ctx || !out || (n && (!data || !off || !elen || !key))) { setError("plasship_seqdb_upload: bad argument"); return PLASSHIP_ERR_ARG; }
+    if (dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS && dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES) {
+        setError("plasship_seqdb_upload: dbtype must be amino acids (0) or nucleotides (1)"); return PLASSHIP_ERR_UNSUPPORTED;
+    }
+    if (n >= 0xFFFFFFFFull) { setError("plasship_seqdb_upload: too many sequences"); return PLASSHIP_ERR_UNSUPPORTED; }
+    PH_CHECK(hipSetDevice(ctx->device));
+    // ids are ranks in key order (DBReader::getId); repack the data in id order so that device offsets
+    // are monotone and neighbouring ids are neighbours in HBM.
+    std::vector<uint32_t> perm(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    bool sorted = true;
+    for (size_t i = 1; i < n && sorted; i++) sorted = key[i - 1] <= key[i];
+    if (!sorted) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    plasship_seqdb *db = new plasship_seqdb();
+    db->dbtype = dbtype; db->n = n;
+    db->h_key.resize(n); db->h_elen.resize(n); db->h_off.resize(n);
+    uint64_t total = 0; uint32_t maxE = 0;
+    for (size_t i = 0; i < n; i++) {
+        uint32_t s = perm[i];
+        if (off[s] + elen[s] > data_bytes) { delete db; setError("plasship_seqdb_upload: entry beyond data"); return PLASSHIP_ERR_ARG; }
+        if (elen[s] < 2) { delete db; setError("plasship_seqdb_upload: sequence entry shorter than \"\\n\\0\""); return PLASSHIP_ERR_ARG; }
+        db->h_key[i] = key[s]; db->h_elen[i] = elen[s]; db->h_off[i] = total;
+        total += elen[s]; maxE = std::max(maxE, elen[s]);
+    }
+    db->dataBytes = total; db->maxEntryLen = maxE; db->residues = total - 2 * (uint64_t) n; db->hostIndexValid = true;
+    std::vector<uint32_t> hlen(n);
+    for (size_t i = 0; i < n; i++) hlen[i] = db->h_elen[i] - 2;
+    // pad the data buffer so 16-byte vector loads at the tail stay in bounds
+    if (db->d_data.alloc(total + 64) != hipSuccess || db->d_off.alloc((n + 1) * 8) != hipSuccess ||
+        db->d_len.alloc((n + 1) * 4) != hipSuccess || db->d_key.alloc((n + 1) * 4) != hipSuccess) {
+        delete db; setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    PH_CHECK(hipMemsetAsync(db->d_data.p, 0, total + 64, ctx->stream));
+    // stage in id order through a pinned-size bounce buffer
+    {
+        const size_t CH = 64u << 20;
+        std::vector<char> bounce(std::min<uint64_t>(CH, std::max<uint64_t>(total, 1)));
+        uint64_t done = 0; size_t i = 0;
+        while (i < n) {
+            size_t fill = 0; uint64_t base = db->h_off[i];
+            while (i < n && fill + db->h_elen[i] <= bounce.size()) {
+                memcpy(bounce.data() + fill, data + off[perm[i]], db->h_elen[i]); fill += db->h_elen[i]; i++;
+            }
+            if (fill == 0) {   // single entry larger than the bounce buffer
+                PH_CHECK(hipMemcpy((char *) db->d_data.p + base, data + off[perm[i]], db->h_elen[i], hipMemcpyHostToDevice));
+                i++;
+            } else {
+                PH_CHECK(hipMemcpy((char *) db->d_data.p + base, bounce.data(), fill, hipMemcpyHostToDevice));
+            }
+            done = base + fill;
+        }
+        (void) done;
+    }
+    std::vector<uint64_t> hoff(n + 1);
+    for (size_t i = 0; i < n; i++) hoff[i] = db->h_off[i];
+    hoff[n] = total;
+    PH_CHECK(hipMemcpy(db->d_off.p, hoff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    if (n) {
+        PH_CHECK(hipMemcpy(db->d_len.p, hlen.data(), n * 4, hipMemcpyHostToDevice));
+        PH_CHECK(hipMemcpy(db->d_key.p, db->h_key.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    *out = db;
+    return PLASSHIP_OK;
+}
+
+extern "C" int plasship_seqdb_read(plasship_ctx *ctx, const char *db_path, plasship_seqdb **out) {
+    if (!ctx || !db_path || !out) { setError("plasship_seqdb_read: bad argument"); return PLASSHIP_ERR_ARG; }
+    HostDB h; std::string err;
+    if (!readDBFiles(db_path, h, err)) { setError(err); return PLASSHIP_ERR_IO; }
+    return plasship_seqdb_upload(ctx, h.data.data(), h.data.size(), h.off.data(), h.elen.data(), h.key.data(), h.key.size(), h.dbtype, out);
+}
+
+static int ensureHostIndex(plasship_ctx *ctx, plasship_seqdb *db) {
+    if (db->hostIndexValid) return PLASSHIP_OK;
+    size_t n = db->n;
+    db->h_key.resize(n); db->h_off.resize(n + 1); db->h_elen.resize(n);
+    std::vector<uint32_t> len(n);
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(hipMemcpy(db->h_off.data(), db->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    if (n) {
+        PH_CHECK(hipMemcpy(db->h_key.data(), db->d_key.p, n * 4, hipMemcpyDeviceToHost));
+        PH_CHECK(hipMemcpy(len.data(), db->d_len.p, n * 4, hipMemcpyDeviceToHost));
+    }
+    for (size_t i = 0; i < n; i++) db->h_elen[i] = len[i] + 2;
+    db->h_off.resize(n);
+    db->hostIndexValid = true;
+    return PLASSHIP_OK;
+}
+
+extern "C" int plasship_seqdb_info(const plasship_seqdb *db, size_t *n, uint64_t *residues, uint32_t *max_entry_len,
+                                   int *dbtype, uint64_t *data_bytes) {
+    if (!db) { setError("plasship_seqdb_info: db is NULL"); return PLASSHIP_ERR_ARG; }
+    if (n) *n = db->n;
+    if (residues) *residues = db->residues;
+    if (max_entry_len) *max_entry_len = db->maxEntryLen;
+    if (dbtype) *dbtype = db->dbtype;
+    if (data_bytes) *data_bytes = db->dataBytes;
+    return PLASSHIP_OK;
+}
+
+extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *cdb, char *data, uint64_t *off,
+                                       uint32_t *elen, uint32_t *key) {
+    if (!ctx || !cdb) { setError("plasship_seqdb_download: bad argument"); return PLASSHIP_ERR_ARG; }
+    plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
+    PH_CHECK(hipSetDevice(ctx->device));
+    int rc = ensureHostIndex(ctx, db); if (rc) return rc;
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (data && db->dataBytes) PH_CHECK(hipMemcpy(data, db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost));
+    if (off) memcpy(off, db->h_off.data(), db->n * 8);
+    if (elen) memcpy(elen, db->h_elen.data(), db->n * 4);
+    if (key) memcpy(key, db->h_key.data(), db->n * 4);
+    return PLASSHIP_OK;
+}
+
+extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb, const char *db_path) {
+    if (!ctx || !cdb || !db_path) { setError("plasship_seqdb_write: bad argument"); return PLASSHIP_ERR_ARG; }
+    plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
+    PH_CHECK(hipSetDevice(ctx->device));
+    int rc = ensureHostIndex(ctx, db); if (rc) return rc;
+    std::vector<char> data(db->dataBytes);
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (db->dataBytes) PH_CHECK(hipMemcpy(data.data(), db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost));
+    // device layout already is the canonical DB layout: entries in key order, each "SEQ\n\0"
+    std::string err; DBFileWriter w;
+    if (!w.open(db_path, db->dbtype, err)) { setError(err); return PLASSHIP_ERR_IO; }
+    for (size_t i = 0; i < db->n; i++) w.add(db->h_key[i], data.data() + db->h_off[i], db->h_elen[i] - 1);
+    if (!w.close(err)) { setError(err); return PLASSHIP_ERR_IO; }
+    return PLASSHIP_OK;
+}
+
+extern "C" void plasship_seqdb_free(plasship_ctx *ctx, plasship_seqdb *db) {
+    if (!db) return;
+    if (ctx) (void) hipSetDevice(ctx->device);
+    delete db;
+}

@@ -1,0 +1,954 @@
+// plasship: kmermatcher on gfx950 (rows K1–K8 of SURVEY.md §8a).  Product code.
+//
+// Reference behaviour reproduced (file:line in /root/reference/lib/mmseqs/src):
+//   linclust/kmermatcher.cpp:77-385    fillKmerPositionArray: letter mapping, k-mer index, XXH64 score,
+//                                      per-sequence selection of the lowest-hash k-mers, identity record
+//   linclust/kmermatcher.cpp:408-412   sort #1 (kmer, seqLen desc, id, pos)
+//   linclust/kmermatcher.cpp:450-559   assignGroup: rep = first of each equal-kmer run, diagonal, filter
+//   linclust/kmermatcher.cpp:427-431   sort #2 (rep, target, diagonal)
+//   linclust/kmermatcher.cpp:809-924   writeKmerMatcherResult: best diagonal per (rep, target)
+//   linclust/kmermatcher.cpp:705-724   every key gets an entry ("key\t0\t0" self line first)
+//
+// MI355X design (not a translation of the CPU algorithm):
+//   * extraction: one wavefront per sequence, codes staged through LDS in 64-position tiles; the
+//     reference's 65 536-bin threshold walk becomes a two-level 256-bin LDS radix select, the per
+//     sequence std::sort becomes an LDS bitonic sort of only the <= ~60 candidate k-mers.
+//   * sort #1 is NOT a sort: only grouping by equal k-mer and the identity of the run's first record
+//     matter (its order is destroyed by sort #2 anyway).  Records are hash-partitioned (1–2 scatter
+//     passes, unstable, LDS-privatised histograms) into buckets that fit an LDS hash table; the run
+//     head is an atomicMax/atomicMin over (seqLen desc, id, pos).  One read+write per level instead
+//     of the 8+ passes of an LSD radix sort over 16-byte records.
+//   * sort #2 must be a true sort (the reference scans across rep boundaries, Appendix A.3): records
+//     are range-partitioned by rep id (order preserving) and each bucket is bitonic-sorted in LDS.
+//   * per-(rep,target) reduction: one thread per run head walks its run.
+// Integer work only; the single float expression (Util::canBeCovered) is IEEE-exact.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "host_util.hpp"
+#include <algorithm>
+#include <climits>
+#include <cstring>
+
+namespace plasship {
+
+#define BIT63 (1ULL << 63)
+
+// ---- record layouts (kmermatcher.h:49-55: KmerPosition<short> 16 B, KmerPosition<int> 20 B) -------------
+template <bool LONG> struct Rec;
+template <> struct __attribute__((aligned(16))) Rec<false> { uint64_t kmer; uint32_t id; uint16_t len; int16_t pos; };
+template <> struct __attribute__((aligned(8))) Rec<true> { uint64_t kmer; uint32_t id; int32_t len; int32_t pos; uint32_t pad; };
+
+template <bool LONG> __device__ __forceinline__ bool isSentinel(const Rec<LONG> &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }
+
+// ---- XXH64 of one little-endian u64 (xxhash 0.8.0, call site kmermatcher.cpp:33-38) ---------------------
+__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__host__ __device__ __forceinline__ uint64_t xxh64U64(uint64_t v, uint64_t seed) {
+    const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
+                   P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+    uint64_t h = seed + P5 + 8;
+    uint64_t k1 = rotl64(v * P2, 31) * P1;
+    h ^= k1;
+    h = rotl64(h, 27) * P1 + P4;
+    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
+    return h;
+}
+// 2-bit alphabet A0 C1 T2 G3, complement = code ^ 2 (Util.cpp:601-638)
+__device__ __forceinline__ uint64_t revComplementDev(uint64_t kmer, int k) {
+    uint64_t x = kmer ^ 0xAAAAAAAAAAAAAAAAULL;                         // complement every 2-bit letter
+    x = ((x >> 2) & 0x3333333333333333ULL) | ((x & 0x3333333333333333ULL) << 2);
+    x = ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL) | ((x & 0x0F0F0F0F0F0F0F0FULL) << 4);
+    x = __builtin_bswap64(x);                                          // reverse the 32 letters
+    return x >> (64 - 2 * k);
+}
+
+// =====================================================================================================
+// 1. slot bounds (computeKmerCount, kmermatcher.cpp:576-585): every sequence owns a fixed slot range
+//    of the record array, exactly like the reference's pre-sized array; unused slots keep 0xFF.
+// =====================================================================================================
+__global__ void boundsKernel(const uint32_t *__restrict__ len, uint32_t n, int k, int kps, float scale, uint32_t *__restrict__ bound) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int L = (int) len[i];
+        const int adj = max(1, L - k + 2);
+        bound[i] = (uint32_t) min(adj, (int) ((float) (size_t) kps + (scale * (float) L)));
+    }
+}
+
+// =====================================================================================================
+// 2. extraction + selection, one wavefront (= one 64-thread block) per sequence
+// =====================================================================================================
+struct Cand { uint64_t kmer; uint32_t pos; uint32_t score; };   // score: low 16 bits hash, bit 31 = skipped
+
+struct ExtractArgs {
+    SeqView s;
+    const uint64_t *slotOff;        // [n+1]
+    void *arr;                      // Rec<LONG>[total]
+    const unsigned char *map;       // 256-entry letter -> code
+    uint64_t powers[24];            // AA: (alphabet-1)^i
+    int k, xCode, kps, ignoreMulti;
+    float scale;
+    uint64_t seed;
+    uint32_t *overflowIds, *overflowCount;
+    // fallback launch: explicit id list and per-sequence global scratch
+    const uint32_t *idList; uint32_t nIds; Cand *scratch; const uint64_t *scratchOff; const uint32_t *scratchCap;
+};
+
+__device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
+    const uint32_t sa = a.score, sb = b.score;
+    if (sa != sb) return sa < sb;
+    const uint64_t ka = nucl ? (a.kmer | BIT63) : a.kmer, kb = nucl ? (b.kmer | BIT63) : b.kmer;
+    if (ka != kb) return ka < kb;
+    return a.pos < b.pos;
+}
+
+// bitonic sort of p[0..P) (P power of two) by one wavefront; padding entries carry score 0xFFFFFFFF
+__device__ void waveBitonicSortCands(Cand *p, uint32_t P, bool nucl) {
+    for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+            for (uint32_t i = threadIdx.x; i < P; i += 64) {
+                const uint32_t l = i ^ j;
+                if (l > i) {
+                    Cand a = p[i], b = p[l];
+                    const bool up = (i & kk) == 0;
+                    if (candLess(b, a, nucl) == up) { p[i] = b; p[l] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <bool NUCL, bool LONG, int CAP, bool FALLBACK>
+__global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
+    __shared__ unsigned char sMap[256];
+    __shared__ unsigned char sCode[64 + 32];
+    __shared__ uint32_t sHist[256];
+    __shared__ Cand sCand[FALLBACK ? 1 : CAP];
+    typedef Rec<LONG> R;
+    R *arr = reinterpret_cast<R *>(a.arr);
+    const int lane = threadIdx.x;
+    const int k = a.k;
+    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
+    __syncthreads();
+    uint64_t pow31 = 1;                                    // 31^lane
+    for (int i = 0; i < lane; i++) pow31 *= 31;
+
+    const uint32_t nWork = FALLBACK ? a.nIds : a.s.n;
+    for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
+        const uint32_t id = FALLBACK ? a.idList[w] : w;
+        const uint32_t L = a.s.len[id];
+        const char *base = a.s.data + a.s.off[id];
+        const uint64_t slot = a.slotOff[id];
+        const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - slot);
+        Cand *cand = FALLBACK ? (a.scratch + a.scratchOff[w]) : sCand;
+        const uint32_t cap = FALLBACK ? a.scratchCap[w] : (uint32_t) CAP;
+        const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
+        const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));   // kmermatcher.cpp:223
+        const bool allCand = (size_t) nWin <= consideredRaw;
+
+        uint32_t C = 0;            // candidates pushed (wave-uniform)
+        uint32_t n = 0;            // valid k-mers
+        bool overflow = false;
+        uint64_t seqHash = 0;      // Util::hash (Util.h:337-345): h = h*31 + code
+        uint32_t sStar = 0; int tooMuch = 0; size_t considered = 0;
+        uint32_t b1 = 0, cumBefore1 = 0;
+
+        // pass 0: all candidates pushed / or coarse histogram; pass 1: fine histogram; pass 2: push score <= s*
+        const int nPass = allCand ? 1 : 3;
+        for (int pass = 0; pass < nPass; pass++) {
+            if (pass < 2 && !allCand) { for (int i = lane; i < 256; i += 64) sHist[i] = 0; }
+            __syncthreads();
+            for (uint32_t t0 = 0; t0 < L; t0 += 64) {
+                // stage codes of positions [t0, t0+64+k-1)
+                const uint32_t p = t0 + lane;
+                unsigned char c = (p < L) ? sMap[(unsigned char) base[p]] : (unsigned char) a.xCode;
+                sCode[lane] = c;
+                if (lane < k - 1) { const uint32_t p2 = t0 + 64 + lane; sCode[64 + lane] = (p2 < L) ? sMap[(unsigned char) base[p2]] : (unsigned char) a.xCode; }
+                if (pass == 0) {   // identity hash, tile-wise Horner: h = h*31^m + sum code[j]*31^(m-1-j)
+                    const uint32_t m = min(64u, L - t0);
+                    const uint64_t pw = __shfl(pow31, (int) (m - 1 - min((uint32_t) lane, m - 1)), 64);
+                    uint64_t term = ((uint32_t) lane < m) ? (uint64_t) c * pw : 0ull;
+                    term = waveReduceSumU64(term);
+                    const uint64_t pm = __shfl(pow31, (int) (m - 1), 64) * 31ull;      // 31^m
+                    seqHash = seqHash * pm + term;
+                }
+                __syncthreads();
+                bool valid = (p < nWin);
+                uint64_t kmer = 0; uint32_t pos = p;
+                if (valid) {
+                    bool hasX = false;
+                    if (NUCL) {
+                        uint64_t f = 0;
+                        for (int i = 0; i < k; i++) { const unsigned char ci = sCode[lane + i]; hasX |= (ci == (unsigned char) a.xCode); f = (f << 2) | (ci & 3); }
+                        const uint64_t r = revComplementDev(f, k);
+                        if (hasX || r == f) valid = false;
+                        else {
+                            const bool pickRev = r < f;
+                            const uint64_t cc = pickRev ? r : f;
+                            kmer = pickRev ? cc : (cc | BIT63);
+                            pos = pickRev ? (L - p - k) : p;
+                        }
+                    } else {
+                        for (int i = 0; i < k; i++) { const unsigned char ci = sCode[lane + i]; hasX |= (ci == (unsigned char) a.xCode); kmer += (uint64_t) ci * a.powers[i]; }
+                        if (hasX) valid = false;
+                    }
+                }
+                uint32_t score = 0;
+                if (valid) score = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
+                bool push = false;
+                if (allCand) push = valid;
+                else if (pass == 0) { if (valid) atomicAdd(&sHist[score >> 8], 1u); }
+                else if (pass == 1) { if (valid && (score >> 8) == b1) atomicAdd(&sHist[score & 255], 1u); }
+                else push = valid && score <= sStar;
+                if (pass == 0) n += (uint32_t) __popcll(__ballot(valid));
+                if (allCand || pass == 2) {
+                    const unsigned long long mask = __ballot(push);
+                    const uint32_t rank = (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL));
+                    const uint32_t cnt = (uint32_t) __popcll(mask);
+                    if (C + cnt > cap) overflow = true;
+                    else if (push) { Cand cd; cd.kmer = kmer; cd.pos = pos; cd.score = score; cand[C + rank] = cd; }
+                    C += cnt;
+                }
+                __syncthreads();
+                if (overflow) break;
+            }
+            if (overflow) break;
+            if (!allCand && pass < 2) {
+                // radix-select step over the 256-bin histogram: first bin where the running count reaches `target`
+                __syncthreads();
+                if (pass == 0) considered = min(consideredRaw, (size_t) n);
+                const uint32_t target = (pass == 0) ? (uint32_t) considered : (uint32_t) considered - cumBefore1;
+                const uint32_t h0 = sHist[lane * 4], h1 = sHist[lane * 4 + 1], h2 = sHist[lane * 4 + 2], h3 = sHist[lane * 4 + 3];
+                const uint32_t mine = h0 + h1 + h2 + h3;
+                const uint32_t incl = waveInclusiveScan(mine);
+                const unsigned long long reach = __ballot(incl >= target && target > 0);
+                uint32_t bin = 255, before = 0, upto = 0;
+                if (reach) {
+                    const int fl = __ffsll((long long) reach) - 1;
+                    const uint32_t exB = __shfl(incl - mine, fl, 64);
+                    const uint32_t q0 = __shfl(h0, fl, 64), q1 = __shfl(h1, fl, 64), q2 = __shfl(h2, fl, 64), q3 = __shfl(h3, fl, 64);
+                    uint32_t run = exB; bin = (uint32_t) fl * 4;
+                    if (run + q0 >= target) { before = run; upto = run + q0; }
+                    else if (run + q0 + q1 >= target) { bin += 1; before = run + q0; upto = before + q1; }
+                    else if (run + q0 + q1 + q2 >= target) { bin += 2; before = run + q0 + q1; upto = before + q2; }
+                    else { bin += 3; before = run + q0 + q1 + q2; upto = before + q3; }
+                }
+                if (pass == 0) { b1 = bin; cumBefore1 = before; }
+                else { sStar = (b1 << 8) | bin; tooMuch = (int) (cumBefore1 + upto) - (int) considered; }
+                if (pass == 0 && (considered == 0)) break;     // nothing can be selected (n == 0)
+            }
+        }
+        if (overflow) {
+            if (!FALLBACK && lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
+            __syncthreads();
+            continue;
+        }
+        if (allCand) {
+            considered = min(consideredRaw, (size_t) n);   // == n
+            // threshold walk ends one past the largest score present; no surplus in the last bin
+            uint32_t mx = 0;
+            for (uint32_t i = lane; i < C; i += 64) mx = max(mx, cand[i].score);
+            sStar = (uint32_t) waveReduceMax((int) mx); tooMuch = 0;
+        }
+        // ---- order candidates like SequencePosition::compareByScore[Reverse] (kmermatcher.h:13-45) ----
+        uint32_t P = 1; while (P < C) P <<= 1;
+        if (P > cap) P = cap;      // cap is a power of two >= C in both modes
+        for (uint32_t i = C + lane; i < P; i += 64) { Cand cd; cd.kmer = ~0ULL; cd.pos = 0xFFFFFFFFu; cd.score = 0xFFFFFFFFu; cand[i] = cd; }
+        __syncthreads();
+        bool sortedNeeded = true;
+        if (sortedNeeded && C > 1) waveBitonicSortCands(cand, P, NUCL);
+        // ---- repeated k-mer skipping (kmermatcher.cpp:277-301), exact emulation of the index walk ----
+        if (a.ignoreMulti) {
+            bool rep = false;
+            for (uint32_t i = 1 + lane; i < C; i += 64) {
+                const uint64_t x = NUCL ? (cand[i].kmer | BIT63) : cand[i].kmer, y = NUCL ? (cand[i - 1].kmer | BIT63) : cand[i - 1].kmer;
+                rep |= (x == y);
+            }
+            if (__ballot(rep)) {
+                for (uint32_t i = lane; i < C; i += 64) cand[i].score |= 0x80000000u;      // skipped until visited
+                __syncthreads();
+                if (lane == 0) {
+                    uint32_t i = 0;
+                    while (i < C) {
+                        const uint64_t km = NUCL ? (cand[i].kmer | BIT63) : cand[i].kmer;
+                        if (i + 1 < C && (NUCL ? (cand[i + 1].kmer | BIT63) : cand[i + 1].kmer) == km) {
+                            do { i++; if (i >= C) break; } while ((NUCL ? (cand[i].kmer | BIT63) : cand[i].kmer) == km);
+                            if (i >= C) break;
+                        }
+                        cand[i].score &= 0x7FFFFFFFu;
+                        i++;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- selection walk (kmermatcher.cpp:274-347) as prefix counts over the sorted candidates ----
+        uint32_t binCarry = 0, selCarry = 0;
+        for (uint32_t c0 = 0; c0 < C; c0 += 64) {
+            const uint32_t i = c0 + lane;
+            Cand cd; cd.kmer = 0; cd.pos = 0; cd.score = 0x80000000u;
+            if (i < C) cd = cand[i];
+            const bool v = (i < C) && !(cd.score & 0x80000000u);
+            const uint32_t sc = cd.score & 0xFFFFu;
+            const bool isBin = v && sc == sStar;
+            const unsigned long long mb = __ballot(isBin);
+            const uint32_t binRank = binCarry + (uint32_t) __popcll(mb & ((1ULL << lane) - 1ULL));
+            const bool selectable = v && (sc < sStar || (isBin && (tooMuch == 0 || (int) binRank < tooMuch)));
+            const unsigned long long ms = __ballot(selectable);
+            const uint32_t selRank = selCarry + (uint32_t) __popcll(ms & ((1ULL << lane) - 1ULL));
+            if (selectable && (size_t) selRank < considered) {
+                R r; r.kmer = cd.kmer; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) cd.pos;
+                if constexpr (LONG) r.pad = 0;
+                arr[slot + 1 + selRank] = r;
+            }
+            binCarry += (uint32_t) __popcll(mb); selCarry += (uint32_t) __popcll(ms);
+        }
+        const uint32_t numSel = (uint32_t) min((size_t) selCarry, considered);
+        if (lane == 0) {   // identity record (kmermatcher.cpp:241-249)
+            R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
+            if constexpr (LONG) r.pad = 0;
+            arr[slot] = r;
+        }
+        for (uint32_t i = 1 + numSel + lane; i < bound; i += 64) {
+            R r; memset(&r, 0xFF, sizeof(R));
+            arr[slot + i] = r;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+
+// =====================================================================================================
+// 3. segmented, unstable bucket partition (used for the hash grouping and for the rep-range sort)
+// =====================================================================================================
+enum { KEY_HASH = 0, KEY_RANGE = 1 };
+template <bool NUCL, int MODE> __device__ __forceinline__ uint64_t bucketKey(uint64_t kmerField, int rangeBits) {
+    if (MODE == KEY_HASH) {
+        const uint64_t K = NUCL ? (kmerField & ~BIT63) : kmerField;
+        uint64_t x = K * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+        return x;
+    }
+    return (kmerField & ~BIT63) << (64 - rangeBits);    // left-align the rep id: top bits = id range
+}
+
+constexpr int PT_BLOCK = 256;
+constexpr int PT_ITEMS = 16;
+constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;
+
+struct PartArgs {
+    const void *in; void *out;
+    const uint64_t *segStart;       // [nSeg] first record of the segment in `in`
+    const uint64_t *segCount;       // [nSeg] valid records in the segment
+    uint32_t *count;                // [nSeg << bits]
+    unsigned long long *cursor;     // [nSeg << bits] running write positions (scatter)
+    int shift, bits, rangeBits, dropSentinels;
+    int sharedTable;                // all segments accumulate into one bucket table (segment id does not offset it)
+    unsigned long long *minKey;     // optional: global minimum of (kmer | BIT63) (NUCL first-run quirk)
+};
+
+template <bool NUCL, bool LONG, int MODE>
+__global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
+    __shared__ uint32_t sh[4096];
+    typedef Rec<LONG> R;
+    const R *in = reinterpret_cast<const R *>(a.in);
+    const uint32_t seg = blockIdx.y;
+    const uint64_t s0 = a.segStart[seg], cnt = a.segCount[seg];
+    const uint64_t t0 = (uint64_t) blockIdx.x * PT_TILE;
+    if (t0 >= cnt) return;
+    const uint32_t nb = 1u << a.bits;
+    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) sh[i] = 0;
+    __syncthreads();
+    unsigned long long mn = ~0ULL;
+#pragma unroll 4
+    for (int it = 0; it < PT_ITEMS; it++) {
+        const uint64_t i = t0 + (uint64_t) it * PT_BLOCK + threadIdx.x;
+        if (i < cnt) {
+            const R r = in[s0 + i];
+            if (a.dropSentinels && isSentinel(r)) continue;
+            const uint32_t b = (uint32_t) (bucketKey<NUCL, MODE>(r.kmer, a.rangeBits) >> a.shift) & (nb - 1);
+            atomicAdd(&sh[b], 1u);
+            if (NUCL && a.minKey) mn = min(mn, (unsigned long long) (r.kmer | BIT63));
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) atomicAdd(&a.count[(a.sharedTable ? 0 : ((uint64_t) seg << a.bits)) + i], c); }
+    if (NUCL && a.minKey) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned long long) __shfl_xor(mn, o, 64));
+        if (laneId() == 0 && mn != ~0ULL) atomicMin(a.minKey, mn);
+    }
+}
+
+template <bool NUCL, bool LONG, int MODE>
+__global__ __launch_bounds__(PT_BLOCK) void partScatterKernel(PartArgs a) {
+    __shared__ uint32_t sh[4096];
+    __shared__ unsigned long long sbase[4096];
+    typedef Rec<LONG> R;
+    const R *in = reinterpret_cast<const R *>(a.in);
+    R *out = reinterpret_cast<R *>(a.out);
+    const uint32_t seg = blockIdx.y;
+    const uint64_t s0 = a.segStart[seg], cnt = a.segCount[seg];
+    const uint64_t t0 = (uint64_t) blockIdx.x * PT_TILE;
+    if (t0 >= cnt) return;
+    const uint32_t nb = 1u << a.bits;
+    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) sh[i] = 0;
+    __syncthreads();
+    R recs[PT_ITEMS]; uint32_t bkt[PT_ITEMS]; uint32_t rk[PT_ITEMS];
+#pragma unroll
+    for (int it = 0; it < PT_ITEMS; it++) {
+        const uint64_t i = t0 + (uint64_t) it * PT_BLOCK + threadIdx.x;
+        bkt[it] = 0xFFFFFFFFu;
+        if (i < cnt) {
+            recs[it] = in[s0 + i];
+            if (!(a.dropSentinels && isSentinel(recs[it]))) {
+                bkt[it] = (uint32_t) (bucketKey<NUCL, MODE>(recs[it].kmer, a.rangeBits) >> a.shift) & (nb - 1);
+                rk[it] = atomicAdd(&sh[bkt[it]], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) sbase[i] = atomicAdd(&a.cursor[(a.sharedTable ? 0 : ((uint64_t) seg << a.bits)) + i], (unsigned long long) c); }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < PT_ITEMS; it++)
+        if (bkt[it] != 0xFFFFFFFFu) out[sbase[bkt[it]] + rk[it]] = recs[it];
+}
+
+__global__ void copyU64Kernel(const uint64_t *__restrict__ src, unsigned long long *__restrict__ dst, uint64_t n) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) dst[i] = src[i];
+}
+__global__ void diffU64Kernel(const uint64_t *__restrict__ start, uint64_t *__restrict__ cnt, uint64_t n) {   // cnt[i] = start[i+1]-start[i]
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) cnt[i] = start[i + 1] - start[i];
+}
+
+// =====================================================================================================
+// 4. assignGroup over hash buckets with an LDS hash table (kmermatcher.cpp:450-559)
+// =====================================================================================================
+constexpr int GR_BLOCK = 256;
+constexpr uint32_t GR_HT = 2048;            // slots
+constexpr uint32_t GR_MAXKEYS = 1536;       // distinct k-mers per sub-pass before splitting further
+
+struct GroupArgs {
+    const void *in; void *out;
+    const uint64_t *bucketStart;     // [nBuckets+1]
+    uint32_t nBuckets, bucketsPerBlock;
+    uint64_t *outCount;              // [gridDim.x] records written by block j at out[bucketStart[j*bucketsPerBlock] ...]
+    int includeOnlyExtendable, covMode; float covThr;
+    const unsigned long long *minKey;   // NUCL: K of the globally first run
+};
+
+__device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
+    switch (covMode) {
+        case 0: return (q / t >= covThr) && (t / q >= covThr);
+        case 1: return (t / q) >= covThr;
+        case 2: return (q / t) >= covThr;
+        case 3: return ((t / q) >= covThr) && (t / q) <= 1.0f;
+        case 4: return ((q / t) >= covThr) && (q / t) <= 1.0f;
+        case 5: return (fminf(t, q) / fmaxf(t, q)) >= covThr;
+        default: return true;
+    }
+}
+
+template <bool NUCL, bool LONG>
+__global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
+    __shared__ unsigned long long hKey[GR_HT];
+    __shared__ unsigned long long hBest[GR_HT];
+    __shared__ uint32_t hCnt[GR_HT];
+    __shared__ uint32_t hLen[GR_HT];
+    __shared__ uint32_t sFlag[2];
+    __shared__ uint32_t sWaveCnt[GR_BLOCK / 64];
+    typedef Rec<LONG> R;
+    const R *in = reinterpret_cast<const R *>(a.in);
+    R *out = reinterpret_cast<R *>(a.out);
+    const uint32_t bBegin = blockIdx.x * a.bucketsPerBlock;
+    const uint32_t bEnd = min(a.nBuckets, bBegin + a.bucketsPerBlock);
+    if (bBegin >= a.nBuckets) { if (threadIdx.x == 0) a.outCount[blockIdx.x] = 0; return; }
+    unsigned long long written = 0;                  // block-uniform
+    const uint64_t arena = a.bucketStart[bBegin];
+    const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
+    for (uint32_t b = bBegin; b < bEnd; b++) {
+        const uint64_t s0 = a.bucketStart[b], s1 = a.bucketStart[b + 1];
+        if (s1 <= s0) continue;
+        uint32_t nSub = 1;                           // sub-passes by a secondary hash when too many distinct k-mers
+        const unsigned long long writtenAtBucketStart = written;
+        for (;;) {
+            bool redo = false;
+            for (uint32_t sub = 0; sub < nSub && !redo; sub++) {
+                for (uint32_t i = threadIdx.x; i < GR_HT; i += GR_BLOCK) { hKey[i] = ~0ULL; hBest[i] = ~0ULL; hCnt[i] = 0; hLen[i] = 0; }
+                if (threadIdx.x == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+                __syncthreads();
+                // phase A: insert keys, count members, longest sequence
+                for (uint64_t i = s0 + threadIdx.x; i < s1; i += GR_BLOCK) {
+                    const R r = in[i];
+                    const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
+                    const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
+                    if (nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub) continue;
+                    uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
+                    for (uint32_t probe = 0; probe < GR_HT; probe++) {
+                        const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, K);
+                        if (prev == ~0ULL) { atomicAdd(&sFlag[0], 1u); }
+                        if (prev == ~0ULL || prev == K) { atomicAdd(&hCnt[slot], 1u); atomicMax(&hLen[slot], (uint32_t) r.len); break; }
+                        slot = (slot + 1) & (GR_HT - 1);
+                        if (probe == GR_HT - 1) atomicExch(&sFlag[1], 1u);
+                    }
+                }
+                __syncthreads();
+                if (sFlag[1] || sFlag[0] > GR_MAXKEYS) { redo = true; __syncthreads(); break; }
+                // phase B: head of the run = (longest, smallest id, smallest pos[, reverse strand first])
+                for (uint64_t i = s0 + threadIdx.x; i < s1; i += GR_BLOCK) {
+                    const R r = in[i];
+                    const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
+                    const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
+                    if (nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub) continue;
+                    uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
+                    while (hKey[slot] != K) slot = (slot + 1) & (GR_HT - 1);
+                    if ((uint32_t) r.len == hLen[slot]) {
+                        const unsigned long long packed = ((unsigned long long) r.id << 22) | ((unsigned long long) (uint32_t) r.pos << 1) | (NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL);
+                        atomicMin(&hBest[slot], packed);
+                    }
+                }
+                __syncthreads();
+                // phase C: every member of a run of size >= 2 becomes (rep, member, diagonal) if it passes the filter
+                for (uint64_t i0 = s0; i0 < s1; i0 += GR_BLOCK) {
+                    const uint64_t i = i0 + threadIdx.x;
+                    bool keep = false; R o; memset(&o, 0, sizeof(R));
+                    if (i < s1) {
+                        const R r = in[i];
+                        const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
+                        const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
+                        if (!(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
+                            uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
+                            while (hKey[slot] != K) slot = (slot + 1) & (GR_HT - 1);
+                            if (hCnt[slot] >= 2) {
+                                const unsigned long long best = hBest[slot];
+                                const uint32_t repId = (uint32_t) (best >> 22);
+                                const int repPos = (int) ((best >> 1) & 0x1FFFFFu);
+                                const int queryLen = (int) hLen[slot];
+                                const int mLen = (int) r.len, mPos = (int) r.pos;
+                                int diagonal = repPos - mPos;
+                                unsigned long long rId = repId;
+                                if (NUCL) {
+                                    bool repIsReverse = ((best & 1ULL) == 0);
+                                    if (K == firstRunKey) repIsReverse = false;       // kmermatcher.cpp:463 (never refreshed for run 0)
+                                    const bool targetIsReverse = ((r.kmer & BIT63) == 0);
+                                    int qp, tp; bool qRev;
+                                    // positions are truncated to T exactly like the reference's T queryPos/targetPos
+                                    if (repIsReverse && !targetIsReverse) { qp = repPos; tp = mPos; qRev = true; }
+                                    else if (repIsReverse && targetIsReverse) { qp = (queryLen - 1) - repPos; tp = (mLen - 1) - mPos; qRev = false; }
+                                    else if (!repIsReverse && targetIsReverse) { qp = (queryLen - 1) - repPos; tp = (mLen - 1) - mPos; qRev = true; }
+                                    else { qp = repPos; tp = mPos; qRev = false; }
+                                    if (!LONG) { qp = (int) (short) qp; tp = (int) (short) tp; }
+                                    diagonal = qp - tp;
+                                    rId = qRev ? (rId & ~BIT63) : (rId | BIT63);
+                                }
+                                const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - mLen));
+                                const bool cov = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) mLen);
+                                keep = (!a.includeOnlyExtendable && cov) || (canBeExtended && a.includeOnlyExtendable);
+                                o.kmer = rId; o.id = r.id; o.len = r.len; o.pos = (decltype(o.pos)) diagonal;
+                            }
+                        }
+                    }
+                    // block-wide compaction into this block's arena
+                    const unsigned long long mk = __ballot(keep);
+                    const uint32_t wr = (uint32_t) __popcll(mk & ((1ULL << laneId()) - 1ULL));
+                    if (laneId() == 0) sWaveCnt[threadIdx.x >> 6] = (uint32_t) __popcll(mk);
+                    __syncthreads();
+                    uint32_t woff = 0, tot = 0;
+#pragma unroll
+                    for (int w = 0; w < GR_BLOCK / 64; w++) { if (w < (int) (threadIdx.x >> 6)) woff += sWaveCnt[w]; tot += sWaveCnt[w]; }
+                    if (keep) out[arena + written + woff + wr] = o;
+                    written += tot;
+                    __syncthreads();
+                }
+            }
+            if (!redo) break;
+            // a retry discards what completed sub-passes of this attempt wrote: rewind the arena cursor
+            nSub *= 2;
+            written = writtenAtBucketStart;
+            __syncthreads();
+        }
+    }
+    if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
+}
+
+// =====================================================================================================
+// 5. sort #2: bitonic sort of one rep-range bucket (LDS when it fits, in place in HBM otherwise)
+// =====================================================================================================
+constexpr int LS_BLOCK = 256;
+template <bool NUCL, bool LONG> __device__ __forceinline__ bool recLess2(const Rec<LONG> &x, const Rec<LONG> &y) {   // kmermatcher.h:98-130
+    const uint64_t a = NUCL ? (x.kmer | BIT63) : x.kmer, b = NUCL ? (y.kmer | BIT63) : y.kmer;
+    if (a != b) return a < b;
+    if (x.id != y.id) return x.id < y.id;
+    if (x.pos != y.pos) return x.pos < y.pos;
+    return x.kmer < y.kmer;      // canonical tie-break where the reference comparator ties (strand bit)
+}
+
+template <bool NUCL, bool LONG, int CAPS>
+__global__ __launch_bounds__(LS_BLOCK) void localSortKernel(void *arr, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
+                                                            void *bigScratch, const uint64_t *__restrict__ bigOff) {
+    typedef Rec<LONG> R;
+    __shared__ R s[CAPS];
+    R *g = reinterpret_cast<R *>(arr);
+    for (uint32_t b = blockIdx.x; b < nBuckets; b += gridDim.x) {
+        const uint64_t s0 = bucketStart[b], s1 = bucketStart[b + 1];
+        const uint64_t cnt = s1 - s0;
+        if (cnt <= 1) continue;
+        uint64_t P = 1; while (P < cnt) P <<= 1;
+        R *p;
+        if (P <= (uint64_t) CAPS) p = s; else p = reinterpret_cast<R *>(bigScratch) + bigOff[b];
+        for (uint64_t i = threadIdx.x; i < P; i += LS_BLOCK) {
+            R r;
+            if (i < cnt) r = g[s0 + i]; else memset(&r, 0xFF, sizeof(R));
+            p[i] = r;
+        }
+        __syncthreads();
+        for (uint64_t kk = 2; kk <= P; kk <<= 1) {
+            for (uint64_t j = kk >> 1; j > 0; j >>= 1) {
+                for (uint64_t i = threadIdx.x; i < P; i += LS_BLOCK) {
+                    const uint64_t l = i ^ j;
+                    if (l > i) {
+                        const R x = p[i], y = p[l];
+                        const bool up = (i & kk) == 0;
+                        // padding records (all 0xFF) must sort last: compare raw for them
+                        bool yLess;
+                        if (isSentinel(y)) yLess = false; else if (isSentinel(x)) yLess = true; else yLess = recLess2<NUCL, LONG>(y, x);
+                        bool xLess;
+                        if (isSentinel(x)) xLess = false; else if (isSentinel(y)) xLess = true; else xLess = recLess2<NUCL, LONG>(x, y);
+                        if (up ? yLess : xLess) { p[i] = y; p[l] = x; }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) g[s0 + i] = p[i];
+        __syncthreads();
+    }
+}
+
+// =====================================================================================================
+// 6. best diagonal per (rep, target) run (writeKmerMatcherResult, kmermatcher.cpp:835-923)
+// =====================================================================================================
+template <bool NUCL, bool LONG>
+__global__ void reduceRunsKernel(const void *arr, uint64_t n, CandHit *__restrict__ tmpHits, uint32_t *__restrict__ emit,
+                                 uint32_t *__restrict__ perRep) {
+    typedef Rec<LONG> R;
+    const R *h = reinterpret_cast<const R *>(arr);
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const R r = h[i];
+        const uint64_t rep = NUCL ? (r.kmer & ~BIT63) : r.kmer;
+        bool head = (i == 0);
+        if (!head) { const R q = h[i - 1]; const uint64_t prep = NUCL ? (q.kmer & ~BIT63) : q.kmer; head = (prep != rep) || (q.id != r.id); }
+        uint32_t e = 0;
+        if (head) {
+            const uint32_t targetId = r.id;
+            auto diagonal = r.pos; auto prevDiagonal = r.pos;
+            uint64_t maxDiagonal = 0, diagonalCnt = 0, topScore = 0;
+            int bestRev = NUCL ? ((r.kmer & BIT63) == 0) : 0;
+            // NOTE: the reference's scan tests only the target id, so it runs across a rep boundary when the
+            // next rep starts with the same target (Appendix A.3) — reproduced; it can also run past the
+            // compaction point into stale sort-#1 records (probability ~1/N per run) — not reproduced.
+            for (uint64_t j = i; j < n; j++) {
+                const R x = h[j];
+                if (x.id != targetId) break;
+                if (prevDiagonal == x.pos) diagonalCnt++; else diagonalCnt = 1;
+                if (diagonalCnt >= maxDiagonal) { diagonal = x.pos; maxDiagonal = diagonalCnt; if (NUCL) bestRev = ((x.kmer & BIT63) == 0); }
+                prevDiagonal = x.pos; topScore++;
+            }
+            if ((uint64_t) targetId != rep) {
+                CandHit c; c.target = targetId; c.prefScore = bestRev ? -(int) topScore : (int) topScore;
+                c.diag16 = (uint32_t) (uint16_t) diagonal; c.query = (uint32_t) rep;
+                tmpHits[i] = c; e = 1;
+                atomicAdd(&perRep[(uint32_t) rep], 1u);
+            }
+        }
+        emit[i] = e;
+    }
+}
+
+__global__ void fillU32Kernel(uint32_t *p, uint32_t v, uint64_t n) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void placeHitsKernel(const CandHit *__restrict__ tmpHits, const uint32_t *__restrict__ emit, const uint64_t *__restrict__ epos,
+                                uint64_t n, CandHit *__restrict__ hits) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        if (emit[i]) { const CandHit c = tmpHits[i]; hits[epos[i] + (uint64_t) c.query + 1] = c; }
+}
+__global__ void placeSelfKernel(const uint64_t *__restrict__ qoff, uint32_t nq, CandHit *__restrict__ hits) {
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+        CandHit c; c.target = q; c.prefScore = 0; c.diag16 = 0; c.query = q;
+        hits[qoff[q]] = c;
+    }
+}
+
+}  // namespace plasship
+using namespace plasship;
+
+// ---- host orchestration --------------------------------------------------------------------------------
+namespace {
+
+struct Timer {
+    plasship_ctx *ctx; int slot;
+    void start(int s) { slot = s; (void) hipEventRecord(ctx->ev[s], ctx->stream); }
+    float stop(int s2) { (void) hipEventRecord(ctx->ev[s2], ctx->stream); (void) hipEventSynchronize(ctx->ev[s2]); float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[slot], ctx->ev[s2]); return ms; }
+};
+
+static inline unsigned gridFor(uint64_t n, unsigned block, unsigned cap = 65535u * 8) {
+    uint64_t g = (n + block - 1) / block; if (g < 1) g = 1; if (g > cap) g = cap; return (unsigned) g;
+}
+static int ceilLog2(uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; }
+
+template <bool NUCL, bool LONG>
+int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
+                  plasship_kmermatch_stats *stats) {
+    typedef Rec<LONG> R;
+    hipStream_t st = ctx->stream;
+    const uint32_t N = (uint32_t) db->n;
+    const int k = par->kmer_size;
+    Timer tm{ctx, 0};
+    float msExtract = 0, msSort1 = 0, msGroup = 0, msSort2 = 0, msReduce = 0;
+
+    // ---- slot bounds + offsets ----
+    DevBuf dBound, dSlotOff, dScanTmp;
+    const size_t scanTmpBytes = exclusiveScanTmpBytes((size_t) N + 2) + (1u << 20);
+    if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess) {
+        setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    tm.start(0);
+    if (N) hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
+    if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t total = 0;
+    PH_CHECK(hipMemcpyAsync(&total, dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+
+    DevBuf dA, dB;   // ping-pong record arrays
+    if (dA.alloc(std::max<uint64_t>(total, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(total, 1) * sizeof(R)) != hipSuccess) {
+        setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE;
+    }
+
+    // ---- extraction ----
+    DevBuf dMap, dOvIds, dOvCnt;
+    if (dMap.alloc(256) != hipSuccess || dOvIds.alloc(((size_t) N + 1) * 4) != hipSuccess || dOvCnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    const unsigned char *map = aa2numTable(NUCL, par->alphabet_size);
+    PH_CHECK(hipMemcpyAsync(dMap.p, map, 256, hipMemcpyHostToDevice, st));
+    PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));
+    ExtractArgs ea; memset(&ea, 0, sizeof(ea));
+    ea.s = db->view(); ea.slotOff = dSlotOff.as<uint64_t>(); ea.arr = dA.p; ea.map = dMap.as<unsigned char>();
+    const int alph = NUCL ? 5 : par->alphabet_size;
+    { uint64_t p = 1; for (int i = 0; i < 24; i++) { ea.powers[i] = p; p *= (uint64_t) (alph - 1); } }
+    ea.k = k; ea.xCode = map[(int) 'X']; ea.kps = par->kmers_per_seq; ea.ignoreMulti = par->ignore_multi_kmer; ea.scale = par->kmers_per_seq_scale;
+    ea.seed = (uint64_t) par->hash_shift; ea.overflowIds = dOvIds.as<uint32_t>(); ea.overflowCount = dOvCnt.as<uint32_t>();
+    constexpr int CAP = NUCL ? 1024 : 256;
+    if (N) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
+    uint32_t nOv = 0;
+    PH_CHECK(hipMemcpyAsync(&nOv, dOvCnt.p, 4, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    if (nOv) {   // sequences whose candidate set did not fit LDS: same kernel, candidates in HBM scratch
+        std::vector<uint32_t> ids(nOv), lens(nOv);
+        DevBuf dLens, dSOff, dSCap, dScratch;
+        if (dLens.alloc((size_t) nOv * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(gatherU32Kernel, dim3(gridFor(nOv, 256, 1024)), dim3(256), 0, st, db->d_len.as<uint32_t>(), dOvIds.as<uint32_t>(), nOv, dLens.as<uint32_t>());
+        PH_CHECK(hipMemcpyAsync(lens.data(), dLens.p, (size_t) nOv * 4, hipMemcpyDeviceToHost, st));
+        PH_CHECK(hipStreamSynchronize(st));
+        std::vector<uint64_t> soff(nOv); std::vector<uint32_t> scap(nOv); uint64_t tot = 0;
+        for (uint32_t i = 0; i < nOv; i++) { uint32_t c = 64; while (c < lens[i] + 1) c <<= 1; scap[i] = c; soff[i] = tot; tot += c; }
+        if (dSOff.alloc((size_t) nOv * 8) != hipSuccess || dSCap.alloc((size_t) nOv * 4) != hipSuccess || dScratch.alloc(tot * sizeof(Cand)) != hipSuccess) {
+            setError("kmermatch: out of device memory for the long-sequence scratch"); return PLASSHIP_ERR_DEVICE;
+        }
+        PH_CHECK(hipMemcpyAsync(dSOff.p, soff.data(), (size_t) nOv * 8, hipMemcpyHostToDevice, st));
+        PH_CHECK(hipMemcpyAsync(dSCap.p, scap.data(), (size_t) nOv * 4, hipMemcpyHostToDevice, st));
+        ExtractArgs fa = ea; fa.idList = dOvIds.as<uint32_t>(); fa.nIds = nOv; fa.scratch = dScratch.as<Cand>(); fa.scratchOff = dSOff.as<uint64_t>(); fa.scratchCap = dSCap.as<uint32_t>();
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(std::min<uint32_t>(nOv, (uint32_t) ctx->numCU * 8)), dim3(64), 0, st, fa);
+        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(hipGetLastError());
+    }
+    msExtract = tm.stop(1);
+
+    // ---- hash partition (replaces sort #1) ----
+    tm.start(0);
+    const int totalBits = std::max(0, ceilLog2((total + 767) / 768));          // ~768 records per final bucket
+    const int b1 = std::min(totalBits, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
+    const uint32_t nB1 = 1u << b1, nB = 1u << (b1 + b2);
+    DevBuf dCnt1, dStart1, dCur1, dSeg0Start, dSeg0Cnt, dMinKey, dCnt2, dStart2, dCur2, dSegCnt1;
+    if (dCnt1.alloc((size_t) nB1 * 4) != hipSuccess || dStart1.alloc(((size_t) nB1 + 1) * 8) != hipSuccess || dCur1.alloc((size_t) nB1 * 8) != hipSuccess ||
+        dSeg0Start.alloc(8) != hipSuccess || dSeg0Cnt.alloc(8) != hipSuccess || dMinKey.alloc(8) != hipSuccess || dSegCnt1.alloc((size_t) nB1 * 8) != hipSuccess ||
+        dCnt2.alloc((size_t) nB * 4) != hipSuccess || dStart2.alloc(((size_t) nB + 1) * 8) != hipSuccess || dCur2.alloc((size_t) nB * 8) != hipSuccess) {
+        setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    { uint64_t z = 0; PH_CHECK(hipMemcpyAsync(dSeg0Start.p, &z, 8, hipMemcpyHostToDevice, st)); PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &total, 8, hipMemcpyHostToDevice, st)); }
+    PH_CHECK(hipMemsetAsync(dMinKey.p, 0xFF, 8, st));
+    PH_CHECK(hipMemsetAsync(dCnt1.p, 0, (size_t) nB1 * 4, st));
+    PartArgs pa; memset(&pa, 0, sizeof(pa));
+    pa.in = dA.p; pa.out = dB.p; pa.segStart = dSeg0Start.as<uint64_t>(); pa.segCount = dSeg0Cnt.as<uint64_t>(); pa.count = dCnt1.as<uint32_t>();
+    pa.cursor = dCur1.as<unsigned long long>(); pa.shift = 64 - b1; pa.bits = b1; pa.rangeBits = 0; pa.dropSentinels = 1; pa.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
+    if (b1 == 0) pa.shift = 63;   // single bucket: (key >> 63) & 0 == 0
+    const unsigned tiles0 = (unsigned) std::max<uint64_t>(1, (total + PT_TILE - 1) / PT_TILE);
+    hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
+    if (exclusiveScanU32(st, dCnt1.as<uint32_t>(), dStart1.as<uint64_t>(), nB1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dCur1.as<unsigned long long>(), (uint64_t) nB1);
+    pa.minKey = nullptr;
+    hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
+    std::vector<uint64_t> hStart1(nB1 + 1);
+    PH_CHECK(hipMemcpyAsync(hStart1.data(), dStart1.p, ((size_t) nB1 + 1) * 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    const uint64_t Nk = hStart1[nB1];
+    void *cur = dB.p, *other = dA.p;
+    const uint64_t *dBucketStart = dStart1.as<uint64_t>();
+    if (b2 > 0) {
+        uint64_t maxSeg = 0; for (uint32_t i = 0; i < nB1; i++) maxSeg = std::max(maxSeg, hStart1[i + 1] - hStart1[i]);
+        hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dSegCnt1.as<uint64_t>(), (uint64_t) nB1);
+        PH_CHECK(hipMemsetAsync(dCnt2.p, 0, (size_t) nB * 4, st));
+        PartArgs p2; memset(&p2, 0, sizeof(p2));
+        p2.in = cur; p2.out = other; p2.segStart = dStart1.as<uint64_t>(); p2.segCount = dSegCnt1.as<uint64_t>(); p2.count = dCnt2.as<uint32_t>();
+        p2.cursor = dCur2.as<unsigned long long>(); p2.shift = 64 - b1 - b2; p2.bits = b2; p2.dropSentinels = 0;
+        const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxSeg + PT_TILE - 1) / PT_TILE);
+        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), 0, st, p2);
+        if (exclusiveScanU32(st, dCnt2.as<uint32_t>(), dStart2.as<uint64_t>(), nB, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB, 256, 1024)), dim3(256), 0, st, dStart2.as<uint64_t>(), dCur2.as<unsigned long long>(), (uint64_t) nB);
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), 0, st, p2);
+        std::swap(cur, other);
+        dBucketStart = dStart2.as<uint64_t>();
+    }
+    msSort1 = tm.stop(1);
+
+    // ---- assignGroup ----
+    tm.start(0);
+    const uint32_t nBuckets = (b2 > 0) ? nB : nB1;
+    const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) ctx->numCU * 8);
+    const uint32_t bpb = (nBuckets + gBlocks - 1) / gBlocks;
+    const uint32_t gGrid = (nBuckets + bpb - 1) / bpb;
+    DevBuf dOutCnt, dArenaStart;
+    if (dOutCnt.alloc((size_t) gGrid * 8) != hipSuccess || dArenaStart.alloc((size_t) gGrid * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    GroupArgs ga; memset(&ga, 0, sizeof(ga));
+    ga.in = cur; ga.out = other; ga.bucketStart = dBucketStart; ga.nBuckets = nBuckets; ga.bucketsPerBlock = bpb; ga.outCount = dOutCnt.as<uint64_t>();
+    ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
+    hipLaunchKernelGGL((groupKernel<NUCL, LONG>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+    std::vector<uint64_t> hOutCnt(gGrid), hBStart(nBuckets + 1);
+    PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hBStart.data(), dBucketStart, ((size_t) nBuckets + 1) * 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    std::vector<uint64_t> hArena(gGrid); uint64_t Nm = 0, maxArena = 0;
+    for (uint32_t j = 0; j < gGrid; j++) { hArena[j] = hBStart[(size_t) j * bpb]; Nm += hOutCnt[j]; maxArena = std::max(maxArena, hOutCnt[j]); }
+    PH_CHECK(hipMemcpyAsync(dArenaStart.p, hArena.data(), (size_t) gGrid * 8, hipMemcpyHostToDevice, st));
+    std::swap(cur, other);   // cur = grouped records, scattered in arenas
+    msGroup = tm.stop(1);
+
+    // ---- sort #2: range partition by rep id + local bitonic sort ----
+    tm.start(0);
+    const int repBits = std::max(1, ceilLog2((uint64_t) N));
+    const int wantBits = std::max(0, ceilLog2((Nm + 1023) / 1024));
+    const int sBits = std::min(wantBits, repBits);
+    const int s1 = std::min(sBits, 11), s2 = std::min(std::max(sBits - s1, 0), 11);
+    const uint32_t nS1 = 1u << s1, nS = 1u << (s1 + s2);
+    DevBuf dRC1, dRS1, dRCur1, dRSegCnt, dRC2, dRS2, dRCur2;
+    if (dRC1.alloc((size_t) nS1 * 4) != hipSuccess || dRS1.alloc(((size_t) nS1 + 1) * 8) != hipSuccess || dRCur1.alloc((size_t) nS1 * 8) != hipSuccess ||
+        dRSegCnt.alloc((size_t) nS1 * 8) != hipSuccess || dRC2.alloc((size_t) nS * 4) != hipSuccess || dRS2.alloc(((size_t) nS + 1) * 8) != hipSuccess ||
+        dRCur2.alloc((size_t) nS * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    const uint64_t *dSortStart = nullptr; uint32_t nSortBuckets = 0;
+    std::vector<uint64_t> hSortStart;
+    {
+        // level 1 reads the grouped records straight out of the group kernel's arenas (segments); all arenas
+        // accumulate into one bucket table.
+        PH_CHECK(hipMemsetAsync(dRC1.p, 0, (size_t) nS1 * 4, st));
+        PartArgs p1; memset(&p1, 0, sizeof(p1));
+        p1.in = cur; p1.out = other; p1.segStart = dArenaStart.as<uint64_t>(); p1.segCount = dOutCnt.as<uint64_t>(); p1.count = dRC1.as<uint32_t>();
+        p1.cursor = dRCur1.as<unsigned long long>(); p1.shift = 64 - s1; p1.bits = s1; p1.rangeBits = repBits; p1.dropSentinels = 0; p1.sharedTable = 1;
+        if (s1 == 0) p1.shift = 63;
+        const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxArena + PT_TILE - 1) / PT_TILE);
+        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, gGrid), dim3(PT_BLOCK), 0, st, p1);
+        if (exclusiveScanU32(st, dRC1.as<uint32_t>(), dRS1.as<uint64_t>(), nS1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nS1, 256, 64)), dim3(256), 0, st, dRS1.as<uint64_t>(), dRCur1.as<unsigned long long>(), (uint64_t) nS1);
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, gGrid), dim3(PT_BLOCK), 0, st, p1);
+        std::swap(cur, other);
+        std::vector<uint64_t> hS1(nS1 + 1);
+        PH_CHECK(hipMemcpyAsync(hS1.data(), dRS1.p, ((size_t) nS1 + 1) * 8, hipMemcpyDeviceToHost, st));
+        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(hipGetLastError());
+        dSortStart = dRS1.as<uint64_t>(); nSortBuckets = nS1; hSortStart = hS1;
+        if (s2 > 0) {
+            uint64_t maxSeg = 0; for (uint32_t i = 0; i < nS1; i++) maxSeg = std::max(maxSeg, hS1[i + 1] - hS1[i]);
+            hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nS1, 256, 64)), dim3(256), 0, st, dRS1.as<uint64_t>(), dRSegCnt.as<uint64_t>(), (uint64_t) nS1);
+            PH_CHECK(hipMemsetAsync(dRC2.p, 0, (size_t) nS * 4, st));
+            PartArgs p2; memset(&p2, 0, sizeof(p2));
+            p2.in = cur; p2.out = other; p2.segStart = dRS1.as<uint64_t>(); p2.segCount = dRSegCnt.as<uint64_t>(); p2.count = dRC2.as<uint32_t>();
+            p2.cursor = dRCur2.as<unsigned long long>(); p2.shift = 64 - s1 - s2; p2.bits = s2; p2.rangeBits = repBits; p2.dropSentinels = 0;
+            const unsigned tiles2 = (unsigned) std::max<uint64_t>(1, (maxSeg + PT_TILE - 1) / PT_TILE);
+            hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), 0, st, p2);
+            if (exclusiveScanU32(st, dRC2.as<uint32_t>(), dRS2.as<uint64_t>(), nS, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+            hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nS, 256, 1024)), dim3(256), 0, st, dRS2.as<uint64_t>(), dRCur2.as<unsigned long long>(), (uint64_t) nS);
+            hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), 0, st, p2);
+            std::swap(cur, other);
+            hSortStart.resize((size_t) nS + 1);
+            PH_CHECK(hipMemcpyAsync(hSortStart.data(), dRS2.p, ((size_t) nS + 1) * 8, hipMemcpyDeviceToHost, st));
+            PH_CHECK(hipStreamSynchronize(st));
+            dSortStart = dRS2.as<uint64_t>(); nSortBuckets = nS;
+        }
+    }
+    // local sorts; buckets beyond the LDS capacity sort in HBM scratch
+    constexpr int CAPS = LONG ? 2048 : 4096;
+    DevBuf dBigOff, dBigScratch;
+    {
+        std::vector<uint64_t> bigOff(nSortBuckets, 0); uint64_t bigTot = 0;
+        for (uint32_t b = 0; b < nSortBuckets; b++) {
+            const uint64_t c = hSortStart[b + 1] - hSortStart[b];
+            uint64_t P = 1; while (P < c) P <<= 1;
+            if (P > (uint64_t) CAPS) { bigOff[b] = bigTot; bigTot += P; }
+        }
+        if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * sizeof(R)) != hipSuccess) {
+            setError("kmermatch: out of device memory for oversized sort buckets"); return PLASSHIP_ERR_DEVICE;
+        }
+        PH_CHECK(hipMemcpyAsync(dBigOff.p, bigOff.data(), (size_t) nSortBuckets * 8, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL((localSortKernel<NUCL, LONG, CAPS>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * 16)), dim3(LS_BLOCK), 0, st,
+                       cur, dSortStart, nSortBuckets, dBigScratch.p, dBigOff.as<uint64_t>());
+    msSort2 = tm.stop(1);
+
+    // ---- per-(rep,target) reduction + CSR ----
+    tm.start(0);
+    DevBuf dTmpHits, dEmit, dEpos, dPerRep, dQoff;
+    if (dTmpHits.alloc(std::max<uint64_t>(Nm, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc(std::max<uint64_t>(Nm, 1) * 4) != hipSuccess ||
+        dEpos.alloc((Nm + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    DevBuf dScanTmp2; const size_t scanTmp2Bytes = exclusiveScanTmpBytes(std::max<uint64_t>(Nm, N) + 2);
+    if (dScanTmp2.alloc(scanTmp2Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor((uint64_t) N + 1, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>(), 1u, (uint64_t) N);
+    if (Nm) hipLaunchKernelGGL((reduceRunsKernel<NUCL, LONG>), dim3(gridFor(Nm, 256, 65535)), dim3(256), 0, st, (const void *) cur, Nm, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
+    if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), Nm, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    plasship_cands *c = new plasship_cands();
+    c->reverseCapable = NUCL; c->nQueries = N;
+    if (c->d_qoff.alloc(((size_t) N + 1) * 8) != hipSuccess) { delete c; setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { delete c; setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t Nc = 0;
+    PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + Nm, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    c->nHits = Nc + N; c->nNonSelf = Nc;
+    if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { delete c; setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (N) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), N, c->d_hits.as<CandHit>());
+    if (Nm) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(Nm, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), Nm, c->d_hits.as<CandHit>());
+    msReduce = tm.stop(1);
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    if (stats) {
+        stats->n_kmer_records = Nk; stats->n_grouped = Nm; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
+        stats->ms_extract = msExtract; stats->ms_sort1 = msSort1; stats->ms_group = msGroup; stats->ms_sort2 = msSort2; stats->ms_reduce = msReduce;
+    }
+    *out = c;
+    return PLASSHIP_OK;
+}
+}  // namespace
+
+extern "C" int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par,
+                                  plasship_cands **out, plasship_kmermatch_stats *stats) {
+    if (!ctx || !db || !par || !out) { setError("plasship_kmermatch: bad argument"); return PLASSHIP_ERR_ARG; }
+    const bool nucl = db->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES;
+    if (par->kmer_size < 2 || par->kmer_size > (nucl ? 31 : 23)) { setError("plasship_kmermatch: unsupported k"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (!nucl && par->alphabet_size != 13 && par->alphabet_size != 21) { setError("plasship_kmermatch: --alph-size must be 13 or 21"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (db->maxEntryLen >= (1u << 20)) { setError("plasship_kmermatch: sequences of 2^20 residues or more are not supported"); return PLASSHIP_ERR_UNSUPPORTED; }
+    PH_CHECK(hipSetDevice(ctx->device));
+    const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX);     // kmermatcher.cpp:797-802
+    if (nucl) return lng ? kmermatchImpl<true, true>(ctx, db, par, out, stats) : kmermatchImpl<true, false>(ctx, db, par, out, stats);
+    return lng ? kmermatchImpl<false, true>(ctx, db, par, out, stats) : kmermatchImpl<false, false>(ctx, db, par, out, stats);
+}

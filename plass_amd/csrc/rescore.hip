@@ -1,0 +1,287 @@
+// plasship: rescorediagonal on gfx950 (rows R1–R5 of SURVEY.md §8a).  Product code.
+//
+// Reference behaviour reproduced (file:line in /root/reference/lib/mmseqs/src):
+//   alignment/rescorediagonal.cpp:193-334   per-hit loop: canBeCovered gate, isIdentity, filters
+//   alignment/DistanceCalculator.h:93-113   computeUngappedAlignment: try all ±65536 wraps of the u16
+//                                           diagonal, strictly-better score wins, first wins ties
+//   alignment/DistanceCalculator.h:115-175  overlap geometry for one diagonal
+//   alignment/DistanceCalculator.h:204-220  mode 3 end-to-end score, '*' trimmed at either end
+//   alignment/rescorediagonal.cpp:251-297   alnLen, coordinates, identity count, seqId, coverage
+//
+// Kernel design: one wavefront per candidate pair.  The 123x123 ASCII-indexed score table
+// (SubstitutionMatrix.h:56-73; 15 KB) lives in LDS; lanes stride over the overlap, one byte of query
+// and target each (HBM-resident packed sequence data, both reads coalesced across the wave), the
+// table lookup is an LDS gather, and score / identity counts are reduced with wave shuffles.  Lane 0
+// finishes the integer and IEEE-exact fp arithmetic (float divisions, double fma/div for the bit
+// score); the only transcendental piece — the E-value — is replaced by a host-built per-query-length
+// minimum-score table, which is exact because E(score) is monotone (host_util.cpp).
+// -ffp-contract=off: no float expression here may be fused behind our back.
+#include "common.hpp"
+#include "device_utils.hpp"
+#include "host_util.hpp"
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+
+namespace plasship {
+
+struct RescoreArgs {
+    SeqView q, t;
+    const uint64_t *qoff;        // CSR over queries (only for nHits)
+    const CandHit *hits;
+    uint64_t nHits;
+    AlnRec *out;                 // [nHits]
+    uint32_t *accept;            // [nHits]
+    const uint32_t *minScore;    // [maxQLen+1] minimum raw score passing -e for that query length
+    uint32_t minScoreLen;
+    const signed char *mat;      // 123*123 in global, staged to LDS
+    int sameDB, includeIdentity, reverseCapable;
+    int covMode; float covThr;
+    float seqIdThr; int alnLenThr, seqIdMode;
+    double lambda, logK, ln2;
+    unsigned long long *stats;   // [0] accepted, [1] overlap residues
+};
+
+__device__ __forceinline__ bool canBeCoveredDev(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
+    switch (covMode) {
+        case 0: return (q / t >= covThr) && (t / q >= covThr);
+        case 1: return (t / q) >= covThr;
+        case 2: return (q / t) >= covThr;
+        case 3: return ((t / q) >= covThr) && (t / q) <= 1.0f;
+        case 4: return ((q / t) >= covThr) && (q / t) <= 1.0f;
+        case 5: return (fminf(t, q) / fmaxf(t, q)) >= covThr;
+        default: return true;
+    }
+}
+__device__ __forceinline__ bool hasCoverageDev(float covThr, int covMode, float qc, float tc) {  // Util.cpp:552-568
+    switch (covMode) {
+        case 0: return (qc >= covThr) && (tc >= covThr);
+        case 1: return qc >= covThr;
+        case 2: return tc >= covThr;
+        default: return true;
+    }
+}
+__device__ __forceinline__ float computeCovDev(unsigned s, unsigned e, unsigned len) {            // StripedSmithWaterman.cpp:1055-1057
+    return (float) (min(len, max(s, e)) - min(s, e) + 1) / (float) len;
+}
+// complement of an ASCII nucleotide exactly as rescorediagonal.cpp:175-178 builds the reverse query:
+// num2aa[reverse(aa2num[c])] with aa2num = NucleotideMatrix letter mapping (NucleotideMatrix.cpp:17-61)
+__device__ __forceinline__ char nuclRevCompChar(char c) {
+    switch (c & ~0x20) {
+        case 'A': return 'T';
+        case 'C': case 'M': case 'Y': case 'H': return 'G';
+        case 'T': case 'U': case 'W': return 'A';
+        case 'G': case 'K': case 'B': case 'D': case 'V': case 'R': case 'S': return 'C';
+        default: return 'X';
+    }
+}
+
+constexpr int RS_BLOCK = 256;
+
+// Scores ONE diagonal with the whole wave; returns (all lanes) score/first/last/idCnt; valid=false if
+// the diagonal does not intersect.  Mode 3 only.
+struct DiagScore { bool valid; unsigned score; int first, last; unsigned diagLen; int idCnt; };
+
+template <bool REV>
+__device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, unsigned qLen, const char *__restrict__ t,
+                                                   unsigned tLen, int diagonal, const signed char *__restrict__ smat) {
+    DiagScore r; r.valid = false; r.score = 0; r.first = -1; r.last = -1; r.diagLen = 0; r.idCnt = 0;
+    const unsigned dist = (unsigned) abs(diagonal);
+    unsigned qo, to, len;
+    if (diagonal >= 0 && dist < qLen) { qo = dist; to = 0; len = min(tLen, qLen - dist); }
+    else if (diagonal < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, qLen); }
+    else return r;
+    r.valid = true; r.diagLen = len;
+    if (len == 0) { r.first = 0; r.last = -1; return r; }   // empty sequence: reference reads out of bounds; unsupported
+    // REV: the aligned query is the reverse complement of the stored one: qrev[i] = comp(q[qLen-1-i])
+    auto Q = [&](unsigned i) -> char { return REV ? nuclRevCompChar(q[qLen - 1 - (qo + i)]) : q[qo + i]; };
+    const char q0 = Q(0), t0 = t[to], qe = Q(len - 1), te = t[to + len - 1];
+    unsigned first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+    unsigned last = len - 1;
+    if (last > 0 && (qe == '*' || te == '*')) last--;
+    int s = 0, ids = 0;
+    for (unsigned p = first + (unsigned) laneId(); p <= last; p += 64) {
+        const char a = Q(p), b = t[to + p];
+        s += (int) smat[(int) a * 123 + (int) b];
+        ids += ((a & ~0x20) == (b & ~0x20)) ? 1 : 0;
+    }
+    s = waveReduceSum(s); ids = waveReduceSum(ids);
+    r.score = (unsigned) max(s, 0); r.first = (int) first; r.last = (int) last; r.idCnt = ids;
+    return r;
+}
+
+__global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
+    __shared__ signed char smat[123 * 123 + 7];
+    for (int i = threadIdx.x; i < 123 * 123; i += RS_BLOCK) smat[i] = a.mat[i];
+    __syncthreads();
+    const int wavesPerBlock = RS_BLOCK / WAVE;
+    const uint64_t stride = (uint64_t) gridDim.x * wavesPerBlock;
+    unsigned long long accLocal = 0, ovLocal = 0;
+    for (uint64_t h = (uint64_t) blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); h < a.nHits; h += stride) {
+        const CandHit hit = a.hits[h];
+        const uint32_t qid = hit.query, tid = hit.target;
+        const char *q = a.q.data + a.q.off[qid];
+        const unsigned qLen = a.q.len[qid];
+        const char *t = a.t.data + a.t.off[tid];
+        const unsigned tLen = a.t.len[tid];
+        const bool isReverse = a.reverseCapable && hit.prefScore < 0;
+        const bool isIdentity = (qid == tid) && (a.includeIdentity || a.sameDB);
+        AlnRec rec; memset(&rec, 0, sizeof(rec));
+        rec.query = qid; rec.target = tid;
+        bool accepted = false;
+        if (canBeCoveredDev(a.covThr, a.covMode, (float) qLen, (float) tLen)) {
+            // computeUngappedAlignment: best over all wraps; default LocalAlignment if none scores > 0
+            int bStart = -1, bEnd = -1, bDiag = 0, bIds = 0; unsigned bScore = 0, bDiagLen = 0, bDist = 0;
+            const unsigned d16 = hit.diag16 & 0xFFFFu;
+            for (unsigned d = 1; d <= 1 + tLen / 32768; d++) {
+                const int real = (int) (d16 - d * 65536u);
+                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat);
+                if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
+            }
+            for (unsigned d = 0; d <= qLen / 65536; d++) {
+                const int real = (int) (d * 65536u + d16);
+                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat);
+                if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
+            }
+            ovLocal += bDiagLen;
+            // ---- lane-uniform finish (rescorediagonal.cpp:251-314) ----
+            const int distance = (int) bScore;
+            const int bitScore = (int) (fma(a.lambda, (double) distance, -a.logK) / a.ln2 + 0.5);
+            const int alnLen = (bEnd - bStart) + 1;
+            int qS, qE, dS, dE;
+            if (bDiag >= 0) { qS = bStart + (int) bDist; qE = bEnd + (int) bDist; dS = bStart; dE = bEnd; }
+            else { qS = bStart; qE = bEnd; dS = bStart + (int) bDist; dE = bEnd + (int) bDist; }
+            const uint32_t ms = (qLen < a.minScoreLen) ? a.minScore[qLen] : 0xFFFFFFFFu;
+            const bool hasEvalue = (uint32_t) distance >= ms;
+            // default alignment (no wrap scored > 0): the reference's identity loop then runs over the
+            // single index -1 of both strings; for the identity pair both bytes are the same byte.
+            int idCnt = bIds;
+            if (bStart < 0) idCnt = isIdentity ? 1 : 0;
+            float seqId = 0.0f;
+            if (hasEvalue || isIdentity) {
+                switch (a.seqIdMode) {                                                     // Util.cpp:588-598
+                    case 0: seqId = (float) idCnt / (float) alnLen; break;
+                    case 1: seqId = (float) idCnt / (float) min((int) qLen, (int) tLen); break;
+                    case 2: seqId = (float) idCnt / (float) max((int) qLen, (int) tLen); break;
+                    default: seqId = 0.0f;
+                }
+            }
+            const float queryCov = computeCovDev((unsigned) qS, (unsigned) qE, qLen);
+            const float targetCov = computeCovDev((unsigned) dS, (unsigned) dE, tLen);
+            if (isReverse) { qS = (int) qLen - qS - 1; qE = (int) qLen - qE - 1; }
+            const bool hasCov = hasCoverageDev(a.covThr, a.covMode, queryCov, targetCov);
+            const bool hasSeqId = (double) seqId >= (double) (a.seqIdThr - FLT_EPSILON);
+            const bool hasAlnLen = alnLen >= a.alnLenThr;
+            accepted = isIdentity || (hasAlnLen && hasCov && hasSeqId && hasEvalue);
+            rec.bitScore = bitScore; rec.rawScore = distance; rec.seqId = seqId;
+            rec.qStart = qS; rec.qEnd = qE; rec.qLen = (int) qLen; rec.dbStart = dS; rec.dbEnd = dE; rec.dbLen = (int) tLen;
+            rec.alnLen = alnLen; rec.reversed = isReverse ? 1 : 0;
+        }
+        rec.accepted = accepted ? 1 : 0;
+        if (laneId() == 0) {
+            a.out[h] = rec;
+            a.accept[h] = accepted ? 1u : 0u;
+            accLocal += accepted ? 1 : 0;
+        }
+    }
+    if (laneId() == 0) {
+        if (accLocal) atomicAdd(&a.stats[0], accLocal);
+        if (ovLocal) atomicAdd(&a.stats[1], ovLocal);
+    }
+}
+
+__global__ void compactAlnKernel(const AlnRec *__restrict__ in, const uint32_t *__restrict__ accept,
+                                 const uint64_t *__restrict__ pos, AlnRec *__restrict__ out, uint64_t n) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
+        if (accept[i]) out[pos[i]] = in[i];
+}
+__global__ void gatherOffsetsKernel(const uint64_t *__restrict__ candQoff, const uint64_t *__restrict__ pos,
+                                    uint64_t *__restrict__ alnQoff, uint64_t nQ) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i <= nQ; i += (uint64_t) gridDim.x * blockDim.x)
+        alnQoff[i] = pos[candQoff[i]];
+}
+__global__ void markLengthsKernel(const uint32_t *__restrict__ len, uint32_t n, uint32_t *__restrict__ present, uint32_t cap) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        uint32_t l = len[i];
+        if (l < cap) present[l] = 1;
+    }
+}
+
+}  // namespace plasship
+using namespace plasship;
+
+extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, const plasship_seqdb *tdb,
+                                const plasship_cands *c, const plasship_rescore_params *par, plasship_alns **out,
+                                plasship_rescore_stats *stats) {
+    if (!ctx || !qdb || !tdb || !c || !par || !out) { setError("plasship_rescore: bad argument"); return PLASSHIP_ERR_ARG; }
+    if (par->rescore_mode != 3) { setError("plasship_rescore: only --rescore-mode 3 (end-to-end) runs on the GPU path"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (c->nQueries != qdb->n) { setError("plasship_rescore: candidate list does not belong to the query DB"); return PLASSHIP_ERR_ARG; }
+    if (qdb->dbtype != tdb->dbtype) { setError("plasship_rescore: query and target DB types differ"); return PLASSHIP_ERR_ARG; }
+    PH_CHECK(hipSetDevice(ctx->device));
+    const bool nucl = qdb->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES;
+    const uint64_t nHits = c->nHits;
+    const uint32_t maxQLen = qdb->maxEntryLen >= 2 ? qdb->maxEntryLen - 2 : 0;
+
+    // E-value gate table: which query lengths exist (device) -> min passing score per length (host, exact doubles)
+    DevBuf dPresent, dMinScore, dMat, dStats;
+    const uint32_t tabLen = maxQLen + 1;
+    if (dPresent.alloc((size_t) tabLen * 4) != hipSuccess || dMinScore.alloc((size_t) tabLen * 4) != hipSuccess ||
+        dMat.alloc(123 * 123) != hipSuccess || dStats.alloc(16) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dPresent.p, 0, (size_t) tabLen * 4, ctx->stream));
+    PH_CHECK(hipMemsetAsync(dStats.p, 0, 16, ctx->stream));
+    if (qdb->n) hipLaunchKernelGGL(markLengthsKernel, dim3(std::min<size_t>(4096, (qdb->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                                   qdb->d_len.as<uint32_t>(), (uint32_t) qdb->n, dPresent.as<uint32_t>(), tabLen);
+    std::vector<uint32_t> present(tabLen), minScore(tabLen, 0xFFFFFFFFu);
+    PH_CHECK(hipMemcpyAsync(present.data(), dPresent.p, (size_t) tabLen * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    HostEvaluer ev(nucl, tdb->residues);
+    {
+        // max raw score of an overlap of length L: max matrix entry (11 for BLOSUM62 W-W, 2 for nucl) * L
+        const int maxEntry = nucl ? 2 : 11;
+        for (uint32_t l = 1; l < tabLen; l++)
+            if (present[l]) minScore[l] = (uint32_t) ev.minScoreForEvalue(par->eval_thr, (int) l, maxEntry * (int) l + 1);
+    }
+    PH_CHECK(hipMemcpyAsync(dMinScore.p, minScore.data(), (size_t) tabLen * 4, hipMemcpyHostToDevice, ctx->stream));
+    PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(nucl), 123 * 123, hipMemcpyHostToDevice, ctx->stream));
+
+    DevBuf dAll, dAccept, dPos, dTmp;
+    const size_t tmpBytes = exclusiveScanTmpBytes(nHits);
+    if (dAll.alloc(std::max<uint64_t>(nHits, 1) * sizeof(AlnRec)) != hipSuccess || dAccept.alloc(std::max<uint64_t>(nHits, 1) * 4) != hipSuccess ||
+        dPos.alloc((nHits + 1) * 8) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+
+    RescoreArgs a;
+    a.q = qdb->view(); a.t = tdb->view(); a.qoff = c->d_qoff.as<uint64_t>(); a.hits = c->d_hits.as<CandHit>(); a.nHits = nHits;
+    a.out = dAll.as<AlnRec>(); a.accept = dAccept.as<uint32_t>(); a.minScore = dMinScore.as<uint32_t>(); a.minScoreLen = tabLen;
+    a.mat = dMat.as<signed char>(); a.sameDB = (qdb == tdb); a.includeIdentity = par->include_identity; a.reverseCapable = c->reverseCapable;
+    a.covMode = par->cov_mode; a.covThr = par->cov_thr; a.seqIdThr = par->seq_id_thr; a.alnLenThr = par->min_aln_len; a.seqIdMode = par->seq_id_mode;
+    a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.stats = dStats.as<unsigned long long>();
+    const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 3) / 4 + 1, (uint64_t) ctx->numCU * 32);
+    PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
+    hipLaunchKernelGGL(rescoreKernel, dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
+    if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), nHits, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t nAcc = 0;
+    PH_CHECK(hipMemcpyAsync(&nAcc, dPos.as<uint64_t>() + nHits, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+
+    plasship_alns *al = new plasship_alns();
+    al->nQueries = qdb->n; al->nLines = nAcc; al->nucl = nucl; al->addBacktrace = par->add_backtrace != 0; al->dbResidues = tdb->residues;
+    if (al->d_qoff.alloc((qdb->n + 1) * 8) != hipSuccess || al->d_recs.alloc(std::max<uint64_t>(nAcc, 1) * sizeof(AlnRec)) != hipSuccess) {
+        delete al; setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    if (nHits) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((nHits + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
+                                  dAll.as<AlnRec>(), dAccept.as<uint32_t>(), dPos.as<uint64_t>(), al->d_recs.as<AlnRec>(), nHits);
+    hipLaunchKernelGGL(gatherOffsetsKernel, dim3((unsigned) std::min<uint64_t>((qdb->n + 256) / 256, 65535)), dim3(256), 0, ctx->stream,
+                       c->d_qoff.as<uint64_t>(), dPos.as<uint64_t>(), al->d_qoff.as<uint64_t>(), (uint64_t) qdb->n);
+    unsigned long long hs[2] = {0, 0};
+    PH_CHECK(hipMemcpyAsync(hs, dStats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(hipGetLastError());
+    al->qdb = qdb; al->tdb = tdb;
+    if (stats) {
+        stats->n_scored = nHits; stats->n_accepted = nAcc; stats->overlap_residues = hs[1];
+        float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
+    }
+    *out = al;
+    return PLASSHIP_OK;
+}

@@ -1,0 +1,78 @@
+#!/bin/bash
+# GENERATION-TIME ONLY (build container). Produces the golden fixtures in this directory by running
+# the UNMODIFIED reference binaries step by step and canonicalising every DB (key order).
+#
+# The reference binaries come from the survey-time out-of-tree build:
+#   cmake -DCMAKE_BUILD_TYPE=Release -DCMAKE_POLICY_VERSION_MINIMUM=3.5 -DHAVE_MPI=0 \
+#         -DHAVE_TESTS=0 -DVERSION_OVERRIDE=survey /root/reference && make -j8 plass penguin
+# (REF_BUILD, default /tmp/plass-build).  The reference cannot be rebuilt with a plain g++ recipe
+# (Parameters.cpp needs cmake-generated headers), so there is no oracle/_ref; these fixtures are the pin.
+# Fixtures are DATA: inputs are the reference's bundled example reads turned into DBs by the
+# reference's own (out-of-scope) preprocessing; expected outputs are what its hot modules wrote.
+set -euo pipefail
+HERE=$(cd "$(dirname "$0")" && pwd)
+REPO=$(cd "$HERE/../.." && pwd)
+B=${REF_BUILD:-/tmp/plass-build}
+PLASS=$B/src/plass; PENGUIN=$B/src/penguin
+EX=/root/reference/examples
+W=$(mktemp -d /tmp/golden.XXXXXX)
+CANON="python3 $REPO/tools/dbcanon.py"
+Q="--threads 4 -v 1"
+
+# ---------- protein example (config C1): preprocessing by the reference, then step-level modules ----
+$PLASS assemble $EX/reads_1.fastq.gz $EX/reads_2.fastq.gz $W/out.fas $W/tmp --num-iterations 1 \
+       --remove-tmp-files 0 --delete-tmp-inc 0 $Q > $W/aa.log
+T=$(ls -d $W/tmp/[0-9]*/)
+S=$W/aa; mkdir -p $S
+$CANON ${T}aa_6f_start_long $S/seq_0
+KM="--alph-size 13 --kmer-per-seq 60 --kmer-per-seq-scale nucl:0.200,aa:0.000 -k 14 -c 0 --cov-mode 0 --ignore-multi-kmer 1 --max-seq-len 65535"
+RS="--rescore-mode 3 -e 1e-05 -c 0 -a 0 --cov-mode 0 --min-seq-id 0.9 --min-aln-len 0 --seq-id-mode 0 --sort-results 0"
+AS="--min-seq-id 0.9 --max-seq-len 65535 --keep-target 1 --rescore-mode 3"
+for i in 0 1 2; do
+  if [ $i -eq 0 ]; then HS=67; EXT=0; else HS=68; EXT=1; fi
+  $PLASS kmermatcher $S/seq_$i $W/p $KM --hash-shift $HS --include-only-extendable $EXT $Q >> $W/aa.log
+  $PLASS rescorediagonal $S/seq_$i $S/seq_$i $W/p $W/a $RS $Q >> $W/aa.log
+  $PLASS assembleresults $S/seq_$i $W/a $W/s $AS $Q >> $W/aa.log
+  $CANON $W/p $S/pref_$i; $CANON $W/a $S/aln_$i; $CANON $W/s $S/seq_$((i+1))
+  rm -f $W/p* $W/a.* $W/a $W/a_* $W/s $W/s.* 2>/dev/null || true
+done
+# variants: -a 1 backtrace, --rescore-mode 2 (local), --keep-target 0
+$PLASS kmermatcher $S/seq_0 $W/p $KM --hash-shift 67 --include-only-extendable 0 $Q >> $W/aa.log
+$PLASS rescorediagonal $S/seq_0 $S/seq_0 $W/p $W/a --rescore-mode 2 -e 1e-05 -c 0 -a 1 --cov-mode 0 --min-seq-id 0.9 $Q >> $W/aa.log
+$CANON $W/a $S/aln_0_mode2_bt
+$PLASS assembleresults $S/seq_0 $S/aln_0 $W/s --min-seq-id 0.9 --max-seq-len 65535 --keep-target 0 --rescore-mode 3 $Q >> $W/aa.log
+$CANON $W/s $S/seq_1_keeptarget0
+rm -f $W/p* $W/a.* $W/a $W/s $W/s.*
+cat > $S/MANIFEST <<M
+protein example: seq_0 = aa_6f_start_long of 'plass assemble examples/reads_{1,2}.fastq.gz'
+iteration i: kmermatcher seq_i -> pref_i [$KM --hash-shift 67|68|68 --include-only-extendable 0|1|1]
+             rescorediagonal seq_i seq_i pref_i -> aln_i [$RS]
+             assembleresults seq_i aln_i -> seq_{i+1} [$AS]
+aln_0_mode2_bt: rescorediagonal --rescore-mode 2 -a 1 on pref_0; seq_1_keeptarget0: assembleresults --keep-target 0
+M
+tar -C $W -czf $HERE/example_aa.tar.gz aa
+
+# ---------- nucleotide example (penguin nuclassemble stage, config C5's nucleotide path) -----------
+$PENGUIN nuclassemble $EX/reads_1.fastq.gz $EX/reads_2.fastq.gz $W/outn.fas $W/tmpn --num-iterations 1 \
+       --remove-tmp-files 0 --delete-tmp-inc 0 $Q > $W/nucl.log
+T=$(ls -d $W/tmpn/[0-9]*/)
+S=$W/nucl; mkdir -p $S
+$CANON ${T}nucl_reads $S/seq_0
+KM="--alph-size 5 --kmer-per-seq 60 --kmer-per-seq-scale 0.100 -k 22 -c 0 --cov-mode 0 --ignore-multi-kmer 1 --max-seq-len 200000 --hash-shift 67 --include-only-extendable 1"
+RS="--rescore-mode 3 -e 1e-05 -c 0 -a 0 --cov-mode 0 --min-seq-id 0.99 --min-aln-len 0 --seq-id-mode 0 --sort-results 0"
+AS="--min-seq-id 0.99 --max-seq-len 200000 --keep-target 1 --rescore-mode 3"
+for i in 0 1; do
+  $PENGUIN kmermatcher $S/seq_$i $W/p $KM $Q >> $W/nucl.log
+  $PENGUIN rescorediagonal $S/seq_$i $S/seq_$i $W/p $W/a $RS $Q >> $W/nucl.log
+  $PENGUIN nuclassembleresults $S/seq_$i $W/a $W/s $AS $Q >> $W/nucl.log
+  $CANON $W/p $S/pref_$i; $CANON $W/a $S/aln_$i; $CANON $W/s $S/seq_$((i+1))
+  rm -f $W/p* $W/a.* $W/a $W/s $W/s.* 2>/dev/null || true
+done
+cat > $S/MANIFEST <<M
+nucleotide example: seq_0 = nucl_reads of 'penguin nuclassemble examples/reads_{1,2}.fastq.gz'
+iteration i: kmermatcher seq_i -> pref_i [$KM]; rescorediagonal -> aln_i [$RS]; nuclassembleresults -> seq_{i+1} [$AS]
+(no cyclecheck between iterations: out of scope, SURVEY.md §2)
+M
+tar -C $W -czf $HERE/example_nucl.tar.gz nucl
+ls -la $HERE/*.tar.gz
+rm -rf $W
