@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py — candidate read-overlaps per second per assembly iteration on MI355X (BASELINE.json metric).
+
+A "step" is one assembly iteration of the hot path — kmermatcher -> rescorediagonal -> assembleresults — over
+the synthetic protein-fragment DB of BASELINE.json configs[1] (1 M synthetic 2x150 bp protein-coding reads,
+500 k pairs, ~1.6 M protein fragments), chained on the device like `plass assemble --num-iterations K`
+(iteration 0: --hash-shift 67 --include-only-extendable 0; later: 68,68,69,… and 1; src/workflow/Assembler.cpp:99-110).
+The input DB is resident in HBM before the timed region; W warm-up iterations (iteration 0 on the same DB,
+results discarded) run first.  value = sum over the K timed iterations of the candidate overlaps kmermatcher
+emitted (non-self prefilter lines) / wall time, max over ranks, summed over ranks.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): every rank assembles its own partition of the
+community (independent genomes, seed = rank) — weak scaling, no data-path collective (multi-GPU).
+
+Also reported on the same JSON line:
+  roofline     — dominant kernel of the timed run: algorithmic bytes / its HIP-event time
+  cpu_baseline — the CPU oracle (a single-threaded port of the reference algorithm, oracle/) timed on a bounded
+                 sample of the same workload on this host (rank 0, N=1 only)
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def hash_shift(it):
+    hs = 67
+    for i in range(it + 1):
+        hs += i % 2
+    return hs
+
+
+def load_workload(pairs, seed):
+    import numpy as np
+    from plass_amd import synth
+    cache = os.path.join(tempfile.gettempdir(), "plasship_bench_cache")
+    os.makedirs(cache, exist_ok=True)
+    f = os.path.join(cache, "frag_p%d_s%d.npz" % (pairs, seed))
+    if os.path.exists(f):
+        z = np.load(f)
+        return z["data"].tobytes(), z["off"], z["elen"], z["key"]
+    data, off, elen, key = synth.protein_fragment_db(pairs, seed=seed)
+    try:
+        np.savez(f, data=np.frombuffer(data, dtype=np.uint8), off=off, elen=elen, key=key)
+    except OSError:
+        pass
+    return data, off, elen, key
+
+
+def one_iteration(ctx, db, it):
+    import plass_amd
+    par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=hash_shift(it),
+                                    include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
+    cands, kst = ctx.kmermatcher(db, par)
+    alns, rst = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5))
+    out, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
+    alns.free(); cands.free()
+    return out, kst, rst, ast
+
+
+def stage_table(kst, rst, ast):
+    """per stage: (HIP-event ms, algorithmic bytes per SURVEY.md §8d)"""
+    s = kst.record_bytes
+    R, Nk, Nm, Nc = kst.residues, kst.n_kmer_records, kst.n_grouped, kst.n_candidates
+    return {
+        "extract_kernel": (kst.ms_extract_kernel, R + s * Nk),
+        "hash_partition": (kst.ms_sort1, 2 * s * Nk),
+        "group_kernel": (kst.ms_group, s * Nk + s * Nm),
+        "rep_sort": (kst.ms_sort2, 2 * s * Nm),
+        "run_reduce": (kst.ms_reduce, s * Nm + 12 * Nc),
+        "rescore_kernel": (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored),
+        "assemble_kernel": (ast.ms_assemble_kernel, 32 * ast.n_alignments + 2 * R + 2 * ast.rescored_residues),
+    }
+
+
+def cpu_baseline(sample_pairs, iters):
+    """the CPU oracle (port, 1 thread) on a bounded sample of the same workload; module compute time only"""
+    import __graft_entry__ as g
+    from plass_amd import synth
+    if not os.path.exists(g.oracle_bin()):
+        subprocess.check_call(["make", "-j", "4"], cwd=os.path.join(ROOT, "oracle"))
+    data, off, elen, key = synth.protein_fragment_db(sample_pairs, seed=101)
+    tot_t, tot_c = 0.0, 0
+    with tempfile.TemporaryDirectory() as td:
+        synth.write_db(os.path.join(td, "seq_0"), data, off, elen, key, 0)
+        for it in range(iters):
+            s, p, a, o = (os.path.join(td, x) for x in ("seq_%d" % it, "pref", "aln", "seq_%d" % (it + 1)))
+            e1 = g.run_oracle(["kmermatcher", s, p, "--alph-size", "13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "0", "-k", "14", "-c", "0",
+                               "--hash-shift", str(hash_shift(it)), "--include-only-extendable", "1" if it else "0", "--ignore-multi-kmer", "1"])
+            e2 = g.run_oracle(["rescorediagonal", s, s, p, a, "--min-seq-id", "0.9", "-e", "1e-5", "-c", "0"])
+            e3 = g.run_oracle(["assembleresults", s, a, o, "--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1"])
+            tot_c += int(re.search(r"N_c=(\d+)", e1).group(1))
+            for e in (e1, e2, e3):
+                tot_t += float(re.search(r"([0-9.]+) s\s*$", e.strip()).group(1))
+    return {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": 1, "kind": "port",
+            "sample": "%d read pairs (%d protein fragments), %d iterations, oracle module compute time (no DB I/O), 1 thread"
+                      % (sample_pairs, len(key), iters)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=500000, help="read pairs per GPU (500000 = 1 M reads, BASELINE configs[1])")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=40000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import plass_amd
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+
+    data, off, elen, key = load_workload(args.pairs, seed=1 + rank)
+    ctx = plass_amd.Context(local)
+    db0 = ctx.upload_seqdb(data, off, elen, key, 0)
+    n_frag = len(key)
+
+    def barrier():
+        ctx.sync(); torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out, _, _, _ = one_iteration(ctx, db0, 0)
+        out.free()
+    barrier()
+    t0 = time.perf_counter()
+    db = db0
+    stats = []
+    overlaps = 0
+    for it in range(args.steps):
+        out, kst, rst, ast = one_iteration(ctx, db, it)
+        overlaps += kst.n_candidates
+        stats.append(stage_table(kst, rst, ast))
+        if db is not db0:
+            db.free()
+        db = out
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        oc = torch.tensor([overlaps], dtype=torch.int64, device="cuda")
+        dist.all_reduce(oc, op=dist.ReduceOp.SUM)
+        overlaps = int(oc.item())
+
+    if rank == 0:
+        # dominant kernel over the timed iterations (rank 0's HIP-event times)
+        tot = {}
+        for st in stats:
+            for k, (ms, b) in st.items():
+                a = tot.setdefault(k, [0.0, 0])
+                a[0] += ms; a[1] += b
+        dom = max(tot, key=lambda k: tot[k][0])
+        ms_avg = tot[dom][0] / len(stats)
+        bytes_avg = tot[dom][1] / len(stats)
+        achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
+        line = {
+            "metric": "read-overlaps/s per assembly iteration", "value": overlaps / elapsed, "unit": "overlaps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 (integer hash, byte compare; f32 ratios)",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d synthetic 2x150 bp protein-coding reads per GPU (%d read pairs, %d protein fragments), "
+                                   "--num-iterations %d, k=14, alph 13, kmer-per-seq 60, min-seq-id 0.9, e 1e-5" % (2 * args.pairs, args.pairs, n_frag, args.steps),
+                       "parallelism": "1 process per GPU, independent partitions" if world > 1 else "1 GPU",
+                       "candidate_overlaps": overlaps},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg,
+                         "stage_ms_per_step": {k: v[0] / len(stats) for k, v in tot.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_pairs, min(args.steps, 3))
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -86,7 +86,9 @@ typedef struct plasship_kmermatch_stats {
     uint64_t n_grouped;        /* N_m: records after assignGroup                                 */
     uint64_t n_candidates;     /* N_c: non-self prefilter lines                                  */
     uint32_t record_bytes;     /* 16 (T=short) or 20 (T=int) in the reference layout             */
-    float ms_extract, ms_sort1, ms_group, ms_sort2, ms_reduce; /* HIP-event kernel times         */
+    float ms_extract, ms_sort1, ms_group, ms_sort2, ms_reduce; /* HIP-event stage times (incl. scans)  */
+    float ms_extract_kernel;   /* the extraction kernel launch alone (HIP events on the ctx stream)  */
+    uint64_t residues;         /* R: residues read by the extraction                              */
 } plasship_kmermatch_stats;
 
 int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par,
@@ -158,7 +160,10 @@ typedef struct plasship_assemble_stats {
     uint64_t n_extended;        /* queries that became (longer) contigs                          */
     uint64_t n_rescored;        /* deferred hits re-scored on an extended query (A4)             */
     uint64_t out_residues;
-    float ms_kernel;
+    float ms_kernel;            /* whole stage (arena sizing .. output DB)                          */
+    float ms_assemble_kernel;   /* the per-query extension kernel alone                              */
+    uint64_t n_alignments;      /* alignment lines consumed                                          */
+    uint64_t rescored_residues; /* overlap residues re-scored                                        */
 } plasship_assemble_stats;
 
 int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *a,

@@ -23,7 +23,8 @@ class _KmermatchParams(C.Structure):
 class KmermatchStats(C.Structure):
     _fields_ = [("n_kmer_records", C.c_uint64), ("n_grouped", C.c_uint64), ("n_candidates", C.c_uint64),
                 ("record_bytes", C.c_uint32), ("ms_extract", C.c_float), ("ms_sort1", C.c_float),
-                ("ms_group", C.c_float), ("ms_sort2", C.c_float), ("ms_reduce", C.c_float)]
+                ("ms_group", C.c_float), ("ms_sort2", C.c_float), ("ms_reduce", C.c_float), ("ms_extract_kernel", C.c_float),
+                ("residues", C.c_uint64)]
 
 
 class _RescoreParams(C.Structure):
@@ -41,7 +42,8 @@ class _AssembleParams(C.Structure):
 
 
 class AssembleStats(C.Structure):
-    _fields_ = [("n_extended", C.c_uint64), ("n_rescored", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float)]
+    _fields_ = [("n_extended", C.c_uint64), ("n_rescored", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float),
+                ("ms_assemble_kernel", C.c_float), ("n_alignments", C.c_uint64), ("rescored_residues", C.c_uint64)]
 
 
 class AlnRecord(C.Structure):

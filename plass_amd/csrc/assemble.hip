@@ -45,7 +45,7 @@ struct AsmArgs {
     const signed char *mat;
     double lambda, logK, ln2;
     float seqIdThr; uint64_t maxSeqLen; int rescoreMode;
-    unsigned long long *stats;                  // [0] extended, [1] rescored
+    unsigned long long *stats;                  // [0] extended, [1] rescored hits, [2] rescored overlap residues
 };
 
 // text round trip of seqId (Util.cpp:278-307 + strtod in Matcher.cpp:265)
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void assembleKernel(AsmArgs a) {
     for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
     __syncthreads();
     const int lane = threadIdx.x;
-    unsigned long long nExt = 0, nResc = 0;
+    unsigned long long nExt = 0, nResc = 0, nRescRes = 0;
     for (uint32_t id = blockIdx.x; id < a.s.n; id += gridDim.x) {
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
         const uint32_t h = (uint32_t) (h1 - h0);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(64) void assembleKernel(AsmArgs a) {
                 const unsigned tLen = a.s.len[x.target];
                 const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
                 const Rescored rs = rescoreOnDiagonal(qs, querySeqLen, tSeq, tLen, diag, smat);
-                nResc++;
+                nResc++; nRescRes += rs.diagonalLen;
                 // updateAlignment
                 const int dist = abs(diag);
                 int qS, qE, dS, dE;
@@ -225,7 +225,7 @@ __global__ __launch_bounds__(64) void assembleKernel(AsmArgs a) {
         }
         __syncthreads();
     }
-    if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); }
+    if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
 }
 
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
@@ -294,12 +294,12 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     const size_t tmpBytes = exclusiveScanTmpBytes((size_t) N + 2);
     if (dLeftCap.alloc(((size_t) N + 1) * 4) != hipSuccess || dBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dArenaOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
         dTmp.alloc(tmpBytes) != hipSuccess || dItems.alloc(std::max<uint64_t>(nLines, 1) * sizeof(Item)) != hipSuccess || dFlags.alloc(((size_t) N + 1) * 4) != hipSuccess ||
-        dNewLen.alloc(((size_t) N + 1) * 4) != hipSuccess || dNewStart.alloc(((size_t) N + 1) * 8) != hipSuccess || dMat.alloc(123 * 123) != hipSuccess || dStats.alloc(16) != hipSuccess) {
+        dNewLen.alloc(((size_t) N + 1) * 4) != hipSuccess || dNewStart.alloc(((size_t) N + 1) * 8) != hipSuccess || dMat.alloc(123 * 123) != hipSuccess || dStats.alloc(32) != hipSuccess) {
         setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync(dFlags.p, 0, ((size_t) N + 1) * 4, st));
     PH_CHECK(hipMemsetAsync(dNewLen.p, 0, ((size_t) N + 1) * 4, st));
-    PH_CHECK(hipMemsetAsync(dStats.p, 0, 16, st));
+    PH_CHECK(hipMemsetAsync(dStats.p, 0, 32, st));
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(false), 123 * 123, hipMemcpyHostToDevice, st));
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
@@ -315,7 +315,9 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
     a.mat = dMat.as<signed char>(); a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.seqIdThr = par->seq_id_thr; a.maxSeqLen = par->max_seq_len; a.rescoreMode = par->rescore_mode;
     a.stats = dStats.as<unsigned long long>();
+    PH_CHECK(hipEventRecord(ctx->ev[2], st));
     if (N) hipLaunchKernelGGL(assembleKernel, dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, a);
+    PH_CHECK(hipEventRecord(ctx->ev[3], st));
     // ---- output DB: extended queries + carried-over sequences, in key order ----
     DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;
     if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
@@ -340,16 +342,18 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
     if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
-    uint32_t maxLen = 0; unsigned long long hs[2] = {0, 0};
+    uint32_t maxLen = 0; unsigned long long hs[4] = {0, 0, 0, 0};
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
     PH_CHECK(hipMemcpyAsync(&maxLen, dMaxLen.p, 4, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipMemcpyAsync(hs, dStats.p, 16, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hs, dStats.p, 32, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
     o->maxEntryLen = maxLen + 2;
     if (stats) {
         stats->n_extended = hs[0]; stats->n_rescored = hs[1]; stats->out_residues = o->residues;
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
+        ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); stats->ms_assemble_kernel = ms;
+        stats->n_alignments = nLines; stats->rescored_residues = hs[2];
     }
     *out = o;
     return PLASSHIP_OK;

@@ -740,7 +740,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     ea.k = k; ea.xCode = map[(int) 'X']; ea.kps = par->kmers_per_seq; ea.ignoreMulti = par->ignore_multi_kmer; ea.scale = par->kmers_per_seq_scale;
     ea.seed = (uint64_t) par->hash_shift; ea.overflowIds = dOvIds.as<uint32_t>(); ea.overflowCount = dOvCnt.as<uint32_t>();
     constexpr int CAP = NUCL ? 1024 : 256;
+    PH_CHECK(hipEventRecord(ctx->ev[2], st));
     if (N) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
+    PH_CHECK(hipEventRecord(ctx->ev[3], st));
     uint32_t nOv = 0;
     PH_CHECK(hipMemcpyAsync(&nOv, dOvCnt.p, 4, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
@@ -933,6 +935,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipGetLastError());
     if (stats) {
         stats->n_kmer_records = Nk; stats->n_grouped = Nm; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
+        { float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); stats->ms_extract_kernel = ms; }
+        stats->residues = db->residues;
         stats->ms_extract = msExtract; stats->ms_sort1 = msSort1; stats->ms_group = msGroup; stats->ms_sort2 = msSort2; stats->ms_reduce = msReduce;
     }
     *out = c;

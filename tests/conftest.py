@@ -1,0 +1,79 @@
+import os
+import subprocess
+import sys
+import tarfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle_bin():
+    """CPU oracle (test infrastructure) — built on demand with plain g++."""
+    p = os.path.join(ROOT, "oracle", "build", "plass_oracle")
+    if not os.path.exists(p) or not os.path.exists(os.path.join(ROOT, "oracle", "build", "liboracle.so")):
+        subprocess.check_call(["make", "-j", "4"], cwd=os.path.join(ROOT, "oracle"))
+    return p
+
+
+@pytest.fixture(scope="session")
+def golden(tmp_path_factory):
+    """golden DBs written by the unmodified reference (tests/golden/make_golden.sh)"""
+    d = tmp_path_factory.mktemp("golden")
+    for name in ("example_aa.tar.gz", "example_nucl.tar.gz"):
+        with tarfile.open(os.path.join(ROOT, "tests", "golden", name)) as t:
+            t.extractall(d)
+    return str(d)
+
+
+def run_oracle(oracle_bin, args):
+    p = subprocess.run([oracle_bin] + [str(a) for a in args], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert p.returncode == 0, p.stderr
+    return p.stderr
+
+
+def read_db(path):
+    path = str(path)
+    if os.path.exists(path):
+        data = open(path, "rb").read()
+    else:
+        data, i = b"", 0
+        while os.path.exists("%s.%d" % (path, i)):
+            data += open("%s.%d" % (path, i), "rb").read()
+            i += 1
+    ent = {}
+    for line in open(path + ".index", "rb"):
+        k, o, l = line.split()[:3]
+        assert int(k) not in ent
+        ent[int(k)] = data[int(o):int(o) + int(l)]
+    dbtype = int.from_bytes(open(path + ".dbtype", "rb").read()[:4], "little")
+    return dbtype, ent
+
+
+def assert_same_db(a, b, what=""):
+    ta, ea = read_db(a)
+    tb, eb = read_db(b)
+    assert ta == tb, "%s: dbtype %d != %d" % (what, ta, tb)
+    assert ea.keys() == eb.keys(), "%s: key sets differ" % what
+    bad = [k for k in ea if ea[k] != eb[k]]
+    assert not bad, "%s: %d entries differ, first key %d:\n%r\n%r" % (what, len(bad), bad[0], ea[bad[0]][:300], eb[bad[0]][:300])
+
+
+AA_KM = ["--alph-size", "13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "nucl:0.200,aa:0.000", "-k", "14", "-c", "0",
+         "--cov-mode", "0", "--ignore-multi-kmer", "1"]
+AA_RS = ["--rescore-mode", "3", "-e", "1e-05", "-c", "0", "-a", "0", "--cov-mode", "0", "--min-seq-id", "0.9"]
+AA_AS = ["--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1", "--rescore-mode", "3"]
+NUCL_KM = ["--alph-size", "5", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "0.100", "-k", "22", "-c", "0", "--cov-mode", "0",
+           "--ignore-multi-kmer", "1", "--hash-shift", "67", "--include-only-extendable", "1"]
+NUCL_RS = ["--rescore-mode", "3", "-e", "1e-05", "-c", "0", "-a", "0", "--cov-mode", "0", "--min-seq-id", "0.99"]
+NUCL_AS = ["--min-seq-id", "0.99", "--max-seq-len", "200000", "--keep-target", "1", "--rescore-mode", "3"]
+
+
+def aa_iter_flags(i):
+    return ["--hash-shift", "67" if i == 0 else "68", "--include-only-extendable", "0" if i == 0 else "1"]

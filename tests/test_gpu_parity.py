@@ -1,0 +1,204 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path through the C-ABI (ctypes binding of
+include/plasship.h) against (a) golden DBs written by the unmodified reference and (b) the CPU oracle on
+seeded synthetic and adversarial inputs.  Everything is bit-exact: DB entries are compared byte for byte."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import (AA_AS, AA_KM, AA_RS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plass_amd
+    c = plass_amd.Context(0)
+    yield c
+    c.close()
+
+
+def km_params(it, nucl=False):
+    import plass_amd
+    if nucl:
+        return plass_amd.KmermatchParams(k=22, alph_size=5, kmer_per_seq=60, kmer_per_seq_scale=0.1, hash_shift=67,
+                                         include_only_extendable=True, ignore_multi_kmer=True, cov_mode=0, c=0.0)
+    return plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=67 if it == 0 else 68,
+                                     include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
+
+
+@pytest.mark.parametrize("it", [0, 1, 2])
+def test_golden_aa_modules(ctx, golden, tmp_path, it):
+    """each module separately, inputs = the reference's DBs, outputs must equal the reference's DBs"""
+    import plass_amd
+    s = os.path.join(golden, "aa")
+    db = ctx.read_seqdb(f"{s}/seq_{it}")
+    cands, st = ctx.kmermatcher(db, km_params(it))
+    cands.write(tmp_path / "pref")
+    assert_same_db(f"{s}/pref_{it}", tmp_path / "pref", "kmermatcher")
+    pref = ctx.read_prefdb(db, db, f"{s}/pref_{it}")
+    alns, _ = ctx.rescorediagonal(db, db, pref, plass_amd.RescoreParams(min_seq_id=0.9))
+    alns.write(tmp_path / "aln")
+    assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "rescorediagonal")
+    aln_in = ctx.read_alndb(db, f"{s}/aln_{it}")
+    out, _ = ctx.assembleresults(db, aln_in, plass_amd.AssembleParams(min_seq_id=0.9))
+    out.write(tmp_path / "seq")
+    assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "assembleresults")
+
+
+def test_golden_aa_chained_on_device(ctx, golden, tmp_path):
+    """three iterations without touching disk in between: the contigs must equal the reference's"""
+    import plass_amd
+    s = os.path.join(golden, "aa")
+    db = ctx.read_seqdb(f"{s}/seq_0")
+    for it in range(3):
+        cands, _ = ctx.kmermatcher(db, km_params(it))
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+        db2, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9))
+        db2.write(tmp_path / f"seq_{it + 1}")
+        assert_same_db(f"{s}/seq_{it + 1}", tmp_path / f"seq_{it + 1}", f"chained iteration {it}")
+        alns.free(); cands.free()
+        db = db2
+
+
+def test_golden_aa_keep_target0(ctx, golden, tmp_path):
+    import plass_amd
+    s = os.path.join(golden, "aa")
+    db = ctx.read_seqdb(f"{s}/seq_0")
+    aln_in = ctx.read_alndb(db, f"{s}/aln_0")
+    out, _ = ctx.assembleresults(db, aln_in, plass_amd.AssembleParams(min_seq_id=0.9, keep_target=False))
+    out.write(tmp_path / "seq")
+    assert_same_db(f"{s}/seq_1_keeptarget0", tmp_path / "seq", "keep-target 0")
+
+
+@pytest.mark.parametrize("it", [0, 1])
+def test_golden_nucl_kmermatcher_rescore(ctx, golden, tmp_path, it):
+    import plass_amd
+    s = os.path.join(golden, "nucl")
+    db = ctx.read_seqdb(f"{s}/seq_{it}")
+    cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+    cands.write(tmp_path / "pref")
+    assert_same_db(f"{s}/pref_{it}", tmp_path / "pref", "nucl kmermatcher")
+    alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+    alns.write(tmp_path / "aln")
+    assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "nucl rescorediagonal")
+
+
+def _oracle_iteration(oracle_bin, d, it):
+    run_oracle(oracle_bin, ["kmermatcher", d / f"o_seq_{it}", d / f"o_pref_{it}"] + AA_KM + aa_iter_flags(it))
+    run_oracle(oracle_bin, ["rescorediagonal", d / f"o_seq_{it}", d / f"o_seq_{it}", d / f"o_pref_{it}", d / f"o_aln_{it}"] + AA_RS)
+    run_oracle(oracle_bin, ["assembleresults", d / f"o_seq_{it}", d / f"o_aln_{it}", d / f"o_seq_{it + 1}"] + AA_AS)
+
+
+def test_synthetic_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path):
+    """40 k read pairs (about 130 k protein fragments, 0.3 M candidate overlaps per iteration): every DB of
+    every iteration equals the oracle's"""
+    import plass_amd
+    from plass_amd import synth
+    data, off, elen, key = synth.protein_fragment_db(40000, seed=11)
+    synth.write_db(str(tmp_path / "o_seq_0"), data, off, elen, key, 0)
+    db = ctx.upload_seqdb(data, off, elen, key, 0)
+    for it in range(3):
+        _oracle_iteration(oracle_bin, tmp_path, it)
+        cands, kst = ctx.kmermatcher(db, km_params(it))
+        cands.write(tmp_path / "g_pref")
+        assert_same_db(tmp_path / f"o_pref_{it}", tmp_path / "g_pref", f"kmermatcher it{it}")
+        alns, rst = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+        alns.write(tmp_path / "g_aln")
+        assert_same_db(tmp_path / f"o_aln_{it}", tmp_path / "g_aln", f"rescorediagonal it{it}")
+        db2, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9))
+        db2.write(tmp_path / "g_seq")
+        assert_same_db(tmp_path / f"o_seq_{it + 1}", tmp_path / "g_seq", f"assembleresults it{it}")
+        assert kst.n_candidates > 50000 and rst.n_accepted > kst.n_candidates // 4
+        # size-independent properties
+        i0, i1 = db.info(), db2.info()
+        assert i1["n"] == i0["n"] and i1["residues"] >= i0["residues"]
+        db = db2
+
+
+def _write_fasta_like_db(path, seqs, dbtype=0, keys=None):
+    from plass_amd import synth
+    arrs = [np.frombuffer(s.encode(), dtype=np.uint8) for s in seqs]
+    data, off, elen, key = synth.pack_db(arrs)
+    if keys is not None:
+        key = np.asarray(keys, dtype=np.uint32)
+    synth.write_db(str(path), data, off, elen, key, dbtype)
+    return data, off, elen, key
+
+
+def test_adversarial_inputs_vs_oracle(ctx, oracle_bin, tmp_path):
+    """ragged and hostile inputs: sequences shorter than k, X / '*' residues, low-complexity repeats (repeated
+    k-mers, many ties in the hash threshold bin), exact duplicates, one contig above 32 767 residues (switches the
+    reference to KmerPosition<int>), sparse non-contiguous keys, lower-case letters"""
+    import plass_amd
+    rng = np.random.default_rng(5)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    base = "".join(rng.choice(list(aa), size=4000))
+    seqs = []
+    for i in range(400):
+        p = int(rng.integers(0, 3900)); l = int(rng.integers(40, 100))
+        seqs.append(base[p:p + l])
+    seqs += ["MKV", "A" * 13, "A" * 14, "A" * 200, "AS" * 120, "MKVLAAGX" * 10, "XXXXXXXXXXXXXXXXXXXXXXXX", base[100:180] + "*", base[100:180] + "*",
+             base[1000:1100].lower(), base[1000:1100], "*" + base[2000:2060], base[500:2500]]
+    long_contig = "".join(rng.choice(list(aa), size=33000))
+    seqs += [long_contig, long_contig[32000:] + base[:60], base[3000:3050] + long_contig[:70]]
+    keys = np.cumsum(rng.integers(1, 4, size=len(seqs))).astype(np.uint32)
+    perm = rng.permutation(len(seqs))                       # index file order != key order
+    _write_fasta_like_db(tmp_path / "seq", [seqs[i] for i in perm], 0, keys[perm])
+    db = ctx.read_seqdb(tmp_path / "seq")
+    assert db.info()["max_entry_len"] >= 32767
+    for it, ext in ((0, False), (1, True)):
+        flags = ["--hash-shift", "67", "--include-only-extendable", "1" if ext else "0"]
+        run_oracle(oracle_bin, ["kmermatcher", tmp_path / "seq", tmp_path / f"o_pref{it}"] + AA_KM + flags)
+        par = km_params(0); par.include_only_extendable = ext
+        cands, _ = ctx.kmermatcher(db, par)
+        cands.write(tmp_path / f"g_pref{it}")
+        assert_same_db(tmp_path / f"o_pref{it}", tmp_path / f"g_pref{it}", f"adversarial kmermatcher ext={ext}")
+        run_oracle(oracle_bin, ["rescorediagonal", tmp_path / "seq", tmp_path / "seq", tmp_path / f"o_pref{it}", tmp_path / f"o_aln{it}"] + AA_RS)
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+        alns.write(tmp_path / f"g_aln{it}")
+        assert_same_db(tmp_path / f"o_aln{it}", tmp_path / f"g_aln{it}", "adversarial rescorediagonal")
+        run_oracle(oracle_bin, ["assembleresults", tmp_path / "seq", tmp_path / f"o_aln{it}", tmp_path / f"o_seq{it}"] + AA_AS)
+        out, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9))
+        out.write(tmp_path / f"g_seq{it}")
+        assert_same_db(tmp_path / f"o_seq{it}", tmp_path / f"g_seq{it}", "adversarial assembleresults")
+
+
+def test_empty_and_singleton_db(ctx, oracle_bin, tmp_path):
+    import plass_amd
+    _write_fasta_like_db(tmp_path / "one", ["MKVLAAGIVGLLLAQPSWAETGEKSLYELDRSSAKNRLIMGAVGYL"], 0)
+    db = ctx.read_seqdb(tmp_path / "one")
+    cands, st = ctx.kmermatcher(db, km_params(0))
+    assert st.n_candidates == 0
+    cands.write(tmp_path / "g_pref")
+    run_oracle(oracle_bin, ["kmermatcher", tmp_path / "one", tmp_path / "o_pref"] + AA_KM + aa_iter_flags(0))
+    assert_same_db(tmp_path / "o_pref", tmp_path / "g_pref", "singleton")
+    alns, _ = ctx.rescorediagonal(db, db, cands)
+    out, ast = ctx.assembleresults(db, alns)
+    assert ast.n_extended == 0 and out.info()["n"] == 1
+
+
+def test_order_invariance_and_idempotence(ctx, tmp_path):
+    """property at a size the oracle is not run on (0.4 M fragments): results do not depend on the order of the
+    input index, and running a module twice gives identical bytes"""
+    import plass_amd
+    from plass_amd import synth
+    data, off, elen, key = synth.protein_fragment_db(125000, seed=21)
+    db = ctx.upload_seqdb(data, off, elen, key, 0)
+    rng = np.random.default_rng(1)
+    p = rng.permutation(len(key))
+    db_shuffled = ctx.upload_seqdb(data, off[p], elen[p], key[p], 0)
+    outs = []
+    for d in (db, db, db_shuffled):
+        cands, kst = ctx.kmermatcher(d, km_params(0))
+        alns, rst = ctx.rescorediagonal(d, d, cands)
+        o, ast = ctx.assembleresults(d, alns)
+        q, t, s, dg = cands.download()
+        outs.append((q.tobytes(), t.tobytes(), s.tobytes(), dg.tobytes(), o.download()[0], kst.n_candidates, rst.n_accepted, ast.n_extended))
+        # structural properties: hits sorted by (query, target), no self hits in the list, every accepted line within bounds
+        assert np.all((q[1:] > q[:-1]) | ((q[1:] == q[:-1]) & (t[1:] > t[:-1]))) and not np.any(q == t)
+        assert rst.n_accepted >= len(key) and ast.n_extended > 0
+        o.free(); alns.free(); cands.free()
+    assert outs[0] == outs[1], "same input, different output"
+    assert outs[0] == outs[2], "output depends on input index order"

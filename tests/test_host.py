@@ -1,0 +1,65 @@
+"""Host-side checks that need no GPU: the C-ABI library exports what include/plasship.h declares, fails loudly
+without a device, and the synthetic generator is deterministic."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "plasship.h")).read()
+    return sorted(set(re.findall(r"\b(plasship_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol():
+    import plass_amd
+    from plass_amd import _lib
+    if not os.path.exists(plass_amd.lib_path()):
+        import __graft_entry__ as g
+        g.build()
+    lib = plass_amd.load_library()
+    declared = _declared_symbols()
+    assert len(declared) >= 24
+    bound = {s[0] for s in _lib.SYMBOLS}
+    for name in declared:
+        assert hasattr(lib, name), "missing export " + name
+        assert name in bound, "python binding does not cover " + name
+    assert lib.plasship_version().startswith(b"plasship")
+
+
+def test_no_cpu_fallback():
+    """without a GPU the product must refuse to run (no silent CPU path)"""
+    import plass_amd
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(plass_amd.PlasshipError):
+        plass_amd.Context(0)
+
+
+def test_product_does_not_reference_oracle():
+    """the product tree never includes, links or executes anything under oracle/"""
+    for d, _, files in os.walk(os.path.join(ROOT, "plass_amd")):
+        if "build" in d:
+            continue
+        for f in files:
+            if f.endswith((".hip", ".cpp", ".hpp", ".h", ".py", "Makefile")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                for line in txt.splitlines():
+                    if re.search(r'#include\s+"[^"]*oracle|^\s*(import|from)\s+oracle\b|oracle/build|liboracle|plass_oracle', line):
+                        raise AssertionError("%s references the oracle: %s" % (f, line))
+
+
+def test_synth_deterministic():
+    from plass_amd import synth
+    a = synth.protein_fragment_db(300, seed=3)
+    b = synth.protein_fragment_db(300, seed=3)
+    assert a[0] == b[0] and np.array_equal(a[2], b[2])
+    data, off, elen, key = a
+    assert len(key) > 300 and (elen - 2).min() >= 45 and (elen - 2).max() <= 50
+    for o, l in zip(off[:50], elen[:50]):
+        e = data[int(o):int(o) + int(l)]
+        assert e.endswith(b"\n\x00") and b"*" not in e[:-3]

@@ -1,0 +1,67 @@
+"""The CPU oracle against everything the reference wrote for this path (golden vectors) — runs without a GPU.
+Golden DBs: tests/golden/*.tar.gz, produced by the unmodified reference binaries (tests/golden/make_golden.sh)."""
+import ctypes as C
+import os
+
+import pytest
+
+from conftest import (AA_AS, AA_KM, AA_RS, NUCL_AS, NUCL_KM, NUCL_RS, ROOT, aa_iter_flags, assert_same_db, run_oracle)
+
+
+@pytest.mark.parametrize("it", [0, 1, 2])
+def test_oracle_aa_iteration(oracle_bin, golden, tmp_path, it):
+    s = os.path.join(golden, "aa")
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/seq_{it}", tmp_path / "pref"] + AA_KM + aa_iter_flags(it))
+    assert_same_db(f"{s}/pref_{it}", tmp_path / "pref", "kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/seq_{it}", f"{s}/seq_{it}", f"{s}/pref_{it}", tmp_path / "aln"] + AA_RS)
+    assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "rescorediagonal")
+    run_oracle(oracle_bin, ["assembleresults", f"{s}/seq_{it}", f"{s}/aln_{it}", tmp_path / "seq"] + AA_AS)
+    assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "assembleresults")
+
+
+def test_oracle_aa_variants(oracle_bin, golden, tmp_path):
+    s = os.path.join(golden, "aa")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/seq_0", f"{s}/seq_0", f"{s}/pref_0", tmp_path / "aln", "--rescore-mode", "2", "-e", "1e-05",
+                            "-c", "0", "-a", "1", "--cov-mode", "0", "--min-seq-id", "0.9"])
+    assert_same_db(f"{s}/aln_0_mode2_bt", tmp_path / "aln", "rescore mode 2 + backtrace")
+    run_oracle(oracle_bin, ["assembleresults", f"{s}/seq_0", f"{s}/aln_0", tmp_path / "seq", "--min-seq-id", "0.9", "--max-seq-len", "65535",
+                            "--keep-target", "0", "--rescore-mode", "3"])
+    assert_same_db(f"{s}/seq_1_keeptarget0", tmp_path / "seq", "keep-target 0")
+
+
+@pytest.mark.parametrize("it", [0, 1])
+def test_oracle_nucl_iteration(oracle_bin, golden, tmp_path, it):
+    s = os.path.join(golden, "nucl")
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/seq_{it}", tmp_path / "pref"] + NUCL_KM)
+    assert_same_db(f"{s}/pref_{it}", tmp_path / "pref", "nucl kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/seq_{it}", f"{s}/seq_{it}", f"{s}/pref_{it}", tmp_path / "aln"] + NUCL_RS)
+    assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "nucl rescorediagonal")
+    run_oracle(oracle_bin, ["nuclassembleresults", f"{s}/seq_{it}", f"{s}/aln_{it}", tmp_path / "seq"] + NUCL_AS)
+    assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "nuclassembleresults")
+
+
+def test_oracle_known_answers(oracle_bin):
+    """constants captured from the reference (oracle/ref_tables.h): XXH64, revComplement, bit scores, E-values"""
+    lib = C.CDLL(os.path.join(ROOT, "oracle", "build", "liboracle.so"))
+    lib.oracle_xxh64_u64.restype = C.c_ulonglong; lib.oracle_xxh64_u64.argtypes = [C.c_ulonglong, C.c_ulonglong]
+    lib.oracle_revcomp.restype = C.c_ulonglong; lib.oracle_revcomp.argtypes = [C.c_ulonglong, C.c_int]
+    for f in ("oracle_bitscore", "oracle_raw_from_bit"):
+        getattr(lib, f).restype = C.c_double; getattr(lib, f).argtypes = [C.c_int, C.c_double]
+    lib.oracle_evalue.restype = C.c_double; lib.oracle_evalue.argtypes = [C.c_int, C.c_ulonglong, C.c_double, C.c_double]
+    lib.oracle_kat_xxh64.restype = C.POINTER(C.c_ulonglong); lib.oracle_kat_revcomp.restype = C.POINTER(C.c_ulonglong)
+    lib.oracle_kat_aa.restype = C.POINTER(C.c_double); lib.oracle_kat_nuc.restype = C.POINTER(C.c_double)
+    kx = lib.oracle_kat_xxh64()
+    for i in range(4):
+        assert lib.oracle_xxh64_u64(kx[3 * i], kx[3 * i + 1]) == kx[3 * i + 2]
+    assert lib.oracle_xxh64_u64(12345, 67) == 11599637584503786452
+    kr = lib.oracle_kat_revcomp()
+    for i in range(3):
+        assert lib.oracle_revcomp(kr[3 * i], int(kr[3 * i + 1])) == kr[3 * i + 2]
+    ka, kn = lib.oracle_kat_aa(), lib.oracle_kat_nuc()
+    assert lib.oracle_bitscore(0, 100.0) == ka[0] and lib.oracle_raw_from_bit(0, 100.0) == ka[1]
+    assert lib.oracle_bitscore(1, 100.0) == kn[0] and lib.oracle_raw_from_bit(1, 100.0) == kn[1]
+    # E-values agree with the reference to the printed precision (%.3E) and far beyond
+    for got, want in ((lib.oracle_evalue(0, 1000000, 60, 50), ka[2]), (lib.oracle_evalue(0, 1000000, 37, 48), ka[3]),
+                      (lib.oracle_evalue(0, 1000000, 250, 4000), ka[4]), (lib.oracle_evalue(1, 1000000, 60, 150), kn[2]),
+                      (lib.oracle_evalue(1, 1000000, 100, 150), kn[3])):
+        assert abs(got - want) <= 1e-12 * abs(want)
