@@ -6,9 +6,49 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <numeric>
+#include <unordered_map>
 
 namespace plasship {
+// ---- caching allocator (see common.hpp) -----------------------------------------------------------
+namespace {
+std::mutex g_poolMu;
+std::multimap<size_t, void *> g_poolFree;            // size class -> cached block
+std::unordered_map<void *, size_t> g_poolLive;       // block -> size class
+int g_ctxCount = 0;
+size_t sizeClass(size_t n) {
+    if (n < 4096) return 4096;
+    int e = 63 - __builtin_clzll((unsigned long long) n);      // 2^e <= n
+    const size_t step = (size_t) 1 << (e - 3);                 // eight classes per octave
+    return (n + step - 1) / step * step;
+}
+}  // namespace
+hipError_t poolMalloc(void **p, size_t n) {
+    const size_t c = sizeClass(n);
+    {
+        std::lock_guard<std::mutex> g(g_poolMu);
+        auto it = g_poolFree.find(c);
+        if (it != g_poolFree.end()) { *p = it->second; g_poolFree.erase(it); g_poolLive[*p] = c; return hipSuccess; }
+    }
+    hipError_t e = hipMalloc(p, c);
+    if (e != hipSuccess) { (void) hipGetLastError(); poolTrim(); e = hipMalloc(p, c); }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(g_poolMu); g_poolLive[*p] = c; }
+    return e;
+}
+void poolFree(void *p) {
+    std::lock_guard<std::mutex> g(g_poolMu);
+    auto it = g_poolLive.find(p);
+    if (it == g_poolLive.end()) { (void) hipFree(p); return; }
+    g_poolFree.emplace(it->second, p);
+    g_poolLive.erase(it);
+}
+void poolTrim() {
+    std::lock_guard<std::mutex> g(g_poolMu);
+    for (auto &kv : g_poolFree) (void) hipFree(kv.second);
+    g_poolFree.clear();
+}
 static thread_local std::string g_err;
 void setError(const std::string &msg) { g_err = msg; }
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
@@ -41,6 +81,7 @@ extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
     c->numCU = prop.multiProcessorCount;
     PH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &ev : c->ev) PH_CHECK(hipEventCreate(&ev));
+    { std::lock_guard<std::mutex> g(g_poolMu); g_ctxCount++; }
     *out = c;
     return PLASSHIP_OK;
 }
@@ -51,6 +92,8 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     (void) hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    bool last; { std::lock_guard<std::mutex> g(g_poolMu); last = (--g_ctxCount <= 0); }
+    if (last) poolTrim();
     delete ctx;
 }
 
