@@ -46,6 +46,7 @@ struct AsmArgs {
     double lambda, logK, ln2;
     float seqIdThr; uint64_t maxSeqLen; int rescoreMode;
     unsigned long long *stats;                  // [0] extended, [1] rescored hits, [2] rescored overlap residues
+    uint32_t *bigList; uint32_t *bigCount; uint32_t nBig;   // queries with more than 64 alignments (HBM-resident queue)
 };
 
 // text round trip of seqId (Util.cpp:278-307 + strtod in Matcher.cpp:265)
@@ -86,13 +87,14 @@ __device__ __forceinline__ Rescored rescoreOnDiagonal(const char *q, unsigned qL
     return r;
 }
 
-__global__ __launch_bounds__(64) void assembleKernel(AsmArgs a) {
+__global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
     for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
     __syncthreads();
     const int lane = threadIdx.x;
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0;
-    for (uint32_t id = blockIdx.x; id < a.s.n; id += gridDim.x) {
+    for (uint32_t w = blockIdx.x; w < a.nBig; w += gridDim.x) {
+        const uint32_t id = a.bigList[w];
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
         const uint32_t h = (uint32_t) (h1 - h0);
         if (h == 0) continue;
@@ -228,6 +230,137 @@ __global__ __launch_bounds__(64) void assembleKernel(AsmArgs a) {
     if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
 }
 
+// ---- the common case: at most 64 alignments per query => the whole queue lives in registers, one item per lane;
+//      four independent waves per block share the LDS score table; no block barriers in the loop ----
+__device__ __forceinline__ void waveMemSync() {   // make this wave's global stores visible to its own later loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
+    __shared__ signed char smat[123 * 123 + 7];
+    for (int i = threadIdx.x; i < 123 * 123; i += 256) smat[i] = a.mat[i];
+    __syncthreads();
+    const int lane = laneId();
+    const uint32_t wavesTotal = gridDim.x * 4;
+    unsigned long long nExt = 0, nResc = 0, nRescRes = 0;
+    for (uint32_t id = blockIdx.x * 4 + (threadIdx.x >> 6); id < a.s.n; id += wavesTotal) {
+        const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
+        const uint32_t h = (uint32_t) (h1 - h0);
+        if (h == 0) continue;
+        const uint64_t aoff = a.arenaOff[id];
+        if (a.arenaOff[id + 1] == aoff) continue;          // no non-self hit: can never be extended
+        if (h > 64) { if (lane == 0) { const uint32_t o = atomicAdd(a.bigCount, 1u); a.bigList[o] = id; } continue; }
+        const char *orig = a.s.data + a.s.off[id];
+        unsigned querySeqLen = a.s.len[id];
+        // ---- queue fill (assembleresult.cpp:161-189): lane i owns alignment i ----
+        uint32_t xTarget = 0, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2;
+        int xScore = 0, xQStart = 0, xQEnd = 0, xDbStart = 0, xDbEnd = 0; float xSeqId = 0.0f;
+        if ((uint32_t) lane < h) {
+            const AlnRec r = a.recs[h0 + lane];
+            xTarget = r.target;
+            const int aq = (r.qStart == -1) ? 0 : r.qStart, ad = (r.dbStart == -1) ? 0 : r.dbStart;
+            xAlnLen = (uint32_t) (max(abs(r.qEnd - aq), abs(r.dbEnd - ad)) + 1);
+            const int rawScore = (int) (fma((double) r.bitScore, a.ln2, a.logK) / a.lambda + 0.5);
+            const float scorePerCol = (float) rawScore / (float) ((double) xAlnLen + 0.5);
+            const float sid = r.fromText ? r.seqId : seqIdThroughText(r.seqId);
+            const float alnLen = (float) xAlnLen;
+            const float ids = sid * alnLen;
+            xSeqId = (float) ((double) ids / ((double) alnLen + 0.5));
+            xScore = (int) (scorePerCol * 100);
+            xQStart = r.qStart; xQEnd = r.qEnd; xQLen = (uint32_t) r.qLen; xDbStart = r.dbStart; xDbEnd = r.dbEnd; xDbLen = (uint32_t) r.dbLen;
+            xState = 0;
+        }
+        (void) xSeqId;   // the protein comparator never looks at seqId (only re-scored hits are gated on it)
+        char *buf = a.arena + aoff;
+        uint64_t curStart = a.leftCap[id];
+        for (uint32_t i = lane; i < querySeqLen; i += 64) buf[curStart + i] = orig[i];
+        uint64_t curLen = querySeqLen;
+        bool couldExtend = false;
+        uint32_t inQueue = h;
+        while (inQueue > 0) {
+            unsigned leftOff = 0, rightOff = 0;
+            bool brokeOut = false;
+            if (xState == 1) xState = 2;
+            for (;;) {
+                // ---- selectFragmentToExtend: wave arg-max = priority_queue::top (strict comparator) ----
+                int bs = xScore; uint32_t bl = xAlnLen, bt = xTarget; int bi = (xState == 0) ? lane : -1;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const int os = __shfl_xor(bs, o, 64); const uint32_t ol = __shfl_xor(bl, o, 64), ot = __shfl_xor(bt, o, 64); const int oi = __shfl_xor(bi, o, 64);
+                    const bool better = (oi >= 0) && ((bi < 0) || (os > bs) || (os == bs && (ol > bl || (ol == bl && ot < bt))));
+                    if (better) { bs = os; bl = ol; bt = ot; bi = oi; }
+                }
+                if (bi < 0) { inQueue = 0; break; }
+                if (lane == bi) xState = 2;                         // popped
+                inQueue--;
+                const uint32_t bTarget = bt;
+                const int bQStart = __shfl(xQStart, bi, 64), bQEnd = __shfl(xQEnd, bi, 64), bDbStart = __shfl(xDbStart, bi, 64), bDbEnd = __shfl(xDbEnd, bi, 64);
+                const uint32_t bQLen = __shfl(xQLen, bi, 64), bDbLen = __shfl(xDbLen, bi, 64);
+                const bool notBoth = !(bDbStart == 0 && bQStart == 0);
+                const bool rightStart = bDbStart == 0 && (bDbEnd != (int) bDbLen - 1);
+                const bool leftStart = bQStart == 0 && (bQEnd != (int) bQLen - 1);
+                if (!((rightStart || leftStart) && notBoth && (bTarget != id))) continue;
+                const char *tSeq = a.s.data + a.s.off[bTarget];
+                const unsigned tLen = a.s.len[bTarget];
+                if (bDbStart == 0) { if ((tLen - ((unsigned) bDbEnd + 1)) <= rightOff) continue; }
+                else if (bQStart == 0) { if (bDbStart <= (int) leftOff) continue; }
+                const unsigned dbStart = (unsigned) bDbStart, dbEnd = (unsigned) bDbEnd, qStart = (unsigned) bQStart, qEnd = (unsigned) bQEnd;
+                if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
+                    if (rightOff > 0) { if (lane == bi) xState = 1; continue; }
+                    const unsigned fragLen = tLen - (dbEnd + 1);
+                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + curLen + i] = tSeq[dbEnd + 1 + i];
+                    curLen += fragLen; rightOff += fragLen;
+                    if (lane == 0) atomicOr(&a.flags[bTarget], 0x80u);
+                } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
+                    if (leftOff > 0) { if (lane == bi) xState = 1; continue; }
+                    const unsigned fragLen = dbStart;
+                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    curStart -= fragLen;
+                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + i] = tSeq[i];
+                    curLen += fragLen; leftOff += fragLen;
+                    if (lane == 0) atomicOr(&a.flags[bTarget], 0x80u);
+                }
+            }
+            if (leftOff > 0 || rightOff > 0) couldExtend = true;
+            if (brokeOut && inQueue > 0) break;
+            // ---- re-score deferred hits on the extended query (assembleresult.cpp:288-313) ----
+            querySeqLen = (unsigned) curLen;
+            const char *qs = buf + curStart;
+            unsigned long long deferred = __ballot(xState == 1);
+            if (deferred) waveMemSync();
+            while (deferred) {
+                const int dl = __ffsll((long long) deferred) - 1;
+                deferred &= deferred - 1;
+                const uint32_t tg = __shfl(xTarget, dl, 64);
+                const int dqs = __shfl(xQStart, dl, 64), dds = __shfl(xDbStart, dl, 64);
+                const char *tSeq = a.s.data + a.s.off[tg];
+                const unsigned tLen = a.s.len[tg];
+                const int diag = (int) ((unsigned) dqs + leftOff) - dds;
+                const Rescored rs = rescoreOnDiagonal(qs, querySeqLen, tSeq, tLen, diag, smat);
+                nResc++; nRescRes += rs.diagonalLen;
+                const int dist = abs(diag);
+                int qS, qE, dS, dE;
+                if (diag >= 0) { qS = rs.startPos + dist; qE = rs.endPos + dist; dS = rs.startPos; dE = rs.endPos; }
+                else { qS = rs.startPos; qE = rs.endPos; dS = rs.startPos + dist; dE = rs.endPos + dist; }
+                const float seqId = (float) rs.idExcl / ((float) qE - (float) qS);
+                const float spc = (float) rs.score / (float) ((double) rs.diagonalLen + 0.5);
+                if (lane == dl) {
+                    xSeqId = seqId; xQLen = querySeqLen; xDbLen = tLen; xAlnLen = rs.diagonalLen; xScore = (int) (spc * 100);
+                    xQStart = qS; xQEnd = qE; xDbStart = dS; xDbEnd = dE;
+                    xState = (seqId >= a.seqIdThr) ? 0u : 2u;
+                }
+            }
+            inQueue = (uint32_t) __popcll(__ballot(xState == 0));
+        }
+        if (couldExtend) {
+            if (lane == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; }
+            nExt++;
+        }
+    }
+    if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
+}
+
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
 __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
                                 uint64_t *__restrict__ bytes) {
@@ -315,8 +448,16 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
     a.mat = dMat.as<signed char>(); a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.seqIdThr = par->seq_id_thr; a.maxSeqLen = par->max_seq_len; a.rescoreMode = par->rescore_mode;
     a.stats = dStats.as<unsigned long long>();
+    DevBuf dBigList, dBigCount;
+    if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dBigCount.alloc(4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dBigCount.p, 0, 4, st));
+    a.bigList = dBigList.as<uint32_t>(); a.bigCount = dBigCount.as<uint32_t>(); a.nBig = 0;
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
-    if (N) hipLaunchKernelGGL(assembleKernel, dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, a);
+    if (N) hipLaunchKernelGGL(assembleSmallKernel, dim3(std::min<uint32_t>((N + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
+    uint32_t nBig = 0;
+    PH_CHECK(hipMemcpyAsync(&nBig, dBigCount.p, 4, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    if (nBig) { a.nBig = nBig; hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(nBig, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a); }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     // ---- output DB: extended queries + carried-over sequences, in key order ----
     DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;

@@ -574,55 +574,64 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 }
 
 // =====================================================================================================
-// 5. sort #2: bitonic sort of one rep-range bucket (LDS when it fits, in place in HBM otherwise)
+// 5. sort #2: bitonic sort of one rep-range bucket on PACKED 64-bit keys (LDS; HBM scratch when oversized)
+//    key = [rep - bucketBase | target id | diagonal + bias | strand bit]  — the order of
+//    compareRepSequenceAndIdAndDiag[Reverse] (kmermatcher.h:98-130) with the canonical strand tie-break.
 // =====================================================================================================
 constexpr int LS_BLOCK = 256;
-template <bool NUCL, bool LONG> __device__ __forceinline__ bool recLess2(const Rec<LONG> &x, const Rec<LONG> &y) {   // kmermatcher.h:98-130
-    const uint64_t a = NUCL ? (x.kmer | BIT63) : x.kmer, b = NUCL ? (y.kmer | BIT63) : y.kmer;
-    if (a != b) return a < b;
-    if (x.id != y.id) return x.id < y.id;
-    if (x.pos != y.pos) return x.pos < y.pos;
-    return x.kmer < y.kmer;      // canonical tie-break where the reference comparator ties (strand bit)
-}
+template <bool LONG> struct DiagPack { static constexpr int BITS = LONG ? 22 : 16; static constexpr int64_t BIAS = LONG ? (1 << 21) : 32768; };
 
 template <bool NUCL, bool LONG, int CAPS>
 __global__ __launch_bounds__(LS_BLOCK) void localSortKernel(void *arr, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
-                                                            void *bigScratch, const uint64_t *__restrict__ bigOff) {
+                                                            unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
+                                                            int localBits, int idBits) {
     typedef Rec<LONG> R;
-    __shared__ R s[CAPS];
+    __shared__ unsigned long long s[CAPS];
     R *g = reinterpret_cast<R *>(arr);
+    constexpr int DB = DiagPack<LONG>::BITS;
     for (uint32_t b = blockIdx.x; b < nBuckets; b += gridDim.x) {
         const uint64_t s0 = bucketStart[b], s1 = bucketStart[b + 1];
         const uint64_t cnt = s1 - s0;
         if (cnt <= 1) continue;
         uint64_t P = 1; while (P < cnt) P <<= 1;
-        R *p;
-        if (P <= (uint64_t) CAPS) p = s; else p = reinterpret_cast<R *>(bigScratch) + bigOff[b];
+        unsigned long long *p = (P <= (uint64_t) CAPS) ? s : (bigScratch + bigOff[b]);
+        const uint64_t baseRep = (uint64_t) b << localBits;
         for (uint64_t i = threadIdx.x; i < P; i += LS_BLOCK) {
-            R r;
-            if (i < cnt) r = g[s0 + i]; else memset(&r, 0xFF, sizeof(R));
-            p[i] = r;
+            unsigned long long key = ~0ULL;
+            if (i < cnt) {
+                const R r = g[s0 + i];
+                const uint64_t rep = r.kmer & ~BIT63;
+                key = (((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS)) << 1;
+                key |= NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL;
+            }
+            p[i] = key;
         }
         __syncthreads();
         for (uint64_t kk = 2; kk <= P; kk <<= 1) {
             for (uint64_t j = kk >> 1; j > 0; j >>= 1) {
-                for (uint64_t i = threadIdx.x; i < P; i += LS_BLOCK) {
-                    const uint64_t l = i ^ j;
-                    if (l > i) {
-                        const R x = p[i], y = p[l];
-                        const bool up = (i & kk) == 0;
-                        // padding records (all 0xFF) must sort last: compare raw for them
-                        bool yLess;
-                        if (isSentinel(y)) yLess = false; else if (isSentinel(x)) yLess = true; else yLess = recLess2<NUCL, LONG>(y, x);
-                        bool xLess;
-                        if (isSentinel(x)) xLess = false; else if (isSentinel(y)) xLess = true; else xLess = recLess2<NUCL, LONG>(x, y);
-                        if (up ? yLess : xLess) { p[i] = y; p[l] = x; }
-                    }
+                // each thread handles the compare-exchange pairs (i, i^j) with i < i^j: enumerate them directly
+                for (uint64_t t = threadIdx.x; t < (P >> 1); t += LS_BLOCK) {
+                    const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                    const uint64_t l = i | j;
+                    const unsigned long long x = p[i], y = p[l];
+                    const bool up = (i & kk) == 0;
+                    if ((x > y) == up) { p[i] = y; p[l] = x; }
                 }
                 __syncthreads();
             }
         }
-        for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) g[s0 + i] = p[i];
+        for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) {
+            const unsigned long long key = p[i];
+            R r; memset(&r, 0, sizeof(R));
+            const uint64_t k1 = key >> 1;
+            const int64_t dg = (int64_t) (k1 & ((1ULL << DB) - 1)) - DiagPack<LONG>::BIAS;
+            const uint64_t k2 = k1 >> DB;
+            r.id = (uint32_t) (k2 & ((1ULL << idBits) - 1));
+            const uint64_t rep = (k2 >> idBits) + baseRep;
+            r.kmer = NUCL ? (rep | ((key & 1ULL) << 63)) : rep;
+            r.pos = (decltype(r.pos)) dg; r.len = 0;
+            g[s0 + i] = r;
+        }
         __syncthreads();
     }
 }
@@ -843,7 +852,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     tm.start(0);
     const int repBits = std::max(1, ceilLog2((uint64_t) N));
     const int wantBits = std::max(0, ceilLog2((Nm + 1023) / 1024));
-    const int sBits = std::min(wantBits, repBits);
+    // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
+    const int allowedLocal = 62 - repBits - DiagPack<LONG>::BITS;
+    const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
+    if (sBits > 22) { setError("kmermatch: too many sequences for the packed rep-sort key"); return PLASSHIP_ERR_UNSUPPORTED; }
     const int s1 = std::min(sBits, 11), s2 = std::min(std::max(sBits - s1, 0), 11);
     const uint32_t nS1 = 1u << s1, nS = 1u << (s1 + s2);
     DevBuf dRC1, dRS1, dRCur1, dRSegCnt, dRC2, dRS2, dRCur2;
@@ -891,7 +903,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
     }
     // local sorts; buckets beyond the LDS capacity sort in HBM scratch
-    constexpr int CAPS = LONG ? 2048 : 4096;
+    constexpr int CAPS = 4096;
     DevBuf dBigOff, dBigScratch;
     {
         std::vector<uint64_t> bigOff(nSortBuckets, 0); uint64_t bigTot = 0;
@@ -900,13 +912,13 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             uint64_t P = 1; while (P < c) P <<= 1;
             if (P > (uint64_t) CAPS) { bigOff[b] = bigTot; bigTot += P; }
         }
-        if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * sizeof(R)) != hipSuccess) {
+        if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess) {
             setError("kmermatch: out of device memory for oversized sort buckets"); return PLASSHIP_ERR_DEVICE;
         }
         PH_CHECK(hipMemcpyAsync(dBigOff.p, bigOff.data(), (size_t) nSortBuckets * 8, hipMemcpyHostToDevice, st));
     }
     hipLaunchKernelGGL((localSortKernel<NUCL, LONG, CAPS>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * 16)), dim3(LS_BLOCK), 0, st,
-                       cur, dSortStart, nSortBuckets, dBigScratch.p, dBigOff.as<uint64_t>());
+                       cur, dSortStart, nSortBuckets, dBigScratch.as<unsigned long long>(), dBigOff.as<uint64_t>(), repBits - sBits, repBits);
     msSort2 = tm.stop(1);
 
     // ---- per-(rep,target) reduction + CSR ----
