@@ -123,6 +123,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
     __shared__ unsigned char sCode[64 + 32];
     __shared__ uint32_t sHist[256];
     __shared__ Cand sCand[FALLBACK ? 1 : CAP];
+    __shared__ unsigned long long sSet[FALLBACK ? 1 : 2 * CAP];     // duplicate-k-mer detection without sorting
     typedef Rec<LONG> R;
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
@@ -248,6 +249,45 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
             uint32_t mx = 0;
             for (uint32_t i = lane; i < C; i += 64) mx = max(mx, cand[i].score);
             sStar = (uint32_t) waveReduceMax((int) mx); tooMuch = 0;
+        }
+        // ---- fast path: when no candidate k-mer repeats and the threshold bin has no surplus, the reference's
+        //      sort + walk selects exactly the candidate set (C == considered), in an order that does not matter ----
+        bool needOrder = (tooMuch != 0);
+        if (!needOrder && a.ignoreMulti && C > 1) {
+            if (FALLBACK) needOrder = true;
+            else {
+                for (uint32_t i = lane; i < 2 * CAP; i += 64) sSet[i] = ~0ULL;
+                __syncthreads();
+                bool dup = false;
+                for (uint32_t i = lane; i < C; i += 64) {
+                    const unsigned long long K = NUCL ? (cand[i].kmer | BIT63) : cand[i].kmer;
+                    uint32_t slot = (uint32_t) ((K * 0x9E3779B97F4A7C15ULL) >> 40) & (2 * CAP - 1);
+                    for (;;) {
+                        const unsigned long long prev = atomicCAS(&sSet[slot], ~0ULL, K);
+                        if (prev == ~0ULL) break;
+                        if (prev == K) { dup = true; break; }
+                        slot = (slot + 1) & (2 * CAP - 1);
+                    }
+                }
+                needOrder = __ballot(dup) != 0ULL;
+                __syncthreads();
+            }
+        }
+        if (!needOrder) {
+            for (uint32_t i = lane; i < C; i += 64) {
+                const Cand cd = cand[i];
+                R r; r.kmer = cd.kmer; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) cd.pos;
+                if constexpr (LONG) r.pad = 0;
+                arr[slot + 1 + i] = r;
+            }
+            if (lane == 0) {   // identity record (kmermatcher.cpp:241-249)
+                R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
+                if constexpr (LONG) r.pad = 0;
+                arr[slot] = r;
+            }
+            for (uint32_t i = 1 + C + lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; }
+            __syncthreads();
+            continue;
         }
         // ---- order candidates like SequencePosition::compareByScore[Reverse] (kmermatcher.h:13-45) ----
         uint32_t P = 1; while (P < C) P <<= 1;

@@ -77,14 +77,22 @@ __device__ __forceinline__ char nuclRevCompChar(char c) {
 }
 
 constexpr int RS_BLOCK = 256;
+constexpr int RS_GROUP = 16;      // lanes per candidate pair: a 50-residue read overlap is one 64-byte step
 
-// Scores ONE diagonal with the whole wave; returns (all lanes) score/first/last/idCnt; valid=false if
-// the diagonal does not intersect.  Mode 3 only.
+__device__ __forceinline__ int groupReduceSum16(int v) {
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    return v;
+}
+__device__ __forceinline__ uint32_t loadU32Unaligned(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
+
+// Scores ONE diagonal with a 16-lane group (4 residues per lane and step); returns (all lanes of the group)
+// score/first/last/idCnt; valid=false if the diagonal does not intersect.  Mode 3 only.
 struct DiagScore { bool valid; unsigned score; int first, last; unsigned diagLen; int idCnt; };
 
 template <bool REV>
 __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, unsigned qLen, const char *__restrict__ t,
-                                                   unsigned tLen, int diagonal, const signed char *__restrict__ smat) {
+                                                   unsigned tLen, int diagonal, const signed char *__restrict__ smat, int sl) {
     DiagScore r; r.valid = false; r.score = 0; r.first = -1; r.last = -1; r.diagLen = 0; r.idCnt = 0;
     const unsigned dist = (unsigned) abs(diagonal);
     unsigned qo, to, len;
@@ -96,16 +104,32 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
     // REV: the aligned query is the reverse complement of the stored one: qrev[i] = comp(q[qLen-1-i])
     auto Q = [&](unsigned i) -> char { return REV ? nuclRevCompChar(q[qLen - 1 - (qo + i)]) : q[qo + i]; };
     const char q0 = Q(0), t0 = t[to], qe = Q(len - 1), te = t[to + len - 1];
-    unsigned first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+    const unsigned first = (q0 == '*' || t0 == '*') ? 1u : 0u;
     unsigned last = len - 1;
     if (last > 0 && (qe == '*' || te == '*')) last--;
     int s = 0, ids = 0;
-    for (unsigned p = first + (unsigned) laneId(); p <= last; p += 64) {
-        const char a = Q(p), b = t[to + p];
-        s += (int) smat[(int) a * 123 + (int) b];
-        ids += ((a & ~0x20) == (b & ~0x20)) ? 1 : 0;
+    for (unsigned p = first + 4u * (unsigned) sl; p <= last; p += 4u * RS_GROUP) {
+        // 4 consecutive residues of both sequences (unaligned dword loads; the DB buffer is padded past its end)
+        uint32_t tw = loadU32Unaligned(t + to + p);
+        uint32_t qw;
+        if (REV) {
+            const unsigned rem = qLen - (qo + p);            // stored residues left of (and including) this one
+            if (rem >= 4) qw = __builtin_bswap32(loadU32Unaligned(q + (qLen - 1 - (qo + p)) - 3));
+            else { qw = 0; for (unsigned j = 0; j < rem; j++) qw |= (uint32_t) (unsigned char) q[qLen - 1 - (qo + p + j)] << (8 * j); }   // never read before the buffer
+        }
+        else qw = loadU32Unaligned(q + qo + p);
+        const unsigned n = min(4u, last - p + 1);
+#pragma unroll
+        for (unsigned j = 0; j < 4; j++) {
+            if (j < n) {
+                char a = (char) (qw >> (8 * j)), b = (char) (tw >> (8 * j));
+                if (REV) a = nuclRevCompChar(a);
+                s += (int) smat[(int) a * 123 + (int) b];
+                ids += ((a & ~0x20) == (b & ~0x20)) ? 1 : 0;
+            }
+        }
     }
-    s = waveReduceSum(s); ids = waveReduceSum(ids);
+    s = groupReduceSum16(s); ids = groupReduceSum16(ids);
     r.score = (unsigned) max(s, 0); r.first = (int) first; r.last = (int) last; r.idCnt = ids;
     return r;
 }
@@ -114,10 +138,11 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
     for (int i = threadIdx.x; i < 123 * 123; i += RS_BLOCK) smat[i] = a.mat[i];
     __syncthreads();
-    const int wavesPerBlock = RS_BLOCK / WAVE;
-    const uint64_t stride = (uint64_t) gridDim.x * wavesPerBlock;
+    const int groupsPerBlock = RS_BLOCK / RS_GROUP;
+    const int sl = threadIdx.x & (RS_GROUP - 1);
+    const uint64_t stride = (uint64_t) gridDim.x * groupsPerBlock;
     unsigned long long accLocal = 0, ovLocal = 0;
-    for (uint64_t h = (uint64_t) blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); h < a.nHits; h += stride) {
+    for (uint64_t h = (uint64_t) blockIdx.x * groupsPerBlock + (threadIdx.x / RS_GROUP); h < a.nHits; h += stride) {
         const CandHit hit = a.hits[h];
         const uint32_t qid = hit.query, tid = hit.target;
         const char *q = a.q.data + a.q.off[qid];
@@ -135,16 +160,16 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
             const unsigned d16 = hit.diag16 & 0xFFFFu;
             for (unsigned d = 1; d <= 1 + tLen / 32768; d++) {
                 const int real = (int) (d16 - d * 65536u);
-                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat);
+                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat, sl);
                 if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
             }
             for (unsigned d = 0; d <= qLen / 65536; d++) {
                 const int real = (int) (d * 65536u + d16);
-                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat);
+                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat, sl);
                 if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
             }
-            ovLocal += bDiagLen;
-            // ---- lane-uniform finish (rescorediagonal.cpp:251-314) ----
+            if (sl == 0) ovLocal += bDiagLen;
+            // ---- group-uniform finish (rescorediagonal.cpp:251-314) ----
             const int distance = (int) bScore;
             const int bitScore = (int) (fma(a.lambda, (double) distance, -a.logK) / a.ln2 + 0.5);
             const int alnLen = (bEnd - bStart) + 1;
@@ -178,12 +203,13 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
             rec.alnLen = alnLen; rec.reversed = isReverse ? 1 : 0;
         }
         rec.accepted = accepted ? 1 : 0;
-        if (laneId() == 0) {
+        if (sl == 0) {
             a.out[h] = rec;
             a.accept[h] = accepted ? 1u : 0u;
             accLocal += accepted ? 1 : 0;
         }
     }
+    accLocal = waveReduceSumU64(accLocal); ovLocal = waveReduceSumU64(ovLocal);
     if (laneId() == 0) {
         if (accLocal) atomicAdd(&a.stats[0], accLocal);
         if (ovLocal) atomicAdd(&a.stats[1], ovLocal);
@@ -255,7 +281,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     a.mat = dMat.as<signed char>(); a.sameDB = (qdb == tdb); a.includeIdentity = par->include_identity; a.reverseCapable = c->reverseCapable;
     a.covMode = par->cov_mode; a.covThr = par->cov_thr; a.seqIdThr = par->seq_id_thr; a.alnLenThr = par->min_aln_len; a.seqIdMode = par->seq_id_mode;
     a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.stats = dStats.as<unsigned long long>();
-    const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 3) / 4 + 1, (uint64_t) ctx->numCU * 32);
+    const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 15) / 16 + 1, (uint64_t) ctx->numCU * 8);
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(rescoreKernel, dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
