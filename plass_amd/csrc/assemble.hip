@@ -254,7 +254,7 @@ __global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
         const char *orig = a.s.data + a.s.off[id];
         unsigned querySeqLen = a.s.len[id];
         // ---- queue fill (assembleresult.cpp:161-189): lane i owns alignment i ----
-        uint32_t xTarget = 0, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2;
+        uint32_t xTarget = 0, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2, xTLen = 0; uint64_t xTOff = 0;
         int xScore = 0, xQStart = 0, xQEnd = 0, xDbStart = 0, xDbEnd = 0; float xSeqId = 0.0f;
         if ((uint32_t) lane < h) {
             const AlnRec r = a.recs[h0 + lane];
@@ -270,6 +270,7 @@ __global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
             xScore = (int) (scorePerCol * 100);
             xQStart = r.qStart; xQEnd = r.qEnd; xQLen = (uint32_t) r.qLen; xDbStart = r.dbStart; xDbEnd = r.dbEnd; xDbLen = (uint32_t) r.dbLen;
             xState = 0;
+            xTOff = a.s.off[xTarget]; xTLen = a.s.len[xTarget];      // fetched up front: one memory round trip less per pop
         }
         (void) xSeqId;   // the protein comparator never looks at seqId (only re-scored hits are gated on it)
         char *buf = a.arena + aoff;
@@ -301,8 +302,8 @@ __global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
                 const bool rightStart = bDbStart == 0 && (bDbEnd != (int) bDbLen - 1);
                 const bool leftStart = bQStart == 0 && (bQEnd != (int) bQLen - 1);
                 if (!((rightStart || leftStart) && notBoth && (bTarget != id))) continue;
-                const char *tSeq = a.s.data + a.s.off[bTarget];
-                const unsigned tLen = a.s.len[bTarget];
+                const char *tSeq = a.s.data + __shfl(xTOff, bi, 64);
+                const unsigned tLen = __shfl(xTLen, bi, 64);
                 if (bDbStart == 0) { if ((tLen - ((unsigned) bDbEnd + 1)) <= rightOff) continue; }
                 else if (bQStart == 0) { if (bDbStart <= (int) leftOff) continue; }
                 const unsigned dbStart = (unsigned) bDbStart, dbEnd = (unsigned) bDbEnd, qStart = (unsigned) bQStart, qEnd = (unsigned) bQEnd;
@@ -334,8 +335,9 @@ __global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
                 deferred &= deferred - 1;
                 const uint32_t tg = __shfl(xTarget, dl, 64);
                 const int dqs = __shfl(xQStart, dl, 64), dds = __shfl(xDbStart, dl, 64);
-                const char *tSeq = a.s.data + a.s.off[tg];
-                const unsigned tLen = a.s.len[tg];
+                const char *tSeq = a.s.data + __shfl(xTOff, dl, 64);
+                const unsigned tLen = __shfl(xTLen, dl, 64);
+                (void) tg;
                 const int diag = (int) ((unsigned) dqs + leftOff) - dds;
                 const Rescored rs = rescoreOnDiagonal(qs, querySeqLen, tSeq, tLen, diag, smat);
                 nResc++; nRescRes += rs.diagonalLen;
@@ -363,12 +365,26 @@ __global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
 
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
 __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
-                                uint64_t *__restrict__ bytes) {
+                                uint64_t *__restrict__ bytes, uint64_t maxSeqLen) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
         uint64_t sum = 0;
-        for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) { const AlnRec r = recs[i]; if (r.target != id) sum += (uint64_t) r.dbLen; }
+        bool can = false;
+        for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) {
+            const AlnRec r = recs[i];
+            if (r.target == id) continue;
+            sum += (uint64_t) r.dbLen;
+            // exact pre-screen: the first extension of a query is decided by coordinates the alignment already
+            // carries (selectFragmentToExtend + the two geometry tests, assembleresult.cpp:40-57,211-263); if no
+            // alignment can start an extension the greedy loop drains its queue without changing anything.
+            const bool notBoth = !(r.dbStart == 0 && r.qStart == 0);
+            const bool rightStart = r.dbStart == 0 && (r.dbEnd != r.dbLen - 1);
+            const bool leftStart = r.qStart == 0 && (r.qEnd != r.qLen - 1);
+            if (!((rightStart || leftStart) && notBoth)) continue;
+            if (r.dbStart == 0) can |= (r.qEnd == r.qLen - 1) && (r.dbLen - (r.dbEnd + 1) > 0);
+            else if (r.qStart == 0) can |= (r.dbEnd == r.dbLen - 1) && (r.dbStart > 0) && ((uint64_t) r.qLen + (uint64_t) r.dbStart < maxSeqLen);
+        }
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
-        bytes[id] = sum ? (2 * sum + s.len[id] + 8) : 0;
+        bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 8) : 0;
     }
 }
 
@@ -436,7 +452,7 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(false), 123 * 123, hipMemcpyHostToDevice, st));
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
-    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>());
+    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len);
     if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t arenaBytes = 0;
     PH_CHECK(hipMemcpyAsync(&arenaBytes, dArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));

@@ -29,8 +29,12 @@ hipError_t poolMalloc(void **p, size_t n) {
     const size_t c = sizeClass(n);
     {
         std::lock_guard<std::mutex> g(g_poolMu);
-        auto it = g_poolFree.find(c);
-        if (it != g_poolFree.end()) { *p = it->second; g_poolFree.erase(it); g_poolLive[*p] = c; return hipSuccess; }
+        // best fit: the smallest cached block that is large enough, as long as it is not absurdly larger
+        // (iterations shrink and grow their arrays; an exact-class match would miss and fall into hipMalloc)
+        auto it = g_poolFree.lower_bound(c);
+        if (it != g_poolFree.end() && (it->first <= 8 * c || it->first <= (size_t) 1 << 20)) {
+            *p = it->second; const size_t got = it->first; g_poolFree.erase(it); g_poolLive[*p] = got; return hipSuccess;
+        }
     }
     hipError_t e = hipMalloc(p, c);
     if (e != hipSuccess) { (void) hipGetLastError(); poolTrim(); e = hipMalloc(p, c); }

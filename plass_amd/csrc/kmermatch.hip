@@ -614,102 +614,191 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 }
 
 // =====================================================================================================
-// 5. sort #2: bitonic sort of one rep-range bucket on PACKED 64-bit keys (LDS; HBM scratch when oversized)
-//    key = [rep - bucketBase | target id | diagonal + bias | strand bit]  — the order of
-//    compareRepSequenceAndIdAndDiag[Reverse] (kmermatcher.h:98-130) with the canonical strand tie-break.
+// 5. sort #2 + run reduction, per rep-range bucket.
+//    compareRepSequenceAndIdAndDiag[Reverse] (kmermatcher.h:98-130) orders by (rep, target, diagonal); what
+//    writeKmerMatcherResult (kmermatcher.cpp:835-923) needs from that order is, per (rep,target), the multiset of
+//    diagonals in ascending order.  Overlapping reads share many k-mers on ONE diagonal (N_m/N_c ~ 3..10), so the
+//    bucket is first aggregated in an LDS hash table to unique (rep,target,diagonal) triples with multiplicities,
+//    and only the triples are bitonic-sorted (packed 64-bit keys).  Buckets that do not fit sort all their packed
+//    keys in HBM scratch and run-length encode them.  Output: weighted triples in global (rep,target,diagonal) order.
 // =====================================================================================================
 constexpr int LS_BLOCK = 256;
+constexpr uint32_t AGG_CAP = 2048;          // records per bucket handled in LDS (=> at most 2048 distinct triples)
+constexpr uint32_t AGG_HT = 4096;           // hash slots
 template <bool LONG> struct DiagPack { static constexpr int BITS = LONG ? 22 : 16; static constexpr int64_t BIAS = LONG ? (1 << 21) : 32768; };
+struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag; uint32_t cnt; };   // cnt bit 31: some record of the run is forward-strand
 
-template <bool NUCL, bool LONG, int CAPS>
-__global__ __launch_bounds__(LS_BLOCK) void localSortKernel(void *arr, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
-                                                            unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
-                                                            int localBits, int idBits) {
+template <bool NUCL, bool LONG>
+__global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void *outTriples, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
+                                                          unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
+                                                          uint32_t *__restrict__ uniqueCount, int localBits, int idBits) {
     typedef Rec<LONG> R;
-    __shared__ unsigned long long s[CAPS];
-    R *g = reinterpret_cast<R *>(arr);
+    __shared__ unsigned long long hKey[AGG_HT];
+    __shared__ uint32_t hVal[AGG_HT];
+    __shared__ unsigned long long lKey[AGG_CAP];
+    __shared__ uint32_t lVal[AGG_CAP];
+    __shared__ uint32_t sCount;
+    __shared__ uint32_t sWave[LS_BLOCK / 64];
+    const R *g = reinterpret_cast<const R *>(arr);
+    Triple *out = reinterpret_cast<Triple *>(outTriples);
     constexpr int DB = DiagPack<LONG>::BITS;
     for (uint32_t b = blockIdx.x; b < nBuckets; b += gridDim.x) {
         const uint64_t s0 = bucketStart[b], s1 = bucketStart[b + 1];
         const uint64_t cnt = s1 - s0;
-        if (cnt <= 1) continue;
-        uint64_t P = 1; while (P < cnt) P <<= 1;
-        unsigned long long *p = (P <= (uint64_t) CAPS) ? s : (bigScratch + bigOff[b]);
+        if (cnt == 0) { if (threadIdx.x == 0) uniqueCount[b] = 0; continue; }
         const uint64_t baseRep = (uint64_t) b << localBits;
-        for (uint64_t i = threadIdx.x; i < P; i += LS_BLOCK) {
-            unsigned long long key = ~0ULL;
-            if (i < cnt) {
+        auto decode = [&](unsigned long long key, uint32_t val) {
+            Triple t;
+            t.diag = (int32_t) ((int64_t) (key & ((1ULL << DB) - 1)) - DiagPack<LONG>::BIAS);
+            const uint64_t k2 = key >> DB;
+            t.target = (uint32_t) (k2 & ((1ULL << idBits) - 1));
+            t.rep = (uint32_t) ((k2 >> idBits) + baseRep);
+            t.cnt = val;
+            return t;
+        };
+        if (cnt <= AGG_CAP) {
+            for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) { hKey[i] = ~0ULL; hVal[i] = 0; }
+            if (threadIdx.x == 0) sCount = 0;
+            __syncthreads();
+            for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) {
                 const R r = g[s0 + i];
                 const uint64_t rep = r.kmer & ~BIT63;
-                key = (((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS)) << 1;
-                key |= NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL;
-            }
-            p[i] = key;
-        }
-        __syncthreads();
-        for (uint64_t kk = 2; kk <= P; kk <<= 1) {
-            for (uint64_t j = kk >> 1; j > 0; j >>= 1) {
-                // each thread handles the compare-exchange pairs (i, i^j) with i < i^j: enumerate them directly
-                for (uint64_t t = threadIdx.x; t < (P >> 1); t += LS_BLOCK) {
-                    const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                    const uint64_t l = i | j;
-                    const unsigned long long x = p[i], y = p[l];
-                    const bool up = (i & kk) == 0;
-                    if ((x > y) == up) { p[i] = y; p[l] = x; }
+                const unsigned long long key = ((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS);
+                uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 40) & (AGG_HT - 1);
+                for (;;) {
+                    const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, key);
+                    if (prev == ~0ULL || prev == key) break;
+                    slot = (slot + 1) & (AGG_HT - 1);
                 }
+                atomicAdd(&hVal[slot], 1u);
+                if (NUCL && (r.kmer & BIT63)) atomicOr(&hVal[slot], 0x80000000u);
+            }
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) {
+                const unsigned long long k = hKey[i];
+                if (k != ~0ULL) { const uint32_t o = atomicAdd(&sCount, 1u); lKey[o] = k; lVal[o] = hVal[i]; }
+            }
+            __syncthreads();
+            const uint32_t U = sCount;
+            uint32_t P = 1; while (P < U) P <<= 1;
+            for (uint32_t i = U + threadIdx.x; i < P; i += LS_BLOCK) { lKey[i] = ~0ULL; lVal[i] = 0; }
+            __syncthreads();
+            for (uint32_t kk = 2; kk <= P; kk <<= 1) {
+                for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+                    for (uint32_t t = threadIdx.x; t < (P >> 1); t += LS_BLOCK) {
+                        const uint32_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const uint32_t l = i | j;
+                        const unsigned long long x = lKey[i], y = lKey[l];
+                        const bool up = (i & kk) == 0;
+                        if ((x > y) == up) { lKey[i] = y; lKey[l] = x; const uint32_t vx = lVal[i]; lVal[i] = lVal[l]; lVal[l] = vx; }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) out[s0 + i] = decode(lKey[i], lVal[i]);
+            if (threadIdx.x == 0) uniqueCount[b] = U;
+            __syncthreads();
+        } else {
+            // oversized bucket: sort every packed key (strand bit in the LSB) in HBM scratch, then run-length encode
+            uint64_t P = 1; while (P < cnt) P <<= 1;
+            unsigned long long *p = bigScratch + bigOff[b];
+            for (uint64_t i = threadIdx.x; i < P; i += LS_BLOCK) {
+                unsigned long long key = ~0ULL;
+                if (i < cnt) {
+                    const R r = g[s0 + i];
+                    const uint64_t rep = r.kmer & ~BIT63;
+                    key = (((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS)) << 1;
+                    key |= NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL;
+                }
+                p[i] = key;
+            }
+            __syncthreads();
+            for (uint64_t kk = 2; kk <= P; kk <<= 1) {
+                for (uint64_t j = kk >> 1; j > 0; j >>= 1) {
+                    for (uint64_t t = threadIdx.x; t < (P >> 1); t += LS_BLOCK) {
+                        const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                        const uint64_t l = i | j;
+                        const unsigned long long x = p[i], y = p[l];
+                        const bool up = (i & kk) == 0;
+                        if ((x > y) == up) { p[i] = y; p[l] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+            uint32_t written = 0;
+            for (uint64_t i0 = 0; i0 < cnt; i0 += LS_BLOCK) {
+                const uint64_t i = i0 + threadIdx.x;
+                bool head = false; Triple t; t.rep = t.target = t.cnt = 0; t.diag = 0;
+                if (i < cnt) {
+                    const unsigned long long k = p[i] >> 1;
+                    head = (i == 0) || ((p[i - 1] >> 1) != k);
+                    if (head) {
+                        uint32_t c = 0, fwd = 0;
+                        for (uint64_t j = i; j < cnt && (p[j] >> 1) == k; j++) { c++; fwd |= (uint32_t) (p[j] & 1ULL); }
+                        t = decode(k, c | (fwd ? 0x80000000u : 0u));
+                    }
+                }
+                const unsigned long long mk = __ballot(head);
+                const uint32_t wr = (uint32_t) __popcll(mk & ((1ULL << laneId()) - 1ULL));
+                if (laneId() == 0) sWave[threadIdx.x >> 6] = (uint32_t) __popcll(mk);
+                __syncthreads();
+                uint32_t woff = 0, tot = 0;
+#pragma unroll
+                for (int w = 0; w < LS_BLOCK / 64; w++) { if (w < (int) (threadIdx.x >> 6)) woff += sWave[w]; tot += sWave[w]; }
+                if (head) out[s0 + written + woff + wr] = t;
+                written += tot;
                 __syncthreads();
             }
+            if (threadIdx.x == 0) uniqueCount[b] = written;
+            __syncthreads();
         }
-        for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) {
-            const unsigned long long key = p[i];
-            R r; memset(&r, 0, sizeof(R));
-            const uint64_t k1 = key >> 1;
-            const int64_t dg = (int64_t) (k1 & ((1ULL << DB) - 1)) - DiagPack<LONG>::BIAS;
-            const uint64_t k2 = k1 >> DB;
-            r.id = (uint32_t) (k2 & ((1ULL << idBits) - 1));
-            const uint64_t rep = (k2 >> idBits) + baseRep;
-            r.kmer = NUCL ? (rep | ((key & 1ULL) << 63)) : rep;
-            r.pos = (decltype(r.pos)) dg; r.len = 0;
-            g[s0 + i] = r;
-        }
-        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__restrict__ in, const uint64_t *__restrict__ bucketStart,
+                                                            const uint64_t *__restrict__ tripleStart, uint32_t nBuckets, Triple *__restrict__ out) {
+    // one wave per bucket
+    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
+        const uint64_t s0 = bucketStart[b], d0 = tripleStart[b], n = tripleStart[b + 1] - d0;
+        for (uint64_t i = laneId(); i < n; i += 64) out[d0 + i] = in[s0 + i];
     }
 }
 
 // =====================================================================================================
-// 6. best diagonal per (rep, target) run (writeKmerMatcherResult, kmermatcher.cpp:835-923)
+// 6. best diagonal per (rep, target) run (writeKmerMatcherResult, kmermatcher.cpp:835-923) over weighted triples
 // =====================================================================================================
-template <bool NUCL, bool LONG>
-__global__ void reduceRunsKernel(const void *arr, uint64_t n, CandHit *__restrict__ tmpHits, uint32_t *__restrict__ emit,
+template <bool NUCL>
+__global__ void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, CandHit *__restrict__ tmpHits, uint32_t *__restrict__ emit,
                                  uint32_t *__restrict__ perRep) {
-    typedef Rec<LONG> R;
-    const R *h = reinterpret_cast<const R *>(arr);
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
-        const R r = h[i];
-        const uint64_t rep = NUCL ? (r.kmer & ~BIT63) : r.kmer;
+        const Triple r = h[i];
         bool head = (i == 0);
-        if (!head) { const R q = h[i - 1]; const uint64_t prep = NUCL ? (q.kmer & ~BIT63) : q.kmer; head = (prep != rep) || (q.id != r.id); }
+        if (!head) { const Triple q = h[i - 1]; head = (q.rep != r.rep) || (q.target != r.target); }
         uint32_t e = 0;
         if (head) {
-            const uint32_t targetId = r.id;
-            auto diagonal = r.pos; auto prevDiagonal = r.pos;
+            const uint32_t targetId = r.target;
+            int32_t diagonal = r.diag, prevDiagonal = r.diag;
             uint64_t maxDiagonal = 0, diagonalCnt = 0, topScore = 0;
-            int bestRev = NUCL ? ((r.kmer & BIT63) == 0) : 0;
+            int bestRev = NUCL ? ((r.cnt & 0x80000000u) == 0) : 0;
             // NOTE: the reference's scan tests only the target id, so it runs across a rep boundary when the
-            // next rep starts with the same target (Appendix A.3) — reproduced; it can also run past the
-            // compaction point into stale sort-#1 records (probability ~1/N per run) — not reproduced.
+            // next rep starts with the same target (Appendix A.3) — reproduced (a run of equal diagonals then
+            // continues across the boundary); it can also run past the compaction point into stale sort-#1
+            // records (probability ~1/N per run) — not reproduced.
             for (uint64_t j = i; j < n; j++) {
-                const R x = h[j];
-                if (x.id != targetId) break;
-                if (prevDiagonal == x.pos) diagonalCnt++; else diagonalCnt = 1;
-                if (diagonalCnt >= maxDiagonal) { diagonal = x.pos; maxDiagonal = diagonalCnt; if (NUCL) bestRev = ((x.kmer & BIT63) == 0); }
-                prevDiagonal = x.pos; topScore++;
+                const Triple x = h[j];
+                if (x.target != targetId) break;
+                const uint64_t c = x.cnt & 0x7FFFFFFFu;
+                if (prevDiagonal == x.diag) diagonalCnt += c; else diagonalCnt = c;
+                // every record of the run is checked against the running maximum; the count only grows inside a
+                // run, so the state after the run is what the record-by-record walk leaves behind
+                if (diagonalCnt >= maxDiagonal) { diagonal = x.diag; maxDiagonal = diagonalCnt; if (NUCL) bestRev = ((x.cnt & 0x80000000u) == 0); }
+                prevDiagonal = x.diag; topScore += c;
             }
-            if ((uint64_t) targetId != rep) {
+            if (targetId != r.rep) {
                 CandHit c; c.target = targetId; c.prefScore = bestRev ? -(int) topScore : (int) topScore;
-                c.diag16 = (uint32_t) (uint16_t) diagonal; c.query = (uint32_t) rep;
+                c.diag16 = (uint32_t) (uint16_t) diagonal; c.query = r.rep;
                 tmpHits[i] = c; e = 1;
-                atomicAdd(&perRep[(uint32_t) rep], 1u);
+                atomicAdd(&perRep[r.rep], 1u);
             }
         }
         emit[i] = e;
@@ -942,46 +1031,54 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             dSortStart = dRS2.as<uint64_t>(); nSortBuckets = nS;
         }
     }
-    // local sorts; buckets beyond the LDS capacity sort in HBM scratch
-    constexpr int CAPS = 4096;
-    DevBuf dBigOff, dBigScratch;
+    // aggregate + sort each bucket; buckets beyond the LDS capacity sort in HBM scratch
+    DevBuf dBigOff, dBigScratch, dUnique, dTripleStart;
     {
         std::vector<uint64_t> bigOff(nSortBuckets, 0); uint64_t bigTot = 0;
         for (uint32_t b = 0; b < nSortBuckets; b++) {
             const uint64_t c = hSortStart[b + 1] - hSortStart[b];
-            uint64_t P = 1; while (P < c) P <<= 1;
-            if (P > (uint64_t) CAPS) { bigOff[b] = bigTot; bigTot += P; }
+            if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; bigOff[b] = bigTot; bigTot += P; }
         }
-        if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess) {
-            setError("kmermatch: out of device memory for oversized sort buckets"); return PLASSHIP_ERR_DEVICE;
+        if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess ||
+            dUnique.alloc(((size_t) nSortBuckets + 1) * 4) != hipSuccess || dTripleStart.alloc(((size_t) nSortBuckets + 2) * 8) != hipSuccess) {
+            setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE;
         }
         PH_CHECK(hipMemcpyAsync(dBigOff.p, bigOff.data(), (size_t) nSortBuckets * 8, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL((localSortKernel<NUCL, LONG, CAPS>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * 16)), dim3(LS_BLOCK), 0, st,
-                       cur, dSortStart, nSortBuckets, dBigScratch.as<unsigned long long>(), dBigOff.as<uint64_t>(), repBits - sBits, repBits);
+    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * 16)), dim3(LS_BLOCK), 0, st,
+                       (const void *) cur, other, dSortStart, nSortBuckets, dBigScratch.as<unsigned long long>(), dBigOff.as<uint64_t>(),
+                       dUnique.as<uint32_t>(), repBits - sBits, repBits);
+    DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
+    if (dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSortBuckets, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t nTriples = 0;
+    PH_CHECK(hipMemcpyAsync(&nTriples, dTripleStart.as<uint64_t>() + nSortBuckets, 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(compactTriplesKernel, dim3(std::min<uint32_t>((nSortBuckets + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st,
+                       (const Triple *) other, dSortStart, dTripleStart.as<uint64_t>(), nSortBuckets, (Triple *) cur);
     msSort2 = tm.stop(1);
+    PH_CHECK(hipGetLastError());
 
     // ---- per-(rep,target) reduction + CSR ----
     tm.start(0);
     DevBuf dTmpHits, dEmit, dEpos, dPerRep, dQoff;
-    if (dTmpHits.alloc(std::max<uint64_t>(Nm, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc(std::max<uint64_t>(Nm, 1) * 4) != hipSuccess ||
-        dEpos.alloc((Nm + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    DevBuf dScanTmp2; const size_t scanTmp2Bytes = exclusiveScanTmpBytes(std::max<uint64_t>(Nm, N) + 2);
+    if (dTmpHits.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc(std::max<uint64_t>(nTriples, 1) * 4) != hipSuccess ||
+        dEpos.alloc((nTriples + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    DevBuf dScanTmp2; const size_t scanTmp2Bytes = exclusiveScanTmpBytes(std::max<uint64_t>(nTriples, N) + 2);
     if (dScanTmp2.alloc(scanTmp2Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor((uint64_t) N + 1, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>(), 1u, (uint64_t) N);
-    if (Nm) hipLaunchKernelGGL((reduceRunsKernel<NUCL, LONG>), dim3(gridFor(Nm, 256, 65535)), dim3(256), 0, st, (const void *) cur, Nm, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
-    if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), Nm, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    if (nTriples) hipLaunchKernelGGL((reduceRunsKernel<NUCL>), dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, (const Triple *) cur, nTriples, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
+    if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     plasship_cands *c = new plasship_cands();
     c->reverseCapable = NUCL; c->nQueries = N;
     if (c->d_qoff.alloc(((size_t) N + 1) * 8) != hipSuccess) { delete c; setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { delete c; setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t Nc = 0;
-    PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + Nm, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nTriples, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     c->nHits = Nc + N; c->nNonSelf = Nc;
     if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { delete c; setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (N) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), N, c->d_hits.as<CandHit>());
-    if (Nm) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(Nm, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), Nm, c->d_hits.as<CandHit>());
+    if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, c->d_hits.as<CandHit>());
     msReduce = tm.stop(1);
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
