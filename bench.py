@@ -29,6 +29,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+WALL = []               # host wall ms per module call (kmermatcher, rescorediagonal, assembleresults)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -60,10 +61,15 @@ def one_iteration(ctx, db, it):
     import plass_amd
     par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=hash_shift(it),
                                     include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
+    t0 = time.perf_counter()
     cands, kst = ctx.kmermatcher(db, par)
+    t1 = time.perf_counter()
     alns, rst = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5))
+    t2 = time.perf_counter()
     out, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
+    t3 = time.perf_counter()
     alns.free(); cands.free()
+    WALL.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
     return out, kst, rst, ast
 
 
@@ -190,7 +196,8 @@ def main():
                        "candidate_overlaps": overlaps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg,
-                         "stage_ms_per_step": {k: v[0] / len(stats) for k, v in tot.items()}},
+                         "stage_ms_per_step": {k: v[0] / len(stats) for k, v in tot.items()},
+                         "module_wall_ms_per_step": [round(sum(w[i] for w in WALL[-args.steps:]) / args.steps, 3) for i in range(3)]},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_pairs, min(args.steps, 3))

@@ -47,6 +47,7 @@ struct AsmArgs {
     float seqIdThr; uint64_t maxSeqLen; int rescoreMode;
     unsigned long long *stats;                  // [0] extended, [1] rescored hits, [2] rescored overlap residues
     uint32_t *bigList; uint32_t *bigCount; uint32_t nBig;   // queries with more than 64 alignments (HBM-resident queue)
+    uint32_t *midList; uint32_t *midCount; uint32_t nMid;   // 17..64 alignments: one wavefront per query
 };
 
 // text round trip of seqId (Util.cpp:278-307 + strtod in Matcher.cpp:265)
@@ -230,97 +231,140 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
     if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
 }
 
-// ---- the common case: at most 64 alignments per query => the whole queue lives in registers, one item per lane;
-//      four independent waves per block share the LDS score table; no block barriers in the loop ----
+// ---- the common cases: the whole queue of a query lives in registers, one alignment per lane.
+//      G = 16: four queries per wavefront (a read has a handful of overlaps); G = 64: one query per wavefront.
+//      Sixteen/four independent groups per block share the LDS score table; no block barriers in the loop. ----
 __device__ __forceinline__ void waveMemSync() {   // make this wave's global stores visible to its own later loads
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+template <int G> __device__ __forceinline__ int groupSum(int v) {
+#pragma unroll
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    return v;
+}
+template <int G> __device__ __forceinline__ unsigned long long groupBallot(bool p) {
+    const unsigned long long m = __ballot(p);
+    if (G == 64) return m;
+    return (m >> ((laneId() / G) * G)) & ((1ULL << G) - 1ULL);
+}
 
-__global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
+template <int G>
+__device__ __forceinline__ Rescored rescoreOnDiagonalG(const char *q, unsigned qLen, const char *t, unsigned tLen, int diagonal,
+                                                       const signed char *smat, int gl) {
+    Rescored r; r.startPos = -1; r.endPos = -1; r.score = 0; r.diagonalLen = 0; r.idExcl = 0;
+    const unsigned dist = (unsigned) abs(diagonal);
+    unsigned qo, to, len;
+    if (diagonal >= 0 && dist < qLen) { qo = dist; to = 0; len = min(tLen, qLen - dist); }
+    else if (diagonal < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, qLen); }
+    else return r;
+    r.diagonalLen = len;
+    if (len == 0) return r;
+    unsigned first = (q[qo] == '*' || t[to] == '*') ? 1u : 0u;
+    unsigned last = len - 1;
+    if (last > 0 && (q[qo + len - 1] == '*' || t[to + len - 1] == '*')) last--;
+    int s = 0, ids = 0;
+    for (unsigned p = first + (unsigned) gl; p <= last; p += G) {
+        const char a = q[qo + p], b = t[to + p];
+        s += (int) smat[(int) a * 123 + (int) b];
+        if (p < last) ids += (a == b) ? 1 : 0;          // [qStart, qEnd): the last aligned column is not counted
+    }
+    s = groupSum<G>(s); ids = groupSum<G>(ids);
+    r.score = (unsigned) max(s, 0); r.startPos = (int) first; r.endPos = (int) last; r.idExcl = ids;
+    return r;
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
     for (int i = threadIdx.x; i < 123 * 123; i += 256) smat[i] = a.mat[i];
     __syncthreads();
-    const int lane = laneId();
-    const uint32_t wavesTotal = gridDim.x * 4;
+    const int gl = threadIdx.x & (G - 1);                         // lane within the group
+    const uint32_t groupsTotal = gridDim.x * (256 / G);
+    const uint32_t nWork = (G == 64) ? a.nMid : a.s.n;
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0;
-    for (uint32_t id = blockIdx.x * 4 + (threadIdx.x >> 6); id < a.s.n; id += wavesTotal) {
+    for (uint32_t w = blockIdx.x * (256 / G) + threadIdx.x / G; w < nWork; w += groupsTotal) {
+        const uint32_t id = (G == 64) ? a.midList[w] : w;
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
         const uint32_t h = (uint32_t) (h1 - h0);
         if (h == 0) continue;
         const uint64_t aoff = a.arenaOff[id];
-        if (a.arenaOff[id + 1] == aoff) continue;          // no non-self hit: can never be extended
-        if (h > 64) { if (lane == 0) { const uint32_t o = atomicAdd(a.bigCount, 1u); a.bigList[o] = id; } continue; }
+        if (a.arenaOff[id + 1] == aoff) continue;          // pre-screened: can never be extended
+        if (G == 16 && h > 16) {                           // bigger queues go to the wider tiers
+            if (gl == 0) { if (h > 64) { const uint32_t o = atomicAdd(a.bigCount, 1u); a.bigList[o] = id; } else { const uint32_t o = atomicAdd(a.midCount, 1u); a.midList[o] = id; } }
+            continue;
+        }
         const char *orig = a.s.data + a.s.off[id];
         unsigned querySeqLen = a.s.len[id];
         // ---- queue fill (assembleresult.cpp:161-189): lane i owns alignment i ----
-        uint32_t xTarget = 0, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2, xTLen = 0; uint64_t xTOff = 0;
-        int xScore = 0, xQStart = 0, xQEnd = 0, xDbStart = 0, xDbEnd = 0; float xSeqId = 0.0f;
-        if ((uint32_t) lane < h) {
-            const AlnRec r = a.recs[h0 + lane];
+        uint32_t xTarget = 0xFFFFFFFFu, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2, xTLen = 0; uint64_t xTOff = 0;
+        int xScore = 0, xQStart = 0, xQEnd = 0, xDbStart = 0, xDbEnd = 0;
+        if ((uint32_t) gl < h) {
+            const AlnRec r = a.recs[h0 + gl];
             xTarget = r.target;
             const int aq = (r.qStart == -1) ? 0 : r.qStart, ad = (r.dbStart == -1) ? 0 : r.dbStart;
             xAlnLen = (uint32_t) (max(abs(r.qEnd - aq), abs(r.dbEnd - ad)) + 1);
             const int rawScore = (int) (fma((double) r.bitScore, a.ln2, a.logK) / a.lambda + 0.5);
             const float scorePerCol = (float) rawScore / (float) ((double) xAlnLen + 0.5);
-            const float sid = r.fromText ? r.seqId : seqIdThroughText(r.seqId);
-            const float alnLen = (float) xAlnLen;
-            const float ids = sid * alnLen;
-            xSeqId = (float) ((double) ids / ((double) alnLen + 0.5));
             xScore = (int) (scorePerCol * 100);
             xQStart = r.qStart; xQEnd = r.qEnd; xQLen = (uint32_t) r.qLen; xDbStart = r.dbStart; xDbEnd = r.dbEnd; xDbLen = (uint32_t) r.dbLen;
-            xState = 0;
+            // the self alignment is popped and discarded without any effect (selectFragmentToExtend: isNotIdentity):
+            // it never enters the register queue
+            xState = (xTarget == id) ? 2u : 0u;
             xTOff = a.s.off[xTarget]; xTLen = a.s.len[xTarget];      // fetched up front: one memory round trip less per pop
         }
-        (void) xSeqId;   // the protein comparator never looks at seqId (only re-scored hits are gated on it)
+        // tie-break of CompareResultByScore (smaller key wins) as a rank among the group's targets
+        uint32_t tRank = 0;
+#pragma unroll 4
+        for (int j = 0; j < G; j++) { const uint32_t ot = __shfl(xTarget, j, G); tRank += (ot < xTarget) ? 1u : 0u; }
         char *buf = a.arena + aoff;
         uint64_t curStart = a.leftCap[id];
-        for (uint32_t i = lane; i < querySeqLen; i += 64) buf[curStart + i] = orig[i];
+        for (uint32_t i = gl; i < querySeqLen; i += G) buf[curStart + i] = orig[i];
         uint64_t curLen = querySeqLen;
         bool couldExtend = false;
-        uint32_t inQueue = h;
+        uint32_t inQueue = (uint32_t) __popcll(groupBallot<G>(xState == 0));
         while (inQueue > 0) {
             unsigned leftOff = 0, rightOff = 0;
             bool brokeOut = false;
             if (xState == 1) xState = 2;
             for (;;) {
-                // ---- selectFragmentToExtend: wave arg-max = priority_queue::top (strict comparator) ----
-                int bs = xScore; uint32_t bl = xAlnLen, bt = xTarget; int bi = (xState == 0) ? lane : -1;
+                // ---- selectFragmentToExtend: arg-max of (score, alnLength, smaller key) = priority_queue::top ----
+                unsigned long long key = 0;
+                if (xState == 0) key = ((unsigned long long) ((uint32_t) xScore ^ 0x80000000u) << 32) | ((unsigned long long) xAlnLen << 6) | (unsigned long long) (63u - tRank);
+                unsigned long long best = key;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const int os = __shfl_xor(bs, o, 64); const uint32_t ol = __shfl_xor(bl, o, 64), ot = __shfl_xor(bt, o, 64); const int oi = __shfl_xor(bi, o, 64);
-                    const bool better = (oi >= 0) && ((bi < 0) || (os > bs) || (os == bs && (ol > bl || (ol == bl && ot < bt))));
-                    if (better) { bs = os; bl = ol; bt = ot; bi = oi; }
-                }
-                if (bi < 0) { inQueue = 0; break; }
-                if (lane == bi) xState = 2;                         // popped
+                for (int o = G / 2; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(best, o, G); best = (ok > best) ? ok : best; }
+                if (best == 0) { inQueue = 0; break; }
+                const bool mine = (key == best);                   // exactly one lane (ranks are distinct)
+                const int bi = __ffsll((long long) groupBallot<G>(mine)) - 1;
+                if (mine) xState = 2;                              // popped
                 inQueue--;
-                const uint32_t bTarget = bt;
-                const int bQStart = __shfl(xQStart, bi, 64), bQEnd = __shfl(xQEnd, bi, 64), bDbStart = __shfl(xDbStart, bi, 64), bDbEnd = __shfl(xDbEnd, bi, 64);
-                const uint32_t bQLen = __shfl(xQLen, bi, 64), bDbLen = __shfl(xDbLen, bi, 64);
+                const uint32_t bTarget = __shfl(xTarget, bi, G);
+                const int bQStart = __shfl(xQStart, bi, G), bQEnd = __shfl(xQEnd, bi, G), bDbStart = __shfl(xDbStart, bi, G), bDbEnd = __shfl(xDbEnd, bi, G);
+                const uint32_t bQLen = __shfl(xQLen, bi, G), bDbLen = __shfl(xDbLen, bi, G);
                 const bool notBoth = !(bDbStart == 0 && bQStart == 0);
                 const bool rightStart = bDbStart == 0 && (bDbEnd != (int) bDbLen - 1);
                 const bool leftStart = bQStart == 0 && (bQEnd != (int) bQLen - 1);
-                if (!((rightStart || leftStart) && notBoth && (bTarget != id))) continue;
-                const char *tSeq = a.s.data + __shfl(xTOff, bi, 64);
-                const unsigned tLen = __shfl(xTLen, bi, 64);
+                if (!((rightStart || leftStart) && notBoth)) continue;
+                const char *tSeq = a.s.data + __shfl(xTOff, bi, G);
+                const unsigned tLen = __shfl(xTLen, bi, G);
                 if (bDbStart == 0) { if ((tLen - ((unsigned) bDbEnd + 1)) <= rightOff) continue; }
                 else if (bQStart == 0) { if (bDbStart <= (int) leftOff) continue; }
                 const unsigned dbStart = (unsigned) bDbStart, dbEnd = (unsigned) bDbEnd, qStart = (unsigned) bQStart, qEnd = (unsigned) bQEnd;
                 if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
-                    if (rightOff > 0) { if (lane == bi) xState = 1; continue; }
+                    if (rightOff > 0) { if (mine) xState = 1; continue; }
                     const unsigned fragLen = tLen - (dbEnd + 1);
-                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + curLen + i] = tSeq[dbEnd + 1 + i];
+                    for (unsigned i = gl; i < fragLen; i += G) buf[curStart + curLen + i] = tSeq[dbEnd + 1 + i];
                     curLen += fragLen; rightOff += fragLen;
-                    if (lane == 0) atomicOr(&a.flags[bTarget], 0x80u);
+                    if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
                 } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
-                    if (leftOff > 0) { if (lane == bi) xState = 1; continue; }
+                    if (leftOff > 0) { if (mine) xState = 1; continue; }
                     const unsigned fragLen = dbStart;
                     if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
                     curStart -= fragLen;
-                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + i] = tSeq[i];
+                    for (unsigned i = gl; i < fragLen; i += G) buf[curStart + i] = tSeq[i];
                     curLen += fragLen; leftOff += fragLen;
-                    if (lane == 0) atomicOr(&a.flags[bTarget], 0x80u);
+                    if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
                 }
             }
             if (leftOff > 0 || rightOff > 0) couldExtend = true;
@@ -328,39 +372,37 @@ __global__ __launch_bounds__(256) void assembleSmallKernel(AsmArgs a) {
             // ---- re-score deferred hits on the extended query (assembleresult.cpp:288-313) ----
             querySeqLen = (unsigned) curLen;
             const char *qs = buf + curStart;
-            unsigned long long deferred = __ballot(xState == 1);
+            unsigned long long deferred = groupBallot<G>(xState == 1);
             if (deferred) waveMemSync();
             while (deferred) {
                 const int dl = __ffsll((long long) deferred) - 1;
                 deferred &= deferred - 1;
-                const uint32_t tg = __shfl(xTarget, dl, 64);
-                const int dqs = __shfl(xQStart, dl, 64), dds = __shfl(xDbStart, dl, 64);
-                const char *tSeq = a.s.data + __shfl(xTOff, dl, 64);
-                const unsigned tLen = __shfl(xTLen, dl, 64);
-                (void) tg;
+                const int dqs = __shfl(xQStart, dl, G), dds = __shfl(xDbStart, dl, G);
+                const char *tSeq = a.s.data + __shfl(xTOff, dl, G);
+                const unsigned tLen = __shfl(xTLen, dl, G);
                 const int diag = (int) ((unsigned) dqs + leftOff) - dds;
-                const Rescored rs = rescoreOnDiagonal(qs, querySeqLen, tSeq, tLen, diag, smat);
-                nResc++; nRescRes += rs.diagonalLen;
+                const Rescored rs = rescoreOnDiagonalG<G>(qs, querySeqLen, tSeq, tLen, diag, smat, gl);
+                nResc += (gl == 0); nRescRes += (gl == 0) ? rs.diagonalLen : 0;
                 const int dist = abs(diag);
                 int qS, qE, dS, dE;
                 if (diag >= 0) { qS = rs.startPos + dist; qE = rs.endPos + dist; dS = rs.startPos; dE = rs.endPos; }
                 else { qS = rs.startPos; qE = rs.endPos; dS = rs.startPos + dist; dE = rs.endPos + dist; }
                 const float seqId = (float) rs.idExcl / ((float) qE - (float) qS);
                 const float spc = (float) rs.score / (float) ((double) rs.diagonalLen + 0.5);
-                if (lane == dl) {
-                    xSeqId = seqId; xQLen = querySeqLen; xDbLen = tLen; xAlnLen = rs.diagonalLen; xScore = (int) (spc * 100);
+                if (gl == dl) {
+                    xQLen = querySeqLen; xDbLen = tLen; xAlnLen = rs.diagonalLen; xScore = (int) (spc * 100);
                     xQStart = qS; xQEnd = qE; xDbStart = dS; xDbEnd = dE;
                     xState = (seqId >= a.seqIdThr) ? 0u : 2u;
                 }
             }
-            inQueue = (uint32_t) __popcll(__ballot(xState == 0));
+            inQueue = (uint32_t) __popcll(groupBallot<G>(xState == 0));
         }
         if (couldExtend) {
-            if (lane == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; }
-            nExt++;
+            if (gl == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; nExt++; }
         }
     }
-    if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
+    nExt = waveReduceSumU64(nExt); nResc = waveReduceSumU64(nResc); nRescRes = waveReduceSumU64(nRescRes);
+    if (laneId() == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
 }
 
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
@@ -464,16 +506,18 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
     a.mat = dMat.as<signed char>(); a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.seqIdThr = par->seq_id_thr; a.maxSeqLen = par->max_seq_len; a.rescoreMode = par->rescore_mode;
     a.stats = dStats.as<unsigned long long>();
-    DevBuf dBigList, dBigCount;
-    if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dBigCount.alloc(4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(dBigCount.p, 0, 4, st));
-    a.bigList = dBigList.as<uint32_t>(); a.bigCount = dBigCount.as<uint32_t>(); a.nBig = 0;
+    DevBuf dBigList, dMidList, dCounts;
+    if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCounts.alloc(8) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 8, st));
+    a.bigList = dBigList.as<uint32_t>(); a.bigCount = dCounts.as<uint32_t>(); a.nBig = 0;
+    a.midList = dMidList.as<uint32_t>(); a.midCount = dCounts.as<uint32_t>() + 1; a.nMid = 0;
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
-    if (N) hipLaunchKernelGGL(assembleSmallKernel, dim3(std::min<uint32_t>((N + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
-    uint32_t nBig = 0;
-    PH_CHECK(hipMemcpyAsync(&nBig, dBigCount.p, 4, hipMemcpyDeviceToHost, st));
+    if (N) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
+    uint32_t cnts[2] = {0, 0};
+    PH_CHECK(hipMemcpyAsync(cnts, dCounts.p, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
-    if (nBig) { a.nBig = nBig; hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(nBig, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a); }
+    if (cnts[1]) { a.nMid = cnts[1]; hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((cnts[1] + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a); }
+    if (cnts[0]) { a.nBig = cnts[0]; hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(cnts[0], (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a); }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     // ---- output DB: extended queries + carried-over sequences, in key order ----
     DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;

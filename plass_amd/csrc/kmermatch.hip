@@ -117,13 +117,39 @@ __device__ void waveBitonicSortCands(Cand *p, uint32_t P, bool nucl) {
     }
 }
 
+// k-mer of the window starting at p from a code accessor (Indexer::int2index / computeKmerIdx + canonical strand,
+// kmermatcher.cpp:149-213); returns false for windows containing X or (nucleotide) reverse-palindromes
+template <bool NUCL, class F>
+__device__ __forceinline__ bool kmerFromCodes(F codeAt, int k, unsigned char xCode, const uint64_t *powers, uint32_t L, uint32_t p,
+                                              uint64_t &kmer, uint32_t &pos) {
+    bool hasX = false; kmer = 0; pos = p;
+    if (NUCL) {
+        uint64_t f = 0;
+        for (int i = 0; i < k; i++) { const unsigned char ci = codeAt(i); hasX |= (ci == xCode); f = (f << 2) | (ci & 3); }
+        const uint64_t r = revComplementDev(f, k);
+        if (hasX || r == f) return false;
+        const bool pickRev = r < f;
+        const uint64_t cc = pickRev ? r : f;
+        kmer = pickRev ? cc : (cc | BIT63);
+        pos = pickRev ? (L - p - k) : p;
+        return true;
+    }
+    for (int i = 0; i < k; i++) { const unsigned char ci = codeAt(i); hasX |= (ci == xCode); kmer += (uint64_t) ci * powers[i]; }
+    return !hasX;
+}
+
+constexpr uint32_t RES_L = 1056;    // sequences up to this length keep their codes (and per-window hash scores) resident in LDS
+
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK>
 __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
     __shared__ unsigned char sMap[256];
     __shared__ unsigned char sCode[64 + 32];
     __shared__ uint32_t sHist[256];
     __shared__ Cand sCand[FALLBACK ? 1 : CAP];
-    __shared__ unsigned long long sSet[FALLBACK ? 1 : 2 * CAP];     // duplicate-k-mer detection without sorting
+    __shared__ unsigned long long sSet[FALLBACK ? 1 : 2 * CAP];     // duplicate-k-mer detection without sorting (after the passes)
+    unsigned short *sScore = reinterpret_cast<unsigned short *>(sSet); // per-window hash scores (during the passes; 2*CAP*8 >= RES_L*2 bytes)
+    __shared__ unsigned char sCodeAll[FALLBACK ? 1 : RES_L + 32];     // codes of a resident sequence
+    __shared__ unsigned long long sValid[RES_L / 64 + 2];            // per-tile validity masks
     typedef Rec<LONG> R;
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
@@ -155,46 +181,54 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
 
         // pass 0: all candidates pushed / or coarse histogram; pass 1: fine histogram; pass 2: push score <= s*
         const int nPass = allCand ? 1 : 3;
+        const bool resident = !FALLBACK && L <= RES_L;      // whole sequence staged once; later passes reuse codes and scores
+        const bool useCache = resident && !allCand;
+        if (resident) {
+            for (uint32_t i = lane; i < L + 31; i += 64) sCodeAll[i] = (i < L) ? sMap[(unsigned char) base[i]] : (unsigned char) a.xCode;
+            __syncthreads();
+        }
         for (int pass = 0; pass < nPass; pass++) {
             if (pass < 2 && !allCand) { for (int i = lane; i < 256; i += 64) sHist[i] = 0; }
             __syncthreads();
             for (uint32_t t0 = 0; t0 < L; t0 += 64) {
-                // stage codes of positions [t0, t0+64+k-1)
                 const uint32_t p = t0 + lane;
-                unsigned char c = (p < L) ? sMap[(unsigned char) base[p]] : (unsigned char) a.xCode;
-                sCode[lane] = c;
-                if (lane < k - 1) { const uint32_t p2 = t0 + 64 + lane; sCode[64 + lane] = (p2 < L) ? sMap[(unsigned char) base[p2]] : (unsigned char) a.xCode; }
-                if (pass == 0) {   // identity hash, tile-wise Horner: h = h*31^m + sum code[j]*31^(m-1-j)
-                    const uint32_t m = min(64u, L - t0);
-                    const uint64_t pw = __shfl(pow31, (int) (m - 1 - min((uint32_t) lane, m - 1)), 64);
-                    uint64_t term = ((uint32_t) lane < m) ? (uint64_t) c * pw : 0ull;
-                    term = waveReduceSumU64(term);
-                    const uint64_t pm = __shfl(pow31, (int) (m - 1), 64) * 31ull;      // 31^m
-                    seqHash = seqHash * pm + term;
-                }
-                __syncthreads();
-                bool valid = (p < nWin);
-                uint64_t kmer = 0; uint32_t pos = p;
-                if (valid) {
-                    bool hasX = false;
-                    if (NUCL) {
-                        uint64_t f = 0;
-                        for (int i = 0; i < k; i++) { const unsigned char ci = sCode[lane + i]; hasX |= (ci == (unsigned char) a.xCode); f = (f << 2) | (ci & 3); }
-                        const uint64_t r = revComplementDev(f, k);
-                        if (hasX || r == f) valid = false;
-                        else {
-                            const bool pickRev = r < f;
-                            const uint64_t cc = pickRev ? r : f;
-                            kmer = pickRev ? cc : (cc | BIT63);
-                            pos = pickRev ? (L - p - k) : p;
-                        }
-                    } else {
-                        for (int i = 0; i < k; i++) { const unsigned char ci = sCode[lane + i]; hasX |= (ci == (unsigned char) a.xCode); kmer += (uint64_t) ci * a.powers[i]; }
-                        if (hasX) valid = false;
+                bool valid; uint64_t kmer = 0; uint32_t pos = p, score = 0;
+                const bool cached = useCache && pass > 0;          // scores come from LDS: no staging, no hashing
+                if (!cached) {
+                    unsigned char c;
+                    if (resident) c = (p < L) ? sCodeAll[p] : (unsigned char) a.xCode;
+                    else {
+                        // stage codes of positions [t0, t0+64+k-1)
+                        c = (p < L) ? sMap[(unsigned char) base[p]] : (unsigned char) a.xCode;
+                        sCode[lane] = c;
+                        if (lane < k - 1) { const uint32_t p2 = t0 + 64 + lane; sCode[64 + lane] = (p2 < L) ? sMap[(unsigned char) base[p2]] : (unsigned char) a.xCode; }
                     }
+                    if (pass == 0) {   // identity hash, tile-wise Horner: h = h*31^m + sum code[j]*31^(m-1-j)
+                        const uint32_t m = min(64u, L - t0);
+                        const uint64_t pw = __shfl(pow31, (int) (m - 1 - min((uint32_t) lane, m - 1)), 64);
+                        uint64_t term = ((uint32_t) lane < m) ? (uint64_t) c * pw : 0ull;
+                        term = waveReduceSumU64(term);
+                        const uint64_t pm = __shfl(pow31, (int) (m - 1), 64) * 31ull;      // 31^m
+                        seqHash = seqHash * pm + term;
+                    }
+                    if (!resident) __syncthreads();
+                    valid = (p < nWin);
+                    if (valid) {
+                        if (resident) valid = kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
+                        else valid = kmerFromCodes<NUCL>([&](int i) { return sCode[lane + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
+                    }
+                    if (valid) score = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
+                    if (useCache) {
+                        if (p < RES_L) sScore[p] = (unsigned short) score;
+                        const unsigned long long vm = __ballot(valid);
+                        if (lane == 0) sValid[t0 >> 6] = vm;
+                    }
+                } else {
+                    valid = ((sValid[t0 >> 6] >> lane) & 1ULL) != 0;
+                    score = valid ? (uint32_t) sScore[p] : 0u;
+                    if (pass == 2 && valid && score <= sStar)      // only the ~60 selected windows rebuild their k-mer
+                        (void) kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                 }
-                uint32_t score = 0;
-                if (valid) score = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
                 bool push = false;
                 if (allCand) push = valid;
                 else if (pass == 0) { if (valid) atomicAdd(&sHist[score >> 8], 1u); }
@@ -623,8 +657,8 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 //    keys in HBM scratch and run-length encode them.  Output: weighted triples in global (rep,target,diagonal) order.
 // =====================================================================================================
 constexpr int LS_BLOCK = 256;
-constexpr uint32_t AGG_CAP = 2048;          // records per bucket handled in LDS (=> at most 2048 distinct triples)
-constexpr uint32_t AGG_HT = 4096;           // hash slots
+constexpr uint32_t AGG_CAP = 1024;          // records per bucket handled in LDS (=> at most 1024 distinct triples)
+constexpr uint32_t AGG_HT = 2048;           // hash slots
 template <bool LONG> struct DiagPack { static constexpr int BITS = LONG ? 22 : 16; static constexpr int64_t BIAS = LONG ? (1 << 21) : 32768; };
 struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag; uint32_t cnt; };   // cnt bit 31: some record of the run is forward-strand
 
@@ -980,7 +1014,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // ---- sort #2: range partition by rep id + local bitonic sort ----
     tm.start(0);
     const int repBits = std::max(1, ceilLog2((uint64_t) N));
-    const int wantBits = std::max(0, ceilLog2((Nm + 1023) / 1024));
+    const int wantBits = std::max(0, ceilLog2((Nm + 511) / 512));
     // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
     const int allowedLocal = 62 - repBits - DiagPack<LONG>::BITS;
     const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
