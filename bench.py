@@ -124,20 +124,17 @@ def main():
 
     import torch
     import plass_amd
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    from plass_amd import dist as pdist
+    rank, local, world = pdist.env_world()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
+    dist = None
+    if world > 1:      # one process per GPU over RCCL ("nccl" backend on ROCm)
+        dist = pdist.init("nccl", rank, world, device=torch.device("cuda", local))
+    plan = pdist.partition_plan(world)
 
-    data, off, elen, key = load_workload(args.pairs, seed=1 + rank)
+    data, off, elen, key = load_workload(args.pairs, seed=plan["seeds"][rank])
     ctx = plass_amd.Context(local)
     db0 = ctx.upload_seqdb(data, off, elen, key, 0)
     n_frag = len(key)
@@ -166,13 +163,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-        oc = torch.tensor([overlaps], dtype=torch.int64, device="cuda")
-        dist.all_reduce(oc, op=dist.ReduceOp.SUM)
-        overlaps = int(oc.item())
+    elapsed, overlaps = pdist.reduce_step(dist, elapsed, overlaps, device="cuda")
 
     if rank == 0:
         # dominant kernel over the timed iterations (rank 0's HIP-event times)
