@@ -690,30 +690,36 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
             t.cnt = val;
             return t;
         };
-        if (cnt <= AGG_CAP) {
+        auto packRec = [&](const R &r, uint32_t &val) {
+            const uint64_t rep = r.kmer & ~BIT63;
+            val = 1u | ((NUCL && (r.kmer & BIT63)) ? 0x80000000u : 0u);
+            return (unsigned long long) (((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS));
+        };
+        auto clearTable = [&]() {
             for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) { hKey[i] = ~0ULL; hVal[i] = 0; }
             if (threadIdx.x == 0) sCount = 0;
             __syncthreads();
-            for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) {
-                const R r = g[s0 + i];
-                const uint64_t rep = r.kmer & ~BIT63;
-                const unsigned long long key = ((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS);
-                uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 40) & (AGG_HT - 1);
-                for (;;) {
-                    const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, key);
-                    if (prev == ~0ULL || prev == key) break;
-                    slot = (slot + 1) & (AGG_HT - 1);
-                }
-                atomicAdd(&hVal[slot], 1u);
-                if (NUCL && (r.kmer & BIT63)) atomicOr(&hVal[slot], 0x80000000u);
+        };
+        auto insert = [&](unsigned long long key, uint32_t val) {      // count adds, strand flag ORs
+            uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 40) & (AGG_HT - 1);
+            for (;;) {
+                const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, key);
+                if (prev == ~0ULL || prev == key) break;
+                slot = (slot + 1) & (AGG_HT - 1);
             }
-            __syncthreads();
+            atomicAdd(&hVal[slot], val & 0x7FFFFFFFu);
+            if (val & 0x80000000u) atomicOr(&hVal[slot], 0x80000000u);
+        };
+        // table -> lKey/lVal (unordered); returns the number of distinct keys (block-uniform)
+        auto extract = [&]() {
             for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) {
                 const unsigned long long k = hKey[i];
                 if (k != ~0ULL) { const uint32_t o = atomicAdd(&sCount, 1u); lKey[o] = k; lVal[o] = hVal[i]; }
             }
             __syncthreads();
-            const uint32_t U = sCount;
+            return sCount;
+        };
+        auto sortListAndWrite = [&](uint32_t U) {
             uint32_t P = 1; while (P < U) P <<= 1;
             for (uint32_t i = U + threadIdx.x; i < P; i += LS_BLOCK) { lKey[i] = ~0ULL; lVal[i] = 0; }
             __syncthreads();
@@ -732,59 +738,92 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
             for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) out[s0 + i] = decode(lKey[i], lVal[i]);
             if (threadIdx.x == 0) uniqueCount[b] = U;
             __syncthreads();
-        } else {
-            // oversized bucket: sort every packed key (strand bit in the LSB) in HBM scratch, then run-length encode
-            uint64_t P = 1; while (P < cnt) P <<= 1;
-            unsigned long long *p = bigScratch + bigOff[b];
-            for (uint64_t i = threadIdx.x; i < P; i += LS_BLOCK) {
-                unsigned long long key = ~0ULL;
-                if (i < cnt) {
-                    const R r = g[s0 + i];
-                    const uint64_t rep = r.kmer & ~BIT63;
-                    key = (((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS)) << 1;
-                    key |= NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL;
-                }
-                p[i] = key;
-            }
+        };
+        if (cnt <= AGG_CAP) {
+            clearTable();
+            for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) { uint32_t v; const unsigned long long key = packRec(g[s0 + i], v); insert(key, v); }
             __syncthreads();
-            for (uint64_t kk = 2; kk <= P; kk <<= 1) {
-                for (uint64_t j = kk >> 1; j > 0; j >>= 1) {
-                    for (uint64_t t = threadIdx.x; t < (P >> 1); t += LS_BLOCK) {
-                        const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-                        const uint64_t l = i | j;
-                        const unsigned long long x = p[i], y = p[l];
-                        const bool up = (i & kk) == 0;
-                        if ((x > y) == up) { p[i] = y; p[l] = x; }
+            sortListAndWrite(extract());
+        } else {
+            // oversized bucket (hot representatives): aggregate chunk by chunk in LDS, spill the partial (key,count)
+            // pairs to HBM scratch, then merge the partials — in LDS again when they fit, else by sorting them in HBM
+            unsigned long long *pk = bigScratch + bigOff[b];           // [2*P]: keys then values
+            uint64_t P0 = 1; while (P0 < cnt) P0 <<= 1;
+            unsigned long long *pv = pk + P0;
+            uint64_t nPart = 0;
+            for (uint64_t c0 = 0; c0 < cnt; c0 += AGG_CAP) {
+                const uint64_t c1 = min(cnt, c0 + (uint64_t) AGG_CAP);
+                clearTable();
+                for (uint64_t i = c0 + threadIdx.x; i < c1; i += LS_BLOCK) { uint32_t v; const unsigned long long key = packRec(g[s0 + i], v); insert(key, v); }
+                __syncthreads();
+                const uint32_t U = extract();
+                for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) { pk[nPart + i] = lKey[i]; pv[nPart + i] = lVal[i]; }
+                nPart += U;
+                __syncthreads();
+            }
+            // second level: distinct keys among the partials
+            bool fits = true;
+            if (nPart <= (uint64_t) AGG_HT) {
+                clearTable();
+                for (uint64_t i = threadIdx.x; i < nPart; i += LS_BLOCK) insert(pk[i], (uint32_t) pv[i]);
+                __syncthreads();
+                // count distinct keys before extracting (the list holds AGG_CAP entries)
+                uint32_t mine = 0;
+                for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) mine += (hKey[i] != ~0ULL) ? 1u : 0u;
+                mine = (uint32_t) waveReduceSum((int) mine);
+                if (laneId() == 0) sWave[threadIdx.x >> 6] = mine;
+                __syncthreads();
+                uint32_t tot = 0;
+#pragma unroll
+                for (int w = 0; w < LS_BLOCK / 64; w++) tot += sWave[w];
+                __syncthreads();
+                fits = tot <= AGG_CAP;
+                if (fits) sortListAndWrite(extract());
+            } else fits = false;
+            if (!fits) {
+                // sort the partial pairs by key in HBM scratch, then merge runs of equal keys
+                uint64_t P = 1; while (P < nPart) P <<= 1;
+                for (uint64_t i = nPart + threadIdx.x; i < P; i += LS_BLOCK) { pk[i] = ~0ULL; pv[i] = 0; }
+                __syncthreads();
+                for (uint64_t kk = 2; kk <= P; kk <<= 1) {
+                    for (uint64_t j = kk >> 1; j > 0; j >>= 1) {
+                        for (uint64_t t = threadIdx.x; t < (P >> 1); t += LS_BLOCK) {
+                            const uint64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                            const uint64_t l = i | j;
+                            const unsigned long long x = pk[i], y = pk[l];
+                            const bool up = (i & kk) == 0;
+                            if ((x > y) == up) { pk[i] = y; pk[l] = x; const unsigned long long vx = pv[i]; pv[i] = pv[l]; pv[l] = vx; }
+                        }
+                        __syncthreads();
                     }
+                }
+                uint32_t written = 0;
+                for (uint64_t i0 = 0; i0 < nPart; i0 += LS_BLOCK) {
+                    const uint64_t i = i0 + threadIdx.x;
+                    bool head = false; Triple t; t.rep = t.target = t.cnt = 0; t.diag = 0;
+                    if (i < nPart) {
+                        const unsigned long long k = pk[i];
+                        head = (i == 0) || (pk[i - 1] != k);
+                        if (head) {
+                            uint32_t c = 0, fwd = 0;
+                            for (uint64_t j = i; j < nPart && pk[j] == k; j++) { c += (uint32_t) pv[j] & 0x7FFFFFFFu; fwd |= (uint32_t) pv[j] & 0x80000000u; }
+                            t = decode(k, c | fwd);
+                        }
+                    }
+                    const unsigned long long mk = __ballot(head);
+                    const uint32_t wr = (uint32_t) __popcll(mk & ((1ULL << laneId()) - 1ULL));
+                    if (laneId() == 0) sWave[threadIdx.x >> 6] = (uint32_t) __popcll(mk);
+                    __syncthreads();
+                    uint32_t woff = 0, tot = 0;
+#pragma unroll
+                    for (int w = 0; w < LS_BLOCK / 64; w++) { if (w < (int) (threadIdx.x >> 6)) woff += sWave[w]; tot += sWave[w]; }
+                    if (head) out[s0 + written + woff + wr] = t;
+                    written += tot;
                     __syncthreads();
                 }
-            }
-            uint32_t written = 0;
-            for (uint64_t i0 = 0; i0 < cnt; i0 += LS_BLOCK) {
-                const uint64_t i = i0 + threadIdx.x;
-                bool head = false; Triple t; t.rep = t.target = t.cnt = 0; t.diag = 0;
-                if (i < cnt) {
-                    const unsigned long long k = p[i] >> 1;
-                    head = (i == 0) || ((p[i - 1] >> 1) != k);
-                    if (head) {
-                        uint32_t c = 0, fwd = 0;
-                        for (uint64_t j = i; j < cnt && (p[j] >> 1) == k; j++) { c++; fwd |= (uint32_t) (p[j] & 1ULL); }
-                        t = decode(k, c | (fwd ? 0x80000000u : 0u));
-                    }
-                }
-                const unsigned long long mk = __ballot(head);
-                const uint32_t wr = (uint32_t) __popcll(mk & ((1ULL << laneId()) - 1ULL));
-                if (laneId() == 0) sWave[threadIdx.x >> 6] = (uint32_t) __popcll(mk);
-                __syncthreads();
-                uint32_t woff = 0, tot = 0;
-#pragma unroll
-                for (int w = 0; w < LS_BLOCK / 64; w++) { if (w < (int) (threadIdx.x >> 6)) woff += sWave[w]; tot += sWave[w]; }
-                if (head) out[s0 + written + woff + wr] = t;
-                written += tot;
+                if (threadIdx.x == 0) uniqueCount[b] = written;
                 __syncthreads();
             }
-            if (threadIdx.x == 0) uniqueCount[b] = written;
-            __syncthreads();
         }
     }
 }
@@ -1071,7 +1110,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         std::vector<uint64_t> bigOff(nSortBuckets, 0); uint64_t bigTot = 0;
         for (uint32_t b = 0; b < nSortBuckets; b++) {
             const uint64_t c = hSortStart[b + 1] - hSortStart[b];
-            if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; bigOff[b] = bigTot; bigTot += P; }
+            if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; bigOff[b] = bigTot; bigTot += 2 * P; }
         }
         if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess ||
             dUnique.alloc(((size_t) nSortBuckets + 1) * 4) != hipSuccess || dTripleStart.alloc(((size_t) nSortBuckets + 2) * 8) != hipSuccess) {
