@@ -90,6 +90,8 @@ struct ExtractArgs {
     uint32_t *overflowIds, *overflowCount;
     // fallback launch: explicit id list and per-sequence global scratch
     const uint32_t *idList; uint32_t nIds; Cand *scratch; const uint64_t *scratchOff; const uint32_t *scratchCap;
+    // regular launch after the one-thread-per-sequence kernel: only the queued ids (count read on the device)
+    const uint32_t *waveList; const uint32_t *waveCount;
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -138,7 +140,7 @@ __device__ __forceinline__ bool kmerFromCodes(F codeAt, int k, unsigned char xCo
     return !hasX;
 }
 
-constexpr uint32_t RES_L = 1056;    // sequences up to this length keep their codes (and per-window hash scores) resident in LDS
+constexpr uint32_t RES_L = 992;     // sequences up to this length keep their codes (and per-window hash scores) resident in LDS
 
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK>
 __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
@@ -159,13 +161,38 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
     uint64_t pow31 = 1;                                    // 31^lane
     for (int i = 0; i < lane; i++) pow31 *= 31;
 
-    const uint32_t nWork = FALLBACK ? a.nIds : a.s.n;
+    const uint32_t nWork = FALLBACK ? a.nIds : (a.waveList ? *a.waveCount : a.s.n);
+    auto idAt = [&](uint32_t w) { return a.waveList ? a.waveList[w] : w; };
+    // software pipeline over sequences (regular launch): the index entry of sequence w+2*grid and the first 128 bytes
+    // of sequence w+grid are in flight while sequence w is processed, so a short read never waits on HBM latency
+    struct Meta { uint32_t L; uint64_t off, slot, slot1; };
+    auto loadMeta = [&](uint32_t id) { Meta m; m.L = a.s.len[id]; m.off = a.s.off[id]; m.slot = a.slotOff[id]; m.slot1 = a.slotOff[id + 1]; return m; };
+    Meta mNext = {0, 0, 0, 0}, mNext2 = {0, 0, 0, 0};
+    char pb0 = 0, pb1 = 0;
+    if (!FALLBACK && blockIdx.x < nWork) {
+        mNext = loadMeta(idAt(blockIdx.x));
+        if (blockIdx.x + gridDim.x < nWork) mNext2 = loadMeta(idAt(blockIdx.x + gridDim.x));
+        if ((uint32_t) lane < mNext.L) pb0 = a.s.data[mNext.off + lane];
+        if ((uint32_t) lane + 64 < mNext.L) pb1 = a.s.data[mNext.off + lane + 64];
+    }
     for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
-        const uint32_t id = FALLBACK ? a.idList[w] : w;
-        const uint32_t L = a.s.len[id];
-        const char *base = a.s.data + a.s.off[id];
-        const uint64_t slot = a.slotOff[id];
-        const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - slot);
+        const uint32_t id = FALLBACK ? a.idList[w] : idAt(w);
+        Meta cur;
+        char cb0 = 0, cb1 = 0;
+        if (FALLBACK) cur = loadMeta(id);
+        else {
+            cur = mNext; cb0 = pb0; cb1 = pb1;
+            mNext = mNext2;
+            if (w + gridDim.x < nWork) {
+                pb0 = ((uint32_t) lane < mNext.L) ? a.s.data[mNext.off + lane] : (char) 0;
+                pb1 = ((uint32_t) lane + 64 < mNext.L) ? a.s.data[mNext.off + lane + 64] : (char) 0;
+            }
+            if (w + 2 * gridDim.x < nWork) mNext2 = loadMeta(idAt(w + 2 * gridDim.x));
+        }
+        const uint32_t L = cur.L;
+        const char *base = a.s.data + cur.off;
+        const uint64_t slot = cur.slot;
+        const uint32_t bound = (uint32_t) (cur.slot1 - slot);
         Cand *cand = FALLBACK ? (a.scratch + a.scratchOff[w]) : sCand;
         const uint32_t cap = FALLBACK ? a.scratchCap[w] : (uint32_t) CAP;
         const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
@@ -184,7 +211,10 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
         const bool resident = !FALLBACK && L <= RES_L;      // whole sequence staged once; later passes reuse codes and scores
         const bool useCache = resident && !allCand;
         if (resident) {
-            for (uint32_t i = lane; i < L + 31; i += 64) sCodeAll[i] = (i < L) ? sMap[(unsigned char) base[i]] : (unsigned char) a.xCode;
+            for (uint32_t i = lane; i < L + 31; i += 64) {
+                const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < L) ? base[i] : (char) 0));      // first 128 bytes were prefetched
+                sCodeAll[i] = (i < L) ? sMap[(unsigned char) ch] : (unsigned char) a.xCode;
+            }
             __syncthreads();
         }
         for (int pass = 0; pass < nPass; pass++) {
@@ -387,6 +417,103 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
             arr[slot + i] = r;
         }
         __syncthreads();
+    }
+}
+
+// =====================================================================================================
+// 2b. short protein sequences, ONE THREAD per sequence.
+//     When a sequence has no more valid k-mers than kmermatcher would consider (n <= kmer-per-seq - 1 + scale*L, true
+//     for every <= ~72-residue read fragment), the reference selects ALL its k-mers unless one repeats inside the
+//     sequence.  Then no per-sequence threshold, sort or wave coordination is needed: a lane rolls the k-mer index
+//     along its sequence (exact division by the alphabet base via the modular inverse), hashes, and writes its slot
+//     range.  Sequences that are longer, or in which two k-mers share a 16-bit hash score (possible repeat), are
+//     queued for the wave-per-sequence kernel, which then owns their slot range.  ~60 instructions per sequence
+//     instead of ~850 wave-instructions.
+// =====================================================================================================
+constexpr uint32_t SHORT_MAXL = 128;
+struct ShortArgs {
+    SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map;
+    int k, xCode, kps, ignoreMulti; float scale; uint64_t seed;
+    uint64_t base, top, inv; int tz;     // alphabet base; base^(k-1); exact division by base = (x >> tz) * inv
+    uint32_t *waveList, *waveCount;
+};
+
+template <bool LONG>
+__global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
+    __shared__ unsigned char sMap[256];
+    __shared__ __attribute__((aligned(16))) unsigned short sSet[64 * 128];   // per-lane open-addressing set of (score + 1)
+    typedef Rec<LONG> R;
+    R *arr = reinterpret_cast<R *>(a.arr);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
+    __syncthreads();
+    unsigned short *mySet = sSet + lane * 128;
+    const int k = a.k;
+    for (uint32_t b0 = blockIdx.x * 64; b0 < a.s.n; b0 += gridDim.x * 64) {
+        const uint32_t id = b0 + lane;
+        const bool active = id < a.s.n;
+        bool toWave = false;
+        if (active) {
+            const uint32_t L = a.s.len[id];
+            const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
+            const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));
+            if (L > SHORT_MAXL || (size_t) nWin > consideredRaw) toWave = true;
+            else {
+                const char *base = a.s.data + a.s.off[id];
+                const uint64_t slot = a.slotOff[id];
+                const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - slot);
+                if (a.ignoreMulti) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 16; i++) q[i] = z; }
+                uint64_t idx = 0, seqHash = 0, fifoLo = 0, fifoHi = 0;   // fifo: the k codes of the current window, 8 bits each
+                uint64_t pw = 1;
+                int lastX = -1;
+                uint32_t nOut = 0;
+                uint32_t word = 0;
+                for (uint32_t i = 0; i < L; i++) {
+                    if ((i & 3) == 0) __builtin_memcpy(&word, base + i, 4);                 // buffer is padded past its end
+                    const unsigned char c = sMap[(word >> (8 * (i & 3))) & 0xFF];
+                    seqHash = seqHash * 31 + c;
+                    if (c == (unsigned char) a.xCode) lastX = (int) i;
+                    if (i < (uint32_t) k) {                         // first window: idx = sum code[i] * base^i
+                        idx += (uint64_t) c * pw; pw *= a.base;
+                        if (i < 8) fifoLo |= (uint64_t) c << (8 * i); else fifoHi |= (uint64_t) c << (8 * (i - 8));
+                    } else {                                        // roll: drop the oldest digit, append the new one on top
+                        const uint64_t cOut = fifoLo & 0xFF;
+                        idx = (((idx - cOut) >> a.tz) * a.inv) + (uint64_t) c * a.top;
+                        fifoLo = (fifoLo >> 8) | (fifoHi << 56); fifoHi >>= 8;
+                        if (k - 1 < 8) fifoLo |= (uint64_t) c << (8 * (k - 1)); else fifoHi |= (uint64_t) c << (8 * (k - 1 - 8));
+                    }
+                    if (i + 1 >= (uint32_t) k) {
+                        const uint32_t p = i + 1 - k;
+                        if (lastX < (int) p) {
+                            const uint32_t score = (uint32_t) (xxh64U64(idx, a.seed) & 0xFFFFu);
+                            if (a.ignoreMulti) {
+                                const unsigned short tag = (unsigned short) (score + 1);
+                                if (tag == 0) toWave = true;
+                                uint32_t sl = (score * 40503u >> 7) & 127;
+                                for (;;) { const unsigned short v = mySet[sl]; if (v == tag) { toWave = true; break; } if (v == 0) { mySet[sl] = tag; break; } sl = (sl + 1) & 127; }
+                            }
+                            R r; r.kmer = idx; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) p;
+                            if constexpr (LONG) r.pad = 0;
+                            arr[slot + 1 + nOut] = r; nOut++;
+                        }
+                    }
+                }
+                if (!toWave) {
+                    R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
+                    if constexpr (LONG) r.pad = 0;
+                    arr[slot] = r;
+                    R sen; memset(&sen, 0xFF, sizeof(R));
+                    for (uint32_t i = 1 + nOut; i < bound; i++) arr[slot + i] = sen;
+                }
+            }
+        }
+        const unsigned long long m = __ballot(toWave);
+        if (m) {
+            uint32_t basePos = 0;
+            if (lane == 0) basePos = atomicAdd(a.waveCount, (uint32_t) __popcll(m));
+            basePos = __shfl(basePos, 0, 64);
+            if (toWave) a.waveList[basePos + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL))] = id;
+        }
     }
 }
 
@@ -950,8 +1077,21 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     { uint64_t p = 1; for (int i = 0; i < 24; i++) { ea.powers[i] = p; p *= (uint64_t) (alph - 1); } }
     ea.k = k; ea.xCode = map[(int) 'X']; ea.kps = par->kmers_per_seq; ea.ignoreMulti = par->ignore_multi_kmer; ea.scale = par->kmers_per_seq_scale;
     ea.seed = (uint64_t) par->hash_shift; ea.overflowIds = dOvIds.as<uint32_t>(); ea.overflowCount = dOvCnt.as<uint32_t>();
-    constexpr int CAP = NUCL ? 1024 : 256;
+    constexpr int CAP = NUCL ? 1024 : 128;     // candidate k-mers per sequence held in LDS (more: HBM-scratch launch)
+    DevBuf dWaveList, dWaveCount;
+    if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dWaveCount.p, 0, 4, st));
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
+    if (!NUCL && k <= 16 && N) {
+        // short sequences: one thread each; everything else is queued for the wave-per-sequence kernel
+        ShortArgs sa; memset(&sa, 0, sizeof(sa));
+        sa.s = ea.s; sa.slotOff = ea.slotOff; sa.arr = ea.arr; sa.map = ea.map; sa.k = k; sa.xCode = ea.xCode; sa.kps = ea.kps; sa.ignoreMulti = ea.ignoreMulti;
+        sa.scale = ea.scale; sa.seed = ea.seed; sa.base = (uint64_t) (alph - 1); sa.top = ea.powers[k - 1];
+        { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
+        sa.waveList = dWaveList.as<uint32_t>(); sa.waveCount = dWaveCount.as<uint32_t>();
+        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((N + 63) / 64, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, sa);
+        ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
+    }
     if (N) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     uint32_t nOv = 0;
