@@ -5,8 +5,8 @@ A "step" is one assembly iteration of the hot path — kmermatcher -> rescoredia
 the synthetic protein-fragment DB of BASELINE.json configs[1] (1 M synthetic 2x150 bp protein-coding reads,
 500 k pairs, ~1.6 M protein fragments), chained on the device like `plass assemble --num-iterations K`
 (iteration 0: --hash-shift 67 --include-only-extendable 0; later: 68,68,69,… and 1; src/workflow/Assembler.cpp:99-110).
-The input DB is resident in HBM before the timed region; W warm-up iterations (iteration 0 on the same DB,
-results discarded) run first.  value = sum over the K timed iterations of the candidate overlaps kmermatcher
+The input DB is resident in HBM before the timed region; each of the W warm-up steps is one untimed traversal of
+the same K-iteration chain (results discarded), so every iteration's kernels and buffers are warm.  value = sum over the K timed iterations of the candidate overlaps kmermatcher
 emitted (non-self prefilter lines) / wall time, max over ranks, summed over ranks.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU): every rank assembles its own partition of the
@@ -74,18 +74,21 @@ def one_iteration(ctx, db, it):
 
 
 def stage_table(kst, rst, ast):
-    """per stage: (HIP-event ms, algorithmic bytes per SURVEY.md §8d)"""
+    """per kernel / stage: (HIP-event ms, algorithmic bytes per SURVEY.md §8d, is_single_kernel)"""
     s = kst.record_bytes
-    R, Nk, Nm, Nc = kst.residues, kst.n_kmer_records, kst.n_grouped, kst.n_candidates
-    return {
-        "extract_kernel": (kst.ms_extract_kernel, R + s * Nk),
-        "hash_partition": (kst.ms_sort1, 2 * s * Nk),
-        "group_kernel": (kst.ms_group, s * Nk + s * Nm),
-        "rep_sort": (kst.ms_sort2, 2 * s * Nm),
-        "run_reduce": (kst.ms_reduce, s * Nm + 12 * Nc),
-        "rescore_kernel": (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored),
-        "assemble_kernel": (ast.ms_assemble_kernel, 32 * ast.n_alignments + 2 * R + 2 * ast.rescored_residues),
+    Nk, Nm, Nc = kst.n_kmer_records, kst.n_grouped, kst.n_candidates
+    t = {
+        "extractShortKernel": (kst.ms_extract_short_kernel, kst.short_residues + s * kst.short_records, True),
+        "extractKernel": (kst.ms_extract_wave_kernel, kst.wave_residues + s * kst.wave_records, True),
+        "hash_partition(partHist+partScatter x levels)": (kst.ms_sort1, 2 * s * Nk, False),
+        "groupKernel": (kst.ms_group, s * Nk + s * Nm, True),
+        "rep_sort(partition+aggSortKernel)": (kst.ms_sort2, 2 * s * Nm, False),
+        "run_reduce(reduceRunsKernel+CSR)": (kst.ms_reduce, s * Nm + 12 * Nc, False),
+        "rescoreKernel": (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored, True),
     }
+    for i, name in enumerate(("assembleGroupKernel<16>", "assembleGroupKernel<64>", "assembleBigKernel")):
+        t[name] = (ast.ms_tier_kernel[i], 32 * ast.tier_alignments[i] + 2 * ast.tier_query_residues[i] + 2 * ast.tier_rescored_residues[i], True)
+    return t
 
 
 def cpu_baseline(sample_pairs, iters):
@@ -145,9 +148,17 @@ def main():
             dist.barrier()
         ctx.sync(); torch.cuda.synchronize()
 
+    # warm-up: W untimed traversals of the same K-iteration chain (iteration i of the chain works on the output of
+    # iteration i-1, so warming with iteration 0 alone would leave the later iterations' kernels, tiers and buffer sizes cold)
     for _ in range(args.warmup):
-        out, _, _, _ = one_iteration(ctx, db0, 0)
-        out.free()
+        wdb = db0
+        for it in range(args.steps):
+            out, _, _, _ = one_iteration(ctx, wdb, it)
+            if wdb is not db0:
+                wdb.free()
+            wdb = out
+        if wdb is not db0:
+            wdb.free()
     barrier()
     t0 = time.perf_counter()
     db = db0
@@ -169,10 +180,10 @@ def main():
         # dominant kernel over the timed iterations (rank 0's HIP-event times)
         tot = {}
         for st in stats:
-            for k, (ms, b) in st.items():
-                a = tot.setdefault(k, [0.0, 0])
+            for k, (ms, b, single) in st.items():
+                a = tot.setdefault(k, [0.0, 0, single])
                 a[0] += ms; a[1] += b
-        dom = max(tot, key=lambda k: tot[k][0])
+        dom = max((k for k in tot if tot[k][2]), key=lambda k: tot[k][0])
         ms_avg = tot[dom][0] / len(stats)
         bytes_avg = tot[dom][1] / len(stats)
         achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0

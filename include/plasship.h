@@ -87,8 +87,11 @@ typedef struct plasship_kmermatch_stats {
     uint64_t n_candidates;     /* N_c: non-self prefilter lines                                  */
     uint32_t record_bytes;     /* 16 (T=short) or 20 (T=int) in the reference layout             */
     float ms_extract, ms_sort1, ms_group, ms_sort2, ms_reduce; /* HIP-event stage times (incl. scans)  */
-    float ms_extract_kernel;   /* the extraction kernel launch alone (HIP events on the ctx stream)  */
+    float ms_extract_kernel;   /* both extraction kernel launches (HIP events on the ctx stream)     */
     uint64_t residues;         /* R: residues read by the extraction                              */
+    /* per kernel: one-thread-per-sequence kernel (short reads) and wave-per-sequence kernel (the rest) */
+    float ms_extract_short_kernel, ms_extract_wave_kernel;
+    uint64_t short_residues, short_records, wave_residues, wave_records;
 } plasship_kmermatch_stats;
 
 int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par,
@@ -164,6 +167,9 @@ typedef struct plasship_assemble_stats {
     float ms_assemble_kernel;   /* the per-query extension kernel alone                              */
     uint64_t n_alignments;      /* alignment lines consumed                                          */
     uint64_t rescored_residues; /* overlap residues re-scored                                        */
+    /* per kernel tier: [0] 16 lanes per query (<= 16 alignments), [1] one wave per query (17..64), [2] HBM queue (> 64) */
+    float ms_tier_kernel[3];
+    uint64_t tier_alignments[3], tier_query_residues[3], tier_rescored_residues[3];
 } plasship_assemble_stats;
 
 int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *a,

@@ -24,7 +24,8 @@ class KmermatchStats(C.Structure):
     _fields_ = [("n_kmer_records", C.c_uint64), ("n_grouped", C.c_uint64), ("n_candidates", C.c_uint64),
                 ("record_bytes", C.c_uint32), ("ms_extract", C.c_float), ("ms_sort1", C.c_float),
                 ("ms_group", C.c_float), ("ms_sort2", C.c_float), ("ms_reduce", C.c_float), ("ms_extract_kernel", C.c_float),
-                ("residues", C.c_uint64)]
+                ("residues", C.c_uint64), ("ms_extract_short_kernel", C.c_float), ("ms_extract_wave_kernel", C.c_float),
+                ("short_residues", C.c_uint64), ("short_records", C.c_uint64), ("wave_residues", C.c_uint64), ("wave_records", C.c_uint64)]
 
 
 class _RescoreParams(C.Structure):
@@ -43,7 +44,9 @@ class _AssembleParams(C.Structure):
 
 class AssembleStats(C.Structure):
     _fields_ = [("n_extended", C.c_uint64), ("n_rescored", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float),
-                ("ms_assemble_kernel", C.c_float), ("n_alignments", C.c_uint64), ("rescored_residues", C.c_uint64)]
+                ("ms_assemble_kernel", C.c_float), ("n_alignments", C.c_uint64), ("rescored_residues", C.c_uint64),
+                ("ms_tier_kernel", C.c_float * 3), ("tier_alignments", C.c_uint64 * 3), ("tier_query_residues", C.c_uint64 * 3),
+                ("tier_rescored_residues", C.c_uint64 * 3)]
 
 
 class AlnRecord(C.Structure):

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
     for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
     __syncthreads();
     const int lane = threadIdx.x;
-    unsigned long long nExt = 0, nResc = 0, nRescRes = 0;
+    unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
     for (uint32_t w = blockIdx.x; w < a.nBig; w += gridDim.x) {
         const uint32_t id = a.bigList[w];
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
         Item *it = a.items + h0;
         const char *orig = a.s.data + a.s.off[id];
         unsigned querySeqLen = a.s.len[id];
+        nAln += h; nQRes += querySeqLen;
         // ---- queue fill (assembleresult.cpp:161-189) ----
         for (uint32_t i = lane; i < h; i += 64) {
             const AlnRec r = a.recs[h0 + i];
@@ -228,7 +229,10 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
         }
         __syncthreads();
     }
-    if (lane == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
+    if (lane == 0) {
+        if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes);
+        if (nAln) { atomicAdd(&a.stats[9], nAln); atomicAdd(&a.stats[10], nQRes); atomicAdd(&a.stats[11], nRescRes); }
+    }
 }
 
 // ---- the common cases: the whole queue of a query lives in registers, one alignment per lane.
@@ -282,7 +286,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
     const int gl = threadIdx.x & (G - 1);                         // lane within the group
     const uint32_t groupsTotal = gridDim.x * (256 / G);
     const uint32_t nWork = (G == 64) ? a.nMid : a.s.n;
-    unsigned long long nExt = 0, nResc = 0, nRescRes = 0;
+    unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
     for (uint32_t w = blockIdx.x * (256 / G) + threadIdx.x / G; w < nWork; w += groupsTotal) {
         const uint32_t id = (G == 64) ? a.midList[w] : w;
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
@@ -296,6 +300,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
         }
         const char *orig = a.s.data + a.s.off[id];
         unsigned querySeqLen = a.s.len[id];
+        if (gl == 0) { nAln += h; nQRes += querySeqLen; }
         // ---- queue fill (assembleresult.cpp:161-189): lane i owns alignment i ----
         uint32_t xTarget = 0xFFFFFFFFu, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2, xTLen = 0; uint64_t xTOff = 0;
         int xScore = 0, xQStart = 0, xQEnd = 0, xDbStart = 0, xDbEnd = 0;
@@ -401,8 +406,12 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
             if (gl == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; nExt++; }
         }
     }
-    nExt = waveReduceSumU64(nExt); nResc = waveReduceSumU64(nResc); nRescRes = waveReduceSumU64(nRescRes);
-    if (laneId() == 0) { if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes); }
+    nExt = waveReduceSumU64(nExt); nResc = waveReduceSumU64(nResc); nRescRes = waveReduceSumU64(nRescRes); nAln = waveReduceSumU64(nAln); nQRes = waveReduceSumU64(nQRes);
+    if (laneId() == 0) {
+        if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes);
+        const int tier = (G == 16) ? 0 : 1;
+        if (nAln) { atomicAdd(&a.stats[3 + 3 * tier], nAln); atomicAdd(&a.stats[4 + 3 * tier], nQRes); atomicAdd(&a.stats[5 + 3 * tier], nRescRes); }
+    }
 }
 
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
@@ -485,12 +494,12 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     const size_t tmpBytes = exclusiveScanTmpBytes((size_t) N + 2);
     if (dLeftCap.alloc(((size_t) N + 1) * 4) != hipSuccess || dBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dArenaOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
         dTmp.alloc(tmpBytes) != hipSuccess || dItems.alloc(std::max<uint64_t>(nLines, 1) * sizeof(Item)) != hipSuccess || dFlags.alloc(((size_t) N + 1) * 4) != hipSuccess ||
-        dNewLen.alloc(((size_t) N + 1) * 4) != hipSuccess || dNewStart.alloc(((size_t) N + 1) * 8) != hipSuccess || dMat.alloc(123 * 123) != hipSuccess || dStats.alloc(32) != hipSuccess) {
+        dNewLen.alloc(((size_t) N + 1) * 4) != hipSuccess || dNewStart.alloc(((size_t) N + 1) * 8) != hipSuccess || dMat.alloc(123 * 123) != hipSuccess || dStats.alloc(128) != hipSuccess) {
         setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync(dFlags.p, 0, ((size_t) N + 1) * 4, st));
     PH_CHECK(hipMemsetAsync(dNewLen.p, 0, ((size_t) N + 1) * 4, st));
-    PH_CHECK(hipMemsetAsync(dStats.p, 0, 32, st));
+    PH_CHECK(hipMemsetAsync(dStats.p, 0, 128, st));
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(false), 123 * 123, hipMemcpyHostToDevice, st));
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
@@ -513,12 +522,16 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.midList = dMidList.as<uint32_t>(); a.midCount = dCounts.as<uint32_t>() + 1; a.nMid = 0;
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     if (N) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
+    PH_CHECK(hipEventRecord(ctx->ev[3], st));
     uint32_t cnts[2] = {0, 0};
     PH_CHECK(hipMemcpyAsync(cnts, dCounts.p, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipEventRecord(ctx->ev[4], st));
     if (cnts[1]) { a.nMid = cnts[1]; hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((cnts[1] + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a); }
+    PH_CHECK(hipEventRecord(ctx->ev[5], st));
+    PH_CHECK(hipEventRecord(ctx->ev[6], st));
     if (cnts[0]) { a.nBig = cnts[0]; hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(cnts[0], (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a); }
-    PH_CHECK(hipEventRecord(ctx->ev[3], st));
+    PH_CHECK(hipEventRecord(ctx->ev[7], st));
     // ---- output DB: extended queries + carried-over sequences, in key order ----
     DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;
     if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
@@ -543,17 +556,22 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
     if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
-    uint32_t maxLen = 0; unsigned long long hs[4] = {0, 0, 0, 0};
+    uint32_t maxLen = 0; unsigned long long hs[16] = {0};
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
     PH_CHECK(hipMemcpyAsync(&maxLen, dMaxLen.p, 4, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipMemcpyAsync(hs, dStats.p, 32, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hs, dStats.p, 128, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
     o->maxEntryLen = maxLen + 2;
     if (stats) {
         stats->n_extended = hs[0]; stats->n_rescored = hs[1]; stats->out_residues = o->residues;
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
-        ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); stats->ms_assemble_kernel = ms;
+        float sum = 0;
+        for (int t = 0; t < 3; t++) {
+            ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2 + 2 * t], ctx->ev[3 + 2 * t]); stats->ms_tier_kernel[t] = ms; sum += ms;
+            stats->tier_alignments[t] = hs[3 + 3 * t]; stats->tier_query_residues[t] = hs[4 + 3 * t]; stats->tier_rescored_residues[t] = hs[5 + 3 * t];
+        }
+        stats->ms_assemble_kernel = sum;
         stats->n_alignments = nLines; stats->rescored_residues = hs[2];
     }
     *out = o;

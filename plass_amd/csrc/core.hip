@@ -4,6 +4,8 @@
 #include "common.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -18,6 +20,7 @@ std::mutex g_poolMu;
 std::multimap<size_t, void *> g_poolFree;            // size class -> cached block
 std::unordered_map<void *, size_t> g_poolLive;       // block -> size class
 int g_ctxCount = 0;
+size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
 size_t sizeClass(size_t n) {
     if (n < 4096) return 4096;
     int e = 63 - __builtin_clzll((unsigned long long) n);      // 2^e <= n
@@ -33,12 +36,14 @@ hipError_t poolMalloc(void **p, size_t n) {
         // (iterations shrink and grow their arrays; an exact-class match would miss and fall into hipMalloc)
         auto it = g_poolFree.lower_bound(c);
         if (it != g_poolFree.end() && (it->first <= 8 * c || it->first <= (size_t) 1 << 20)) {
-            *p = it->second; const size_t got = it->first; g_poolFree.erase(it); g_poolLive[*p] = got; return hipSuccess;
+            *p = it->second; const size_t got = it->first; g_poolFree.erase(it); g_poolLive[*p] = got; g_poolHits++; return hipSuccess;
         }
     }
+    const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, c);
     if (e != hipSuccess) { (void) hipGetLastError(); poolTrim(); e = hipMalloc(p, c); }
-    if (e == hipSuccess) { std::lock_guard<std::mutex> g(g_poolMu); g_poolLive[*p] = c; }
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(g_poolMu); g_poolLive[*p] = c; g_poolMisses++; g_poolMissMs += ms; g_poolMissBytes += (double) c; }
     return e;
 }
 void poolFree(void *p) {
@@ -97,7 +102,10 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     bool last; { std::lock_guard<std::mutex> g(g_poolMu); last = (--g_ctxCount <= 0); }
-    if (last) poolTrim();
+    if (last) {
+        if (getenv("PLASSHIP_POOL_STATS")) fprintf(stderr, "plasship pool: %zu hits, %zu misses (%.1f ms in hipMalloc, %.1f MB)\n", g_poolHits, g_poolMisses, g_poolMissMs, g_poolMissBytes / 1e6);
+        poolTrim();
+    }
     delete ctx;
 }
 

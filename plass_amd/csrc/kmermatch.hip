@@ -92,6 +92,7 @@ struct ExtractArgs {
     const uint32_t *idList; uint32_t nIds; Cand *scratch; const uint64_t *scratchOff; const uint32_t *scratchCap;
     // regular launch after the one-thread-per-sequence kernel: only the queued ids (count read on the device)
     const uint32_t *waveList; const uint32_t *waveCount;
+    unsigned long long *kstats;     // [2] residues, [3] records handled by the wave-per-sequence kernel (incl. its HBM-scratch launch)
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -159,6 +160,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
     for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
     __syncthreads();
     uint64_t pow31 = 1;                                    // 31^lane
+    unsigned long long stRes = 0, stRec = 0;
     for (int i = 0; i < lane; i++) pow31 *= 31;
 
     const uint32_t nWork = FALLBACK ? a.nIds : (a.waveList ? *a.waveCount : a.s.n);
@@ -350,6 +352,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
                 arr[slot] = r;
             }
             for (uint32_t i = 1 + C + lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; }
+            stRes += L; stRec += 1 + C;
             __syncthreads();
             continue;
         }
@@ -416,8 +419,10 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
             R r; memset(&r, 0xFF, sizeof(R));
             arr[slot + i] = r;
         }
+        stRes += L; stRec += 1 + numSel;
         __syncthreads();
     }
+    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
 }
 
 // =====================================================================================================
@@ -436,6 +441,7 @@ struct ShortArgs {
     int k, xCode, kps, ignoreMulti; float scale; uint64_t seed;
     uint64_t base, top, inv; int tz;     // alphabet base; base^(k-1); exact division by base = (x >> tz) * inv
     uint32_t *waveList, *waveCount;
+    unsigned long long *kstats;          // [0] residues, [1] records handled by this kernel
 };
 
 template <bool LONG>
@@ -449,6 +455,7 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
     __syncthreads();
     unsigned short *mySet = sSet + lane * 128;
     const int k = a.k;
+    unsigned long long stRes = 0, stRec = 0;
     for (uint32_t b0 = blockIdx.x * 64; b0 < a.s.n; b0 += gridDim.x * 64) {
         const uint32_t id = b0 + lane;
         const bool active = id < a.s.n;
@@ -504,6 +511,7 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                     arr[slot] = r;
                     R sen; memset(&sen, 0xFF, sizeof(R));
                     for (uint32_t i = 1 + nOut; i < bound; i++) arr[slot + i] = sen;
+                    stRes += L; stRec += 1 + nOut;
                 }
             }
         }
@@ -515,6 +523,8 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
             if (toWave) a.waveList[basePos + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL))] = id;
         }
     }
+    stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
+    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
 }
 
 __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
@@ -1078,9 +1088,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     ea.k = k; ea.xCode = map[(int) 'X']; ea.kps = par->kmers_per_seq; ea.ignoreMulti = par->ignore_multi_kmer; ea.scale = par->kmers_per_seq_scale;
     ea.seed = (uint64_t) par->hash_shift; ea.overflowIds = dOvIds.as<uint32_t>(); ea.overflowCount = dOvCnt.as<uint32_t>();
     constexpr int CAP = NUCL ? 1024 : 128;     // candidate k-mers per sequence held in LDS (more: HBM-scratch launch)
-    DevBuf dWaveList, dWaveCount;
-    if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    DevBuf dWaveList, dWaveCount, dKStats;
+    if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess || dKStats.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dWaveCount.p, 0, 4, st));
+    PH_CHECK(hipMemsetAsync(dKStats.p, 0, 32, st));
+    ea.kstats = dKStats.as<unsigned long long>();
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     if (!NUCL && k <= 16 && N) {
         // short sequences: one thread each; everything else is queued for the wave-per-sequence kernel
@@ -1088,12 +1100,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         sa.s = ea.s; sa.slotOff = ea.slotOff; sa.arr = ea.arr; sa.map = ea.map; sa.k = k; sa.xCode = ea.xCode; sa.kps = ea.kps; sa.ignoreMulti = ea.ignoreMulti;
         sa.scale = ea.scale; sa.seed = ea.seed; sa.base = (uint64_t) (alph - 1); sa.top = ea.powers[k - 1];
         { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
-        sa.waveList = dWaveList.as<uint32_t>(); sa.waveCount = dWaveCount.as<uint32_t>();
+        sa.waveList = dWaveList.as<uint32_t>(); sa.waveCount = dWaveCount.as<uint32_t>(); sa.kstats = dKStats.as<unsigned long long>();
         hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((N + 63) / 64, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, sa);
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
     }
-    if (N) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
+    PH_CHECK(hipEventRecord(ctx->ev[4], st));
+    if (N) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
+    PH_CHECK(hipEventRecord(ctx->ev[5], st));
     uint32_t nOv = 0;
     PH_CHECK(hipMemcpyAsync(&nOv, dOvCnt.p, 4, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
@@ -1122,7 +1136,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // ---- hash partition (replaces sort #1) ----
     tm.start(0);
     const int totalBits = std::max(0, ceilLog2((total + 767) / 768));          // ~768 records per final bucket
-    const int b1 = std::min(totalBits, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
+    // coarse level first: few wide buckets => every tile writes long contiguous runs; the fine level then scatters inside a
+    // bucket that fits the L2 / Infinity Cache
+    const int b2w = (totalBits > 11) ? 11 : 0;
+    const int b1 = std::min(totalBits - b2w, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
     const uint32_t nB1 = 1u << b1, nB = 1u << (b1 + b2);
     DevBuf dCnt1, dStart1, dCur1, dSeg0Start, dSeg0Cnt, dMinKey, dCnt2, dStart2, dCur2, dSegCnt1;
     if (dCnt1.alloc((size_t) nB1 * 4) != hipSuccess || dStart1.alloc(((size_t) nB1 + 1) * 8) != hipSuccess || dCur1.alloc((size_t) nB1 * 8) != hipSuccess ||
@@ -1198,7 +1215,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const int allowedLocal = 62 - repBits - DiagPack<LONG>::BITS;
     const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
     if (sBits > 22) { setError("kmermatch: too many sequences for the packed rep-sort key"); return PLASSHIP_ERR_UNSUPPORTED; }
-    const int s1 = std::min(sBits, 11), s2 = std::min(std::max(sBits - s1, 0), 11);
+    const int s2w = (sBits > 11) ? 11 : 0;
+    const int s1 = std::min(sBits - s2w, 11), s2 = std::min(std::max(sBits - s1, 0), 11);
     const uint32_t nS1 = 1u << s1, nS = 1u << (s1 + s2);
     DevBuf dRC1, dRS1, dRCur1, dRSegCnt, dRC2, dRS2, dRCur2;
     if (dRC1.alloc((size_t) nS1 * 4) != hipSuccess || dRS1.alloc(((size_t) nS1 + 1) * 8) != hipSuccess || dRCur1.alloc((size_t) nS1 * 8) != hipSuccess ||
@@ -1297,7 +1315,13 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipGetLastError());
     if (stats) {
         stats->n_kmer_records = Nk; stats->n_grouped = Nm; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
-        { float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); stats->ms_extract_kernel = ms; }
+        {
+            float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
+            stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;
+            unsigned long long ks[4] = {0, 0, 0, 0};
+            PH_CHECK(hipMemcpy(ks, dKStats.p, 32, hipMemcpyDeviceToHost));
+            stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
+        }
         stats->residues = db->residues;
         stats->ms_extract = msExtract; stats->ms_sort1 = msSort1; stats->ms_group = msGroup; stats->ms_sort2 = msSort2; stats->ms_reduce = msReduce;
     }
