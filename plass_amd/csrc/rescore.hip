@@ -40,6 +40,7 @@ struct RescoreArgs {
     float seqIdThr; int alnLenThr, seqIdMode;
     double lambda, logK, ln2;
     unsigned long long *stats;   // [0] accepted, [1] overlap residues
+    unsigned long long *longList, *longCount;   // hit indices queued for the 16-lane kernel
 };
 
 __device__ __forceinline__ bool canBeCoveredDev(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -77,11 +78,13 @@ __device__ __forceinline__ char nuclRevCompChar(char c) {
 }
 
 constexpr int RS_BLOCK = 256;
-constexpr int RS_GROUP = 16;      // lanes per candidate pair: a 50-residue read overlap is one 64-byte step
+// lanes per candidate pair: G = 1 (one thread per pair: short read overlaps, ~6 wave-instructions per pair)
+// or G = 16 (long overlaps, queued by the first kernel)
+constexpr uint32_t RS_SHORT_MAX = 512;   // min(qLen, tLen) handled by one thread
 
-__device__ __forceinline__ int groupReduceSum16(int v) {
+template <int G> __device__ __forceinline__ int groupReduceSumG(int v) {
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 16);
+    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
     return v;
 }
 __device__ __forceinline__ uint32_t loadU32Unaligned(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
@@ -90,7 +93,7 @@ __device__ __forceinline__ uint32_t loadU32Unaligned(const char *p) { uint32_t w
 // score/first/last/idCnt; valid=false if the diagonal does not intersect.  Mode 3 only.
 struct DiagScore { bool valid; unsigned score; int first, last; unsigned diagLen; int idCnt; };
 
-template <bool REV>
+template <bool REV, int G>
 __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, unsigned qLen, const char *__restrict__ t,
                                                    unsigned tLen, int diagonal, const signed char *__restrict__ smat, int sl) {
     DiagScore r; r.valid = false; r.score = 0; r.first = -1; r.last = -1; r.diagLen = 0; r.idCnt = 0;
@@ -108,7 +111,7 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
     unsigned last = len - 1;
     if (last > 0 && (qe == '*' || te == '*')) last--;
     int s = 0, ids = 0;
-    for (unsigned p = first + 4u * (unsigned) sl; p <= last; p += 4u * RS_GROUP) {
+    for (unsigned p = first + 4u * (unsigned) sl; p <= last; p += 4u * G) {
         // 4 consecutive residues of both sequences (unaligned dword loads; the DB buffer is padded past its end)
         uint32_t tw = loadU32Unaligned(t + to + p);
         uint32_t qw;
@@ -129,26 +132,33 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
             }
         }
     }
-    s = groupReduceSum16(s); ids = groupReduceSum16(ids);
+    if (G > 1) { s = groupReduceSumG<G>(s); ids = groupReduceSumG<G>(ids); }
     r.score = (unsigned) max(s, 0); r.first = (int) first; r.last = (int) last; r.idCnt = ids;
     return r;
 }
 
+template <int G>
 __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
     for (int i = threadIdx.x; i < 123 * 123; i += RS_BLOCK) smat[i] = a.mat[i];
     __syncthreads();
-    const int groupsPerBlock = RS_BLOCK / RS_GROUP;
-    const int sl = threadIdx.x & (RS_GROUP - 1);
+    const int groupsPerBlock = RS_BLOCK / G;
+    const int sl = threadIdx.x & (G - 1);
     const uint64_t stride = (uint64_t) gridDim.x * groupsPerBlock;
     unsigned long long accLocal = 0, ovLocal = 0;
-    for (uint64_t h = (uint64_t) blockIdx.x * groupsPerBlock + (threadIdx.x / RS_GROUP); h < a.nHits; h += stride) {
+    const uint64_t nWork = (G == 1) ? a.nHits : (uint64_t) *a.longCount;
+    for (uint64_t w = (uint64_t) blockIdx.x * groupsPerBlock + (threadIdx.x / G); w < nWork; w += stride) {
+        const uint64_t h = (G == 1) ? w : a.longList[w];
         const CandHit hit = a.hits[h];
         const uint32_t qid = hit.query, tid = hit.target;
         const char *q = a.q.data + a.q.off[qid];
         const unsigned qLen = a.q.len[qid];
         const char *t = a.t.data + a.t.off[tid];
         const unsigned tLen = a.t.len[tid];
+        if (G == 1 && min(qLen, tLen) > RS_SHORT_MAX) {       // long overlap: 16 lanes will score it
+            const unsigned long long o = atomicAdd(a.longCount, 1ULL); a.longList[o] = h;
+            continue;
+        }
         const bool isReverse = a.reverseCapable && hit.prefScore < 0;
         const bool isIdentity = (qid == tid) && (a.includeIdentity || a.sameDB);
         AlnRec rec; memset(&rec, 0, sizeof(rec));
@@ -160,12 +170,12 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
             const unsigned d16 = hit.diag16 & 0xFFFFu;
             for (unsigned d = 1; d <= 1 + tLen / 32768; d++) {
                 const int real = (int) (d16 - d * 65536u);
-                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat, sl);
+                DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sl);
                 if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
             }
             for (unsigned d = 0; d <= qLen / 65536; d++) {
                 const int real = (int) (d * 65536u + d16);
-                DiagScore s = isReverse ? scoreDiagonal<true>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false>(q, qLen, t, tLen, real, smat, sl);
+                DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sl);
                 if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
             }
             if (sl == 0) ovLocal += bDiagLen;
@@ -281,9 +291,14 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     a.mat = dMat.as<signed char>(); a.sameDB = (qdb == tdb); a.includeIdentity = par->include_identity; a.reverseCapable = c->reverseCapable;
     a.covMode = par->cov_mode; a.covThr = par->cov_thr; a.seqIdThr = par->seq_id_thr; a.alnLenThr = par->min_aln_len; a.seqIdMode = par->seq_id_mode;
     a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.stats = dStats.as<unsigned long long>();
-    const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 15) / 16 + 1, (uint64_t) ctx->numCU * 8);
+    DevBuf dLongList, dLongCount;
+    if (dLongList.alloc(std::max<uint64_t>(nHits, 1) * 8) != hipSuccess || dLongCount.alloc(8) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 8, ctx->stream));
+    a.longList = dLongList.as<unsigned long long>(); a.longCount = dLongCount.as<unsigned long long>();
+    const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * 8);
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(rescoreKernel, dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rescoreKernel<1>, dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL(rescoreKernel<16>, dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), nHits, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t nAcc = 0;
