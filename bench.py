@@ -86,8 +86,8 @@ def stage_table(kst, rst, ast):
         "run_reduce(reduceRunsKernel+CSR)": (kst.ms_reduce, s * Nm + 12 * Nc, False),
         "rescoreKernel": (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored, True),
     }
-    for i, name in enumerate(("assembleGroupKernel<16>", "assembleGroupKernel<64>", "assembleBigKernel")):
-        t[name] = (ast.ms_tier_kernel[i], 32 * ast.tier_alignments[i] + 2 * ast.tier_query_residues[i] + 2 * ast.tier_rescored_residues[i], True)
+    for i, (name, single) in enumerate((("assembleGroupKernel<16>", True), ("assembleGroupKernel<32>+<64>", False), ("assembleBigKernel", True))):
+        t[name] = (ast.ms_tier_kernel[i], 32 * ast.tier_alignments[i] + 2 * ast.tier_query_residues[i] + 2 * ast.tier_rescored_residues[i], single)
     return t
 
 

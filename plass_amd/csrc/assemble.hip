@@ -47,7 +47,8 @@ struct AsmArgs {
     float seqIdThr; uint64_t maxSeqLen; int rescoreMode;
     unsigned long long *stats;                  // [0] extended, [1] rescored hits, [2] rescored overlap residues
     uint32_t *bigList; uint32_t *bigCount; uint32_t nBig;   // queries with more than 64 alignments (HBM-resident queue)
-    uint32_t *midList; uint32_t *midCount; uint32_t nMid;   // 17..64 alignments: one wavefront per query
+    uint32_t *midList; uint32_t *midCount; uint32_t nMid;   // 33..64 alignments: one wavefront per query
+    uint32_t *mid32List; uint32_t *mid32Count; uint32_t nMid32;   // 17..32 alignments: half a wavefront per query
 };
 
 // text round trip of seqId (Util.cpp:278-307 + strtod in Matcher.cpp:265)
@@ -285,17 +286,21 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
     __syncthreads();
     const int gl = threadIdx.x & (G - 1);                         // lane within the group
     const uint32_t groupsTotal = gridDim.x * (256 / G);
-    const uint32_t nWork = (G == 64) ? a.nMid : a.s.n;
+    const uint32_t nWork = (G == 64) ? a.nMid : ((G == 32) ? a.nMid32 : a.s.n);
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
     for (uint32_t w = blockIdx.x * (256 / G) + threadIdx.x / G; w < nWork; w += groupsTotal) {
-        const uint32_t id = (G == 64) ? a.midList[w] : w;
+        const uint32_t id = (G == 64) ? a.midList[w] : ((G == 32) ? a.mid32List[w] : w);
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
         const uint32_t h = (uint32_t) (h1 - h0);
         if (h == 0) continue;
         const uint64_t aoff = a.arenaOff[id];
         if (a.arenaOff[id + 1] == aoff) continue;          // pre-screened: can never be extended
         if (G == 16 && h > 16) {                           // bigger queues go to the wider tiers
-            if (gl == 0) { if (h > 64) { const uint32_t o = atomicAdd(a.bigCount, 1u); a.bigList[o] = id; } else { const uint32_t o = atomicAdd(a.midCount, 1u); a.midList[o] = id; } }
+            if (gl == 0) {
+                if (h > 64) { const uint32_t o = atomicAdd(a.bigCount, 1u); a.bigList[o] = id; }
+                else if (h > 32) { const uint32_t o = atomicAdd(a.midCount, 1u); a.midList[o] = id; }
+                else { const uint32_t o = atomicAdd(a.mid32Count, 1u); a.mid32List[o] = id; }
+            }
             continue;
         }
         const char *orig = a.s.data + a.s.off[id];
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
     nExt = waveReduceSumU64(nExt); nResc = waveReduceSumU64(nResc); nRescRes = waveReduceSumU64(nRescRes); nAln = waveReduceSumU64(nAln); nQRes = waveReduceSumU64(nQRes);
     if (laneId() == 0) {
         if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes);
-        const int tier = (G == 16) ? 0 : 1;
+        const int tier = (G == 16) ? 0 : 1;      // the 32- and 64-lane kernels share tier 1 in the statistics
         if (nAln) { atomicAdd(&a.stats[3 + 3 * tier], nAln); atomicAdd(&a.stats[4 + 3 * tier], nQRes); atomicAdd(&a.stats[5 + 3 * tier], nRescRes); }
     }
 }
@@ -515,18 +520,20 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
     a.mat = dMat.as<signed char>(); a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.seqIdThr = par->seq_id_thr; a.maxSeqLen = par->max_seq_len; a.rescoreMode = par->rescore_mode;
     a.stats = dStats.as<unsigned long long>();
-    DevBuf dBigList, dMidList, dCounts;
-    if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCounts.alloc(8) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 8, st));
+    DevBuf dBigList, dMidList, dMid32List, dCounts;
+    if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMid32List.alloc(((size_t) N + 1) * 4) != hipSuccess || dCounts.alloc(16) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 16, st));
     a.bigList = dBigList.as<uint32_t>(); a.bigCount = dCounts.as<uint32_t>(); a.nBig = 0;
     a.midList = dMidList.as<uint32_t>(); a.midCount = dCounts.as<uint32_t>() + 1; a.nMid = 0;
+    a.mid32List = dMid32List.as<uint32_t>(); a.mid32Count = dCounts.as<uint32_t>() + 2; a.nMid32 = 0;
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     if (N) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
-    uint32_t cnts[2] = {0, 0};
-    PH_CHECK(hipMemcpyAsync(cnts, dCounts.p, 8, hipMemcpyDeviceToHost, st));
+    uint32_t cnts[4] = {0, 0, 0, 0};
+    PH_CHECK(hipMemcpyAsync(cnts, dCounts.p, 16, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
+    if (cnts[2]) { a.nMid32 = cnts[2]; hipLaunchKernelGGL(assembleGroupKernel<32>, dim3(std::min<uint32_t>((cnts[2] + 7) / 8, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a); }
     if (cnts[1]) { a.nMid = cnts[1]; hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((cnts[1] + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a); }
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     PH_CHECK(hipEventRecord(ctx->ev[6], st));
