@@ -307,7 +307,7 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
     size_t nCand = 0;
     {
         const KPos<T> *h = arr.data();
-        const size_t end = totalKmersPerSplit;
+        const size_t end = par.debugNoStaleScan ? writePos : totalKmersPerSplit;
         std::string buf; char tmp[100];
         uint64_t lastTargetId = UINT64_MAX, repSeqId = UINT64_MAX;
         unsigned writeSets = 0;

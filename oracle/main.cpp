@@ -55,6 +55,7 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
             else if (a == "--add-self-matches") par.includeIdentity = atoi(v.c_str()) != 0;
             else if (a == "--max-seq-len") par.maxSeqLen = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--keep-target") par.keepTarget = atoi(v.c_str()) != 0;
+            else if (a == "--oracle-no-stale-scan") par.debugNoStaleScan = atoi(v.c_str()) != 0;
             else { /* accepted and ignored: --sub-mat --threads -v --compressed --mask … */ }
         } else pos.push_back(a);
     }

@@ -93,6 +93,7 @@ struct ExtractArgs {
     // regular launch after the one-thread-per-sequence kernel: only the queued ids (count read on the device)
     const uint32_t *waveList; const uint32_t *waveCount;
     unsigned long long *kstats;     // [2] residues, [3] records handled by the wave-per-sequence kernel (incl. its HBM-scratch launch)
+    uint64_t slotBias;              // subtracted from every slot offset (re-extraction of one sequence into a scratch array)
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
     // software pipeline over sequences (regular launch): the index entry of sequence w+2*grid and the first 128 bytes
     // of sequence w+grid are in flight while sequence w is processed, so a short read never waits on HBM latency
     struct Meta { uint32_t L; uint64_t off, slot, slot1; };
-    auto loadMeta = [&](uint32_t id) { Meta m; m.L = a.s.len[id]; m.off = a.s.off[id]; m.slot = a.slotOff[id]; m.slot1 = a.slotOff[id + 1]; return m; };
+    auto loadMeta = [&](uint32_t id) { Meta m; m.L = a.s.len[id]; m.off = a.s.off[id]; m.slot = a.slotOff[id] - a.slotBias; m.slot1 = a.slotOff[id + 1] - a.slotBias; return m; };
     Meta mNext = {0, 0, 0, 0}, mNext2 = {0, 0, 0, 0};
     char pb0 = 0, pb1 = 0;
     if (!FALLBACK && blockIdx.x < nWork) {
@@ -648,6 +649,7 @@ struct GroupArgs {
     uint64_t *outCount;              // [gridDim.x] records written by block j at out[bucketStart[j*bucketsPerBlock] ...]
     int includeOnlyExtendable, covMode; float covThr;
     const unsigned long long *minKey;   // NUCL: K of the globally first run
+    unsigned long long *maxRepTarget;   // max over emitted records of (rep << 32 | member): the last run of sort #2
 };
 
 __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -677,6 +679,7 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
     const uint32_t bEnd = min(a.nBuckets, bBegin + a.bucketsPerBlock);
     if (bBegin >= a.nBuckets) { if (threadIdx.x == 0) a.outCount[blockIdx.x] = 0; return; }
     unsigned long long written = 0;                  // block-uniform
+    unsigned long long maxRT = 0;
     const uint64_t arena = a.bucketStart[bBegin];
     const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
     for (uint32_t b = bBegin; b < bEnd; b++) {
@@ -758,6 +761,7 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
                                 const bool cov = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) mLen);
                                 keep = (!a.includeOnlyExtendable && cov) || (canBeExtended && a.includeOnlyExtendable);
                                 o.kmer = rId; o.id = r.id; o.len = r.len; o.pos = (decltype(o.pos)) diagonal;
+                                if (keep) maxRT = max(maxRT, (unsigned long long) (((rId & ~BIT63) << 32) | (unsigned long long) r.id));
                             }
                         }
                     }
@@ -780,6 +784,11 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
             written = writtenAtBucketStart;
             __syncthreads();
         }
+    }
+    if (a.maxRepTarget) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxRT = max(maxRT, (unsigned long long) __shfl_xor(maxRT, o, 64));
+        if (laneId() == 0 && maxRT) atomicMax(a.maxRepTarget, maxRT);
     }
     if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
 }
@@ -1015,6 +1024,38 @@ __global__ void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, CandH
     }
 }
 
+// =====================================================================================================
+// 7. The reference's run scan does not stop at the compaction point of assignGroup: if the sort-#1 record that
+//    happens to sit right behind it belongs to the target of the very last (rep,target) run, it is counted too
+//    (kmermatcher.cpp:880-898).  Those "stale" records are the sort-#1 records of rank
+//    N_m, N_m+1, ...  This path has no k-mer-sorted array, so the rank of every record of that one target is
+//    counted directly: one streaming pass over the N_k records.
+// =====================================================================================================
+template <bool NUCL, bool LONG> __host__ __device__ __forceinline__ bool recLess1(const Rec<LONG> &a, const Rec<LONG> &b) {   // kmermatcher.h:56-96
+    const uint64_t ak = NUCL ? (a.kmer | BIT63) : a.kmer, bk = NUCL ? (b.kmer | BIT63) : b.kmer;
+    if (ak != bk) return ak < bk;
+    if (a.len != b.len) return a.len > b.len;
+    if (a.id != b.id) return a.id < b.id;
+    if (a.pos != b.pos) return a.pos < b.pos;
+    return a.kmer < b.kmer;      // canonical strand tie-break (reverse first)
+}
+template <bool NUCL, bool LONG>
+__global__ __launch_bounds__(256) void rankKernel(const void *recs, uint64_t n, const void *tkeys, uint32_t m, unsigned long long *diff) {
+    typedef Rec<LONG> R;
+    const R *g = reinterpret_cast<const R *>(recs);
+    const R *tk = reinterpret_cast<const R *>(tkeys);
+    __shared__ uint32_t sDiff[1025];
+    const bool useLds = m <= 1024;
+    if (useLds) { for (uint32_t i = threadIdx.x; i <= m; i += 256) sDiff[i] = 0; __syncthreads(); }
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t) gridDim.x * 256) {
+        const R r = g[i];
+        uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
+        if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
+    }
+    if (useLds) { __syncthreads(); for (uint32_t i = threadIdx.x; i <= m; i += 256) { const uint32_t c = sDiff[i]; if (c) atomicAdd(&diff[i], (unsigned long long) c); } }
+}
+
 __global__ void fillU32Kernel(uint32_t *p, uint32_t v, uint64_t n) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) p[i] = v;
 }
@@ -1190,10 +1231,12 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) ctx->numCU * 8);
     const uint32_t bpb = (nBuckets + gBlocks - 1) / gBlocks;
     const uint32_t gGrid = (nBuckets + bpb - 1) / bpb;
-    DevBuf dOutCnt, dArenaStart;
-    if (dOutCnt.alloc((size_t) gGrid * 8) != hipSuccess || dArenaStart.alloc((size_t) gGrid * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    DevBuf dOutCnt, dArenaStart, dMaxRT;
+    if (dOutCnt.alloc((size_t) gGrid * 8) != hipSuccess || dArenaStart.alloc((size_t) gGrid * 8) != hipSuccess || dMaxRT.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     GroupArgs ga; memset(&ga, 0, sizeof(ga));
     ga.in = cur; ga.out = other; ga.bucketStart = dBucketStart; ga.nBuckets = nBuckets; ga.bucketsPerBlock = bpb; ga.outCount = dOutCnt.as<uint64_t>();
+    PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
+    ga.maxRepTarget = dMaxRT.as<unsigned long long>();
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
     hipLaunchKernelGGL((groupKernel<NUCL, LONG>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     std::vector<uint64_t> hOutCnt(gGrid), hBStart(nBuckets + 1);
@@ -1204,8 +1247,53 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     std::vector<uint64_t> hArena(gGrid); uint64_t Nm = 0, maxArena = 0;
     for (uint32_t j = 0; j < gGrid; j++) { hArena[j] = hBStart[(size_t) j * bpb]; Nm += hOutCnt[j]; maxArena = std::max(maxArena, hOutCnt[j]); }
     PH_CHECK(hipMemcpyAsync(dArenaStart.p, hArena.data(), (size_t) gGrid * 8, hipMemcpyHostToDevice, st));
-    std::swap(cur, other);   // cur = grouped records, scattered in arenas
+    std::swap(cur, other);   // cur = grouped records, scattered in arenas; other = the N_k hash-bucketed records (dense)
     msGroup = tm.stop(1);
+
+    // ---- stale records behind the compaction point that continue the last run (see section 7 above) ----
+    std::vector<int64_t> stalePos;          // original k-mer positions of the sort-#1 records of rank N_m, N_m+1, … that belong to T
+    uint32_t staleT = 0;
+    if (Nm > 0 && Nm < Nk) {
+        unsigned long long maxRT = 0;
+        PH_CHECK(hipMemcpy(&maxRT, dMaxRT.p, 8, hipMemcpyDeviceToHost));
+        staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
+        uint64_t so[2]; uint32_t tLen = 0;
+        PH_CHECK(hipMemcpy(so, dSlotOff.as<uint64_t>() + staleT, 16, hipMemcpyDeviceToHost));
+        PH_CHECK(hipMemcpy(&tLen, db->d_len.as<uint32_t>() + staleT, 4, hipMemcpyDeviceToHost));
+        const uint32_t tb = (uint32_t) (so[1] - so[0]);
+        DevBuf dTRec, dTId, dTScr, dTOff, dTCap, dDiff;
+        uint32_t cap = 64; while (cap < tLen + 1) cap <<= 1;
+        const uint64_t zero = 0;
+        if (dTRec.alloc((size_t) tb * sizeof(R)) != hipSuccess || dTId.alloc(4) != hipSuccess || dTScr.alloc((size_t) cap * sizeof(Cand)) != hipSuccess ||
+            dTOff.alloc(8) != hipSuccess || dTCap.alloc(4) != hipSuccess || dDiff.alloc(((size_t) tb + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemcpyAsync(dTId.p, &staleT, 4, hipMemcpyHostToDevice, st));
+        PH_CHECK(hipMemcpyAsync(dTOff.p, &zero, 8, hipMemcpyHostToDevice, st));
+        PH_CHECK(hipMemcpyAsync(dTCap.p, &cap, 4, hipMemcpyHostToDevice, st));
+        PH_CHECK(hipMemsetAsync(dDiff.p, 0, ((size_t) tb + 1) * 8, st));
+        // re-extract the records of T into a scratch array with the very kernel that produced them
+        ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
+        ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(1), dim3(64), 0, st, ta);
+        std::vector<R> trec(tb);
+        PH_CHECK(hipMemcpyAsync(trec.data(), dTRec.p, (size_t) tb * sizeof(R), hipMemcpyDeviceToHost, st));
+        PH_CHECK(hipStreamSynchronize(st));
+        trec.erase(std::remove_if(trec.begin(), trec.end(), [](const R &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }), trec.end());
+        std::sort(trec.begin(), trec.end(), [](const R &x, const R &y) { return recLess1<NUCL, LONG>(x, y); });
+        const uint32_t m = (uint32_t) trec.size();
+        if (m) {
+            PH_CHECK(hipMemcpyAsync(dTRec.p, trec.data(), (size_t) m * sizeof(R), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((rankKernel<NUCL, LONG>), dim3(gridFor(Nk, 256, (unsigned) ctx->numCU * 8)), dim3(256), 0, st, (const void *) other, Nk, (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
+            std::vector<unsigned long long> diff((size_t) m + 1);
+            PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
+            PH_CHECK(hipStreamSynchronize(st));
+            unsigned long long rank = 0, expect = Nm;
+            for (uint32_t j = 0; j < m; j++) {
+                rank += diff[j];                         // records strictly before trec[j] in sort-#1 order
+                if (rank == expect) { stalePos.push_back((int64_t) trec[j].pos); expect++; }
+                else if (rank > expect) break;
+            }
+        }
+    }
 
     // ---- sort #2: range partition by rep id + local bitonic sort ----
     tm.start(0);
@@ -1313,6 +1401,48 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     msReduce = tm.stop(1);
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
+    if (!stalePos.empty() && nTriples > 0) {
+        // the runs that end at the very end of the sorted array (the last (rep,T) run, and the T-runs of directly preceding
+        // reps whose scan the reference lets run across the rep boundary) continue into the stale records: redo them
+        const Triple *dTr = reinterpret_cast<const Triple *>(cur);
+        std::vector<Triple> tail; uint64_t want = std::min<uint64_t>(nTriples, 4096);
+        for (;;) {
+            tail.resize(want);
+            PH_CHECK(hipMemcpy(tail.data(), dTr + (nTriples - want), want * sizeof(Triple), hipMemcpyDeviceToHost));
+            if (tail.front().target != staleT || want == nTriples) break;
+            want = std::min<uint64_t>(nTriples, want * 2);
+        }
+        if (tail.back().target == staleT) {
+            size_t b0 = tail.size(); while (b0 > 0 && tail[b0 - 1].target == staleT) b0--;
+            for (size_t h0 = b0; h0 < tail.size(); h0++) {
+                if (!(h0 == b0 || tail[h0].rep != tail[h0 - 1].rep)) continue;       // not a run head
+                int32_t diagonal = tail[h0].diag, prevDiagonal = tail[h0].diag;
+                uint64_t maxDiagonal = 0, diagonalCnt = 0, topScore = 0;
+                int bestRev = NUCL ? ((tail[h0].cnt & 0x80000000u) == 0) : 0;
+                for (size_t j = h0; j < tail.size(); j++) {
+                    const uint64_t cc = tail[j].cnt & 0x7FFFFFFFu;
+                    if (prevDiagonal == tail[j].diag) diagonalCnt += cc; else diagonalCnt = cc;
+                    if (diagonalCnt >= maxDiagonal) { diagonal = tail[j].diag; maxDiagonal = diagonalCnt; if (NUCL) bestRev = ((tail[j].cnt & 0x80000000u) == 0); }
+                    prevDiagonal = tail[j].diag; topScore += cc;
+                }
+                for (int64_t sp : stalePos) {          // stale records: pos = original k-mer position, kmer field = SIZE_T_MAX (forward)
+                    const int32_t d = LONG ? (int32_t) sp : (int32_t) (int16_t) sp;
+                    if (prevDiagonal == d) diagonalCnt++; else diagonalCnt = 1;
+                    if (diagonalCnt >= maxDiagonal) { diagonal = d; maxDiagonal = diagonalCnt; if (NUCL) bestRev = 0; }
+                    prevDiagonal = d; topScore++;
+                }
+                const uint32_t rep = tail[h0].rep;
+                if (rep == staleT) continue;                                       // self run: scanned but never emitted
+                uint64_t qn = 0;
+                PH_CHECK(hipMemcpy(&qn, c->d_qoff.as<uint64_t>() + rep + 1, 8, hipMemcpyDeviceToHost));
+                CandHit hh;
+                PH_CHECK(hipMemcpy(&hh, c->d_hits.as<CandHit>() + (qn - 1), sizeof(CandHit), hipMemcpyDeviceToHost));
+                if (hh.target != staleT || hh.query != rep) { delete c; setError("kmermatch: internal error while patching the last run"); return PLASSHIP_ERR_DEVICE; }
+                hh.prefScore = bestRev ? -(int) topScore : (int) topScore; hh.diag16 = (uint32_t) (uint16_t) diagonal;
+                PH_CHECK(hipMemcpy(c->d_hits.as<CandHit>() + (qn - 1), &hh, sizeof(CandHit), hipMemcpyHostToDevice));
+            }
+        }
+    }
     if (stats) {
         stats->n_kmer_records = Nk; stats->n_grouped = Nm; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
         {

@@ -85,6 +85,19 @@ def test_golden_nucl_kmermatcher_rescore(ctx, golden, tmp_path, it):
     assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "nucl rescorediagonal")
 
 
+@pytest.mark.parametrize("case", [1, 2, 3, 4])
+def test_golden_stale_scan_quirk(ctx, golden, tmp_path, case):
+    """inputs on which the reference's run scan continues into stale records behind the compaction point
+    (SURVEY.md Appendix A.3): the reference's own output is the expectation"""
+    d = os.path.join(golden, "q1", f"case{case}")
+    ext = open(os.path.join(d, "ext")).read().strip() == "1"
+    db = ctx.read_seqdb(os.path.join(d, "seq"))
+    par = km_params(0); par.include_only_extendable = ext
+    cands, _ = ctx.kmermatcher(db, par)
+    cands.write(tmp_path / "pref")
+    assert_same_db(os.path.join(d, "pref"), tmp_path / "pref", f"stale-scan case {case}")
+
+
 def _oracle_iteration(oracle_bin, d, it):
     run_oracle(oracle_bin, ["kmermatcher", d / f"o_seq_{it}", d / f"o_pref_{it}"] + AA_KM + aa_iter_flags(it))
     run_oracle(oracle_bin, ["rescorediagonal", d / f"o_seq_{it}", d / f"o_seq_{it}", d / f"o_pref_{it}", d / f"o_aln_{it}"] + AA_RS)

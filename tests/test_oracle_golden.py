@@ -65,3 +65,15 @@ def test_oracle_known_answers(oracle_bin):
                       (lib.oracle_evalue(0, 1000000, 250, 4000), ka[4]), (lib.oracle_evalue(1, 1000000, 60, 150), kn[2]),
                       (lib.oracle_evalue(1, 1000000, 100, 150), kn[3])):
         assert abs(got - want) <= 1e-12 * abs(want)
+
+
+@pytest.mark.parametrize("case", [1, 2, 3, 4])
+def test_oracle_stale_scan_quirk(oracle_bin, golden, tmp_path, case):
+    d = os.path.join(golden, "q1", f"case{case}")
+    ext = open(os.path.join(d, "ext")).read().strip()
+    flags = AA_KM + ["--hash-shift", "67", "--include-only-extendable", ext]
+    run_oracle(oracle_bin, ["kmermatcher", f"{d}/seq", tmp_path / "pref"] + flags)
+    assert_same_db(f"{d}/pref", tmp_path / "pref", "stale scan (reference behaviour)")
+    run_oracle(oracle_bin, ["kmermatcher", f"{d}/seq", tmp_path / "pref2"] + flags + ["--oracle-no-stale-scan", "1"])
+    with pytest.raises(AssertionError):          # the fixture really exercises the quirk
+        assert_same_db(f"{d}/pref", tmp_path / "pref2", "without the stale scan")
