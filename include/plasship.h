@@ -1,5 +1,5 @@
 /* plasship — C-ABI of the MI355X-native Plass/PenguiN hot path
- *   kmermatcher -> rescorediagonal -> assembleresults
+ *   kmermatcher -> rescorediagonal -> assembleresults | nuclassembleresults
  *
  * This is the drop-in boundary.  In the reference each of the three steps is an
  * MMseqs2 "module" `int f(int argc, const char** argv, const Command&)` (mm/commons/Command.h:91-102)
@@ -150,8 +150,14 @@ typedef struct plasship_aln_record {   /* one accepted alignment line, binary */
 int plasship_alns_download(plasship_ctx *ctx, const plasship_alns *a, plasship_aln_record *out);
 void plasship_alns_free(plasship_ctx *ctx, plasship_alns *a);
 
-/* ---- assembleresults  (replaces int assembleresult(int, const char**, const Command&),
- *      src/assembler/assembleresult.cpp:358-368; flags LocalParameters.h:96-102) --------------- */
+/* ---- assembleresults / nuclassembleresults
+ *      protein DB    -> replaces int assembleresult(int, const char**, const Command&),
+ *                       src/assembler/assembleresult.cpp:358-368
+ *      nucleotide DB -> replaces int nuclassembleresult(int, const char**, const Command&),
+ *                       src/assembler/nuclassembleresult.cpp:400-410 (reverse-strand hits, Bayesian comparator,
+ *                       libstdc++ heap order; comparator decisions that fall on the 0.45 / 0.55 thresholds are
+ *                       evaluated with the host's libm like the reference does)
+ *      flags LocalParameters.h:96-102 ----------------------------------------------------------- */
 typedef struct plasship_assemble_params {
     float seq_id_thr;       /* --min-seq-id                                                      */
     uint64_t max_seq_len;   /* --max-seq-len                                                     */

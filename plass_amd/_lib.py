@@ -224,6 +224,12 @@ class Context:
         _check(self.lib.plasship_assemble(self.h, db.h, alns.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_assemble")
         return SeqDB(self, h), st
 
+    # the library picks the variant from the DB type; this name mirrors the reference module for nucleotide DBs
+    def nuclassembleresults(self, db, alns, par=None):
+        if db.info()["dbtype"] != 1:
+            raise ValueError("nuclassembleresults needs a nucleotide sequence DB")
+        return self.assembleresults(db, alns, par or AssembleParams(min_seq_id=0.99, max_seq_len=200000))
+
 
 class SeqDB:
     def __init__(self, ctx, h):

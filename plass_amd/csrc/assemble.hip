@@ -1,4 +1,4 @@
-// plasship: assembleresults on gfx950 (rows A1–A5 of SURVEY.md §8a), protein variant.  Product code.
+// plasship: assembleresults / nuclassembleresults on gfx950 (rows A1–A5 of SURVEY.md §8a).  Product code.
 //
 // Reference behaviour reproduced (file:line in /root/reference):
 //   src/assembler/assembleresult.cpp:19-36     CompareResultByScore (score, alnLength, smaller key) — strict
@@ -16,7 +16,8 @@
 // (query + every target that could ever be attached on either side), so no allocation happens in the loop.
 // Because the comparator is a strict total order, std::priority_queue's pop order is "max of what is in
 // the queue", which is what the wave arg-max computes.
-// The nucleotide variants (non-strict Bayesian comparator, heap-order dependent) stay on the host side.
+// The nucleotide variant (non-strict Bayesian comparator, heap-order dependent) has its own kernel below that
+// replays libstdc++'s heap operations (assembleNuclKernel).
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "host_util.hpp"
@@ -49,6 +50,12 @@ struct AsmArgs {
     uint32_t *bigList; uint32_t *bigCount; uint32_t nBig;   // queries with more than 64 alignments (HBM-resident queue)
     uint32_t *midList; uint32_t *midCount; uint32_t nMid;   // 33..64 alignments: one wavefront per query
     uint32_t *mid32List; uint32_t *mid32Count; uint32_t nMid32;   // 17..32 alignments: half a wavefront per query
+    uint32_t *heap;                             // nucleotide variant: [3*nLines] index heap + deferral list + consumed targets per query
+    // nucleotide variant: comparator decisions on a threshold come from a host-evaluated table (see nuclLess)
+    const uint32_t *ambKeys; const uint8_t *ambVals; uint32_t ambMask;    // open addressing, 4 words per key, empty = alpha1 0
+    uint32_t *needKeys; uint32_t *needCount; uint32_t needCap;            // tuples the table lacks
+    uint32_t *redoList; uint32_t *redoCount;                              // queries that met such a tuple: run again
+    const uint32_t *queryList; uint32_t nQueryList;                       // list-driven pass (nullptr = all queries)
 };
 
 // text round trip of seqId (Util.cpp:278-307 + strtod in Matcher.cpp:265)
@@ -233,6 +240,293 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
     if (lane == 0) {
         if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes);
         if (nAln) { atomicAdd(&a.stats[9], nAln); atomicAdd(&a.stats[10], nQRes); atomicAdd(&a.stats[11], nRescRes); }
+    }
+}
+
+// =====================================================================================================
+// nuclassembleresults (src/assembler/nuclassembleresult.cpp): same greedy loop on nucleotide reads with
+//   * hits on the reverse strand (qStart > qEnd): coordinates mirrored, fragments reverse-complemented (:196-224,59-68)
+//   * a Bayesian comparator (beta-binomial tail via lgamma/log/exp, :36-70) that is NOT a strict weak ordering,
+//     so the pop order is whatever libstdc++'s binary heap produces: std::push_heap / std::pop_heap are replayed
+//     verbatim (bits/stl_heap.h __push_heap / __adjust_heap) on an index heap
+//   * the length cap on both sides (:271-275,301-305); seqId of the parsed hits is not rescaled.
+// The comparator's doubles come from the device math library; a decision can differ from glibc's only when p lies
+// within rounding distance of 0.45 / 0.55 (the reference itself depends on the host's libm variant there).
+// One wavefront per query; lane 0 runs the heap, all lanes copy and re-score.
+// =====================================================================================================
+__device__ __forceinline__ char nuclRevN(char c) {          // getNuclRevFragment: num2aa[reverse(aa2num[c])], X -> N
+    switch (c & ~0x20) {
+        case 'A': return 'T';
+        case 'C': case 'M': case 'Y': case 'H': return 'G';
+        case 'T': case 'U': case 'W': return 'A';
+        case 'G': case 'K': case 'B': case 'D': case 'V': case 'R': case 'S': return 'C';
+        default: return 'N';
+    }
+}
+// comparator state of one query: the first decision the table cannot answer aborts the query (it is re-run after
+// the host has evaluated the tuple with its libm)
+struct NuclCmp { const AsmArgs *a; bool abort; };
+__device__ __forceinline__ uint32_t ambHash(uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
+    return (a1 * 0x9E3779B1u) ^ (b1 * 0x85EBCA77u) ^ (a2 * 0xC2B2AE3Du) ^ (b2 * 0x27D4EB2Fu);
+}
+__device__ bool nuclLess(const Item &r1, const Item &r2, NuclCmp &c) {   // CompareNuclResultByScore (nuclassembleresult.cpp:36-70)
+    if (c.abort) return false;
+    const unsigned mm1 = (unsigned) ((double) ((1.0f - r1.seqId) * (float) r1.alnLength) + 0.5);
+    const unsigned mm2 = (unsigned) ((double) ((1.0f - r2.seqId) * (float) r2.alnLength) + 0.5);
+    const unsigned alpha1 = mm1 + 1, alpha2 = mm2 + 1;
+    const unsigned beta1 = r1.alnLength - mm1 + 1, beta2 = r2.alnLength - mm2 + 1;
+    const double log_c = (lgamma((double) (beta1 + beta2)) + lgamma((double) (alpha1 + beta1))) -
+                         (lgamma((double) (alpha1 + beta1 + beta2)) + lgamma((double) beta1));
+    double log_r = 0.0, p = 0.0;
+    for (size_t idx = 0; idx < alpha2; idx++) {
+        p += exp(log_r + log_c);
+        log_r = log((double) (alpha1 + idx)) + log((double) (beta2 + idx)) - (log((double) (idx + 1)) + log((double) (idx + alpha1 + beta1 + beta2))) + log_r;
+    }
+    int cls = (p < 0.45) ? 0 : ((p > 0.55) ? 1 : 2);
+    // The reference's decision is glibc's rounding of p whenever p sits on a threshold (zero mismatches on both sides and
+    // overlap lengths 9 : 11 give exactly 0.45).  Device and host libm agree to ~1e-15; inside a 1e-9 band the class is
+    // taken from the host-evaluated table instead.
+    const double AMB_EPS = 1e-9;
+    if (fabs(p - 0.45) < AMB_EPS || fabs(p - 0.55) < AMB_EPS) {
+        const AsmArgs &a = *c.a;
+        bool found = false;
+        if (a.ambMask) {
+            uint32_t slot = ambHash(alpha1, beta1, alpha2, beta2) & a.ambMask;
+            for (;;) {
+                const uint32_t *k = a.ambKeys + 4 * (size_t) slot;
+                if (k[0] == 0) break;
+                if (k[0] == alpha1 && k[1] == beta1 && k[2] == alpha2 && k[3] == beta2) { cls = a.ambVals[slot]; found = true; break; }
+                slot = (slot + 1) & a.ambMask;
+            }
+        }
+        if (!found) {
+            const uint32_t w = atomicAdd(a.needCount, 1u);
+            if (w < a.needCap) { uint32_t *k = a.needKeys + 4 * (size_t) w; k[0] = alpha1; k[1] = beta1; k[2] = alpha2; k[3] = beta2; }
+            c.abort = true;
+            return false;
+        }
+    }
+    if (cls == 0) return true;
+    if (cls == 1) return false;
+    if (r1.dbLen - r1.alnLength < r2.dbLen - r2.alnLength) return true;
+    if (r1.dbLen - r1.alnLength > r2.dbLen - r2.alnLength) return false;
+    return true;
+}
+__device__ void heapPush(uint32_t *hp, uint32_t &n, uint32_t v, const Item *it, NuclCmp &c) {      // vector::push_back + std::push_heap
+    uint32_t hole = n++;
+    while (hole > 0) {
+        const uint32_t parent = (hole - 1) / 2;
+        if (!nuclLess(it[hp[parent]], it[v], c)) break;
+        hp[hole] = hp[parent]; hole = parent;
+    }
+    hp[hole] = v;
+}
+__device__ uint32_t heapPop(uint32_t *hp, uint32_t &n, const Item *it, NuclCmp &c) {               // top() + std::pop_heap + pop_back
+    const uint32_t top = hp[0];
+    if (n > 1) {
+        const uint32_t value = hp[n - 1];
+        const uint32_t len = n - 1;
+        uint32_t hole = 0, second = 0;
+        while ((int64_t) second < ((int64_t) len - 1) / 2) {
+            second = 2 * (second + 1);
+            if (nuclLess(it[hp[second]], it[hp[second - 1]], c)) second--;
+            hp[hole] = hp[second]; hole = second;
+        }
+        if ((len & 1) == 0 && (int64_t) second == ((int64_t) len - 2) / 2) {
+            second = 2 * (second + 1);
+            hp[hole] = hp[second - 1]; hole = second - 1;
+        }
+        while (hole > 0) {                                         // __push_heap(first, hole, 0, value)
+            const uint32_t parent = (hole - 1) / 2;
+            if (!nuclLess(it[hp[parent]], it[value], c)) break;
+            hp[hole] = hp[parent]; hole = parent;
+        }
+        hp[hole] = value;
+    }
+    n--;
+    return top;
+}
+
+// mode-3 score of query vs (optionally reverse-complemented) target on one diagonal + the counts updateNuclAlignment needs
+__device__ __forceinline__ Rescored rescoreOnDiagonalNucl(const char *q, unsigned qLen, const char *t, unsigned tLen, int diagonal,
+                                                          const signed char *smat, bool rev) {
+    Rescored r; r.startPos = -1; r.endPos = -1; r.score = 0; r.diagonalLen = 0; r.idExcl = 0;
+    const unsigned dist = (unsigned) abs(diagonal);
+    unsigned qo, to, len;
+    if (diagonal >= 0 && dist < qLen) { qo = dist; to = 0; len = min(tLen, qLen - dist); }
+    else if (diagonal < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, qLen); }
+    else return r;
+    r.diagonalLen = len;
+    if (len == 0) return r;
+    auto T = [&](unsigned i) -> char { return rev ? nuclRevN(t[tLen - 1 - (to + i)]) : t[to + i]; };
+    unsigned first = (q[qo] == '*' || T(0) == '*') ? 1u : 0u;
+    unsigned last = len - 1;
+    if (last > 0 && (q[qo + len - 1] == '*' || T(len - 1) == '*')) last--;
+    int s = 0, ids = 0;
+    for (unsigned p = first + (unsigned) laneId(); p <= last; p += 64) {
+        const char a = q[qo + p], b = T(p);
+        s += (int) smat[(int) a * 123 + (int) b];
+        if (p < last) ids += (a == b) ? 1 : 0;
+    }
+    s = waveReduceSum(s); ids = waveReduceSum(ids);
+    r.score = (unsigned) max(s, 0); r.startPos = (int) first; r.endPos = (int) last; r.idExcl = ids;
+    return r;
+}
+
+__global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
+    __shared__ signed char smat[123 * 123 + 7];
+    __shared__ uint32_t sPop;
+    __shared__ int sAbort;
+    for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
+    __syncthreads();
+    const int lane = threadIdx.x;
+    unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
+    const uint32_t nWork = a.queryList ? a.nQueryList : a.s.n;
+    NuclCmp cmp; cmp.a = &a; cmp.abort = false;
+    for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
+        const uint32_t id = a.queryList ? a.queryList[w] : w;
+        const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
+        const uint32_t h = (uint32_t) (h1 - h0);
+        if (h == 0) continue;
+        const uint64_t aoff = a.arenaOff[id];
+        if (a.arenaOff[id + 1] == aoff) continue;          // only the self hit: nothing can happen
+        Item *it = a.items + h0;
+        uint32_t *hp = a.heap + 3 * h0;          // binary heap of item indices
+        uint32_t *def = hp + h;                  // tmpAlignments: deferred items in pop order
+        uint32_t *used = def + h;                // targets attached so far (flag 0x80 is committed when the query completes)
+        uint32_t nUsed = 0;
+        cmp.abort = false;
+        if (lane == 0) sAbort = 0;
+        unsigned long long qResc = 0, qRescRes = 0;
+        const char *orig = a.s.data + a.s.off[id];
+        unsigned querySeqLen = a.s.len[id];
+        // ---- queue fill (nuclassembleresult.cpp:196-224); pad = useReverse of the hit's target ----
+        for (uint32_t i = lane; i < h; i += 64) {
+            const AlnRec r = a.recs[h0 + i];
+            Item x;
+            x.target = r.target;
+            const int aq = (r.qStart == -1) ? 0 : r.qStart, ad = (r.dbStart == -1) ? 0 : r.dbStart;
+            x.alnLength = (uint32_t) (max(abs(r.qEnd - aq), abs(r.dbEnd - ad)) + 1);
+            const int rawScore = (int) (fma((double) r.bitScore, a.ln2, a.logK) / a.lambda + 0.5);
+            const float scorePerCol = (float) rawScore / (float) ((double) x.alnLength + 0.5);
+            x.seqId = r.fromText ? r.seqId : seqIdThroughText(r.seqId);
+            x.score = (int) (scorePerCol * 100);
+            x.qStart = r.qStart; x.qEnd = r.qEnd; x.qLen = (uint32_t) r.qLen; x.dbStart = r.dbStart; x.dbEnd = r.dbEnd; x.dbLen = (uint32_t) r.dbLen;
+            x.pad = 0;
+            if (x.qStart > x.qEnd) {
+                x.pad = 1;
+                const int t0 = x.qStart; x.qStart = x.qEnd; x.qEnd = t0;
+                const unsigned dbs = (unsigned) x.dbStart;
+                x.dbStart = (int) (x.dbLen - (unsigned) x.dbEnd - 1);
+                x.dbEnd = (int) (x.dbLen - dbs - 1);
+            }
+            x.state = 0;
+            it[i] = x;
+        }
+        __syncthreads();
+        uint32_t nHeap = 0;
+        if (lane == 0) { for (uint32_t i = 0; i < h && !cmp.abort; i++) heapPush(hp, nHeap, i, it, cmp); if (cmp.abort) sAbort = 1; }
+        nHeap = h;
+        char *buf = a.arena + aoff;
+        uint64_t curStart = a.leftCap[id];
+        for (uint32_t i = lane; i < querySeqLen; i += 64) buf[curStart + i] = orig[i];
+        uint64_t curLen = querySeqLen;
+        __syncthreads();
+        bool couldExtend = false;
+        bool aborted = sAbort != 0;
+        while (nHeap > 0 && !aborted) {
+            unsigned leftOff = 0, rightOff = 0;
+            bool brokeOut = false;
+            uint32_t nDef = 0;
+            while (nHeap > 0) {
+                // ---- selectNuclFragmentToExtend: pop the heap's top until one is extendable ----
+                if (lane == 0) { uint32_t n2 = nHeap; sPop = heapPop(hp, n2, it, cmp); if (cmp.abort) sAbort = 1; }
+                nHeap--;
+                __syncthreads();
+                if (sAbort) { aborted = true; break; }
+                const uint32_t bi = sPop;
+                const Item best = it[bi];
+                __syncthreads();
+                const bool notBoth = !(best.dbStart == 0 && best.qStart == 0);
+                const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
+                const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
+                if (!((rightStart || leftStart) && notBoth && best.target != id)) continue;
+                const char *tSeq = a.s.data + a.s.off[best.target];
+                const unsigned tLen = a.s.len[best.target];
+                const bool rev = best.pad != 0;
+                if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff) continue; }
+                else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff) continue; }
+                const unsigned dbStart = (unsigned) best.dbStart, dbEnd = (unsigned) best.dbEnd, qStart = (unsigned) best.qStart, qEnd = (unsigned) best.qEnd;
+                if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
+                    if (rightOff > 0) { if (lane == 0) def[nDef] = bi; nDef++; continue; }
+                    const unsigned fragLen = tLen - (dbEnd + 1);
+                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    for (unsigned i = lane; i < fragLen; i += 64)
+                        buf[curStart + curLen + i] = rev ? nuclRevN(tSeq[fragLen - 1 - i]) : tSeq[dbEnd + 1 + i];
+                    curLen += fragLen; rightOff += fragLen;
+                    if (lane == 0) used[nUsed] = best.target;
+                    nUsed++;
+                } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
+                    if (leftOff > 0) { if (lane == 0) def[nDef] = bi; nDef++; continue; }
+                    const unsigned fragLen = dbStart;
+                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    curStart -= fragLen;
+                    for (unsigned i = lane; i < fragLen; i += 64)
+                        buf[curStart + i] = rev ? nuclRevN(tSeq[(tLen - dbStart) + (fragLen - 1 - i)]) : tSeq[i];
+                    curLen += fragLen; leftOff += fragLen;
+                    if (lane == 0) used[nUsed] = best.target;
+                    nUsed++;
+                }
+                __syncthreads();
+            }
+            if (aborted) break;
+            if (leftOff > 0 || rightOff > 0) couldExtend = true;
+            if (brokeOut && nHeap > 0) break;
+            // ---- re-score deferred hits on the extended query (nuclassembleresult.cpp:332-355) in deferral order ----
+            querySeqLen = (unsigned) curLen;
+            const char *qs = buf + curStart;
+            __syncthreads();
+            for (uint32_t d = 0; d < nDef; d++) {
+                const uint32_t found = def[d];
+                Item x = it[found];
+                const char *tSeq = a.s.data + a.s.off[x.target];
+                const unsigned tLen = a.s.len[x.target];
+                const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
+                const Rescored rs = rescoreOnDiagonalNucl(qs, querySeqLen, tSeq, tLen, diag, smat, x.pad != 0);
+                qResc++; qRescRes += rs.diagonalLen;
+                const int dist = abs(diag);
+                int qS, qE, dS, dE;
+                if (diag >= 0) { qS = rs.startPos + dist; qE = rs.endPos + dist; dS = rs.startPos; dE = rs.endPos; }
+                else { qS = rs.startPos; qE = rs.endPos; dS = rs.startPos + dist; dE = rs.endPos + dist; }
+                const float seqId = (float) rs.idExcl / ((float) qE - (float) qS);
+                x.seqId = seqId; x.qLen = querySeqLen; x.dbLen = tLen; x.alnLength = rs.diagonalLen;
+                const float spc = (float) rs.score / (float) ((double) x.alnLength + 0.5);
+                x.score = (int) (spc * 100);
+                x.qStart = qS; x.qEnd = qE; x.dbStart = dS; x.dbEnd = dE;
+                const bool requeue = seqId >= a.seqIdThr;
+                __syncthreads();
+                if (lane == 0) { it[found] = x; if (requeue) { uint32_t n2 = nHeap; heapPush(hp, n2, found, it, cmp); if (cmp.abort) sAbort = 1; } }
+                if (requeue) nHeap++;
+                __syncthreads();
+                if (sAbort) { aborted = true; break; }
+            }
+        }
+        __syncthreads();
+        if (aborted) {                                       // nothing of this query has been published
+            if (lane == 0) a.redoList[atomicAdd(a.redoCount, 1u)] = id;
+        } else {
+            nAln += h; nQRes += a.s.len[id]; nResc += qResc; nRescRes += qRescRes;
+            for (uint32_t i = lane; i < nUsed; i += 64) atomicOr(&a.flags[used[i]], 0x80u);
+            if (couldExtend) {
+                if (lane == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; }
+                nExt++;
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes);
+        if (nAln) { atomicAdd(&a.stats[3], nAln); atomicAdd(&a.stats[4], nQRes); atomicAdd(&a.stats[5], nRescRes); }
     }
 }
 
@@ -421,10 +715,10 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
 
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
 __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
-                                uint64_t *__restrict__ bytes, uint64_t maxSeqLen) {
+                                uint64_t *__restrict__ bytes, uint64_t maxSeqLen, int noPrescreen) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
         uint64_t sum = 0;
-        bool can = false;
+        bool can = noPrescreen != 0;       // nucleotide hits are mirrored first; the loop decides
         for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) {
             const AlnRec r = recs[i];
             if (r.target == id) continue;
@@ -485,10 +779,46 @@ __global__ void maxU32Kernel(const uint32_t *__restrict__ v, uint64_t n, uint32_
 }  // namespace plasship
 using namespace plasship;
 
+// host side of the comparator table: evaluate new tuples with the platform libm, rebuild the open-addressing table
+static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n) {
+    auto hashOf = [](const uint32_t *k) { return (k[0] * 0x9E3779B1u) ^ (k[1] * 0x85EBCA77u) ^ (k[2] * 0xC2B2AE3Du) ^ (k[3] * 0x27D4EB2Fu); };
+    auto insertInto = [&](std::vector<uint32_t> &keys, std::vector<uint8_t> &vals, uint32_t slots, const uint32_t *k, uint8_t v) -> bool {
+        uint32_t s = hashOf(k) & (slots - 1);
+        while (keys[4 * (size_t) s] != 0) {
+            if (memcmp(&keys[4 * (size_t) s], k, 16) == 0) return false;
+            s = (s + 1) & (slots - 1);
+        }
+        memcpy(&keys[4 * (size_t) s], k, 16); vals[s] = v;
+        return true;
+    };
+    size_t have = 0;
+    for (size_t i = 0; i < ctx->ambVals.size(); i++) have += ctx->ambKeys[4 * i] != 0;
+    uint32_t slots = ctx->ambSlots ? ctx->ambSlots : 1024;
+    while ((have + n) * 2 > slots) slots *= 2;
+    if (slots != ctx->ambSlots) {                             // grow: re-insert what is there
+        std::vector<uint32_t> nk((size_t) slots * 4, 0); std::vector<uint8_t> nv(slots, 0);
+        for (size_t i = 0; i < ctx->ambVals.size(); i++)
+            if (ctx->ambKeys[4 * i] != 0) insertInto(nk, nv, slots, &ctx->ambKeys[4 * i], ctx->ambVals[i]);
+        ctx->ambKeys.swap(nk); ctx->ambVals.swap(nv); ctx->ambSlots = slots;
+        ctx->d_ambKeys.release(); ctx->d_ambVals.release();
+        if (ctx->d_ambKeys.alloc((size_t) slots * 16) != hipSuccess || ctx->d_ambVals.alloc(slots) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    }
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t *k = tuples + 4 * (size_t) i;
+        if (k[0] == 0) continue;
+        insertInto(ctx->ambKeys, ctx->ambVals, slots, k, (uint8_t) nuclPosteriorClass(k[0], k[1], k[2], k[3]));
+    }
+    PH_CHECK(hipMemcpy(ctx->d_ambKeys.p, ctx->ambKeys.data(), (size_t) slots * 16, hipMemcpyHostToDevice));
+    PH_CHECK(hipMemcpy(ctx->d_ambVals.p, ctx->ambVals.data(), slots, hipMemcpyHostToDevice));
+    return PLASSHIP_OK;
+}
+
 extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al,
                                  const plasship_assemble_params *par, plasship_seqdb **out, plasship_assemble_stats *stats) {
     if (!ctx || !db || !al || !par || !out) { setError("plasship_assemble: bad argument"); return PLASSHIP_ERR_ARG; }
-    if (db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_assemble: only the protein variant (assembleresults) runs on the GPU path"); return PLASSHIP_ERR_UNSUPPORTED; }
+    // protein DB -> assembleresults; nucleotide DB -> nuclassembleresults (what the nuclassemble workflow runs on reads)
+    const bool nucl = db->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES;
+    if (!nucl && db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_assemble: the sequence DB is neither amino acids nor nucleotides"); return PLASSHIP_ERR_ARG; }
     if (par->rescore_mode != 3) { setError("plasship_assemble: only --rescore-mode 3"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (al->nQueries != db->n) { setError("plasship_assemble: alignment list does not belong to the DB"); return PLASSHIP_ERR_ARG; }
     PH_CHECK(hipSetDevice(ctx->device));
@@ -505,16 +835,16 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     PH_CHECK(hipMemsetAsync(dFlags.p, 0, ((size_t) N + 1) * 4, st));
     PH_CHECK(hipMemsetAsync(dNewLen.p, 0, ((size_t) N + 1) * 4, st));
     PH_CHECK(hipMemsetAsync(dStats.p, 0, 128, st));
-    PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(false), 123 * 123, hipMemcpyHostToDevice, st));
+    PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(nucl), 123 * 123, hipMemcpyHostToDevice, st));
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
-    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len);
+    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len, nucl ? 1 : 0);
     if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t arenaBytes = 0;
     PH_CHECK(hipMemcpyAsync(&arenaBytes, dArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     if (dArena.alloc(arenaBytes + 64) != hipSuccess) { setError("plasship_assemble: out of device memory for the extension arena"); return PLASSHIP_ERR_DEVICE; }
-    HostEvaluer ev(false, db->residues);
+    HostEvaluer ev(nucl, db->residues);
     AsmArgs a; memset(&a, 0, sizeof(a));
     a.s = sv; a.qoff = al->d_qoff.as<uint64_t>(); a.recs = al->d_recs.as<AlnRec>(); a.items = dItems.as<Item>(); a.arenaOff = dArenaOff.as<uint64_t>();
     a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
@@ -526,6 +856,41 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.bigList = dBigList.as<uint32_t>(); a.bigCount = dCounts.as<uint32_t>(); a.nBig = 0;
     a.midList = dMidList.as<uint32_t>(); a.midCount = dCounts.as<uint32_t>() + 1; a.nMid = 0;
     a.mid32List = dMid32List.as<uint32_t>(); a.mid32Count = dCounts.as<uint32_t>() + 2; a.nMid32 = 0;
+    DevBuf dHeap, dNeed, dRedo[2], dCnt;
+    if (nucl) {
+        const uint32_t needCap = 1u << 16;
+        if (dHeap.alloc(std::max<uint64_t>(nLines, 1) * 12) != hipSuccess || dNeed.alloc((size_t) needCap * 16) != hipSuccess || dRedo[0].alloc(((size_t) N + 1) * 4) != hipSuccess ||
+            dRedo[1].alloc(((size_t) N + 1) * 4) != hipSuccess || dCnt.alloc(8) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        a.heap = dHeap.as<uint32_t>();
+        a.needKeys = dNeed.as<uint32_t>(); a.needCount = dCnt.as<uint32_t>(); a.needCap = needCap; a.redoCount = dCnt.as<uint32_t>() + 1;
+        PH_CHECK(hipEventRecord(ctx->ev[2], st));
+        // Pass 0 runs every query; a query that needs a comparator decision the table lacks leaves no trace and is
+        // run again once the host has evaluated the tuple (the set of such tuples is small and recurs, so the table
+        // kept in the context makes later calls single-pass).
+        uint32_t nWork = N;
+        for (int pass = 0; nWork > 0; pass++) {
+            if (pass > 256) { setError("plasship_assemble: comparator table did not converge"); return PLASSHIP_ERR_DEVICE; }
+            a.ambKeys = ctx->d_ambKeys.as<uint32_t>(); a.ambVals = ctx->d_ambVals.as<uint8_t>(); a.ambMask = ctx->ambSlots ? ctx->ambSlots - 1 : 0;
+            a.queryList = pass ? dRedo[(pass + 1) & 1].as<uint32_t>() : nullptr; a.nQueryList = nWork;
+            a.redoList = dRedo[pass & 1].as<uint32_t>();
+            PH_CHECK(hipMemsetAsync(dCnt.p, 0, 8, st));
+            hipLaunchKernelGGL(assembleNuclKernel, dim3(std::min<uint32_t>(nWork, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
+            uint32_t cnt[2] = {0, 0};
+            PH_CHECK(hipMemcpyAsync(cnt, dCnt.p, 8, hipMemcpyDeviceToHost, st));
+            PH_CHECK(hipStreamSynchronize(st));
+            PH_CHECK(hipGetLastError());
+            nWork = cnt[1];
+            if (nWork == 0) break;
+            const uint32_t nNeed = std::min(cnt[0], needCap);
+            if (nNeed == 0) { setError("plasship_assemble: queries aborted without a missing comparator tuple"); return PLASSHIP_ERR_DEVICE; }
+            std::vector<uint32_t> need((size_t) nNeed * 4);
+            PH_CHECK(hipMemcpy(need.data(), dNeed.p, need.size() * 4, hipMemcpyDeviceToHost));
+            const int rc = ambTableInsert(ctx, need.data(), nNeed);
+            if (rc != PLASSHIP_OK) return rc;
+        }
+        PH_CHECK(hipEventRecord(ctx->ev[3], st));
+        for (int e = 4; e <= 7; e++) PH_CHECK(hipEventRecord(ctx->ev[e], st));
+    } else {
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     if (N) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
@@ -539,6 +904,7 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     PH_CHECK(hipEventRecord(ctx->ev[6], st));
     if (cnts[0]) { a.nBig = cnts[0]; hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(cnts[0], (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a); }
     PH_CHECK(hipEventRecord(ctx->ev[7], st));
+    }
     // ---- output DB: extended queries + carried-over sequences, in key order ----
     DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;
     if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||

@@ -39,7 +39,7 @@ static int fail(const char *what) { fprintf(stdout, "%s: %s\n", what, plasship_l
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults> <dbs…> [flags]\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults> <dbs…> [flags]\n"); return EXIT_FAILURE; }
     const std::string mod = argv[1];
     Flags f; std::vector<std::string> pos;
     if (mod == "kmermatcher") f.covThr = 0.8f;   // setLinearFilterDefault (kmermatcher.cpp:566-573); workflows pass -c
@@ -109,10 +109,17 @@ int main(int argc, char **argv) {
         fprintf(stdout, "scored: %llu accepted: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_scored, (unsigned long long) st.n_accepted, st.ms_kernel);
         if (plasship_alns_write(ctx, al, pos[3].c_str())) return fail("rescorediagonal");
         plasship_alns_free(ctx, al); plasship_cands_free(ctx, c); if (t != q) plasship_seqdb_free(ctx, t); plasship_seqdb_free(ctx, q);
-    } else if (mod == "assembleresults") {
-        if (pos.size() != 3) { fprintf(stdout, "assembleresults <i:sequenceDB> <i:alnResult> <o:reprSeqDB>\n"); return EXIT_FAILURE; }
+    } else if (mod == "assembleresults" || mod == "nuclassembleresults") {
+        if (pos.size() != 3) { fprintf(stdout, "%s <i:sequenceDB> <i:alnResult> <o:reprSeqDB>\n", mod.c_str()); return EXIT_FAILURE; }
         plasship_seqdb *db = nullptr, *o = nullptr; plasship_alns *al = nullptr;
         if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("assembleresults");
+        // the library picks the variant from the DB type (protein -> assembleresults, nucleotide -> nuclassembleresults);
+        // the module name has to agree, the reference's assembleresults on nucleotides uses another comparator
+        int dbtype = -1; plasship_seqdb_info(db, nullptr, nullptr, nullptr, &dbtype, nullptr);
+        if ((mod == "nuclassembleresults") != (dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES)) {
+            fprintf(stdout, "plass-hip: %s needs a %s sequence DB\n", mod.c_str(), mod == "nuclassembleresults" ? "nucleotide" : "protein");
+            return EXIT_FAILURE;
+        }
         if (plasship_alns_read(ctx, db, pos[1].c_str(), &al)) return fail("assembleresults");
         plasship_assemble_params p; memset(&p, 0, sizeof(p));
         p.seq_id_thr = f.seqIdThr; p.max_seq_len = f.maxSeqLen; p.keep_target = f.keepTarget; p.rescore_mode = f.rescoreMode;

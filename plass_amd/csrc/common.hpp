@@ -70,6 +70,12 @@ struct plasship_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     int numCU = 0;
+    // nuclassembleresults: comparator decisions that lie on a threshold, resolved with the host libm (assemble.hip);
+    // kept for the lifetime of the context (the same few (alpha, beta) tuples recur in every iteration)
+    std::vector<uint32_t> ambKeys;      // 4 words per entry
+    std::vector<uint8_t> ambVals;
+    plasship::DevBuf d_ambKeys, d_ambVals;
+    uint32_t ambSlots = 0;              // power of two, 0 = no table yet
 };
 
 struct plasship_seqdb {

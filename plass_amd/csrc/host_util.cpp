@@ -143,4 +143,17 @@ int HostEvaluer::minScoreForEvalue(double thr, int qLen, int maxScore) const {
     return hi;
 }
 
+int nuclPosteriorClass(uint32_t alpha1, uint32_t beta1, uint32_t alpha2, uint32_t beta2) {
+    const unsigned a1 = alpha1, b1 = beta1, a2 = alpha2, b2 = beta2;
+    const double log_c = (std::lgamma(b1 + b2) + std::lgamma(a1 + b1)) - (std::lgamma(a1 + b1 + b2) + std::lgamma(b1));
+    double log_r = 0.0, p = 0.0;
+    for (size_t idx = 0; idx < a2; idx++) {
+        p += exp(log_r + log_c);
+        log_r = log(a1 + idx) + log(b2 + idx) - (log(idx + 1) + log(idx + a1 + b1 + b2)) + log_r;
+    }
+    if (p < 0.45) return 0;
+    if (p > 0.55) return 1;
+    return 2;
+}
+
 }  // namespace plasship

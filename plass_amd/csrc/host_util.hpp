@@ -40,6 +40,12 @@ struct HostEvaluer {
     int minScoreForEvalue(double thr, int qLen, int maxScore) const;
 };
 
+// CompareNuclResultByScore's posterior (nuclassembleresult.cpp:36-70) with the platform libm, as the reference computes
+// it: the decision p < 0.45 / p > 0.55 is defined by glibc's lgamma/log/exp whenever p falls on a threshold
+// (e.g. zero mismatches on both sides and overlap lengths 9 : 11 give p = 0.45 up to rounding).
+// returns 0 (p < 0.45), 1 (p > 0.55) or 2 (in between)
+int nuclPosteriorClass(uint32_t alpha1, uint32_t beta1, uint32_t alpha2, uint32_t beta2);
+
 const signed char *asciiSubMat(bool nucl);                 // 123 x 123
 const unsigned char *aa2numTable(bool nucl, int alphabetSize);
 }  // namespace plasship

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (AA_AS, AA_KM, AA_RS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle)
+from conftest import (AA_AS, AA_KM, AA_RS, NUCL_AS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle)
 
 pytestmark = pytest.mark.gpu
 
@@ -83,6 +83,61 @@ def test_golden_nucl_kmermatcher_rescore(ctx, golden, tmp_path, it):
     alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
     alns.write(tmp_path / "aln")
     assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "nucl rescorediagonal")
+
+
+def nucl_as_params():
+    import plass_amd
+    return plass_amd.AssembleParams(min_seq_id=0.99, max_seq_len=200000)
+
+
+@pytest.mark.parametrize("it", [0, 1])
+def test_golden_nucl_assembleresults(ctx, golden, tmp_path, it):
+    """nuclassembleresults (Bayesian comparator, libstdc++ heap order, reverse-strand hits): the reference's contigs"""
+    s = os.path.join(golden, "nucl")
+    db = ctx.read_seqdb(f"{s}/seq_{it}")
+    aln_in = ctx.read_alndb(db, f"{s}/aln_{it}")
+    out, st = ctx.assembleresults(db, aln_in, nucl_as_params())
+    out.write(tmp_path / "seq")
+    assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "nuclassembleresults")
+    assert st.n_extended > 0
+
+
+def test_golden_nucl_chained_on_device(ctx, golden, tmp_path):
+    import plass_amd
+    s = os.path.join(golden, "nucl")
+    db = ctx.read_seqdb(f"{s}/seq_0")
+    for it in range(2):
+        cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+        db2, _ = ctx.assembleresults(db, alns, nucl_as_params())
+        db2.write(tmp_path / f"seq_{it + 1}")
+        assert_same_db(f"{s}/seq_{it + 1}", tmp_path / f"seq_{it + 1}", f"nucl chained iteration {it}")
+        db = db2
+
+
+def test_synthetic_nucl_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path):
+    """15 k read pairs of a synthetic genome, both strands: every DB of three penguin-style iterations equals the oracle's"""
+    import plass_amd
+    from plass_amd import synth
+    data, off, elen, key = synth.nucleotide_read_db(15000, seed=17)
+    synth.write_db(str(tmp_path / "o_seq_0"), data, off, elen, key, 1)
+    db = ctx.upload_seqdb(data, off, elen, key, 1)
+    for it in range(3):
+        run_oracle(oracle_bin, ["kmermatcher", tmp_path / f"o_seq_{it}", tmp_path / f"o_pref_{it}"] + NUCL_KM)
+        run_oracle(oracle_bin, ["rescorediagonal", tmp_path / f"o_seq_{it}", tmp_path / f"o_seq_{it}", tmp_path / f"o_pref_{it}", tmp_path / f"o_aln_{it}"] + NUCL_RS)
+        run_oracle(oracle_bin, ["nuclassembleresults", tmp_path / f"o_seq_{it}", tmp_path / f"o_aln_{it}", tmp_path / f"o_seq_{it + 1}"] + NUCL_AS)
+        cands, kst = ctx.kmermatcher(db, km_params(it, nucl=True))
+        cands.write(tmp_path / "g_pref")
+        assert_same_db(tmp_path / f"o_pref_{it}", tmp_path / "g_pref", f"nucl kmermatcher it{it}")
+        alns, rst = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+        alns.write(tmp_path / "g_aln")
+        assert_same_db(tmp_path / f"o_aln_{it}", tmp_path / "g_aln", f"nucl rescorediagonal it{it}")
+        db2, ast = ctx.assembleresults(db, alns, nucl_as_params())
+        db2.write(tmp_path / "g_seq")
+        assert_same_db(tmp_path / f"o_seq_{it + 1}", tmp_path / "g_seq", f"nuclassembleresults it{it}")
+        if it == 0:
+            assert ast.n_extended > 1000
+        db = db2
 
 
 @pytest.mark.parametrize("case", [1, 2, 3, 4])
