@@ -168,6 +168,11 @@ def main():
         out, kst, rst, ast = one_iteration(ctx, db, it)
         overlaps += kst.n_candidates
         stats.append(stage_table(kst, rst, ast))
+        if os.environ.get("PLASS_BENCH_VERBOSE") and rank == 0:     # per-iteration counters, to stderr
+            print("it%d kmer: Nk=%d Nm=%d Nc=%d | rescore: scored=%d accepted=%d ov=%d | assemble: aln=%d ext=%d resc=%d rescRes=%d tiers ms=%s aln=%s qres=%s rres=%s | wall %s" % (
+                it, kst.n_kmer_records, kst.n_grouped, kst.n_candidates, rst.n_scored, rst.n_accepted, rst.overlap_residues,
+                ast.n_alignments, ast.n_extended, ast.n_rescored, ast.rescored_residues, ["%.2f" % x for x in ast.ms_tier_kernel],
+                list(ast.tier_alignments), list(ast.tier_query_residues), list(ast.tier_rescored_residues), ["%.2f" % x for x in WALL[-1]]), file=sys.stderr)
         if db is not db0:
             db.free()
         db = out

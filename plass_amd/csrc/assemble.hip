@@ -47,9 +47,10 @@ struct AsmArgs {
     double lambda, logK, ln2;
     float seqIdThr; uint64_t maxSeqLen; int rescoreMode;
     unsigned long long *stats;                  // [0] extended, [1] rescored hits, [2] rescored overlap residues
-    uint32_t *bigList; uint32_t *bigCount; uint32_t nBig;   // queries with more than 64 alignments (HBM-resident queue)
-    uint32_t *midList; uint32_t *midCount; uint32_t nMid;   // 33..64 alignments: one wavefront per query
-    uint32_t *mid32List; uint32_t *mid32Count; uint32_t nMid32;   // 17..32 alignments: half a wavefront per query
+    uint32_t *bigList; uint32_t nBig;   // queries with more than 64 alignments (HBM-resident queue)
+    uint32_t *midList; uint32_t nMid;   // 33..64 alignments: one wavefront per query
+    uint32_t *mid32List; uint32_t nMid32;   // 17..32 alignments: half a wavefront per query
+    uint32_t *smallList; uint32_t nSmall;                         // <= 16 alignments: 16 lanes per query
     uint32_t *heap;                             // nucleotide variant: [3*nLines] index heap + deferral list + consumed targets per query
     // nucleotide variant: comparator decisions on a threshold come from a host-evaluated table (see nuclLess)
     const uint32_t *ambKeys; const uint8_t *ambVals; uint32_t ambMask;    // open addressing, 4 words per key, empty = alpha1 0
@@ -70,6 +71,43 @@ __device__ __forceinline__ float seqIdThroughText(float f) {
     return (float) ((double) t / den);
 }
 
+// 8 residues per lane and memory round trip: the loops below are latency bound (a query is a chain of dependent
+// loads), so fewer, wider accesses are what counts.  gfx950 global loads/stores take unaligned addresses; sequence and
+// arena buffers are padded past their ends, bytes beyond the range are masked off.
+__device__ __forceinline__ uint64_t loadU64Unaligned(const char *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
+__device__ __forceinline__ void storeU64Unaligned(char *p, uint64_t w) { __builtin_memcpy(p, &w, 8); }
+template <int G> __device__ __forceinline__ void copyBytesG(char *dst, const char *src, unsigned n, int gl) {
+    for (unsigned i = 8u * (unsigned) gl; i < n; i += 8u * G) {
+        if (i + 8 <= n) storeU64Unaligned(dst + i, loadU64Unaligned(src + i));
+        else for (unsigned j = i; j < n; j++) dst[j] = src[j];
+    }
+}
+// computeGlobalSubstitutionStartEndDistance (DistanceCalculator.h:204-220) over an ungapped overlap of `len` columns:
+// first/last column ('*' trimming), score sum over [first, last], identities over [first, last).  The boundary bytes
+// and the first 8-residue words are requested together (one memory round trip for overlaps up to 8*G residues).
+template <int G> __device__ __forceinline__ void scoreColumnsG(const char *q, const char *t, unsigned len, const signed char *smat, int gl,
+                                                               unsigned &first, unsigned &last, int &s, int &ids) {
+    const unsigned p0 = 8u * (unsigned) gl;
+    uint64_t qw = 0, tw = 0;
+    if (p0 < len) { qw = loadU64Unaligned(q + p0); tw = loadU64Unaligned(t + p0); }
+    const char q0 = q[0], t0 = t[0], qe = q[len - 1], te = t[len - 1];
+    first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+    last = len - 1;
+    if (last > 0 && (qe == '*' || te == '*')) last--;
+    for (unsigned p = p0; p < len; p += 8u * G) {
+        if (p != p0) { qw = loadU64Unaligned(q + p); tw = loadU64Unaligned(t + p); }
+#pragma unroll
+        for (unsigned j = 0; j < 8; j++) {
+            const unsigned c = p + j;
+            if (c >= first && c <= last) {
+                const unsigned a = (unsigned) (qw >> (8 * j)) & 0xFFu, b = (unsigned) (tw >> (8 * j)) & 0xFFu;
+                s += (int) smat[a * 123 + b];
+                if (c < last) ids += (a == b) ? 1 : 0;          // [qStart, qEnd): the last aligned column is not counted
+            }
+        }
+    }
+}
+
 // ungappedAlignmentByDiagonal, mode 3 (DistanceCalculator.h:115-175,204-220) + the counts updateAlignment needs
 struct Rescored { int startPos, endPos; unsigned score, diagonalLen; int idExcl; };
 __device__ __forceinline__ Rescored rescoreOnDiagonal(const char *q, unsigned qLen, const char *t, unsigned tLen, int diagonal,
@@ -82,15 +120,9 @@ __device__ __forceinline__ Rescored rescoreOnDiagonal(const char *q, unsigned qL
     else return r;
     r.diagonalLen = len;
     if (len == 0) return r;
-    unsigned first = (q[qo] == '*' || t[to] == '*') ? 1u : 0u;
-    unsigned last = len - 1;
-    if (last > 0 && (q[qo + len - 1] == '*' || t[to + len - 1] == '*')) last--;
+    unsigned first, last;
     int s = 0, ids = 0;
-    for (unsigned p = first + (unsigned) laneId(); p <= last; p += 64) {
-        const char a = q[qo + p], b = t[to + p];
-        s += (int) smat[(int) a * 123 + (int) b];
-        if (p < last) ids += (a == b) ? 1 : 0;          // [qStart, qEnd): the last aligned column is not counted
-    }
+    scoreColumnsG<64>(q + qo, t + to, len, smat, laneId(), first, last, s, ids);
     s = waveReduceSum(s); ids = waveReduceSum(ids);
     r.score = (unsigned) max(s, 0); r.startPos = (int) first; r.endPos = (int) last; r.idExcl = ids;
     return r;
@@ -134,7 +166,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
         // the query starts in the middle of its arena slice
         char *buf = a.arena + aoff;
         uint64_t curStart = a.leftCap[id];
-        for (uint32_t i = lane; i < querySeqLen; i += 64) buf[curStart + i] = orig[i];
+        copyBytesG<64>(buf + curStart, orig, querySeqLen, lane);
         uint64_t curLen = querySeqLen;
         __syncthreads();
         bool couldExtend = false;
@@ -179,7 +211,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
                 if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
                     if (rightOff > 0) { if (lane == 0) it[bi].state = 1; __syncthreads(); continue; }
                     const unsigned fragLen = tLen - (dbEnd + 1);
-                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + curLen + i] = tSeq[dbEnd + 1 + i];
+                    copyBytesG<64>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, lane);
                     curLen += fragLen; rightOff += fragLen;
                     if (lane == 0) atomicOr(&a.flags[best.target], 0x80u);
                 } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
@@ -187,7 +219,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
                     const unsigned fragLen = dbStart;
                     if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
                     curStart -= fragLen;
-                    for (unsigned i = lane; i < fragLen; i += 64) buf[curStart + i] = tSeq[i];
+                    copyBytesG<64>(buf + curStart, tSeq, fragLen, lane);
                     curLen += fragLen; leftOff += fragLen;
                     if (lane == 0) atomicOr(&a.flags[best.target], 0x80u);
                 }
@@ -559,15 +591,9 @@ __device__ __forceinline__ Rescored rescoreOnDiagonalG(const char *q, unsigned q
     else return r;
     r.diagonalLen = len;
     if (len == 0) return r;
-    unsigned first = (q[qo] == '*' || t[to] == '*') ? 1u : 0u;
-    unsigned last = len - 1;
-    if (last > 0 && (q[qo + len - 1] == '*' || t[to + len - 1] == '*')) last--;
+    unsigned first, last;
     int s = 0, ids = 0;
-    for (unsigned p = first + (unsigned) gl; p <= last; p += G) {
-        const char a = q[qo + p], b = t[to + p];
-        s += (int) smat[(int) a * 123 + (int) b];
-        if (p < last) ids += (a == b) ? 1 : 0;          // [qStart, qEnd): the last aligned column is not counted
-    }
+    scoreColumnsG<G>(q + qo, t + to, len, smat, gl, first, last, s, ids);
     s = groupSum<G>(s); ids = groupSum<G>(ids);
     r.score = (unsigned) max(s, 0); r.startPos = (int) first; r.endPos = (int) last; r.idExcl = ids;
     return r;
@@ -580,23 +606,13 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
     __syncthreads();
     const int gl = threadIdx.x & (G - 1);                         // lane within the group
     const uint32_t groupsTotal = gridDim.x * (256 / G);
-    const uint32_t nWork = (G == 64) ? a.nMid : ((G == 32) ? a.nMid32 : a.s.n);
+    const uint32_t nWork = (G == 64) ? a.nMid : ((G == 32) ? a.nMid32 : a.nSmall);
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
     for (uint32_t w = blockIdx.x * (256 / G) + threadIdx.x / G; w < nWork; w += groupsTotal) {
-        const uint32_t id = (G == 64) ? a.midList[w] : ((G == 32) ? a.mid32List[w] : w);
+        const uint32_t id = (G == 64) ? a.midList[w] : ((G == 32) ? a.mid32List[w] : a.smallList[w]);   // work lists: arenaSizeKernel
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
         const uint32_t h = (uint32_t) (h1 - h0);
-        if (h == 0) continue;
         const uint64_t aoff = a.arenaOff[id];
-        if (a.arenaOff[id + 1] == aoff) continue;          // pre-screened: can never be extended
-        if (G == 16 && h > 16) {                           // bigger queues go to the wider tiers
-            if (gl == 0) {
-                if (h > 64) { const uint32_t o = atomicAdd(a.bigCount, 1u); a.bigList[o] = id; }
-                else if (h > 32) { const uint32_t o = atomicAdd(a.midCount, 1u); a.midList[o] = id; }
-                else { const uint32_t o = atomicAdd(a.mid32Count, 1u); a.mid32List[o] = id; }
-            }
-            continue;
-        }
         const char *orig = a.s.data + a.s.off[id];
         unsigned querySeqLen = a.s.len[id];
         if (gl == 0) { nAln += h; nQRes += querySeqLen; }
@@ -623,7 +639,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
         for (int j = 0; j < G; j++) { const uint32_t ot = __shfl(xTarget, j, G); tRank += (ot < xTarget) ? 1u : 0u; }
         char *buf = a.arena + aoff;
         uint64_t curStart = a.leftCap[id];
-        for (uint32_t i = gl; i < querySeqLen; i += G) buf[curStart + i] = orig[i];
+        copyBytesG<G>(buf + curStart, orig, querySeqLen, gl);
         uint64_t curLen = querySeqLen;
         bool couldExtend = false;
         uint32_t inQueue = (uint32_t) __popcll(groupBallot<G>(xState == 0));
@@ -658,7 +674,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
                 if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
                     if (rightOff > 0) { if (mine) xState = 1; continue; }
                     const unsigned fragLen = tLen - (dbEnd + 1);
-                    for (unsigned i = gl; i < fragLen; i += G) buf[curStart + curLen + i] = tSeq[dbEnd + 1 + i];
+                    copyBytesG<G>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, gl);
                     curLen += fragLen; rightOff += fragLen;
                     if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
                 } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
@@ -666,7 +682,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
                     const unsigned fragLen = dbStart;
                     if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
                     curStart -= fragLen;
-                    for (unsigned i = gl; i < fragLen; i += G) buf[curStart + i] = tSeq[i];
+                    copyBytesG<G>(buf + curStart, tSeq, fragLen, gl);
                     curLen += fragLen; leftOff += fragLen;
                     if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
                 }
@@ -714,9 +730,16 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
 }
 
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
+// ... and the work lists of the extension kernels: queries that passed the pre-screen, by queue size (<= 16, <= 32,
+// <= 64, more), appended wave-aggregated; lists[t] has room for n ids, counts[t] is the fill
 __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
-                                uint64_t *__restrict__ bytes, uint64_t maxSeqLen, int noPrescreen) {
-    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
+                                uint64_t *__restrict__ bytes, uint64_t maxSeqLen, int noPrescreen,
+                                uint32_t *__restrict__ list0, uint32_t *__restrict__ list1, uint32_t *__restrict__ list2, uint32_t *__restrict__ list3,
+                                uint32_t *__restrict__ counts) {
+    const uint32_t nRound = (s.n + 63u) & ~63u;              // whole wavefronts stay in the loop (ballots below)
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < nRound; id += gridDim.x * blockDim.x) {
+        int tier = -1;
+        if (id < s.n) {
         uint64_t sum = 0;
         bool can = noPrescreen != 0;       // nucleotide hits are mirrored first; the loop decides
         for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) {
@@ -735,6 +758,20 @@ __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, co
         }
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
         bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 8) : 0;
+        if (sum && can && list0) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = (noPrescreen || h <= 16) ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3)); }   // nucleotide variant: one list
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const unsigned long long m = __ballot(tier == t);
+            if (m == 0) continue;
+            uint32_t base = 0;
+            if (laneId() == __ffsll((long long) m) - 1) base = atomicAdd(&counts[t], (uint32_t) __popcll(m));
+            base = __shfl(base, __ffsll((long long) m) - 1, 64);
+            if (tier == t) {
+                uint32_t *l = t == 0 ? list0 : (t == 1 ? list1 : (t == 2 ? list2 : list3));
+                l[base + (uint32_t) __popcll(m & ((1ULL << laneId()) - 1ULL))] = id;
+            }
+        }
     }
 }
 
@@ -754,15 +791,17 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
                                                       const uint64_t *__restrict__ outOff, const uint32_t *__restrict__ keep,
                                                       const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
                                                       char *__restrict__ outData, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey) {
-    const int wavesPerBlock = 256 / 64;
-    for (uint32_t id = blockIdx.x * wavesPerBlock + (threadIdx.x >> 6); id < s.n; id += gridDim.x * wavesPerBlock) {
+    // 16 lanes per sequence, 8 bytes per lane and step (a read fragment is one step); four sequences per wavefront
+    const int G = 16, groupsPerBlock = 256 / G;
+    const int gl = threadIdx.x & (G - 1);
+    for (uint32_t id = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id < s.n; id += gridDim.x * groupsPerBlock) {
         if (!keep[id]) continue;
         const uint64_t o = outOff[id];
         const bool ext = (flags[id] & 0x20u) != 0;
         const uint32_t L = ext ? newLen[id] : s.len[id];
         const char *src = ext ? (arena + newStart[id]) : (s.data + s.off[id]);
-        for (uint32_t i = laneId(); i < L; i += 64) outData[o + i] = src[i];
-        if (laneId() == 0) {
+        copyBytesG<G>(outData + o, src, L, gl);
+        if (gl == 0) {
             outData[o + L] = '\n'; outData[o + L + 1] = '\0';
             const uint64_t j = keepPos[id];
             outOffArr[j] = o; outLen[j] = L; outKey[j] = inKey[id];
@@ -838,10 +877,18 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(nucl), 123 * 123, hipMemcpyHostToDevice, st));
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
-    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len, nucl ? 1 : 0);
+    // work lists by queue size: [0] <= 16 alignments, [1] <= 32, [2] <= 64, [3] more (filled by arenaSizeKernel)
+    DevBuf dBigList, dMidList, dMid32List, dSmallList, dCounts;
+    if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMid32List.alloc(((size_t) N + 1) * 4) != hipSuccess ||
+        dSmallList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCounts.alloc(16) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 16, st));
+    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len, nucl ? 1 : 0,
+                              dSmallList.as<uint32_t>(), dMid32List.as<uint32_t>(), dMidList.as<uint32_t>(), dBigList.as<uint32_t>(), dCounts.as<uint32_t>());
     if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t arenaBytes = 0;
+    uint32_t cnts[4] = {0, 0, 0, 0};
     PH_CHECK(hipMemcpyAsync(&arenaBytes, dArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(cnts, dCounts.p, 16, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     if (dArena.alloc(arenaBytes + 64) != hipSuccess) { setError("plasship_assemble: out of device memory for the extension arena"); return PLASSHIP_ERR_DEVICE; }
     HostEvaluer ev(nucl, db->residues);
@@ -850,12 +897,10 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
     a.mat = dMat.as<signed char>(); a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.seqIdThr = par->seq_id_thr; a.maxSeqLen = par->max_seq_len; a.rescoreMode = par->rescore_mode;
     a.stats = dStats.as<unsigned long long>();
-    DevBuf dBigList, dMidList, dMid32List, dCounts;
-    if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMid32List.alloc(((size_t) N + 1) * 4) != hipSuccess || dCounts.alloc(16) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 16, st));
-    a.bigList = dBigList.as<uint32_t>(); a.bigCount = dCounts.as<uint32_t>(); a.nBig = 0;
-    a.midList = dMidList.as<uint32_t>(); a.midCount = dCounts.as<uint32_t>() + 1; a.nMid = 0;
-    a.mid32List = dMid32List.as<uint32_t>(); a.mid32Count = dCounts.as<uint32_t>() + 2; a.nMid32 = 0;
+    a.smallList = dSmallList.as<uint32_t>(); a.nSmall = cnts[0];
+    a.mid32List = dMid32List.as<uint32_t>(); a.nMid32 = cnts[1];
+    a.midList = dMidList.as<uint32_t>(); a.nMid = cnts[2];
+    a.bigList = dBigList.as<uint32_t>(); a.nBig = cnts[3];
     DevBuf dHeap, dNeed, dRedo[2], dCnt;
     if (nucl) {
         const uint32_t needCap = 1u << 16;
@@ -867,11 +912,11 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
         // Pass 0 runs every query; a query that needs a comparator decision the table lacks leaves no trace and is
         // run again once the host has evaluated the tuple (the set of such tuples is small and recurs, so the table
         // kept in the context makes later calls single-pass).
-        uint32_t nWork = N;
+        uint32_t nWork = cnts[0];
         for (int pass = 0; nWork > 0; pass++) {
             if (pass > 256) { setError("plasship_assemble: comparator table did not converge"); return PLASSHIP_ERR_DEVICE; }
             a.ambKeys = ctx->d_ambKeys.as<uint32_t>(); a.ambVals = ctx->d_ambVals.as<uint8_t>(); a.ambMask = ctx->ambSlots ? ctx->ambSlots - 1 : 0;
-            a.queryList = pass ? dRedo[(pass + 1) & 1].as<uint32_t>() : nullptr; a.nQueryList = nWork;
+            a.queryList = pass ? dRedo[(pass + 1) & 1].as<uint32_t>() : dSmallList.as<uint32_t>(); a.nQueryList = nWork;
             a.redoList = dRedo[pass & 1].as<uint32_t>();
             PH_CHECK(hipMemsetAsync(dCnt.p, 0, 8, st));
             hipLaunchKernelGGL(assembleNuclKernel, dim3(std::min<uint32_t>(nWork, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
@@ -892,17 +937,14 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
         for (int e = 4; e <= 7; e++) PH_CHECK(hipEventRecord(ctx->ev[e], st));
     } else {
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
-    if (N) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
+    if (a.nSmall) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
-    uint32_t cnts[4] = {0, 0, 0, 0};
-    PH_CHECK(hipMemcpyAsync(cnts, dCounts.p, 16, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    if (cnts[2]) { a.nMid32 = cnts[2]; hipLaunchKernelGGL(assembleGroupKernel<32>, dim3(std::min<uint32_t>((cnts[2] + 7) / 8, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a); }
-    if (cnts[1]) { a.nMid = cnts[1]; hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((cnts[1] + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a); }
+    if (a.nMid32) hipLaunchKernelGGL(assembleGroupKernel<32>, dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
+    if (a.nMid) hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     PH_CHECK(hipEventRecord(ctx->ev[6], st));
-    if (cnts[0]) { a.nBig = cnts[0]; hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(cnts[0], (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a); }
+    if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(a.nBig, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[7], st));
     }
     // ---- output DB: extended queries + carried-over sequences, in key order ----
@@ -923,7 +965,7 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
         delete o; setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
-    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 3) / 4, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, sv, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(),
+    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, sv, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(),
                               dNewStart.as<uint64_t>(), dArena.as<char>(), dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
                               o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));

@@ -133,13 +133,28 @@ double HostEvaluer::evalue(double y, double qLen) const {
     return g[1] * std::exp(-g[0] * y) * area;
 }
 
-int HostEvaluer::minScoreForEvalue(double thr, int qLen, int maxScore) const {
+int HostEvaluer::minScoreForEvalue(double thr, int qLen, int maxScore, int guess) const {
     // E(s) is strictly decreasing in s for fixed lengths (exponential factor times a decreasing,
-    // positive area); bisection on the exact double predicate the reference evaluates.
-    if (evalue(0, qLen) <= thr) return 0;
-    if (!(evalue(maxScore, qLen) <= thr)) return maxScore + 1;
-    int lo = 0, hi = maxScore;            // pred(lo) false, pred(hi) true
-    while (hi - lo > 1) { int mid = lo + (hi - lo) / 2; if (evalue(mid, qLen) <= thr) hi = mid; else lo = mid; }
+    // positive area); search on the exact double predicate the reference evaluates.  `guess` (the answer of a
+    // neighbouring length, or < 0) only picks where the bracketing starts: a gallop around it, then bisection.
+    auto pred = [&](int s) { return evalue(s, qLen) <= thr; };
+    int lo, hi;                            // invariant: pred(lo) false, pred(hi) true
+    if (guess >= 1 && guess <= maxScore) {
+        if (pred(guess)) {
+            hi = guess; int step = 1; lo = -1;
+            while (hi - step >= 0) { if (pred(hi - step)) { hi -= step; step *= 2; } else { lo = hi - step; break; } }
+            if (lo < 0) { if (pred(0)) return 0; lo = 0; }
+        } else {
+            lo = guess; int step = 1; hi = -1;
+            while (lo + step <= maxScore) { if (!pred(lo + step)) { lo += step; step *= 2; } else { hi = lo + step; break; } }
+            if (hi < 0) { if (!pred(maxScore)) return maxScore + 1; hi = maxScore; }
+        }
+    } else {
+        if (pred(0)) return 0;
+        if (!pred(maxScore)) return maxScore + 1;
+        lo = 0; hi = maxScore;
+    }
+    while (hi - lo > 1) { int mid = lo + (hi - lo) / 2; if (pred(mid)) hi = mid; else lo = mid; }
     return hi;
 }
 

@@ -37,7 +37,7 @@ struct HostEvaluer {
     double bitScore(double score) const;
     double rawFromBit(double bits) const;
     // smallest integer score s in [0, maxScore] with evalue(s, qLen) <= thr, or maxScore+1 if none
-    int minScoreForEvalue(double thr, int qLen, int maxScore) const;
+    int minScoreForEvalue(double thr, int qLen, int maxScore, int guess = -1) const;
 };
 
 // CompareNuclResultByScore's posterior (nuclassembleresult.cpp:36-70) with the platform libm, as the reference computes

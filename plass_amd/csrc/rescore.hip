@@ -274,8 +274,9 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     {
         // max raw score of an overlap of length L: max matrix entry (11 for BLOSUM62 W-W, 2 for nucl) * L
         const int maxEntry = nucl ? 2 : 11;
+        int guess = -1;                                   // neighbouring lengths have neighbouring thresholds
         for (uint32_t l = 1; l < tabLen; l++)
-            if (present[l]) minScore[l] = (uint32_t) ev.minScoreForEvalue(par->eval_thr, (int) l, maxEntry * (int) l + 1);
+            if (present[l]) { guess = ev.minScoreForEvalue(par->eval_thr, (int) l, maxEntry * (int) l + 1, guess); minScore[l] = (uint32_t) guess; }
     }
     PH_CHECK(hipMemcpyAsync(dMinScore.p, minScore.data(), (size_t) tabLen * 4, hipMemcpyHostToDevice, ctx->stream));
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(nucl), 123 * 123, hipMemcpyHostToDevice, ctx->stream));
