@@ -569,10 +569,25 @@ __device__ __forceinline__ void waveMemSync() {   // make this wave's global sto
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
+// reductions over a group: inside a row of 16 lanes on the VALU (DPP), across rows with shuffles
 template <int G> __device__ __forceinline__ int groupSum(int v) {
+    v = rowSum16(v);
 #pragma unroll
-    for (int o = G / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, G);
+    for (int o = 16; o < G; o <<= 1) v += __shfl_xor(v, o, G);
     return v;
+}
+template <int G> __device__ __forceinline__ unsigned long long groupMax(unsigned long long v) {
+    v = rowMax16(v);
+#pragma unroll
+    for (int o = 16; o < G; o <<= 1) { const unsigned long long ok = __shfl_xor(v, o, G); v = (ok > v) ? ok : v; }
+    return v;
+}
+// rank of `mine` among the group's values (number of strictly smaller ones)
+template <int G> __device__ __forceinline__ uint32_t groupRank(uint32_t mine) {
+    uint32_t r = rowCountLess16(mine, mine, false);
+#pragma unroll
+    for (int o = 16; o < G; o += 16) r += rowCountLess16((uint32_t) __shfl_xor((int) mine, o, G), mine, true);
+    return r;
 }
 template <int G> __device__ __forceinline__ unsigned long long groupBallot(bool p) {
     const unsigned long long m = __ballot(p);
@@ -634,9 +649,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
             xTOff = a.s.off[xTarget]; xTLen = a.s.len[xTarget];      // fetched up front: one memory round trip less per pop
         }
         // tie-break of CompareResultByScore (smaller key wins) as a rank among the group's targets
-        uint32_t tRank = 0;
-#pragma unroll 4
-        for (int j = 0; j < G; j++) { const uint32_t ot = __shfl(xTarget, j, G); tRank += (ot < xTarget) ? 1u : 0u; }
+        const uint32_t tRank = groupRank<G>(xTarget);
         char *buf = a.arena + aoff;
         uint64_t curStart = a.leftCap[id];
         copyBytesG<G>(buf + curStart, orig, querySeqLen, gl);
@@ -651,41 +664,49 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
                 // ---- selectFragmentToExtend: arg-max of (score, alnLength, smaller key) = priority_queue::top ----
                 unsigned long long key = 0;
                 if (xState == 0) key = ((unsigned long long) ((uint32_t) xScore ^ 0x80000000u) << 32) | ((unsigned long long) xAlnLen << 6) | (unsigned long long) (63u - tRank);
-                unsigned long long best = key;
-#pragma unroll
-                for (int o = G / 2; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(best, o, G); best = (ok > best) ? ok : best; }
+                const unsigned long long best = groupMax<G>(key);
                 if (best == 0) { inQueue = 0; break; }
                 const bool mine = (key == best);                   // exactly one lane (ranks are distinct)
-                const int bi = __ffsll((long long) groupBallot<G>(mine)) - 1;
-                if (mine) xState = 2;                              // popped
                 inQueue--;
-                const uint32_t bTarget = __shfl(xTarget, bi, G);
-                const int bQStart = __shfl(xQStart, bi, G), bQEnd = __shfl(xQEnd, bi, G), bDbStart = __shfl(xDbStart, bi, G), bDbEnd = __shfl(xDbEnd, bi, G);
-                const uint32_t bQLen = __shfl(xQLen, bi, G), bDbLen = __shfl(xDbLen, bi, G);
-                const bool notBoth = !(bDbStart == 0 && bQStart == 0);
-                const bool rightStart = bDbStart == 0 && (bDbEnd != (int) bDbLen - 1);
-                const bool leftStart = bQStart == 0 && (bQEnd != (int) bQLen - 1);
-                if (!((rightStart || leftStart) && notBoth)) continue;
+                // the owning lane has everything the geometry tests need (offsets and lengths are group-uniform): it
+                // decides, the group learns the outcome through a ballot; only an actual extension broadcasts data
+                int act = 0;                                       // 0 discarded, 1 deferred, 2 right, 3 left, 4 length cap
+                if (mine) {
+                    xState = 2;                                    // popped
+                    const bool notBoth = !(xDbStart == 0 && xQStart == 0);
+                    const bool rightStart = xDbStart == 0 && (xDbEnd != (int) xDbLen - 1);
+                    const bool leftStart = xQStart == 0 && (xQEnd != (int) xQLen - 1);
+                    if ((rightStart || leftStart) && notBoth) {
+                        bool skip = false;
+                        if (xDbStart == 0) skip = (xTLen - ((unsigned) xDbEnd + 1)) <= rightOff;
+                        else if (xQStart == 0) skip = xDbStart <= (int) leftOff;
+                        if (!skip) {
+                            if ((unsigned) xDbStart == 0 && (unsigned) xQEnd == (querySeqLen - 1)) act = (rightOff > 0) ? 1 : 2;
+                            else if ((unsigned) xQStart == 0 && (unsigned) xDbEnd == (xTLen - 1))
+                                act = (leftOff > 0) ? 1 : ((curLen + (unsigned) xDbStart >= a.maxSeqLen) ? 4 : 3);
+                        }
+                    }
+                    if (act == 1) xState = 1;
+                }
+                const unsigned long long ext = groupBallot<G>(act >= 2);
+                if (ext == 0) continue;
+                const int bi = __ffsll((long long) ext) - 1;
+                const int bAct = __shfl(act, bi, G);
+                if (bAct == 4) { brokeOut = true; break; }
                 const char *tSeq = a.s.data + __shfl(xTOff, bi, G);
-                const unsigned tLen = __shfl(xTLen, bi, G);
-                if (bDbStart == 0) { if ((tLen - ((unsigned) bDbEnd + 1)) <= rightOff) continue; }
-                else if (bQStart == 0) { if (bDbStart <= (int) leftOff) continue; }
-                const unsigned dbStart = (unsigned) bDbStart, dbEnd = (unsigned) bDbEnd, qStart = (unsigned) bQStart, qEnd = (unsigned) bQEnd;
-                if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
-                    if (rightOff > 0) { if (mine) xState = 1; continue; }
+                const uint32_t bTarget = __shfl(xTarget, bi, G);
+                if (bAct == 2) {                                                         // right extension
+                    const unsigned tLen = __shfl(xTLen, bi, G), dbEnd = (unsigned) __shfl(xDbEnd, bi, G);
                     const unsigned fragLen = tLen - (dbEnd + 1);
                     copyBytesG<G>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, gl);
                     curLen += fragLen; rightOff += fragLen;
-                    if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
-                } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
-                    if (leftOff > 0) { if (mine) xState = 1; continue; }
-                    const unsigned fragLen = dbStart;
-                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                } else {                                                                 // left extension
+                    const unsigned fragLen = (unsigned) __shfl(xDbStart, bi, G);
                     curStart -= fragLen;
                     copyBytesG<G>(buf + curStart, tSeq, fragLen, gl);
                     curLen += fragLen; leftOff += fragLen;
-                    if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
                 }
+                if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
             }
             if (leftOff > 0 || rightOff > 0) couldExtend = true;
             if (brokeOut && inQueue > 0) break;
@@ -847,8 +868,8 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
         if (k[0] == 0) continue;
         insertInto(ctx->ambKeys, ctx->ambVals, slots, k, (uint8_t) nuclPosteriorClass(k[0], k[1], k[2], k[3]));
     }
-    PH_CHECK(hipMemcpy(ctx->d_ambKeys.p, ctx->ambKeys.data(), (size_t) slots * 16, hipMemcpyHostToDevice));
-    PH_CHECK(hipMemcpy(ctx->d_ambVals.p, ctx->ambVals.data(), slots, hipMemcpyHostToDevice));
+    PH_COPY_SYNC(ctx->stream, ctx->d_ambKeys.p, ctx->ambKeys.data(), (size_t) slots * 16, hipMemcpyHostToDevice);
+    PH_COPY_SYNC(ctx->stream, ctx->d_ambVals.p, ctx->ambVals.data(), slots, hipMemcpyHostToDevice);
     return PLASSHIP_OK;
 }
 
@@ -929,7 +950,7 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
             const uint32_t nNeed = std::min(cnt[0], needCap);
             if (nNeed == 0) { setError("plasship_assemble: queries aborted without a missing comparator tuple"); return PLASSHIP_ERR_DEVICE; }
             std::vector<uint32_t> need((size_t) nNeed * 4);
-            PH_CHECK(hipMemcpy(need.data(), dNeed.p, need.size() * 4, hipMemcpyDeviceToHost));
+            PH_COPY_SYNC(ctx->stream, need.data(), dNeed.p, need.size() * 4, hipMemcpyDeviceToHost);
             const int rc = ambTableInsert(ctx, need.data(), nNeed);
             if (rc != PLASSHIP_OK) return rc;
         }

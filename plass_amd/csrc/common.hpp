@@ -20,6 +20,13 @@ std::string hipErrStr(hipError_t e, const char *what, const char *file, int line
             return PLASSHIP_ERR_DEVICE;                                                  \
         }                                                                                \
     } while (0)
+// The context stream is non-blocking: a plain hipMemcpy runs on the null stream and is NOT ordered with work queued on
+// it.  Every blocking copy in the library goes through this: queued on the context stream, then waited for.
+#define PH_COPY_SYNC(st, dst, src, bytes, kind)                                          \
+    do {                                                                                 \
+        PH_CHECK(hipMemcpyAsync((dst), (src), (bytes), (kind), (st)));                   \
+        PH_CHECK(hipStreamSynchronize(st));                                              \
+    } while (0)
 
 // Caching device allocator: hipMalloc/hipFree synchronise the device and cost 0.1–1 ms each, which would
 // dominate an assembly iteration on a 1 M-read set.  Freed blocks are kept (size classes with <= 12.5 % slack)

@@ -28,7 +28,16 @@ size_t sizeClass(size_t n) {
     return (n + step - 1) / step * step;
 }
 }  // namespace
+// debugging aid: PLASSHIP_POOL_POISON=<0..255> fills every block handed out with that byte, so that a kernel reading
+// memory it did not write fails the same way on every run (recycled blocks otherwise hold the previous call's data)
+static int poisonByte() { static const int v = [] { const char *e = getenv("PLASSHIP_POOL_POISON"); return e ? atoi(e) : -1; }(); return v; }
+static hipError_t poolMallocRaw(void **p, size_t n);
 hipError_t poolMalloc(void **p, size_t n) {
+    const hipError_t e = poolMallocRaw(p, n);
+    if (e == hipSuccess && poisonByte() >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poisonByte(), n); (void) hipDeviceSynchronize(); }
+    return e;
+}
+static hipError_t poolMallocRaw(void **p, size_t n) {
     const size_t c = sizeClass(n);
     {
         std::lock_guard<std::mutex> g(g_poolMu);
@@ -152,7 +161,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         db->d_len.alloc((n + 1) * 4) != hipSuccess || db->d_key.alloc((n + 1) * 4) != hipSuccess) {
         delete db; setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    PH_CHECK(hipMemsetAsync(db->d_data.p, 0, total + 64, ctx->stream));
+    PH_CHECK(hipMemsetAsync((char *) db->d_data.p + total, 0, 64, ctx->stream));     // the padding only; the entries are copied below
     // stage in id order through a pinned-size bounce buffer
     {
         const size_t CH = 64u << 20;
@@ -164,10 +173,10 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
                 memcpy(bounce.data() + fill, data + off[perm[i]], db->h_elen[i]); fill += db->h_elen[i]; i++;
             }
             if (fill == 0) {   // single entry larger than the bounce buffer
-                PH_CHECK(hipMemcpy((char *) db->d_data.p + base, data + off[perm[i]], db->h_elen[i], hipMemcpyHostToDevice));
+                PH_COPY_SYNC(ctx->stream, (char *) db->d_data.p + base, data + off[perm[i]], db->h_elen[i], hipMemcpyHostToDevice);
                 i++;
             } else {
-                PH_CHECK(hipMemcpy((char *) db->d_data.p + base, bounce.data(), fill, hipMemcpyHostToDevice));
+                PH_COPY_SYNC(ctx->stream, (char *) db->d_data.p + base, bounce.data(), fill, hipMemcpyHostToDevice);
             }
             done = base + fill;
         }
@@ -176,10 +185,10 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
     std::vector<uint64_t> hoff(n + 1);
     for (size_t i = 0; i < n; i++) hoff[i] = db->h_off[i];
     hoff[n] = total;
-    PH_CHECK(hipMemcpy(db->d_off.p, hoff.data(), (n + 1) * 8, hipMemcpyHostToDevice));
+    PH_COPY_SYNC(ctx->stream, db->d_off.p, hoff.data(), (n + 1) * 8, hipMemcpyHostToDevice);
     if (n) {
-        PH_CHECK(hipMemcpy(db->d_len.p, hlen.data(), n * 4, hipMemcpyHostToDevice));
-        PH_CHECK(hipMemcpy(db->d_key.p, db->h_key.data(), n * 4, hipMemcpyHostToDevice));
+        PH_COPY_SYNC(ctx->stream, db->d_len.p, hlen.data(), n * 4, hipMemcpyHostToDevice);
+        PH_COPY_SYNC(ctx->stream, db->d_key.p, db->h_key.data(), n * 4, hipMemcpyHostToDevice);
     }
     PH_CHECK(hipStreamSynchronize(ctx->stream));
     *out = db;
@@ -199,10 +208,10 @@ static int ensureHostIndex(plasship_ctx *ctx, plasship_seqdb *db) {
     db->h_key.resize(n); db->h_off.resize(n + 1); db->h_elen.resize(n);
     std::vector<uint32_t> len(n);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    PH_CHECK(hipMemcpy(db->h_off.data(), db->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost));
+    PH_COPY_SYNC(ctx->stream, db->h_off.data(), db->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost);
     if (n) {
-        PH_CHECK(hipMemcpy(db->h_key.data(), db->d_key.p, n * 4, hipMemcpyDeviceToHost));
-        PH_CHECK(hipMemcpy(len.data(), db->d_len.p, n * 4, hipMemcpyDeviceToHost));
+        PH_COPY_SYNC(ctx->stream, db->h_key.data(), db->d_key.p, n * 4, hipMemcpyDeviceToHost);
+        PH_COPY_SYNC(ctx->stream, len.data(), db->d_len.p, n * 4, hipMemcpyDeviceToHost);
     }
     for (size_t i = 0; i < n; i++) db->h_elen[i] = len[i] + 2;
     db->h_off.resize(n);
@@ -228,7 +237,7 @@ extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *
     PH_CHECK(hipSetDevice(ctx->device));
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    if (data && db->dataBytes) PH_CHECK(hipMemcpy(data, db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost));
+    if (data && db->dataBytes) PH_COPY_SYNC(ctx->stream, data, db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost);
     if (off) memcpy(off, db->h_off.data(), db->n * 8);
     if (elen) memcpy(elen, db->h_elen.data(), db->n * 4);
     if (key) memcpy(key, db->h_key.data(), db->n * 4);
@@ -242,7 +251,7 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
     std::vector<char> data(db->dataBytes);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    if (db->dataBytes) PH_CHECK(hipMemcpy(data.data(), db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost));
+    if (db->dataBytes) PH_COPY_SYNC(ctx->stream, data.data(), db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost);
     // device layout already is the canonical DB layout: entries in key order, each "SEQ\n\0"
     std::string err; DBFileWriter w;
     if (!w.open(db_path, db->dbtype, err)) { setError(err); return PLASSHIP_ERR_IO; }

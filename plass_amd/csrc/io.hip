@@ -16,7 +16,7 @@ static int hostKeys(plasship_ctx *ctx, const plasship_seqdb *cdb, const std::vec
     if (!db->hostIndexValid && db->h_key.size() != db->n) {
         db->h_key.resize(db->n);
         PH_CHECK(hipStreamSynchronize(ctx->stream));
-        if (db->n) PH_CHECK(hipMemcpy(db->h_key.data(), db->d_key.p, db->n * 4, hipMemcpyDeviceToHost));
+        if (db->n) PH_COPY_SYNC(ctx->stream, db->h_key.data(), db->d_key.p, db->n * 4, hipMemcpyDeviceToHost);
     }
     *keys = &db->h_key;
     return PLASSHIP_OK;
@@ -92,8 +92,8 @@ extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb,
     if (c->d_qoff.alloc((nQ + 1) * 8) != hipSuccess || c->d_hits.alloc(std::max<size_t>(hits.size(), 1) * sizeof(CandHit)) != hipSuccess) {
         delete c; setError("plasship_cands_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    PH_CHECK(hipMemcpy(c->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice));
-    if (!hits.empty()) PH_CHECK(hipMemcpy(c->d_hits.p, hits.data(), hits.size() * sizeof(CandHit), hipMemcpyHostToDevice));
+    PH_COPY_SYNC(ctx->stream, c->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice);
+    if (!hits.empty()) PH_COPY_SYNC(ctx->stream, c->d_hits.p, hits.data(), hits.size() * sizeof(CandHit), hipMemcpyHostToDevice);
     *out = c;
     return PLASSHIP_OK;
 }
@@ -101,8 +101,8 @@ extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb,
 static int fetchCands(plasship_ctx *ctx, const plasship_cands *c, std::vector<uint64_t> &qoff, std::vector<CandHit> &hits) {
     qoff.resize(c->nQueries + 1); hits.resize(c->nHits);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    PH_CHECK(hipMemcpy(qoff.data(), c->d_qoff.p, (c->nQueries + 1) * 8, hipMemcpyDeviceToHost));
-    if (c->nHits) PH_CHECK(hipMemcpy(hits.data(), c->d_hits.p, c->nHits * sizeof(CandHit), hipMemcpyDeviceToHost));
+    PH_COPY_SYNC(ctx->stream, qoff.data(), c->d_qoff.p, (c->nQueries + 1) * 8, hipMemcpyDeviceToHost);
+    if (c->nHits) PH_COPY_SYNC(ctx->stream, hits.data(), c->d_hits.p, c->nHits * sizeof(CandHit), hipMemcpyDeviceToHost);
     return PLASSHIP_OK;
 }
 
@@ -167,8 +167,8 @@ extern "C" void plasship_alns_free(plasship_ctx *ctx, plasship_alns *a) {
 static int fetchAlns(plasship_ctx *ctx, const plasship_alns *a, std::vector<uint64_t> &qoff, std::vector<AlnRec> &recs) {
     qoff.resize(a->nQueries + 1); recs.resize(a->nLines);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    PH_CHECK(hipMemcpy(qoff.data(), a->d_qoff.p, (a->nQueries + 1) * 8, hipMemcpyDeviceToHost));
-    if (a->nLines) PH_CHECK(hipMemcpy(recs.data(), a->d_recs.p, a->nLines * sizeof(AlnRec), hipMemcpyDeviceToHost));
+    PH_COPY_SYNC(ctx->stream, qoff.data(), a->d_qoff.p, (a->nQueries + 1) * 8, hipMemcpyDeviceToHost);
+    if (a->nLines) PH_COPY_SYNC(ctx->stream, recs.data(), a->d_recs.p, a->nLines * sizeof(AlnRec), hipMemcpyDeviceToHost);
     return PLASSHIP_OK;
 }
 
@@ -276,8 +276,8 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
     if (a->d_qoff.alloc((nQ + 1) * 8) != hipSuccess || a->d_recs.alloc(std::max<size_t>(recs.size(), 1) * sizeof(AlnRec)) != hipSuccess) {
         delete a; setError("plasship_alns_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    PH_CHECK(hipMemcpy(a->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice));
-    if (!recs.empty()) PH_CHECK(hipMemcpy(a->d_recs.p, recs.data(), recs.size() * sizeof(AlnRec), hipMemcpyHostToDevice));
+    PH_COPY_SYNC(ctx->stream, a->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice);
+    if (!recs.empty()) PH_COPY_SYNC(ctx->stream, a->d_recs.p, recs.data(), recs.size() * sizeof(AlnRec), hipMemcpyHostToDevice);
     *out = a;
     return PLASSHIP_OK;
 }

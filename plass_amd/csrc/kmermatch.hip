@@ -26,6 +26,7 @@
 #include "device_utils.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <cstdlib>
 #include <climits>
 #include <cstring>
 
@@ -1255,11 +1256,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     uint32_t staleT = 0;
     if (Nm > 0 && Nm < Nk) {
         unsigned long long maxRT = 0;
-        PH_CHECK(hipMemcpy(&maxRT, dMaxRT.p, 8, hipMemcpyDeviceToHost));
+        PH_COPY_SYNC(st, &maxRT, dMaxRT.p, 8, hipMemcpyDeviceToHost);
         staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
         uint64_t so[2]; uint32_t tLen = 0;
-        PH_CHECK(hipMemcpy(so, dSlotOff.as<uint64_t>() + staleT, 16, hipMemcpyDeviceToHost));
-        PH_CHECK(hipMemcpy(&tLen, db->d_len.as<uint32_t>() + staleT, 4, hipMemcpyDeviceToHost));
+        PH_COPY_SYNC(st, so, dSlotOff.as<uint64_t>() + staleT, 16, hipMemcpyDeviceToHost);
+        PH_COPY_SYNC(st, &tLen, db->d_len.as<uint32_t>() + staleT, 4, hipMemcpyDeviceToHost);
         const uint32_t tb = (uint32_t) (so[1] - so[0]);
         DevBuf dTRec, dTId, dTScr, dTOff, dTCap, dDiff;
         uint32_t cap = 64; while (cap < tLen + 1) cap <<= 1;
@@ -1408,7 +1409,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         std::vector<Triple> tail; uint64_t want = std::min<uint64_t>(nTriples, 4096);
         for (;;) {
             tail.resize(want);
-            PH_CHECK(hipMemcpy(tail.data(), dTr + (nTriples - want), want * sizeof(Triple), hipMemcpyDeviceToHost));
+            PH_COPY_SYNC(st, tail.data(), dTr + (nTriples - want), want * sizeof(Triple), hipMemcpyDeviceToHost);
             if (tail.front().target != staleT || want == nTriples) break;
             want = std::min<uint64_t>(nTriples, want * 2);
         }
@@ -1434,12 +1435,12 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
                 const uint32_t rep = tail[h0].rep;
                 if (rep == staleT) continue;                                       // self run: scanned but never emitted
                 uint64_t qn = 0;
-                PH_CHECK(hipMemcpy(&qn, c->d_qoff.as<uint64_t>() + rep + 1, 8, hipMemcpyDeviceToHost));
+                PH_COPY_SYNC(st, &qn, c->d_qoff.as<uint64_t>() + rep + 1, 8, hipMemcpyDeviceToHost);
                 CandHit hh;
-                PH_CHECK(hipMemcpy(&hh, c->d_hits.as<CandHit>() + (qn - 1), sizeof(CandHit), hipMemcpyDeviceToHost));
+                PH_COPY_SYNC(st, &hh, c->d_hits.as<CandHit>() + (qn - 1), sizeof(CandHit), hipMemcpyDeviceToHost);
                 if (hh.target != staleT || hh.query != rep) { delete c; setError("kmermatch: internal error while patching the last run"); return PLASSHIP_ERR_DEVICE; }
                 hh.prefScore = bestRev ? -(int) topScore : (int) topScore; hh.diag16 = (uint32_t) (uint16_t) diagonal;
-                PH_CHECK(hipMemcpy(c->d_hits.as<CandHit>() + (qn - 1), &hh, sizeof(CandHit), hipMemcpyHostToDevice));
+                PH_COPY_SYNC(st, c->d_hits.as<CandHit>() + (qn - 1), &hh, sizeof(CandHit), hipMemcpyHostToDevice);
             }
         }
     }
@@ -1449,7 +1450,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
             stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;
             unsigned long long ks[4] = {0, 0, 0, 0};
-            PH_CHECK(hipMemcpy(ks, dKStats.p, 32, hipMemcpyDeviceToHost));
+            PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost);
             stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
         }
         stats->residues = db->residues;

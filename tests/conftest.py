@@ -62,7 +62,24 @@ def assert_same_db(a, b, what=""):
     assert ta == tb, "%s: dbtype %d != %d" % (what, ta, tb)
     assert ea.keys() == eb.keys(), "%s: key sets differ" % what
     bad = [k for k in ea if ea[k] != eb[k]]
-    assert not bad, "%s: %d entries differ, first key %d:\n%r\n%r" % (what, len(bad), bad[0], ea[bad[0]][:300], eb[bad[0]][:300])
+    if bad:
+        _keep_failure(a, b, what)
+    assert not bad, "%s: %d entries differ (keys %s), first key %d:\n%r\n%r" % (what, len(bad), bad[:10], bad[0], ea[bad[0]][:300], eb[bad[0]][:300])
+
+
+def _keep_failure(a, b, what):
+    """on a GPU box: keep both DBs of a parity failure under gpurun_out/ (merged back by gpurun) for offline analysis"""
+    import glob
+    import shutil
+    out = os.path.join(ROOT, "gpurun_out", "parity_failures", "".join(c if c.isalnum() else "_" for c in what)[:60])
+    try:
+        os.makedirs(out, exist_ok=True)
+        for tag, path in (("expected", str(a)), ("got", str(b))):
+            for f in glob.glob(path + "*"):
+                if os.path.getsize(f) < (8 << 20):
+                    shutil.copy(f, os.path.join(out, tag + "_" + os.path.basename(f)))
+    except OSError:
+        pass
 
 
 AA_KM = ["--alph-size", "13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "nucl:0.200,aa:0.000", "-k", "14", "-c", "0",
