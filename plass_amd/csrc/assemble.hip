@@ -751,16 +751,14 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
 }
 
 // arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
-// ... and the work lists of the extension kernels: queries that passed the pre-screen, by queue size (<= 16, <= 32,
-// <= 64, more), appended wave-aggregated; lists[t] has room for n ids, counts[t] is the fill
+// ... and the tier of each query that passed the pre-screen, by queue size (<= 16, <= 32, <= 64, more), as flags packed
+// for two 64-bit prefix sums (tierA: tier 0 | tier 1 << 32, tierB: tier 2 | tier 3 << 32); listKernel turns the scanned
+// positions into the work lists of the extension kernels (id order, no atomics)
 __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
                                 uint64_t *__restrict__ bytes, uint64_t maxSeqLen, int noPrescreen,
-                                uint32_t *__restrict__ list0, uint32_t *__restrict__ list1, uint32_t *__restrict__ list2, uint32_t *__restrict__ list3,
-                                uint32_t *__restrict__ counts) {
-    const uint32_t nRound = (s.n + 63u) & ~63u;              // whole wavefronts stay in the loop (ballots below)
-    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < nRound; id += gridDim.x * blockDim.x) {
+                                uint64_t *__restrict__ tierA, uint64_t *__restrict__ tierB) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
         int tier = -1;
-        if (id < s.n) {
         uint64_t sum = 0;
         bool can = noPrescreen != 0;       // nucleotide hits are mirrored first; the loop decides
         for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) {
@@ -779,20 +777,20 @@ __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, co
         }
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
         bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 8) : 0;
-        if (sum && can && list0) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = (noPrescreen || h <= 16) ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3)); }   // nucleotide variant: one list
-        }
-#pragma unroll
-        for (int t = 0; t < 4; t++) {
-            const unsigned long long m = __ballot(tier == t);
-            if (m == 0) continue;
-            uint32_t base = 0;
-            if (laneId() == __ffsll((long long) m) - 1) base = atomicAdd(&counts[t], (uint32_t) __popcll(m));
-            base = __shfl(base, __ffsll((long long) m) - 1, 64);
-            if (tier == t) {
-                uint32_t *l = t == 0 ? list0 : (t == 1 ? list1 : (t == 2 ? list2 : list3));
-                l[base + (uint32_t) __popcll(m & ((1ULL << laneId()) - 1ULL))] = id;
-            }
-        }
+        if (sum && can) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = (noPrescreen || h <= 16) ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3)); }   // nucleotide variant: one list
+        tierA[id] = (tier == 0) ? 1ull : ((tier == 1) ? (1ull << 32) : 0ull);
+        tierB[id] = (tier == 2) ? 1ull : ((tier == 3) ? (1ull << 32) : 0ull);
+    }
+}
+__global__ void listKernel(uint32_t n, const uint64_t *__restrict__ tierA, const uint64_t *__restrict__ tierB, const uint64_t *__restrict__ posA,
+                           const uint64_t *__restrict__ posB, uint32_t *__restrict__ list0, uint32_t *__restrict__ list1, uint32_t *__restrict__ list2,
+                           uint32_t *__restrict__ list3) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += gridDim.x * blockDim.x) {
+        const uint64_t a = tierA[id], b = tierB[id];
+        if (a & 0xFFFFFFFFull) list0[(uint32_t) posA[id]] = id;
+        else if (a) list1[(uint32_t) (posA[id] >> 32)] = id;
+        else if (b & 0xFFFFFFFFull) list2[(uint32_t) posB[id]] = id;
+        else if (b) list3[(uint32_t) (posB[id] >> 32)] = id;
     }
 }
 
@@ -899,18 +897,25 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
     // work lists by queue size: [0] <= 16 alignments, [1] <= 32, [2] <= 64, [3] more (filled by arenaSizeKernel)
-    DevBuf dBigList, dMidList, dMid32List, dSmallList, dCounts;
+    DevBuf dBigList, dMidList, dMid32List, dSmallList, dTierA, dTierB, dPosA, dPosB;
     if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMid32List.alloc(((size_t) N + 1) * 4) != hipSuccess ||
-        dSmallList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCounts.alloc(16) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 16, st));
+        dSmallList.alloc(((size_t) N + 1) * 4) != hipSuccess || dTierA.alloc(((size_t) N + 1) * 8) != hipSuccess || dTierB.alloc(((size_t) N + 1) * 8) != hipSuccess ||
+        dPosA.alloc(((size_t) N + 2) * 8) != hipSuccess || dPosB.alloc(((size_t) N + 2) * 8) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len, nucl ? 1 : 0,
-                              dSmallList.as<uint32_t>(), dMid32List.as<uint32_t>(), dMidList.as<uint32_t>(), dBigList.as<uint32_t>(), dCounts.as<uint32_t>());
+                              dTierA.as<uint64_t>(), dTierB.as<uint64_t>());
+    if (exclusiveScanU64(st, dTierA.as<uint64_t>(), dPosA.as<uint64_t>(), N, dTmp.p, tmpBytes) || exclusiveScanU64(st, dTierB.as<uint64_t>(), dPosB.as<uint64_t>(), N, dTmp.p, tmpBytes)) {
+        setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE;
+    }
+    if (N) hipLaunchKernelGGL(listKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, N, dTierA.as<uint64_t>(), dTierB.as<uint64_t>(), dPosA.as<uint64_t>(), dPosB.as<uint64_t>(),
+                              dSmallList.as<uint32_t>(), dMid32List.as<uint32_t>(), dMidList.as<uint32_t>(), dBigList.as<uint32_t>());
     if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t arenaBytes = 0;
-    uint32_t cnts[4] = {0, 0, 0, 0};
+    uint64_t totA = 0, totB = 0;
     PH_CHECK(hipMemcpyAsync(&arenaBytes, dArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipMemcpyAsync(cnts, dCounts.p, 16, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(&totA, dPosA.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(&totB, dPosB.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
+    const uint32_t cnts[4] = {(uint32_t) totA, (uint32_t) (totA >> 32), (uint32_t) totB, (uint32_t) (totB >> 32)};
     if (dArena.alloc(arenaBytes + 64) != hipSuccess) { setError("plasship_assemble: out of device memory for the extension arena"); return PLASSHIP_ERR_DEVICE; }
     HostEvaluer ev(nucl, db->residues);
     AsmArgs a; memset(&a, 0, sizeof(a));
