@@ -207,4 +207,105 @@ DB nuclassembleresults(const DB &seqDb, const DB &alnDb, const Params &par) {
     return doAssembly<true, CompareNuclResultByScore>(seqDb, alnDb, par);
 }
 
+// ---- guidedassembleresults (src/assembler/guidedassembleresult.cpp:136-385) ---------------------------------------
+// Nucleotide ORFs are extended exactly like nuclassembleresults does (same Bayesian comparator :23-75, no reverse
+// strand, no score / seqId rescaling of the parsed hits), and every extension is mirrored on the protein twin; an
+// extension never crosses a '*' (:183-184,234-244).
+bool guidedassembleresults(const DB &nuclDb, const DB &aaDb, const DB &alnDb, const Params &par, DB &outNucl, DB &outAa, std::string &err) {
+    const signed char *mat = asciiSubMat(true);                                            // :152-153
+    const size_t N = nuclDb.size();
+    if (aaDb.size() != N) { err = "guidedassembleresults: nucleotide and protein DB differ in size"; return false; }
+    std::vector<unsigned char> wasExtended(N, 0);
+    outNucl = DB(); outNucl.dbtype = nuclDb.dbtype; outAa = DB(); outAa.dbtype = aaDb.dbtype;
+    std::vector<Result> nuclAlignments, tmp;
+    for (size_t id = 0; id < N; id++) {
+        const unsigned queryKey = nuclDb.key[id];
+        unsigned nuclQuerySeqLen = nuclDb.seqLen(id);
+        const size_t aaQueryId = aaDb.getId(queryKey);
+        if (aaQueryId == (size_t) -1) { err = "guidedassembleresults: protein twin missing"; return false; }
+        std::string nuclQuery(nuclDb.entry(id), nuclQuerySeqLen);
+        const unsigned aaQuerySeqLen = aaDb.seqLen(aaQueryId);
+        std::string aaQuery(aaDb.entry(aaQueryId), aaQuerySeqLen);
+        const bool excludeLeftExtension = (aaQuery[0] == '*');                             // :183-184 (reads [0] of an empty string like the reference)
+        const bool excludeRightExtension = (aaQuery[aaQuerySeqLen - 1] == '*');
+        nuclAlignments.clear();
+        const size_t alnId = alnDb.getId(queryKey);
+        if (alnId != (size_t) -1) readAlignmentResults(nuclAlignments, alnDb.entry(alnId));
+        bool queryCouldBeExtended = false;
+        std::priority_queue<Result, std::vector<Result>, CompareNuclResultByScore> alnQueue;
+        for (size_t i = 0; i < nuclAlignments.size(); i++) {                               // :194-205
+            if (nuclAlignments[i].seqId < par.seqIdThr) continue;
+            alnQueue.push(nuclAlignments[i]);
+            if (nuclAlignments.size() > 1) wasExtended[nuclDb.getId(nuclAlignments[i].dbKey)] |= 0x40;
+        }
+        while (!alnQueue.empty()) {
+            unsigned leftOff = 0, rightOff = 0;
+            tmp.clear();
+            Result best;
+            while ((best = selectFragmentToExtend(alnQueue, queryKey)).dbKey != UINT_MAX) {
+                const size_t tId = nuclDb.getId(best.dbKey), aaTId = aaDb.getId(best.dbKey);
+                if (tId == (size_t) -1 || aaTId == (size_t) -1) { err = "guidedassembleresults: target missing"; return false; }
+                const char *nuclTargetSeq = nuclDb.entry(tId);
+                const unsigned nuclTargetSeqLen = nuclDb.seqLen(tId);
+                const char *aaTargetSeq = aaDb.entry(aaTId);
+                const unsigned aaTargetSeqLen = aaDb.seqLen(aaTId);
+                if (best.dbStartPos == 0) {                                                // :234-244
+                    if (((nuclTargetSeqLen - ((unsigned) best.dbEndPos + 1)) <= rightOff) || excludeRightExtension || aaTargetSeq[0] == '*') continue;
+                } else if (best.qStartPos == 0) {
+                    if ((best.dbStartPos <= (int) leftOff) || excludeLeftExtension || aaTargetSeq[aaTargetSeqLen - 1] == '*') continue;
+                }
+                wasExtended[tId] |= 0x10;
+                const int nuclDbStartPos = best.dbStartPos, nuclDbEndPos = best.dbEndPos, qStartPos = best.qStartPos, qEndPos = best.qEndPos;
+                if (nuclDbStartPos == 0 && qEndPos == ((int) nuclQuerySeqLen - 1)) {        // right extension :251-275
+                    if (rightOff > 0) { tmp.push_back(best); continue; }
+                    const unsigned nuclDbFragLen = (nuclTargetSeqLen - (unsigned) nuclDbEndPos) - 1;
+                    const unsigned aaDbFragLen = (nuclTargetSeqLen / 3 - (unsigned) (nuclDbEndPos / 3)) - 1;
+                    if (nuclQuery.size() + nuclDbFragLen >= par.maxSeqLen) break;
+                    nuclQuery += std::string(nuclTargetSeq + nuclDbEndPos + 1, nuclDbFragLen);
+                    aaQuery += std::string(aaTargetSeq + nuclDbEndPos / 3 + 1, aaDbFragLen);
+                    rightOff += nuclDbFragLen;
+                    wasExtended[tId] |= 0x80;
+                } else if (qStartPos == 0 && nuclDbEndPos == ((int) nuclTargetSeqLen - 1)) { // left extension :276-301
+                    if (leftOff > 0) { tmp.push_back(best); continue; }
+                    const unsigned nuclDbFragLen = (unsigned) nuclDbStartPos;
+                    if (nuclQuery.size() + nuclDbFragLen >= par.maxSeqLen) break;
+                    const int hasStart = (aaTargetSeq[0] == '*') ? 1 : 0;
+                    nuclQuery = std::string(nuclTargetSeq, nuclDbFragLen) + nuclQuery;
+                    aaQuery = std::string(aaTargetSeq, nuclDbFragLen / 3 + hasStart) + aaQuery;
+                    leftOff += nuclDbFragLen;
+                    wasExtended[tId] |= 0x80;
+                }
+            }
+            if (leftOff > 0 || rightOff > 0) queryCouldBeExtended = true;
+            if (!alnQueue.empty()) break;
+            nuclQuerySeqLen = (unsigned) nuclQuery.length();
+            const char *qs = nuclQuery.c_str();
+            for (size_t i = 0; i < tmp.size(); i++) {                                       // :315-334
+                const size_t tId = nuclDb.getId(tmp[i].dbKey);
+                const unsigned tSeqLen = nuclDb.seqLen(tId);
+                const char *tSeq = nuclDb.entry(tId);
+                const int diag = (int) ((unsigned) tmp[i].qStartPos + leftOff) - tmp[i].dbStartPos;
+                LocalAlignment aln = ungappedAlignmentByDiagonal(qs, nuclQuerySeqLen, tSeq, tSeqLen, diag, mat, par.rescoreMode);
+                updateAlignment(tmp[i], aln, qs, nuclQuerySeqLen, tSeq, tSeqLen);
+                if (tmp[i].seqId >= par.seqIdThr) alnQueue.push(tmp[i]);
+            }
+        }
+        if (queryCouldBeExtended) {                                                        // :336-342
+            nuclQuery.push_back('\n'); aaQuery.push_back('\n');
+            wasExtended[id] |= 0x20;
+            outNucl.add(queryKey, nuclQuery.data(), nuclQuery.size());
+            outAa.add(queryKey, aaQuery.data(), aaQuery.size());
+        }
+    }
+    for (size_t id = 0; id < N; id++) {                                                     // :346-367 (protein entry taken BY THE SAME id)
+        const bool isNotContig = !(wasExtended[id] & 0x20), wasNotExtended = !(wasExtended[id] & 0x80);
+        if (isNotContig && (par.keepTarget || wasNotExtended)) {
+            outNucl.add(nuclDb.key[id], nuclDb.entry(id), nuclDb.elen[id] - 1);
+            outAa.add(aaDb.key[id], aaDb.entry(id), aaDb.elen[id] - 1);
+        }
+    }
+    outNucl.sortByKey(); outAa.sortByKey();
+    return true;
+}
+
 }  // namespace oracle

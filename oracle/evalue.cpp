@@ -24,6 +24,16 @@ const unsigned char *aa2num(bool nucl, int alphabetSize) {
 Evaluer::Evaluer(bool nucl, uint64_t dbResidues)
     : g(nucl ? REF_NUC_GAPLESS_GUMBEL : REF_AA_GAPLESS_GUMBEL), logK(std::log(g[1])), dbRes((double) dbResidues) {}
 
+// gapped evaluer on the nucleotide matrix (proteinaln2nucl.cpp:54-58); only the penguin workflow's 5/2 penalties have
+// captured parameters (ALP simulates them at start-up with a fixed seed, EvalueComputation.h:46-51,92-100)
+Evaluer Evaluer::nuclGapped(int gapOpen, int gapExtend, uint64_t dbResidues, bool *ok) {
+    Evaluer e(true, dbResidues);
+    const bool have = (gapOpen == 5 && gapExtend == 2);
+    if (ok) *ok = have;
+    if (have) { e.g = REF_NUC_GAPPED_5_2_GUMBEL; e.logK = std::log(e.g[1]); }
+    return e;
+}
+
 // evaluer.bitScore(score, logK) = (lambda*score - logK)/log(2.0)
 double Evaluer::bitScore(double score) const { return std::fma(g[0], score, -logK) / std::log(2.0); }
 

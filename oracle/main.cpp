@@ -4,6 +4,8 @@
 //   plass_oracle kmermatcher <seqDB> <prefDB> [flags]
 //   plass_oracle rescorediagonal <qDB> <tDB> <prefDB> <alnDB> [flags]
 //   plass_oracle assembleresults|nuclassembleresults <seqDB> <alnDB> <outDB> [flags]
+//   plass_oracle guidedassembleresults <nuclDB> <aaDB> <nuclAlnDB> <outNuclDB> <outAaDB> [flags]
+//   plass_oracle proteinaln2nucl <qNuclDB> <tNuclDB> <qAaDB> <tAaDB> <alnDB> <outAlnDB> [flags]
 #include "oracle.hpp"
 #include <chrono>
 #include <cstdio>
@@ -56,6 +58,8 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
             else if (a == "--max-seq-len") par.maxSeqLen = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--keep-target") par.keepTarget = atoi(v.c_str()) != 0;
             else if (a == "--oracle-no-stale-scan") par.debugNoStaleScan = atoi(v.c_str()) != 0;
+            else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) par.gapOpenNucl = atoi(t.c_str()); }
+            else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) par.gapExtendNucl = atoi(t.c_str()); }
             else { /* accepted and ignored: --sub-mat --threads -v --compressed --mask … */ }
         } else pos.push_back(a);
     }
@@ -97,6 +101,25 @@ int main(int argc, char **argv) {
         DB out = (mod == "assembleresults") ? assembleresults(seq, aln, par) : nuclassembleresults(seq, aln, par);
         fprintf(stderr, "oracle %s: %.3f s\n", mod.c_str(), now() - t0);
         if (!writeDB(pos[2], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "guidedassembleresults") {
+        if (pos.size() != 5) { fprintf(stderr, "guidedassembleresults <nuclDB> <aaDB> <nuclAlnDB> <outNuclDB> <outAaDB>\n"); return 1; }
+        DB nucl, aa, aln, on, oa;
+        if (!readDB(pos[0], nucl, err) || !readDB(pos[1], aa, err) || !readDB(pos[2], aln, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        double t0 = now();
+        if (!guidedassembleresults(nucl, aa, aln, par, on, oa, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        fprintf(stderr, "oracle guidedassembleresults: %.3f s\n", now() - t0);
+        if (!writeDB(pos[3], on, err) || !writeDB(pos[4], oa, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "proteinaln2nucl") {
+        if (pos.size() != 6) { fprintf(stderr, "proteinaln2nucl <qNuclDB> <tNuclDB> <qAaDB> <tAaDB> <alnDB> <outAlnDB>\n"); return 1; }
+        DB qn, tn, qa, ta, aln, out;
+        const bool same = pos[0] == pos[1] && pos[2] == pos[3];
+        if (!same && (pos[0] == pos[1] || pos[2] == pos[3])) { fprintf(stderr, "Either query database == target database for nucleotide and amino acid or != for both\n"); return 1; }
+        if (!readDB(pos[0], qn, err) || !readDB(pos[2], qa, err) || !readDB(pos[4], aln, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!same && (!readDB(pos[1], tn, err) || !readDB(pos[3], ta, err))) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        double t0 = now();
+        if (!proteinaln2nucl(qn, same ? qn : tn, qa, same ? qa : ta, aln, par, out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        fprintf(stderr, "oracle proteinaln2nucl: %.3f s\n", now() - t0);
+        if (!writeDB(pos[5], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else { fprintf(stderr, "unknown module %s\n", mod.c_str()); return 1; }
     return 0;
 }

@@ -26,7 +26,7 @@ def oracle_bin():
 def golden(tmp_path_factory):
     """golden DBs written by the unmodified reference (tests/golden/make_golden.sh)"""
     d = tmp_path_factory.mktemp("golden")
-    for name in ("example_aa.tar.gz", "example_nucl.tar.gz", "stale_scan_cases.tar.gz"):
+    for name in ("example_aa.tar.gz", "example_nucl.tar.gz", "example_guided.tar.gz", "stale_scan_cases.tar.gz"):
         with tarfile.open(os.path.join(ROOT, "tests", "golden", name)) as t:
             t.extractall(d)
     return str(d)
@@ -90,6 +90,12 @@ NUCL_KM = ["--alph-size", "5", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "
            "--ignore-multi-kmer", "1", "--hash-shift", "67", "--include-only-extendable", "1"]
 NUCL_RS = ["--rescore-mode", "3", "-e", "1e-05", "-c", "0", "-a", "0", "--cov-mode", "0", "--min-seq-id", "0.99"]
 NUCL_AS = ["--min-seq-id", "0.99", "--max-seq-len", "200000", "--keep-target", "1", "--rescore-mode", "3"]
+# penguin guided_nuclassemble: protein k-mer matching / re-scoring on the translated ORFs, then nucleotide-level assembly
+GD_KM = ["--alph-size", "nucl:5,aa:13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "0.100", "-k", "14", "-c", "0", "--cov-mode", "1",
+         "--ignore-multi-kmer", "1", "--hash-shift", "67", "--include-only-extendable", "1"]
+GD_RS = ["--rescore-mode", "3", "-e", "1e-05", "-c", "0", "-a", "1", "--cov-mode", "1", "--min-seq-id", "0.97"]
+GD_P2N = ["--gap-open", "5", "--gap-extend", "2"]
+GD_AS = ["--min-seq-id", "0.99", "--max-seq-len", "200000", "--keep-target", "1", "--rescore-mode", "3"]
 
 
 def aa_iter_flags(i):

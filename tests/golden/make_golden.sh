@@ -74,5 +74,33 @@ iteration i: kmermatcher seq_i -> pref_i [$KM]; rescorediagonal -> aln_i [$RS]; 
 (no cyclecheck between iterations: out of scope, SURVEY.md §2)
 M
 tar -C $W -czf $HERE/example_nucl.tar.gz nucl
+
+# ---------- guided example (penguin guided_nuclassemble stage: protein-guided nucleotide assembly, config C5) ----------
+$PENGUIN guided_nuclassemble $EX/reads_1.fastq.gz $EX/reads_2.fastq.gz $W/outg.fas $W/tmpg --num-iterations 2 \
+       --remove-tmp-files 0 --delete-tmp-inc 0 $Q > $W/guided.log
+T=$(ls -d $W/tmpg/[0-9]*/)guidedassembly_tmp/
+S=$W/guided; mkdir -p $S
+$CANON ${T}nucl_6f_start_long $S/nucl_0; $CANON ${T}aa_6f_start_long $S/aa_0
+KM="--alph-size nucl:5,aa:13 --kmer-per-seq 60 --kmer-per-seq-scale 0.100 -k 14 -c 0 --cov-mode 1 --ignore-multi-kmer 1 --max-seq-len 200000 --hash-shift 67 --include-only-extendable 1"
+RS="--rescore-mode 3 -e 1e-05 -c 0 -a 1 --cov-mode 1 --min-seq-id 0.97 --min-aln-len 0 --seq-id-mode 0 --sort-results 0"
+P2N="--gap-open 5 --gap-extend 2"
+AS="--min-seq-id 0.99 --max-seq-len 200000 --keep-target 1 --rescore-mode 3"
+for i in 0 1; do
+  $PENGUIN kmermatcher $S/aa_$i $W/p $KM $Q >> $W/guided.log
+  $PENGUIN rescorediagonal $S/aa_$i $S/aa_$i $W/p $W/a $RS $Q >> $W/guided.log
+  $PENGUIN proteinaln2nucl $S/nucl_$i $S/nucl_$i $S/aa_$i $S/aa_$i $W/a $W/an $P2N $Q >> $W/guided.log
+  $PENGUIN guidedassembleresults $S/nucl_$i $S/aa_$i $W/an $W/sn $W/sa $AS $Q >> $W/guided.log
+  if [ $i -eq 0 ]; then $CANON $W/p $S/pref_$i; $CANON $W/a $S/aln_$i; $CANON $W/an $S/aln_nucl_$i; fi   # iteration 1: outputs only (size)
+  $CANON $W/sn $S/nucl_$((i+1)); $CANON $W/sa $S/aa_$((i+1))
+  rm -f $W/p* $W/a.* $W/a $W/an $W/an.* $W/sn $W/sn.* $W/sa $W/sa.* 2>/dev/null || true
+done
+cat > $S/MANIFEST <<M
+guided example: nucl_0 / aa_0 = nucl_6f_start_long / aa_6f_start_long of 'penguin guided_nuclassemble examples/reads_{1,2}.fastq.gz'
+iteration i: kmermatcher aa_i -> pref_i [$KM]; rescorediagonal aa_i aa_i pref_i -> aln_i [$RS];
+             proteinaln2nucl nucl_i nucl_i aa_i aa_i aln_i -> aln_nucl_i [$P2N];
+             guidedassembleresults nucl_i aa_i aln_nucl_i -> nucl_{i+1} aa_{i+1} [$AS]
+(pref / aln / aln_nucl kept for iteration 0 only)
+M
+tar -C $W -czf $HERE/example_guided.tar.gz guided
 ls -la $HERE/*.tar.gz
 rm -rf $W

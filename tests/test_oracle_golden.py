@@ -5,7 +5,7 @@ import os
 
 import pytest
 
-from conftest import (AA_AS, AA_KM, AA_RS, NUCL_AS, NUCL_KM, NUCL_RS, ROOT, aa_iter_flags, assert_same_db, run_oracle)
+from conftest import (AA_AS, AA_KM, AA_RS, GD_AS, GD_KM, GD_P2N, GD_RS, NUCL_AS, NUCL_KM, NUCL_RS, ROOT, aa_iter_flags, assert_same_db, run_oracle)
 
 
 @pytest.mark.parametrize("it", [0, 1, 2])
@@ -38,6 +38,28 @@ def test_oracle_nucl_iteration(oracle_bin, golden, tmp_path, it):
     assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "nucl rescorediagonal")
     run_oracle(oracle_bin, ["nuclassembleresults", f"{s}/seq_{it}", f"{s}/aln_{it}", tmp_path / "seq"] + NUCL_AS)
     assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "nuclassembleresults")
+
+
+def test_oracle_guided_iterations(oracle_bin, golden, tmp_path):
+    """penguin's protein-guided stage: kmermatcher + rescorediagonal (-a 1) on the protein twins, proteinaln2nucl,
+    guidedassembleresults; iteration 0 module by module, iteration 1 chained on the oracle's own DBs"""
+    s = os.path.join(golden, "guided")
+    t = tmp_path
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/aa_0", t / "pref"] + GD_KM)
+    assert_same_db(f"{s}/pref_0", t / "pref", "guided kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/aa_0", f"{s}/aa_0", f"{s}/pref_0", t / "aln"] + GD_RS)
+    assert_same_db(f"{s}/aln_0", t / "aln", "guided rescorediagonal -a 1")
+    run_oracle(oracle_bin, ["proteinaln2nucl", f"{s}/nucl_0", f"{s}/nucl_0", f"{s}/aa_0", f"{s}/aa_0", f"{s}/aln_0", t / "aln_nucl"] + GD_P2N)
+    assert_same_db(f"{s}/aln_nucl_0", t / "aln_nucl", "proteinaln2nucl")
+    run_oracle(oracle_bin, ["guidedassembleresults", f"{s}/nucl_0", f"{s}/aa_0", f"{s}/aln_nucl_0", t / "nucl_1", t / "aa_1"] + GD_AS)
+    assert_same_db(f"{s}/nucl_1", t / "nucl_1", "guidedassembleresults nucl")
+    assert_same_db(f"{s}/aa_1", t / "aa_1", "guidedassembleresults aa")
+    run_oracle(oracle_bin, ["kmermatcher", t / "aa_1", t / "pref1"] + GD_KM)
+    run_oracle(oracle_bin, ["rescorediagonal", t / "aa_1", t / "aa_1", t / "pref1", t / "aln1"] + GD_RS)
+    run_oracle(oracle_bin, ["proteinaln2nucl", t / "nucl_1", t / "nucl_1", t / "aa_1", t / "aa_1", t / "aln1", t / "aln_nucl1"] + GD_P2N)
+    run_oracle(oracle_bin, ["guidedassembleresults", t / "nucl_1", t / "aa_1", t / "aln_nucl1", t / "nucl_2", t / "aa_2"] + GD_AS)
+    assert_same_db(f"{s}/nucl_2", t / "nucl_2", "guided iteration 1 nucl")
+    assert_same_db(f"{s}/aa_2", t / "aa_2", "guided iteration 1 aa")
 
 
 def test_oracle_known_answers(oracle_bin):
