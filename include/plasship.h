@@ -1,5 +1,6 @@
 /* plasship — C-ABI of the MI355X-native Plass/PenguiN hot path
  *   kmermatcher -> rescorediagonal -> assembleresults | nuclassembleresults
+ *   kmermatcher -> rescorediagonal -a 1 -> proteinaln2nucl -> guidedassembleresults      (penguin guided_nuclassemble)
  *
  * This is the drop-in boundary.  In the reference each of the three steps is an
  * MMseqs2 "module" `int f(int argc, const char** argv, const Command&)` (mm/commons/Command.h:91-102)
@@ -180,6 +181,30 @@ typedef struct plasship_assemble_stats {
 
 int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *a,
                       const plasship_assemble_params *par, plasship_seqdb **out, plasship_assemble_stats *stats);
+
+/* ---- guidedassembleresults  (replaces int guidedassembleresults(int, const char**, const Command&),
+ *      src/assembler/guidedassembleresult.cpp:387-397; positional args <nuclDB> <aaDB> <nuclAlnDB> <outNuclDB> <outAaDB>,
+ *      flags as for assembleresults).  nucl_db and aa_db hold the same keys (ORF i and its translation); `a` is the
+ *      nucleotide-level alignment list (plasship_aln2nucl, or plasship_alns_read on nucl_db). ------------------------ */
+int plasship_guided_assemble(plasship_ctx *ctx, const plasship_seqdb *nucl_db, const plasship_seqdb *aa_db, const plasship_alns *a,
+                             const plasship_assemble_params *par, plasship_seqdb **out_nucl, plasship_seqdb **out_aa,
+                             plasship_assemble_stats *stats);
+
+/* ---- proteinaln2nucl  (replaces int proteinaln2nucl(int, const char**, const Command&), mm/util/proteinaln2nucl.cpp:13-204;
+ *      positional args <qNuclDB> <tNuclDB> <qAaDB> <tAaDB> <alnDB> <outAlnDB>).  `a` is a protein alignment list with
+ *      backtrace (plasship_rescore with add_backtrace, or plasship_alns_read on the protein DB); the result refers to the
+ *      nucleotide DBs.  Ungapped alignments only (what --rescore-mode 3 produces). ------------------------------------- */
+typedef struct plasship_aln2nucl_params {
+    int32_t gap_open;      /* --gap-open   (nucleotide value; the penguin workflow passes 5)                        */
+    int32_t gap_extend;    /* --gap-extend (nucleotide value; the penguin workflow passes 2)                        */
+} plasship_aln2nucl_params;
+typedef struct plasship_aln2nucl_stats {
+    uint64_t n_alignments;
+    float ms_kernel;
+} plasship_aln2nucl_stats;
+int plasship_aln2nucl(plasship_ctx *ctx, const plasship_seqdb *q_nucl, const plasship_seqdb *t_nucl, const plasship_seqdb *q_aa,
+                      const plasship_seqdb *t_aa, const plasship_alns *a, const plasship_aln2nucl_params *par, plasship_alns **out,
+                      plasship_aln2nucl_stats *stats);
 
 #ifdef __cplusplus
 }

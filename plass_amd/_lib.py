@@ -49,6 +49,14 @@ class AssembleStats(C.Structure):
                 ("tier_rescored_residues", C.c_uint64 * 3)]
 
 
+class _Aln2NuclParams(C.Structure):
+    _fields_ = [("gap_open", C.c_int32), ("gap_extend", C.c_int32)]
+
+
+class Aln2NuclStats(C.Structure):
+    _fields_ = [("n_alignments", C.c_uint64), ("ms_kernel", C.c_float)]
+
+
 class AlnRecord(C.Structure):
     _fields_ = [("query_key", C.c_uint32), ("target_key", C.c_uint32), ("bit_score", C.c_int32), ("raw_score", C.c_int32),
                 ("seq_id", C.c_float), ("q_start", C.c_int32), ("q_end", C.c_int32), ("q_len", C.c_int32),
@@ -83,6 +91,8 @@ SYMBOLS = [
     ("plasship_alns_download", C.c_int, [P, P, P]),
     ("plasship_alns_free", None, [P, P]),
     ("plasship_assemble", C.c_int, [P, P, P, C.POINTER(_AssembleParams), C.POINTER(P), C.POINTER(AssembleStats)]),
+    ("plasship_guided_assemble", C.c_int, [P, P, P, P, C.POINTER(_AssembleParams), C.POINTER(P), C.POINTER(P), C.POINTER(AssembleStats)]),
+    ("plasship_aln2nucl", C.c_int, [P, P, P, P, P, P, C.POINTER(_Aln2NuclParams), C.POINTER(P), C.POINTER(Aln2NuclStats)]),
 ]
 
 _lib = None
@@ -223,6 +233,19 @@ class Context:
         h = P(); st = AssembleStats(); cp = par._c()
         _check(self.lib.plasship_assemble(self.h, db.h, alns.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_assemble")
         return SeqDB(self, h), st
+
+    def guidedassembleresults(self, nucl_db, aa_db, alns, par=None):
+        """(nuclDB, aaDB, nucleotide-level alignments) -> (nuclDB', aaDB'); reference module guidedassembleresults"""
+        par = par or AssembleParams(min_seq_id=0.99, max_seq_len=200000)
+        hn = P(); ha = P(); st = AssembleStats(); cp = par._c()
+        _check(self.lib.plasship_guided_assemble(self.h, nucl_db.h, aa_db.h, alns.h, C.byref(cp), C.byref(hn), C.byref(ha), C.byref(st)), "plasship_guided_assemble")
+        return SeqDB(self, hn), SeqDB(self, ha), st
+
+    def proteinaln2nucl(self, nucl_db, aa_db, alns, gap_open=5, gap_extend=2):
+        """protein alignments (with backtrace) of aa_db onto the nucleotide twins in nucl_db; reference module proteinaln2nucl"""
+        h = P(); st = Aln2NuclStats(); cp = _Aln2NuclParams(gap_open, gap_extend)
+        _check(self.lib.plasship_aln2nucl(self.h, nucl_db.h, nucl_db.h, aa_db.h, aa_db.h, alns.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_aln2nucl")
+        return Alignments(self, h, nucl_db, nucl_db), st
 
     # the library picks the variant from the DB type; this name mirrors the reference module for nucleotide DBs
     def nuclassembleresults(self, db, alns, par=None):

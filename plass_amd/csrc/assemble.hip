@@ -57,6 +57,8 @@ struct AsmArgs {
     uint32_t *needKeys; uint32_t *needCount; uint32_t needCap;            // tuples the table lacks
     uint32_t *redoList; uint32_t *redoCount;                              // queries that met such a tuple: run again
     const uint32_t *queryList; uint32_t nQueryList;                       // list-driven pass (nullptr = all queries)
+    // guided variant: the protein twins (same ids) and their arena
+    SeqView aa; char *aaArena; const uint64_t *aaArenaOff; const uint32_t *aaLeftCap; uint32_t *aaNewLen; uint64_t *aaNewStart;
 };
 
 // text round trip of seqId (Util.cpp:278-307 + strtod in Matcher.cpp:265)
@@ -405,10 +407,15 @@ __device__ __forceinline__ Rescored rescoreOnDiagonalNucl(const char *q, unsigne
     return r;
 }
 
+// GUIDED = guidedassembleresults (src/assembler/guidedassembleresult.cpp:136-343): the same loop on nucleotide ORFs without
+// strand handling; hits are taken as parsed (no rescaling, :194-205 drops those below --min-seq-id), an extension never
+// crosses a '*' of the protein twins (:183-184,234-244) and is mirrored on the twin (:258-259,267-271,291-296).
+template <bool GUIDED>
 __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
     __shared__ uint32_t sPop;
     __shared__ int sAbort;
+    __shared__ uint32_t sPushed;
     for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
     __syncthreads();
     const int lane = threadIdx.x;
@@ -442,23 +449,36 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
             const int rawScore = (int) (fma((double) r.bitScore, a.ln2, a.logK) / a.lambda + 0.5);
             const float scorePerCol = (float) rawScore / (float) ((double) x.alnLength + 0.5);
             x.seqId = r.fromText ? r.seqId : seqIdThroughText(r.seqId);
-            x.score = (int) (scorePerCol * 100);
+            x.score = GUIDED ? r.bitScore : (int) (scorePerCol * 100);
             x.qStart = r.qStart; x.qEnd = r.qEnd; x.qLen = (uint32_t) r.qLen; x.dbStart = r.dbStart; x.dbEnd = r.dbEnd; x.dbLen = (uint32_t) r.dbLen;
             x.pad = 0;
-            if (x.qStart > x.qEnd) {
+            if (!GUIDED && x.qStart > x.qEnd) {
                 x.pad = 1;
                 const int t0 = x.qStart; x.qStart = x.qEnd; x.qEnd = t0;
                 const unsigned dbs = (unsigned) x.dbStart;
                 x.dbStart = (int) (x.dbLen - (unsigned) x.dbEnd - 1);
                 x.dbEnd = (int) (x.dbLen - dbs - 1);
             }
-            x.state = 0;
+            x.state = (GUIDED && x.seqId < a.seqIdThr) ? 2u : 0u;     // guided: re-evaluated on the nucleotide level, never queued
             it[i] = x;
         }
         __syncthreads();
         uint32_t nHeap = 0;
-        if (lane == 0) { for (uint32_t i = 0; i < h && !cmp.abort; i++) heapPush(hp, nHeap, i, it, cmp); if (cmp.abort) sAbort = 1; }
-        nHeap = h;
+        if (lane == 0) {
+            for (uint32_t i = 0; i < h && !cmp.abort; i++) if (it[i].state == 0) heapPush(hp, nHeap, i, it, cmp);
+            if (cmp.abort) sAbort = 1;
+            sPushed = nHeap;
+        }
+        __syncthreads();
+        nHeap = sPushed;
+        // guided: the protein twin of the query and its own arena slice
+        const char *aaQ = nullptr; char *aaBuf = nullptr; uint64_t aaStart = 0, aaLen = 0; bool exclL = false, exclR = false;
+        if (GUIDED) {
+            aaQ = a.aa.data + a.aa.off[id]; aaLen = a.aa.len[id];
+            exclL = aaQ[0] == '*'; exclR = aaQ[aaLen - 1] == '*';
+            aaBuf = a.aaArena + a.aaArenaOff[id]; aaStart = a.aaLeftCap[id];
+            copyBytesG<64>(aaBuf + aaStart, aaQ, (unsigned) aaLen, lane);
+        }
         char *buf = a.arena + aoff;
         uint64_t curStart = a.leftCap[id];
         for (uint32_t i = lane; i < querySeqLen; i += 64) buf[curStart + i] = orig[i];
@@ -486,8 +506,10 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
                 const char *tSeq = a.s.data + a.s.off[best.target];
                 const unsigned tLen = a.s.len[best.target];
                 const bool rev = best.pad != 0;
-                if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff) continue; }
-                else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff) continue; }
+                const char *aaT = nullptr; unsigned aaTLen = 0;
+                if (GUIDED) { aaT = a.aa.data + a.aa.off[best.target]; aaTLen = a.aa.len[best.target]; }
+                if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff || (GUIDED && (exclR || aaT[0] == '*'))) continue; }
+                else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff || (GUIDED && (exclL || aaT[aaTLen - 1] == '*'))) continue; }
                 const unsigned dbStart = (unsigned) best.dbStart, dbEnd = (unsigned) best.dbEnd, qStart = (unsigned) best.qStart, qEnd = (unsigned) best.qEnd;
                 if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
                     if (rightOff > 0) { if (lane == 0) def[nDef] = bi; nDef++; continue; }
@@ -496,6 +518,11 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
                     for (unsigned i = lane; i < fragLen; i += 64)
                         buf[curStart + curLen + i] = rev ? nuclRevN(tSeq[fragLen - 1 - i]) : tSeq[dbEnd + 1 + i];
                     curLen += fragLen; rightOff += fragLen;
+                    if (GUIDED) {                                    // protein twin: aaTargetSeq + dbEnd/3 + 1, (tLen/3 - dbEnd/3) - 1 bytes
+                        const unsigned aaFrag = (tLen / 3 - dbEnd / 3) - 1;
+                        if (aaStart + aaLen + aaFrag > a.aaArenaOff[id + 1] - a.aaArenaOff[id]) { if (lane == 0) atomicAdd(&a.stats[12], 1ull); }
+                        else { copyBytesG<64>(aaBuf + aaStart + aaLen, aaT + dbEnd / 3 + 1, aaFrag, lane); aaLen += aaFrag; }
+                    }
                     if (lane == 0) used[nUsed] = best.target;
                     nUsed++;
                 } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
@@ -506,6 +533,11 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
                     for (unsigned i = lane; i < fragLen; i += 64)
                         buf[curStart + i] = rev ? nuclRevN(tSeq[(tLen - dbStart) + (fragLen - 1 - i)]) : tSeq[i];
                     curLen += fragLen; leftOff += fragLen;
+                    if (GUIDED) {                                    // protein twin: the first fragLen/3 (+1 behind a start '*') residues
+                        const unsigned aaFrag = fragLen / 3 + ((aaT[0] == '*') ? 1u : 0u);
+                        if (aaFrag > aaStart) { if (lane == 0) atomicAdd(&a.stats[12], 1ull); }
+                        else { aaStart -= aaFrag; copyBytesG<64>(aaBuf + aaStart, aaT, aaFrag, lane); aaLen += aaFrag; }
+                    }
                     if (lane == 0) used[nUsed] = best.target;
                     nUsed++;
                 }
@@ -550,7 +582,10 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
             nAln += h; nQRes += a.s.len[id]; nResc += qResc; nRescRes += qRescRes;
             for (uint32_t i = lane; i < nUsed; i += 64) atomicOr(&a.flags[used[i]], 0x80u);
             if (couldExtend) {
-                if (lane == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; }
+                if (lane == 0) {
+                    atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart;
+                    if (GUIDED) { a.aaNewLen[id] = (uint32_t) aaLen; a.aaNewStart[id] = a.aaArenaOff[id] + aaStart; }
+                }
                 nExt++;
             }
         }
@@ -756,15 +791,17 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
 // positions into the work lists of the extension kernels (id order, no atomics)
 __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
                                 uint64_t *__restrict__ bytes, uint64_t maxSeqLen, int noPrescreen,
-                                uint64_t *__restrict__ tierA, uint64_t *__restrict__ tierB) {
+                                uint64_t *__restrict__ tierA, uint64_t *__restrict__ tierB,
+                                const uint32_t *__restrict__ aaLen, uint32_t *__restrict__ aaLeftCap, uint64_t *__restrict__ aaBytes) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
         int tier = -1;
-        uint64_t sum = 0;
+        uint64_t sum = 0, sumAa = 0;
         bool can = noPrescreen != 0;       // nucleotide hits are mirrored first; the loop decides
         for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) {
             const AlnRec r = recs[i];
             if (r.target == id) continue;
             sum += (uint64_t) r.dbLen;
+            sumAa += (uint64_t) r.dbLen / 3 + 2;               // guided: a twin fragment is at most dbLen/3 + 1 residues
             // exact pre-screen: the first extension of a query is decided by coordinates the alignment already
             // carries (selectFragmentToExtend + the two geometry tests, assembleresult.cpp:40-57,211-263); if no
             // alignment can start an extension the greedy loop drains its queue without changing anything.
@@ -777,6 +814,7 @@ __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, co
         }
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
         bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 8) : 0;
+        if (aaBytes) { aaLeftCap[id] = (uint32_t) std::min<uint64_t>(sumAa, 0xFFFFFFFFull); aaBytes[id] = (sum && can) ? (2 * sumAa + aaLen[id] + 8) : 0; }
         if (sum && can) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = (noPrescreen || h <= 16) ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3)); }   // nucleotide variant: one list
         tierA[id] = (tier == 0) ? 1ull : ((tier == 1) ? (1ull << 32) : 0ull);
         tierB[id] = (tier == 2) ? 1ull : ((tier == 3) ? (1ull << 32) : 0ull);
@@ -871,9 +909,48 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
     return PLASSHIP_OK;
 }
 
-extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al,
-                                 const plasship_assemble_params *par, plasship_seqdb **out, plasship_assemble_stats *stats) {
-    if (!ctx || !db || !al || !par || !out) { setError("plasship_assemble: bad argument"); return PLASSHIP_ERR_ARG; }
+// builds one output DB (extended entries from the arena + carried-over entries of `db`), entries in key order
+static int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
+                         const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out) {
+    hipStream_t st = ctx->stream;
+    const uint32_t N = (uint32_t) db->n;
+    const SeqView sv = db->view();
+    DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;
+    if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
+        dKeepPos.alloc(((size_t) N + 2) * 8) != hipSuccess || dMaxLen.alloc(4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (N) hipLaunchKernelGGL(outLenKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, dFlags, dNewLen, keepTarget, dOutBytes.as<uint64_t>(), dKeep.as<uint32_t>());
+    if (exclusiveScanU64(st, dOutBytes.as<uint64_t>(), dOutOff.as<uint64_t>(), N, dTmp, tmpBytes) ||
+        exclusiveScanU32(st, dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), N, dTmp, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t outBytes = 0, outN = 0;
+    PH_CHECK(hipMemcpyAsync(&outBytes, dOutOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(&outN, dKeepPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    plasship_seqdb *o = new plasship_seqdb();
+    o->dbtype = db->dbtype; o->n = (size_t) outN; o->dataBytes = outBytes; o->residues = outBytes - 2 * outN; o->hostIndexValid = false;
+    if (o->d_data.alloc(outBytes + 64) != hipSuccess || o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
+        delete o; setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
+    }
+    PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
+    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, sv, dFlags, dNewLen,
+                              dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
+                              o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+    PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
+    PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
+    if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
+    uint32_t maxLen = 0;
+    PH_CHECK(hipMemcpyAsync(&maxLen, dMaxLen.p, 4, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    o->maxEntryLen = maxLen + 2;
+    *out = o;
+    return PLASSHIP_OK;
+}
+
+// aaDb == nullptr: assembleresults (protein DB) / nuclassembleresults (nucleotide DB); aaDb != nullptr: guidedassembleresults
+static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_seqdb *aaDb, const plasship_alns *al,
+                        const plasship_assemble_params *par, plasship_seqdb **out, plasship_seqdb **outAa, plasship_assemble_stats *stats) {
+    const bool guided = aaDb != nullptr;
     // protein DB -> assembleresults; nucleotide DB -> nuclassembleresults (what the nuclassemble workflow runs on reads)
     const bool nucl = db->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES;
     if (!nucl && db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_assemble: the sequence DB is neither amino acids nor nucleotides"); return PLASSHIP_ERR_ARG; }
@@ -897,26 +974,32 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
     // work lists by queue size: [0] <= 16 alignments, [1] <= 32, [2] <= 64, [3] more (filled by arenaSizeKernel)
-    DevBuf dBigList, dMidList, dMid32List, dSmallList, dTierA, dTierB, dPosA, dPosB;
+    DevBuf dBigList, dMidList, dMid32List, dSmallList, dTierA, dTierB, dPosA, dPosB, dAaLeftCap, dAaBytes, dAaArenaOff, dAaArena, dAaNewLen, dAaNewStart;
+    if (guided && (dAaLeftCap.alloc(((size_t) N + 1) * 4) != hipSuccess || dAaBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dAaArenaOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
+                   dAaNewLen.alloc(((size_t) N + 1) * 4) != hipSuccess || dAaNewStart.alloc(((size_t) N + 1) * 8) != hipSuccess)) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (guided) PH_CHECK(hipMemsetAsync(dAaNewLen.p, 0, ((size_t) N + 1) * 4, st));
     if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMid32List.alloc(((size_t) N + 1) * 4) != hipSuccess ||
         dSmallList.alloc(((size_t) N + 1) * 4) != hipSuccess || dTierA.alloc(((size_t) N + 1) * 8) != hipSuccess || dTierB.alloc(((size_t) N + 1) * 8) != hipSuccess ||
         dPosA.alloc(((size_t) N + 2) * 8) != hipSuccess || dPosB.alloc(((size_t) N + 2) * 8) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len, nucl ? 1 : 0,
-                              dTierA.as<uint64_t>(), dTierB.as<uint64_t>());
+                              dTierA.as<uint64_t>(), dTierB.as<uint64_t>(),
+                              guided ? aaDb->d_len.as<uint32_t>() : (const uint32_t *) nullptr, dAaLeftCap.as<uint32_t>(), guided ? dAaBytes.as<uint64_t>() : (uint64_t *) nullptr);
+    if (guided && exclusiveScanU64(st, dAaBytes.as<uint64_t>(), dAaArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU64(st, dTierA.as<uint64_t>(), dPosA.as<uint64_t>(), N, dTmp.p, tmpBytes) || exclusiveScanU64(st, dTierB.as<uint64_t>(), dPosB.as<uint64_t>(), N, dTmp.p, tmpBytes)) {
         setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE;
     }
     if (N) hipLaunchKernelGGL(listKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, N, dTierA.as<uint64_t>(), dTierB.as<uint64_t>(), dPosA.as<uint64_t>(), dPosB.as<uint64_t>(),
                               dSmallList.as<uint32_t>(), dMid32List.as<uint32_t>(), dMidList.as<uint32_t>(), dBigList.as<uint32_t>());
     if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t arenaBytes = 0;
+    uint64_t arenaBytes = 0, aaArenaBytes = 0;
     uint64_t totA = 0, totB = 0;
+    if (guided) PH_CHECK(hipMemcpyAsync(&aaArenaBytes, dAaArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&arenaBytes, dArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&totA, dPosA.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&totB, dPosB.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     const uint32_t cnts[4] = {(uint32_t) totA, (uint32_t) (totA >> 32), (uint32_t) totB, (uint32_t) (totB >> 32)};
-    if (dArena.alloc(arenaBytes + 64) != hipSuccess) { setError("plasship_assemble: out of device memory for the extension arena"); return PLASSHIP_ERR_DEVICE; }
+    if (dArena.alloc(arenaBytes + 64) != hipSuccess || (guided && dAaArena.alloc(aaArenaBytes + 64) != hipSuccess)) { setError("plasship_assemble: out of device memory for the extension arena"); return PLASSHIP_ERR_DEVICE; }
     HostEvaluer ev(nucl, db->residues);
     AsmArgs a; memset(&a, 0, sizeof(a));
     a.s = sv; a.qoff = al->d_qoff.as<uint64_t>(); a.recs = al->d_recs.as<AlnRec>(); a.items = dItems.as<Item>(); a.arenaOff = dArenaOff.as<uint64_t>();
@@ -927,6 +1010,10 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     a.mid32List = dMid32List.as<uint32_t>(); a.nMid32 = cnts[1];
     a.midList = dMidList.as<uint32_t>(); a.nMid = cnts[2];
     a.bigList = dBigList.as<uint32_t>(); a.nBig = cnts[3];
+    if (guided) {
+        a.aa = aaDb->view(); a.aaArena = dAaArena.as<char>(); a.aaArenaOff = dAaArenaOff.as<uint64_t>(); a.aaLeftCap = dAaLeftCap.as<uint32_t>();
+        a.aaNewLen = dAaNewLen.as<uint32_t>(); a.aaNewStart = dAaNewStart.as<uint64_t>();
+    }
     DevBuf dHeap, dNeed, dRedo[2], dCnt;
     if (nucl) {
         const uint32_t needCap = 1u << 16;
@@ -945,7 +1032,8 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
             a.queryList = pass ? dRedo[(pass + 1) & 1].as<uint32_t>() : dSmallList.as<uint32_t>(); a.nQueryList = nWork;
             a.redoList = dRedo[pass & 1].as<uint32_t>();
             PH_CHECK(hipMemsetAsync(dCnt.p, 0, 8, st));
-            hipLaunchKernelGGL(assembleNuclKernel, dim3(std::min<uint32_t>(nWork, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
+            if (guided) hipLaunchKernelGGL(assembleNuclKernel<true>, dim3(std::min<uint32_t>(nWork, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
+            else hipLaunchKernelGGL(assembleNuclKernel<false>, dim3(std::min<uint32_t>(nWork, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
             uint32_t cnt[2] = {0, 0};
             PH_CHECK(hipMemcpyAsync(cnt, dCnt.p, 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(hipStreamSynchronize(st));
@@ -973,37 +1061,20 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
     if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(a.nBig, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[7], st));
     }
-    // ---- output DB: extended queries + carried-over sequences, in key order ----
-    DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;
-    if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
-        dKeepPos.alloc(((size_t) N + 2) * 8) != hipSuccess || dMaxLen.alloc(4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (N) hipLaunchKernelGGL(outLenKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), par->keep_target, dOutBytes.as<uint64_t>(), dKeep.as<uint32_t>());
-    if (exclusiveScanU64(st, dOutBytes.as<uint64_t>(), dOutOff.as<uint64_t>(), N, dTmp.p, tmpBytes) ||
-        exclusiveScanU32(st, dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t outBytes = 0, outN = 0;
-    PH_CHECK(hipMemcpyAsync(&outBytes, dOutOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipMemcpyAsync(&outN, dKeepPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
-    PH_CHECK(hipGetLastError());
-    plasship_seqdb *o = new plasship_seqdb();
-    o->dbtype = db->dbtype; o->n = (size_t) outN; o->dataBytes = outBytes; o->residues = outBytes - 2 * outN; o->hostIndexValid = false;
-    if (o->d_data.alloc(outBytes + 64) != hipSuccess || o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
-        delete o; setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
+    // ---- output DB(s): extended queries + carried-over sequences, in key order ----
+    plasship_seqdb *o = nullptr, *oAa = nullptr;
+    int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), dArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &o);
+    if (rcOut != PLASSHIP_OK) return rcOut;
+    if (guided) {
+        rcOut = buildOutputDB(ctx, aaDb, dFlags.as<uint32_t>(), dAaNewLen.as<uint32_t>(), dAaNewStart.as<uint64_t>(), dAaArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &oAa);
+        if (rcOut != PLASSHIP_OK) { delete o; return rcOut; }
     }
-    PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
-    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, sv, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(),
-                              dNewStart.as<uint64_t>(), dArena.as<char>(), dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
-                              o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
-    PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
-    PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
-    if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
-    uint32_t maxLen = 0; unsigned long long hs[16] = {0};
+    unsigned long long hs[16] = {0};
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
-    PH_CHECK(hipMemcpyAsync(&maxLen, dMaxLen.p, 4, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hs, dStats.p, 128, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
-    o->maxEntryLen = maxLen + 2;
+    if (hs[12]) { delete o; delete oAa; setError("plasship_guided_assemble: an alignment asks for a protein fragment the twin does not have (coordinates are not codon aligned)"); return PLASSHIP_ERR_ARG; }
     if (stats) {
         stats->n_extended = hs[0]; stats->n_rescored = hs[1]; stats->out_residues = o->residues;
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
@@ -1016,5 +1087,26 @@ extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, co
         stats->n_alignments = nLines; stats->rescored_residues = hs[2];
     }
     *out = o;
+    if (guided) *outAa = oAa;
     return PLASSHIP_OK;
+}
+
+extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al,
+                                 const plasship_assemble_params *par, plasship_seqdb **out, plasship_assemble_stats *stats) {
+    if (!ctx || !db || !al || !par || !out) { setError("plasship_assemble: bad argument"); return PLASSHIP_ERR_ARG; }
+    return assembleImpl(ctx, db, nullptr, al, par, out, nullptr, stats);
+}
+
+extern "C" int plasship_guided_assemble(plasship_ctx *ctx, const plasship_seqdb *nucl_db, const plasship_seqdb *aa_db, const plasship_alns *al,
+                                        const plasship_assemble_params *par, plasship_seqdb **out_nucl, plasship_seqdb **out_aa,
+                                        plasship_assemble_stats *stats) {
+    if (!ctx || !nucl_db || !aa_db || !al || !par || !out_nucl || !out_aa) { setError("plasship_guided_assemble: bad argument"); return PLASSHIP_ERR_ARG; }
+    if (nucl_db->dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES || aa_db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_guided_assemble: needs a nucleotide DB and its protein twin DB"); return PLASSHIP_ERR_ARG; }
+    if (nucl_db->n != aa_db->n) { setError("plasship_guided_assemble: the two DBs differ in size"); return PLASSHIP_ERR_ARG; }
+    PH_CHECK(hipSetDevice(ctx->device));
+    // the reference addresses the twin of entry i by the same id (guidedassembleresult.cpp:363): the key sets must be equal
+    bool differ = false;
+    { const int rc = deviceKeysDiffer(ctx, nucl_db->d_key.as<uint32_t>(), aa_db->d_key.as<uint32_t>(), nucl_db->n, &differ); if (rc) return rc; }
+    if (differ) { setError("plasship_guided_assemble: nucleotide and protein DB have different keys"); return PLASSHIP_ERR_ARG; }
+    return assembleImpl(ctx, nucl_db, aa_db, al, par, out_nucl, out_aa, stats);
 }

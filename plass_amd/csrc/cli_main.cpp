@@ -33,13 +33,14 @@ struct Flags {
     int rescoreMode = 3, minAlnLen = 0, seqIdMode = 0, addBt = 0, addSelf = 0, keepTarget = 1, wrapped = 0, filterHits = 0, sortResults = 0;
     double evalThr = 1e-5;
     unsigned long long maxSeqLen = 65535;
+    int gapOpenNucl = 5, gapExtendNucl = 2;
 };
 
 static int fail(const char *what) { fprintf(stdout, "%s: %s\n", what, plasship_last_error()); return EXIT_FAILURE; }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults> <dbs…> [flags]\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl> <dbs…> [flags]\n"); return EXIT_FAILURE; }
     const std::string mod = argv[1];
     Flags f; std::vector<std::string> pos;
     if (mod == "kmermatcher") f.covThr = 0.8f;   // setLinearFilterDefault (kmermatcher.cpp:566-573); workflows pass -c
@@ -66,6 +67,8 @@ int main(int argc, char **argv) {
             else if (a == "--add-self-matches") f.addSelf = atoi(v.c_str());
             else if (a == "--max-seq-len") f.maxSeqLen = strtoull(v.c_str(), nullptr, 10);
             else if (a == "--keep-target") f.keepTarget = atoi(v.c_str());
+            else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) f.gapOpenNucl = atoi(t.c_str()); }
+            else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) f.gapExtendNucl = atoi(t.c_str()); }
             else if (a == "--wrapped-scoring") f.wrapped = atoi(v.c_str());
             else if (a == "--filter-hits") f.filterHits = atoi(v.c_str());
             else if (a == "--sort-results") f.sortResults = atoi(v.c_str());
@@ -128,6 +131,31 @@ int main(int argc, char **argv) {
         fprintf(stdout, "extended: %llu rescored: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_extended, (unsigned long long) st.n_rescored, st.ms_kernel);
         if (plasship_seqdb_write(ctx, o, pos[2].c_str())) return fail("assembleresults");
         plasship_seqdb_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, db);
+    } else if (mod == "guidedassembleresults") {
+        if (pos.size() != 5) { fprintf(stdout, "guidedassembleresults <i:nuclSequenceDB> <i:aaSequenceDB> <i:nuclAlnResult> <o:nuclAssembly> <o:aaAssembly>\n"); return EXIT_FAILURE; }
+        plasship_seqdb *nu = nullptr, *aa = nullptr, *on = nullptr, *oa = nullptr; plasship_alns *al = nullptr;
+        if (plasship_seqdb_read(ctx, pos[0].c_str(), &nu) || plasship_seqdb_read(ctx, pos[1].c_str(), &aa)) return fail("guidedassembleresults");
+        if (plasship_alns_read(ctx, nu, pos[2].c_str(), &al)) return fail("guidedassembleresults");
+        plasship_assemble_params p; memset(&p, 0, sizeof(p));
+        p.seq_id_thr = f.seqIdThr; p.max_seq_len = f.maxSeqLen; p.keep_target = f.keepTarget; p.rescore_mode = f.rescoreMode;
+        plasship_assemble_stats st; memset(&st, 0, sizeof(st));
+        if (plasship_guided_assemble(ctx, nu, aa, al, &p, &on, &oa, &st)) return fail("guidedassembleresults");
+        fprintf(stdout, "extended: %llu rescored: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_extended, (unsigned long long) st.n_rescored, st.ms_kernel);
+        if (plasship_seqdb_write(ctx, on, pos[3].c_str()) || plasship_seqdb_write(ctx, oa, pos[4].c_str())) return fail("guidedassembleresults");
+        plasship_seqdb_free(ctx, on); plasship_seqdb_free(ctx, oa); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, aa); plasship_seqdb_free(ctx, nu);
+    } else if (mod == "proteinaln2nucl") {
+        if (pos.size() != 6) { fprintf(stdout, "proteinaln2nucl <i:queryNuclDB> <i:targetNuclDB> <i:queryAaDB> <i:targetAaDB> <i:alnDB> <o:alnDB>\n"); return EXIT_FAILURE; }
+        if ((pos[0] == pos[1]) != (pos[2] == pos[3])) { fprintf(stdout, "Either query database == target database for nucleotide and amino acid or != for both\n"); return EXIT_FAILURE; }
+        if (pos[0] != pos[1]) { fprintf(stdout, "plass-hip: proteinaln2nucl with separate query and target DBs is not supported (the assembly workflows use one DB)\n"); return EXIT_FAILURE; }
+        plasship_seqdb *nu = nullptr, *aa = nullptr; plasship_alns *al = nullptr, *o = nullptr;
+        if (plasship_seqdb_read(ctx, pos[0].c_str(), &nu) || plasship_seqdb_read(ctx, pos[2].c_str(), &aa)) return fail("proteinaln2nucl");
+        if (plasship_alns_read(ctx, aa, pos[4].c_str(), &al)) return fail("proteinaln2nucl");
+        plasship_aln2nucl_params p; p.gap_open = f.gapOpenNucl; p.gap_extend = f.gapExtendNucl;
+        plasship_aln2nucl_stats st; memset(&st, 0, sizeof(st));
+        if (plasship_aln2nucl(ctx, nu, nu, aa, aa, al, &p, &o, &st)) return fail("proteinaln2nucl");
+        fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
+        if (plasship_alns_write(ctx, o, pos[5].c_str())) return fail("proteinaln2nucl");
+        plasship_alns_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, aa); plasship_seqdb_free(ctx, nu);
     } else {
         fprintf(stdout, "plass-hip: module \"%s\" is not part of the GPU hot path (use the reference binary for it)\n", mod.c_str());
         rc = EXIT_FAILURE;

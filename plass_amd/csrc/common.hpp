@@ -67,7 +67,7 @@ struct AlnRec {
     int32_t reversed;
     int32_t accepted;
     int32_t fromText;
-    int32_t pad;
+    int32_t btKind;            // backtrace of the record: 0 unknown / none, 1 one run of alnLen 'M' (ungapped), 2 anything else
 };
 
 }  // namespace plasship
@@ -116,8 +116,14 @@ struct plasship_alns {
     bool nucl = false;
     bool addBacktrace = false;
     uint64_t dbResidues = 0;       // of the target DB (E-value area)
+    int gappedOpen = 0, gappedExtend = 0;   // != 0: E-values of the gapped nucleotide evaluer (list made by plasship_aln2nucl)
     plasship::DevBuf d_qoff;       // uint64 [nQueries+1]
     plasship::DevBuf d_recs;       // AlnRec [nLines]
     // DBs the list refers to (ids -> keys for text output); they must outlive this object
     const plasship_seqdb *qdb = nullptr, *tdb = nullptr;
 };
+
+namespace plasship {
+// sets *differ when two key arrays (device, n entries) are not identical
+int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, size_t n, bool *differ);
+}

@@ -72,6 +72,18 @@ void setError(const std::string &msg) { g_err = msg; }
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
     return std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
 }
+__global__ void keysDifferKernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t n, uint32_t *__restrict__ flag) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (a[i] != b[i]) *flag = 1u;
+}
+int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, size_t n, bool *differ) {
+    DevBuf dFlag; uint32_t d = 0;
+    if (dFlag.alloc(4) != hipSuccess) { setError("out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dFlag.p, 0, 4, ctx->stream));
+    if (n) hipLaunchKernelGGL(keysDifferKernel, dim3(std::min<uint32_t>(((uint32_t) n + 255) / 256, 1024)), dim3(256), 0, ctx->stream, a, b, (uint32_t) n, dFlag.as<uint32_t>());
+    PH_COPY_SYNC(ctx->stream, &d, dFlag.p, 4, hipMemcpyDeviceToHost);
+    *differ = d != 0;
+    return PLASSHIP_OK;
+}
 }  // namespace plasship
 using namespace plasship;
 

@@ -109,6 +109,12 @@ const unsigned char *aa2numTable(bool nucl, int alphabetSize) {
 // fused multiply-adds there (checked against known answers captured from it).
 HostEvaluer::HostEvaluer(bool nucl, uint64_t dbResidues)
     : g(nucl ? PH_NUC_GAPLESS_GUMBEL : PH_AA_GAPLESS_GUMBEL), logK(std::log(g[1])), ln2(std::log(2.0)), dbRes((double) dbResidues) {}
+bool HostEvaluer::nuclGapped(int gapOpen, int gapExtend, uint64_t dbResidues, HostEvaluer &out) {
+    if (gapOpen != 5 || gapExtend != 2) return false;
+    out = HostEvaluer(true, dbResidues);
+    out.g = PH_NUC_GAPPED_5_2_GUMBEL; out.logK = std::log(out.g[1]);
+    return true;
+}
 double HostEvaluer::bitScore(double s) const { return std::fma(g[0], s, -logK) / ln2; }
 double HostEvaluer::rawFromBit(double b) const { return std::fma(b, ln2, logK) / g[0]; }
 

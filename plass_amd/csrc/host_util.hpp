@@ -33,6 +33,9 @@ char *fmtU64(uint64_t v, char *p);
 struct HostEvaluer {
     const double *g; double logK, ln2, dbRes;
     HostEvaluer(bool nucl, uint64_t dbResidues);
+    // gapped evaluer on the nucleotide matrix as proteinaln2nucl builds it (mm/util/proteinaln2nucl.cpp:54-58); parameters exist
+    // for the penguin workflow's --gap-open 5 --gap-extend 2 only (captured from the reference's ALP run)
+    static bool nuclGapped(int gapOpen, int gapExtend, uint64_t dbResidues, HostEvaluer &out);
     double evalue(double score, double qLen) const;
     double bitScore(double score) const;
     double rawFromBit(double bits) const;

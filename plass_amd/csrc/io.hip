@@ -208,6 +208,7 @@ extern "C" int plasship_alns_write(plasship_ctx *ctx, const plasship_alns *a, co
     rc = hostKeys(ctx, a->qdb, &qk); if (rc) return rc;
     rc = hostKeys(ctx, a->tdb, &tk); if (rc) return rc;
     HostEvaluer ev(a->nucl, a->dbResidues);
+    if (a->gappedOpen && !HostEvaluer::nuclGapped(a->gappedOpen, a->gappedExtend, a->dbResidues, ev)) { setError("plasship_alns_write: no Gumbel parameters for these gap penalties"); return PLASSHIP_ERR_UNSUPPORTED; }
     std::string err; DBFileWriter w;
     if (!w.open(db_path, PLASSHIP_DBTYPE_ALIGNMENT_RES, err)) { setError(err); return PLASSHIP_ERR_IO; }
     std::string buf;
@@ -264,6 +265,12 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
             int aq = r.qStart == -1 ? 0 : r.qStart, ad = r.dbStart == -1 ? 0 : r.dbStart;
             r.alnLen = std::max(std::abs(r.qEnd - aq), std::abs(r.dbEnd - ad)) + 1;          // Matcher::computeAlnLength
             r.reversed = 0; r.accepted = 1; r.fromText = 1;
+            if (nf >= 11) {     // backtrace column: "<alnLen>M" is what rescorediagonal -a 1 writes (DistanceCalculator: ungapped)
+                const char *b = f[10]; long v = 0; bool digits = false;
+                while (*b >= '0' && *b <= '9') { v = v * 10 + (*b - '0'); b++; digits = true; }
+                const bool oneRun = digits && *b == 'M' && (b[1] == '\n' || b[1] == '\0' || b[1] == ' ' || b[1] == '\t');
+                r.btKind = (oneRun && v == r.alnLen) ? 1 : 2;
+            }
             recs.push_back(r);
             while (*p != '\n' && *p != '\0') p++;
             if (*p == '\n') p++;

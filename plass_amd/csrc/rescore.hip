@@ -212,7 +212,7 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
             rec.qStart = qS; rec.qEnd = qE; rec.qLen = (int) qLen; rec.dbStart = dS; rec.dbEnd = dE; rec.dbLen = (int) tLen;
             rec.alnLen = alnLen; rec.reversed = isReverse ? 1 : 0;
         }
-        rec.accepted = accepted ? 1 : 0;
+        rec.accepted = accepted ? 1 : 0; rec.btKind = 1;        // ungapped: the backtrace is one run of alnLen 'M'
         if (sl == 0) {
             a.out[h] = rec;
             a.accept[h] = accepted ? 1u : 0u;

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (AA_AS, AA_KM, AA_RS, NUCL_AS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle)
+from conftest import (AA_AS, AA_KM, AA_RS, GD_AS, GD_KM, GD_P2N, GD_RS, NUCL_AS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle)
 
 pytestmark = pytest.mark.gpu
 
@@ -138,6 +138,57 @@ def test_synthetic_nucl_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path):
         if it == 0:
             assert ast.n_extended > 1000
         db = db2
+
+
+def gd_km_params():
+    import plass_amd
+    return plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.1, hash_shift=67,
+                                     include_only_extendable=True, ignore_multi_kmer=True, cov_mode=1, c=0.0)
+
+
+def gd_rs_params():
+    import plass_amd
+    return plass_amd.RescoreParams(min_seq_id=0.97, cov_mode=1, a=True)
+
+
+def test_golden_guided_modules(ctx, golden, tmp_path):
+    """penguin's protein-guided stage, module by module on the reference's DBs: kmermatcher and rescorediagonal -a 1 on
+    the translated ORFs, proteinaln2nucl, guidedassembleresults (nucleotide ORFs + protein twins)"""
+    import plass_amd
+    s = os.path.join(golden, "guided")
+    aa = ctx.read_seqdb(f"{s}/aa_0"); nu = ctx.read_seqdb(f"{s}/nucl_0")
+    cands, _ = ctx.kmermatcher(aa, gd_km_params())
+    cands.write(tmp_path / "pref")
+    assert_same_db(f"{s}/pref_0", tmp_path / "pref", "guided kmermatcher")
+    pref = ctx.read_prefdb(aa, aa, f"{s}/pref_0")
+    alns, _ = ctx.rescorediagonal(aa, aa, pref, gd_rs_params())
+    alns.write(tmp_path / "aln")
+    assert_same_db(f"{s}/aln_0", tmp_path / "aln", "guided rescorediagonal -a 1")
+    aln_in = ctx.read_alndb(aa, f"{s}/aln_0")                      # text with backtrace column
+    naln, _ = ctx.proteinaln2nucl(nu, aa, aln_in)
+    naln.write(tmp_path / "aln_nucl")
+    assert_same_db(f"{s}/aln_nucl_0", tmp_path / "aln_nucl", "proteinaln2nucl")
+    naln_in = ctx.read_alndb(nu, f"{s}/aln_nucl_0")
+    on, oa, st = ctx.guidedassembleresults(nu, aa, naln_in)
+    on.write(tmp_path / "nucl_1"); oa.write(tmp_path / "aa_1")
+    assert_same_db(f"{s}/nucl_1", tmp_path / "nucl_1", "guidedassembleresults nucl")
+    assert_same_db(f"{s}/aa_1", tmp_path / "aa_1", "guidedassembleresults aa")
+    assert st.n_extended > 100
+
+
+def test_golden_guided_chained_on_device(ctx, golden, tmp_path):
+    """two guided iterations without touching disk: the contigs and their protein twins equal the reference's"""
+    s = os.path.join(golden, "guided")
+    aa = ctx.read_seqdb(f"{s}/aa_0"); nu = ctx.read_seqdb(f"{s}/nucl_0")
+    for it in range(2):
+        cands, _ = ctx.kmermatcher(aa, gd_km_params())
+        alns, _ = ctx.rescorediagonal(aa, aa, cands, gd_rs_params())
+        naln, _ = ctx.proteinaln2nucl(nu, aa, alns)
+        nu2, aa2, _ = ctx.guidedassembleresults(nu, aa, naln)
+        nu2.write(tmp_path / f"nucl_{it + 1}"); aa2.write(tmp_path / f"aa_{it + 1}")
+        assert_same_db(f"{s}/nucl_{it + 1}", tmp_path / f"nucl_{it + 1}", f"guided chained nucl it{it}")
+        assert_same_db(f"{s}/aa_{it + 1}", tmp_path / f"aa_{it + 1}", f"guided chained aa it{it}")
+        nu, aa = nu2, aa2
 
 
 @pytest.mark.parametrize("case", [1, 2, 3, 4])
