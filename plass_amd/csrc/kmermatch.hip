@@ -143,6 +143,38 @@ __device__ __forceinline__ bool kmerFromCodes(F codeAt, int k, unsigned char xCo
     return !hasX;
 }
 
+// Protein k-mer index straight from the code bytes in LDS (Indexer::int2index, mm/prefiltering/Indexer.h:20-83: sum code[i] *
+// base^i): two unaligned 8-byte LDS reads fetch all k <= 14 codes, an 'X' is found with a SWAR zero-byte test, the sum is two
+// 24-bit Horner halves (base <= 16 keeps every partial sum below 2^24) joined by one 32x32->64 multiply-add.  The window
+// loop is issue bound; this replaces 14 LDS byte reads and 14 64-bit multiply-adds per window.
+__device__ __forceinline__ bool kmerIndexFast(const unsigned char *w, int k, unsigned xCode, uint32_t base, uint32_t base7, uint64_t &kmer) {
+    uint64_t w0, w1; __builtin_memcpy(&w0, w, 8); __builtin_memcpy(&w1, w + 8, 8);
+    const uint64_t m0 = (k >= 8) ? ~0ULL : ((1ULL << (8 * k)) - 1ULL);
+    const uint64_t m1 = (k <= 8) ? 0ULL : ((1ULL << (8 * (k - 8))) - 1ULL);       // k <= 14
+    w0 &= m0; w1 &= m1;
+    const uint64_t ones = 0x0101010101010101ULL, highs = 0x8080808080808080ULL, xs = ones * xCode;
+    const uint64_t x0 = w0 ^ xs, x1 = w1 ^ xs;
+    const uint64_t z = (((x0 - ones) & ~x0 & highs) & m0) | (((x1 - ones) & ~x1 & highs) & m1);
+    const uint32_t a0 = (uint32_t) w0, a1 = (uint32_t) (w0 >> 32), b0 = (uint32_t) w1, b1 = (uint32_t) (w1 >> 32);
+    // codes c0..c6 = bytes 0..6 of w0; c7 = byte 7 of w0; c8..c13 = bytes 0..5 of w1
+    uint32_t lo = (a1 >> 16) & 0xFFu;                                   // c6
+    lo = __umul24(lo, base) + ((a1 >> 8) & 0xFFu);                      // c5
+    lo = __umul24(lo, base) + (a1 & 0xFFu);                             // c4
+    lo = __umul24(lo, base) + (a0 >> 24);                               // c3
+    lo = __umul24(lo, base) + ((a0 >> 16) & 0xFFu);                     // c2
+    lo = __umul24(lo, base) + ((a0 >> 8) & 0xFFu);                      // c1
+    lo = __umul24(lo, base) + (a0 & 0xFFu);                             // c0
+    uint32_t hi = (b1 >> 8) & 0xFFu;                                    // c13
+    hi = __umul24(hi, base) + (b1 & 0xFFu);                             // c12
+    hi = __umul24(hi, base) + (b0 >> 24);                               // c11
+    hi = __umul24(hi, base) + ((b0 >> 16) & 0xFFu);                     // c10
+    hi = __umul24(hi, base) + ((b0 >> 8) & 0xFFu);                      // c9
+    hi = __umul24(hi, base) + (b0 & 0xFFu);                             // c8
+    hi = __umul24(hi, base) + (a1 >> 24);                               // c7
+    kmer = (uint64_t) lo + (uint64_t) hi * (uint64_t) base7;
+    return z == 0;
+}
+
 constexpr uint32_t RES_L = 992;     // sequences up to this length keep their codes (and per-window hash scores) resident in LDS
 
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK>
@@ -161,6 +193,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
     const int k = a.k;
     for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
     __syncthreads();
+    const bool fastIdx = !NUCL && k <= 14 && a.powers[1] <= 16;      // see kmerIndexFast
     uint64_t pow31 = 1;                                    // 31^lane
     unsigned long long stRes = 0, stRec = 0;
     for (int i = 0; i < lane; i++) pow31 *= 31;
@@ -248,7 +281,8 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
                     if (!resident) __syncthreads();
                     valid = (p < nWin);
                     if (valid) {
-                        if (resident) valid = kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
+                        if (!NUCL && fastIdx) { pos = p; valid = kmerIndexFast(resident ? &sCodeAll[p] : &sCode[lane], k, (unsigned) a.xCode, (uint32_t) a.powers[1], (uint32_t) a.powers[7], kmer); }
+                        else if (resident) valid = kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                         else valid = kmerFromCodes<NUCL>([&](int i) { return sCode[lane + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                     }
                     if (valid) score = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
@@ -261,7 +295,10 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
                     valid = ((sValid[t0 >> 6] >> lane) & 1ULL) != 0;
                     score = valid ? (uint32_t) sScore[p] : 0u;
                     if (pass == 2 && valid && score <= sStar)      // only the ~60 selected windows rebuild their k-mer
-                        (void) kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
+                    {
+                        if (!NUCL && fastIdx) { pos = p; (void) kmerIndexFast(&sCodeAll[p], k, (unsigned) a.xCode, (uint32_t) a.powers[1], (uint32_t) a.powers[7], kmer); }
+                        else (void) kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
+                    }
                 }
                 bool push = false;
                 if (allCand) push = valid;
@@ -449,13 +486,14 @@ struct ShortArgs {
 template <bool LONG>
 __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
     __shared__ unsigned char sMap[256];
-    __shared__ __attribute__((aligned(16))) unsigned short sSet[64 * 128];   // per-lane open-addressing set of (score + 1)
+    __shared__ __attribute__((aligned(16))) unsigned short sSet[64 * 64];    // per-lane open-addressing set of (score + 1): 64 slots (8 KB per
+                                                                             // wavefront keeps ~4 wavefronts per SIMD resident; this kernel is latency bound)
     typedef Rec<LONG> R;
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
     __syncthreads();
-    unsigned short *mySet = sSet + lane * 128;
+    unsigned short *mySet = sSet + lane * 64;
     const int k = a.k;
     unsigned long long stRes = 0, stRec = 0;
     for (uint32_t b0 = blockIdx.x * 64; b0 < a.s.n; b0 += gridDim.x * 64) {
@@ -471,7 +509,7 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                 const char *base = a.s.data + a.s.off[id];
                 const uint64_t slot = a.slotOff[id];
                 const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - slot);
-                if (a.ignoreMulti) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 16; i++) q[i] = z; }
+                if (a.ignoreMulti) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 8; i++) q[i] = z; }
                 uint64_t idx = 0, seqHash = 0, fifoLo = 0, fifoHi = 0;   // fifo: the k codes of the current window, 8 bits each
                 uint64_t pw = 1;
                 int lastX = -1;
@@ -497,9 +535,11 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                             const uint32_t score = (uint32_t) (xxh64U64(idx, a.seed) & 0xFFFFu);
                             if (a.ignoreMulti) {
                                 const unsigned short tag = (unsigned short) (score + 1);
-                                if (tag == 0) toWave = true;
-                                uint32_t sl = (score * 40503u >> 7) & 127;
-                                for (;;) { const unsigned short v = mySet[sl]; if (v == tag) { toWave = true; break; } if (v == 0) { mySet[sl] = tag; break; } sl = (sl + 1) & 127; }
+                                if (tag == 0 || nOut >= 48) toWave = true;      // table nearly full: let the wave kernel do this one
+                                else {
+                                    uint32_t sl = (score * 40503u >> 7) & 63;
+                                    for (;;) { const unsigned short v = mySet[sl]; if (v == tag) { toWave = true; break; } if (v == 0) { mySet[sl] = tag; break; } sl = (sl + 1) & 63; }
+                                }
                             }
                             R r; r.kmer = idx; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) p;
                             if constexpr (LONG) r.pad = 0;
@@ -1143,7 +1183,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         sa.scale = ea.scale; sa.seed = ea.seed; sa.base = (uint64_t) (alph - 1); sa.top = ea.powers[k - 1];
         { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
         sa.waveList = dWaveList.as<uint32_t>(); sa.waveCount = dWaveCount.as<uint32_t>(); sa.kstats = dKStats.as<unsigned long long>();
-        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((N + 63) / 64, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, sa);
+        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((N + 63) / 64, (uint32_t) ctx->numCU * 20)), dim3(64), 0, st, sa);
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
