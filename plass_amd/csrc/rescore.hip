@@ -111,6 +111,23 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
     unsigned last = len - 1;
     if (last > 0 && (qe == '*' || te == '*')) last--;
     int s = 0, ids = 0;
+    if (!REV && G == 1) {
+        // one thread per pair: 16 residues of both sequences per round trip (unaligned 16-byte loads; buffers are padded).
+        // The loop is bound by the number of memory requests, not by bytes: every lane streams its own two sequences.
+        for (unsigned p = first; p <= last; p += 16u) {
+            uint64_t qw[2], tw[2];
+            __builtin_memcpy(qw, q + qo + p, 16); __builtin_memcpy(tw, t + to + p, 16);
+            const unsigned n = min(16u, last - p + 1);
+#pragma unroll
+            for (unsigned j = 0; j < 16; j++) {
+                if (j < n) {
+                    const unsigned a = (unsigned) (qw[j >> 3] >> (8 * (j & 7))) & 0xFFu, b = (unsigned) (tw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
+                    s += (int) smat[a * 123 + b];
+                    ids += ((a & ~0x20u) == (b & ~0x20u)) ? 1 : 0;
+                }
+            }
+        }
+    } else
     for (unsigned p = first + 4u * (unsigned) sl; p <= last; p += 4u * G) {
         // 4 consecutive residues of both sequences (unaligned dword loads; the DB buffer is padded past its end)
         uint32_t tw = loadU32Unaligned(t + to + p);
