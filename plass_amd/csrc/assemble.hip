@@ -750,6 +750,33 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
             const char *qs = buf + curStart;
             unsigned long long deferred = groupBallot<G>(xState == 1);
             if (deferred) waveMemSync();
+            if (G >= 32) {
+                // wide queues: every deferred lane re-scores its own hit (8 residues per step), all hits of the round in
+                // parallel and without cross-lane traffic; with a dozen or more deferred hits this beats taking them one
+                // after the other with the whole group (most of whose lanes idle on a 50-150 residue overlap)
+                if (xState == 1) {
+                    const char *tSeq = a.s.data + xTOff;
+                    const int diag = (int) ((unsigned) xQStart + leftOff) - xDbStart;
+                    const unsigned dist = (unsigned) abs(diag);
+                    unsigned qo = 0, to = 0, len = 0; bool hit = true;
+                    if (diag >= 0 && dist < querySeqLen) { qo = dist; to = 0; len = min(xTLen, querySeqLen - dist); }
+                    else if (diag < 0 && dist < xTLen) { qo = 0; to = dist; len = min(xTLen - dist, querySeqLen); }
+                    else hit = false;
+                    unsigned first = 0, last = 0; int sc = 0, ids = 0; int startPos = -1, endPos = -1;
+                    if (hit && len > 0) { scoreColumnsG<1>(qs + qo, tSeq + to, len, smat, 0, first, last, sc, ids); startPos = (int) first; endPos = (int) last; }
+                    const unsigned score = (unsigned) max(sc, 0);
+                    nResc += 1; nRescRes += hit ? len : 0;
+                    int qS, qE, dS, dE;
+                    if (diag >= 0) { qS = startPos + (int) dist; qE = endPos + (int) dist; dS = startPos; dE = endPos; }
+                    else { qS = startPos; qE = endPos; dS = startPos + (int) dist; dE = endPos + (int) dist; }
+                    const float seqId = (float) ids / ((float) qE - (float) qS);
+                    const float spc = (float) score / (float) ((double) (hit ? len : 0u) + 0.5);
+                    xQLen = querySeqLen; xDbLen = xTLen; xAlnLen = hit ? len : 0u; xScore = (int) (spc * 100);
+                    xQStart = qS; xQEnd = qE; xDbStart = dS; xDbEnd = dE;
+                    xState = (seqId >= a.seqIdThr) ? 0u : 2u;
+                }
+                deferred = 0;
+            }
             while (deferred) {
                 const int dl = __ffsll((long long) deferred) - 1;
                 deferred &= deferred - 1;
