@@ -176,57 +176,86 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
         while (inQueue > 0) {
             unsigned leftOff = 0, rightOff = 0;
             bool brokeOut = false;
-            // deferred list of this round = items with state 1; clear leftovers of the previous round
-            for (uint32_t i = lane; i < h; i += 64) if (it[i].state == 1) it[i].state = 2;
-            __syncthreads();
-            for (;;) {
-                // ---- selectFragmentToExtend: pop the maximum until one is extendable ----
-                int bs = INT_MIN; uint32_t bl = 0, bt = 0xFFFFFFFFu, bi = 0xFFFFFFFFu;
-                for (uint32_t i = lane; i < h; i += 64) {
-                    const Item x = it[i];
-                    if (x.state != 0) continue;
-                    const bool better = (bi == 0xFFFFFFFFu) || (x.score > bs) || (x.score == bs && (x.alnLength > bl || (x.alnLength == bl && x.target < bt)));
-                    if (better) { bs = x.score; bl = x.alnLength; bt = x.target; bi = i; }
+            // ---- one round as a function of the set of queued hits (see assembleGroupKernel): best right-extendable and
+            //      best left-extendable hit, then every popped hit classified with the final offsets ----
+            unsigned long long bestR = 0, bestL = 0; uint32_t idxR = 0xFFFFFFFFu, idxL = 0xFFFFFFFFu;
+            for (uint32_t i = lane; i < h; i += 64) {
+                Item x = it[i];
+                if (x.state == 1) { it[i].state = 2; continue; }      // leftovers of the previous round
+                if (x.state != 0) continue;
+                // ranks inside the queue are not precomputed here: ties on (score, alnLength) are broken by the smaller target id
+                const unsigned long long key = ((unsigned long long) ((uint32_t) x.score ^ 0x80000000u) << 32) | (unsigned long long) x.alnLength;
+                const bool notBoth = !(x.dbStart == 0 && x.qStart == 0);
+                const bool rightStart = x.dbStart == 0 && (x.dbEnd != (int) x.dbLen - 1);
+                const bool leftStart = x.qStart == 0 && (x.qEnd != (int) x.qLen - 1);
+                if (!((rightStart || leftStart) && notBoth) || x.target == id) continue;
+                const unsigned tLen = a.s.len[x.target];
+                if (x.dbStart == 0) {
+                    const unsigned fragR = tLen - ((unsigned) x.dbEnd + 1);
+                    if (fragR > 0 && (unsigned) x.qEnd == (querySeqLen - 1) && (key > bestR || (key == bestR && x.target < it[idxR].target))) { bestR = key; idxR = i; }
+                } else if (x.qStart == 0) {
+                    if (x.dbStart > 0 && (unsigned) x.dbEnd == (tLen - 1) && (key > bestL || (key == bestL && x.target < it[idxL].target))) { bestL = key; idxL = i; }
                 }
+            }
+            // wave arg-max with the target id as the final tie-break
+            uint32_t tgtR = idxR != 0xFFFFFFFFu ? it[idxR].target : 0xFFFFFFFFu, tgtL = idxL != 0xFFFFFFFFu ? it[idxL].target : 0xFFFFFFFFu;
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const int os = __shfl_xor(bs, o, 64); const uint32_t ol = __shfl_xor(bl, o, 64), ot = __shfl_xor(bt, o, 64), oi = __shfl_xor(bi, o, 64);
-                    const bool better = (oi != 0xFFFFFFFFu) && ((bi == 0xFFFFFFFFu) || (os > bs) || (os == bs && (ol > bl || (ol == bl && ot < bt))));
-                    if (better) { bs = os; bl = ol; bt = ot; bi = oi; }
-                }
-                if (bi == 0xFFFFFFFFu) { inQueue = 0; break; }      // queue empty
-                Item best = it[bi];
-                __syncthreads();
-                if (lane == 0) it[bi].state = 2;                    // popped
-                inQueue--;
-                __syncthreads();
-                const bool notBoth = !(best.dbStart == 0 && best.qStart == 0);
-                const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
-                const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
-                const bool notIdentity = best.target != id;
-                if (!((rightStart || leftStart) && notBoth && notIdentity)) continue;    // discarded
-                const char *tSeq = a.s.data + a.s.off[best.target];
-                const unsigned tLen = a.s.len[best.target];
-                if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff) continue; }
-                else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff) continue; }
-                const unsigned dbStart = (unsigned) best.dbStart, dbEnd = (unsigned) best.dbEnd, qStart = (unsigned) best.qStart, qEnd = (unsigned) best.qEnd;
-                if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
-                    if (rightOff > 0) { if (lane == 0) it[bi].state = 1; __syncthreads(); continue; }
-                    const unsigned fragLen = tLen - (dbEnd + 1);
-                    copyBytesG<64>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, lane);
-                    curLen += fragLen; rightOff += fragLen;
-                    if (lane == 0) atomicOr(&a.flags[best.target], 0x80u);
-                } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
-                    if (leftOff > 0) { if (lane == 0) it[bi].state = 1; __syncthreads(); continue; }
-                    const unsigned fragLen = dbStart;
-                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+            for (int o = 32; o > 0; o >>= 1) {
+                const unsigned long long okR = __shfl_xor(bestR, o, 64), okL = __shfl_xor(bestL, o, 64);
+                const uint32_t oiR = __shfl_xor(idxR, o, 64), oiL = __shfl_xor(idxL, o, 64), otR = __shfl_xor(tgtR, o, 64), otL = __shfl_xor(tgtL, o, 64);
+                if (oiR != 0xFFFFFFFFu && (idxR == 0xFFFFFFFFu || okR > bestR || (okR == bestR && otR < tgtR))) { bestR = okR; idxR = oiR; tgtR = otR; }
+                if (oiL != 0xFFFFFFFFu && (idxL == 0xFFFFFFFFu || okL > bestL || (okL == bestL && otL < tgtL))) { bestL = okL; idxL = oiL; tgtL = otL; }
+            }
+            const bool haveR = idxR != 0xFFFFFFFFu, haveL = idxL != 0xFFFFFFFFu;
+            // full priority order between the two: (score, alnLength) then the smaller target id wins
+            const bool rFirst = haveR && (!haveL || bestR > bestL || (bestR == bestL && tgtR < tgtL));
+            __syncthreads();
+            auto extendRight = [&]() {
+                const Item x = it[idxR];
+                const char *tSeq = a.s.data + a.s.off[x.target];
+                const unsigned tLen = a.s.len[x.target], dbEnd = (unsigned) x.dbEnd, fragLen = tLen - (dbEnd + 1);
+                copyBytesG<64>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, lane);
+                curLen += fragLen; rightOff += fragLen;
+                if (lane == 0) atomicOr(&a.flags[x.target], 0x80u);
+            };
+            if (rFirst) extendRight();
+            if (haveL) {
+                const Item x = it[idxL];
+                const unsigned fragLen = (unsigned) x.dbStart;
+                if (curLen + fragLen >= a.maxSeqLen) brokeOut = true;
+                else {
+                    const char *tSeq = a.s.data + a.s.off[x.target];
                     curStart -= fragLen;
                     copyBytesG<64>(buf + curStart, tSeq, fragLen, lane);
                     curLen += fragLen; leftOff += fragLen;
-                    if (lane == 0) atomicOr(&a.flags[best.target], 0x80u);
+                    if (lane == 0) atomicOr(&a.flags[x.target], 0x80u);
                 }
-                __syncthreads();
             }
+            if (haveR && !rFirst && !brokeOut) extendRight();
+            __syncthreads();
+            uint32_t still = 0;
+            for (uint32_t i = lane; i < h; i += 64) {
+                const Item x = it[i];
+                if (x.state != 0) continue;
+                if (brokeOut) {                                    // hits ranked below the left hit were never popped
+                    const unsigned long long key = ((unsigned long long) ((uint32_t) x.score ^ 0x80000000u) << 32) | (unsigned long long) x.alnLength;
+                    const bool below = key < bestL || (key == bestL && x.target > tgtL);
+                    if (below) { still++; continue; }
+                }
+                uint32_t st = 2;
+                const bool used = (i == idxR && (rFirst || !brokeOut)) || i == idxL;
+                const bool notBoth = !(x.dbStart == 0 && x.qStart == 0);
+                const bool rightStart = x.dbStart == 0 && (x.dbEnd != (int) x.dbLen - 1);
+                const bool leftStart = x.qStart == 0 && (x.qEnd != (int) x.qLen - 1);
+                if (!used && (rightStart || leftStart) && notBoth && x.target != id) {
+                    const unsigned tLen = a.s.len[x.target];
+                    if (x.dbStart == 0) { if ((tLen - ((unsigned) x.dbEnd + 1)) > rightOff && (unsigned) x.qEnd == (querySeqLen - 1) && rightOff > 0) st = 1; }
+                    else if (x.qStart == 0) { if (x.dbStart > (int) leftOff && (unsigned) x.dbEnd == (tLen - 1) && leftOff > 0) st = 1; }
+                }
+                it[i].state = st;
+            }
+            inQueue = (uint32_t) waveReduceSum((int) still);
+            __syncthreads();
             if (leftOff > 0 || rightOff > 0) couldExtend = true;
             if (brokeOut && inQueue > 0) break;
             // ---- re-score deferred hits on the extended query (assembleresult.cpp:288-313) ----
@@ -695,54 +724,63 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
             unsigned leftOff = 0, rightOff = 0;
             bool brokeOut = false;
             if (xState == 1) xState = 2;
-            for (;;) {
-                // ---- selectFragmentToExtend: arg-max of (score, alnLength, smaller key) = priority_queue::top ----
-                unsigned long long key = 0;
-                if (xState == 0) key = ((unsigned long long) ((uint32_t) xScore ^ 0x80000000u) << 32) | ((unsigned long long) xAlnLen << 6) | (unsigned long long) (63u - tRank);
-                const unsigned long long best = groupMax<G>(key);
-                if (best == 0) { inQueue = 0; break; }
-                const bool mine = (key == best);                   // exactly one lane (ranks are distinct)
-                inQueue--;
-                // the owning lane has everything the geometry tests need (offsets and lengths are group-uniform): it
-                // decides, the group learns the outcome through a ballot; only an actual extension broadcasts data
-                int act = 0;                                       // 0 discarded, 1 deferred, 2 right, 3 left, 4 length cap
-                if (mine) {
-                    xState = 2;                                    // popped
-                    const bool notBoth = !(xDbStart == 0 && xQStart == 0);
-                    const bool rightStart = xDbStart == 0 && (xDbEnd != (int) xDbLen - 1);
-                    const bool leftStart = xQStart == 0 && (xQEnd != (int) xQLen - 1);
-                    if ((rightStart || leftStart) && notBoth) {
-                        bool skip = false;
-                        if (xDbStart == 0) skip = (xTLen - ((unsigned) xDbEnd + 1)) <= rightOff;
-                        else if (xQStart == 0) skip = xDbStart <= (int) leftOff;
-                        if (!skip) {
-                            if ((unsigned) xDbStart == 0 && (unsigned) xQEnd == (querySeqLen - 1)) act = (rightOff > 0) ? 1 : 2;
-                            else if ((unsigned) xQStart == 0 && (unsigned) xDbEnd == (xTLen - 1))
-                                act = (leftOff > 0) ? 1 : ((curLen + (unsigned) xDbStart >= a.maxSeqLen) ? 4 : 3);
-                        }
-                    }
-                    if (act == 1) xState = 1;
+            // ---- one round of the reference's pop loop (assembleresult.cpp:203-283), without popping hit by hit.
+            // The comparator is a strict total order, so the round is a function of the SET of queued hits: the best hit
+            // that can extend to the right does so, the best that can extend to the left does so (whichever ranks higher
+            // first: the length cap of the left extension sees the right fragment only then); every other hit is popped
+            // after "its" extension (a hit popped earlier would have been the extension itself, or is one the geometry
+            // tests drop whatever the offsets are) and is dropped or deferred by the same tests with the final offsets.
+            // O(1) reductions per round instead of one arg-max per popped hit (O(h) per round).
+            unsigned long long key = 0;
+            bool rType = false, lType = false, rBranch = false, lBranch = false;
+            unsigned fragR = 0;
+            if (xState == 0) {
+                key = ((unsigned long long) ((uint32_t) xScore ^ 0x80000000u) << 32) | ((unsigned long long) xAlnLen << 6) | (unsigned long long) (63u - tRank);
+                const bool notBoth = !(xDbStart == 0 && xQStart == 0);
+                const bool rightStart = xDbStart == 0 && (xDbEnd != (int) xDbLen - 1);
+                const bool leftStart = xQStart == 0 && (xQEnd != (int) xQLen - 1);
+                if ((rightStart || leftStart) && notBoth) {
+                    if (xDbStart == 0) { rBranch = true; fragR = xTLen - ((unsigned) xDbEnd + 1); rType = fragR > 0 && (unsigned) xQEnd == (querySeqLen - 1); }
+                    else if (xQStart == 0) { lBranch = true; lType = xDbStart > 0 && (unsigned) xDbEnd == (xTLen - 1); }
                 }
-                const unsigned long long ext = groupBallot<G>(act >= 2);
-                if (ext == 0) continue;
-                const int bi = __ffsll((long long) ext) - 1;
-                const int bAct = __shfl(act, bi, G);
-                if (bAct == 4) { brokeOut = true; break; }
+            }
+            const unsigned long long bestR = groupMax<G>(rType ? key : 0ULL), bestL = groupMax<G>(lType ? key : 0ULL);
+            const bool rFirst = bestR != 0 && bestR > bestL;
+            const bool isR = rType && key == bestR, isL = lType && key == bestL;
+            auto extendRight = [&]() {
+                const int bi = __ffsll((long long) groupBallot<G>(isR)) - 1;
                 const char *tSeq = a.s.data + __shfl(xTOff, bi, G);
                 const uint32_t bTarget = __shfl(xTarget, bi, G);
-                if (bAct == 2) {                                                         // right extension
-                    const unsigned tLen = __shfl(xTLen, bi, G), dbEnd = (unsigned) __shfl(xDbEnd, bi, G);
-                    const unsigned fragLen = tLen - (dbEnd + 1);
-                    copyBytesG<G>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, gl);
-                    curLen += fragLen; rightOff += fragLen;
-                } else {                                                                 // left extension
-                    const unsigned fragLen = (unsigned) __shfl(xDbStart, bi, G);
+                const unsigned fragLen = __shfl(fragR, bi, G), dbEnd = (unsigned) __shfl(xDbEnd, bi, G);
+                copyBytesG<G>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, gl);
+                curLen += fragLen; rightOff += fragLen;
+                if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
+            };
+            if (rFirst) extendRight();
+            if (bestL != 0) {
+                const int bi = __ffsll((long long) groupBallot<G>(isL)) - 1;
+                const unsigned fragLen = (unsigned) __shfl(xDbStart, bi, G);
+                if (curLen + fragLen >= a.maxSeqLen) brokeOut = true;                  // assembleresult.cpp:259-263
+                else {
+                    const char *tSeq = a.s.data + __shfl(xTOff, bi, G);
+                    const uint32_t bTarget = __shfl(xTarget, bi, G);
                     curStart -= fragLen;
                     copyBytesG<G>(buf + curStart, tSeq, fragLen, gl);
                     curLen += fragLen; leftOff += fragLen;
+                    if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
                 }
-                if (gl == 0) atomicOr(&a.flags[bTarget], 0x80u);
             }
+            if (bestR != 0 && !rFirst && !brokeOut) extendRight();
+            // every hit of the round that was popped: used, dropped or deferred
+            if (xState == 0 && (!brokeOut || key >= bestL)) {       // at the length cap the hits ranked below the left hit stay queued
+                uint32_t st = 2;
+                if (!(isR && (rFirst || !brokeOut)) && !isL) {
+                    if (rBranch) { if (fragR > rightOff && (unsigned) xQEnd == (querySeqLen - 1) && rightOff > 0) st = 1; }
+                    else if (lBranch) { if (xDbStart > (int) leftOff && (unsigned) xDbEnd == (xTLen - 1) && leftOff > 0) st = 1; }
+                }
+                xState = st;
+            }
+            inQueue = (uint32_t) __popcll(groupBallot<G>(xState == 0));
             if (leftOff > 0 || rightOff > 0) couldExtend = true;
             if (brokeOut && inQueue > 0) break;
             // ---- re-score deferred hits on the extended query (assembleresult.cpp:288-313) ----
