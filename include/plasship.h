@@ -93,6 +93,8 @@ typedef struct plasship_kmermatch_stats {
     /* per kernel: one-thread-per-sequence kernel (short reads) and wave-per-sequence kernel (the rest) */
     float ms_extract_short_kernel, ms_extract_wave_kernel;
     uint64_t short_residues, short_records, wave_residues, wave_records;
+    float ms_part_scatter;      /* the partScatterKernel launches of the hash partition (sort #1), summed            */
+    int32_t n_part_scatter;     /* how many (1 or 2 levels)                                                          */
 } plasship_kmermatch_stats;
 
 int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par,

@@ -25,7 +25,8 @@ class KmermatchStats(C.Structure):
                 ("record_bytes", C.c_uint32), ("ms_extract", C.c_float), ("ms_sort1", C.c_float),
                 ("ms_group", C.c_float), ("ms_sort2", C.c_float), ("ms_reduce", C.c_float), ("ms_extract_kernel", C.c_float),
                 ("residues", C.c_uint64), ("ms_extract_short_kernel", C.c_float), ("ms_extract_wave_kernel", C.c_float),
-                ("short_residues", C.c_uint64), ("short_records", C.c_uint64), ("wave_residues", C.c_uint64), ("wave_records", C.c_uint64)]
+                ("short_residues", C.c_uint64), ("short_records", C.c_uint64), ("wave_residues", C.c_uint64), ("wave_records", C.c_uint64),
+                ("ms_part_scatter", C.c_float), ("n_part_scatter", C.c_int32)]
 
 
 class _RescoreParams(C.Structure):

@@ -75,7 +75,7 @@ struct AlnRec {
 struct plasship_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[16] = {};
     int numCU = 0;
     // nuclassembleresults: comparator decisions that lie on a threshold, resolved with the host libm (assemble.hip);
     // kept for the lifetime of the context (the same few (alpha, beta) tuples recur in every iteration)

@@ -1241,7 +1241,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (exclusiveScanU32(st, dCnt1.as<uint32_t>(), dStart1.as<uint64_t>(), nB1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dCur1.as<unsigned long long>(), (uint64_t) nB1);
     pa.minKey = nullptr;
+    PH_CHECK(hipEventRecord(ctx->ev[8], st));
     hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
+    PH_CHECK(hipEventRecord(ctx->ev[9], st));
+    int nScatter = 1;
     std::vector<uint64_t> hStart1(nB1 + 1);
     PH_CHECK(hipMemcpyAsync(hStart1.data(), dStart1.p, ((size_t) nB1 + 1) * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
@@ -1260,7 +1263,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), 0, st, p2);
         if (exclusiveScanU32(st, dCnt2.as<uint32_t>(), dStart2.as<uint64_t>(), nB, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB, 256, 1024)), dim3(256), 0, st, dStart2.as<uint64_t>(), dCur2.as<unsigned long long>(), (uint64_t) nB);
+        PH_CHECK(hipEventRecord(ctx->ev[10], st));
         hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), 0, st, p2);
+        PH_CHECK(hipEventRecord(ctx->ev[11], st));
+        nScatter = 2;
         std::swap(cur, other);
         dBucketStart = dStart2.as<uint64_t>();
     }
@@ -1489,6 +1495,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         {
             float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
             stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;
+            float msS = 0, msS2 = 0; (void) hipEventElapsedTime(&msS, ctx->ev[8], ctx->ev[9]); if (nScatter == 2) (void) hipEventElapsedTime(&msS2, ctx->ev[10], ctx->ev[11]);
+            stats->ms_part_scatter = msS + msS2; stats->n_part_scatter = nScatter;
             unsigned long long ks[4] = {0, 0, 0, 0};
             PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost);
             stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
