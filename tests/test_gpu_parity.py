@@ -236,6 +236,44 @@ def test_synthetic_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path):
         db = db2
 
 
+def test_length_cap_vs_oracle(ctx, oracle_bin, tmp_path):
+    """--max-seq-len small enough that the length cap fires all the time (assembleresult.cpp:259-263: left extension only;
+    nuclassembleresult.cpp:271-275,301-305: both sides): the round then stops at the capped hit, hits ranked below it stay
+    queued and the query is abandoned with what it has"""
+    import plass_amd
+    from plass_amd import synth
+    data, off, elen, key = synth.protein_fragment_db(12000, seed=31)
+    synth.write_db(str(tmp_path / "a_seq_0"), data, off, elen, key, 0)
+    db = ctx.upload_seqdb(data, off, elen, key, 0)
+    for it in range(3):
+        cap = (90, 140, 200)[it]
+        run_oracle(oracle_bin, ["kmermatcher", tmp_path / f"a_seq_{it}", tmp_path / "o_pref"] + AA_KM + aa_iter_flags(it))
+        run_oracle(oracle_bin, ["rescorediagonal", tmp_path / f"a_seq_{it}", tmp_path / f"a_seq_{it}", tmp_path / "o_pref", tmp_path / "o_aln"] + AA_RS)
+        run_oracle(oracle_bin, ["assembleresults", tmp_path / f"a_seq_{it}", tmp_path / "o_aln", tmp_path / f"a_seq_{it + 1}", "--min-seq-id", "0.9",
+                                "--max-seq-len", str(cap), "--keep-target", "1", "--rescore-mode", "3"])
+        cands, _ = ctx.kmermatcher(db, km_params(it))
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+        db2, st = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=cap))
+        db2.write(tmp_path / "g_seq")
+        assert_same_db(tmp_path / f"a_seq_{it + 1}", tmp_path / "g_seq", f"assembleresults with --max-seq-len {cap} it{it}")
+        db = db2
+    data, off, elen, key = synth.nucleotide_read_db(6000, seed=33)
+    synth.write_db(str(tmp_path / "n_seq_0"), data, off, elen, key, 1)
+    db = ctx.upload_seqdb(data, off, elen, key, 1)
+    for it in range(2):
+        cap = (260, 400)[it]
+        run_oracle(oracle_bin, ["kmermatcher", tmp_path / f"n_seq_{it}", tmp_path / "o_pref"] + NUCL_KM)
+        run_oracle(oracle_bin, ["rescorediagonal", tmp_path / f"n_seq_{it}", tmp_path / f"n_seq_{it}", tmp_path / "o_pref", tmp_path / "o_aln"] + NUCL_RS)
+        run_oracle(oracle_bin, ["nuclassembleresults", tmp_path / f"n_seq_{it}", tmp_path / "o_aln", tmp_path / f"n_seq_{it + 1}", "--min-seq-id", "0.99",
+                                "--max-seq-len", str(cap), "--keep-target", "1", "--rescore-mode", "3"])
+        cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+        db2, st = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.99, max_seq_len=cap))
+        db2.write(tmp_path / "g_seq")
+        assert_same_db(tmp_path / f"n_seq_{it + 1}", tmp_path / "g_seq", f"nuclassembleresults with --max-seq-len {cap} it{it}")
+        db = db2
+
+
 def _write_fasta_like_db(path, seqs, dbtype=0, keys=None):
     from plass_amd import synth
     arrs = [np.frombuffer(s.encode(), dtype=np.uint8) for s in seqs]
