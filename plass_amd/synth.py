@@ -154,6 +154,35 @@ def nucleotide_read_db(n_pairs, genome_len=None, seed=1, coverage=20.0):
     return pack_db([_BASES[r] for r in reads])
 
 
+def orf_twin_dbs(n_pairs, genome_len=None, seed=1, coverage=20.0, min_codons=45):
+    """PenguiN's guided stage works on nucleotide ORFs and their translations under the same keys (extractorfs +
+    translatenucs --add-orf-stop).  Returns (nucl_db, aa_db), each (data, off, elen, key): for every read and frame the
+    stop-free stretch of >= min_codons codons (a terminal stop codon is kept: '*' in the protein twin), the nucleotide
+    entry being exactly the 3*len codons the protein entry translates.  Simple per-read loop (test sizes)."""
+    rng = np.random.default_rng(seed)
+    if genome_len is None:
+        genome_len = max(20000, int(300 * n_pairs / coverage))
+    genome = make_genome(rng, genome_len)
+    reads = make_reads(rng, genome, n_pairs)
+    tab = _codon_table()
+    nucl, aa = [], []
+    for r in reads:
+        for strand in (r, (3 - r)[::-1]):
+            for f in range(3):
+                nc = (strand.size - f) // 3
+                c = strand[f:f + 3 * nc].reshape(nc, 3).astype(np.int64)
+                prot = tab[c[:, 0] * 16 + c[:, 1] * 4 + c[:, 2]]
+                stops = np.nonzero(prot == ord("*"))[0]
+                # stop-free stretches (a stretch may end WITH its stop codon)
+                begin = 0
+                for e in list(stops) + [nc]:
+                    end = min(e + 1, nc) if e < nc else nc          # include the stop codon when there is one
+                    if (e - begin) >= min_codons:
+                        aa.append(prot[begin:end].copy()); nucl.append(_BASES[strand[f + 3 * begin:f + 3 * end]])
+                    begin = e + 1
+    return pack_db(nucl), pack_db(aa)
+
+
 def write_db(path, data, off, elen, key, dbtype=0):
     with open(path, "wb") as f:
         f.write(data)

@@ -236,6 +236,41 @@ def test_synthetic_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path):
         db = db2
 
 
+def test_synthetic_guided_vs_oracle(ctx, oracle_bin, tmp_path):
+    """protein-guided nucleotide assembly on synthetic ORF twins (a few thousand reads at 20x): protein k-mer matching and
+    re-scoring with backtrace, proteinaln2nucl, guidedassembleresults — every DB of two iterations equals the oracle's,
+    also with a small --max-seq-len in the second one"""
+    import plass_amd
+    from plass_amd import synth
+    (nd, no, ne, nk), (ad, ao, ae, ak) = synth.orf_twin_dbs(2500, seed=41)
+    t = tmp_path
+    synth.write_db(str(t / "nucl_0"), nd, no, ne, nk, 1); synth.write_db(str(t / "aa_0"), ad, ao, ae, ak, 0)
+    nu = ctx.upload_seqdb(nd, no, ne, nk, 1); aa = ctx.upload_seqdb(ad, ao, ae, ak, 0)
+    for it in range(2):
+        cap = (200000, 420)[it]
+        as_flags = ["--min-seq-id", "0.99", "--max-seq-len", str(cap), "--keep-target", "1", "--rescore-mode", "3"]
+        run_oracle(oracle_bin, ["kmermatcher", t / f"aa_{it}", t / "o_pref"] + GD_KM)
+        run_oracle(oracle_bin, ["rescorediagonal", t / f"aa_{it}", t / f"aa_{it}", t / "o_pref", t / "o_aln"] + GD_RS)
+        run_oracle(oracle_bin, ["proteinaln2nucl", t / f"nucl_{it}", t / f"nucl_{it}", t / f"aa_{it}", t / f"aa_{it}", t / "o_aln", t / "o_aln_nucl"] + GD_P2N)
+        run_oracle(oracle_bin, ["guidedassembleresults", t / f"nucl_{it}", t / f"aa_{it}", t / "o_aln_nucl", t / f"nucl_{it + 1}", t / f"aa_{it + 1}"] + as_flags)
+        cands, _ = ctx.kmermatcher(aa, gd_km_params())
+        cands.write(t / "g_pref")
+        assert_same_db(t / "o_pref", t / "g_pref", f"guided kmermatcher it{it}")
+        alns, _ = ctx.rescorediagonal(aa, aa, cands, gd_rs_params())
+        alns.write(t / "g_aln")
+        assert_same_db(t / "o_aln", t / "g_aln", f"guided rescorediagonal it{it}")
+        naln, _ = ctx.proteinaln2nucl(nu, aa, alns)
+        naln.write(t / "g_aln_nucl")
+        assert_same_db(t / "o_aln_nucl", t / "g_aln_nucl", f"proteinaln2nucl it{it}")
+        nu2, aa2, st = ctx.guidedassembleresults(nu, aa, naln, plass_amd.AssembleParams(min_seq_id=0.99, max_seq_len=cap))
+        nu2.write(t / "g_nucl"); aa2.write(t / "g_aa")
+        assert_same_db(t / f"nucl_{it + 1}", t / "g_nucl", f"guidedassembleresults nucl it{it}")
+        assert_same_db(t / f"aa_{it + 1}", t / "g_aa", f"guidedassembleresults aa it{it}")
+        if it == 0:
+            assert st.n_extended > 200
+        nu, aa = nu2, aa2
+
+
 def test_length_cap_vs_oracle(ctx, oracle_bin, tmp_path):
     """--max-seq-len small enough that the length cap fires all the time (assembleresult.cpp:259-263: left extension only;
     nuclassembleresult.cpp:271-275,301-305: both sides): the round then stops at the capped hit, hits ranked below it stay
