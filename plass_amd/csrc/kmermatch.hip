@@ -599,11 +599,21 @@ struct PartArgs {
     int shift, bits, rangeBits, dropSentinels;
     int sharedTable;                // all segments accumulate into one bucket table (segment id does not offset it)
     unsigned long long *minKey;     // optional: global minimum of (kmer | BIT63) (NUCL first-run quirk)
+    // optional: histogram of the records by k-mer VALUE (VH_BINS monotone bins of the sort-#1 key): bounds the sort-#1 rank
+    // of any record without sorting, which is all the stale-record check (section 7) needs most of the time
+    uint32_t *valueHist; int valueShift;
 };
+constexpr uint32_t VH_BINS = 4096;
+template <bool NUCL> __device__ __host__ __forceinline__ uint32_t valueBin(uint64_t kmerField, int shift) {
+    const uint64_t v = NUCL ? (kmerField & ~BIT63) : kmerField;       // sort #1 compares (kmer | bit 63) for nucleotides
+    const uint64_t b = v >> shift;
+    return b < VH_BINS ? (uint32_t) b : VH_BINS - 1;                   // identity records (64-bit hashes) collect in the last bin
+}
 
 template <bool NUCL, bool LONG, int MODE>
 __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
     __shared__ uint32_t sh[4096];
+    __shared__ uint32_t shv[VH_BINS];
     typedef Rec<LONG> R;
     const R *in = reinterpret_cast<const R *>(a.in);
     const uint32_t seg = blockIdx.y;
@@ -612,6 +622,7 @@ __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
     if (t0 >= cnt) return;
     const uint32_t nb = 1u << a.bits;
     for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) sh[i] = 0;
+    if (a.valueHist) for (uint32_t i = threadIdx.x; i < VH_BINS; i += PT_BLOCK) shv[i] = 0;
     __syncthreads();
     unsigned long long mn = ~0ULL;
 #pragma unroll 4
@@ -622,11 +633,13 @@ __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
             if (a.dropSentinels && isSentinel(r)) continue;
             const uint32_t b = (uint32_t) (bucketKey<NUCL, MODE>(r.kmer, a.rangeBits) >> a.shift) & (nb - 1);
             atomicAdd(&sh[b], 1u);
+            if (a.valueHist) atomicAdd(&shv[valueBin<NUCL>(r.kmer, a.valueShift)], 1u);
             if (NUCL && a.minKey) mn = min(mn, (unsigned long long) (r.kmer | BIT63));
         }
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) atomicAdd(&a.count[(a.sharedTable ? 0 : ((uint64_t) seg << a.bits)) + i], c); }
+    if (a.valueHist) for (uint32_t i = threadIdx.x; i < VH_BINS; i += PT_BLOCK) { const uint32_t c = shv[i]; if (c) atomicAdd(&a.valueHist[i], c); }
     if (NUCL && a.minKey) {
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned long long) __shfl_xor(mn, o, 64));
@@ -1236,11 +1249,19 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     pa.in = dA.p; pa.out = dB.p; pa.segStart = dSeg0Start.as<uint64_t>(); pa.segCount = dSeg0Cnt.as<uint64_t>(); pa.count = dCnt1.as<uint32_t>();
     pa.cursor = dCur1.as<unsigned long long>(); pa.shift = 64 - b1; pa.bits = b1; pa.rangeBits = 0; pa.dropSentinels = 1; pa.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
     if (b1 == 0) pa.shift = 63;   // single bucket: (key >> 63) & 0 == 0
+    // value histogram for the stale-record check: bins of the k-mer value (real k-mers need keyBits bits)
+    DevBuf dVHist;
+    if (dVHist.alloc(VH_BINS * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dVHist.p, 0, VH_BINS * 4, st));
+    int keyBits = 0;
+    if (NUCL) keyBits = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
+    const int valueShift = std::max(0, keyBits - 12);
+    pa.valueHist = dVHist.as<uint32_t>(); pa.valueShift = valueShift;
     const unsigned tiles0 = (unsigned) std::max<uint64_t>(1, (total + PT_TILE - 1) / PT_TILE);
     hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
     if (exclusiveScanU32(st, dCnt1.as<uint32_t>(), dStart1.as<uint64_t>(), nB1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dCur1.as<unsigned long long>(), (uint64_t) nB1);
-    pa.minKey = nullptr;
+    pa.minKey = nullptr; pa.valueHist = nullptr;
     PH_CHECK(hipEventRecord(ctx->ev[8], st));
     hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
     PH_CHECK(hipEventRecord(ctx->ev[9], st));
@@ -1327,7 +1348,17 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         trec.erase(std::remove_if(trec.begin(), trec.end(), [](const R &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }), trec.end());
         std::sort(trec.begin(), trec.end(), [](const R &x, const R &y) { return recLess1<NUCL, LONG>(x, y); });
         const uint32_t m = (uint32_t) trec.size();
+        // cheap exact filter first: the value histogram bounds the sort-#1 rank of every record of T; the scan can only reach
+        // a record of T if rank N_m itself can be one of them
+        bool mayHit = false;
         if (m) {
+            std::vector<uint32_t> vh(VH_BINS);
+            PH_COPY_SYNC(st, vh.data(), dVHist.p, VH_BINS * 4, hipMemcpyDeviceToHost);
+            std::vector<uint64_t> cum(VH_BINS + 1, 0);
+            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + vh[b];
+            for (uint32_t j = 0; j < m && !mayHit; j++) { const uint32_t b = valueBin<NUCL>(trec[j].kmer, valueShift); mayHit = Nm >= cum[b] && Nm < cum[b + 1]; }
+        }
+        if (m && mayHit) {
             PH_CHECK(hipMemcpyAsync(dTRec.p, trec.data(), (size_t) m * sizeof(R), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((rankKernel<NUCL, LONG>), dim3(gridFor(Nk, 256, (unsigned) ctx->numCU * 8)), dim3(256), 0, st, (const void *) other, Nk, (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
             std::vector<unsigned long long> diff((size_t) m + 1);
