@@ -725,7 +725,7 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
     __shared__ uint32_t hCnt[GR_HT];
     __shared__ uint32_t hLen[GR_HT];
     __shared__ uint32_t sFlag[2];
-    __shared__ uint32_t sWaveCnt[GR_BLOCK / 64];
+    __shared__ uint32_t sCursor;
     typedef Rec<LONG> R;
     const R *in = reinterpret_cast<const R *>(a.in);
     R *out = reinterpret_cast<R *>(a.out);
@@ -745,7 +745,7 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
             bool redo = false;
             for (uint32_t sub = 0; sub < nSub && !redo; sub++) {
                 for (uint32_t i = threadIdx.x; i < GR_HT; i += GR_BLOCK) { hKey[i] = ~0ULL; hBest[i] = ~0ULL; hCnt[i] = 0; hLen[i] = 0; }
-                if (threadIdx.x == 0) { sFlag[0] = 0; sFlag[1] = 0; }
+                if (threadIdx.x == 0) { sFlag[0] = 0; sFlag[1] = 0; sCursor = 0; }
                 __syncthreads();
                 // phase A: insert keys, count members, longest sequence
                 for (uint64_t i = s0 + threadIdx.x; i < s1; i += GR_BLOCK) {
@@ -819,18 +819,21 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
                             }
                         }
                     }
-                    // block-wide compaction into this block's arena
+                    // compaction into this block's arena: the order inside the arena is irrelevant (the next stage is a
+                    // partition), so every wavefront just claims a run from an LDS cursor — no block barrier in this loop
                     const unsigned long long mk = __ballot(keep);
                     const uint32_t wr = (uint32_t) __popcll(mk & ((1ULL << laneId()) - 1ULL));
-                    if (laneId() == 0) sWaveCnt[threadIdx.x >> 6] = (uint32_t) __popcll(mk);
-                    __syncthreads();
-                    uint32_t woff = 0, tot = 0;
-#pragma unroll
-                    for (int w = 0; w < GR_BLOCK / 64; w++) { if (w < (int) (threadIdx.x >> 6)) woff += sWaveCnt[w]; tot += sWaveCnt[w]; }
-                    if (keep) out[arena + written + woff + wr] = o;
-                    written += tot;
-                    __syncthreads();
+                    uint32_t wbase = 0;
+                    if (mk) {
+                        if (laneId() == 0) wbase = atomicAdd(&sCursor, (uint32_t) __popcll(mk));
+                        wbase = __shfl(wbase, 0, 64);
+                    }
+                    if (keep) out[arena + written + wbase + wr] = o;
                 }
+                __syncthreads();
+                written += sCursor;
+                __syncthreads();
+                if (threadIdx.x == 0) sCursor = 0;
             }
             if (!redo) break;
             // a retry discards what completed sub-passes of this attempt wrote: rewind the arena cursor
@@ -1230,7 +1233,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
 
     // ---- hash partition (replaces sort #1) ----
     tm.start(0);
-    const int totalBits = std::max(0, ceilLog2((total + 767) / 768));          // ~768 records per final bucket
+    const int totalBits = std::max(0, ceilLog2((total + 1535) / 1536));        // ~1000-1500 records per final bucket: the group kernel pays a fixed
+                                                                               // number of block barriers per bucket
     // coarse level first: few wide buckets => every tile writes long contiguous runs; the fine level then scatters inside a
     // bucket that fits the L2 / Infinity Cache
     const int b2w = (totalBits > 11) ? 11 : 0;
