@@ -649,8 +649,9 @@ __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
 
 template <bool NUCL, bool LONG, int MODE>
 __global__ __launch_bounds__(PT_BLOCK) void partScatterKernel(PartArgs a) {
-    __shared__ uint32_t sh[4096];
-    __shared__ unsigned long long sbase[4096];
+    // bucket tables sized by the launch (dynamic LDS: 12 bytes per bucket): with the few hundred buckets of a level the
+    // kernel is limited by registers, not by LDS, and more tiles are in flight per CU
+    extern __shared__ unsigned long long ptDyn[];
     typedef Rec<LONG> R;
     const R *in = reinterpret_cast<const R *>(a.in);
     R *out = reinterpret_cast<R *>(a.out);
@@ -659,18 +660,20 @@ __global__ __launch_bounds__(PT_BLOCK) void partScatterKernel(PartArgs a) {
     const uint64_t t0 = (uint64_t) blockIdx.x * PT_TILE;
     if (t0 >= cnt) return;
     const uint32_t nb = 1u << a.bits;
+    unsigned long long *sbase = ptDyn;                                   // [nb]
+    uint32_t *sh = reinterpret_cast<uint32_t *>(ptDyn + nb);             // [nb]
     for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) sh[i] = 0;
     __syncthreads();
-    R recs[PT_ITEMS]; uint32_t bkt[PT_ITEMS]; uint32_t rk[PT_ITEMS];
+    R recs[PT_ITEMS]; uint32_t br[PT_ITEMS];                             // bucket (12 bits) | rank inside the tile's bucket (<= 4096: 13 bits)
 #pragma unroll
     for (int it = 0; it < PT_ITEMS; it++) {
         const uint64_t i = t0 + (uint64_t) it * PT_BLOCK + threadIdx.x;
-        bkt[it] = 0xFFFFFFFFu;
+        br[it] = 0xFFFFFFFFu;
         if (i < cnt) {
             recs[it] = in[s0 + i];
             if (!(a.dropSentinels && isSentinel(recs[it]))) {
-                bkt[it] = (uint32_t) (bucketKey<NUCL, MODE>(recs[it].kmer, a.rangeBits) >> a.shift) & (nb - 1);
-                rk[it] = atomicAdd(&sh[bkt[it]], 1u);
+                const uint32_t b = (uint32_t) (bucketKey<NUCL, MODE>(recs[it].kmer, a.rangeBits) >> a.shift) & (nb - 1);
+                br[it] = (b << 16) | atomicAdd(&sh[b], 1u);
             }
         }
     }
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(PT_BLOCK) void partScatterKernel(PartArgs a) {
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PT_ITEMS; it++)
-        if (bkt[it] != 0xFFFFFFFFu) out[sbase[bkt[it]] + rk[it]] = recs[it];
+        if (br[it] != 0xFFFFFFFFu) out[sbase[br[it] >> 16] + (br[it] & 0xFFFFu)] = recs[it];
 }
 
 __global__ void copyU64Kernel(const uint64_t *__restrict__ src, unsigned long long *__restrict__ dst, uint64_t n) {
@@ -1267,7 +1270,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dCur1.as<unsigned long long>(), (uint64_t) nB1);
     pa.minKey = nullptr; pa.valueHist = nullptr;
     PH_CHECK(hipEventRecord(ctx->ev[8], st));
-    hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
+    hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), (size_t) 12 << pa.bits, st, pa);
     PH_CHECK(hipEventRecord(ctx->ev[9], st));
     int nScatter = 1;
     std::vector<uint64_t> hStart1(nB1 + 1);
@@ -1289,7 +1292,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         if (exclusiveScanU32(st, dCnt2.as<uint32_t>(), dStart2.as<uint64_t>(), nB, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB, 256, 1024)), dim3(256), 0, st, dStart2.as<uint64_t>(), dCur2.as<unsigned long long>(), (uint64_t) nB);
         PH_CHECK(hipEventRecord(ctx->ev[10], st));
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), 0, st, p2);
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), (size_t) 12 << p2.bits, st, p2);
         PH_CHECK(hipEventRecord(ctx->ev[11], st));
         nScatter = 2;
         std::swap(cur, other);
@@ -1406,7 +1409,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, gGrid), dim3(PT_BLOCK), 0, st, p1);
         if (exclusiveScanU32(st, dRC1.as<uint32_t>(), dRS1.as<uint64_t>(), nS1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nS1, 256, 64)), dim3(256), 0, st, dRS1.as<uint64_t>(), dRCur1.as<unsigned long long>(), (uint64_t) nS1);
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, gGrid), dim3(PT_BLOCK), 0, st, p1);
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, gGrid), dim3(PT_BLOCK), (size_t) 12 << p1.bits, st, p1);
         std::swap(cur, other);
         std::vector<uint64_t> hS1(nS1 + 1);
         PH_CHECK(hipMemcpyAsync(hS1.data(), dRS1.p, ((size_t) nS1 + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -1424,7 +1427,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), 0, st, p2);
             if (exclusiveScanU32(st, dRC2.as<uint32_t>(), dRS2.as<uint64_t>(), nS, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
             hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nS, 256, 1024)), dim3(256), 0, st, dRS2.as<uint64_t>(), dRCur2.as<unsigned long long>(), (uint64_t) nS);
-            hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), 0, st, p2);
+            hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), (size_t) 12 << p2.bits, st, p2);
             std::swap(cur, other);
             hSortStart.resize((size_t) nS + 1);
             PH_CHECK(hipMemcpyAsync(hSortStart.data(), dRS2.p, ((size_t) nS + 1) * 8, hipMemcpyDeviceToHost, st));
