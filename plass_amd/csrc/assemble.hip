@@ -110,6 +110,30 @@ template <int G> __device__ __forceinline__ void scoreColumnsG(const char *q, co
     }
 }
 
+// the same for ONE lane walking the whole overlap: 32 residues of both sequences are requested per round trip (two
+// unaligned 16-byte loads each) — the walk is a chain of dependent memory round trips, so fewer and wider is what counts
+__device__ __forceinline__ void scoreColumnsSerial(const char *q, const char *t, unsigned len, const signed char *smat,
+                                                   unsigned &first, unsigned &last, int &s, int &ids) {
+    const char q0 = q[0], t0 = t[0], qe = q[len - 1], te = t[len - 1];
+    uint64_t qw[4], tw[4];
+    __builtin_memcpy(qw, q, 32); __builtin_memcpy(tw, t, 32);
+    first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+    last = len - 1;
+    if (last > 0 && (qe == '*' || te == '*')) last--;
+    for (unsigned p = 0; p < len; p += 32) {
+        if (p) { __builtin_memcpy(qw, q + p, 32); __builtin_memcpy(tw, t + p, 32); }
+#pragma unroll
+        for (unsigned j = 0; j < 32; j++) {
+            const unsigned c = p + j;
+            if (c >= first && c <= last) {
+                const unsigned a = (unsigned) (qw[j >> 3] >> (8 * (j & 7))) & 0xFFu, b = (unsigned) (tw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
+                s += (int) smat[a * 123 + b];
+                if (c < last) ids += (a == b) ? 1 : 0;
+            }
+        }
+    }
+}
+
 // ungappedAlignmentByDiagonal, mode 3 (DistanceCalculator.h:115-175,204-220) + the counts updateAlignment needs
 struct Rescored { int startPos, endPos; unsigned score, diagonalLen; int idExcl; };
 __device__ __forceinline__ Rescored rescoreOnDiagonal(const char *q, unsigned qLen, const char *t, unsigned tLen, int diagonal,
@@ -801,7 +825,7 @@ __global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
                     else if (diag < 0 && dist < xTLen) { qo = 0; to = dist; len = min(xTLen - dist, querySeqLen); }
                     else hit = false;
                     unsigned first = 0, last = 0; int sc = 0, ids = 0; int startPos = -1, endPos = -1;
-                    if (hit && len > 0) { scoreColumnsG<1>(qs + qo, tSeq + to, len, smat, 0, first, last, sc, ids); startPos = (int) first; endPos = (int) last; }
+                    if (hit && len > 0) { scoreColumnsSerial(qs + qo, tSeq + to, len, smat, first, last, sc, ids); startPos = (int) first; endPos = (int) last; }
                     const unsigned score = (unsigned) max(sc, 0);
                     nResc += 1; nRescRes += hit ? len : 0;
                     int qS, qE, dS, dE;
@@ -878,7 +902,7 @@ __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, co
             else if (r.qStart == 0) can |= (r.dbEnd == r.dbLen - 1) && (r.dbStart > 0) && ((uint64_t) r.qLen + (uint64_t) r.dbStart < maxSeqLen);
         }
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
-        bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 8) : 0;
+        bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 40) : 0;      // slack: the re-scoring loops read up to 32 bytes past the query
         if (aaBytes) { aaLeftCap[id] = (uint32_t) std::min<uint64_t>(sumAa, 0xFFFFFFFFull); aaBytes[id] = (sum && can) ? (2 * sumAa + aaLen[id] + 8) : 0; }
         if (sum && can) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = (noPrescreen || h <= 16) ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3)); }   // nucleotide variant: one list
         tierA[id] = (tier == 0) ? 1ull : ((tier == 1) ? (1ull << 32) : 0ull);
