@@ -91,6 +91,10 @@ def stage_table(kst, rst, ast):
         "rescoreKernel": (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored, True, 1),
     }
     t["extractShortKernel"] += (1,); t["extractKernel"] += (1,)
+    # whole kmermatcher stage against SURVEY.md section 8d's B_K = R + 4*s*N_k + 4*s*N_m + 12*N_c (every kernel and the host
+    # round trips in between count): the number the north star's "achieved HBM bandwidth in kmermatcher" refers to
+    t["kmermatcher_stage"] = (kst.ms_extract + kst.ms_sort1 + kst.ms_group + kst.ms_sort2 + kst.ms_reduce,
+                              kst.residues + 4 * s * Nk + 4 * s * Nm + 12 * Nc, False, 1)
     for i, (name, single) in enumerate((("assembleGroupKernel<16>", True), ("assembleGroupKernel<32>+<64>", False), ("assembleBigKernel", True))):
         t[name] = (ast.ms_tier_kernel[i], 32 * ast.tier_alignments[i] + 2 * ast.tier_query_residues[i] + 2 * ast.tier_rescored_residues[i], single, 1)
     return t
@@ -138,7 +142,8 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dist = None
-    if world > 1:      # one process per GPU over RCCL ("nccl" backend on ROCm)
+    if world > 1 or os.environ.get("PLASS_BENCH_FORCE_DIST"):      # one process per GPU over RCCL ("nccl" backend on ROCm); the env
+        # switch runs the same collectives in a 1-rank group (what a 1-GPU box can check of the N > 1 path)
         dist = pdist.init("nccl", rank, world, device=torch.device("cuda", local))
     plan = pdist.partition_plan(world)
 
@@ -210,6 +215,9 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
                          "stage_ms_per_step": {k: v[0] / len(stats) for k, v in tot.items()},
+                         "kmermatcher_stage": {"algorithmic_bytes_per_step": tot["kmermatcher_stage"][1] / len(stats),
+                                               "ms_per_step": tot["kmermatcher_stage"][0] / len(stats),
+                                               "frac": (tot["kmermatcher_stage"][1] / (tot["kmermatcher_stage"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot["kmermatcher_stage"][0] > 0 else 0.0},
                          "module_wall_ms_per_step": [round(sum(w[i] for w in WALL[-args.steps:]) / args.steps, 3) for i in range(3)]},
         }
         if world == 1 and not args.no_cpu_baseline:
