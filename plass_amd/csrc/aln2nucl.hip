@@ -10,6 +10,7 @@
 #include "device_utils.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <memory>
 #include <cstring>
 
 namespace plasship {
@@ -84,12 +85,13 @@ extern "C" int plasship_aln2nucl(plasship_ctx *ctx, const plasship_seqdb *q_nucl
     int rc = deviceKeysDiffer(ctx, q_nucl->d_key.as<uint32_t>(), q_aa->d_key.as<uint32_t>(), q_nucl->n, &differ); if (rc) return rc;
     if (!differ && t_nucl != q_nucl) { rc = deviceKeysDiffer(ctx, t_nucl->d_key.as<uint32_t>(), t_aa->d_key.as<uint32_t>(), t_nucl->n, &differ); if (rc) return rc; }
     if (differ) { setError("plasship_aln2nucl: nucleotide and protein DB have different keys"); return PLASSHIP_ERR_ARG; }
-    plasship_alns *o = new plasship_alns();
+    std::unique_ptr<plasship_alns> holder(new plasship_alns());      // released to the caller on success only
+    plasship_alns *o = holder.get();
     o->nQueries = al->nQueries; o->nLines = al->nLines; o->nucl = true; o->addBacktrace = true; o->dbResidues = t_nucl->residues;
     o->gappedOpen = par->gap_open; o->gappedExtend = par->gap_extend; o->qdb = q_nucl; o->tdb = t_nucl;
     DevBuf dMat, dErr;
     if (o->d_qoff.alloc((al->nQueries + 1) * 8) != hipSuccess || o->d_recs.alloc(std::max<uint64_t>(al->nLines, 1) * sizeof(AlnRec)) != hipSuccess ||
-        dMat.alloc(123 * 123) != hipSuccess || dErr.alloc(8) != hipSuccess) { delete o; setError("plasship_aln2nucl: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        dMat.alloc(123 * 123) != hipSuccess || dErr.alloc(8) != hipSuccess) { setError("plasship_aln2nucl: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemcpyAsync(o->d_qoff.p, al->d_qoff.p, (al->nQueries + 1) * 8, hipMemcpyDeviceToDevice, st));
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(true), 123 * 123, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dErr.p, 0, 8, st));
@@ -103,9 +105,9 @@ extern "C" int plasship_aln2nucl(plasship_ctx *ctx, const plasship_seqdb *q_nucl
     uint32_t herr[2] = {0, 0};
     PH_COPY_SYNC(st, herr, dErr.p, 8, hipMemcpyDeviceToHost);
     PH_CHECK(hipGetLastError());
-    if (herr[0]) { delete o; setError("plasship_aln2nucl: Alignment contains unalignable character"); return PLASSHIP_ERR_ARG; }
-    if (herr[1]) { delete o; setError("plasship_aln2nucl: only ungapped alignments (one 'M' run, rescorediagonal -a 1) are supported"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (herr[0]) { setError("plasship_aln2nucl: Alignment contains unalignable character"); return PLASSHIP_ERR_ARG; }
+    if (herr[1]) { setError("plasship_aln2nucl: only ungapped alignments (one 'M' run, rescorediagonal -a 1) are supported"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (stats) { stats->n_alignments = al->nLines; float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms; }
-    *out = o;
+    *out = holder.release();
     return PLASSHIP_OK;
 }

@@ -22,6 +22,7 @@
 #include "device_utils.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <memory>
 #include <cstring>
 
 namespace plasship {
@@ -1015,10 +1016,11 @@ static int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint
     PH_CHECK(hipMemcpyAsync(&outN, dKeepPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
-    plasship_seqdb *o = new plasship_seqdb();
+    std::unique_ptr<plasship_seqdb> holder(new plasship_seqdb());   // released to the caller on success only
+    plasship_seqdb *o = holder.get();
     o->dbtype = db->dbtype; o->n = (size_t) outN; o->dataBytes = outBytes; o->residues = outBytes - 2 * outN; o->hostIndexValid = false;
     if (o->d_data.alloc(outBytes + 64) != hipSuccess || o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
-        delete o; setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
+        setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
     if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, sv, dFlags, dNewLen,
@@ -1032,7 +1034,7 @@ static int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
     o->maxEntryLen = maxLen + 2;
-    *out = o;
+    *out = holder.release();
     return PLASSHIP_OK;
 }
 
@@ -1154,16 +1156,18 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     plasship_seqdb *o = nullptr, *oAa = nullptr;
     int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), dArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &o);
     if (rcOut != PLASSHIP_OK) return rcOut;
+    std::unique_ptr<plasship_seqdb> holdO(o), holdAa;              // released to the caller on success only
     if (guided) {
         rcOut = buildOutputDB(ctx, aaDb, dFlags.as<uint32_t>(), dAaNewLen.as<uint32_t>(), dAaNewStart.as<uint64_t>(), dAaArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &oAa);
-        if (rcOut != PLASSHIP_OK) { delete o; return rcOut; }
+        if (rcOut != PLASSHIP_OK) return rcOut;
+        holdAa.reset(oAa);
     }
     unsigned long long hs[16] = {0};
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
     PH_CHECK(hipMemcpyAsync(hs, dStats.p, 128, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
-    if (hs[12]) { delete o; delete oAa; setError("plasship_guided_assemble: an alignment asks for a protein fragment the twin does not have (coordinates are not codon aligned)"); return PLASSHIP_ERR_ARG; }
+    if (hs[12]) { setError("plasship_guided_assemble: an alignment asks for a protein fragment the twin does not have (coordinates are not codon aligned)"); return PLASSHIP_ERR_ARG; }
     if (stats) {
         stats->n_extended = hs[0]; stats->n_rescored = hs[1]; stats->out_residues = o->residues;
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
@@ -1175,8 +1179,8 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         stats->ms_assemble_kernel = sum;
         stats->n_alignments = nLines; stats->rescored_residues = hs[2];
     }
-    *out = o;
-    if (guided) *outAa = oAa;
+    *out = holdO.release();
+    if (guided) *outAa = holdAa.release();
     return PLASSHIP_OK;
 }
 

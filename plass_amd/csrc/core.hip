@@ -4,6 +4,7 @@
 #include "common.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <memory>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -104,7 +105,8 @@ extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
     }
     if (device_ordinal >= count) { setError("plasship_ctx_create: device ordinal out of range"); return PLASSHIP_ERR_ARG; }
     PH_CHECK(hipSetDevice(device_ordinal));
-    plasship_ctx *c = new plasship_ctx();
+    std::unique_ptr<plasship_ctx> holder(new plasship_ctx());
+    plasship_ctx *c = holder.get();
     c->device = device_ordinal;
     hipDeviceProp_t prop;
     PH_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
@@ -112,7 +114,7 @@ extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
     PH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     for (auto &ev : c->ev) PH_CHECK(hipEventCreate(&ev));
     { std::lock_guard<std::mutex> g(g_poolMu); g_ctxCount++; }
-    *out = c;
+    *out = holder.release();
     return PLASSHIP_OK;
 }
 
@@ -154,14 +156,15 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
     bool sorted = true;
     for (size_t i = 1; i < n && sorted; i++) sorted = key[i - 1] <= key[i];
     if (!sorted) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
-    plasship_seqdb *db = new plasship_seqdb();
+    std::unique_ptr<plasship_seqdb> holder(new plasship_seqdb());   // released to the caller on success only
+    plasship_seqdb *db = holder.get();
     db->dbtype = dbtype; db->n = n;
     db->h_key.resize(n); db->h_elen.resize(n); db->h_off.resize(n);
     uint64_t total = 0; uint32_t maxE = 0;
     for (size_t i = 0; i < n; i++) {
         uint32_t s = perm[i];
-        if (off[s] + elen[s] > data_bytes) { delete db; setError("plasship_seqdb_upload: entry beyond data"); return PLASSHIP_ERR_ARG; }
-        if (elen[s] < 2) { delete db; setError("plasship_seqdb_upload: sequence entry shorter than \"\\n\\0\""); return PLASSHIP_ERR_ARG; }
+        if (off[s] + elen[s] > data_bytes) { setError("plasship_seqdb_upload: entry beyond data"); return PLASSHIP_ERR_ARG; }
+        if (elen[s] < 2) { setError("plasship_seqdb_upload: sequence entry shorter than \"\\n\\0\""); return PLASSHIP_ERR_ARG; }
         db->h_key[i] = key[s]; db->h_elen[i] = elen[s]; db->h_off[i] = total;
         total += elen[s]; maxE = std::max(maxE, elen[s]);
     }
@@ -171,7 +174,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
     // pad the data buffer so 16-byte vector loads at the tail stay in bounds
     if (db->d_data.alloc(total + 64) != hipSuccess || db->d_off.alloc((n + 1) * 8) != hipSuccess ||
         db->d_len.alloc((n + 1) * 4) != hipSuccess || db->d_key.alloc((n + 1) * 4) != hipSuccess) {
-        delete db; setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE;
+        setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) db->d_data.p + total, 0, 64, ctx->stream));     // the padding only; the entries are copied below
     // stage in id order through a pinned-size bounce buffer
@@ -203,7 +206,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         PH_COPY_SYNC(ctx->stream, db->d_key.p, db->h_key.data(), n * 4, hipMemcpyHostToDevice);
     }
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    *out = db;
+    *out = holder.release();
     return PLASSHIP_OK;
 }
 

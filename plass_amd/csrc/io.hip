@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <memory>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -86,15 +87,16 @@ extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb,
         }
     }
     qoff[nQ] = hits.size();
-    plasship_cands *c = new plasship_cands();
+    std::unique_ptr<plasship_cands> holder(new plasship_cands());   // released to the caller on success only
+    plasship_cands *c = holder.get();
     c->reverseCapable = (h.dbtype == PLASSHIP_DBTYPE_PREFILTER_REV_RES);
     c->nQueries = nQ; c->nHits = hits.size(); c->nNonSelf = nonSelf;
     if (c->d_qoff.alloc((nQ + 1) * 8) != hipSuccess || c->d_hits.alloc(std::max<size_t>(hits.size(), 1) * sizeof(CandHit)) != hipSuccess) {
-        delete c; setError("plasship_cands_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
+        setError("plasship_cands_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     PH_COPY_SYNC(ctx->stream, c->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice);
     if (!hits.empty()) PH_COPY_SYNC(ctx->stream, c->d_hits.p, hits.data(), hits.size() * sizeof(CandHit), hipMemcpyHostToDevice);
-    *out = c;
+    *out = holder.release();
     return PLASSHIP_OK;
 }
 
@@ -277,14 +279,15 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
         }
     }
     qoff[nQ] = recs.size();
-    plasship_alns *a = new plasship_alns();
+    std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
+    plasship_alns *a = holder.get();
     a->nQueries = nQ; a->nLines = recs.size(); a->nucl = db->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES; a->dbResidues = db->residues;
     a->qdb = db; a->tdb = db;
     if (a->d_qoff.alloc((nQ + 1) * 8) != hipSuccess || a->d_recs.alloc(std::max<size_t>(recs.size(), 1) * sizeof(AlnRec)) != hipSuccess) {
-        delete a; setError("plasship_alns_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
+        setError("plasship_alns_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     PH_COPY_SYNC(ctx->stream, a->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice);
     if (!recs.empty()) PH_COPY_SYNC(ctx->stream, a->d_recs.p, recs.data(), recs.size() * sizeof(AlnRec), hipMemcpyHostToDevice);
-    *out = a;
+    *out = holder.release();
     return PLASSHIP_OK;
 }

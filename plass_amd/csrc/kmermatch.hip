@@ -26,6 +26,7 @@
 #include "device_utils.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <memory>
 #include <cstdlib>
 #include <climits>
 #include <cstring>
@@ -1472,15 +1473,16 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor((uint64_t) N + 1, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>(), 1u, (uint64_t) N);
     if (nTriples) hipLaunchKernelGGL((reduceRunsKernel<NUCL>), dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, (const Triple *) cur, nTriples, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
     if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    plasship_cands *c = new plasship_cands();
+    std::unique_ptr<plasship_cands> holder(new plasship_cands());   // released to the caller on success only
+    plasship_cands *c = holder.get();
     c->reverseCapable = NUCL; c->nQueries = N;
-    if (c->d_qoff.alloc(((size_t) N + 1) * 8) != hipSuccess) { delete c; setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { delete c; setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    if (c->d_qoff.alloc(((size_t) N + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t Nc = 0;
     PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nTriples, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     c->nHits = Nc + N; c->nNonSelf = Nc;
-    if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { delete c; setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (N) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), N, c->d_hits.as<CandHit>());
     if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, c->d_hits.as<CandHit>());
     msReduce = tm.stop(1);
@@ -1522,7 +1524,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
                 PH_COPY_SYNC(st, &qn, c->d_qoff.as<uint64_t>() + rep + 1, 8, hipMemcpyDeviceToHost);
                 CandHit hh;
                 PH_COPY_SYNC(st, &hh, c->d_hits.as<CandHit>() + (qn - 1), sizeof(CandHit), hipMemcpyDeviceToHost);
-                if (hh.target != staleT || hh.query != rep) { delete c; setError("kmermatch: internal error while patching the last run"); return PLASSHIP_ERR_DEVICE; }
+                if (hh.target != staleT || hh.query != rep) { setError("kmermatch: internal error while patching the last run"); return PLASSHIP_ERR_DEVICE; }
                 hh.prefScore = bestRev ? -(int) topScore : (int) topScore; hh.diag16 = (uint32_t) (uint16_t) diagonal;
                 PH_COPY_SYNC(st, c->d_hits.as<CandHit>() + (qn - 1), &hh, sizeof(CandHit), hipMemcpyHostToDevice);
             }
@@ -1542,7 +1544,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         stats->residues = db->residues;
         stats->ms_extract = msExtract; stats->ms_sort1 = msSort1; stats->ms_group = msGroup; stats->ms_sort2 = msSort2; stats->ms_reduce = msReduce;
     }
-    *out = c;
+    *out = holder.release();
     return PLASSHIP_OK;
 }
 }  // namespace

@@ -20,6 +20,7 @@
 #include "device_utils.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <memory>
 #include <cfloat>
 #include <cstring>
 
@@ -323,10 +324,11 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     PH_CHECK(hipMemcpyAsync(&nAcc, dPos.as<uint64_t>() + nHits, 8, hipMemcpyDeviceToHost, ctx->stream));
     PH_CHECK(hipStreamSynchronize(ctx->stream));
 
-    plasship_alns *al = new plasship_alns();
+    std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
+    plasship_alns *al = holder.get();
     al->nQueries = qdb->n; al->nLines = nAcc; al->nucl = nucl; al->addBacktrace = par->add_backtrace != 0; al->dbResidues = tdb->residues;
     if (al->d_qoff.alloc((qdb->n + 1) * 8) != hipSuccess || al->d_recs.alloc(std::max<uint64_t>(nAcc, 1) * sizeof(AlnRec)) != hipSuccess) {
-        delete al; setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE;
+        setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     if (nHits) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((nHits + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
                                   dAll.as<AlnRec>(), dAccept.as<uint32_t>(), dPos.as<uint64_t>(), al->d_recs.as<AlnRec>(), nHits);
@@ -341,6 +343,6 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
         stats->n_scored = nHits; stats->n_accepted = nAcc; stats->overlap_residues = hs[1];
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
     }
-    *out = al;
+    *out = holder.release();
     return PLASSHIP_OK;
 }
