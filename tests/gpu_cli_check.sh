@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU-box check through the command-line boundary: run the three hot modules of plass-hip on the golden
+# GPU-box check through the command-line boundary: run every module of plass-hip on the golden
 # inputs and compare every output DB with what the unmodified reference wrote (tests/golden/*.tar.gz).
 # Usage: tests/gpu_cli_check.sh [workdir]
 set -u
@@ -8,6 +8,7 @@ W=${1:-/tmp/plasship_cli_check}
 rm -rf "$W"; mkdir -p "$W"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_aa.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_nucl.tar.gz"
+tar -C "$W" -xzf "$ROOT/tests/golden/example_guided.tar.gz"
 P="timeout 300 $ROOT/plass_amd/plass-hip"
 D="python3 $ROOT/tools/dbdiff.py"
 fails=0
@@ -35,6 +36,21 @@ for i in 0 1; do
   check $S/pref_$i $W/o_pref "nucl kmermatcher it$i"
   $P rescorediagonal $S/seq_$i $S/seq_$i $S/pref_$i $W/o_aln $RS | tail -2 || echo "rescorediagonal rc=$?"
   check $S/aln_$i $W/o_aln "nucl rescorediagonal it$i"
+  $P nuclassembleresults $S/seq_$i $S/aln_$i $W/o_seq --min-seq-id 0.99 --max-seq-len 200000 --keep-target 1 --rescore-mode 3 | tail -2 || echo "nuclassembleresults rc=$?"
+  check $S/seq_$((i+1)) $W/o_seq "nucl nuclassembleresults it$i"
 done
+# penguin's protein-guided stage: the reference passes "--kmer-per-seq-scale 0.100 --alph-size nucl:5,aa:13 --gap-open 5 --gap-extend 2"
+S=$W/guided
+KM="--alph-size nucl:5,aa:13 --kmer-per-seq 60 --kmer-per-seq-scale 0.100 -k 14 -c 0 --cov-mode 1 --ignore-multi-kmer 1 --max-seq-len 200000 --hash-shift 67 --include-only-extendable 1"
+RS="--rescore-mode 3 -e 1e-05 -c 0 -a 1 --cov-mode 1 --min-seq-id 0.97 --min-aln-len 0 --seq-id-mode 0 --sort-results 0"
+$P kmermatcher $S/aa_0 $W/o_pref $KM | tail -2 || echo "kmermatcher rc=$?"
+check $S/pref_0 $W/o_pref "guided kmermatcher"
+$P rescorediagonal $S/aa_0 $S/aa_0 $S/pref_0 $W/o_aln $RS | tail -2 || echo "rescorediagonal rc=$?"
+check $S/aln_0 $W/o_aln "guided rescorediagonal -a 1"
+$P proteinaln2nucl $S/nucl_0 $S/nucl_0 $S/aa_0 $S/aa_0 $S/aln_0 $W/o_aln_nucl --gap-open 5 --gap-extend 2 | tail -2 || echo "proteinaln2nucl rc=$?"
+check $S/aln_nucl_0 $W/o_aln_nucl "proteinaln2nucl"
+$P guidedassembleresults $S/nucl_0 $S/aa_0 $S/aln_nucl_0 $W/o_nucl $W/o_aa --min-seq-id 0.99 --max-seq-len 200000 --keep-target 1 --rescore-mode 3 | tail -2 || echo "guidedassembleresults rc=$?"
+check $S/nucl_1 $W/o_nucl "guidedassembleresults nucl"
+check $S/aa_1 $W/o_aa "guidedassembleresults aa"
 echo "failures: $fails"
 exit $fails

@@ -394,3 +394,14 @@ def test_order_invariance_and_idempotence(ctx, tmp_path):
         o.free(); alns.free(); cands.free()
     assert outs[0] == outs[1], "same input, different output"
     assert outs[0] == outs[2], "output depends on input index order"
+
+
+def test_cli_boundary_all_modules(tmp_path):
+    """the drop-in boundary itself: `plass-hip <module> <DBs> <reference flags>` for every module, DB files in, DB files
+    out, compared with the reference's golden DBs (tests/gpu_cli_check.sh)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["bash", os.path.join(root, "tests", "gpu_cli_check.sh"), str(tmp_path / "cli")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0 and "failures: 0" in p.stdout, p.stdout[-3000:]
+    assert p.stdout.count("PASS ") >= 21
+
