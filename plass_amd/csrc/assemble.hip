@@ -58,6 +58,7 @@ struct AsmArgs {
     uint32_t *needKeys; uint32_t *needCount; uint32_t needCap;            // tuples the table lacks
     uint32_t *redoList; uint32_t *redoCount;                              // queries that met such a tuple: run again
     const uint32_t *queryList; uint32_t nQueryList;                       // list-driven pass (nullptr = all queries)
+    uint8_t *cmpCache;                          // nucleotide variants: memo of the comparator's posterior class (see nuclLess)
     // guided variant: the protein twins (same ids) and their arena
     SeqView aa; char *aaArena; const uint64_t *aaArenaOff; const uint32_t *aaLeftCap; uint32_t *aaNewLen; uint64_t *aaNewStart;
 };
@@ -353,6 +354,7 @@ __device__ __forceinline__ char nuclRevN(char c) {          // getNuclRevFragmen
 }
 // comparator state of one query: the first decision the table cannot answer aborts the query (it is re-run after
 // the host has evaluated the tuple with its libm)
+constexpr unsigned CMP_LEN = 512, CMP_MM = 8;          // memoised range: overlaps shorter than 512 columns with fewer than 8 mismatches
 struct NuclCmp { const AsmArgs *a; bool abort; };
 __device__ __forceinline__ uint32_t ambHash(uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
     return (a1 * 0x9E3779B1u) ^ (b1 * 0x85EBCA77u) ^ (a2 * 0xC2B2AE3Du) ^ (b2 * 0x27D4EB2Fu);
@@ -363,6 +365,20 @@ __device__ bool nuclLess(const Item &r1, const Item &r2, NuclCmp &c) {   // Comp
     const unsigned mm2 = (unsigned) ((double) ((1.0f - r2.seqId) * (float) r2.alnLength) + 0.5);
     const unsigned alpha1 = mm1 + 1, alpha2 = mm2 + 1;
     const unsigned beta1 = r1.alnLength - mm1 + 1, beta2 = r2.alnLength - mm2 + 1;
+    // The posterior class depends on (mismatches, overlap length) of the two hits only, and read overlaps use a small part of
+    // that space over and over: classes are memoised in a direct-mapped table (1 byte per tuple, 0 = not yet known; racing
+    // writers store the same value).  A hit skips four lgamma and a loop of exp / log in double precision.
+    const bool cacheable = c.a->cmpCache && mm1 < CMP_MM && mm2 < CMP_MM && r1.alnLength < CMP_LEN && r2.alnLength < CMP_LEN;
+    const size_t cidx = cacheable ? ((((size_t) r1.alnLength * CMP_MM + mm1) * CMP_LEN + r2.alnLength) * CMP_MM + mm2) : 0;
+    int memo = cacheable ? (int) c.a->cmpCache[cidx] : 0;
+    if (memo) {
+        const int cls = memo - 1;
+        if (cls == 0) return true;
+        if (cls == 1) return false;
+        if (r1.dbLen - r1.alnLength < r2.dbLen - r2.alnLength) return true;
+        if (r1.dbLen - r1.alnLength > r2.dbLen - r2.alnLength) return false;
+        return true;
+    }
     const double log_c = (lgamma((double) (beta1 + beta2)) + lgamma((double) (alpha1 + beta1))) -
                          (lgamma((double) (alpha1 + beta1 + beta2)) + lgamma((double) beta1));
     double log_r = 0.0, p = 0.0;
@@ -394,6 +410,7 @@ __device__ bool nuclLess(const Item &r1, const Item &r2, NuclCmp &c) {   // Comp
             return false;
         }
     }
+    if (cacheable) c.a->cmpCache[cidx] = (uint8_t) (cls + 1);        // (classes on a threshold come from the host table and are stored alike)
     if (cls == 0) return true;
     if (cls == 1) return false;
     if (r1.dbLen - r1.alnLength < r2.dbLen - r2.alnLength) return true;
@@ -1111,6 +1128,12 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         if (dHeap.alloc(std::max<uint64_t>(nLines, 1) * 12) != hipSuccess || dNeed.alloc((size_t) needCap * 16) != hipSuccess || dRedo[0].alloc(((size_t) N + 1) * 4) != hipSuccess ||
             dRedo[1].alloc(((size_t) N + 1) * 4) != hipSuccess || dCnt.alloc(8) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         a.heap = dHeap.as<uint32_t>();
+        if (!ctx->d_cmpCache.p) {
+            const size_t cb = (size_t) CMP_LEN * CMP_MM * CMP_LEN * CMP_MM;
+            if (ctx->d_cmpCache.alloc(cb) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            PH_CHECK(hipMemsetAsync(ctx->d_cmpCache.p, 0, cb, st));
+        }
+        a.cmpCache = ctx->d_cmpCache.as<uint8_t>();
         a.needKeys = dNeed.as<uint32_t>(); a.needCount = dCnt.as<uint32_t>(); a.needCap = needCap; a.redoCount = dCnt.as<uint32_t>() + 1;
         PH_CHECK(hipEventRecord(ctx->ev[2], st));
         // Pass 0 runs every query; a query that needs a comparator decision the table lacks leaves no trace and is

@@ -82,6 +82,7 @@ struct plasship_ctx {
     std::vector<uint32_t> ambKeys;      // 4 words per entry
     std::vector<uint8_t> ambVals;
     plasship::DevBuf d_ambKeys, d_ambVals;
+    plasship::DevBuf d_cmpCache;        // memo of the nucleotide comparator's posterior classes (assemble.hip, nuclLess)
     uint32_t ambSlots = 0;              // power of two, 0 = no table yet
 };
 
