@@ -236,6 +236,10 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
         const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
         const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));   // kmermatcher.cpp:223
         const bool allCand = (size_t) nWin <= consideredRaw;
+        if (!FALLBACK && std::min((size_t) nWin, consideredRaw) > (size_t) cap) {       // cannot fit this instantiation's LDS: next tier
+            if (lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
+            continue;
+        }
 
         uint32_t C = 0;            // candidates pushed (wave-uniform)
         uint32_t n = 0;            // valid k-mers
@@ -1189,7 +1193,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     { uint64_t p = 1; for (int i = 0; i < 24; i++) { ea.powers[i] = p; p *= (uint64_t) (alph - 1); } }
     ea.k = k; ea.xCode = map[(int) 'X']; ea.kps = par->kmers_per_seq; ea.ignoreMulti = par->ignore_multi_kmer; ea.scale = par->kmers_per_seq_scale;
     ea.seed = (uint64_t) par->hash_shift; ea.overflowIds = dOvIds.as<uint32_t>(); ea.overflowCount = dOvCnt.as<uint32_t>();
-    constexpr int CAP = NUCL ? 1024 : 128;     // candidate k-mers per sequence held in LDS (more: HBM-scratch launch)
+    // candidate k-mers per sequence held in LDS.  128 covers every protein sequence (59 considered k-mers) and every
+    // nucleotide sequence up to ~690 nt (59 + 0.1 L); the 1024-candidate instantiation (35 KB of LDS, one wavefront per SIMD)
+    // only sees the longer nucleotide contigs, queued by the first launch; what does not fit there either goes to the
+    // HBM-scratch launch.
+    constexpr int CAP = 128, CAP2 = NUCL ? 1024 : 0;
     DevBuf dWaveList, dWaveCount, dKStats;
     if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess || dKStats.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dWaveCount.p, 0, 4, st));
@@ -1209,6 +1217,15 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
     if (N) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
+    DevBuf dOv2Ids, dOv2Cnt;
+    if (CAP2 && N) {
+        if (dOv2Ids.alloc(((size_t) N + 1) * 4) != hipSuccess || dOv2Cnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemsetAsync(dOv2Cnt.p, 0, 4, st));
+        ExtractArgs e2 = ea; e2.waveList = dOvIds.as<uint32_t>(); e2.waveCount = dOvCnt.as<uint32_t>();
+        e2.overflowIds = dOv2Ids.as<uint32_t>(); e2.overflowCount = dOv2Cnt.as<uint32_t>();
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, (CAP2 ? CAP2 : 128), false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 4)), dim3(64), 0, st, e2);
+        std::swap(dOvIds.p, dOv2Ids.p); std::swap(dOvCnt.p, dOv2Cnt.p);       // the HBM-scratch launch below takes what is left
+    }
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     uint32_t nOv = 0;
     PH_CHECK(hipMemcpyAsync(&nOv, dOvCnt.p, 4, hipMemcpyDeviceToHost, st));
