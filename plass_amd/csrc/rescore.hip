@@ -96,7 +96,7 @@ struct DiagScore { bool valid; unsigned score; int first, last; unsigned diagLen
 
 template <bool REV, int G>
 __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, unsigned qLen, const char *__restrict__ t,
-                                                   unsigned tLen, int diagonal, const signed char *__restrict__ smat, int sl) {
+                                                   unsigned tLen, int diagonal, const signed char *__restrict__ smat, const unsigned char *__restrict__ comp, int sl) {
     DiagScore r; r.valid = false; r.score = 0; r.first = -1; r.last = -1; r.diagLen = 0; r.idCnt = 0;
     const unsigned dist = (unsigned) abs(diagonal);
     unsigned qo, to, len;
@@ -106,23 +106,38 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
     r.valid = true; r.diagLen = len;
     if (len == 0) { r.first = 0; r.last = -1; return r; }   // empty sequence: reference reads out of bounds; unsupported
     // REV: the aligned query is the reverse complement of the stored one: qrev[i] = comp(q[qLen-1-i])
-    auto Q = [&](unsigned i) -> char { return REV ? nuclRevCompChar(q[qLen - 1 - (qo + i)]) : q[qo + i]; };
+    auto Q = [&](unsigned i) -> char { return REV ? (char) comp[(unsigned char) q[qLen - 1 - (qo + i)]] : q[qo + i]; };
     const char q0 = Q(0), t0 = t[to], qe = Q(len - 1), te = t[to + len - 1];
     const unsigned first = (q0 == '*' || t0 == '*') ? 1u : 0u;
     unsigned last = len - 1;
     if (last > 0 && (qe == '*' || te == '*')) last--;
     int s = 0, ids = 0;
-    if (!REV && G == 1) {
+    if (G == 1) {
         // one thread per pair: 16 residues of both sequences per round trip (unaligned 16-byte loads; buffers are padded).
         // The loop is bound by the number of memory requests, not by bytes: every lane streams its own two sequences.
+        // REV: the aligned query is the reverse complement of the stored one — the 16 stored bytes that end at the mirrored
+        // position are loaded and walked backwards (never reading before the start of the buffer).
         for (unsigned p = first; p <= last; p += 16u) {
             uint64_t qw[2], tw[2];
-            __builtin_memcpy(qw, q + qo + p, 16); __builtin_memcpy(tw, t + to + p, 16);
+            __builtin_memcpy(tw, t + to + p, 16);
             const unsigned n = min(16u, last - p + 1);
+            bool wide = true;
+            if (REV) {
+                const unsigned rem = qLen - (qo + p);            // stored residues left of (and including) the mirrored position
+                wide = rem >= 16;
+                if (wide) __builtin_memcpy(qw, q + (qLen - 1 - (qo + p)) - 15, 16);
+            } else __builtin_memcpy(qw, q + qo + p, 16);
 #pragma unroll
             for (unsigned j = 0; j < 16; j++) {
                 if (j < n) {
-                    const unsigned a = (unsigned) (qw[j >> 3] >> (8 * (j & 7))) & 0xFFu, b = (unsigned) (tw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
+                    unsigned a;
+                    if (!REV) a = (unsigned) (qw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
+                    else {
+                        const unsigned jj = 15u - j;                 // byte of the loaded block that holds stored position mirror - j
+                        const char c = wide ? (char) (qw[jj >> 3] >> (8 * (jj & 7))) : q[qLen - 1 - (qo + p + j)];
+                        a = (unsigned) comp[(unsigned char) c];
+                    }
+                    const unsigned b = (unsigned) (tw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
                     s += (int) smat[a * 123 + b];
                     ids += ((a & ~0x20u) == (b & ~0x20u)) ? 1 : 0;
                 }
@@ -144,7 +159,7 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
         for (unsigned j = 0; j < 4; j++) {
             if (j < n) {
                 char a = (char) (qw >> (8 * j)), b = (char) (tw >> (8 * j));
-                if (REV) a = nuclRevCompChar(a);
+                if (REV) a = (char) comp[(unsigned char) a];
                 s += (int) smat[(int) a * 123 + (int) b];
                 ids += ((a & ~0x20) == (b & ~0x20)) ? 1 : 0;
             }
@@ -158,7 +173,9 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
 template <int G>
 __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
+    __shared__ unsigned char sComp[256];                 // reverse-strand hits: complement of a stored letter (getRevFragment's mapping)
     for (int i = threadIdx.x; i < 123 * 123; i += RS_BLOCK) smat[i] = a.mat[i];
+    for (int i = threadIdx.x; i < 256; i += RS_BLOCK) sComp[i] = (unsigned char) nuclRevCompChar((char) i);
     __syncthreads();
     const int groupsPerBlock = RS_BLOCK / G;
     const int sl = threadIdx.x & (G - 1);
@@ -188,12 +205,12 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
             const unsigned d16 = hit.diag16 & 0xFFFFu;
             for (unsigned d = 1; d <= 1 + tLen / 32768; d++) {
                 const int real = (int) (d16 - d * 65536u);
-                DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sl);
+                DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sComp, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sComp, sl);
                 if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
             }
             for (unsigned d = 0; d <= qLen / 65536; d++) {
                 const int real = (int) (d * 65536u + d16);
-                DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sl);
+                DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sComp, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sComp, sl);
                 if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
             }
             if (sl == 0) ovLocal += bDiagLen;
