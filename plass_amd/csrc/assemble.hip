@@ -668,6 +668,187 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
     }
 }
 
+// ---- nucleotide / guided variants, ONE THREAD per query (queries with up to a few hundred hits: the reads and most contigs).
+//      The loop is the reference's, statement by statement; what a wavefront per query wastes here is 63 lanes during every
+//      heap operation (each a chain of dependent loads).  Queue, deferral list and hit records live in the query's slice of
+//      the global scratch arrays like in assembleNuclKernel; copies and re-scoring walk 8 / 32 bytes per step. ----
+__device__ __forceinline__ void copyBytesSerial(char *dst, const char *src, unsigned n) {
+    unsigned i = 0;
+    for (; i + 8 <= n; i += 8) storeU64Unaligned(dst + i, loadU64Unaligned(src + i));
+    for (; i < n; i++) dst[i] = src[i];
+}
+__device__ __forceinline__ void copyRevCompSerial(char *dst, const char *src, unsigned n) {     // getNuclRevFragment
+    for (unsigned i = 0; i < n; i++) dst[i] = nuclRevN(src[n - 1 - i]);
+}
+template <bool GUIDED>
+__global__ __launch_bounds__(64) void assembleNuclThreadKernel(AsmArgs a) {
+    __shared__ signed char smat[123 * 123 + 7];
+    for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
+    __syncthreads();
+    unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
+    NuclCmp cmp; cmp.a = &a; cmp.abort = false;
+    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < a.nQueryList; w += gridDim.x * 64) {
+        const uint32_t id = a.queryList[w];
+        const uint64_t h0 = a.qoff[id];
+        const uint32_t h = (uint32_t) (a.qoff[id + 1] - h0);
+        const uint64_t aoff = a.arenaOff[id];
+        Item *it = a.items + h0;
+        uint32_t *hp = a.heap + 3 * h0, *def = hp + h, *used = def + h;
+        uint32_t nUsed = 0;
+        cmp.abort = false;
+        unsigned long long qResc = 0, qRescRes = 0;
+        const char *orig = a.s.data + a.s.off[id];
+        unsigned querySeqLen = a.s.len[id];
+        uint32_t nHeap = 0;
+        for (uint32_t i = 0; i < h && !cmp.abort; i++) {                 // queue fill
+            const AlnRec r = a.recs[h0 + i];
+            Item x;
+            x.target = r.target;
+            const int aq = (r.qStart == -1) ? 0 : r.qStart, ad = (r.dbStart == -1) ? 0 : r.dbStart;
+            x.alnLength = (uint32_t) (max(abs(r.qEnd - aq), abs(r.dbEnd - ad)) + 1);
+            const int rawScore = (int) (fma((double) r.bitScore, a.ln2, a.logK) / a.lambda + 0.5);
+            const float scorePerCol = (float) rawScore / (float) ((double) x.alnLength + 0.5);
+            x.seqId = r.fromText ? r.seqId : seqIdThroughText(r.seqId);
+            x.score = GUIDED ? r.bitScore : (int) (scorePerCol * 100);
+            x.qStart = r.qStart; x.qEnd = r.qEnd; x.qLen = (uint32_t) r.qLen; x.dbStart = r.dbStart; x.dbEnd = r.dbEnd; x.dbLen = (uint32_t) r.dbLen;
+            x.pad = 0;
+            if (!GUIDED && x.qStart > x.qEnd) {
+                x.pad = 1;
+                const int t0 = x.qStart; x.qStart = x.qEnd; x.qEnd = t0;
+                const unsigned dbs = (unsigned) x.dbStart;
+                x.dbStart = (int) (x.dbLen - (unsigned) x.dbEnd - 1);
+                x.dbEnd = (int) (x.dbLen - dbs - 1);
+            }
+            x.state = (GUIDED && x.seqId < a.seqIdThr) ? 2u : 0u;
+            it[i] = x;
+            if (x.state == 0) heapPush(hp, nHeap, i, it, cmp);
+        }
+        const char *aaQ = nullptr; char *aaBuf = nullptr; uint64_t aaStart = 0, aaLen = 0; bool exclL = false, exclR = false;
+        if (GUIDED) {
+            aaQ = a.aa.data + a.aa.off[id]; aaLen = a.aa.len[id];
+            exclL = aaQ[0] == '*'; exclR = aaQ[aaLen - 1] == '*';
+            aaBuf = a.aaArena + a.aaArenaOff[id]; aaStart = a.aaLeftCap[id];
+            copyBytesSerial(aaBuf + aaStart, aaQ, (unsigned) aaLen);
+        }
+        char *buf = a.arena + aoff;
+        uint64_t curStart = a.leftCap[id];
+        copyBytesSerial(buf + curStart, orig, querySeqLen);
+        uint64_t curLen = querySeqLen;
+        bool couldExtend = false;
+        while (nHeap > 0 && !cmp.abort) {
+            unsigned leftOff = 0, rightOff = 0;
+            bool brokeOut = false;
+            uint32_t nDef = 0;
+            while (nHeap > 0) {
+                const uint32_t bi = heapPop(hp, nHeap, it, cmp);
+                if (cmp.abort) break;
+                const Item best = it[bi];
+                const bool notBoth = !(best.dbStart == 0 && best.qStart == 0);
+                const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
+                const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
+                if (!((rightStart || leftStart) && notBoth && best.target != id)) continue;
+                const char *tSeq = a.s.data + a.s.off[best.target];
+                const unsigned tLen = a.s.len[best.target];
+                const bool rev = best.pad != 0;
+                const char *aaT = nullptr; unsigned aaTLen = 0;
+                if (GUIDED) { aaT = a.aa.data + a.aa.off[best.target]; aaTLen = a.aa.len[best.target]; }
+                if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff || (GUIDED && (exclR || aaT[0] == '*'))) continue; }
+                else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff || (GUIDED && (exclL || aaT[aaTLen - 1] == '*'))) continue; }
+                const unsigned dbStart = (unsigned) best.dbStart, dbEnd = (unsigned) best.dbEnd, qStart = (unsigned) best.qStart, qEnd = (unsigned) best.qEnd;
+                if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
+                    if (rightOff > 0) { def[nDef++] = bi; continue; }
+                    const unsigned fragLen = tLen - (dbEnd + 1);
+                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    if (rev) copyRevCompSerial(buf + curStart + curLen, tSeq, fragLen);
+                    else copyBytesSerial(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen);
+                    curLen += fragLen; rightOff += fragLen;
+                    if (GUIDED) {
+                        const unsigned aaFrag = (tLen / 3 - dbEnd / 3) - 1;
+                        if (aaStart + aaLen + aaFrag > a.aaArenaOff[id + 1] - a.aaArenaOff[id]) atomicAdd(&a.stats[12], 1ull);
+                        else { copyBytesSerial(aaBuf + aaStart + aaLen, aaT + dbEnd / 3 + 1, aaFrag); aaLen += aaFrag; }
+                    }
+                    used[nUsed++] = best.target;
+                } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
+                    if (leftOff > 0) { def[nDef++] = bi; continue; }
+                    const unsigned fragLen = dbStart;
+                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    curStart -= fragLen;
+                    if (rev) copyRevCompSerial(buf + curStart, tSeq + (tLen - dbStart), fragLen);
+                    else copyBytesSerial(buf + curStart, tSeq, fragLen);
+                    curLen += fragLen; leftOff += fragLen;
+                    if (GUIDED) {
+                        const unsigned aaFrag = fragLen / 3 + ((aaT[0] == '*') ? 1u : 0u);
+                        if (aaFrag > aaStart) atomicAdd(&a.stats[12], 1ull);
+                        else { aaStart -= aaFrag; copyBytesSerial(aaBuf + aaStart, aaT, aaFrag); aaLen += aaFrag; }
+                    }
+                    used[nUsed++] = best.target;
+                }
+            }
+            if (cmp.abort) break;
+            if (leftOff > 0 || rightOff > 0) couldExtend = true;
+            if (brokeOut && nHeap > 0) break;
+            querySeqLen = (unsigned) curLen;
+            const char *qs = buf + curStart;
+            for (uint32_t d = 0; d < nDef && !cmp.abort; d++) {                // re-score the deferred hits in deferral order
+                const uint32_t found = def[d];
+                Item x = it[found];
+                const char *tSeq = a.s.data + a.s.off[x.target];
+                const unsigned tLen = a.s.len[x.target];
+                const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
+                const unsigned dist = (unsigned) abs(diag);
+                unsigned qo = 0, to = 0, len = 0; bool hit = true;
+                if (diag >= 0 && dist < querySeqLen) { qo = dist; to = 0; len = min(tLen, querySeqLen - dist); }
+                else if (diag < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, querySeqLen); }
+                else hit = false;
+                int startPos = -1, endPos = -1, sc = 0, ids = 0;
+                if (hit && len > 0) {
+                    unsigned first, last;
+                    if (x.pad == 0) scoreColumnsSerial(qs + qo, tSeq + to, len, smat, first, last, sc, ids);
+                    else {                                                    // target walked as its reverse complement
+                        auto T = [&](unsigned i) -> char { return nuclRevN(tSeq[tLen - 1 - (to + i)]); };
+                        first = (qs[qo] == '*' || T(0) == '*') ? 1u : 0u;
+                        last = len - 1;
+                        if (last > 0 && (qs[qo + len - 1] == '*' || T(len - 1) == '*')) last--;
+                        for (unsigned p = first; p <= last; p++) {
+                            const char qa = qs[qo + p], tb = T(p);
+                            sc += (int) smat[(int) qa * 123 + (int) tb];
+                            if (p < last) ids += (qa == tb) ? 1 : 0;
+                        }
+                    }
+                    startPos = (int) first; endPos = (int) last;
+                }
+                const unsigned score = (unsigned) max(sc, 0);
+                qResc++; qRescRes += hit ? len : 0;
+                int qS, qE, dS, dE;
+                if (diag >= 0) { qS = startPos + (int) dist; qE = endPos + (int) dist; dS = startPos; dE = endPos; }
+                else { qS = startPos; qE = endPos; dS = startPos + (int) dist; dE = endPos + (int) dist; }
+                const float seqId = (float) ids / ((float) qE - (float) qS);
+                x.seqId = seqId; x.qLen = querySeqLen; x.dbLen = tLen; x.alnLength = hit ? len : 0u;
+                const float spc = (float) score / (float) ((double) x.alnLength + 0.5);
+                x.score = (int) (spc * 100);
+                x.qStart = qS; x.qEnd = qE; x.dbStart = dS; x.dbEnd = dE;
+                it[found] = x;
+                if (seqId >= a.seqIdThr) heapPush(hp, nHeap, found, it, cmp);
+            }
+        }
+        if (cmp.abort) a.redoList[atomicAdd(a.redoCount, 1u)] = id;          // nothing of this query has been published
+        else {
+            nAln += h; nQRes += a.s.len[id]; nResc += qResc; nRescRes += qRescRes;
+            for (uint32_t i = 0; i < nUsed; i++) atomicOr(&a.flags[used[i]], 0x80u);
+            if (couldExtend) {
+                atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart;
+                if (GUIDED) { a.aaNewLen[id] = (uint32_t) aaLen; a.aaNewStart[id] = a.aaArenaOff[id] + aaStart; }
+                nExt++;
+            }
+        }
+    }
+    nExt = waveReduceSumU64(nExt); nResc = waveReduceSumU64(nResc); nRescRes = waveReduceSumU64(nRescRes); nAln = waveReduceSumU64(nAln); nQRes = waveReduceSumU64(nQRes);
+    if (laneId() == 0) {
+        if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes);
+        if (nAln) { atomicAdd(&a.stats[3], nAln); atomicAdd(&a.stats[4], nQRes); atomicAdd(&a.stats[5], nRescRes); }
+    }
+}
+
 // ---- the common cases: the whole queue of a query lives in registers, one alignment per lane.
 //      G = 16: four queries per wavefront (a read has a handful of overlaps); G = 64: one query per wavefront.
 //      Sixteen/four independent groups per block share the LDS score table; no block barriers in the loop. ----
@@ -922,7 +1103,7 @@ __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, co
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
         bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 40) : 0;      // slack: the re-scoring loops read up to 32 bytes past the query
         if (aaBytes) { aaLeftCap[id] = (uint32_t) std::min<uint64_t>(sumAa, 0xFFFFFFFFull); aaBytes[id] = (sum && can) ? (2 * sumAa + aaLen[id] + 8) : 0; }
-        if (sum && can) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = (noPrescreen || h <= 16) ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3)); }   // nucleotide variant: one list
+        if (sum && can) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = noPrescreen ? (h <= 256 ? 0 : 1) : (h <= 16 ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3))); }   // nucleotide variants: thread-per-query list (one list: the long queues overlap with the many short ones), wave-per-query list
         tierA[id] = (tier == 0) ? 1ull : ((tier == 1) ? (1ull << 32) : 0ull);
         tierB[id] = (tier == 2) ? 1ull : ((tier == 3) ? (1ull << 32) : 0ull);
     }
@@ -1139,15 +1320,29 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         // Pass 0 runs every query; a query that needs a comparator decision the table lacks leaves no trace and is
         // run again once the host has evaluated the tuple (the set of such tuples is small and recurs, so the table
         // kept in the context makes later calls single-pass).
-        uint32_t nWork = cnts[0];
+        // pass 0: queries with up to 256 hits one thread each, the rest one wavefront each; later passes (queries that met
+        // a comparator tuple the table lacked) one wavefront each
+        uint32_t nWork = cnts[0] + cnts[1];
         for (int pass = 0; nWork > 0; pass++) {
             if (pass > 256) { setError("plasship_assemble: comparator table did not converge"); return PLASSHIP_ERR_DEVICE; }
             a.ambKeys = ctx->d_ambKeys.as<uint32_t>(); a.ambVals = ctx->d_ambVals.as<uint8_t>(); a.ambMask = ctx->ambSlots ? ctx->ambSlots - 1 : 0;
-            a.queryList = pass ? dRedo[(pass + 1) & 1].as<uint32_t>() : dSmallList.as<uint32_t>(); a.nQueryList = nWork;
             a.redoList = dRedo[pass & 1].as<uint32_t>();
             PH_CHECK(hipMemsetAsync(dCnt.p, 0, 8, st));
-            if (guided) hipLaunchKernelGGL(assembleNuclKernel<true>, dim3(std::min<uint32_t>(nWork, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
-            else hipLaunchKernelGGL(assembleNuclKernel<false>, dim3(std::min<uint32_t>(nWork, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
+            auto launchWave = [&](const uint32_t *list, uint32_t n) {
+                if (!n) return;
+                a.queryList = list; a.nQueryList = n;
+                if (guided) hipLaunchKernelGGL(assembleNuclKernel<true>, dim3(std::min<uint32_t>(n, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
+                else hipLaunchKernelGGL(assembleNuclKernel<false>, dim3(std::min<uint32_t>(n, (uint32_t) ctx->numCU * 16)), dim3(64), 0, st, a);
+            };
+            if (pass == 0) {
+                if (cnts[0]) {
+                    a.queryList = dSmallList.as<uint32_t>(); a.nQueryList = cnts[0];
+                    const uint32_t grid = std::min<uint32_t>((cnts[0] + 63) / 64, (uint32_t) ctx->numCU * 16);
+                    if (guided) hipLaunchKernelGGL(assembleNuclThreadKernel<true>, dim3(grid), dim3(64), 0, st, a);
+                    else hipLaunchKernelGGL(assembleNuclThreadKernel<false>, dim3(grid), dim3(64), 0, st, a);
+                }
+                launchWave(dMid32List.as<uint32_t>(), cnts[1]);
+            } else launchWave(dRedo[(pass + 1) & 1].as<uint32_t>(), nWork);
             uint32_t cnt[2] = {0, 0};
             PH_CHECK(hipMemcpyAsync(cnt, dCnt.p, 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(hipStreamSynchronize(st));
