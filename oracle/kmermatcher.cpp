@@ -66,8 +66,8 @@ static bool cmpRepIdDiag(const KPos<T> &a, const KPos<T> &b) {          // kmerm
 static bool canBeCovered(float covThr, int covMode, float q, float t) {  // Util.cpp:533-550
     switch (covMode) {
         case 0: return (q / t >= covThr) && (t / q >= covThr);
-        case 1: return (t / q) >= covThr;
-        case 2: return (q / t) >= covThr;
+        case 1: return (q / t) >= covThr;     // COV_MODE_TARGET = 1, COV_MODE_QUERY = 2 (mm/commons/Parameters.h:246-251)
+        case 2: return (t / q) >= covThr;
         case 3: return ((t / q) >= covThr) && (t / q) <= 1.0;
         case 4: return ((q / t) >= covThr) && (q / t) <= 1.0;
         case 5: return (std::min(t, q) / std::max(t, q)) >= covThr;

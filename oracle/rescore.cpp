@@ -160,8 +160,8 @@ void readAlignmentResults(std::vector<Result> &out, const char *data) {     // M
 static bool hasCoverage(float covThr, int covMode, float qCov, float tCov) { // Util.cpp:552-568
     switch (covMode) {
         case 0: return (qCov >= covThr) && (tCov >= covThr);
-        case 1: return qCov >= covThr;
-        case 2: return tCov >= covThr;
+        case 1: return tCov >= covThr;        // COV_MODE_TARGET = 1, COV_MODE_QUERY = 2 (mm/commons/Parameters.h:246-251)
+        case 2: return qCov >= covThr;
         default: return true;
     }
 }

@@ -47,8 +47,8 @@ struct RescoreArgs {
 __device__ __forceinline__ bool canBeCoveredDev(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
     switch (covMode) {
         case 0: return (q / t >= covThr) && (t / q >= covThr);
-        case 1: return (t / q) >= covThr;
-        case 2: return (q / t) >= covThr;
+        case 1: return (q / t) >= covThr;     // COV_MODE_TARGET = 1, COV_MODE_QUERY = 2 (mm/commons/Parameters.h:246-251)
+        case 2: return (t / q) >= covThr;
         case 3: return ((t / q) >= covThr) && (t / q) <= 1.0f;
         case 4: return ((q / t) >= covThr) && (q / t) <= 1.0f;
         case 5: return (fminf(t, q) / fmaxf(t, q)) >= covThr;
@@ -58,8 +58,8 @@ __device__ __forceinline__ bool canBeCoveredDev(float covThr, int covMode, float
 __device__ __forceinline__ bool hasCoverageDev(float covThr, int covMode, float qc, float tc) {  // Util.cpp:552-568
     switch (covMode) {
         case 0: return (qc >= covThr) && (tc >= covThr);
-        case 1: return qc >= covThr;
-        case 2: return tc >= covThr;
+        case 1: return tc >= covThr;
+        case 2: return qc >= covThr;
         default: return true;
     }
 }

@@ -26,7 +26,7 @@ def oracle_bin():
 def golden(tmp_path_factory):
     """golden DBs written by the unmodified reference (tests/golden/make_golden.sh)"""
     d = tmp_path_factory.mktemp("golden")
-    for name in ("example_aa.tar.gz", "example_nucl.tar.gz", "example_guided.tar.gz", "stale_scan_cases.tar.gz"):
+    for name in ("example_aa.tar.gz", "example_aa_sweep.tar.gz", "example_nucl.tar.gz", "example_guided.tar.gz", "stale_scan_cases.tar.gz"):
         with tarfile.open(os.path.join(ROOT, "tests", "golden", name)) as t:
             t.extractall(d)
     return str(d)
@@ -100,3 +100,25 @@ GD_AS = ["--min-seq-id", "0.99", "--max-seq-len", "200000", "--keep-target", "1"
 
 def aa_iter_flags(i):
     return ["--hash-shift", "67" if i == 0 else "68", "--include-only-extendable", "0" if i == 0 else "1"]
+
+
+def sweep_variants():
+    """(name, module, flags) of tests/golden/example_aa_sweep.tar.gz (make_golden_sweep.sh): the reference run with non-default flags"""
+    import io
+    with tarfile.open(os.path.join(ROOT, "tests", "golden", "example_aa_sweep.tar.gz")) as t:
+        txt = t.extractfile("sweep/variants.tsv").read().decode()
+    out = []
+    for line in io.StringIO(txt):
+        name, mod, flags = line.rstrip("\n").split("\t")
+        out.append((name, mod, flags.split()))
+    return out
+
+
+def sweep_positional(golden, mod, out):
+    s = os.path.join(golden, "aa")
+    if mod == "kmermatcher":
+        return [f"{s}/seq_0", out]
+    if mod == "rescorediagonal":
+        return [f"{s}/seq_0", f"{s}/seq_0", f"{s}/pref_0", out]
+    return [f"{s}/seq_0", f"{s}/aln_0", out]
+

@@ -6,7 +6,8 @@ import os
 import numpy as np
 import pytest
 
-from conftest import (AA_AS, AA_KM, AA_RS, GD_AS, GD_KM, GD_P2N, GD_RS, NUCL_AS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle)
+from conftest import (AA_AS, AA_KM, AA_RS, GD_AS, GD_KM, GD_P2N, GD_RS, NUCL_AS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle,
+                      sweep_positional, sweep_variants)
 
 pytestmark = pytest.mark.gpu
 
@@ -404,4 +405,16 @@ def test_cli_boundary_all_modules(tmp_path):
     p = subprocess.run(["bash", os.path.join(root, "tests", "gpu_cli_check.sh"), str(tmp_path / "cli")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0 and "failures: 0" in p.stdout, p.stdout[-3000:]
     assert p.stdout.count("PASS ") >= 21
+
+
+@pytest.mark.parametrize("name,mod,flags", sweep_variants(), ids=[v[0] for v in sweep_variants()])
+def test_cli_flag_sweep(golden, tmp_path, name, mod, flags):
+    """the reference's flags through the command line: `plass-hip <module> … <flags>` must write what the reference wrote
+    (tests/golden/make_golden_sweep.sh)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [os.path.join(root, "plass_amd", "plass-hip"), mod] + [str(x) for x in sweep_positional(golden, mod, tmp_path / "out")] + flags
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-2000:]
+    assert_same_db(os.path.join(golden, "sweep", name), tmp_path / "out", name)
 

@@ -5,7 +5,8 @@ import os
 
 import pytest
 
-from conftest import (AA_AS, AA_KM, AA_RS, GD_AS, GD_KM, GD_P2N, GD_RS, NUCL_AS, NUCL_KM, NUCL_RS, ROOT, aa_iter_flags, assert_same_db, run_oracle)
+from conftest import (AA_AS, AA_KM, AA_RS, GD_AS, GD_KM, GD_P2N, GD_RS, NUCL_AS, NUCL_KM, NUCL_RS, ROOT, aa_iter_flags, assert_same_db, run_oracle,
+                      sweep_positional, sweep_variants)
 
 
 @pytest.mark.parametrize("it", [0, 1, 2])
@@ -60,6 +61,14 @@ def test_oracle_guided_iterations(oracle_bin, golden, tmp_path):
     run_oracle(oracle_bin, ["guidedassembleresults", t / "nucl_1", t / "aa_1", t / "aln_nucl1", t / "nucl_2", t / "aa_2"] + GD_AS)
     assert_same_db(f"{s}/nucl_2", t / "nucl_2", "guided iteration 1 nucl")
     assert_same_db(f"{s}/aa_2", t / "aa_2", "guided iteration 1 aa")
+
+
+@pytest.mark.parametrize("name,mod,flags", sweep_variants(), ids=[v[0] for v in sweep_variants()])
+def test_oracle_flag_sweep(oracle_bin, golden, tmp_path, name, mod, flags):
+    """non-default flags (alphabet 21, k, k-mers per sequence, repeated k-mers, the three coverage modes, E-value / identity
+    / length thresholds, identity modes, self matches + backtrace, length cap, --keep-target 0): the reference's output"""
+    run_oracle(oracle_bin, [mod] + sweep_positional(golden, mod, tmp_path / "out") + flags)
+    assert_same_db(os.path.join(golden, "sweep", name), tmp_path / "out", name)
 
 
 def test_oracle_known_answers(oracle_bin):
