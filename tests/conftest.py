@@ -115,10 +115,22 @@ def sweep_variants():
 
 
 def sweep_positional(golden, mod, out):
+    """positional arguments of a sweep variant; modules of the nucleotide / guided input sets are tagged "nucl:" / "guided:".
+    Returns (module name, arguments, [(golden name suffix, output path)])"""
+    out = str(out)
+    if mod.startswith("nucl:"):
+        s, m = os.path.join(golden, "nucl"), mod[5:]
+        if m == "kmermatcher":
+            return m, [f"{s}/seq_0", out], [("", out)]
+        if m == "rescorediagonal":
+            return m, [f"{s}/seq_0", f"{s}/seq_0", f"{s}/pref_0", out], [("", out)]
+        return m, [f"{s}/seq_0", f"{s}/aln_0", out], [("", out)]
+    if mod.startswith("guided:"):
+        s, m = os.path.join(golden, "guided"), mod[7:]
+        return m, [f"{s}/nucl_0", f"{s}/aa_0", f"{s}/aln_nucl_0", out, out + "_aa"], [("", out), ("_aa", out + "_aa")]
     s = os.path.join(golden, "aa")
     if mod == "kmermatcher":
-        return [f"{s}/seq_0", out]
+        return mod, [f"{s}/seq_0", out], [("", out)]
     if mod == "rescorediagonal":
-        return [f"{s}/seq_0", f"{s}/seq_0", f"{s}/pref_0", out]
-    return [f"{s}/seq_0", f"{s}/aln_0", out]
-
+        return mod, [f"{s}/seq_0", f"{s}/seq_0", f"{s}/pref_0", out], [("", out)]
+    return mod, [f"{s}/seq_0", f"{s}/aln_0", out], [("", out)]

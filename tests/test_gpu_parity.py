@@ -413,8 +413,22 @@ def test_cli_flag_sweep(golden, tmp_path, name, mod, flags):
     (tests/golden/make_golden_sweep.sh)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cmd = [os.path.join(root, "plass_amd", "plass-hip"), mod] + [str(x) for x in sweep_positional(golden, mod, tmp_path / "out")] + flags
+    m, pos, outs = sweep_positional(golden, mod, tmp_path / "out")
+    cmd = [os.path.join(root, "plass_amd", "plass-hip"), m] + pos + flags
     p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert p.returncode == 0, p.stdout[-2000:]
-    assert_same_db(os.path.join(golden, "sweep", name), tmp_path / "out", name)
+    for suffix, path in outs:
+        assert_same_db(os.path.join(golden, "sweep", name + suffix), path, name + suffix)
+
+
+@pytest.mark.parametrize("mod,extra", [("rescorediagonal", ["--rescore-mode", "2"]), ("rescorediagonal", ["--wrapped-scoring", "1"]),
+                                       ("kmermatcher", ["--spaced-kmer-mode", "1"]), ("assembleresults", ["--rescore-mode", "0"])])
+def test_cli_unsupported_fails_loudly(golden, tmp_path, mod, extra):
+    """what the GPU path does not implement exits non-zero with a message (no silent fallback, no output DB)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    m, pos, outs = sweep_positional(golden, mod, tmp_path / "out")
+    p = subprocess.run([os.path.join(root, "plass_amd", "plass-hip"), m] + pos + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
+    assert p.returncode != 0 and ("not supported" in p.stdout or "only" in p.stdout), p.stdout[-800:]
+    assert not os.path.exists(outs[0][1] + ".index")
 

@@ -67,8 +67,10 @@ def test_oracle_guided_iterations(oracle_bin, golden, tmp_path):
 def test_oracle_flag_sweep(oracle_bin, golden, tmp_path, name, mod, flags):
     """non-default flags (alphabet 21, k, k-mers per sequence, repeated k-mers, the three coverage modes, E-value / identity
     / length thresholds, identity modes, self matches + backtrace, length cap, --keep-target 0): the reference's output"""
-    run_oracle(oracle_bin, [mod] + sweep_positional(golden, mod, tmp_path / "out") + flags)
-    assert_same_db(os.path.join(golden, "sweep", name), tmp_path / "out", name)
+    m, pos, outs = sweep_positional(golden, mod, tmp_path / "out")
+    run_oracle(oracle_bin, [m] + pos + flags)
+    for suffix, path in outs:
+        assert_same_db(os.path.join(golden, "sweep", name + suffix), path, name + suffix)
 
 
 def test_oracle_known_answers(oracle_bin):
