@@ -102,5 +102,36 @@ iteration i: kmermatcher aa_i -> pref_i [$KM]; rescorediagonal aa_i aa_i pref_i 
 (pref / aln / aln_nucl kept for iteration 0 only)
 M
 tar -C $W -czf $HERE/example_guided.tar.gz guided
+
+# ---------- long nucleotide contigs (KmerPosition<int>, 16-bit diagonal wrap-around: a contig grows past 65 535 nt) ----------
+S=$W/longnucl; mkdir -p $S
+python3 - "$S/seq_0" "$REPO" <<'PY'
+import sys
+sys.path.insert(0, sys.argv[2])
+import numpy as np
+from plass_amd import synth
+rng = np.random.default_rng(77)
+B = np.frombuffer(b"ACGT", dtype=np.uint8)
+g = rng.integers(0, 4, size=70000, dtype=np.uint8)
+rc = lambda x: (3 - x)[::-1]
+seqs = [g[0:36000], g[35200:52000], rc(g[30000:47000]), g[51000:70000], rc(g[60000:69000])]
+for i in range(400):
+    p = int(rng.integers(0, 69800)); r = g[p:p + 150].copy()
+    if rng.random() < 0.5: r = rc(r)
+    m = rng.random(150) < 0.003; r[m] = rng.integers(0, 4, size=int(m.sum()))
+    seqs.append(r)
+synth.write_db(sys.argv[1], *synth.pack_db([B[s] for s in seqs]), 1)
+PY
+KM="--alph-size 5 --kmer-per-seq 60 --kmer-per-seq-scale 0.100 -k 22 -c 0 --cov-mode 0 --ignore-multi-kmer 1 --max-seq-len 200000 --hash-shift 67 --include-only-extendable 1"
+RS="--rescore-mode 3 -e 1e-05 -c 0 -a 0 --cov-mode 0 --min-seq-id 0.99 --min-aln-len 0 --seq-id-mode 0 --sort-results 0"
+AS="--min-seq-id 0.99 --max-seq-len 200000 --keep-target 1 --rescore-mode 3"
+for i in 0 1; do
+  $PENGUIN kmermatcher $S/seq_$i $W/p $KM $Q >> $W/nucl.log
+  $PENGUIN rescorediagonal $S/seq_$i $S/seq_$i $W/p $W/a $RS $Q >> $W/nucl.log
+  $PENGUIN nuclassembleresults $S/seq_$i $W/a $W/s $AS $Q >> $W/nucl.log
+  $CANON $W/p $S/pref_$i; $CANON $W/a $S/aln_$i; $CANON $W/s $S/seq_$((i+1))
+  rm -f $W/p* $W/a.* $W/a $W/s $W/s.* 2>/dev/null || true
+done
+tar -C $W -czf $HERE/long_nucl.tar.gz longnucl
 ls -la $HERE/*.tar.gz
 rm -rf $W

@@ -116,6 +116,27 @@ def test_golden_nucl_chained_on_device(ctx, golden, tmp_path):
         db = db2
 
 
+@pytest.mark.parametrize("it", [0, 1])
+def test_golden_long_nucleotide_contigs(ctx, golden, tmp_path, it):
+    """contigs of 17-36 kb growing to 70 kb (KmerPosition<int>, 16-bit diagonal wrap-around, contig-contig reverse-strand
+    overlaps): every module on the reference's DBs"""
+    import plass_amd
+    s = os.path.join(golden, "longnucl")
+    db = ctx.read_seqdb(f"{s}/seq_{it}")
+    assert db.info()["max_entry_len"] > 32767
+    cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+    cands.write(tmp_path / "pref")
+    assert_same_db(f"{s}/pref_{it}", tmp_path / "pref", "long nucl kmermatcher")
+    pref = ctx.read_prefdb(db, db, f"{s}/pref_{it}")
+    alns, _ = ctx.rescorediagonal(db, db, pref, plass_amd.RescoreParams(min_seq_id=0.99))
+    alns.write(tmp_path / "aln")
+    assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "long nucl rescorediagonal")
+    aln_in = ctx.read_alndb(db, f"{s}/aln_{it}")
+    out, _ = ctx.assembleresults(db, aln_in, nucl_as_params())
+    out.write(tmp_path / "seq")
+    assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "long nucl nuclassembleresults")
+
+
 def test_synthetic_nucl_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path):
     """15 k read pairs of a synthetic genome, both strands: every DB of three penguin-style iterations equals the oracle's"""
     import plass_amd

@@ -41,6 +41,19 @@ def test_oracle_nucl_iteration(oracle_bin, golden, tmp_path, it):
     assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "nuclassembleresults")
 
 
+@pytest.mark.parametrize("it", [0, 1])
+def test_oracle_long_nucleotide_contigs(oracle_bin, golden, tmp_path, it):
+    """contigs of 17-36 kb that grow to 70 kb: KmerPosition<int> records and the +-65 536 diagonal wrap-around of the 16-bit
+    prefilter diagonal (kmermatcher.cpp:797-802, rescorediagonal.cpp:218-240), reverse-strand overlaps between contigs"""
+    s = os.path.join(golden, "longnucl")
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/seq_{it}", tmp_path / "pref"] + NUCL_KM)
+    assert_same_db(f"{s}/pref_{it}", tmp_path / "pref", "long nucl kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/seq_{it}", f"{s}/seq_{it}", f"{s}/pref_{it}", tmp_path / "aln"] + NUCL_RS)
+    assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "long nucl rescorediagonal")
+    run_oracle(oracle_bin, ["nuclassembleresults", f"{s}/seq_{it}", f"{s}/aln_{it}", tmp_path / "seq"] + NUCL_AS)
+    assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "long nucl nuclassembleresults")
+
+
 def test_oracle_guided_iterations(oracle_bin, golden, tmp_path):
     """penguin's protein-guided stage: kmermatcher + rescorediagonal (-a 1) on the protein twins, proteinaln2nucl,
     guidedassembleresults; iteration 0 module by module, iteration 1 chained on the oracle's own DBs"""
