@@ -137,6 +137,36 @@ def test_golden_long_nucleotide_contigs(ctx, golden, tmp_path, it):
     assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "long nucl nuclassembleresults")
 
 
+@pytest.mark.parametrize("ext", [False, True])
+def test_golden_adversarial_inputs(ctx, golden, tmp_path, ext):
+    """hostile protein and nucleotide inputs, every module on the reference's DBs (adversarial.tar.gz)"""
+    import plass_amd
+    s = os.path.join(golden, "adversarial")
+    e = int(ext)
+    db = ctx.read_seqdb(f"{s}/aa_seq")
+    par = km_params(0); par.include_only_extendable = ext
+    cands, _ = ctx.kmermatcher(db, par)
+    cands.write(tmp_path / "p")
+    assert_same_db(f"{s}/aa_pref{e}", tmp_path / "p", "adversarial aa kmermatcher")
+    alns, _ = ctx.rescorediagonal(db, db, ctx.read_prefdb(db, db, f"{s}/aa_pref{e}"), plass_amd.RescoreParams(min_seq_id=0.9))
+    alns.write(tmp_path / "a")
+    assert_same_db(f"{s}/aa_aln{e}", tmp_path / "a", "adversarial aa rescorediagonal")
+    out, _ = ctx.assembleresults(db, ctx.read_alndb(db, f"{s}/aa_aln{e}"), plass_amd.AssembleParams(min_seq_id=0.9))
+    out.write(tmp_path / "o")
+    assert_same_db(f"{s}/aa_out{e}", tmp_path / "o", "adversarial aa assembleresults")
+    ndb = ctx.read_seqdb(f"{s}/nucl_seq")
+    npar = km_params(0, nucl=True); npar.include_only_extendable = ext
+    cands, _ = ctx.kmermatcher(ndb, npar)
+    cands.write(tmp_path / "np")
+    assert_same_db(f"{s}/n_pref{e}", tmp_path / "np", "adversarial nucl kmermatcher")
+    alns, _ = ctx.rescorediagonal(ndb, ndb, ctx.read_prefdb(ndb, ndb, f"{s}/n_pref{e}"), plass_amd.RescoreParams(min_seq_id=0.99))
+    alns.write(tmp_path / "na")
+    assert_same_db(f"{s}/n_aln{e}", tmp_path / "na", "adversarial nucl rescorediagonal")
+    out, _ = ctx.assembleresults(ndb, ctx.read_alndb(ndb, f"{s}/n_aln{e}"), nucl_as_params())
+    out.write(tmp_path / "no")
+    assert_same_db(f"{s}/n_out{e}", tmp_path / "no", "adversarial nucl nuclassembleresults")
+
+
 def test_synthetic_nucl_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path):
     """15 k read pairs of a synthetic genome, both strands: every DB of three penguin-style iterations equals the oracle's"""
     import plass_amd

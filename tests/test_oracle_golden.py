@@ -54,6 +54,28 @@ def test_oracle_long_nucleotide_contigs(oracle_bin, golden, tmp_path, it):
     assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "long nucl nuclassembleresults")
 
 
+@pytest.mark.parametrize("ext", [0, 1])
+def test_oracle_adversarial_inputs(oracle_bin, golden, tmp_path, ext):
+    """hostile inputs (shorter than k, homopolymers and repeats, X / '*' / N / IUPAC / lower case, duplicates and reverse
+    complement duplicates, a 33 000-residue contig, index order != key order): what the reference wrote (adversarial.tar.gz)"""
+    s = os.path.join(golden, "adversarial")
+    e = ["--include-only-extendable", str(ext)]
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/aa_seq", tmp_path / "p"] + AA_KM + ["--hash-shift", "67"] + e)
+    assert_same_db(f"{s}/aa_pref{ext}", tmp_path / "p", "adversarial aa kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/aa_seq", f"{s}/aa_seq", f"{s}/aa_pref{ext}", tmp_path / "a"] + AA_RS)
+    assert_same_db(f"{s}/aa_aln{ext}", tmp_path / "a", "adversarial aa rescorediagonal")
+    run_oracle(oracle_bin, ["assembleresults", f"{s}/aa_seq", f"{s}/aa_aln{ext}", tmp_path / "o"] + AA_AS)
+    assert_same_db(f"{s}/aa_out{ext}", tmp_path / "o", "adversarial aa assembleresults")
+    nkm = [x for x in NUCL_KM]
+    nkm[nkm.index("--include-only-extendable") + 1] = str(ext)
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/nucl_seq", tmp_path / "np"] + nkm)
+    assert_same_db(f"{s}/n_pref{ext}", tmp_path / "np", "adversarial nucl kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/nucl_seq", f"{s}/nucl_seq", f"{s}/n_pref{ext}", tmp_path / "na"] + NUCL_RS)
+    assert_same_db(f"{s}/n_aln{ext}", tmp_path / "na", "adversarial nucl rescorediagonal")
+    run_oracle(oracle_bin, ["nuclassembleresults", f"{s}/nucl_seq", f"{s}/n_aln{ext}", tmp_path / "no"] + NUCL_AS)
+    assert_same_db(f"{s}/n_out{ext}", tmp_path / "no", "adversarial nucl nuclassembleresults")
+
+
 def test_oracle_guided_iterations(oracle_bin, golden, tmp_path):
     """penguin's protein-guided stage: kmermatcher + rescorediagonal (-a 1) on the protein twins, proteinaln2nucl,
     guidedassembleresults; iteration 0 module by module, iteration 1 chained on the oracle's own DBs"""
