@@ -359,26 +359,10 @@ struct NuclCmp { const AsmArgs *a; bool abort; };
 __device__ __forceinline__ uint32_t ambHash(uint32_t a1, uint32_t b1, uint32_t a2, uint32_t b2) {
     return (a1 * 0x9E3779B1u) ^ (b1 * 0x85EBCA77u) ^ (a2 * 0xC2B2AE3Du) ^ (b2 * 0x27D4EB2Fu);
 }
-__device__ bool nuclLess(const Item &r1, const Item &r2, NuclCmp &c) {   // CompareNuclResultByScore (nuclassembleresult.cpp:36-70)
-    if (c.abort) return false;
-    const unsigned mm1 = (unsigned) ((double) ((1.0f - r1.seqId) * (float) r1.alnLength) + 0.5);
-    const unsigned mm2 = (unsigned) ((double) ((1.0f - r2.seqId) * (float) r2.alnLength) + 0.5);
-    const unsigned alpha1 = mm1 + 1, alpha2 = mm2 + 1;
-    const unsigned beta1 = r1.alnLength - mm1 + 1, beta2 = r2.alnLength - mm2 + 1;
-    // The posterior class depends on (mismatches, overlap length) of the two hits only, and read overlaps use a small part of
-    // that space over and over: classes are memoised in a direct-mapped table (1 byte per tuple, 0 = not yet known; racing
-    // writers store the same value).  A hit skips four lgamma and a loop of exp / log in double precision.
-    const bool cacheable = c.a->cmpCache && mm1 < CMP_MM && mm2 < CMP_MM && r1.alnLength < CMP_LEN && r2.alnLength < CMP_LEN;
-    const size_t cidx = cacheable ? ((((size_t) r1.alnLength * CMP_MM + mm1) * CMP_LEN + r2.alnLength) * CMP_MM + mm2) : 0;
-    int memo = cacheable ? (int) c.a->cmpCache[cidx] : 0;
-    if (memo) {
-        const int cls = memo - 1;
-        if (cls == 0) return true;
-        if (cls == 1) return false;
-        if (r1.dbLen - r1.alnLength < r2.dbLen - r2.alnLength) return true;
-        if (r1.dbLen - r1.alnLength > r2.dbLen - r2.alnLength) return false;
-        return true;
-    }
+// posterior class of one (alpha, beta) tuple the memo does not hold yet: 0 (p < 0.45), 1 (p > 0.55), 2 (between), or -1 when the
+// decision sits on a threshold and the host table lacks the tuple (the query is then re-run).  Kept out of line: it is rare
+// (the memo absorbs it) and its double-precision lgamma / exp / log would otherwise dictate the register budget of the callers.
+__device__ __attribute__((noinline)) int nuclPosteriorClassDev(unsigned alpha1, unsigned beta1, unsigned alpha2, unsigned beta2, const AsmArgs *ap) {
     const double log_c = (lgamma((double) (beta1 + beta2)) + lgamma((double) (alpha1 + beta1))) -
                          (lgamma((double) (alpha1 + beta1 + beta2)) + lgamma((double) beta1));
     double log_r = 0.0, p = 0.0;
@@ -392,25 +376,37 @@ __device__ bool nuclLess(const Item &r1, const Item &r2, NuclCmp &c) {   // Comp
     // taken from the host-evaluated table instead.
     const double AMB_EPS = 1e-9;
     if (fabs(p - 0.45) < AMB_EPS || fabs(p - 0.55) < AMB_EPS) {
-        const AsmArgs &a = *c.a;
-        bool found = false;
+        const AsmArgs &a = *ap;
         if (a.ambMask) {
             uint32_t slot = ambHash(alpha1, beta1, alpha2, beta2) & a.ambMask;
             for (;;) {
                 const uint32_t *k = a.ambKeys + 4 * (size_t) slot;
                 if (k[0] == 0) break;
-                if (k[0] == alpha1 && k[1] == beta1 && k[2] == alpha2 && k[3] == beta2) { cls = a.ambVals[slot]; found = true; break; }
+                if (k[0] == alpha1 && k[1] == beta1 && k[2] == alpha2 && k[3] == beta2) return (int) a.ambVals[slot];
                 slot = (slot + 1) & a.ambMask;
             }
         }
-        if (!found) {
-            const uint32_t w = atomicAdd(a.needCount, 1u);
-            if (w < a.needCap) { uint32_t *k = a.needKeys + 4 * (size_t) w; k[0] = alpha1; k[1] = beta1; k[2] = alpha2; k[3] = beta2; }
-            c.abort = true;
-            return false;
-        }
+        const uint32_t w = atomicAdd(a.needCount, 1u);
+        if (w < a.needCap) { uint32_t *k = a.needKeys + 4 * (size_t) w; k[0] = alpha1; k[1] = beta1; k[2] = alpha2; k[3] = beta2; }
+        return -1;
     }
-    if (cacheable) c.a->cmpCache[cidx] = (uint8_t) (cls + 1);        // (classes on a threshold come from the host table and are stored alike)
+    return cls;
+}
+__device__ __forceinline__ bool nuclLess(const Item &r1, const Item &r2, NuclCmp &c) {   // CompareNuclResultByScore (nuclassembleresult.cpp:36-70)
+    if (c.abort) return false;
+    const unsigned mm1 = (unsigned) ((double) ((1.0f - r1.seqId) * (float) r1.alnLength) + 0.5);
+    const unsigned mm2 = (unsigned) ((double) ((1.0f - r2.seqId) * (float) r2.alnLength) + 0.5);
+    // The posterior class depends on (mismatches, overlap length) of the two hits only, and read overlaps use a small part of
+    // that space over and over: classes are memoised in a direct-mapped table (1 byte per tuple, 0 = not yet known; racing
+    // writers store the same value).  A hit skips four lgamma and a loop of exp / log in double precision.
+    const bool cacheable = c.a->cmpCache && mm1 < CMP_MM && mm2 < CMP_MM && r1.alnLength < CMP_LEN && r2.alnLength < CMP_LEN;
+    const size_t cidx = cacheable ? ((((size_t) r1.alnLength * CMP_MM + mm1) * CMP_LEN + r2.alnLength) * CMP_MM + mm2) : 0;
+    int cls = cacheable ? (int) c.a->cmpCache[cidx] - 1 : -1;
+    if (cls < 0) {
+        cls = nuclPosteriorClassDev(mm1 + 1, r1.alnLength - mm1 + 1, mm2 + 1, r2.alnLength - mm2 + 1, c.a);
+        if (cls < 0) { c.abort = true; return false; }
+        if (cacheable) c.a->cmpCache[cidx] = (uint8_t) (cls + 1);     // (classes on a threshold come from the host table and are stored alike)
+    }
     if (cls == 0) return true;
     if (cls == 1) return false;
     if (r1.dbLen - r1.alnLength < r2.dbLen - r2.alnLength) return true;
@@ -680,14 +676,16 @@ __device__ __forceinline__ void copyBytesSerial(char *dst, const char *src, unsi
 __device__ __forceinline__ void copyRevCompSerial(char *dst, const char *src, unsigned n) {     // getNuclRevFragment
     for (unsigned i = 0; i < n; i++) dst[i] = nuclRevN(src[n - 1 - i]);
 }
+// 256 threads share one score table: the kernel is latency bound, the number of queries in flight per CU is what counts
+constexpr int NT_BLOCK = 256;
 template <bool GUIDED>
-__global__ __launch_bounds__(64) void assembleNuclThreadKernel(AsmArgs a) {
+__global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs a) {    // 4 blocks per CU: at most 128 VGPRs
     __shared__ signed char smat[123 * 123 + 7];
-    for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
+    for (int i = threadIdx.x; i < 123 * 123; i += NT_BLOCK) smat[i] = a.mat[i];
     __syncthreads();
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
     NuclCmp cmp; cmp.a = &a; cmp.abort = false;
-    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < a.nQueryList; w += gridDim.x * 64) {
+    for (uint32_t w = blockIdx.x * NT_BLOCK + threadIdx.x; w < a.nQueryList; w += gridDim.x * NT_BLOCK) {
         const uint32_t id = a.queryList[w];
         const uint64_t h0 = a.qoff[id];
         const uint32_t h = (uint32_t) (a.qoff[id + 1] - h0);
@@ -1337,9 +1335,9 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
             if (pass == 0) {
                 if (cnts[0]) {
                     a.queryList = dSmallList.as<uint32_t>(); a.nQueryList = cnts[0];
-                    const uint32_t grid = std::min<uint32_t>((cnts[0] + 63) / 64, (uint32_t) ctx->numCU * 16);
-                    if (guided) hipLaunchKernelGGL(assembleNuclThreadKernel<true>, dim3(grid), dim3(64), 0, st, a);
-                    else hipLaunchKernelGGL(assembleNuclThreadKernel<false>, dim3(grid), dim3(64), 0, st, a);
+                    const uint32_t grid = std::min<uint32_t>((cnts[0] + NT_BLOCK - 1) / NT_BLOCK, (uint32_t) ctx->numCU * 8);
+                    if (guided) hipLaunchKernelGGL(assembleNuclThreadKernel<true>, dim3(grid), dim3(NT_BLOCK), 0, st, a);
+                    else hipLaunchKernelGGL(assembleNuclThreadKernel<false>, dim3(grid), dim3(NT_BLOCK), 0, st, a);
                 }
                 launchWave(dMid32List.as<uint32_t>(), cnts[1]);
             } else launchWave(dRedo[(pass + 1) & 1].as<uint32_t>(), nWork);
