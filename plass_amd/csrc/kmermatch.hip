@@ -176,6 +176,47 @@ __device__ __forceinline__ bool kmerIndexFast(const unsigned char *w, int k, uns
     return z == 0;
 }
 
+// Nucleotide k-mer (Indexer::computeKmerIdx, mm/prefiltering/Indexer.h:124-131: 2 bits per letter, first letter most significant)
+// straight from the code bytes in LDS: up to four unaligned 8-byte reads fetch the k <= 31 codes (0..3, X = 4), an X is any byte
+// with bit 2 set, and each word's eight 2-bit fields are gathered with three shift-or-mask steps after a byte swap.  Replaces k
+// LDS byte reads and k shift/or pairs per window.
+__device__ __forceinline__ uint32_t pack2x8(uint64_t w) {            // bytes b0..b7 (codes, b0 first) -> 16 bits, b0 most significant
+    uint64_t y = __builtin_bswap64(w & 0x0303030303030303ULL);
+    y = (y | (y >> 6)) & 0x000F000F000F000FULL;
+    y = (y | (y >> 12)) & 0x000000FF000000FFULL;
+    y = (y | (y >> 24)) & 0xFFFFULL;
+    return (uint32_t) y;
+}
+__device__ __forceinline__ bool kmerNuclFast(const unsigned char *w, int k, uint64_t &f) {
+    uint64_t x = 0; f = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (8 * j < k) {
+            uint64_t v; __builtin_memcpy(&v, w + 8 * j, 8);
+            const int nb = k - 8 * j;                               // codes of this word that belong to the k-mer
+            if (nb < 8) v &= (1ULL << (8 * nb)) - 1ULL;
+            x |= v;
+            const int sh = 2 * (k - 8 * (j + 1));
+            const uint64_t g = pack2x8(v);
+            f |= (sh >= 0) ? (g << sh) : (g >> (-sh));
+        }
+    }
+    return (x & 0x0404040404040404ULL) == 0;                        // no X among the k codes
+}
+
+// canonical strand, palindromes dropped, position mirrored for the reverse strand (kmermatcher.cpp:149-187)
+__device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k, uint32_t L, uint32_t p, uint64_t &kmer, uint32_t &pos) {
+    uint64_t f;
+    const bool noX = kmerNuclFast(w, k, f);
+    const uint64_t r = revComplementDev(f, k);
+    kmer = 0; pos = p;
+    if (!noX || r == f) return false;
+    const bool pickRev = r < f;
+    kmer = pickRev ? r : (f | BIT63);
+    pos = pickRev ? (L - p - k) : p;
+    return true;
+}
+
 constexpr uint32_t RES_L = 992;     // sequences up to this length keep their codes (and per-window hash scores) resident in LDS
 
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK>
@@ -287,6 +328,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
                     valid = (p < nWin);
                     if (valid) {
                         if (!NUCL && fastIdx) { pos = p; valid = kmerIndexFast(resident ? &sCodeAll[p] : &sCode[lane], k, (unsigned) a.xCode, (uint32_t) a.powers[1], (uint32_t) a.powers[7], kmer); }
+                        else if (NUCL && a.xCode == 4) valid = kmerNuclCanonical(resident ? &sCodeAll[p] : &sCode[lane], k, L, p, kmer, pos);
                         else if (resident) valid = kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                         else valid = kmerFromCodes<NUCL>([&](int i) { return sCode[lane + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                     }
@@ -302,6 +344,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
                     if (pass == 2 && valid && score <= sStar)      // only the ~60 selected windows rebuild their k-mer
                     {
                         if (!NUCL && fastIdx) { pos = p; (void) kmerIndexFast(&sCodeAll[p], k, (unsigned) a.xCode, (uint32_t) a.powers[1], (uint32_t) a.powers[7], kmer); }
+                        else if (NUCL && a.xCode == 4) (void) kmerNuclCanonical(&sCodeAll[p], k, L, p, kmer, pos);
                         else (void) kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                     }
                 }
