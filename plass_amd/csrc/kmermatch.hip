@@ -563,6 +563,7 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                 int lastX = -1;
                 uint32_t nOut = 0;
                 uint32_t word = 0;
+                R pend0, pend1, pend2;
                 for (uint32_t i = 0; i < L; i++) {
                     if ((i & 3) == 0) __builtin_memcpy(&word, base + i, 4);                 // buffer is padded past its end
                     const unsigned char c = sMap[(word >> (8 * (i & 3))) & 0xFF];
@@ -591,11 +592,15 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                             }
                             R r; r.kmer = idx; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) p;
                             if constexpr (LONG) r.pad = 0;
-                            arr[slot + 1 + nOut] = r; nOut++;
+                            // four records at a time: the lane's stores to one cache line leave together instead of a k-mer apart
+                            switch (nOut & 3u) { case 0: pend0 = r; break; case 1: pend1 = r; break; case 2: pend2 = r; break;
+                                default: { R *d = arr + slot + 1 + (nOut - 3u); d[0] = pend0; d[1] = pend1; d[2] = pend2; d[3] = r; } }
+                            nOut++;
                         }
                     }
                 }
                 if (!toWave) {
+                    { R *d = arr + slot + 1 + (nOut & ~3u); const uint32_t rem = nOut & 3u; if (rem > 0) d[0] = pend0; if (rem > 1) d[1] = pend1; if (rem > 2) d[2] = pend2; }
                     R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
                     if constexpr (LONG) r.pad = 0;
                     arr[slot] = r;
