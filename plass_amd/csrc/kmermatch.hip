@@ -1201,6 +1201,16 @@ static inline unsigned gridFor(uint64_t n, unsigned block, unsigned cap = 65535u
 }
 static int ceilLog2(uint64_t x) { int b = 0; while ((1ULL << b) < x) b++; return b; }
 
+// what the host needs about the target of the last run (the stale-record check), gathered on the device so that it travels with
+// the group kernel's counts in one round trip: {maxRT, slotOff[T], slotOff[T+1], len[T]}
+__global__ void lastRunInfoKernel(const unsigned long long *__restrict__ maxRT, const uint64_t *__restrict__ slotOff, const uint32_t *__restrict__ len,
+                                  uint32_t n, unsigned long long *__restrict__ out) {
+    const unsigned long long m = *maxRT;
+    const uint32_t t = (uint32_t) (m & 0xFFFFFFFFull);
+    out[0] = m;
+    if (t < n) { out[1] = slotOff[t]; out[2] = slotOff[t + 1]; out[3] = len[t]; } else { out[1] = out[2] = out[3] = 0; }
+}
+
 template <bool NUCL, bool LONG>
 int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
                   plasship_kmermatch_stats *stats) {
@@ -1381,6 +1391,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
     hipLaunchKernelGGL((groupKernel<NUCL, LONG>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     std::vector<uint64_t> hOutCnt(gGrid), hBStart(nBuckets + 1);
+    DevBuf dLastRun; unsigned long long hLastRun[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
+    if (dLastRun.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
+    PH_CHECK(hipMemcpyAsync(hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hVHist.data(), dVHist.p, VH_BINS * 4, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hBStart.data(), dBucketStart, ((size_t) nBuckets + 1) * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
@@ -1395,12 +1410,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     std::vector<int64_t> stalePos;          // original k-mer positions of the sort-#1 records of rank N_m, N_m+1, … that belong to T
     uint32_t staleT = 0;
     if (Nm > 0 && Nm < Nk) {
-        unsigned long long maxRT = 0;
-        PH_COPY_SYNC(st, &maxRT, dMaxRT.p, 8, hipMemcpyDeviceToHost);
+        const unsigned long long maxRT = hLastRun[0];
         staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
-        uint64_t so[2]; uint32_t tLen = 0;
-        PH_COPY_SYNC(st, so, dSlotOff.as<uint64_t>() + staleT, 16, hipMemcpyDeviceToHost);
-        PH_COPY_SYNC(st, &tLen, db->d_len.as<uint32_t>() + staleT, 4, hipMemcpyDeviceToHost);
+        const uint64_t so[2] = {hLastRun[1], hLastRun[2]}; const uint32_t tLen = (uint32_t) hLastRun[3];
         const uint32_t tb = (uint32_t) (so[1] - so[0]);
         DevBuf dTRec, dTId, dTScr, dTOff, dTCap, dDiff;
         uint32_t cap = 64; while (cap < tLen + 1) cap <<= 1;
@@ -1425,10 +1437,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         // a record of T if rank N_m itself can be one of them
         bool mayHit = false;
         if (m) {
-            std::vector<uint32_t> vh(VH_BINS);
-            PH_COPY_SYNC(st, vh.data(), dVHist.p, VH_BINS * 4, hipMemcpyDeviceToHost);
             std::vector<uint64_t> cum(VH_BINS + 1, 0);
-            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + vh[b];
+            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + hVHist[b];
             for (uint32_t j = 0; j < m && !mayHit; j++) { const uint32_t b = valueBin<NUCL>(trec[j].kmer, valueShift); mayHit = Nm >= cum[b] && Nm < cum[b + 1]; }
         }
         if (m && mayHit) {
