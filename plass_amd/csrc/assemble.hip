@@ -1197,7 +1197,8 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
 
 // builds one output DB (extended entries from the arena + carried-over entries of `db`), entries in key order
 static int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
-                         const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out) {
+                         const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
+                         const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr) {
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();
@@ -1226,7 +1227,9 @@ static int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
     if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
     uint32_t maxLen = 0;
+    if (doneEvent) PH_CHECK(hipEventRecord(doneEvent, st));
     PH_CHECK(hipMemcpyAsync(&maxLen, dMaxLen.p, 4, hipMemcpyDeviceToHost, st));
+    if (dExtra) PH_CHECK(hipMemcpyAsync(hExtra, dExtra, extraBytes, hipMemcpyDeviceToHost, st));      // the caller's counters ride along
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
     o->maxEntryLen = maxLen + 2;
@@ -1370,7 +1373,9 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     }
     // ---- output DB(s): extended queries + carried-over sequences, in key order ----
     plasship_seqdb *o = nullptr, *oAa = nullptr;
-    int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), dArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &o);
+    unsigned long long hs[16] = {0};
+    int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), dArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &o,
+                              dStats.p, hs, 128, guided ? (hipEvent_t) nullptr : ctx->ev[1]);
     if (rcOut != PLASSHIP_OK) return rcOut;
     std::unique_ptr<plasship_seqdb> holdO(o), holdAa;              // released to the caller on success only
     if (guided) {
@@ -1378,11 +1383,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         if (rcOut != PLASSHIP_OK) return rcOut;
         holdAa.reset(oAa);
     }
-    unsigned long long hs[16] = {0};
-    PH_CHECK(hipEventRecord(ctx->ev[1], st));
-    PH_CHECK(hipMemcpyAsync(hs, dStats.p, 128, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
-    PH_CHECK(hipGetLastError());
+    if (guided) { PH_CHECK(hipEventRecord(ctx->ev[1], st)); PH_CHECK(hipStreamSynchronize(st)); }
     if (hs[12]) { setError("plasship_guided_assemble: an alignment asks for a protein fragment the twin does not have (coordinates are not codon aligned)"); return PLASSHIP_ERR_ARG; }
     if (stats) {
         stats->n_extended = hs[0]; stats->n_rescored = hs[1]; stats->out_residues = o->residues;
