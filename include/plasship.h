@@ -51,6 +51,40 @@ int plasship_ctx_sync(plasship_ctx *ctx);
 /* raw hipStream_t of the context, so a caller can bracket work with its own events */
 void *plasship_ctx_stream(plasship_ctx *ctx);
 
+/* ---- one read set sharded over several GPUs (one process / context per GPU) ------------------
+ * replaces: the reference's split of kmermatcher over MPI ranks by k-mer hash range
+ * (`$RUNNER` = mpirun in data/assemble.sh:92,103; hashStartRange/hashEndRange, mm/linclust/kmermatcher.cpp:312,736-778;
+ * MMseqsMPI::rank/numProc) — here every stage of the iteration is sharded and the result is the single-process one.
+ *
+ * Every rank holds the WHOLE sequence DB (replicated, identical on all ranks) and calls the same entry points with the
+ * same arguments in the same order.  With a communicator set:
+ *   plasship_kmermatch   extracts the k-mers of its share of the sequences, routes the records to the owner of their
+ *                        k-mer hash bucket (all-to-all), groups them there, routes the grouped (rep, member, diagonal)
+ *                        records to the owner of the representative (all-to-all) and returns the candidates of the
+ *                        queries it owns (rank r owns ids [ceil(r*n/world), ceil((r+1)*n/world)); other queries have no
+ *                        lines);
+ *   plasship_rescore     as before (it sees only the owned queries' candidates);
+ *   plasship_assemble /  extend the owned queries, all-gather the extended sequences and return the complete output
+ *   _guided_assemble     DB(s) on every rank.
+ * The library does not talk to a network itself: the caller supplies the three collectives (bench.py: torch.distributed
+ * = RCCL over xGMI on device pointers; tests: an in-process implementation that runs several ranks on one GPU).
+ * All callbacks are collective, return 0 on success, and must have completed (device buffers ready on the context's
+ * stream or the whole device) when they return.  The library synchronises its stream before calling them.            */
+typedef struct plasship_comm {
+    int rank, world;
+    void *user;
+    /* recv[r * bytes_per_rank ...] = send of rank r (host memory) */
+    int (*allgather_host)(void *user, const void *send, void *recv, uint64_t bytes_per_rank);
+    /* device buffers; send is laid out by destination rank (send_bytes[world]), recv by source rank (recv_bytes[world]) */
+    int (*alltoallv_dev)(void *user, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes);
+    /* device buffers; every rank contributes send_bytes (its own entry of recv_bytes[world]); recv laid out by rank */
+    int (*allgatherv_dev)(void *user, const void *d_send, uint64_t send_bytes, void *d_recv, const uint64_t *recv_bytes);
+} plasship_comm;
+/* comm == NULL returns the context to single-GPU operation.  The struct is copied. */
+int plasship_ctx_set_comm(plasship_ctx *ctx, const plasship_comm *comm);
+/* device-to-device copy on the context's stream, waited for (used by in-process communicators) */
+int plasship_ctx_copy_d2d(plasship_ctx *ctx, void *d_dst, const void *d_src, uint64_t bytes);
+
 /* ---- sequence DB  (replaces DBReader<unsigned int>::open/getData/getSeqLen/getDbKey,
  *      mm/commons/DBReader.cpp:150-215,548-589; DBReader.h:185-213) --------------------------- */
 /* data = concatenation of entries "SEQ\n\0"; off/elen index it (elen includes "\n\0");

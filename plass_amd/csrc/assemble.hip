@@ -1151,6 +1151,51 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
         }
     }
 }
+// ---- sharded run: the extended sequences of the owned queries travel to every rank (all-gather), see mergeExtended below ----
+struct __attribute__((aligned(16))) ExtMeta { uint32_t id, len, aaLen, pad; };
+__global__ void extMarkKernel(uint32_t n, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen, const uint32_t *__restrict__ aaNewLen,
+                              uint32_t *__restrict__ keep, uint64_t *__restrict__ bytes, uint64_t *__restrict__ aaBytes) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += gridDim.x * blockDim.x) {
+        const bool ext = (flags[id] & 0x20u) != 0;
+        keep[id] = ext ? 1u : 0u; bytes[id] = ext ? newLen[id] : 0u;
+        if (aaBytes) aaBytes[id] = ext ? aaNewLen[id] : 0u;
+    }
+}
+__global__ __launch_bounds__(256) void extPackKernel(uint32_t n, const uint32_t *__restrict__ keep, const uint64_t *__restrict__ pos, const uint64_t *__restrict__ off,
+                                                     const uint64_t *__restrict__ aaOff, const uint32_t *__restrict__ newLen, const uint64_t *__restrict__ newStart,
+                                                     const char *__restrict__ arena, const uint32_t *__restrict__ aaNewLen, const uint64_t *__restrict__ aaNewStart,
+                                                     const char *__restrict__ aaArena, ExtMeta *__restrict__ meta, char *__restrict__ packed, char *__restrict__ aaPacked) {
+    const int G = 16, groupsPerBlock = 256 / G;
+    const int gl = threadIdx.x & (G - 1);
+    for (uint32_t id = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id < n; id += gridDim.x * groupsPerBlock) {
+        if (!keep[id]) continue;
+        const uint32_t L = newLen[id];
+        copyBytesG<G>(packed + off[id], arena + newStart[id], L, gl);
+        uint32_t La = 0;
+        if (aaPacked) { La = aaNewLen[id]; copyBytesG<G>(aaPacked + aaOff[id], aaArena + aaNewStart[id], La, gl); }
+        if (gl == 0) { ExtMeta m; m.id = id; m.len = L; m.aaLen = La; m.pad = 0; meta[pos[id]] = m; }
+    }
+}
+__global__ void extLensKernel(const ExtMeta *__restrict__ meta, uint64_t m, uint64_t *__restrict__ lens, uint64_t *__restrict__ aaLens) {
+    for (uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t) gridDim.x * blockDim.x) { lens[j] = meta[j].len; if (aaLens) aaLens[j] = meta[j].aaLen; }
+}
+__global__ void extMergeKernel(const ExtMeta *__restrict__ meta, uint64_t m, const uint64_t *__restrict__ start, const uint64_t *__restrict__ aaStart,
+                               uint32_t *__restrict__ flags, uint32_t *__restrict__ newLen, uint64_t *__restrict__ newStart,
+                               uint32_t *__restrict__ aaNewLen, uint64_t *__restrict__ aaNewStart) {
+    for (uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (uint64_t) gridDim.x * blockDim.x) {
+        const ExtMeta e = meta[j];
+        atomicOr(&flags[e.id], 0x20u); newLen[e.id] = e.len; newStart[e.id] = start[j];
+        if (aaStart) { aaNewLen[e.id] = e.aaLen; aaNewStart[e.id] = aaStart[j]; }
+    }
+}
+__global__ void orFlagsKernel(const uint32_t *__restrict__ all, uint32_t n, int world, uint32_t *__restrict__ flags) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += gridDim.x * blockDim.x) {
+        uint32_t f = flags[id];
+        for (int r = 0; r < world; r++) f |= all[(size_t) r * n + id] & 0x80u;       // "consumed as a target" by any rank's query
+        flags[id] = f;
+    }
+}
+
 __global__ void maxU32Kernel(const uint32_t *__restrict__ v, uint64_t n, uint32_t *__restrict__ out) {
     uint32_t m = 0;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) m = max(m, v[i]);
@@ -1234,6 +1279,65 @@ static int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint
     PH_CHECK(hipGetLastError());
     o->maxEntryLen = maxLen + 2;
     *out = holder.release();
+    return PLASSHIP_OK;
+}
+
+// Sharded run (plasship_ctx_set_comm): every rank has extended the queries it owns.  The extended sequences (and, for the
+// guided variant, their protein twins) are packed, all-gathered and entered into flags / newLen / newStart of every rank as if
+// it had produced them itself, so that buildOutputDB writes the complete DB everywhere; the "consumed" bits only matter with
+// --keep-target 0 and are OR-ed over the ranks then.  gathered / gatheredAa replace the local arenas.
+static int mergeExtended(plasship_ctx *ctx, uint32_t N, bool guided, int keepTarget, uint32_t *dFlags, uint32_t *dNewLen, uint64_t *dNewStart, const char *dArena,
+                         uint32_t *dAaNewLen, uint64_t *dAaNewStart, const char *dAaArena, void *dTmp, size_t tmpBytes, DevBuf &gathered, DevBuf &gatheredAa) {
+    hipStream_t st = ctx->stream;
+    const plasship_comm *cm = commOf(ctx);
+    const int W = cm->world;
+    DevBuf dKeep, dBytes, dAaBytes, dPos, dOff, dAaOff;
+    if (dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dPos.alloc(((size_t) N + 2) * 8) != hipSuccess ||
+        dOff.alloc(((size_t) N + 2) * 8) != hipSuccess || (guided && (dAaBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dAaOff.alloc(((size_t) N + 2) * 8) != hipSuccess))) {
+        setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    const unsigned gridN = std::min<uint32_t>((N + 255) / 256 + 1, 8192);
+    hipLaunchKernelGGL(extMarkKernel, dim3(gridN), dim3(256), 0, st, N, dFlags, dNewLen, guided ? dAaNewLen : (const uint32_t *) nullptr, dKeep.as<uint32_t>(), dBytes.as<uint64_t>(),
+                       guided ? dAaBytes.as<uint64_t>() : (uint64_t *) nullptr);
+    if (exclusiveScanU32(st, dKeep.as<uint32_t>(), dPos.as<uint64_t>(), N, dTmp, tmpBytes) || exclusiveScanU64(st, dBytes.as<uint64_t>(), dOff.as<uint64_t>(), N, dTmp, tmpBytes) ||
+        (guided && exclusiveScanU64(st, dAaBytes.as<uint64_t>(), dAaOff.as<uint64_t>(), N, dTmp, tmpBytes))) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t nExt = 0, extBytes = 0, aaExtBytes = 0;
+    PH_CHECK(hipMemcpyAsync(&nExt, dPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(&extBytes, dOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    if (guided) PH_CHECK(hipMemcpyAsync(&aaExtBytes, dAaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    DevBuf dMeta, dPacked, dAaPacked;
+    if (dMeta.alloc(std::max<uint64_t>(nExt, 1) * sizeof(ExtMeta)) != hipSuccess || dPacked.alloc(extBytes + 64) != hipSuccess || (guided && dAaPacked.alloc(aaExtBytes + 64) != hipSuccess)) {
+        setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    if (N) hipLaunchKernelGGL(extPackKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, N, dKeep.as<uint32_t>(), dPos.as<uint64_t>(), dOff.as<uint64_t>(),
+                              guided ? dAaOff.as<uint64_t>() : (const uint64_t *) nullptr, dNewLen, dNewStart, dArena, dAaNewLen, dAaNewStart, dAaArena,
+                              dMeta.as<ExtMeta>(), dPacked.as<char>(), guided ? dAaPacked.as<char>() : (char *) nullptr);
+    DevBuf gMeta; std::vector<uint64_t> rb;
+    int rc = commAllgathervBytes(ctx, dMeta.p, nExt * sizeof(ExtMeta), gMeta, rb); if (rc) return rc;
+    uint64_t M = 0; for (int r = 0; r < W; r++) M += rb[r] / sizeof(ExtMeta);
+    rc = commAllgathervBytes(ctx, dPacked.p, extBytes, gathered, rb); if (rc) return rc;
+    if (guided) { rc = commAllgathervBytes(ctx, dAaPacked.p, aaExtBytes, gatheredAa, rb); if (rc) return rc; }
+    // the gathered byte blocks are the ranks' packed blocks in rank order = the gathered meta order: starts are a prefix sum
+    DevBuf dLens, dStart, dAaLens, dAaStart, dTmp2; const size_t tmp2Bytes = exclusiveScanTmpBytes(M + 2);
+    if (dLens.alloc((M + 1) * 8) != hipSuccess || dStart.alloc((M + 2) * 8) != hipSuccess || dTmp2.alloc(tmp2Bytes) != hipSuccess ||
+        (guided && (dAaLens.alloc((M + 1) * 8) != hipSuccess || dAaStart.alloc((M + 2) * 8) != hipSuccess))) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (M) {
+        const unsigned gridM = (unsigned) std::min<uint64_t>((M + 255) / 256, 8192);
+        hipLaunchKernelGGL(extLensKernel, dim3(gridM), dim3(256), 0, st, gMeta.as<ExtMeta>(), M, dLens.as<uint64_t>(), guided ? dAaLens.as<uint64_t>() : (uint64_t *) nullptr);
+        if (exclusiveScanU64(st, dLens.as<uint64_t>(), dStart.as<uint64_t>(), M, dTmp2.p, tmp2Bytes) ||
+            (guided && exclusiveScanU64(st, dAaLens.as<uint64_t>(), dAaStart.as<uint64_t>(), M, dTmp2.p, tmp2Bytes))) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(extMergeKernel, dim3(gridM), dim3(256), 0, st, gMeta.as<ExtMeta>(), M, dStart.as<uint64_t>(), guided ? dAaStart.as<uint64_t>() : (const uint64_t *) nullptr,
+                           dFlags, dNewLen, dNewStart, dAaNewLen, dAaNewStart);
+    }
+    if (!keepTarget) {
+        DevBuf gFlags;
+        rc = commAllgathervBytes(ctx, dFlags, (uint64_t) N * 4, gFlags, rb); if (rc) return rc;
+        if (N) hipLaunchKernelGGL(orFlagsKernel, dim3(gridN), dim3(256), 0, st, gFlags.as<uint32_t>(), N, W, dFlags);
+        PH_CHECK(hipStreamSynchronize(st));       // gFlags is released on return
+    }
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
     return PLASSHIP_OK;
 }
 
@@ -1374,12 +1478,20 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     // ---- output DB(s): extended queries + carried-over sequences, in key order ----
     plasship_seqdb *o = nullptr, *oAa = nullptr;
     unsigned long long hs[16] = {0};
-    int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), dArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &o,
+    DevBuf dGathered, dGatheredAa;
+    const char *arenaP = dArena.as<char>(), *aaArenaP = dAaArena.as<char>();
+    if (commOf(ctx)) {
+        const int rc = mergeExtended(ctx, N, guided, par->keep_target, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), dArena.as<char>(),
+                                     dAaNewLen.as<uint32_t>(), dAaNewStart.as<uint64_t>(), dAaArena.as<char>(), dTmp.p, tmpBytes, dGathered, dGatheredAa);
+        if (rc != PLASSHIP_OK) return rc;
+        arenaP = dGathered.as<char>(); aaArenaP = dGatheredAa.as<char>();
+    }
+    int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), arenaP, par->keep_target, dTmp.p, tmpBytes, &o,
                               dStats.p, hs, 128, guided ? (hipEvent_t) nullptr : ctx->ev[1]);
     if (rcOut != PLASSHIP_OK) return rcOut;
     std::unique_ptr<plasship_seqdb> holdO(o), holdAa;              // released to the caller on success only
     if (guided) {
-        rcOut = buildOutputDB(ctx, aaDb, dFlags.as<uint32_t>(), dAaNewLen.as<uint32_t>(), dAaNewStart.as<uint64_t>(), dAaArena.as<char>(), par->keep_target, dTmp.p, tmpBytes, &oAa);
+        rcOut = buildOutputDB(ctx, aaDb, dFlags.as<uint32_t>(), dAaNewLen.as<uint32_t>(), dAaNewStart.as<uint64_t>(), aaArenaP, par->keep_target, dTmp.p, tmpBytes, &oAa);
         if (rcOut != PLASSHIP_OK) return rcOut;
         holdAa.reset(oAa);
     }

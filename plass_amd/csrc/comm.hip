@@ -1,0 +1,85 @@
+// Sharded operation: one read set over several GPUs, one context per GPU (include/plasship.h, plasship_ctx_set_comm).
+// The reference splits kmermatcher over MPI ranks by k-mer hash range (mm/linclust/kmermatcher.cpp:312,736-778) and merges
+// the ranks' files on disk; here the ranks exchange device buffers through three collectives the caller supplies
+// (RCCL via torch.distributed in bench.py).  This file holds the wrappers the stages use; the exchanges themselves are in
+// kmermatch.hip (k-mer records -> bucket owner, grouped records -> rep owner) and assemble.hip (extended sequences).
+#include "common.hpp"
+#include <cstring>
+
+using namespace plasship;
+
+extern "C" int plasship_ctx_set_comm(plasship_ctx *ctx, const plasship_comm *comm) {
+    if (!ctx) { setError("plasship_ctx_set_comm: ctx is NULL"); return PLASSHIP_ERR_ARG; }
+    if (!comm) { ctx->hasComm = false; memset(&ctx->comm, 0, sizeof(ctx->comm)); return PLASSHIP_OK; }
+    if (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world || !comm->allgather_host || !comm->alltoallv_dev || !comm->allgatherv_dev) {
+        setError("plasship_ctx_set_comm: bad communicator (rank/world out of range or a collective is missing)"); return PLASSHIP_ERR_ARG;
+    }
+    if (comm->world > 1024) { setError("plasship_ctx_set_comm: more than 1024 ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
+    ctx->comm = *comm; ctx->hasComm = true;
+    return PLASSHIP_OK;
+}
+
+extern "C" int plasship_ctx_copy_d2d(plasship_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
+    if (!ctx) { setError("plasship_ctx_copy_d2d: ctx is NULL"); return PLASSHIP_ERR_ARG; }
+    PH_CHECK(hipSetDevice(ctx->device));
+    if (bytes) PH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    return PLASSHIP_OK;
+}
+
+namespace plasship {
+
+int commAllgatherHost(plasship_ctx *ctx, const void *send, void *recv, uint64_t bytesPerRank) {
+    const plasship_comm *cm = commOf(ctx);
+    if (!cm) { memcpy(recv, send, bytesPerRank); return PLASSHIP_OK; }
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (cm->allgather_host(cm->user, send, recv, bytesPerRank) != 0) { setError("sharded run: the caller's allgather_host failed"); return PLASSHIP_ERR_DEVICE; }
+    return PLASSHIP_OK;
+}
+
+template <typename F> static int allReduceU64(plasship_ctx *ctx, uint64_t *v, size_t n, F f) {
+    const plasship_comm *cm = commOf(ctx);
+    if (!cm || cm->world == 1 || n == 0) return PLASSHIP_OK;
+    std::vector<uint64_t> all((size_t) cm->world * n);
+    const int rc = commAllgatherHost(ctx, v, all.data(), n * 8);
+    if (rc) return rc;
+    for (size_t i = 0; i < n; i++) { uint64_t x = all[i]; for (int r = 1; r < cm->world; r++) x = f(x, all[(size_t) r * n + i]); v[i] = x; }
+    return PLASSHIP_OK;
+}
+int commAllReduceSumU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allReduceU64(ctx, v, n, [](uint64_t a, uint64_t b) { return a + b; }); }
+int commAllReduceMaxU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allReduceU64(ctx, v, n, [](uint64_t a, uint64_t b) { return a > b ? a : b; }); }
+int commAllReduceMinU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allReduceU64(ctx, v, n, [](uint64_t a, uint64_t b) { return a < b ? a : b; }); }
+
+int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *sendCount, size_t recordBytes, DevBuf &recv,
+                         uint64_t *recvTotal, uint64_t slackRecords) {
+    const plasship_comm *cm = commOf(ctx);
+    if (!cm) { setError("sharded run: no communicator"); return PLASSHIP_ERR_ARG; }
+    const int W = cm->world;
+    // counts first: row r of the gathered matrix = what rank r sends to everybody
+    std::vector<uint64_t> mine(sendCount, sendCount + W), all((size_t) W * W);
+    int rc = commAllgatherHost(ctx, mine.data(), all.data(), (uint64_t) W * 8);
+    if (rc) return rc;
+    std::vector<uint64_t> sendBytes(W), recvBytes(W); uint64_t tot = 0;
+    for (int r = 0; r < W; r++) { sendBytes[r] = sendCount[r] * recordBytes; const uint64_t c = all[(size_t) r * W + cm->rank]; recvBytes[r] = c * recordBytes; tot += c; }
+    if (recv.alloc(std::max<uint64_t>(tot + slackRecords, 1) * recordBytes) != hipSuccess) { setError("sharded run: out of device memory for the receive buffer"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (cm->alltoallv_dev(cm->user, dSend, sendBytes.data(), recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's alltoallv_dev failed"); return PLASSHIP_ERR_DEVICE; }
+    *recvTotal = tot;
+    return PLASSHIP_OK;
+}
+
+int commAllgathervBytes(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, std::vector<uint64_t> &recvBytes) {
+    const plasship_comm *cm = commOf(ctx);
+    if (!cm) { setError("sharded run: no communicator"); return PLASSHIP_ERR_ARG; }
+    const int W = cm->world;
+    recvBytes.assign(W, 0);
+    int rc = commAllgatherHost(ctx, &sendBytes, recvBytes.data(), 8);
+    if (rc) return rc;
+    uint64_t tot = 0; for (int r = 0; r < W; r++) tot += recvBytes[r];
+    if (recv.alloc(tot + 64) != hipSuccess) { setError("sharded run: out of device memory for the gather buffer"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (cm->allgatherv_dev(cm->user, dSend, sendBytes, recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's allgatherv_dev failed"); return PLASSHIP_ERR_DEVICE; }
+    return PLASSHIP_OK;
+}
+
+}  // namespace plasship

@@ -84,6 +84,9 @@ struct plasship_ctx {
     plasship::DevBuf d_ambKeys, d_ambVals;
     plasship::DevBuf d_cmpCache;        // memo of the nucleotide comparator's posterior classes (assemble.hip, nuclLess)
     uint32_t ambSlots = 0;              // power of two, 0 = no table yet
+    // one read set sharded over several GPUs (plasship_ctx_set_comm); world == 1 and hasComm == false: single GPU
+    bool hasComm = false;
+    plasship_comm comm = {};
 };
 
 struct plasship_seqdb {
@@ -125,6 +128,19 @@ struct plasship_alns {
 };
 
 namespace plasship {
+// ---- sharded operation (comm.hip): thin wrappers over the caller's collectives; all of them synchronise the stream first ----
+inline const plasship_comm *commOf(const plasship_ctx *ctx) { return ctx->hasComm ? &ctx->comm : nullptr; }
+// first id owned by rank r of `world` when n ids are split into contiguous ranges: ceil(r*n/world)
+inline uint64_t ownedBegin(uint64_t n, int r, int world) { return ((uint64_t) r * n + (uint64_t) world - 1) / (uint64_t) world; }
+int commAllgatherHost(plasship_ctx *ctx, const void *send, void *recv, uint64_t bytesPerRank);
+int commAllReduceSumU64(plasship_ctx *ctx, uint64_t *v, size_t n);       // in place
+int commAllReduceMaxU64(plasship_ctx *ctx, uint64_t *v, size_t n);
+int commAllReduceMinU64(plasship_ctx *ctx, uint64_t *v, size_t n);
+// all-to-all(v) of fixed-size records laid out by destination; allocates `recv` (capacity (total + slackRecords) records)
+int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *sendCount, size_t recordBytes, DevBuf &recv,
+                         uint64_t *recvTotal, uint64_t slackRecords);
+// all-gather(v) of bytes; allocates `recv`; recvBytes[world] / recvOff[world+1] filled
+int commAllgathervBytes(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, std::vector<uint64_t> &recvBytes);
 // sets *differ when two key arrays (device, n entries) are not identical
 int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, size_t n, bool *differ);
 }

@@ -95,7 +95,9 @@ struct ExtractArgs {
     // regular launch after the one-thread-per-sequence kernel: only the queued ids (count read on the device)
     const uint32_t *waveList; const uint32_t *waveCount;
     unsigned long long *kstats;     // [2] residues, [3] records handled by the wave-per-sequence kernel (incl. its HBM-scratch launch)
-    uint64_t slotBias;              // subtracted from every slot offset (re-extraction of one sequence into a scratch array)
+    uint64_t slotBias;              // subtracted from every slot offset (re-extraction of one sequence into a scratch array;
+                                    // sharded run: first slot of this rank's id range)
+    uint32_t idLo, idHi;            // regular launch without a wave list: ids [idLo, idHi) (sharded run: this rank's share)
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -240,8 +242,8 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
     unsigned long long stRes = 0, stRec = 0;
     for (int i = 0; i < lane; i++) pow31 *= 31;
 
-    const uint32_t nWork = FALLBACK ? a.nIds : (a.waveList ? *a.waveCount : a.s.n);
-    auto idAt = [&](uint32_t w) { return a.waveList ? a.waveList[w] : w; };
+    const uint32_t nWork = FALLBACK ? a.nIds : (a.waveList ? *a.waveCount : (a.idHi - a.idLo));
+    auto idAt = [&](uint32_t w) { return a.waveList ? a.waveList[w] : (a.idLo + w); };
     // software pipeline over sequences (regular launch): the index entry of sequence w+2*grid and the first 128 bytes
     // of sequence w+grid are in flight while sequence w is processed, so a short read never waits on HBM latency
     struct Meta { uint32_t L; uint64_t off, slot, slot1; };
@@ -529,6 +531,7 @@ struct ShortArgs {
     uint64_t base, top, inv; int tz;     // alphabet base; base^(k-1); exact division by base = (x >> tz) * inv
     uint32_t *waveList, *waveCount;
     unsigned long long *kstats;          // [0] residues, [1] records handled by this kernel
+    uint32_t idLo, idHi; uint64_t slotBias;   // ids [idLo, idHi) (sharded run: this rank's share), records at arr[slotOff[id] - slotBias]
 };
 
 template <bool LONG>
@@ -544,9 +547,9 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
     unsigned short *mySet = sSet + lane * 64;
     const int k = a.k;
     unsigned long long stRes = 0, stRec = 0;
-    for (uint32_t b0 = blockIdx.x * 64; b0 < a.s.n; b0 += gridDim.x * 64) {
+    for (uint32_t b0 = a.idLo + blockIdx.x * 64; b0 < a.idHi; b0 += gridDim.x * 64) {
         const uint32_t id = b0 + lane;
-        const bool active = id < a.s.n;
+        const bool active = id < a.idHi;
         bool toWave = false;
         if (active) {
             const uint32_t L = a.s.len[id];
@@ -555,8 +558,8 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
             if (L > SHORT_MAXL || (size_t) nWin > consideredRaw) toWave = true;
             else {
                 const char *base = a.s.data + a.s.off[id];
-                const uint64_t slot = a.slotOff[id];
-                const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - slot);
+                const uint64_t slot = a.slotOff[id] - a.slotBias;
+                const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
                 if (a.ignoreMulti) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 8; i++) q[i] = z; }
                 uint64_t idx = 0, seqHash = 0, fifoLo = 0, fifoHi = 0;   // fifo: the k codes of the current window, 8 bits each
                 uint64_t pw = 1;
@@ -629,14 +632,14 @@ __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t
 // =====================================================================================================
 // 3. segmented, unstable bucket partition (used for the hash grouping and for the rep-range sort)
 // =====================================================================================================
-enum { KEY_HASH = 0, KEY_RANGE = 1 };
-template <bool NUCL, int MODE> __device__ __forceinline__ uint64_t bucketKey(uint64_t kmerField, int rangeBits) {
-    if (MODE == KEY_HASH) {
-        const uint64_t K = NUCL ? (kmerField & ~BIT63) : kmerField;
-        uint64_t x = K * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
-        return x;
-    }
-    return (kmerField & ~BIT63) << (64 - rangeBits);    // left-align the rep id: top bits = id range
+// KEY_OWNER_HASH / KEY_OWNER_REP (sharded run): bucket = the rank that owns the record — the k-mer's hash bucket (low bits of
+// the same mix whose top bits pick the grouping bucket, so the owner's buckets stay uniformly filled) or the representative's
+// id range
+enum { KEY_HASH = 0, KEY_RANGE = 1, KEY_OWNER_HASH = 2, KEY_OWNER_REP = 3 };
+template <bool NUCL> __device__ __forceinline__ uint64_t kmerMix(uint64_t kmerField) {
+    const uint64_t K = NUCL ? (kmerField & ~BIT63) : kmerField;
+    uint64_t x = K * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
+    return x;
 }
 
 constexpr int PT_BLOCK = 256;
@@ -655,7 +658,15 @@ struct PartArgs {
     // optional: histogram of the records by k-mer VALUE (VH_BINS monotone bins of the sort-#1 key): bounds the sort-#1 rank
     // of any record without sorting, which is all the stale-record check (section 7) needs most of the time
     uint32_t *valueHist; int valueShift;
+    uint64_t repBase;               // KEY_RANGE: subtracted from the rep id (sharded run: first rep this rank owns)
+    uint32_t ownerW; uint64_t ownerN;   // KEY_OWNER_*: number of ranks; KEY_OWNER_REP: number of sequences
 };
+template <bool NUCL, int MODE> __device__ __forceinline__ uint32_t bucketOf(const PartArgs &a, uint64_t kmerField, uint32_t nb) {
+    if (MODE == KEY_HASH) return (uint32_t) (kmerMix<NUCL>(kmerField) >> a.shift) & (nb - 1);
+    if (MODE == KEY_RANGE) return (uint32_t) ((((kmerField & ~BIT63) - a.repBase) << (64 - a.rangeBits)) >> a.shift) & (nb - 1);   // left-aligned rep id: top bits = id range
+    if (MODE == KEY_OWNER_HASH) return (uint32_t) (((kmerMix<NUCL>(kmerField) & 0xFFFFFFFFull) * (uint64_t) a.ownerW) >> 32);
+    return (uint32_t) (((kmerField & ~BIT63) * (uint64_t) a.ownerW) / a.ownerN);              // owner r <=> id in [ceil(r n / W), ceil((r+1) n / W))
+}
 constexpr uint32_t VH_BINS = 4096;
 template <bool NUCL> __device__ __host__ __forceinline__ uint32_t valueBin(uint64_t kmerField, int shift) {
     const uint64_t v = NUCL ? (kmerField & ~BIT63) : kmerField;       // sort #1 compares (kmer | bit 63) for nucleotides
@@ -684,7 +695,7 @@ __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
         if (i < cnt) {
             const R r = in[s0 + i];
             if (a.dropSentinels && isSentinel(r)) continue;
-            const uint32_t b = (uint32_t) (bucketKey<NUCL, MODE>(r.kmer, a.rangeBits) >> a.shift) & (nb - 1);
+            const uint32_t b = bucketOf<NUCL, MODE>(a, r.kmer, nb);
             atomicAdd(&sh[b], 1u);
             if (a.valueHist) atomicAdd(&shv[valueBin<NUCL>(r.kmer, a.valueShift)], 1u);
             if (NUCL && a.minKey) mn = min(mn, (unsigned long long) (r.kmer | BIT63));
@@ -725,7 +736,7 @@ __global__ __launch_bounds__(PT_BLOCK) void partScatterKernel(PartArgs a) {
         if (i < cnt) {
             recs[it] = in[s0 + i];
             if (!(a.dropSentinels && isSentinel(recs[it]))) {
-                const uint32_t b = (uint32_t) (bucketKey<NUCL, MODE>(recs[it].kmer, a.rangeBits) >> a.shift) & (nb - 1);
+                const uint32_t b = bucketOf<NUCL, MODE>(a, recs[it].kmer, nb);
                 br[it] = (b << 16) | atomicAdd(&sh[b], 1u);
             }
         }
@@ -924,7 +935,7 @@ struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag;
 template <bool NUCL, bool LONG>
 __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void *outTriples, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
                                                           unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
-                                                          uint32_t *__restrict__ uniqueCount, int localBits, int idBits) {
+                                                          uint32_t *__restrict__ uniqueCount, int localBits, int idBits, uint64_t repBase) {
     typedef Rec<LONG> R;
     __shared__ unsigned long long hKey[AGG_HT];
     __shared__ uint32_t hVal[AGG_HT];
@@ -939,7 +950,7 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
         const uint64_t s0 = bucketStart[b], s1 = bucketStart[b + 1];
         const uint64_t cnt = s1 - s0;
         if (cnt == 0) { if (threadIdx.x == 0) uniqueCount[b] = 0; continue; }
-        const uint64_t baseRep = (uint64_t) b << localBits;
+        const uint64_t baseRep = repBase + ((uint64_t) b << localBits);     // repBase: first rep of this rank's range (sharded run), else 0
         auto decode = [&](unsigned long long key, uint32_t val) {
             Triple t;
             t.diag = (int32_t) ((int64_t) (key & ((1ULL << DB) - 1)) - DiagPack<LONG>::BIAS);
@@ -1100,8 +1111,10 @@ __global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__rest
 // 6. best diagonal per (rep, target) run (writeKmerMatcherResult, kmermatcher.cpp:835-923) over weighted triples
 // =====================================================================================================
 template <bool NUCL>
-__global__ void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, CandHit *__restrict__ tmpHits, uint32_t *__restrict__ emit,
+__global__ void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, uint64_t nScan, CandHit *__restrict__ tmpHits, uint32_t *__restrict__ emit,
                                  uint32_t *__restrict__ perRep) {
+    // h[n .. nScan): what follows this rank's triples in the global (rep, target, diagonal) order as far as the last run's scan
+    // can reach (sharded run: the head of the next ranks' triples and the stale records; nScan == n otherwise)
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
         const Triple r = h[i];
         bool head = (i == 0);
@@ -1116,7 +1129,7 @@ __global__ void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, CandH
             // next rep starts with the same target (Appendix A.3) — reproduced (a run of equal diagonals then
             // continues across the boundary); it can also run past the compaction point into stale sort-#1
             // records (probability ~1/N per run) — not reproduced.
-            for (uint64_t j = i; j < n; j++) {
+            for (uint64_t j = i; j < nScan; j++) {
                 const Triple x = h[j];
                 if (x.target != targetId) break;
                 const uint64_t c = x.cnt & 0x7FFFFFFFu;
@@ -1173,12 +1186,13 @@ __global__ void fillU32Kernel(uint32_t *p, uint32_t v, uint64_t n) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) p[i] = v;
 }
 __global__ void placeHitsKernel(const CandHit *__restrict__ tmpHits, const uint32_t *__restrict__ emit, const uint64_t *__restrict__ epos,
-                                uint64_t n, CandHit *__restrict__ hits) {
+                                uint64_t n, uint32_t qLo, CandHit *__restrict__ hits) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
-        if (emit[i]) { const CandHit c = tmpHits[i]; hits[epos[i] + (uint64_t) c.query + 1] = c; }
+        if (emit[i]) { const CandHit c = tmpHits[i]; hits[epos[i] + (uint64_t) (c.query - qLo) + 1] = c; }      // self lines of queries qLo..query come first
 }
-__global__ void placeSelfKernel(const uint64_t *__restrict__ qoff, uint32_t nq, CandHit *__restrict__ hits) {
-    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += gridDim.x * blockDim.x) {
+// queries [qLo, qHi) have a self line (all of them; sharded run: the ones this rank owns)
+__global__ void placeSelfKernel(const uint64_t *__restrict__ qoff, uint32_t qLo, uint32_t qHi, CandHit *__restrict__ hits) {
+    for (uint32_t q = qLo + blockIdx.x * blockDim.x + threadIdx.x; q < qHi; q += gridDim.x * blockDim.x) {
         CandHit c; c.target = q; c.prefScore = 0; c.diag16 = 0; c.query = q;
         hits[qoff[q]] = c;
     }
@@ -1211,6 +1225,20 @@ __global__ void lastRunInfoKernel(const unsigned long long *__restrict__ maxRT, 
     if (t < n) { out[1] = slotOff[t]; out[2] = slotOff[t + 1]; out[3] = len[t]; } else { out[1] = out[2] = out[3] = 0; }
 }
 
+// sharded run: id ranges with equal shares of the k-mer record slots.  out[r] = first id of rank r (r = 0..W), out[W+1+r] = its slot
+__global__ void splitIdsKernel(const uint64_t *__restrict__ slotOff, uint32_t n, int W, uint64_t *__restrict__ out) {
+    const uint64_t total = slotOff[n];
+    for (int r = threadIdx.x; r <= W; r += blockDim.x) {
+        uint32_t lo = 0, hi = n;
+        if (r == W) lo = n;
+        else {
+            const uint64_t want = (uint64_t) (((unsigned __int128) total * (unsigned) r) / (unsigned) W);
+            while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (slotOff[mid] < want) lo = mid + 1; else hi = mid; }
+        }
+        out[r] = lo; out[W + 1 + r] = slotOff[lo];
+    }
+}
+
 template <bool NUCL, bool LONG>
 int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
                   plasship_kmermatch_stats *stats) {
@@ -1220,6 +1248,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const int k = par->kmer_size;
     Timer tm{ctx, 0};
     float msExtract = 0, msSort1 = 0, msGroup = 0, msSort2 = 0, msReduce = 0;
+    // sharded run (plasship_ctx_set_comm): this rank extracts the sequences [sLo, sHi), owns the k-mer hash buckets that map to
+    // it, and owns the representatives / queries [repBase, repBase + ownedN)
+    const plasship_comm *cm = commOf(ctx);
+    const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
+    const uint64_t repBase = ownedBegin(N, rk, W), ownedN = ownedBegin(N, rk + 1, W) - repBase;
 
     // ---- slot bounds + offsets ----
     DevBuf dBound, dSlotOff, dScanTmp;
@@ -1231,10 +1264,22 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (N) hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
     if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t total = 0;
+    uint32_t sLo = 0, sHi = N; uint64_t slotBias = 0;
+    if (cm) {
+        DevBuf dSplit; std::vector<uint64_t> hSplit(2 * (size_t) W + 2);
+        if (dSplit.alloc(hSplit.size() * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(splitIdsKernel, dim3(1), dim3(256), 0, st, dSlotOff.as<uint64_t>(), N, W, dSplit.as<uint64_t>());
+        PH_COPY_SYNC(st, hSplit.data(), dSplit.p, hSplit.size() * 8, hipMemcpyDeviceToHost);
+        sLo = (uint32_t) hSplit[rk]; sHi = (uint32_t) hSplit[rk + 1]; slotBias = hSplit[W + 1 + rk];
+        total = hSplit[W + 1 + rk + 1] - slotBias;              // slots of this rank's share
+    } else {
     PH_CHECK(hipMemcpyAsync(&total, dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
+    }
+    const uint32_t nMine = sHi - sLo;
 
     DevBuf dA, dB;   // ping-pong record arrays
+    DevBuf dRxA, dRxB, dRxC, dRxD;   // sharded run: what the two exchanges deliver (and their ping-pong partners)
     if (dA.alloc(std::max<uint64_t>(total, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(total, 1) * sizeof(R)) != hipSuccess) {
         setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE;
     }
@@ -1251,6 +1296,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     { uint64_t p = 1; for (int i = 0; i < 24; i++) { ea.powers[i] = p; p *= (uint64_t) (alph - 1); } }
     ea.k = k; ea.xCode = map[(int) 'X']; ea.kps = par->kmers_per_seq; ea.ignoreMulti = par->ignore_multi_kmer; ea.scale = par->kmers_per_seq_scale;
     ea.seed = (uint64_t) par->hash_shift; ea.overflowIds = dOvIds.as<uint32_t>(); ea.overflowCount = dOvCnt.as<uint32_t>();
+    ea.idLo = sLo; ea.idHi = sHi; ea.slotBias = slotBias;
     // candidate k-mers per sequence held in LDS.  128 covers every protein sequence (59 considered k-mers) and every
     // nucleotide sequence up to ~690 nt (59 + 0.1 L); the 1024-candidate instantiation (35 KB of LDS, one wavefront per SIMD)
     // only sees the longer nucleotide contigs, queued by the first launch; what does not fit there either goes to the
@@ -1262,26 +1308,27 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemsetAsync(dKStats.p, 0, 32, st));
     ea.kstats = dKStats.as<unsigned long long>();
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
-    if (!NUCL && k <= 16 && N) {
+    if (!NUCL && k <= 16 && nMine) {
         // short sequences: one thread each; everything else is queued for the wave-per-sequence kernel
         ShortArgs sa; memset(&sa, 0, sizeof(sa));
         sa.s = ea.s; sa.slotOff = ea.slotOff; sa.arr = ea.arr; sa.map = ea.map; sa.k = k; sa.xCode = ea.xCode; sa.kps = ea.kps; sa.ignoreMulti = ea.ignoreMulti;
         sa.scale = ea.scale; sa.seed = ea.seed; sa.base = (uint64_t) (alph - 1); sa.top = ea.powers[k - 1];
         { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
         sa.waveList = dWaveList.as<uint32_t>(); sa.waveCount = dWaveCount.as<uint32_t>(); sa.kstats = dKStats.as<unsigned long long>();
-        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((N + 63) / 64, (uint32_t) ctx->numCU * 20)), dim3(64), 0, st, sa);
+        sa.idLo = sLo; sa.idHi = sHi; sa.slotBias = slotBias;
+        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * 20)), dim3(64), 0, st, sa);
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    if (N) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
+    if (nMine) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
     DevBuf dOv2Ids, dOv2Cnt;
-    if (CAP2 && N) {
+    if (CAP2 && nMine) {
         if (dOv2Ids.alloc(((size_t) N + 1) * 4) != hipSuccess || dOv2Cnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         PH_CHECK(hipMemsetAsync(dOv2Cnt.p, 0, 4, st));
         ExtractArgs e2 = ea; e2.waveList = dOvIds.as<uint32_t>(); e2.waveCount = dOvCnt.as<uint32_t>();
         e2.overflowIds = dOv2Ids.as<uint32_t>(); e2.overflowCount = dOv2Cnt.as<uint32_t>();
-        hipLaunchKernelGGL((extractKernel<NUCL, LONG, (CAP2 ? CAP2 : 128), false>), dim3(std::min<uint32_t>(N, (uint32_t) ctx->numCU * 4)), dim3(64), 0, st, e2);
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, (CAP2 ? CAP2 : 128), false>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * 4)), dim3(64), 0, st, e2);
         std::swap(dOvIds.p, dOv2Ids.p); std::swap(dOvCnt.p, dOv2Cnt.p);       // the HBM-scratch launch below takes what is left
     }
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
@@ -1312,35 +1359,73 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
 
     // ---- hash partition (replaces sort #1) ----
     tm.start(0);
-    const int totalBits = std::max(0, ceilLog2((total + 1535) / 1536));        // ~1000-1500 records per final bucket: the group kernel pays a fixed
+    // value histogram for the stale-record check: bins of the k-mer value (real k-mers need keyBits bits)
+    DevBuf dVHist, dMinKey, dSeg0Start, dSeg0Cnt;
+    if (dVHist.alloc(VH_BINS * 4) != hipSuccess || dMinKey.alloc(8) != hipSuccess || dSeg0Start.alloc(8) != hipSuccess || dSeg0Cnt.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dVHist.p, 0, VH_BINS * 4, st));
+    PH_CHECK(hipMemsetAsync(dMinKey.p, 0xFF, 8, st));
+    { uint64_t z = 0; PH_CHECK(hipMemcpyAsync(dSeg0Start.p, &z, 8, hipMemcpyHostToDevice, st)); PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &total, 8, hipMemcpyHostToDevice, st)); }
+    int keyBits = 0;
+    if (NUCL) keyBits = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
+    const int valueShift = std::max(0, keyBits - 12);
+    void *bufA = dA.p, *bufB = dB.p;        // level 1 reads bufA (partTotal slots), writes bufB
+    uint64_t partTotal = total;
+    if (cm) {
+        // exchange 1: records -> owner of the k-mer's hash bucket.  One partition pass by owner (it also drops the sentinels
+        // and takes the value histogram / minimum key the single-GPU level 1 takes), then an all-to-all(v) of the W runs.
+        const int ob = ceilLog2((uint64_t) W); const uint32_t nbO = 1u << ob;
+        DevBuf dCntO, dStartO, dCurO;
+        if (dCntO.alloc((size_t) nbO * 4) != hipSuccess || dStartO.alloc(((size_t) nbO + 1) * 8) != hipSuccess || dCurO.alloc((size_t) nbO * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemsetAsync(dCntO.p, 0, (size_t) nbO * 4, st));
+        PartArgs po; memset(&po, 0, sizeof(po));
+        po.in = dA.p; po.out = dB.p; po.segStart = dSeg0Start.as<uint64_t>(); po.segCount = dSeg0Cnt.as<uint64_t>(); po.count = dCntO.as<uint32_t>();
+        po.cursor = dCurO.as<unsigned long long>(); po.bits = ob; po.dropSentinels = 1; po.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
+        po.valueHist = dVHist.as<uint32_t>(); po.valueShift = valueShift; po.ownerW = (uint32_t) W; po.ownerN = N;
+        const unsigned tilesO = (unsigned) std::max<uint64_t>(1, (total + PT_TILE - 1) / PT_TILE);
+        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_OWNER_HASH>), dim3(tilesO, 1), dim3(PT_BLOCK), 0, st, po);
+        if (exclusiveScanU32(st, dCntO.as<uint32_t>(), dStartO.as<uint64_t>(), nbO, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(copyU64Kernel, dim3(1), dim3(256), 0, st, dStartO.as<uint64_t>(), dCurO.as<unsigned long long>(), (uint64_t) nbO);
+        po.minKey = nullptr; po.valueHist = nullptr;
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_OWNER_HASH>), dim3(tilesO, 1), dim3(PT_BLOCK), (size_t) 12 << po.bits, st, po);
+        std::vector<uint64_t> hStartO(nbO + 1), sendCount(W);
+        PH_COPY_SYNC(st, hStartO.data(), dStartO.p, ((size_t) nbO + 1) * 8, hipMemcpyDeviceToHost);
+        PH_CHECK(hipGetLastError());
+        for (int r = 0; r < W; r++) sendCount[r] = hStartO[r + 1] - hStartO[r];
+        uint64_t got = 0;
+        int rc = commAlltoallvRecords(ctx, dB.p, sendCount.data(), sizeof(R), dRxA, &got, 0);
+        if (rc) return rc;
+        dA.release(); dB.release();
+        if (dRxB.alloc(std::max<uint64_t>(got, 1) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; }
+        if (NUCL) {              // the globally smallest key (first-run quirk of the group kernel)
+            uint64_t mk = 0; PH_COPY_SYNC(st, &mk, dMinKey.p, 8, hipMemcpyDeviceToHost);
+            rc = commAllReduceMinU64(ctx, &mk, 1); if (rc) return rc;
+            PH_COPY_SYNC(st, dMinKey.p, &mk, 8, hipMemcpyHostToDevice);
+        }
+        bufA = dRxA.p; bufB = dRxB.p; partTotal = got;
+        PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &partTotal, 8, hipMemcpyHostToDevice, st));
+    }
+    const int totalBits = std::max(0, ceilLog2((partTotal + 1535) / 1536));        // ~1000-1500 records per final bucket: the group kernel pays a fixed
                                                                                // number of block barriers per bucket
     // coarse level first: few wide buckets => every tile writes long contiguous runs; the fine level then scatters inside a
     // bucket that fits the L2 / Infinity Cache
     const int b2w = (totalBits > 11) ? 11 : 0;
     const int b1 = std::min(totalBits - b2w, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
     const uint32_t nB1 = 1u << b1, nB = 1u << (b1 + b2);
-    DevBuf dCnt1, dStart1, dCur1, dSeg0Start, dSeg0Cnt, dMinKey, dCnt2, dStart2, dCur2, dSegCnt1;
+    DevBuf dCnt1, dStart1, dCur1, dCnt2, dStart2, dCur2, dSegCnt1;
     if (dCnt1.alloc((size_t) nB1 * 4) != hipSuccess || dStart1.alloc(((size_t) nB1 + 1) * 8) != hipSuccess || dCur1.alloc((size_t) nB1 * 8) != hipSuccess ||
-        dSeg0Start.alloc(8) != hipSuccess || dSeg0Cnt.alloc(8) != hipSuccess || dMinKey.alloc(8) != hipSuccess || dSegCnt1.alloc((size_t) nB1 * 8) != hipSuccess ||
+        dSegCnt1.alloc((size_t) nB1 * 8) != hipSuccess ||
         dCnt2.alloc((size_t) nB * 4) != hipSuccess || dStart2.alloc(((size_t) nB + 1) * 8) != hipSuccess || dCur2.alloc((size_t) nB * 8) != hipSuccess) {
         setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    { uint64_t z = 0; PH_CHECK(hipMemcpyAsync(dSeg0Start.p, &z, 8, hipMemcpyHostToDevice, st)); PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &total, 8, hipMemcpyHostToDevice, st)); }
-    PH_CHECK(hipMemsetAsync(dMinKey.p, 0xFF, 8, st));
     PH_CHECK(hipMemsetAsync(dCnt1.p, 0, (size_t) nB1 * 4, st));
     PartArgs pa; memset(&pa, 0, sizeof(pa));
-    pa.in = dA.p; pa.out = dB.p; pa.segStart = dSeg0Start.as<uint64_t>(); pa.segCount = dSeg0Cnt.as<uint64_t>(); pa.count = dCnt1.as<uint32_t>();
-    pa.cursor = dCur1.as<unsigned long long>(); pa.shift = 64 - b1; pa.bits = b1; pa.rangeBits = 0; pa.dropSentinels = 1; pa.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
+    pa.in = bufA; pa.out = bufB; pa.segStart = dSeg0Start.as<uint64_t>(); pa.segCount = dSeg0Cnt.as<uint64_t>(); pa.count = dCnt1.as<uint32_t>();
+    pa.cursor = dCur1.as<unsigned long long>(); pa.shift = 64 - b1; pa.bits = b1; pa.rangeBits = 0;
+    // the owner pass of a sharded run has already dropped the sentinels and taken the histogram and the minimum key
+    pa.dropSentinels = cm ? 0 : 1; pa.minKey = (NUCL && !cm) ? dMinKey.as<unsigned long long>() : nullptr;
     if (b1 == 0) pa.shift = 63;   // single bucket: (key >> 63) & 0 == 0
-    // value histogram for the stale-record check: bins of the k-mer value (real k-mers need keyBits bits)
-    DevBuf dVHist;
-    if (dVHist.alloc(VH_BINS * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(dVHist.p, 0, VH_BINS * 4, st));
-    int keyBits = 0;
-    if (NUCL) keyBits = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
-    const int valueShift = std::max(0, keyBits - 12);
-    pa.valueHist = dVHist.as<uint32_t>(); pa.valueShift = valueShift;
-    const unsigned tiles0 = (unsigned) std::max<uint64_t>(1, (total + PT_TILE - 1) / PT_TILE);
+    pa.valueHist = cm ? nullptr : dVHist.as<uint32_t>(); pa.valueShift = valueShift;
+    const unsigned tiles0 = (unsigned) std::max<uint64_t>(1, (partTotal + PT_TILE - 1) / PT_TILE);
     hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
     if (exclusiveScanU32(st, dCnt1.as<uint32_t>(), dStart1.as<uint64_t>(), nB1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dCur1.as<unsigned long long>(), (uint64_t) nB1);
@@ -1353,8 +1438,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(hStart1.data(), dStart1.p, ((size_t) nB1 + 1) * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
-    const uint64_t Nk = hStart1[nB1];
-    void *cur = dB.p, *other = dA.p;
+    const uint64_t Nk = hStart1[nB1];          // records on this rank
+    uint64_t NkG = Nk;                         // ... and of the whole run
+    if (cm) { const int rc = commAllReduceSumU64(ctx, &NkG, 1); if (rc) return rc; }
+    void *cur = bufB, *other = bufA;
     const uint64_t *dBucketStart = dStart1.as<uint64_t>();
     if (b2 > 0) {
         uint64_t maxSeg = 0; for (uint32_t i = 0; i < nB1; i++) maxSeg = std::max(maxSeg, hStart1[i + 1] - hStart1[i]);
@@ -1403,13 +1490,26 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     std::vector<uint64_t> hArena(gGrid); uint64_t Nm = 0, maxArena = 0;
     for (uint32_t j = 0; j < gGrid; j++) { hArena[j] = hBStart[(size_t) j * bpb]; Nm += hOutCnt[j]; maxArena = std::max(maxArena, hOutCnt[j]); }
     PH_CHECK(hipMemcpyAsync(dArenaStart.p, hArena.data(), (size_t) gGrid * 8, hipMemcpyHostToDevice, st));
+    const uint64_t NmLocal = Nm;               // grouped records this rank produced
+    std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
+    if (cm) {
+        // the stale-record check below is a property of the WHOLE run: N_m, N_k, the last (rep, target) run and the value
+        // histogram are reduced over the ranks; every rank then takes the same decisions (and the same collectives)
+        uint64_t mx = hLastRun[0];
+        int rc = commAllReduceSumU64(ctx, &Nm, 1); if (rc) return rc;
+        rc = commAllReduceMaxU64(ctx, &mx, 1); if (rc) return rc;
+        rc = commAllReduceSumU64(ctx, hVHistG.data(), hVHistG.size()); if (rc) return rc;
+        PH_CHECK(hipMemcpyAsync(dMaxRT.p, &mx, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
+        PH_COPY_SYNC(st, hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost);
+    }
     std::swap(cur, other);   // cur = grouped records, scattered in arenas; other = the N_k hash-bucketed records (dense)
     msGroup = tm.stop(1);
 
     // ---- stale records behind the compaction point that continue the last run (see section 7 above) ----
     std::vector<int64_t> stalePos;          // original k-mer positions of the sort-#1 records of rank N_m, N_m+1, … that belong to T
     uint32_t staleT = 0;
-    if (Nm > 0 && Nm < Nk) {
+    if (Nm > 0 && Nm < NkG) {
         const unsigned long long maxRT = hLastRun[0];
         staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
         const uint64_t so[2] = {hLastRun[1], hLastRun[2]}; const uint32_t tLen = (uint32_t) hLastRun[3];
@@ -1438,7 +1538,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         bool mayHit = false;
         if (m) {
             std::vector<uint64_t> cum(VH_BINS + 1, 0);
-            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + hVHist[b];
+            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + hVHistG[b];
             for (uint32_t j = 0; j < m && !mayHit; j++) { const uint32_t b = valueBin<NUCL>(trec[j].kmer, valueShift); mayHit = Nm >= cum[b] && Nm < cum[b + 1]; }
         }
         if (m && mayHit) {
@@ -1447,6 +1547,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(hipStreamSynchronize(st));
+            if (cm) {            // every rank counted the records of its own buckets: the sort-#1 ranks are the sums
+                static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+                const int rc = commAllReduceSumU64(ctx, reinterpret_cast<uint64_t *>(diff.data()), diff.size()); if (rc) return rc;
+            }
             unsigned long long rank = 0, expect = Nm;
             for (uint32_t j = 0; j < m; j++) {
                 rank += diff[j];                         // records strictly before trec[j] in sort-#1 order
@@ -1458,10 +1562,44 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
 
     // ---- sort #2: range partition by rep id + local bitonic sort ----
     tm.start(0);
-    const int repBits = std::max(1, ceilLog2((uint64_t) N));
-    const int wantBits = std::max(0, ceilLog2((Nm + 511) / 512));
+    const uint64_t *segStartP = dArenaStart.as<uint64_t>(), *segCountP = dOutCnt.as<uint64_t>();   // where the grouped records are
+    uint32_t nSeg = gGrid; uint64_t maxSeg1 = maxArena, NmHere = NmLocal;
+    const uint64_t haloSlack = 1u << 16;       // room behind the triples for what the last run's scan reaches on later ranks
+    if (cm) {
+        // exchange 2: grouped (rep, member, diagonal) records -> owner of the rep.  Same recipe: one partition pass by owner
+        // straight out of the group kernel's arenas, then an all-to-all(v).
+        const int ob = ceilLog2((uint64_t) W); const uint32_t nbO = 1u << ob;
+        DevBuf dCntO, dStartO, dCurO;
+        if (dCntO.alloc((size_t) nbO * 4) != hipSuccess || dStartO.alloc(((size_t) nbO + 1) * 8) != hipSuccess || dCurO.alloc((size_t) nbO * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemsetAsync(dCntO.p, 0, (size_t) nbO * 4, st));
+        PartArgs po; memset(&po, 0, sizeof(po));
+        po.in = cur; po.out = other; po.segStart = segStartP; po.segCount = segCountP; po.count = dCntO.as<uint32_t>();
+        po.cursor = dCurO.as<unsigned long long>(); po.bits = ob; po.sharedTable = 1; po.ownerW = (uint32_t) W; po.ownerN = std::max<uint64_t>(N, 1);
+        const unsigned tilesO = (unsigned) std::max<uint64_t>(1, (maxArena + PT_TILE - 1) / PT_TILE);
+        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_OWNER_REP>), dim3(tilesO, gGrid), dim3(PT_BLOCK), 0, st, po);
+        if (exclusiveScanU32(st, dCntO.as<uint32_t>(), dStartO.as<uint64_t>(), nbO, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(copyU64Kernel, dim3(1), dim3(256), 0, st, dStartO.as<uint64_t>(), dCurO.as<unsigned long long>(), (uint64_t) nbO);
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_OWNER_REP>), dim3(tilesO, gGrid), dim3(PT_BLOCK), (size_t) 12 << po.bits, st, po);
+        std::vector<uint64_t> hStartO(nbO + 1), sendCount(W);
+        PH_COPY_SYNC(st, hStartO.data(), dStartO.p, ((size_t) nbO + 1) * 8, hipMemcpyDeviceToHost);
+        PH_CHECK(hipGetLastError());
+        for (int r = 0; r < W; r++) sendCount[r] = hStartO[r + 1] - hStartO[r];
+        uint64_t got = 0;
+        const int rc = commAlltoallvRecords(ctx, other, sendCount.data(), sizeof(R), dRxC, &got, haloSlack);
+        if (rc) return rc;
+        dRxA.release(); dRxB.release();
+        if (dRxD.alloc((got + haloSlack) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; }
+        cur = dRxC.p; other = dRxD.p;
+        NmHere = got; maxSeg1 = got; nSeg = 1;
+        PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &NmHere, 8, hipMemcpyHostToDevice, st));
+        segStartP = dSeg0Start.as<uint64_t>(); segCountP = dSeg0Cnt.as<uint64_t>();
+    }
+    // rep ids are sorted relative to the first rep this rank owns (0 on a single GPU); targets are ids of the whole DB
+    const int idBits = std::max(1, ceilLog2((uint64_t) N));
+    const int repBits = cm ? std::max(1, ceilLog2(std::max<uint64_t>(ownedN, 1))) : idBits;
+    const int wantBits = std::max(0, ceilLog2((NmHere + 511) / 512));
     // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
-    const int allowedLocal = 62 - repBits - DiagPack<LONG>::BITS;
+    const int allowedLocal = 62 - idBits - DiagPack<LONG>::BITS;
     const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
     if (sBits > 22) { setError("kmermatch: too many sequences for the packed rep-sort key"); return PLASSHIP_ERR_UNSUPPORTED; }
     const int s2w = (sBits > 11) ? 11 : 0;
@@ -1478,14 +1616,15 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         // accumulate into one bucket table.
         PH_CHECK(hipMemsetAsync(dRC1.p, 0, (size_t) nS1 * 4, st));
         PartArgs p1; memset(&p1, 0, sizeof(p1));
-        p1.in = cur; p1.out = other; p1.segStart = dArenaStart.as<uint64_t>(); p1.segCount = dOutCnt.as<uint64_t>(); p1.count = dRC1.as<uint32_t>();
+        p1.in = cur; p1.out = other; p1.segStart = segStartP; p1.segCount = segCountP; p1.count = dRC1.as<uint32_t>();
         p1.cursor = dRCur1.as<unsigned long long>(); p1.shift = 64 - s1; p1.bits = s1; p1.rangeBits = repBits; p1.dropSentinels = 0; p1.sharedTable = 1;
+        p1.repBase = cm ? repBase : 0;
         if (s1 == 0) p1.shift = 63;
-        const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxArena + PT_TILE - 1) / PT_TILE);
-        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, gGrid), dim3(PT_BLOCK), 0, st, p1);
+        const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxSeg1 + PT_TILE - 1) / PT_TILE);
+        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, nSeg), dim3(PT_BLOCK), 0, st, p1);
         if (exclusiveScanU32(st, dRC1.as<uint32_t>(), dRS1.as<uint64_t>(), nS1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nS1, 256, 64)), dim3(256), 0, st, dRS1.as<uint64_t>(), dRCur1.as<unsigned long long>(), (uint64_t) nS1);
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, gGrid), dim3(PT_BLOCK), (size_t) 12 << p1.bits, st, p1);
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, nSeg), dim3(PT_BLOCK), (size_t) 12 << p1.bits, st, p1);
         std::swap(cur, other);
         std::vector<uint64_t> hS1(nS1 + 1);
         PH_CHECK(hipMemcpyAsync(hS1.data(), dRS1.p, ((size_t) nS1 + 1) * 8, hipMemcpyDeviceToHost, st));
@@ -1498,7 +1637,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             PH_CHECK(hipMemsetAsync(dRC2.p, 0, (size_t) nS * 4, st));
             PartArgs p2; memset(&p2, 0, sizeof(p2));
             p2.in = cur; p2.out = other; p2.segStart = dRS1.as<uint64_t>(); p2.segCount = dRSegCnt.as<uint64_t>(); p2.count = dRC2.as<uint32_t>();
-            p2.cursor = dRCur2.as<unsigned long long>(); p2.shift = 64 - s1 - s2; p2.bits = s2; p2.rangeBits = repBits; p2.dropSentinels = 0;
+            p2.cursor = dRCur2.as<unsigned long long>(); p2.shift = 64 - s1 - s2; p2.bits = s2; p2.rangeBits = repBits; p2.dropSentinels = 0; p2.repBase = cm ? repBase : 0;
             const unsigned tiles2 = (unsigned) std::max<uint64_t>(1, (maxSeg + PT_TILE - 1) / PT_TILE);
             hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), 0, st, p2);
             if (exclusiveScanU32(st, dRC2.as<uint32_t>(), dRS2.as<uint64_t>(), nS, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
@@ -1527,7 +1666,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     }
     hipLaunchKernelGGL((aggSortKernel<NUCL, LONG>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * 16)), dim3(LS_BLOCK), 0, st,
                        (const void *) cur, other, dSortStart, nSortBuckets, dBigScratch.as<unsigned long long>(), dBigOff.as<uint64_t>(),
-                       dUnique.as<uint32_t>(), repBits - sBits, repBits);
+                       dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0));
     DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
     if (dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSortBuckets, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
@@ -1545,8 +1684,62 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         dEpos.alloc((nTriples + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     DevBuf dScanTmp2; const size_t scanTmp2Bytes = exclusiveScanTmpBytes(std::max<uint64_t>(nTriples, N) + 2);
     if (dScanTmp2.alloc(scanTmp2Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t nHalo = 0;
+    if (cm) {
+        // The reference's run scan tests only the target id (Appendix A.3): the last run of this rank continues into the
+        // triples of the next ranks while they carry the same target, and behind the last rank into the stale records.
+        // Every rank publishes the head of its triples (the leading ones with one target); each rank appends what its last
+        // run can reach behind its own triples.
+        Triple *dTr = reinterpret_cast<Triple *>(cur);
+        std::vector<Triple> head; uint64_t headCnt = 0;
+        if (nTriples) {
+            uint64_t want = std::min<uint64_t>(nTriples, 1024);
+            for (;;) {
+                head.resize(want);
+                PH_COPY_SYNC(st, head.data(), dTr, want * sizeof(Triple), hipMemcpyDeviceToHost);
+                headCnt = 0; while (headCnt < want && head[headCnt].target == head[0].target) headCnt++;
+                if (headCnt < want || want == nTriples) break;
+                want = std::min<uint64_t>(nTriples, want * 2);
+            }
+            head.resize(headCnt);
+        }
+        Triple last; memset(&last, 0, sizeof(last));
+        if (nTriples) PH_COPY_SYNC(st, &last, dTr + (nTriples - 1), sizeof(Triple), hipMemcpyDeviceToHost);
+        uint64_t hdr[2] = {nTriples, headCnt}; std::vector<uint64_t> hdrs(2 * (size_t) W);
+        int rc = commAllgatherHost(ctx, hdr, hdrs.data(), 16); if (rc) return rc;
+        uint64_t maxHead = 0; for (int r = 0; r < W; r++) maxHead = std::max(maxHead, hdrs[2 * (size_t) r + 1]);
+        std::vector<Triple> heads;
+        if (maxHead) {
+            std::vector<Triple> mine(maxHead); memset(mine.data(), 0, maxHead * sizeof(Triple));
+            std::copy(head.begin(), head.end(), mine.begin());
+            heads.resize(maxHead * (size_t) W);
+            rc = commAllgatherHost(ctx, mine.data(), heads.data(), maxHead * sizeof(Triple)); if (rc) return rc;
+        }
+        if (nTriples) {
+            std::vector<Triple> halo; bool open = true;          // open: the scan has not met another target yet
+            for (int r = rk + 1; r < W && open; r++) {
+                const uint64_t nr = hdrs[2 * (size_t) r], hr = hdrs[2 * (size_t) r + 1];
+                if (nr == 0) continue;
+                const Triple *hp = heads.data() + maxHead * (size_t) r;
+                if (hp[0].target != last.target) { open = false; break; }
+                halo.insert(halo.end(), hp, hp + hr);
+                if (hr < nr) open = false;
+            }
+            if (open && !stalePos.empty() && staleT == last.target) {
+                for (int64_t sp : stalePos) {      // stale records: pos = original k-mer position, kmer field = SIZE_T_MAX (forward)
+                    Triple t; t.rep = 0xFFFFFFFFu; t.target = staleT; t.diag = LONG ? (int32_t) sp : (int32_t) (int16_t) sp; t.cnt = 1u | 0x80000000u;
+                    halo.push_back(t);
+                }
+            }
+            nHalo = halo.size();
+            if (nHalo > haloSlack) { setError("kmermatch: a (rep, target) run continues over more than 65536 records of other ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
+            if (nHalo) PH_COPY_SYNC(st, dTr + nTriples, halo.data(), nHalo * sizeof(Triple), hipMemcpyHostToDevice);
+        }
+        PH_CHECK(hipMemsetAsync(dPerRep.p, 0, ((size_t) N + 1) * 4, st));
+        if (ownedN) hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor(ownedN, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>() + repBase, 1u, ownedN);
+    } else
     hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor((uint64_t) N + 1, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>(), 1u, (uint64_t) N);
-    if (nTriples) hipLaunchKernelGGL((reduceRunsKernel<NUCL>), dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, (const Triple *) cur, nTriples, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
+    if (nTriples) hipLaunchKernelGGL((reduceRunsKernel<NUCL>), dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, (const Triple *) cur, nTriples, nTriples + nHalo, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
     if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     std::unique_ptr<plasship_cands> holder(new plasship_cands());   // released to the caller on success only
     plasship_cands *c = holder.get();
@@ -1556,14 +1749,15 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     uint64_t Nc = 0;
     PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nTriples, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
-    c->nHits = Nc + N; c->nNonSelf = Nc;
+    const uint32_t qLo = cm ? (uint32_t) repBase : 0u, qHi = cm ? (uint32_t) (repBase + ownedN) : N;      // queries with a self line
+    c->nHits = Nc + (qHi - qLo); c->nNonSelf = Nc;
     if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (N) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), N, c->d_hits.as<CandHit>());
-    if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, c->d_hits.as<CandHit>());
+    if (qHi > qLo) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(qHi - qLo, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), qLo, qHi, c->d_hits.as<CandHit>());
+    if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
     msReduce = tm.stop(1);
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
-    if (!stalePos.empty() && nTriples > 0) {
+    if (!stalePos.empty() && nTriples > 0 && !cm) {
         // the runs that end at the very end of the sorted array (the last (rep,T) run, and the T-runs of directly preceding
         // reps whose scan the reference lets run across the rep boundary) continue into the stale records: redo them
         const Triple *dTr = reinterpret_cast<const Triple *>(cur);
@@ -1606,7 +1800,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
     }
     if (stats) {
-        stats->n_kmer_records = Nk; stats->n_grouped = Nm; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
+        // sharded run: records / grouped records of the whole run, candidates of the owned queries
+        stats->n_kmer_records = NkG; stats->n_grouped = Nm; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
         {
             float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
             stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;

@@ -1,0 +1,232 @@
+"""Communicators for ONE read set sharded over several GPUs (include/plasship.h: plasship_comm / plasship_ctx_set_comm).
+
+The library exchanges device buffers through three collectives its caller supplies:
+
+* `TorchComm`  — torch.distributed (backend "nccl" = RCCL over xGMI): what bench.py uses, one process per GPU.
+* `LocalGroup` — an in-process implementation for tests: W contexts on ONE GPU driven by W Python threads; the
+  "exchange" is a device-to-device copy.  It runs exactly the code a multi-GPU run runs (partition by owner,
+  all-to-all(v), halo of the run scan, all-gather of the extended sequences) on a 1-GPU box.
+
+The reference's counterpart is the MPI split of kmermatcher by k-mer hash range
+(lib/mmseqs/src/linclust/kmermatcher.cpp:312,736-778), merged through files.
+"""
+import ctypes as C
+import threading
+
+from . import _lib
+
+_AG_HOST = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64)
+_A2A_DEV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64))
+_AGV_DEV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64))
+
+
+class CommStruct(C.Structure):
+    """struct plasship_comm"""
+    _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p), ("allgather_host", _AG_HOST),
+                ("alltoallv_dev", _A2A_DEV), ("allgatherv_dev", _AGV_DEV)]
+
+
+def owned_range(n, rank, world):
+    """ids [lo, hi) of the queries / representatives rank owns: lo = ceil(rank * n / world)"""
+    return (rank * n + world - 1) // world, ((rank + 1) * n + world - 1) // world
+
+
+class _CommBase:
+    """keeps the ctypes callbacks alive and installs them on a context"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
+        self.error = None
+        self._cbs = (_AG_HOST(self._wrap(self._allgather_host)), _A2A_DEV(self._wrap(self._alltoallv_dev)),
+                     _AGV_DEV(self._wrap(self._allgatherv_dev)))
+        self.struct = CommStruct(rank, world, None, *self._cbs)
+
+    def _wrap(self, fn):
+        def cb(user, *a):
+            try:
+                fn(*a)
+                return 0
+            except BaseException as e:      # never let an exception cross the C boundary
+                self.error = e
+                self._abort()
+                return 1
+        return cb
+
+    def _abort(self):
+        pass
+
+    def install(self, ctx):
+        lib = ctx.lib
+        _lib._check(lib.plasship_ctx_set_comm(ctx.h, C.byref(self.struct)), "plasship_ctx_set_comm")
+        ctx._comm = self            # keep alive as long as the context
+
+    @staticmethod
+    def uninstall(ctx):
+        _lib._check(ctx.lib.plasship_ctx_set_comm(ctx.h, None), "plasship_ctx_set_comm")
+        ctx._comm = None
+
+
+# ---------------------------------------------------------------------------------------------------
+# in-process group: W ranks = W threads, W contexts on one GPU
+# ---------------------------------------------------------------------------------------------------
+class LocalGroup:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.comms = [LocalComm(self, r) for r in range(world)]
+
+    def run(self, fn, contexts):
+        """fn(rank, ctx) on every rank concurrently (communicators installed); returns the list of results"""
+        out = [None] * self.world
+        err = [None] * self.world
+
+        def work(r):
+            try:
+                self.comms[r].ctx = contexts[r]
+                self.comms[r].install(contexts[r])
+                out[r] = fn(r, contexts[r])
+            except BaseException as e:
+                err[r] = e
+                self.barrier.abort()
+            finally:
+                try:
+                    _CommBase.uninstall(contexts[r])
+                except Exception:
+                    pass
+
+        th = [threading.Thread(target=work, args=(r,)) for r in range(self.world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        for r in range(self.world):
+            e = err[r] or self.comms[r].error
+            if e is not None and not isinstance(e, threading.BrokenBarrierError):
+                raise e
+        for e in err:
+            if e is not None:
+                raise e
+        return out
+
+
+class LocalComm(_CommBase):
+    def __init__(self, group, rank):
+        super().__init__(rank, group.world)
+        self.g = group
+        self.ctx = None
+
+    def _abort(self):
+        self.g.barrier.abort()
+
+    def _copy(self, dst, src, n):
+        _lib._check(self.ctx.lib.plasship_ctx_copy_d2d(self.ctx.h, C.c_void_p(dst), C.c_void_p(src), n), "plasship_ctx_copy_d2d")
+
+    def _allgather_host(self, send, recv, nbytes):
+        g = self.g
+        g.slots[self.rank] = C.string_at(send, nbytes)
+        g.barrier.wait()
+        for r in range(self.world):
+            C.memmove(recv + r * nbytes, g.slots[r], nbytes)
+        g.barrier.wait()
+
+    def _alltoallv_dev(self, d_send, send_bytes, d_recv, recv_bytes):
+        g, W = self.g, self.world
+        g.slots[self.rank] = (d_send or 0, [int(send_bytes[i]) for i in range(W)])
+        g.barrier.wait()
+        roff = 0
+        for r in range(W):
+            src, sb = g.slots[r]
+            n = sb[self.rank]
+            if n != int(recv_bytes[r]):
+                raise RuntimeError("all-to-all size mismatch")
+            if n:
+                self._copy(d_recv + roff, src + sum(sb[:self.rank]), n)
+            roff += n
+        g.barrier.wait()           # nobody reuses its send buffer before everybody has read it
+
+    def _allgatherv_dev(self, d_send, nbytes, d_recv, recv_bytes):
+        g, W = self.g, self.world
+        g.slots[self.rank] = (d_send or 0, int(nbytes))
+        g.barrier.wait()
+        roff = 0
+        for r in range(W):
+            src, n = g.slots[r]
+            if n != int(recv_bytes[r]):
+                raise RuntimeError("all-gather size mismatch")
+            if n:
+                self._copy(d_recv + roff, src, n)
+            roff += n
+        g.barrier.wait()
+
+
+# ---------------------------------------------------------------------------------------------------
+# torch.distributed (RCCL): one process per GPU
+# ---------------------------------------------------------------------------------------------------
+class _DevPtr:
+    """zero-copy view of library-owned device memory for torch (CUDA array interface v2)"""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class TorchComm(_CommBase):
+    """collectives over a torch.distributed process group.  device: torch.device of this rank's GPU (None: CPU tensors,
+    only allgather_host works — the gloo tests)."""
+
+    def __init__(self, dist, device=None, group=None):
+        super().__init__(dist.get_rank(group), dist.get_world_size(group))
+        self.dist, self.device, self.group = dist, device, group
+        self.bytes_moved = 0
+
+    def _view(self, ptr, nbytes):
+        import torch
+        if nbytes == 0:
+            return torch.empty(0, dtype=torch.uint8, device=self.device)
+        return torch.as_tensor(_DevPtr(ptr, nbytes), device=self.device)
+
+    def _allgather_host(self, send, recv, nbytes):
+        import torch
+        t = torch.frombuffer(bytearray(C.string_at(send, nbytes)), dtype=torch.uint8)
+        if self.device is not None:
+            t = t.to(self.device)
+        out = torch.empty(nbytes * self.world, dtype=torch.uint8, device=t.device)
+        self.dist.all_gather_into_tensor(out, t, group=self.group)
+        host = out.cpu().numpy().tobytes()
+        C.memmove(recv, host, len(host))
+
+    def _alltoallv_dev(self, d_send, send_bytes, d_recv, recv_bytes):
+        import torch
+        W = self.world
+        sb = [int(send_bytes[i]) for i in range(W)]
+        rb = [int(recv_bytes[i]) for i in range(W)]
+        inp = self._view(d_send, sum(sb))
+        out = self._view(d_recv, sum(rb))
+        if all(x % 8 == 0 for x in sb + rb):        # records are 16 / 24 bytes: move 8-byte words
+            inp, out = inp.view(torch.int64), out.view(torch.int64)
+            sb, rb = [x // 8 for x in sb], [x // 8 for x in rb]
+        self.dist.all_to_all_single(out, inp, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
+        torch.cuda.synchronize(self.device)
+        self.bytes_moved += int(inp.numel() * inp.element_size())
+
+    def _allgatherv_dev(self, d_send, nbytes, d_recv, recv_bytes):
+        import torch
+        W = self.world
+        rb = [int(recv_bytes[i]) for i in range(W)]
+        mx = max(rb) if rb else 0
+        if mx == 0:
+            return
+        pad = (mx + 15) // 16 * 16
+        mine = torch.zeros(pad, dtype=torch.uint8, device=self.device)
+        if nbytes:
+            mine[:nbytes].copy_(self._view(d_send, nbytes))
+        allb = torch.empty(pad * W, dtype=torch.uint8, device=self.device)
+        self.dist.all_gather_into_tensor(allb, mine, group=self.group)
+        out = self._view(d_recv, sum(rb))
+        off = 0
+        for r in range(W):
+            if rb[r]:
+                out[off:off + rb[r]].copy_(allb[r * pad:r * pad + rb[r]])
+            off += rb[r]
+        torch.cuda.synchronize(self.device)
+        self.bytes_moved += int(nbytes)

@@ -1,0 +1,286 @@
+"""GPU tests of ONE read set sharded over several ranks (include/plasship.h: plasship_ctx_set_comm).
+
+W ranks run as W threads with W contexts on the one GPU of the box (plass_amd.shard.LocalGroup: the collectives are
+device-to-device copies), i.e. exactly the code path of a multi-GPU run: extraction of a share of the sequences,
+partition by owner + all-to-all(v) of the k-mer records and of the grouped records, the halo of the reference's run scan
+across rank boundaries, owned-query rescoring / extension and the all-gather of the extended sequences.  The bar is the
+single-GPU bar: every rank's output DB equals the reference's golden DB (or the single-context result, which the other
+tests pin on the reference), and the union of the ranks' candidate / alignment lists equals the single-context list.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_same_db
+from test_gpu_parity import gd_km_params, gd_rs_params, km_params, nucl_as_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    import plass_amd
+    cs = [plass_amd.Context(0) for _ in range(4)]
+    yield cs
+    for c in cs:
+        c.close()
+
+
+def _run(ctxs, world, fn):
+    from plass_amd.shard import LocalGroup
+    return LocalGroup(world).run(fn, ctxs[:world])
+
+
+def _cands_rows(c):
+    q, t, s, d = c.download()
+    return np.stack([q.astype(np.int64), t.astype(np.int64), s.astype(np.int64), d.astype(np.int64)], axis=1)
+
+
+def _aln_rows(a):
+    return [(r.query_key, r.target_key, r.bit_score, r.raw_score, r.seq_id, r.q_start, r.q_end, r.q_len, r.db_start, r.db_end, r.db_len,
+             r.aln_len, r.reversed) for r in a.download()]
+
+
+def _check_union(per_rank, single, what):
+    """ranks own ascending id ranges and a query's lines live on one rank: concatenation in rank order == single list"""
+    if isinstance(single, np.ndarray):
+        u = np.concatenate(per_rank, axis=0)
+        assert u.shape == single.shape and (u == single).all(), what
+    else:
+        u = [x for part in per_rank for x in part]
+        assert u == single, what
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_golden_aa_chained(ctxs, golden, tmp_path, world):
+    """three protein iterations on the bundled example: every rank ends every iteration with the reference's DB"""
+    import plass_amd
+    s = os.path.join(golden, "aa")
+    ref = ctxs[3]
+    rdb = ref.read_seqdb(f"{s}/seq_0")
+    expect = []
+    for it in range(3):
+        c, _ = ref.kmermatcher(rdb, km_params(it))
+        a, _ = ref.rescorediagonal(rdb, rdb, c, plass_amd.RescoreParams(min_seq_id=0.9))
+        expect.append((_cands_rows(c), _aln_rows(a)))
+        rdb, _ = ref.assembleresults(rdb, a, plass_amd.AssembleParams(min_seq_id=0.9))
+
+    def work(rank, ctx):
+        db = ctx.read_seqdb(f"{s}/seq_0")
+        out = []
+        for it in range(3):
+            cands, kst = ctx.kmermatcher(db, km_params(it))
+            alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+            out.append((_cands_rows(cands), _aln_rows(alns), kst.n_candidates))
+            db2, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9))
+            db2.write(tmp_path / f"r{rank}_seq_{it + 1}")
+            db = db2
+        return out
+
+    res = _run(ctxs, world, work)
+    for it in range(3):
+        _check_union([res[r][it][0] for r in range(world)], expect[it][0], f"candidates it{it}")
+        _check_union([res[r][it][1] for r in range(world)], expect[it][1], f"alignments it{it}")
+        assert sum(res[r][it][2] for r in range(world)) == int((expect[it][0][:, 0] != expect[it][0][:, 1]).sum())
+        for r in range(world):
+            assert_same_db(f"{s}/seq_{it + 1}", tmp_path / f"r{r}_seq_{it + 1}", f"rank {r} of {world}, iteration {it}")
+
+
+@pytest.mark.parametrize("case", [1, 2, 3, 4])
+def test_sharded_stale_scan_quirk(ctxs, golden, tmp_path, case):
+    """the reference's scan into stale records behind the compaction point, when the records are spread over ranks:
+    the ranks reduce N_m / N_k / the sort-#1 ranks, the owner of the last run appends the stale records"""
+    d = os.path.join(golden, "q1", f"case{case}")
+    ext = open(os.path.join(d, "ext")).read().strip() == "1"
+    par = km_params(0); par.include_only_extendable = ext
+    ref = ctxs[3]
+    rdb = ref.read_seqdb(os.path.join(d, "seq"))
+    c, _ = ref.kmermatcher(rdb, par)
+    c.write(tmp_path / "pref")
+    assert_same_db(os.path.join(d, "pref"), tmp_path / "pref", "single context")
+    expect = _cands_rows(c)
+    for world in (2, 3):
+        res = _run(ctxs, world, lambda rank, ctx: _cands_rows(ctx.kmermatcher(ctx.read_seqdb(os.path.join(d, "seq")), par)[0]))
+        _check_union(res, expect, f"stale-scan case {case}, {world} ranks")
+
+
+def test_sharded_golden_nucl_chained(ctxs, golden, tmp_path):
+    """nucleotide path (canonical k-mers, strand bits, first-run quirk key reduced over the ranks, nuclassembleresults)"""
+    import plass_amd
+    s = os.path.join(golden, "nucl")
+    world = 2
+
+    def work(rank, ctx):
+        db = ctx.read_seqdb(f"{s}/seq_0")
+        for it in range(2):
+            cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+            alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+            db2, _ = ctx.assembleresults(db, alns, nucl_as_params())
+            db2.write(tmp_path / f"r{rank}_seq_{it + 1}")
+            db = db2
+
+    _run(ctxs, world, work)
+    for it in range(2):
+        for r in range(world):
+            assert_same_db(f"{s}/seq_{it + 1}", tmp_path / f"r{r}_seq_{it + 1}", f"nucl rank {r}, iteration {it}")
+
+
+def test_sharded_golden_long_nucl(ctxs, golden, tmp_path):
+    """24-byte records (KmerPosition<int>), contigs of tens of kb, 3 ranks"""
+    import plass_amd
+    s = os.path.join(golden, "longnucl")
+    world = 3
+
+    def work(rank, ctx):
+        db = ctx.read_seqdb(f"{s}/seq_0")
+        cands, _ = ctx.kmermatcher(db, km_params(0, nucl=True))
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+        db2, _ = ctx.assembleresults(db, alns, nucl_as_params())
+        db2.write(tmp_path / f"r{rank}_seq_1")
+
+    _run(ctxs, world, work)
+    for r in range(world):
+        assert_same_db(f"{s}/seq_1", tmp_path / f"r{r}_seq_1", f"long nucl rank {r}")
+
+
+def test_sharded_golden_guided_chained(ctxs, golden, tmp_path):
+    """protein-guided stage: two output DBs (nucleotide ORFs + protein twins) gathered from the ranks"""
+    s = os.path.join(golden, "guided")
+    world = 2
+
+    def work(rank, ctx):
+        aa = ctx.read_seqdb(f"{s}/aa_0"); nu = ctx.read_seqdb(f"{s}/nucl_0")
+        for it in range(2):
+            cands, _ = ctx.kmermatcher(aa, gd_km_params())
+            alns, _ = ctx.rescorediagonal(aa, aa, cands, gd_rs_params())
+            naln, _ = ctx.proteinaln2nucl(nu, aa, alns)
+            nu2, aa2, _ = ctx.guidedassembleresults(nu, aa, naln)
+            nu2.write(tmp_path / f"r{rank}_nucl_{it + 1}"); aa2.write(tmp_path / f"r{rank}_aa_{it + 1}")
+            nu, aa = nu2, aa2
+
+    _run(ctxs, world, work)
+    for it in range(2):
+        for r in range(world):
+            assert_same_db(f"{s}/nucl_{it + 1}", tmp_path / f"r{r}_nucl_{it + 1}", f"guided nucl rank {r} it{it}")
+            assert_same_db(f"{s}/aa_{it + 1}", tmp_path / f"r{r}_aa_{it + 1}", f"guided aa rank {r} it{it}")
+
+
+def test_sharded_keep_target0(ctxs, golden, tmp_path):
+    """--keep-target 0: the 'consumed as a target' bits are OR-ed over the ranks before the output DB is built"""
+    import plass_amd
+    s = os.path.join(golden, "aa")
+    world = 3
+
+    def work(rank, ctx):
+        db = ctx.read_seqdb(f"{s}/seq_0")
+        cands, _ = ctx.kmermatcher(db, km_params(0))
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+        out, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, keep_target=False))
+        out.write(tmp_path / f"r{rank}_seq")
+
+    _run(ctxs, world, work)
+    for r in range(world):
+        assert_same_db(f"{s}/seq_1_keeptarget0", tmp_path / f"r{r}_seq", f"keep-target 0 rank {r}")
+
+
+def test_sharded_adversarial_inputs(ctxs, golden, tmp_path):
+    """hostile inputs (shorter than k, homopolymers, duplicates, one long contig, index order != key order) on 3 ranks:
+    ranks with next to nothing to do, owners without records"""
+    import plass_amd
+    s = os.path.join(golden, "adversarial")
+    for kind, nucl, rs, asp in (("aa", False, plass_amd.RescoreParams(min_seq_id=0.9), plass_amd.AssembleParams(min_seq_id=0.9)),
+                                ("nucl", True, plass_amd.RescoreParams(min_seq_id=0.99), nucl_as_params())):
+        src = f"{s}/{kind}_seq"
+        ref = ctxs[3]
+        rdb = ref.read_seqdb(src)
+        c, _ = ref.kmermatcher(rdb, km_params(0, nucl=nucl))
+        a, _ = ref.rescorediagonal(rdb, rdb, c, rs)
+        o, _ = ref.assembleresults(rdb, a, asp)
+        o.write(tmp_path / f"{kind}_expect")
+        expect = _cands_rows(c)
+
+        def work(rank, ctx):
+            db = ctx.read_seqdb(src)
+            cands, _ = ctx.kmermatcher(db, km_params(0, nucl=nucl))
+            alns, _ = ctx.rescorediagonal(db, db, cands, rs)
+            out, _ = ctx.assembleresults(db, alns, asp)
+            out.write(tmp_path / f"{kind}_r{rank}")
+            return _cands_rows(cands)
+
+        res = _run(ctxs, 3, work)
+        _check_union(res, expect, f"adversarial {kind} candidates")
+        for r in range(3):
+            assert_same_db(tmp_path / f"{kind}_expect", tmp_path / f"{kind}_r{r}", f"adversarial {kind} rank {r}")
+
+
+def test_sharded_synthetic_three_ranks(ctxs, tmp_path):
+    """40 k read pairs (130 k protein fragments), 3 iterations on 3 ranks against the single-context run"""
+    import plass_amd
+    from plass_amd import synth
+    data, off, elen, key = synth.protein_fragment_db(40000, seed=5)
+    world = 3
+    ref = ctxs[3]
+    rdb = ref.upload_seqdb(data, off, elen, key, 0)
+    expect = []
+    for it in range(3):
+        c, _ = ref.kmermatcher(rdb, km_params(it))
+        a, _ = ref.rescorediagonal(rdb, rdb, c, plass_amd.RescoreParams(min_seq_id=0.9))
+        expect.append((_cands_rows(c), len(_aln_rows(a))))
+        rdb, _ = ref.assembleresults(rdb, a, plass_amd.AssembleParams(min_seq_id=0.9))
+        rdb.write(tmp_path / f"e_seq_{it + 1}")
+
+    def work(rank, ctx):
+        db = ctx.upload_seqdb(data, off, elen, key, 0)
+        out = []
+        for it in range(3):
+            cands, _ = ctx.kmermatcher(db, km_params(it))
+            alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+            out.append((_cands_rows(cands), alns.count()))
+            db2, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9))
+            db2.write(tmp_path / f"r{rank}_seq_{it + 1}")
+            db = db2
+        return out
+
+    res = _run(ctxs, world, work)
+    for it in range(3):
+        _check_union([res[r][it][0] for r in range(world)], expect[it][0], f"synthetic candidates it{it}")
+        assert sum(res[r][it][1] for r in range(world)) == expect[it][1]
+        for r in range(world):
+            assert_same_db(tmp_path / f"e_seq_{it + 1}", tmp_path / f"r{r}_seq_{it + 1}", f"synthetic rank {r} it{it}")
+
+
+def test_sharded_one_rank_torch_rccl(tmp_path, golden):
+    """the torch.distributed communicator bench.py uses (RCCL on device pointers of the library), in a 1-rank group:
+    the same all-to-all(v) / all-gather calls an 8-GPU run makes, with this rank as its own peer"""
+    import subprocess, sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import plass_amd
+from plass_amd.shard import TorchComm
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+ctx = plass_amd.Context(0)
+s = %r
+def chain(ctx, tag):
+    db = ctx.read_seqdb(s + "/seq_0")
+    for it in range(2):
+        par = plass_amd.KmermatchParams(hash_shift=67 if it == 0 else 68, include_only_extendable=(it > 0))
+        c, _ = ctx.kmermatcher(db, par)
+        a, _ = ctx.rescorediagonal(db, db, c, plass_amd.RescoreParams(min_seq_id=0.9))
+        db, _ = ctx.assembleresults(db, a, plass_amd.AssembleParams(min_seq_id=0.9))
+        db.write(%r + "/" + tag + "_seq_%%d" %% (it + 1))
+comm = TorchComm(dist, torch.device("cuda:0"))
+comm.install(ctx)
+chain(ctx, "rccl")
+assert comm.bytes_moved > 0
+dist.destroy_process_group()
+print("RCCL_OK", comm.bytes_moved)
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(golden, "aa"), str(tmp_path))
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-3000:]
+    for it in range(2):
+        assert_same_db(os.path.join(golden, "aa", f"seq_{it + 1}"), tmp_path / f"rccl_seq_{it + 1}", f"1-rank RCCL iteration {it}")
