@@ -9,8 +9,12 @@ The input DB is resident in HBM before the timed region; each of the W warm-up s
 the same K-iteration chain (results discarded), so every iteration's kernels and buffers are warm.  value = sum over the K timed iterations of the candidate overlaps kmermatcher
 emitted (non-self prefilter lines) / wall time, max over ranks, summed over ranks.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): every rank assembles its own partition of the
-community (independent genomes, seed = rank) — weak scaling, no data-path collective (multi-GPU).
+N > 1 (launched by torch.distributed.run, one rank per GPU), default `--mode sharded`: ONE read set of N x 1 M reads
+(N genomes, one seeded part per rank's worth) is sharded over the N GPUs by k-mer bucket — every rank extracts the k-mers
+of its share of the sequences, the records travel to the owner of their hash bucket and the grouped records to the owner
+of the representative by RCCL all-to-all(v) over xGMI, every rank re-scores and extends the queries it owns and the
+extended sequences are all-gathered (include/plasship.h: plasship_ctx_set_comm).  Per-GPU work is
+fixed as N grows: weak scaling.  `--mode partitions` is the older independent-partitions run (no data-path collective).
 
 Also reported on the same JSON line:
   roofline     — dominant kernel of the timed run: algorithmic bytes / its HIP-event time
@@ -55,6 +59,23 @@ def load_workload(pairs, seed):
     except OSError:
         pass
     return data, off, elen, key
+
+
+def load_sharded_workload(pairs, rank, world, dist):
+    """ONE read set of `world` parts (part r = the set a single GPU gets with seed 1 + r).  Rank r generates part r into the
+    node-local cache, then everybody loads all parts; keys are made unique by a per-part offset."""
+    import numpy as np
+    load_workload(pairs, seed=1 + rank)
+    if dist is not None:
+        dist.barrier()
+    datas, offs, elens, keys = [], [], [], []
+    base, kbase = 0, 0
+    for r in range(world):
+        d, o, e, k = load_workload(pairs, seed=1 + r)
+        datas.append(d); offs.append(np.asarray(o, dtype=np.uint64) + np.uint64(base)); elens.append(np.asarray(e, dtype=np.uint32))
+        keys.append(np.asarray(k, dtype=np.uint32) + np.uint32(kbase))
+        base += len(d); kbase += int(np.max(k)) + 1 if len(k) else 0
+    return b"".join(datas), np.concatenate(offs), np.concatenate(elens), np.concatenate(keys)
 
 
 def one_iteration(ctx, db, it):
@@ -132,6 +153,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=500000, help="read pairs per GPU (500000 = 1 M reads, BASELINE configs[1])")
     ap.add_argument("--cpu-sample-pairs", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["auto", "sharded", "partitions"], default="auto",
+                    help="N > 1: 'sharded' = one read set over the GPUs with RCCL all-to-all (default), 'partitions' = independent sets")
     args = ap.parse_args()
 
     import torch
@@ -146,9 +169,21 @@ def main():
         # switch runs the same collectives in a 1-rank group (what a 1-GPU box can check of the N > 1 path)
         dist = pdist.init("nccl", rank, world, device=torch.device("cuda", local))
     plan = pdist.partition_plan(world)
+    mode = args.mode
+    if mode == "auto":
+        mode = "sharded" if dist is not None else "partitions"
+    if mode == "sharded" and dist is None:
+        raise SystemExit("--mode sharded needs torch.distributed (launch with torch.distributed.run, or PLASS_BENCH_FORCE_DIST=1 on one GPU)")
 
-    data, off, elen, key = load_workload(args.pairs, seed=plan["seeds"][rank])
     ctx = plass_amd.Context(local)
+    comm = None
+    if mode == "sharded":
+        from plass_amd.shard import TorchComm
+        data, off, elen, key = load_sharded_workload(args.pairs, rank, world, dist)
+        comm = TorchComm(dist, torch.device("cuda", local))
+        comm.install(ctx)
+    else:
+        data, off, elen, key = load_workload(args.pairs, seed=plan["seeds"][rank])
     db0 = ctx.upload_seqdb(data, off, elen, key, 0)
     n_frag = len(key)
 
@@ -170,6 +205,8 @@ def main():
         if wdb is not db0:
             wdb.free()
     barrier()
+    if comm is not None:
+        comm.bytes_moved = 0; comm.seconds = 0.0; comm.calls = 0
     t0 = time.perf_counter()
     db = db0
     stats = []
@@ -210,7 +247,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic 2x150 bp protein-coding reads per GPU (%d read pairs, %d protein fragments), "
                                    "--num-iterations %d, k=14, alph 13, kmer-per-seq 60, min-seq-id 0.9, e 1e-5" % (2 * args.pairs, args.pairs, n_frag, args.steps),
-                       "parallelism": "1 process per GPU, independent partitions" if world > 1 else "1 GPU",
+                       "parallelism": ("1 GPU" if world == 1 and mode != "sharded" else
+                                       "%d GPUs, one read set of %d fragments sharded by k-mer bucket (RCCL all-to-all(v) of k-mer and grouped records, "
+                                       "all-gather of extended sequences), sequence DB replicated" % (world, n_frag) if mode == "sharded" else
+                                       "1 process per GPU, independent partitions"),
                        "candidate_overlaps": overlaps},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None, "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
@@ -220,6 +260,9 @@ def main():
                                                "frac": (tot["kmermatcher_stage"][1] / (tot["kmermatcher_stage"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot["kmermatcher_stage"][0] > 0 else 0.0},
                          "module_wall_ms_per_step": [round(sum(w[i] for w in WALL[-args.steps:]) / args.steps, 3) for i in range(3)]},
         }
+        if comm is not None:
+            line["exchange"] = {"device_bytes_sent_per_step_rank0": comm.bytes_moved / max(args.steps, 1), "collective_calls_per_step": comm.calls / max(args.steps, 1),
+                                "ms_in_collectives_per_step_rank0": comm.seconds * 1e3 / max(args.steps, 1)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_pairs, min(args.steps, 3))
         else:

@@ -1313,11 +1313,13 @@ static int mergeExtended(plasship_ctx *ctx, uint32_t N, bool guided, int keepTar
     if (N) hipLaunchKernelGGL(extPackKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, N, dKeep.as<uint32_t>(), dPos.as<uint64_t>(), dOff.as<uint64_t>(),
                               guided ? dAaOff.as<uint64_t>() : (const uint64_t *) nullptr, dNewLen, dNewStart, dArena, dAaNewLen, dAaNewStart, dAaArena,
                               dMeta.as<ExtMeta>(), dPacked.as<char>(), guided ? dAaPacked.as<char>() : (char *) nullptr);
+    PH_TRACE(st, "assemble: packed the extended sequences");
     DevBuf gMeta; std::vector<uint64_t> rb;
     int rc = commAllgathervBytes(ctx, dMeta.p, nExt * sizeof(ExtMeta), gMeta, rb); if (rc) return rc;
     uint64_t M = 0; for (int r = 0; r < W; r++) M += rb[r] / sizeof(ExtMeta);
     rc = commAllgathervBytes(ctx, dPacked.p, extBytes, gathered, rb); if (rc) return rc;
     if (guided) { rc = commAllgathervBytes(ctx, dAaPacked.p, aaExtBytes, gatheredAa, rb); if (rc) return rc; }
+    PH_TRACE(st, "assemble: gathered the extended sequences");
     // the gathered byte blocks are the ranks' packed blocks in rank order = the gathered meta order: starts are a prefix sum
     DevBuf dLens, dStart, dAaLens, dAaStart, dTmp2; const size_t tmp2Bytes = exclusiveScanTmpBytes(M + 2);
     if (dLens.alloc((M + 1) * 8) != hipSuccess || dStart.alloc((M + 2) * 8) != hipSuccess || dTmp2.alloc(tmp2Bytes) != hipSuccess ||
@@ -1330,6 +1332,7 @@ static int mergeExtended(plasship_ctx *ctx, uint32_t N, bool guided, int keepTar
         hipLaunchKernelGGL(extMergeKernel, dim3(gridM), dim3(256), 0, st, gMeta.as<ExtMeta>(), M, dStart.as<uint64_t>(), guided ? dAaStart.as<uint64_t>() : (const uint64_t *) nullptr,
                            dFlags, dNewLen, dNewStart, dAaNewLen, dAaNewStart);
     }
+    PH_TRACE(st, "assemble: merged the extended sequences");
     if (!keepTarget) {
         DevBuf gFlags;
         rc = commAllgathervBytes(ctx, dFlags, (uint64_t) N * 4, gFlags, rb); if (rc) return rc;
@@ -1475,6 +1478,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(a.nBig, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[7], st));
     }
+    PH_TRACE(st, "assemble: extension kernels");
     // ---- output DB(s): extended queries + carried-over sequences, in key order ----
     plasship_seqdb *o = nullptr, *oAa = nullptr;
     unsigned long long hs[16] = {0};

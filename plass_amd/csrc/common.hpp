@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstddef>
+#include <cstdio>
 #include <string>
 #include <vector>
 #include "../../include/plasship.h"
@@ -26,6 +27,16 @@ std::string hipErrStr(hipError_t e, const char *what, const char *file, int line
     do {                                                                                 \
         PH_CHECK(hipMemcpyAsync((dst), (src), (bytes), (kind), (st)));                   \
         PH_CHECK(hipStreamSynchronize(st));                                              \
+    } while (0)
+
+// PLASSHIP_TRACE=1: wait for the stream at every marked stage boundary and say so on stderr (localises a faulting kernel)
+bool traceOn();
+#define PH_TRACE(st, what)                                                                \
+    do {                                                                                 \
+        if (plasship::traceOn()) {                                                       \
+            hipError_t e_ = hipStreamSynchronize(st);                                    \
+            fprintf(stderr, "[plasship] %s: %s\n", (what), hipGetErrorString(e_));       \
+        }                                                                                \
     } while (0)
 
 // Caching device allocator: hipMalloc/hipFree synchronise the device and cost 0.1–1 ms each, which would

@@ -69,6 +69,7 @@ void poolTrim() {
     g_poolFree.clear();
 }
 static thread_local std::string g_err;
+bool traceOn() { static const bool v = getenv("PLASSHIP_TRACE") != nullptr; return v; }
 void setError(const std::string &msg) { g_err = msg; }
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
     return std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);

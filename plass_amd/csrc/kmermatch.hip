@@ -1225,6 +1225,30 @@ __global__ void lastRunInfoKernel(const unsigned long long *__restrict__ maxRT, 
     if (t < n) { out[1] = slotOff[t]; out[2] = slotOff[t + 1]; out[3] = len[t]; } else { out[1] = out[2] = out[3] = 0; }
 }
 
+// PLASSHIP_TRACE: records whose sequence id is out of range (sentinels excepted) — a consistency probe between the stages
+template <bool LONG>
+__global__ void countBadIdsKernel(const void *recs, uint64_t n, uint32_t nSeq, unsigned long long *out) {
+    const Rec<LONG> *g = reinterpret_cast<const Rec<LONG> *>(recs);
+    unsigned long long bad = 0, sen = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const Rec<LONG> r = g[i];
+        if (isSentinel(r)) sen++; else if (r.id >= nSeq) bad++;
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    if (sen) atomicAdd(&out[1], sen);
+}
+template <bool LONG>
+static void traceBadIds(plasship_ctx *ctx, const char *what, const void *recs, uint64_t n, uint32_t nSeq) {
+    if (!traceOn()) return;
+    DevBuf d; unsigned long long h[2] = {0, 0};
+    if (d.alloc(16) != hipSuccess) return;
+    (void) hipMemsetAsync(d.p, 0, 16, ctx->stream);
+    hipLaunchKernelGGL((countBadIdsKernel<LONG>), dim3(1024), dim3(256), 0, ctx->stream, recs, n, nSeq, d.as<unsigned long long>());
+    (void) hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    fprintf(stderr, "[plasship] %s: %llu records, %llu with an id out of range, %llu sentinels (%s)\n", what, (unsigned long long) n, h[0], h[1], hipGetErrorString(e));
+}
+
 // sharded run: id ranges with equal shares of the k-mer record slots.  out[r] = first id of rank r (r = 0..W), out[W+1+r] = its slot
 __global__ void splitIdsKernel(const uint64_t *__restrict__ slotOff, uint32_t n, int W, uint64_t *__restrict__ out) {
     const uint64_t total = slotOff[n];
@@ -1356,6 +1380,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_CHECK(hipGetLastError());
     }
     msExtract = tm.stop(1);
+    PH_TRACE(st, "kmermatch: extraction");
+    traceBadIds<LONG>(ctx, "kmermatch: extracted slots", dA.p, total, N);
 
     // ---- hash partition (replaces sort #1) ----
     tm.start(0);
@@ -1391,9 +1417,13 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_COPY_SYNC(st, hStartO.data(), dStartO.p, ((size_t) nbO + 1) * 8, hipMemcpyDeviceToHost);
         PH_CHECK(hipGetLastError());
         for (int r = 0; r < W; r++) sendCount[r] = hStartO[r + 1] - hStartO[r];
+        PH_TRACE(st, "kmermatch: owner partition of the k-mer records");
+        traceBadIds<LONG>(ctx, "kmermatch: owner-partitioned records", dB.p, hStartO[nbO], N);
         uint64_t got = 0;
         int rc = commAlltoallvRecords(ctx, dB.p, sendCount.data(), sizeof(R), dRxA, &got, 0);
         if (rc) return rc;
+        PH_TRACE(st, "kmermatch: exchange 1");
+        traceBadIds<LONG>(ctx, "kmermatch: received records", dRxA.p, got, N);
         dA.release(); dB.release();
         if (dRxB.alloc(std::max<uint64_t>(got, 1) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; }
         if (NUCL) {              // the globally smallest key (first-run quirk of the group kernel)
@@ -1462,6 +1492,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         dBucketStart = dStart2.as<uint64_t>();
     }
     msSort1 = tm.stop(1);
+    PH_TRACE(st, "kmermatch: hash partition");
+    traceBadIds<LONG>(ctx, "kmermatch: bucketed records", cur, Nk, N);
 
     // ---- assignGroup ----
     tm.start(0);
@@ -1505,6 +1537,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     }
     std::swap(cur, other);   // cur = grouped records, scattered in arenas; other = the N_k hash-bucketed records (dense)
     msGroup = tm.stop(1);
+    PH_TRACE(st, "kmermatch: group");
 
     // ---- stale records behind the compaction point that continue the last run (see section 7 above) ----
     std::vector<int64_t> stalePos;          // original k-mer positions of the sort-#1 records of rank N_m, N_m+1, … that belong to T
@@ -1526,7 +1559,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         // re-extract the records of T into a scratch array with the very kernel that produced them
         ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
         ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
+        if (traceOn()) fprintf(stderr, "[plasship] kmermatch: stale check T=%u slots [%llu, %llu) len %u Nm=%llu NkG=%llu\n", staleT, (unsigned long long) so[0], (unsigned long long) so[1], tLen, (unsigned long long) Nm, (unsigned long long) NkG);
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(1), dim3(64), 0, st, ta);
+        PH_TRACE(st, "kmermatch: re-extraction of the last run's target");
         std::vector<R> trec(tb);
         PH_CHECK(hipMemcpyAsync(trec.data(), dTRec.p, (size_t) tb * sizeof(R), hipMemcpyDeviceToHost, st));
         PH_CHECK(hipStreamSynchronize(st));
@@ -1544,6 +1579,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         if (m && mayHit) {
             PH_CHECK(hipMemcpyAsync(dTRec.p, trec.data(), (size_t) m * sizeof(R), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((rankKernel<NUCL, LONG>), dim3(gridFor(Nk, 256, (unsigned) ctx->numCU * 8)), dim3(256), 0, st, (const void *) other, Nk, (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
+            PH_TRACE(st, "kmermatch: rank pass");
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(hipStreamSynchronize(st));
@@ -1565,6 +1601,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const uint64_t *segStartP = dArenaStart.as<uint64_t>(), *segCountP = dOutCnt.as<uint64_t>();   // where the grouped records are
     uint32_t nSeg = gGrid; uint64_t maxSeg1 = maxArena, NmHere = NmLocal;
     const uint64_t haloSlack = 1u << 16;       // room behind the triples for what the last run's scan reaches on later ranks
+    if (traceOn()) fprintf(stderr, "[plasship] kmermatch: N=%u Nk=%llu NmLocal=%llu gGrid=%u maxArena=%llu stale=%zu\n", N, (unsigned long long) Nk, (unsigned long long) NmLocal, gGrid, (unsigned long long) maxArena, stalePos.size());
+    PH_TRACE(st, "kmermatch: stale-record check");
     if (cm) {
         // exchange 2: grouped (rep, member, diagonal) records -> owner of the rep.  Same recipe: one partition pass by owner
         // straight out of the group kernel's arenas, then an all-to-all(v).
@@ -1577,6 +1615,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         po.cursor = dCurO.as<unsigned long long>(); po.bits = ob; po.sharedTable = 1; po.ownerW = (uint32_t) W; po.ownerN = std::max<uint64_t>(N, 1);
         const unsigned tilesO = (unsigned) std::max<uint64_t>(1, (maxArena + PT_TILE - 1) / PT_TILE);
         hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_OWNER_REP>), dim3(tilesO, gGrid), dim3(PT_BLOCK), 0, st, po);
+        PH_TRACE(st, "kmermatch: owner histogram of the grouped records");
         if (exclusiveScanU32(st, dCntO.as<uint32_t>(), dStartO.as<uint64_t>(), nbO, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(copyU64Kernel, dim3(1), dim3(256), 0, st, dStartO.as<uint64_t>(), dCurO.as<unsigned long long>(), (uint64_t) nbO);
         hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_OWNER_REP>), dim3(tilesO, gGrid), dim3(PT_BLOCK), (size_t) 12 << po.bits, st, po);
@@ -1584,9 +1623,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_COPY_SYNC(st, hStartO.data(), dStartO.p, ((size_t) nbO + 1) * 8, hipMemcpyDeviceToHost);
         PH_CHECK(hipGetLastError());
         for (int r = 0; r < W; r++) sendCount[r] = hStartO[r + 1] - hStartO[r];
+        PH_TRACE(st, "kmermatch: owner partition of the grouped records");
         uint64_t got = 0;
         const int rc = commAlltoallvRecords(ctx, other, sendCount.data(), sizeof(R), dRxC, &got, haloSlack);
         if (rc) return rc;
+        PH_TRACE(st, "kmermatch: exchange 2");
         dRxA.release(); dRxB.release();
         if (dRxD.alloc((got + haloSlack) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; }
         cur = dRxC.p; other = dRxD.p;
@@ -1675,6 +1716,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     hipLaunchKernelGGL(compactTriplesKernel, dim3(std::min<uint32_t>((nSortBuckets + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st,
                        (const Triple *) other, dSortStart, dTripleStart.as<uint64_t>(), nSortBuckets, (Triple *) cur);
     msSort2 = tm.stop(1);
+    PH_TRACE(st, "kmermatch: rep sort");
     PH_CHECK(hipGetLastError());
 
     // ---- per-(rep,target) reduction + CSR ----
@@ -1755,6 +1797,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (qHi > qLo) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(qHi - qLo, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), qLo, qHi, c->d_hits.as<CandHit>());
     if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
     msReduce = tm.stop(1);
+    PH_TRACE(st, "kmermatch: reduce");
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
     if (!stalePos.empty() && nTriples > 0 && !cm) {
@@ -1800,8 +1843,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
     }
     if (stats) {
-        // sharded run: records / grouped records of the whole run, candidates of the owned queries
-        stats->n_kmer_records = NkG; stats->n_grouped = Nm; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
+        // sharded run: what THIS rank's kernels processed (records of its buckets, grouped records of its reps, candidates of its queries)
+        stats->n_kmer_records = Nk; stats->n_grouped = NmHere; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
         {
             float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
             stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;

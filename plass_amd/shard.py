@@ -37,14 +37,19 @@ class _CommBase:
     def __init__(self, rank, world):
         self.rank, self.world = rank, world
         self.error = None
+        self.bytes_moved, self.seconds, self.calls = 0, 0.0, 0      # device bytes this rank sent, time inside collectives, calls
         self._cbs = (_AG_HOST(self._wrap(self._allgather_host)), _A2A_DEV(self._wrap(self._alltoallv_dev)),
                      _AGV_DEV(self._wrap(self._allgatherv_dev)))
         self.struct = CommStruct(rank, world, None, *self._cbs)
 
     def _wrap(self, fn):
         def cb(user, *a):
+            import time
+            t0 = time.perf_counter()
             try:
                 fn(*a)
+                self.seconds += time.perf_counter() - t0
+                self.calls += 1
                 return 0
             except BaseException as e:      # never let an exception cross the C boundary
                 self.error = e
@@ -171,19 +176,25 @@ class _DevPtr:
 
 
 class TorchComm(_CommBase):
-    """collectives over a torch.distributed process group.  device: torch.device of this rank's GPU (None: CPU tensors,
-    only allgather_host works — the gloo tests)."""
+    """collectives over a torch.distributed process group.  device: torch.device of this rank's GPU; None: the "device"
+    pointers are host pointers and the tensors CPU tensors (the gloo tests drive the same split arithmetic that way)."""
 
     def __init__(self, dist, device=None, group=None):
         super().__init__(dist.get_rank(group), dist.get_world_size(group))
         self.dist, self.device, self.group = dist, device, group
-        self.bytes_moved = 0
 
     def _view(self, ptr, nbytes):
         import torch
         if nbytes == 0:
             return torch.empty(0, dtype=torch.uint8, device=self.device)
+        if self.device is None:
+            return torch.frombuffer((C.c_uint8 * nbytes).from_address(ptr), dtype=torch.uint8)
         return torch.as_tensor(_DevPtr(ptr, nbytes), device=self.device)
+
+    def _sync(self):
+        if self.device is not None:
+            import torch
+            torch.cuda.synchronize(self.device)
 
     def _allgather_host(self, send, recv, nbytes):
         import torch
@@ -195,38 +206,50 @@ class TorchComm(_CommBase):
         host = out.cpu().numpy().tobytes()
         C.memmove(recv, host, len(host))
 
+    # Device data moves as point-to-point messages (ncclSend / ncclRecv pairs in one group per round — what an
+    # all-to-all is underneath), in pieces of at most CHUNK bytes: RCCL 2.26.6 silently drops half of a message of more
+    # than 2^30 bytes (tools/rccl_a2a_probe.py shows it with a plain all_to_all_single), and a k-mer record exchange at
+    # 1 M reads per GPU is already 1 GB.  Both ends of a pair know the message size, so they agree on the pieces
+    # without talking; the piece a rank keeps for itself is a plain device copy.
+    CHUNK = 256 << 20
+
+    def _exchange(self, inp, out, soff, sb, roff, rb):
+        """inp[soff[r] : soff[r] + sb[r]] -> rank r;  out[roff[r] : roff[r] + rb[r]] <- rank r   (uint8 tensors)"""
+        dist, W, me, CH = self.dist, self.world, self.rank, self.CHUNK
+        if sb[me]:
+            out[roff[me]:roff[me] + rb[me]].copy_(inp[soff[me]:soff[me] + sb[me]])
+        rounds = max([0] + [(max(sb[r], rb[r]) + CH - 1) // CH for r in range(W) if r != me])
+        for k in range(rounds):
+            ops = []
+            for r in range(W):
+                if r == me:
+                    continue
+                lo, hi = min(k * CH, sb[r]), min((k + 1) * CH, sb[r])
+                if hi > lo:
+                    ops.append(dist.P2POp(dist.isend, inp[soff[r] + lo:soff[r] + hi], r if self.group is None else dist.get_global_rank(self.group, r), self.group))
+                lo, hi = min(k * CH, rb[r]), min((k + 1) * CH, rb[r])
+                if hi > lo:
+                    ops.append(dist.P2POp(dist.irecv, out[roff[r] + lo:roff[r] + hi], r if self.group is None else dist.get_global_rank(self.group, r), self.group))
+            if ops:
+                for q in dist.batch_isend_irecv(ops):
+                    q.wait()
+        self._sync()
+
     def _alltoallv_dev(self, d_send, send_bytes, d_recv, recv_bytes):
-        import torch
         W = self.world
         sb = [int(send_bytes[i]) for i in range(W)]
         rb = [int(recv_bytes[i]) for i in range(W)]
-        inp = self._view(d_send, sum(sb))
-        out = self._view(d_recv, sum(rb))
-        if all(x % 8 == 0 for x in sb + rb):        # records are 16 / 24 bytes: move 8-byte words
-            inp, out = inp.view(torch.int64), out.view(torch.int64)
-            sb, rb = [x // 8 for x in sb], [x // 8 for x in rb]
-        self.dist.all_to_all_single(out, inp, output_split_sizes=rb, input_split_sizes=sb, group=self.group)
-        torch.cuda.synchronize(self.device)
-        self.bytes_moved += int(inp.numel() * inp.element_size())
+        soff = [sum(sb[:r]) for r in range(W)]
+        roff = [sum(rb[:r]) for r in range(W)]
+        self._exchange(self._view(d_send, sum(sb)), self._view(d_recv, sum(rb)), soff, sb, roff, rb)
+        self.bytes_moved += sum(sb)
 
     def _allgatherv_dev(self, d_send, nbytes, d_recv, recv_bytes):
-        import torch
         W = self.world
         rb = [int(recv_bytes[i]) for i in range(W)]
-        mx = max(rb) if rb else 0
-        if mx == 0:
-            return
-        pad = (mx + 15) // 16 * 16
-        mine = torch.zeros(pad, dtype=torch.uint8, device=self.device)
-        if nbytes:
-            mine[:nbytes].copy_(self._view(d_send, nbytes))
-        allb = torch.empty(pad * W, dtype=torch.uint8, device=self.device)
-        self.dist.all_gather_into_tensor(allb, mine, group=self.group)
-        out = self._view(d_recv, sum(rb))
-        off = 0
-        for r in range(W):
-            if rb[r]:
-                out[off:off + rb[r]].copy_(allb[r * pad:r * pad + rb[r]])
-            off += rb[r]
-        torch.cuda.synchronize(self.device)
-        self.bytes_moved += int(nbytes)
+        nbytes = int(nbytes)
+        if rb[self.rank] != nbytes:
+            raise RuntimeError("all-gather size mismatch")
+        roff = [sum(rb[:r]) for r in range(W)]
+        self._exchange(self._view(d_send, nbytes), self._view(d_recv, sum(rb)), [0] * W, [nbytes] * W, roff, rb)
+        self.bytes_moved += nbytes * max(W - 1, 1)
