@@ -78,6 +78,22 @@ def load_sharded_workload(pairs, rank, world, dist):
     return b"".join(datas), np.concatenate(offs), np.concatenate(elens), np.concatenate(keys)
 
 
+def sharded_preflight(ctx, dist, device):
+    """one sharded iteration on a small read set (the same on every rank): every rank must end with the same DB"""
+    import torch
+    from plass_amd import synth
+    data, off, elen, key = synth.protein_fragment_db(3000, seed=7)
+    db = ctx.upload_seqdb(data, off, elen, key, 0)
+    out, kst, _, _ = one_iteration(ctx, db, 0)
+    WALL.pop()
+    i = out.info()
+    t = torch.tensor([i["residues"], -i["residues"], kst.n_candidates], dtype=torch.int64, device=device)
+    mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    if int(mx[0]) != -int(mx[1]):
+        raise RuntimeError("sharded preflight: the ranks ended with different output DBs")
+    out.free(); db.free()
+
+
 def one_iteration(ctx, db, it):
     import plass_amd
     par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=hash_shift(it),
@@ -167,7 +183,7 @@ def main():
     dist = None
     if world > 1 or os.environ.get("PLASS_BENCH_FORCE_DIST"):      # one process per GPU over RCCL ("nccl" backend on ROCm); the env
         # switch runs the same collectives in a 1-rank group (what a 1-GPU box can check of the N > 1 path)
-        dist = pdist.init("nccl", rank, world, device=torch.device("cuda", local))
+        dist = pdist.init("nccl", rank, world, device=torch.device("cuda", local), timeout_s=180)
     plan = pdist.partition_plan(world)
     mode = args.mode
     if mode == "auto":
@@ -177,11 +193,21 @@ def main():
 
     ctx = plass_amd.Context(local)
     comm = None
+    sharded_error = None
     if mode == "sharded":
         from plass_amd.shard import TorchComm
-        data, off, elen, key = load_sharded_workload(args.pairs, rank, world, dist)
         comm = TorchComm(dist, torch.device("cuda", local))
         comm.install(ctx)
+        try:
+            sharded_preflight(ctx, dist, torch.device("cuda", local))
+        except Exception as e:       # e.g. a collective this RCCL / torch build lacks: say so and fall back, on every rank alike
+            if args.mode == "sharded":
+                raise
+            sharded_error = "%s: %s" % (type(e).__name__, e)
+            TorchComm.uninstall(ctx)
+            comm, mode = None, "partitions"
+    if mode == "sharded":
+        data, off, elen, key = load_sharded_workload(args.pairs, rank, world, dist)
     else:
         data, off, elen, key = load_workload(args.pairs, seed=plan["seeds"][rank])
     db0 = ctx.upload_seqdb(data, off, elen, key, 0)
@@ -260,6 +286,8 @@ def main():
                                                "frac": (tot["kmermatcher_stage"][1] / (tot["kmermatcher_stage"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot["kmermatcher_stage"][0] > 0 else 0.0},
                          "module_wall_ms_per_step": [round(sum(w[i] for w in WALL[-args.steps:]) / args.steps, 3) for i in range(3)]},
         }
+        if sharded_error is not None:
+            line["sharded_mode_error"] = sharded_error
         if comm is not None:
             line["exchange"] = {"device_bytes_sent_per_step_rank0": comm.bytes_moved / max(args.steps, 1), "collective_calls_per_step": comm.calls / max(args.steps, 1),
                                 "ms_in_collectives_per_step_rank0": comm.seconds * 1e3 / max(args.steps, 1)}

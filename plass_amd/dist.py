@@ -1,10 +1,9 @@
 """One-process-per-GPU plumbing for the hot path (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in CPU tests).
 
-Round-1 sharding model: the read set is split into independent partitions, one per rank — each rank
-runs kmermatcher -> rescorediagonal -> assembleresults on its own partition with no data-path collective; only the
-barrier, the max-over-ranks step time and the sum of overlap counts cross ranks.  `partition_plan` also carries the
-k-mer-bucket ownership table the bucketed all-to-all (next step) will use, so that its arithmetic is
-already covered by the CPU tests.
+bench.py's control plane: process-group set-up, the barrier-bracketed step time (max over ranks) and the overlap count
+(sum over ranks).  The data path of a sharded run (one read set over the GPUs: DESIGN.md §6) is in plass_amd/shard.py;
+`partition_plan` / `exchange_records` serve the older `--mode partitions` run (independent read sets, no data-path
+collective) and the 2-rank gloo test of the count + record all-to-all.
 """
 import os
 
@@ -14,7 +13,8 @@ def env_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init(backend, rank, world, device=None):
+def init(backend, rank, world, device=None, timeout_s=None):
+    import datetime
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29511")
@@ -23,6 +23,8 @@ def init(backend, rank, world, device=None):
     kw = {}
     if device is not None:
         kw["device_id"] = device
+    if timeout_s:
+        kw["timeout"] = datetime.timedelta(seconds=timeout_s)      # a rank that died must not stall the others for 10 minutes
     dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return dist
 
