@@ -1314,11 +1314,16 @@ static int mergeExtended(plasship_ctx *ctx, uint32_t N, bool guided, int keepTar
                               guided ? dAaOff.as<uint64_t>() : (const uint64_t *) nullptr, dNewLen, dNewStart, dArena, dAaNewLen, dAaNewStart, dAaArena,
                               dMeta.as<ExtMeta>(), dPacked.as<char>(), guided ? dAaPacked.as<char>() : (char *) nullptr);
     PH_TRACE(st, "assemble: packed the extended sequences");
-    DevBuf gMeta; std::vector<uint64_t> rb;
-    int rc = commAllgathervBytes(ctx, dMeta.p, nExt * sizeof(ExtMeta), gMeta, rb); if (rc) return rc;
-    uint64_t M = 0; for (int r = 0; r < W; r++) M += rb[r] / sizeof(ExtMeta);
-    rc = commAllgathervBytes(ctx, dPacked.p, extBytes, gathered, rb); if (rc) return rc;
-    if (guided) { rc = commAllgathervBytes(ctx, dAaPacked.p, aaExtBytes, gatheredAa, rb); if (rc) return rc; }
+    DevBuf gMeta; std::vector<uint64_t> rb(W), rbMeta(W), rbSeq(W), rbAa(W);
+    uint64_t M = 0;
+    {   // sizes of all three payloads in one host all-gather
+        const uint64_t mine[3] = {nExt, extBytes, aaExtBytes}; std::vector<uint64_t> all(3 * (size_t) W);
+        const int rc0 = commAllgatherHost(ctx, mine, all.data(), 24); if (rc0) return rc0;
+        for (int r = 0; r < W; r++) { M += all[3 * (size_t) r]; rbMeta[r] = all[3 * (size_t) r] * sizeof(ExtMeta); rbSeq[r] = all[3 * (size_t) r + 1]; rbAa[r] = all[3 * (size_t) r + 2]; }
+    }
+    int rc = commAllgathervBytesKnown(ctx, dMeta.p, nExt * sizeof(ExtMeta), gMeta, rbMeta); if (rc) return rc;
+    rc = commAllgathervBytesKnown(ctx, dPacked.p, extBytes, gathered, rbSeq); if (rc) return rc;
+    if (guided) { rc = commAllgathervBytesKnown(ctx, dAaPacked.p, aaExtBytes, gatheredAa, rbAa); if (rc) return rc; }
     PH_TRACE(st, "assemble: gathered the extended sequences");
     // the gathered byte blocks are the ranks' packed blocks in rank order = the gathered meta order: starts are a prefix sum
     DevBuf dLens, dStart, dAaLens, dAaStart, dTmp2; const size_t tmp2Bytes = exclusiveScanTmpBytes(M + 2);

@@ -51,7 +51,7 @@ int commAllReduceMaxU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allRe
 int commAllReduceMinU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allReduceU64(ctx, v, n, [](uint64_t a, uint64_t b) { return a < b ? a : b; }); }
 
 int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *sendCount, size_t recordBytes, DevBuf &recv,
-                         uint64_t *recvTotal, uint64_t slackRecords) {
+                         uint64_t *recvTotal, uint64_t slackRecords, uint64_t *allTotal) {
     const plasship_comm *cm = commOf(ctx);
     if (!cm) { setError("sharded run: no communicator"); return PLASSHIP_ERR_ARG; }
     const int W = cm->world;
@@ -65,16 +65,24 @@ int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *s
     PH_CHECK(hipStreamSynchronize(ctx->stream));
     if (cm->alltoallv_dev(cm->user, dSend, sendBytes.data(), recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's alltoallv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     *recvTotal = tot;
+    if (allTotal) { uint64_t a = 0; for (uint64_t c : all) a += c; *allTotal = a; }
     return PLASSHIP_OK;
 }
 
 int commAllgathervBytes(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, std::vector<uint64_t> &recvBytes) {
     const plasship_comm *cm = commOf(ctx);
     if (!cm) { setError("sharded run: no communicator"); return PLASSHIP_ERR_ARG; }
-    const int W = cm->world;
-    recvBytes.assign(W, 0);
-    int rc = commAllgatherHost(ctx, &sendBytes, recvBytes.data(), 8);
+    recvBytes.assign(cm->world, 0);
+    const int rc = commAllgatherHost(ctx, &sendBytes, recvBytes.data(), 8);
     if (rc) return rc;
+    return commAllgathervBytesKnown(ctx, dSend, sendBytes, recv, recvBytes);
+}
+
+int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, const std::vector<uint64_t> &recvBytes) {
+    const plasship_comm *cm = commOf(ctx);
+    if (!cm) { setError("sharded run: no communicator"); return PLASSHIP_ERR_ARG; }
+    const int W = cm->world;
+    if ((int) recvBytes.size() != W || recvBytes[cm->rank] != sendBytes) { setError("sharded run: inconsistent all-gather sizes"); return PLASSHIP_ERR_ARG; }
     uint64_t tot = 0; for (int r = 0; r < W; r++) tot += recvBytes[r];
     if (recv.alloc(tot + 64) != hipSuccess) { setError("sharded run: out of device memory for the gather buffer"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipStreamSynchronize(ctx->stream));

@@ -148,10 +148,13 @@ int commAllReduceSumU64(plasship_ctx *ctx, uint64_t *v, size_t n);       // in p
 int commAllReduceMaxU64(plasship_ctx *ctx, uint64_t *v, size_t n);
 int commAllReduceMinU64(plasship_ctx *ctx, uint64_t *v, size_t n);
 // all-to-all(v) of fixed-size records laid out by destination; allocates `recv` (capacity (total + slackRecords) records)
+// *allTotal (optional): records sent by all ranks together
 int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *sendCount, size_t recordBytes, DevBuf &recv,
-                         uint64_t *recvTotal, uint64_t slackRecords);
+                         uint64_t *recvTotal, uint64_t slackRecords, uint64_t *allTotal = nullptr);
 // all-gather(v) of bytes; allocates `recv`; recvBytes[world] / recvOff[world+1] filled
 int commAllgathervBytes(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, std::vector<uint64_t> &recvBytes);
+// the same when every rank already knows everybody's size (recvBytes[world] given)
+int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, const std::vector<uint64_t> &recvBytes);
 // sets *differ when two key arrays (device, n entries) are not identical
 int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, size_t n, bool *differ);
 }

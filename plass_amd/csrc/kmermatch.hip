@@ -1395,7 +1395,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (NUCL) keyBits = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
     const int valueShift = std::max(0, keyBits - 12);
     void *bufA = dA.p, *bufB = dB.p;        // level 1 reads bufA (partTotal slots), writes bufB
-    uint64_t partTotal = total;
+    uint64_t partTotal = total, NkAll = 0;  // NkAll: records of the whole run (sharded)
     if (cm) {
         // exchange 1: records -> owner of the k-mer's hash bucket.  One partition pass by owner (it also drops the sentinels
         // and takes the value histogram / minimum key the single-GPU level 1 takes), then an all-to-all(v) of the W runs.
@@ -1420,7 +1420,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_TRACE(st, "kmermatch: owner partition of the k-mer records");
         traceBadIds<LONG>(ctx, "kmermatch: owner-partitioned records", dB.p, hStartO[nbO], N);
         uint64_t got = 0;
-        int rc = commAlltoallvRecords(ctx, dB.p, sendCount.data(), sizeof(R), dRxA, &got, 0);
+        int rc = commAlltoallvRecords(ctx, dB.p, sendCount.data(), sizeof(R), dRxA, &got, 0, &NkAll);
         if (rc) return rc;
         PH_TRACE(st, "kmermatch: exchange 1");
         traceBadIds<LONG>(ctx, "kmermatch: received records", dRxA.p, got, N);
@@ -1469,8 +1469,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
     const uint64_t Nk = hStart1[nB1];          // records on this rank
-    uint64_t NkG = Nk;                         // ... and of the whole run
-    if (cm) { const int rc = commAllReduceSumU64(ctx, &NkG, 1); if (rc) return rc; }
+    const uint64_t NkG = cm ? NkAll : Nk;      // ... and of the whole run (the count matrix of exchange 1 has it)
     void *cur = bufB, *other = bufA;
     const uint64_t *dBucketStart = dStart1.as<uint64_t>();
     if (b2 > 0) {
@@ -1527,10 +1526,16 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (cm) {
         // the stale-record check below is a property of the WHOLE run: N_m, N_k, the last (rep, target) run and the value
         // histogram are reduced over the ranks; every rank then takes the same decisions (and the same collectives)
-        uint64_t mx = hLastRun[0];
-        int rc = commAllReduceSumU64(ctx, &Nm, 1); if (rc) return rc;
-        rc = commAllReduceMaxU64(ctx, &mx, 1); if (rc) return rc;
-        rc = commAllReduceSumU64(ctx, hVHistG.data(), hVHistG.size()); if (rc) return rc;
+        // (one all-gather: [N_m, last run, histogram])
+        std::vector<uint64_t> mine(2 + (size_t) VH_BINS), all((2 + (size_t) VH_BINS) * (size_t) W);
+        mine[0] = Nm; mine[1] = hLastRun[0]; std::copy(hVHistG.begin(), hVHistG.end(), mine.begin() + 2);
+        const int rc = commAllgatherHost(ctx, mine.data(), all.data(), mine.size() * 8); if (rc) return rc;
+        uint64_t mx = 0; Nm = 0; std::fill(hVHistG.begin(), hVHistG.end(), 0);
+        for (int r = 0; r < W; r++) {
+            const uint64_t *row = all.data() + (size_t) r * mine.size();
+            Nm += row[0]; mx = std::max(mx, row[1]);
+            for (uint32_t b = 0; b < VH_BINS; b++) hVHistG[b] += row[2 + b];
+        }
         PH_CHECK(hipMemcpyAsync(dMaxRT.p, &mx, 8, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
         PH_COPY_SYNC(st, hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost);
