@@ -242,6 +242,18 @@ int plasship_aln2nucl(plasship_ctx *ctx, const plasship_seqdb *q_nucl, const pla
                       const plasship_seqdb *t_aa, const plasship_alns *a, const plasship_aln2nucl_params *par, plasship_alns **out,
                       plasship_aln2nucl_stats *stats);
 
+/* ---- findassemblystart  (replaces int findassemblystart(int, const char**, const Command&),
+ *      src/assembler/findassemblystart.cpp:35-176; positional args <seqDB> <alnDB> <outSeqDB>; called once, inside
+ *      iteration 0 of data/assemble.sh:110-141).  Sequences whose alignments agree on a "*M" start column are cut to
+ *      "*" + the sequence from that column on; all others are carried over.  Protein DBs only. ------------------------- */
+typedef struct plasship_findstart_stats {
+    uint64_t n_alignments;
+    uint64_t out_residues;
+    float ms_kernel;
+} plasship_findstart_stats;
+int plasship_find_assembly_start(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *a, plasship_seqdb **out,
+                                 plasship_findstart_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@
 //   plass_oracle assembleresults|nuclassembleresults <seqDB> <alnDB> <outDB> [flags]
 //   plass_oracle guidedassembleresults <nuclDB> <aaDB> <nuclAlnDB> <outNuclDB> <outAaDB> [flags]
 //   plass_oracle proteinaln2nucl <qNuclDB> <tNuclDB> <qAaDB> <tAaDB> <alnDB> <outAlnDB> [flags]
+//   plass_oracle findassemblystart <seqDB> <alnDB> <outSeqDB>
 #include "oracle.hpp"
 #include <chrono>
 #include <cstdio>
@@ -120,6 +121,14 @@ int main(int argc, char **argv) {
         if (!proteinaln2nucl(qn, same ? qn : tn, qa, same ? qa : ta, aln, par, out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         fprintf(stderr, "oracle proteinaln2nucl: %.3f s\n", now() - t0);
         if (!writeDB(pos[5], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "findassemblystart") {
+        if (pos.size() != 3) { fprintf(stderr, "findassemblystart <seqDB> <alnDB> <outSeqDB>\n"); return 1; }
+        DB seq, aln, out;
+        if (!readDB(pos[0], seq, err) || !readDB(pos[1], aln, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        double t0 = now();
+        if (!findassemblystart(seq, aln, out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        fprintf(stderr, "oracle findassemblystart: %.3f s\n", now() - t0);
+        if (!writeDB(pos[2], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else { fprintf(stderr, "unknown module %s\n", mod.c_str()); return 1; }
     return 0;
 }

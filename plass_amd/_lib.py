@@ -58,6 +58,10 @@ class Aln2NuclStats(C.Structure):
     _fields_ = [("n_alignments", C.c_uint64), ("ms_kernel", C.c_float)]
 
 
+class FindStartStats(C.Structure):
+    _fields_ = [("n_alignments", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float)]
+
+
 class AlnRecord(C.Structure):
     _fields_ = [("query_key", C.c_uint32), ("target_key", C.c_uint32), ("bit_score", C.c_int32), ("raw_score", C.c_int32),
                 ("seq_id", C.c_float), ("q_start", C.c_int32), ("q_end", C.c_int32), ("q_len", C.c_int32),
@@ -96,6 +100,7 @@ SYMBOLS = [
     ("plasship_assemble", C.c_int, [P, P, P, C.POINTER(_AssembleParams), C.POINTER(P), C.POINTER(AssembleStats)]),
     ("plasship_guided_assemble", C.c_int, [P, P, P, P, C.POINTER(_AssembleParams), C.POINTER(P), C.POINTER(P), C.POINTER(AssembleStats)]),
     ("plasship_aln2nucl", C.c_int, [P, P, P, P, P, P, C.POINTER(_Aln2NuclParams), C.POINTER(P), C.POINTER(Aln2NuclStats)]),
+    ("plasship_find_assembly_start", C.c_int, [P, P, P, C.POINTER(P), C.POINTER(FindStartStats)]),
 ]
 
 _lib = None
@@ -249,6 +254,13 @@ class Context:
         h = P(); st = Aln2NuclStats(); cp = _Aln2NuclParams(gap_open, gap_extend)
         _check(self.lib.plasship_aln2nucl(self.h, nucl_db.h, nucl_db.h, aa_db.h, aa_db.h, alns.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_aln2nucl")
         return Alignments(self, h, nucl_db, nucl_db), st
+
+    def findassemblystart(self, db, alns):
+        """(protein DB, its alignments) -> DB with the consensus "*M" starts cut in; reference module findassemblystart,
+        run once inside iteration 0 of `plass assemble` (data/assemble.sh:110-141)"""
+        h = P(); st = FindStartStats()
+        _check(self.lib.plasship_find_assembly_start(self.h, db.h, alns.h, C.byref(h), C.byref(st)), "plasship_find_assembly_start")
+        return SeqDB(self, h), st
 
     # the library picks the variant from the DB type; this name mirrors the reference module for nucleotide DBs
     def nuclassembleresults(self, db, alns, par=None):

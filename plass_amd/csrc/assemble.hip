@@ -1241,9 +1241,9 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
 }
 
 // builds one output DB (extended entries from the arena + carried-over entries of `db`), entries in key order
-static int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
-                         const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                         const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr) {
+int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
+                            const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
+                            const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent) {
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();

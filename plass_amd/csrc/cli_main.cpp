@@ -40,7 +40,7 @@ static int fail(const char *what) { fprintf(stdout, "%s: %s\n", what, plasship_l
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl> <dbs…> [flags]\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl|findassemblystart> <dbs…> [flags]\n"); return EXIT_FAILURE; }
     const std::string mod = argv[1];
     Flags f; std::vector<std::string> pos;
     if (mod == "kmermatcher") f.covThr = 0.8f;   // setLinearFilterDefault (kmermatcher.cpp:566-573); workflows pass -c
@@ -156,6 +156,16 @@ int main(int argc, char **argv) {
         fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
         if (plasship_alns_write(ctx, o, pos[5].c_str())) return fail("proteinaln2nucl");
         plasship_alns_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, aa); plasship_seqdb_free(ctx, nu);
+    } else if (mod == "findassemblystart") {
+        if (pos.size() != 3) { fprintf(stdout, "findassemblystart <i:sequenceDB> <i:alnDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
+        plasship_seqdb *db = nullptr, *o = nullptr; plasship_alns *al = nullptr;
+        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("findassemblystart");
+        if (plasship_alns_read(ctx, db, pos[1].c_str(), &al)) return fail("findassemblystart");
+        plasship_findstart_stats st; memset(&st, 0, sizeof(st));
+        if (plasship_find_assembly_start(ctx, db, al, &o, &st)) return fail("findassemblystart");
+        fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
+        if (plasship_seqdb_write(ctx, o, pos[2].c_str())) return fail("findassemblystart");
+        plasship_seqdb_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, db);
     } else {
         fprintf(stdout, "plass-hip: module \"%s\" is not part of the GPU hot path (use the reference binary for it)\n", mod.c_str());
         rc = EXIT_FAILURE;

@@ -155,6 +155,11 @@ int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *s
 int commAllgathervBytes(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, std::vector<uint64_t> &recvBytes);
 // the same when every rank already knows everybody's size (recvBytes[world] given)
 int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, const std::vector<uint64_t> &recvBytes);
+// builds an output sequence DB in key order (assemble.hip): entries with flag 0x20 come from `dArena + dNewStart[id]` (dNewLen[id]
+// residues), the others are carried over from `db` (dropped when !keepTarget and flag 0x80 is set)
+int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
+                  const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
+                  const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr);
 // sets *differ when two key arrays (device, n entries) are not identical
 int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, size_t n, bool *differ);
 }

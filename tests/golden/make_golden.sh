@@ -52,6 +52,16 @@ aln_0_mode2_bt: rescorediagonal --rescore-mode 2 -a 1 on pref_0; seq_1_keeptarge
 M
 tar -C $W -czf $HERE/example_aa.tar.gz aa
 
+# ---------- findassemblystart (row N3): iteration 0 of data/assemble.sh:110-150 on the protein example -----------
+F=$W/fs; mkdir -p $F
+$PLASS findassemblystart $S/seq_0 $S/aln_0 $W/corr $Q >> $W/aa.log
+$CANON $W/corr $F/corrected_seqs
+$PLASS kmermatcher $F/corrected_seqs $W/pc $KM --hash-shift 67 --include-only-extendable 0 $Q >> $W/aa.log
+$PLASS rescorediagonal $F/corrected_seqs $F/corrected_seqs $W/pc $W/ac $RS $Q >> $W/aa.log
+$PLASS assembleresults $F/corrected_seqs $W/ac $W/as0 $AS $Q >> $W/aa.log
+$CANON $W/as0 $F/assembly_0
+# (guided_corrected_seqs = findassemblystart on guided/aa_0 + guided/aln_0 is appended after the guided section below)
+
 # ---------- nucleotide example (penguin nuclassemble stage, config C5's nucleotide path) -----------
 $PENGUIN nuclassemble $EX/reads_1.fastq.gz $EX/reads_2.fastq.gz $W/outn.fas $W/tmpn --num-iterations 1 \
        --remove-tmp-files 0 --delete-tmp-inc 0 $Q > $W/nucl.log
@@ -135,3 +145,9 @@ done
 tar -C $W -czf $HERE/long_nucl.tar.gz longnucl
 ls -la $HERE/*.tar.gz
 rm -rf $W
+
+# ---------- findassemblystart on the translated ORFs of the guided example (alignment lines with backtrace) ----------
+$PLASS findassemblystart $W/guided/aa_0 $W/guided/aln_0 $W/gcorr $Q >> $W/aa.log
+$CANON $W/gcorr $W/fs/guided_corrected_seqs
+printf 'corrected_seqs = plass findassemblystart aa/seq_0 aa/aln_0; assembly_0 = kmermatcher + rescorediagonal + assembleresults on it\nguided_corrected_seqs = plass findassemblystart guided/aa_0 guided/aln_0\n' > $W/fs/MANIFEST
+tar -C $W -czf $HERE/findstart.tar.gz fs

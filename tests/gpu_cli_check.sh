@@ -9,6 +9,7 @@ rm -rf "$W"; mkdir -p "$W"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_aa.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_nucl.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_guided.tar.gz"
+tar -C "$W" -xzf "$ROOT/tests/golden/findstart.tar.gz"
 P="timeout 300 $ROOT/plass_amd/plass-hip"
 D="python3 $ROOT/tools/dbdiff.py"
 fails=0
@@ -52,5 +53,10 @@ check $S/aln_nucl_0 $W/o_aln_nucl "proteinaln2nucl"
 $P guidedassembleresults $S/nucl_0 $S/aa_0 $S/aln_nucl_0 $W/o_nucl $W/o_aa --min-seq-id 0.99 --max-seq-len 200000 --keep-target 1 --rescore-mode 3 | tail -2 || echo "guidedassembleresults rc=$?"
 check $S/nucl_1 $W/o_nucl "guidedassembleresults nucl"
 check $S/aa_1 $W/o_aa "guidedassembleresults aa"
+# iteration 0 of plass assemble runs findassemblystart between two kmermatcher / rescorediagonal passes (data/assemble.sh:110-141)
+$P findassemblystart $W/aa/seq_0 $W/aa/aln_0 $W/o_corr --threads 4 | tail -2 || echo "findassemblystart rc=$?"
+check $W/fs/corrected_seqs $W/o_corr "findassemblystart"
+$P findassemblystart $W/guided/aa_0 $W/guided/aln_0 $W/o_gcorr --threads 4 | tail -2 || echo "findassemblystart rc=$?"
+check $W/fs/guided_corrected_seqs $W/o_gcorr "findassemblystart (ORFs, alignments with backtrace)"
 echo "failures: $fails"
 exit $fails

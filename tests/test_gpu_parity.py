@@ -243,6 +243,68 @@ def test_golden_guided_chained_on_device(ctx, golden, tmp_path):
         nu, aa = nu2, aa2
 
 
+def test_golden_findassemblystart(ctx, golden, tmp_path):
+    """row N3 on the reference's DBs, and iteration 0 of `plass assemble` as data/assemble.sh:84-150 runs it, chained on the
+    device: kmermatcher -> rescorediagonal -> findassemblystart -> kmermatcher -> rescorediagonal -> assembleresults"""
+    import plass_amd
+    s, g, f = os.path.join(golden, "aa"), os.path.join(golden, "guided"), os.path.join(golden, "fs")
+    db = ctx.read_seqdb(f"{s}/seq_0")
+    out, st = ctx.findassemblystart(db, ctx.read_alndb(db, f"{s}/aln_0"))
+    out.write(tmp_path / "corr")
+    assert_same_db(f"{f}/corrected_seqs", tmp_path / "corr", "findassemblystart")
+    assert st.n_alignments > 7255
+    gdb = ctx.read_seqdb(f"{g}/aa_0")
+    gout, _ = ctx.findassemblystart(gdb, ctx.read_alndb(gdb, f"{g}/aln_0"))
+    gout.write(tmp_path / "gcorr")
+    assert_same_db(f"{f}/guided_corrected_seqs", tmp_path / "gcorr", "findassemblystart on ORFs")
+    rs, asp = plass_amd.RescoreParams(min_seq_id=0.9), plass_amd.AssembleParams(min_seq_id=0.9)
+    cands, _ = ctx.kmermatcher(db, km_params(0))
+    alns, _ = ctx.rescorediagonal(db, db, cands, rs)
+    corr, _ = ctx.findassemblystart(db, alns)
+    cands2, _ = ctx.kmermatcher(corr, km_params(0))
+    alns2, _ = ctx.rescorediagonal(corr, corr, cands2, rs)
+    as0, _ = ctx.assembleresults(corr, alns2, asp)
+    as0.write(tmp_path / "as0")
+    assert_same_db(f"{f}/assembly_0", tmp_path / "as0", "iteration 0 chained on the device")
+
+
+def test_findassemblystart_vs_oracle(ctx, oracle_bin, tmp_path):
+    """hostile start columns: fragments of one protein family with '*M' / 'xM' / no M at moving offsets, M at position 0,
+    several M, an alignment-free sequence — against the oracle"""
+    import plass_amd
+    from plass_amd import synth
+    rng = np.random.default_rng(17)
+    aa = "ACDEFGHIKLNPQRSTVWY"                                  # no M: the M columns are placed by hand
+    seqs = []
+    for fam in range(300):
+        core = "".join(aa[i] for i in rng.integers(0, len(aa), 90))
+        mpos = int(rng.integers(5, 40))
+        for _ in range(int(rng.integers(2, 9))):
+            a, b = int(rng.integers(0, 30)), int(rng.integers(60, 90))
+            frag = list(core[a:b])
+            kind = int(rng.integers(0, 5))
+            if mpos >= a + 1 and mpos < b and kind < 4:
+                frag[mpos - a] = "M"
+                if kind < 2:
+                    frag[mpos - a - 1] = "*"
+                if kind == 3 and mpos - a + 7 < len(frag):
+                    frag[mpos - a + 7] = "M"
+            if kind == 4 and rng.integers(0, 2):
+                frag[0] = "M"
+            seqs.append("".join(frag))
+    seqs.append("MKV")
+    _write_fasta_like_db(tmp_path / "seq", seqs)
+    run_oracle(oracle_bin, ["kmermatcher", tmp_path / "seq", tmp_path / "pref"] + AA_KM + aa_iter_flags(0))
+    run_oracle(oracle_bin, ["rescorediagonal", tmp_path / "seq", tmp_path / "seq", tmp_path / "pref", tmp_path / "aln"] + AA_RS)
+    run_oracle(oracle_bin, ["findassemblystart", tmp_path / "seq", tmp_path / "aln", tmp_path / "o_corr"])
+    db = ctx.read_seqdb(tmp_path / "seq")
+    out, _ = ctx.findassemblystart(db, ctx.read_alndb(db, tmp_path / "aln"))
+    out.write(tmp_path / "g_corr")
+    assert_same_db(tmp_path / "o_corr", tmp_path / "g_corr", "findassemblystart hostile")
+    _, e0 = read_db(tmp_path / "seq"); _, e1 = read_db(tmp_path / "g_corr")
+    assert sum(1 for k in e0 if e0[k] != e1[k]) > 50            # the case is not vacuous
+
+
 @pytest.mark.parametrize("case", [1, 2, 3, 4])
 def test_golden_stale_scan_quirk(ctx, golden, tmp_path, case):
     """inputs on which the reference's run scan continues into stale records behind the compaction point

@@ -214,6 +214,30 @@ def test_sharded_adversarial_inputs(ctxs, golden, tmp_path):
             assert_same_db(tmp_path / f"{kind}_expect", tmp_path / f"{kind}_r{r}", f"adversarial {kind} rank {r}")
 
 
+def test_sharded_findassemblystart_iteration0(ctxs, golden, tmp_path):
+    """iteration 0 of `plass assemble` (kmermatcher, rescorediagonal, findassemblystart, kmermatcher, rescorediagonal,
+    assembleresults) on 3 ranks: the start votes of the owned queries are max-reduced over the ranks"""
+    import plass_amd
+    s, f = os.path.join(golden, "aa"), os.path.join(golden, "fs")
+    rs, asp = plass_amd.RescoreParams(min_seq_id=0.9), plass_amd.AssembleParams(min_seq_id=0.9)
+
+    def work(rank, ctx):
+        db = ctx.read_seqdb(f"{s}/seq_0")
+        cands, _ = ctx.kmermatcher(db, km_params(0))
+        alns, _ = ctx.rescorediagonal(db, db, cands, rs)
+        corr, _ = ctx.findassemblystart(db, alns)
+        corr.write(tmp_path / f"r{rank}_corr")
+        cands2, _ = ctx.kmermatcher(corr, km_params(0))
+        alns2, _ = ctx.rescorediagonal(corr, corr, cands2, rs)
+        as0, _ = ctx.assembleresults(corr, alns2, asp)
+        as0.write(tmp_path / f"r{rank}_as0")
+
+    _run(ctxs, 3, work)
+    for r in range(3):
+        assert_same_db(f"{f}/corrected_seqs", tmp_path / f"r{r}_corr", f"findassemblystart rank {r}")
+        assert_same_db(f"{f}/assembly_0", tmp_path / f"r{r}_as0", f"iteration 0 rank {r}")
+
+
 def test_sharded_synthetic_three_ranks(ctxs, tmp_path):
     """40 k read pairs (130 k protein fragments), 3 iterations on 3 ranks against the single-context run"""
     import plass_amd

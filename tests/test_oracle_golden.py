@@ -145,3 +145,17 @@ def test_oracle_stale_scan_quirk(oracle_bin, golden, tmp_path, case):
     run_oracle(oracle_bin, ["kmermatcher", f"{d}/seq", tmp_path / "pref2"] + flags + ["--oracle-no-stale-scan", "1"])
     with pytest.raises(AssertionError):          # the fixture really exercises the quirk
         assert_same_db(f"{d}/pref", tmp_path / "pref2", "without the stale scan")
+
+
+def test_oracle_findassemblystart(oracle_bin, golden, tmp_path):
+    """row N3: the consensus "*M" start detection of iteration 0 (77 of 7 255 example fragments are cut; 14 of the
+    translated ORFs of the guided example), and the iteration-0 chain of data/assemble.sh on the corrected sequences"""
+    s, g, f = os.path.join(golden, "aa"), os.path.join(golden, "guided"), os.path.join(golden, "fs")
+    run_oracle(oracle_bin, ["findassemblystart", f"{s}/seq_0", f"{s}/aln_0", tmp_path / "corr"])
+    assert_same_db(f"{f}/corrected_seqs", tmp_path / "corr", "findassemblystart")
+    run_oracle(oracle_bin, ["findassemblystart", f"{g}/aa_0", f"{g}/aln_0", tmp_path / "gcorr"])
+    assert_same_db(f"{f}/guided_corrected_seqs", tmp_path / "gcorr", "findassemblystart on ORFs")
+    run_oracle(oracle_bin, ["kmermatcher", tmp_path / "corr", tmp_path / "pref"] + AA_KM + aa_iter_flags(0))
+    run_oracle(oracle_bin, ["rescorediagonal", tmp_path / "corr", tmp_path / "corr", tmp_path / "pref", tmp_path / "aln"] + AA_RS)
+    run_oracle(oracle_bin, ["assembleresults", tmp_path / "corr", tmp_path / "aln", tmp_path / "as0"] + AA_AS)
+    assert_same_db(f"{f}/assembly_0", tmp_path / "as0", "iteration 0 on the corrected sequences")
