@@ -143,11 +143,10 @@ for i in 0 1; do
   rm -f $W/p* $W/a.* $W/a $W/s $W/s.* 2>/dev/null || true
 done
 tar -C $W -czf $HERE/long_nucl.tar.gz longnucl
-ls -la $HERE/*.tar.gz
-rm -rf $W
-
 # ---------- findassemblystart on the translated ORFs of the guided example (alignment lines with backtrace) ----------
 $PLASS findassemblystart $W/guided/aa_0 $W/guided/aln_0 $W/gcorr $Q >> $W/aa.log
 $CANON $W/gcorr $W/fs/guided_corrected_seqs
 printf 'corrected_seqs = plass findassemblystart aa/seq_0 aa/aln_0; assembly_0 = kmermatcher + rescorediagonal + assembleresults on it\nguided_corrected_seqs = plass findassemblystart guided/aa_0 guided/aln_0\n' > $W/fs/MANIFEST
 tar -C $W -czf $HERE/findstart.tar.gz fs
+ls -la $HERE/*.tar.gz
+rm -rf $W
