@@ -254,6 +254,23 @@ typedef struct plasship_findstart_stats {
 int plasship_find_assembly_start(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *a, plasship_seqdb **out,
                                  plasship_findstart_stats *stats);
 
+/* ---- cyclecheck  (replaces int cyclecheck(int, const char**, const Command&), src/assembler/cyclecheck.cpp:30-291;
+ *      positional args <sequenceDB> <cycleDB>, flags --max-seq-len --chop-cycle; called after every nuclassembleresults of
+ *      the penguin workflows, data/nuclassemble.sh:19-61,132).  out_cycle = the circular / terminally redundant contigs
+ *      (cut at the split diagonal with chop_cycle); out_rest (may be NULL) = all other sequences, what the workflow's
+ *      "<db>_noneCycle" is and the next iteration continues with.  Nucleotide DBs only, k = 22 like the reference. ------ */
+typedef struct plasship_cyclecheck_params {
+    uint64_t max_seq_len;  /* --max-seq-len : sequences of this length or more are skipped (not reported)             */
+    int32_t chop_cycle;    /* --chop-cycle  : write only the first <split diagonal> residues                           */
+} plasship_cyclecheck_params;
+typedef struct plasship_cyclecheck_stats {
+    uint64_t n_cyclic;
+    uint64_t n_wave_small, n_wave_large, n_block;   /* sequences per kernel tier (<= 190 nt, <= 1536 nt, longer)       */
+    float ms_kernel;
+} plasship_cyclecheck_stats;
+int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_cyclecheck_params *par, plasship_seqdb **out_cycle,
+                        plasship_seqdb **out_rest, plasship_cyclecheck_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

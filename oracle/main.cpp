@@ -7,6 +7,7 @@
 //   plass_oracle guidedassembleresults <nuclDB> <aaDB> <nuclAlnDB> <outNuclDB> <outAaDB> [flags]
 //   plass_oracle proteinaln2nucl <qNuclDB> <tNuclDB> <qAaDB> <tAaDB> <alnDB> <outAlnDB> [flags]
 //   plass_oracle findassemblystart <seqDB> <alnDB> <outSeqDB>
+//   plass_oracle cyclecheck <seqDB> <outCycleDB> [--max-seq-len N --chop-cycle 0|1]
 #include "oracle.hpp"
 #include <chrono>
 #include <cstdio>
@@ -31,6 +32,7 @@ static bool multiParam(const std::string &v, const char *which, std::string &out
     return false;
 }
 
+static bool chopCycle = false;      // --chop-cycle (cyclecheck; setCycleCheckDefaults: off unless the workflow passes it)
 static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<std::string> &pos) {
     for (int i = from; i < argc; i++) {
         std::string a = argv[i];
@@ -58,6 +60,7 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
             else if (a == "--add-self-matches") par.includeIdentity = atoi(v.c_str()) != 0;
             else if (a == "--max-seq-len") par.maxSeqLen = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--keep-target") par.keepTarget = atoi(v.c_str()) != 0;
+            else if (a == "--chop-cycle") chopCycle = atoi(v.c_str()) != 0;
             else if (a == "--oracle-no-stale-scan") par.debugNoStaleScan = atoi(v.c_str()) != 0;
             else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) par.gapOpenNucl = atoi(t.c_str()); }
             else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) par.gapExtendNucl = atoi(t.c_str()); }
@@ -129,6 +132,14 @@ int main(int argc, char **argv) {
         if (!findassemblystart(seq, aln, out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         fprintf(stderr, "oracle findassemblystart: %.3f s\n", now() - t0);
         if (!writeDB(pos[2], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "cyclecheck") {
+        if (pos.size() != 2) { fprintf(stderr, "cyclecheck <seqDB> <outCycleDB> [--max-seq-len N --chop-cycle 0|1]\n"); return 1; }
+        DB seq, out;
+        if (!readDB(pos[0], seq, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        double t0 = now();
+        if (!cyclecheck(seq, par, chopCycle, out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        fprintf(stderr, "oracle cyclecheck: %.3f s\n", now() - t0);
+        if (!writeDB(pos[1], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else { fprintf(stderr, "unknown module %s\n", mod.c_str()); return 1; }
     return 0;
 }

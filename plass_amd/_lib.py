@@ -62,6 +62,14 @@ class FindStartStats(C.Structure):
     _fields_ = [("n_alignments", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float)]
 
 
+class _CyclecheckParams(C.Structure):
+    _fields_ = [("max_seq_len", C.c_uint64), ("chop_cycle", C.c_int32)]
+
+
+class CyclecheckStats(C.Structure):
+    _fields_ = [("n_cyclic", C.c_uint64), ("n_wave_small", C.c_uint64), ("n_wave_large", C.c_uint64), ("n_block", C.c_uint64), ("ms_kernel", C.c_float)]
+
+
 class AlnRecord(C.Structure):
     _fields_ = [("query_key", C.c_uint32), ("target_key", C.c_uint32), ("bit_score", C.c_int32), ("raw_score", C.c_int32),
                 ("seq_id", C.c_float), ("q_start", C.c_int32), ("q_end", C.c_int32), ("q_len", C.c_int32),
@@ -101,6 +109,7 @@ SYMBOLS = [
     ("plasship_guided_assemble", C.c_int, [P, P, P, P, C.POINTER(_AssembleParams), C.POINTER(P), C.POINTER(P), C.POINTER(AssembleStats)]),
     ("plasship_aln2nucl", C.c_int, [P, P, P, P, P, P, C.POINTER(_Aln2NuclParams), C.POINTER(P), C.POINTER(Aln2NuclStats)]),
     ("plasship_find_assembly_start", C.c_int, [P, P, P, C.POINTER(P), C.POINTER(FindStartStats)]),
+    ("plasship_cyclecheck", C.c_int, [P, P, C.POINTER(_CyclecheckParams), C.POINTER(P), C.POINTER(P), C.POINTER(CyclecheckStats)]),
 ]
 
 _lib = None
@@ -261,6 +270,13 @@ class Context:
         h = P(); st = FindStartStats()
         _check(self.lib.plasship_find_assembly_start(self.h, db.h, alns.h, C.byref(h), C.byref(st)), "plasship_find_assembly_start")
         return SeqDB(self, h), st
+
+    def cyclecheck(self, db, max_seq_len=200000, chop_cycle=False, with_rest=False):
+        """nucleotide DB -> DB of the circular / terminally redundant contigs (and, with_rest, the DB of all others);
+        reference module cyclecheck, run after every nuclassembleresults of the penguin workflows"""
+        hc = P(); hr = P(); st = CyclecheckStats(); cp = _CyclecheckParams(max_seq_len, int(chop_cycle))
+        _check(self.lib.plasship_cyclecheck(self.h, db.h, C.byref(cp), C.byref(hc), C.byref(hr) if with_rest else None, C.byref(st)), "plasship_cyclecheck")
+        return (SeqDB(self, hc), SeqDB(self, hr), st) if with_rest else (SeqDB(self, hc), st)
 
     # the library picks the variant from the DB type; this name mirrors the reference module for nucleotide DBs
     def nuclassembleresults(self, db, alns, par=None):

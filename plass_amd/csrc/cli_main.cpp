@@ -34,13 +34,14 @@ struct Flags {
     double evalThr = 1e-5;
     unsigned long long maxSeqLen = 65535;
     int gapOpenNucl = 5, gapExtendNucl = 2;
+    int chopCycle = 0;                   // cyclecheck: setCycleCheckDefaults (cyclecheck.cpp:25-28); the workflow passes --chop-cycle
 };
 
 static int fail(const char *what) { fprintf(stdout, "%s: %s\n", what, plasship_last_error()); return EXIT_FAILURE; }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl|findassemblystart> <dbs…> [flags]\n"); return EXIT_FAILURE; }
+    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl|findassemblystart|cyclecheck> <dbs…> [flags]\n"); return EXIT_FAILURE; }
     const std::string mod = argv[1];
     Flags f; std::vector<std::string> pos;
     if (mod == "kmermatcher") f.covThr = 0.8f;   // setLinearFilterDefault (kmermatcher.cpp:566-573); workflows pass -c
@@ -66,6 +67,7 @@ int main(int argc, char **argv) {
             else if (a == "-a") f.addBt = atoi(v.c_str());
             else if (a == "--add-self-matches") f.addSelf = atoi(v.c_str());
             else if (a == "--max-seq-len") f.maxSeqLen = strtoull(v.c_str(), nullptr, 10);
+            else if (a == "--chop-cycle") f.chopCycle = atoi(v.c_str());
             else if (a == "--keep-target") f.keepTarget = atoi(v.c_str());
             else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) f.gapOpenNucl = atoi(t.c_str()); }
             else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) f.gapExtendNucl = atoi(t.c_str()); }
@@ -166,6 +168,16 @@ int main(int argc, char **argv) {
         fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
         if (plasship_seqdb_write(ctx, o, pos[2].c_str())) return fail("findassemblystart");
         plasship_seqdb_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, db);
+    } else if (mod == "cyclecheck") {
+        if (pos.size() != 2) { fprintf(stdout, "cyclecheck <i:sequenceDB> <o:sequenceDBcycle>\n"); return EXIT_FAILURE; }
+        plasship_seqdb *db = nullptr, *o = nullptr;
+        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("cyclecheck");
+        plasship_cyclecheck_params p; p.max_seq_len = f.maxSeqLen; p.chop_cycle = f.chopCycle;
+        plasship_cyclecheck_stats st; memset(&st, 0, sizeof(st));
+        if (plasship_cyclecheck(ctx, db, &p, &o, nullptr, &st)) return fail("cyclecheck");
+        fprintf(stdout, "circular: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_cyclic, st.ms_kernel);
+        if (plasship_seqdb_write(ctx, o, pos[1].c_str())) return fail("cyclecheck");
+        plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
     } else {
         fprintf(stdout, "plass-hip: module \"%s\" is not part of the GPU hot path (use the reference binary for it)\n", mod.c_str());
         rc = EXIT_FAILURE;

@@ -148,5 +148,16 @@ $PLASS findassemblystart $W/guided/aa_0 $W/guided/aln_0 $W/gcorr $Q >> $W/aa.log
 $CANON $W/gcorr $W/fs/guided_corrected_seqs
 printf 'corrected_seqs = plass findassemblystart aa/seq_0 aa/aln_0; assembly_0 = kmermatcher + rescorediagonal + assembleresults on it\nguided_corrected_seqs = plass findassemblystart guided/aa_0 guided/aln_0\n' > $W/fs/MANIFEST
 tar -C $W -czf $HERE/findstart.tar.gz fs
+# ---------- cyclecheck (row N4): crafted circular / linear contigs + the example's contigs ----------
+C=$W/cyc; mkdir -p $C
+python3 $HERE/make_cyclecheck.py $C/in
+for c in 0 1; do
+  $PENGUIN cyclecheck $C/in $W/cy --max-seq-len 50000 --chop-cycle $c $Q > /dev/null; $CANON $W/cy $C/cycle_chop$c; rm -f $W/cy $W/cy.*
+done
+for d in nucl/seq_2 longnucl/seq_0 longnucl/seq_2; do
+  $PENGUIN cyclecheck $W/$d $W/cy --max-seq-len 200000 --chop-cycle 1 $Q > /dev/null; $CANON $W/cy $C/$(echo $d | tr / _)_cycle; rm -f $W/cy $W/cy.*
+done
+printf 'in = make_cyclecheck.py; cycle_chop0|1 = penguin cyclecheck in --max-seq-len 50000 --chop-cycle 0|1; <db>_cycle = penguin cyclecheck <db> --max-seq-len 200000 --chop-cycle 1\n' > $C/MANIFEST
+tar -C $W -czf $HERE/cyclecheck.tar.gz cyc
 ls -la $HERE/*.tar.gz
 rm -rf $W

@@ -10,6 +10,7 @@ tar -C "$W" -xzf "$ROOT/tests/golden/example_aa.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_nucl.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_guided.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/findstart.tar.gz"
+tar -C "$W" -xzf "$ROOT/tests/golden/cyclecheck.tar.gz"
 P="timeout 300 $ROOT/plass_amd/plass-hip"
 D="python3 $ROOT/tools/dbdiff.py"
 fails=0
@@ -58,5 +59,10 @@ $P findassemblystart $W/aa/seq_0 $W/aa/aln_0 $W/o_corr --threads 4 | tail -2 || 
 check $W/fs/corrected_seqs $W/o_corr "findassemblystart"
 $P findassemblystart $W/guided/aa_0 $W/guided/aln_0 $W/o_gcorr --threads 4 | tail -2 || echo "findassemblystart rc=$?"
 check $W/fs/guided_corrected_seqs $W/o_gcorr "findassemblystart (ORFs, alignments with backtrace)"
+# penguin runs cyclecheck after every nuclassembleresults (data/nuclassemble.sh:19-61,132)
+for c in 0 1; do
+  $P cyclecheck $W/cyc/in $W/o_cyc$c --max-seq-len 50000 --chop-cycle $c --threads 4 | tail -2 || echo "cyclecheck rc=$?"
+  check $W/cyc/cycle_chop$c $W/o_cyc$c "cyclecheck --chop-cycle $c"
+done
 echo "failures: $fails"
 exit $fails

@@ -243,6 +243,63 @@ def test_golden_guided_chained_on_device(ctx, golden, tmp_path):
         nu, aa = nu2, aa2
 
 
+def test_golden_cyclecheck(ctx, golden, tmp_path):
+    """row N4 on the reference's outputs: both --chop-cycle modes, the remainder DB the workflow continues with, and the
+    example's contigs (none circular: empty DBs)"""
+    c = os.path.join(golden, "cyc")
+    db = ctx.read_seqdb(f"{c}/in")
+    for chop in (False, True):
+        cyc, rest, st = ctx.cyclecheck(db, max_seq_len=50000, chop_cycle=chop, with_rest=True)
+        cyc.write(tmp_path / f"c{int(chop)}"); rest.write(tmp_path / f"r{int(chop)}")
+        assert_same_db(f"{c}/cycle_chop{int(chop)}", tmp_path / f"c{int(chop)}", f"cyclecheck chop {chop}")
+        assert st.n_cyclic == 64 and st.n_wave_small > 300 and st.n_wave_large > 10 and st.n_block > 30
+        _, ein = read_db(f"{c}/in"); _, ec = read_db(tmp_path / f"c{int(chop)}"); _, er = read_db(tmp_path / f"r{int(chop)}")
+        assert set(ec) | set(er) == set(ein) and not (set(ec) & set(er)) and all(er[k] == ein[k] for k in er)
+    for src, name in ((os.path.join(golden, "nucl", "seq_2"), "nucl_seq_2"), (os.path.join(golden, "longnucl", "seq_0"), "longnucl_seq_0"),
+                      (os.path.join(golden, "longnucl", "seq_2"), "longnucl_seq_2")):
+        cyc, _ = ctx.cyclecheck(ctx.read_seqdb(src), max_seq_len=200000, chop_cycle=True)
+        cyc.write(tmp_path / name)
+        assert_same_db(f"{c}/{name}_cycle", tmp_path / name, f"cyclecheck {name}")
+
+
+def test_cyclecheck_vs_oracle(ctx, oracle_bin, tmp_path):
+    """reads + random circular / linear / repetitive contigs of all kernel tiers against the oracle"""
+    from plass_amd import synth
+    rng = np.random.default_rng(23)
+    B = "ACGT"
+    rnd = lambda n: "".join(B[i] for i in rng.integers(0, 4, n))
+    seqs = []
+    for _ in range(120):
+        n = int(rng.integers(40, 60000) if rng.random() < 0.3 else rng.integers(40, 3000))
+        g = rnd(n)
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            seqs.append(g)
+        elif kind == 1:
+            seqs.append(g + g[:int(rng.integers(22, n + 1))])
+        elif kind == 2:
+            x = g[:int(rng.integers(22, n + 1))]
+            seqs.append(g + "".join(c if rng.random() > 0.03 else B[int(rng.integers(0, 4))] for c in x))
+        elif kind == 3:
+            u = rnd(int(rng.integers(5, 200))); seqs.append((u * (n // len(u) + 1))[:n])
+        else:
+            seqs.append(g[:n // 2] + "N" * int(rng.integers(1, 50)) + g[:n // 2])
+    data, off, elen, key = synth.nucleotide_read_db(3000, seed=9)
+    synth.write_db(str(tmp_path / "reads"), data, off, elen, key, 1)
+    _, er = read_db(tmp_path / "reads")
+    seqs += [v[:-2].decode() for v in list(er.values())[:2000]]
+    _write_fasta_like_db(tmp_path / "seq", seqs, dbtype=1)
+    db = ctx.read_seqdb(tmp_path / "seq")
+    n_cyc = 0
+    for chop in (0, 1):
+        run_oracle(oracle_bin, ["cyclecheck", tmp_path / "seq", tmp_path / f"o{chop}", "--max-seq-len", "200000", "--chop-cycle", chop])
+        cyc, st = ctx.cyclecheck(db, max_seq_len=200000, chop_cycle=bool(chop))
+        cyc.write(tmp_path / f"g{chop}")
+        assert_same_db(tmp_path / f"o{chop}", tmp_path / f"g{chop}", f"cyclecheck vs oracle, chop {chop}")
+        n_cyc = st.n_cyclic
+    assert n_cyc > 20
+
+
 def test_golden_findassemblystart(ctx, golden, tmp_path):
     """row N3 on the reference's DBs, and iteration 0 of `plass assemble` as data/assemble.sh:84-150 runs it, chained on the
     device: kmermatcher -> rescorediagonal -> findassemblystart -> kmermatcher -> rescorediagonal -> assembleresults"""

@@ -159,3 +159,16 @@ def test_oracle_findassemblystart(oracle_bin, golden, tmp_path):
     run_oracle(oracle_bin, ["rescorediagonal", tmp_path / "corr", tmp_path / "corr", tmp_path / "pref", tmp_path / "aln"] + AA_RS)
     run_oracle(oracle_bin, ["assembleresults", tmp_path / "corr", tmp_path / "aln", tmp_path / "as0"] + AA_AS)
     assert_same_db(f"{f}/assembly_0", tmp_path / "as0", "iteration 0 on the corrected sequences")
+
+
+def test_oracle_cyclecheck(oracle_bin, golden, tmp_path):
+    """row N4: circular genomes assembled past their end (exact / 2 % errors, 300 nt - 47 kb), linear controls, repeats, N runs,
+    lower case, tiny sequences, the --max-seq-len boundary, reads; plus the example's contigs (none circular)"""
+    c = os.path.join(golden, "cyc")
+    for chop in (0, 1):
+        run_oracle(oracle_bin, ["cyclecheck", f"{c}/in", tmp_path / f"o{chop}", "--max-seq-len", "50000", "--chop-cycle", chop])
+        assert_same_db(f"{c}/cycle_chop{chop}", tmp_path / f"o{chop}", f"cyclecheck --chop-cycle {chop}")
+    for src, name in ((os.path.join(golden, "nucl", "seq_2"), "nucl_seq_2"), (os.path.join(golden, "longnucl", "seq_0"), "longnucl_seq_0"),
+                      (os.path.join(golden, "longnucl", "seq_2"), "longnucl_seq_2")):
+        run_oracle(oracle_bin, ["cyclecheck", src, tmp_path / name, "--max-seq-len", "200000", "--chop-cycle", "1"])
+        assert_same_db(f"{c}/{name}_cycle", tmp_path / name, f"cyclecheck {name}")
