@@ -12,7 +12,7 @@
 //
 // MI355X-first: the reference sorts three k-mer lists per contig; only "first occurrence per k-mer" matters, so a hash
 // table of (k-mer -> smallest front position, smallest middle position) replaces the sorts — in LDS, one wavefront per
-// sequence, for everything up to 1 536 nt (reads and most contigs), in HBM scratch with one workgroup per sequence for the
+// sequence, for everything up to 3 000 nt (reads and most contigs; the table is sized to the sequence), in HBM scratch with one workgroup per sequence for the
 // long contigs.  Floating point: the hit rate is one float division compared with the double 0.2, as in the reference.
 #include "common.hpp"
 #include "device_utils.hpp"
@@ -74,8 +74,12 @@ __global__ __launch_bounds__(64) void cycleWaveKernel(CycArgs a) {
         const uint32_t L = a.s.len[id];
         const char *seq = a.s.data + a.s.off[id];
         const uint32_t third = L / 3, nk = L - CC_K + 1, nBins = 2 * third + 1;
+        // table sized to the sequence (load <= 0.5 for its 2L/3 front + middle k-mers): clearing it is most of the work
+        // for a sequence without repeats
+        uint32_t slots = 256; while (slots * 3 < L * 4 + 64 && slots < (uint32_t) SLOTS) slots <<= 1;
+        const uint32_t mask = slots - 1;
         for (uint32_t i = lane; i < L; i += 64) sNum[i] = sMap[(unsigned char) seq[i]];
-        for (uint32_t i = lane; i < SLOTS; i += 64) { sKey[i] = CC_EMPTY; sMinF[i] = 0xFFFFFFFFu; sMinM[i] = 0xFFFFFFFFu; }
+        for (uint32_t i = lane; i < slots; i += 64) { sKey[i] = CC_EMPTY; sMinF[i] = 0xFFFFFFFFu; sMinM[i] = 0xFFFFFFFFu; }
         for (uint32_t i = lane; i < nBins; i += 64) sHits[i] = 0;
         if (lane == 0) sAny = 0;
         __syncthreads();
@@ -85,11 +89,11 @@ __global__ __launch_bounds__(64) void cycleWaveKernel(CycArgs a) {
             const int c = kmerClass(p, third);
             if (c == 2) continue;
             const unsigned long long k = kmerAt(p);
-            uint32_t sl = hashSlot(k, SLOTS - 1);
+            uint32_t sl = hashSlot(k, mask);
             for (;;) {
                 const unsigned long long prev = atomicCAS(&sKey[sl], CC_EMPTY, k);
                 if (prev == CC_EMPTY || prev == k) break;
-                sl = (sl + 1) & (SLOTS - 1);
+                sl = (sl + 1) & mask;
             }
             atomicMin(c == 0 ? &sMinF[sl] : &sMinM[sl], p);
         }
@@ -99,11 +103,11 @@ __global__ __launch_bounds__(64) void cycleWaveKernel(CycArgs a) {
             const int c = kmerClass(p, third);
             if (c == 0) continue;
             const unsigned long long k = kmerAt(p);
-            uint32_t sl = hashSlot(k, SLOTS - 1);
+            uint32_t sl = hashSlot(k, mask);
             for (;;) {
                 const unsigned long long kk = sKey[sl];
                 if (kk == k || kk == CC_EMPTY) { if (kk != k) sl = 0xFFFFFFFFu; break; }
-                sl = (sl + 1) & (SLOTS - 1);
+                sl = (sl + 1) & mask;
             }
             if (sl == 0xFFFFFFFFu) continue;
             const uint32_t mf = sMinF[sl], mm = sMinM[sl];
@@ -202,9 +206,11 @@ __global__ __launch_bounds__(256) void cycleBlockKernel(CycArgs a) {
     }
 }
 
-// tier of every sequence: 0 wave kernel with the small table, 1 wave kernel with the large table, 2 workgroup kernel;
-// sequences without a k-mer or at / above --max-seq-len are not circular
-constexpr uint32_t CC_L0 = 190, CC_L1 = 1536;
+// tier of every sequence: 0-3 wave kernel with a table of up to 256 / 512 / 2048 / 4096 slots in LDS (the LDS a wavefront
+// holds decides how many sequences a CU works on at a time: reads and merged read pairs get the small instantiations),
+// 4 workgroup kernel; sequences without a k-mer or at / above --max-seq-len are not circular
+constexpr uint32_t CC_L0 = 190, CC_LA = 380, CC_L1 = 1536, CC_L2 = 3000;
+constexpr int CC_TIERS = 5;
 __global__ void cycleTierKernel(SeqView s, uint64_t maxSeqLen, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, uint32_t *__restrict__ split) {
     for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < s.n; b0 += gridDim.x * blockDim.x) {
         const uint32_t id = b0 + threadIdx.x;
@@ -212,9 +218,9 @@ __global__ void cycleTierKernel(SeqView s, uint64_t maxSeqLen, uint32_t *__restr
         if (id < s.n) {
             const uint32_t L = s.len[id];
             split[id] = 0;
-            if (L >= (uint32_t) CC_K && (uint64_t) L < maxSeqLen) tier = L <= CC_L0 ? 0 : (L <= CC_L1 ? 1 : 2);
+            if (L >= (uint32_t) CC_K && (uint64_t) L < maxSeqLen) tier = L <= CC_L0 ? 0 : (L <= CC_LA ? 1 : (L <= CC_L1 ? 2 : (L <= CC_L2 ? 3 : 4)));
         }
-        for (int t = 0; t < 3; t++) {
+        for (int t = 0; t < CC_TIERS; t++) {
             const unsigned long long m = __ballot(tier == t);
             if (!m) continue;
             uint32_t base = 0;
@@ -253,28 +259,30 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
     const SeqView sv = db->view();
     DevBuf dMap, dLists, dCounts, dSplit, dFlags, dNewLen, dNewStart, dTmp;
     const size_t tmpBytes = exclusiveScanTmpBytes((size_t) N + 2);
-    if (dMap.alloc(256) != hipSuccess || dLists.alloc(((size_t) 3 * N + 1) * 4) != hipSuccess || dCounts.alloc(16) != hipSuccess || dSplit.alloc(((size_t) N + 1) * 4) != hipSuccess ||
+    if (dMap.alloc(256) != hipSuccess || dLists.alloc(((size_t) CC_TIERS * N + 1) * 4) != hipSuccess || dCounts.alloc(32) != hipSuccess || dSplit.alloc(((size_t) N + 1) * 4) != hipSuccess ||
         dFlags.alloc(((size_t) N + 1) * 4) != hipSuccess || dNewLen.alloc(((size_t) N + 1) * 4) != hipSuccess || dNewStart.alloc(((size_t) N + 1) * 8) != hipSuccess ||
         dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship_cyclecheck: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
     PH_CHECK(hipMemcpyAsync(dMap.p, aa2numTable(true, 5), 256, hipMemcpyHostToDevice, st));
-    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 16, st));
+    PH_CHECK(hipMemsetAsync(dCounts.p, 0, 32, st));
     const unsigned gridN = std::min<uint32_t>((N + 255) / 256 + 1, (uint32_t) ctx->numCU * 16);
     if (N) hipLaunchKernelGGL(cycleTierKernel, dim3(gridN), dim3(256), 0, st, sv, (uint64_t) par->max_seq_len, dLists.as<uint32_t>(), dCounts.as<uint32_t>(), dSplit.as<uint32_t>());
-    uint32_t cnt[4] = {0, 0, 0, 0};
-    PH_COPY_SYNC(st, cnt, dCounts.p, 16, hipMemcpyDeviceToHost);
+    uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    PH_COPY_SYNC(st, cnt, dCounts.p, 32, hipMemcpyDeviceToHost);
     CycArgs a; memset(&a, 0, sizeof(a));
     a.s = sv; a.map = dMap.as<unsigned char>(); a.split = dSplit.as<uint32_t>();
     if (cnt[0]) { a.list = dLists.as<uint32_t>(); a.nList = cnt[0]; hipLaunchKernelGGL((cycleWaveKernel<256, CC_L0>), dim3(std::min<uint32_t>(cnt[0], (uint32_t) ctx->numCU * 32)), dim3(64), 0, st, a); }
-    if (cnt[1]) { a.list = dLists.as<uint32_t>() + N; a.nList = cnt[1]; hipLaunchKernelGGL((cycleWaveKernel<2048, CC_L1>), dim3(std::min<uint32_t>(cnt[1], (uint32_t) ctx->numCU * 8)), dim3(64), 0, st, a); }
-    if (cnt[2]) {
+    if (cnt[1]) { a.list = dLists.as<uint32_t>() + N; a.nList = cnt[1]; hipLaunchKernelGGL((cycleWaveKernel<512, CC_LA>), dim3(std::min<uint32_t>(cnt[1], (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, a); }
+    if (cnt[2]) { a.list = dLists.as<uint32_t>() + 2 * (size_t) N; a.nList = cnt[2]; hipLaunchKernelGGL((cycleWaveKernel<2048, CC_L1>), dim3(std::min<uint32_t>(cnt[2], (uint32_t) ctx->numCU * 8)), dim3(64), 0, st, a); }
+    if (cnt[3]) { a.list = dLists.as<uint32_t>() + 3 * (size_t) N; a.nList = cnt[3]; hipLaunchKernelGGL((cycleWaveKernel<4096, CC_L2>), dim3(std::min<uint32_t>(cnt[3], (uint32_t) ctx->numCU * 4)), dim3(64), 0, st, a); }
+    if (cnt[4]) {
         // long contigs: scratch tables in HBM, in batches of at most ~2 GB
-        const uint32_t nLong = cnt[2];
+        const uint32_t nLong = cnt[4];
         std::vector<uint32_t> lens(nLong);
         DevBuf dLens;
         if (dLens.alloc((size_t) nLong * 4) != hipSuccess) { setError("plasship_cyclecheck: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         // lengths of the long sequences in list order (the host has no copy of a device-produced DB's index)
-        hipLaunchKernelGGL(cycleGatherLenKernel, dim3(std::min<uint32_t>((nLong + 255) / 256, 1024)), dim3(256), 0, st, db->d_len.as<uint32_t>(), dLists.as<uint32_t>() + 2 * (size_t) N, nLong, dLens.as<uint32_t>());
+        hipLaunchKernelGGL(cycleGatherLenKernel, dim3(std::min<uint32_t>((nLong + 255) / 256, 1024)), dim3(256), 0, st, db->d_len.as<uint32_t>(), dLists.as<uint32_t>() + 4 * (size_t) N, nLong, dLens.as<uint32_t>());
         PH_COPY_SYNC(st, lens.data(), dLens.p, (size_t) nLong * 4, hipMemcpyDeviceToHost);
         const uint64_t budgetSlots = 1ull << 27;        // 16 bytes per slot
         uint32_t b0 = 0;
@@ -296,7 +304,7 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
             PH_CHECK(hipMemcpyAsync(dSO.p, slotOff.data(), (size_t) nb * 8, hipMemcpyHostToDevice, st));
             PH_CHECK(hipMemcpyAsync(dSC.p, slotCnt.data(), (size_t) nb * 4, hipMemcpyHostToDevice, st));
             PH_CHECK(hipMemcpyAsync(dHO.p, hitOff.data(), (size_t) nb * 8, hipMemcpyHostToDevice, st));
-            a.list = dLists.as<uint32_t>() + 2 * (size_t) N + b0; a.nList = nb;
+            a.list = dLists.as<uint32_t>() + 4 * (size_t) N + b0; a.nList = nb;
             a.keys = dKeys.as<unsigned long long>(); a.minF = dMinF.as<uint32_t>(); a.minM = dMinM.as<uint32_t>(); a.hits = dHits.as<uint32_t>();
             a.slotOff = dSO.as<uint64_t>(); a.slotCnt = dSC.as<uint32_t>(); a.hitOff = dHO.as<uint64_t>();
             hipLaunchKernelGGL(cycleBlockKernel, dim3(std::min<uint32_t>(nb, (uint32_t) ctx->numCU * 4)), dim3(256), 0, st, a);
@@ -320,7 +328,7 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
     }
     if (stats) {
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-        stats->ms_kernel = ms; stats->n_cyclic = oc->n; stats->n_wave_small = cnt[0]; stats->n_wave_large = cnt[1]; stats->n_block = cnt[2];
+        stats->ms_kernel = ms; stats->n_cyclic = oc->n; stats->n_wave_small = cnt[0] + cnt[1]; stats->n_wave_large = cnt[2] + cnt[3]; stats->n_block = cnt[4];
     }
     *out_cycle = holdC.release();
     if (out_rest) *out_rest = orest;

@@ -252,7 +252,7 @@ def test_golden_cyclecheck(ctx, golden, tmp_path):
         cyc, rest, st = ctx.cyclecheck(db, max_seq_len=50000, chop_cycle=chop, with_rest=True)
         cyc.write(tmp_path / f"c{int(chop)}"); rest.write(tmp_path / f"r{int(chop)}")
         assert_same_db(f"{c}/cycle_chop{int(chop)}", tmp_path / f"c{int(chop)}", f"cyclecheck chop {chop}")
-        assert st.n_cyclic == 64 and st.n_wave_small > 300 and st.n_wave_large > 10 and st.n_block > 30
+        assert st.n_cyclic == 64 and st.n_wave_small > 300 and st.n_wave_large > 10 and st.n_block > 20
         _, ein = read_db(f"{c}/in"); _, ec = read_db(tmp_path / f"c{int(chop)}"); _, er = read_db(tmp_path / f"r{int(chop)}")
         assert set(ec) | set(er) == set(ein) and not (set(ec) & set(er)) and all(er[k] == ein[k] for k in er)
     for src, name in ((os.path.join(golden, "nucl", "seq_2"), "nucl_seq_2"), (os.path.join(golden, "longnucl", "seq_0"), "longnucl_seq_0"),
