@@ -210,7 +210,9 @@ def main():
         data, off, elen, key = load_sharded_workload(args.pairs, rank, world, dist)
     else:
         data, off, elen, key = load_workload(args.pairs, seed=plan["seeds"][rank])
+    ctx.sync(); tu0 = time.perf_counter()
     db0 = ctx.upload_seqdb(data, off, elen, key, 0)
+    ctx.sync(); upload_s = time.perf_counter() - tu0            # host buffers -> HBM (PCIe), outside the timed region
     n_frag = len(key)
 
     def barrier():
@@ -252,6 +254,10 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
+    td0 = time.perf_counter()
+    final_bytes = len(db.download()[0]) if args.steps else 0     # final contig DB back to host buffers (PCIe), outside the timed region
+    download_s = time.perf_counter() - td0
+    local_overlaps = overlaps
     elapsed, overlaps = pdist.reduce_step(dist, elapsed, overlaps, device="cuda")
 
     if rank == 0:
@@ -286,6 +292,9 @@ def main():
                                                "frac": (tot["kmermatcher_stage"][1] / (tot["kmermatcher_stage"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot["kmermatcher_stage"][0] > 0 else 0.0},
                          "module_wall_ms_per_step": [round(sum(w[i] for w in WALL[-args.steps:]) / args.steps, 3) for i in range(3)]},
         }
+        # what the job costs a caller that hands over host buffers and wants host buffers back (never `value`): rank 0's share
+        line["host_boundary"] = {"upload_ms": upload_s * 1e3, "upload_bytes": len(data), "download_ms": download_s * 1e3, "download_bytes": final_bytes,
+                                 "pcie_inclusive_overlaps_per_s_rank0": local_overlaps / (t1 - t0 + upload_s + download_s)}
         if sharded_error is not None:
             line["sharded_mode_error"] = sharded_error
         if comm is not None:

@@ -274,6 +274,93 @@ def test_sharded_synthetic_three_ranks(ctxs, tmp_path):
             assert_same_db(tmp_path / f"e_seq_{it + 1}", tmp_path / f"r{r}_seq_{it + 1}", f"synthetic rank {r} it{it}")
 
 
+def test_sharded_eight_ranks_small_set(ctxs):
+    """8 ranks on the 3 000-pair set bench.py uses as its multi-GPU preflight (about 1 200 fragments per rank: owners with a
+    handful of records, empty exchanges): two iterations against the single-context run"""
+    import plass_amd
+    from plass_amd import synth
+    data, off, elen, key = synth.protein_fragment_db(3000, seed=7)
+    rs, asp = plass_amd.RescoreParams(min_seq_id=0.9), plass_amd.AssembleParams(min_seq_id=0.9)
+    ref = ctxs[3]
+    rdb = ref.upload_seqdb(data, off, elen, key, 0)
+    expect = []
+    for it in range(2):
+        c, _ = ref.kmermatcher(rdb, km_params(it))
+        a, _ = ref.rescorediagonal(rdb, rdb, c, rs)
+        rdb, _ = ref.assembleresults(rdb, a, asp)
+        expect.append((_cands_rows(c), rdb.download()[0]))
+    eight = ctxs + [plass_amd.Context(0) for _ in range(4)]
+
+    def work(rank, ctx):
+        db = ctx.upload_seqdb(data, off, elen, key, 0)
+        res = []
+        for it in range(2):
+            c, _ = ctx.kmermatcher(db, km_params(it))
+            a, _ = ctx.rescorediagonal(db, db, c, rs)
+            db, _ = ctx.assembleresults(db, a, asp)
+            res.append((_cands_rows(c), db.download()[0]))
+        return res
+
+    try:
+        got = _run(eight, 8, work)
+    finally:
+        for c in eight[4:]:
+            c.close()
+    for it in range(2):
+        _check_union([got[r][it][0] for r in range(8)], expect[it][0], f"8 ranks, candidates it{it}")
+        for r in range(8):
+            assert got[r][it][1] == expect[it][1], f"8 ranks, rank {r}, contig DB it{it}"
+
+
+def test_full_size_sharded_equals_single_and_properties(ctxs):
+    """BASELINE.json configs[1] (1 M reads = 500 k pairs, 1.6 M protein fragments, ~1 GB of k-mer records): two iterations on
+    2 ranks against the single-context run — candidate lists and contig DBs identical — and size-independent properties of
+    the result: candidates sorted by (query, target) without self hits, accepted alignments a subset of the candidates,
+    every sequence of the output contains its input sequence (greedy extension only appends), key set unchanged"""
+    import plass_amd
+    import bench
+    data, off, elen, key = bench.load_workload(500000, seed=1)
+    rs, asp = plass_amd.RescoreParams(min_seq_id=0.9), plass_amd.AssembleParams(min_seq_id=0.9)
+    ref = ctxs[3]
+    rdb = ref.upload_seqdb(data, off, elen, key, 0)
+    expect = []
+    for it in range(2):
+        c, kst = ref.kmermatcher(rdb, km_params(it))
+        a, rst = ref.rescorediagonal(rdb, rdb, c, rs)
+        q, t, sc, dg = c.download()
+        assert np.all((q[1:] > q[:-1]) | ((q[1:] == q[:-1]) & (t[1:] > t[:-1]))) and not np.any(q == t)
+        assert kst.n_candidates == len(q) > 3_000_000 and len(key) <= rst.n_accepted <= len(q) + len(key)
+        out, ast = ref.assembleresults(rdb, a, asp)
+        d1, o1, e1, k1 = out.download()
+        d0, o0, e0, k0 = rdb.download()
+        assert np.array_equal(k0, k1) and np.all(e1 >= e0) and ast.n_extended > 100000
+        # every output sequence contains the input sequence it grew from (checked on every 97th sequence)
+        for i in range(0, len(k0), 97):
+            s0 = d0[int(o0[i]):int(o0[i]) + int(e0[i]) - 2]; s1 = d1[int(o1[i]):int(o1[i]) + int(e1[i]) - 2]
+            assert s0 in s1
+        expect.append((q.tobytes(), t.tobytes(), sc.tobytes(), dg.tobytes(), d1))
+        a.free(); c.free(); rdb.free(); rdb = out
+
+    def work(rank, ctx):
+        db = ctx.upload_seqdb(data, off, elen, key, 0)
+        res = []
+        for it in range(2):
+            c, _ = ctx.kmermatcher(db, km_params(it))
+            a, _ = ctx.rescorediagonal(db, db, c, rs)
+            out, _ = ctx.assembleresults(db, a, asp)
+            res.append((c.download(), out.download()[0]))
+            a.free(); c.free(); db.free(); db = out
+        db.free()
+        return res
+
+    got = _run(ctxs, 2, work)
+    for it in range(2):
+        for j in range(4):
+            assert b"".join(got[r][it][0][j].tobytes() for r in range(2)) == expect[it][j], f"candidates differ, iteration {it}"
+        for r in range(2):
+            assert got[r][it][1] == expect[it][4], f"contig DB of rank {r} differs, iteration {it}"
+
+
 def test_sharded_one_rank_torch_rccl(tmp_path, golden):
     """the torch.distributed communicator bench.py uses (RCCL on device pointers of the library), in a 1-rank group:
     the same all-to-all(v) / all-gather calls an 8-GPU run makes, with this rank as its own peer"""
