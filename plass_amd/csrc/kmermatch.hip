@@ -1345,7 +1345,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    if (nMine) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, ea);
+    static const int waveBlocksPerCU = [] { const char *e = getenv("PLASSHIP_EXTRACT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();     // 32 one-wavefront workgroups per CU: measured best of 12..64 on the 1 M-read set
+    if (nMine) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU)), dim3(64), 0, st, ea);
     DevBuf dOv2Ids, dOv2Cnt;
     if (CAP2 && nMine) {
         if (dOv2Ids.alloc(((size_t) N + 1) * 4) != hipSuccess || dOv2Cnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
