@@ -654,6 +654,7 @@ struct PartArgs {
     unsigned long long *cursor;     // [nSeg << bits] running write positions (scatter)
     int shift, bits, rangeBits, dropSentinels;
     int sharedTable;                // all segments accumulate into one bucket table (segment id does not offset it)
+    uint32_t segMod;                // != 0: segment s uses table (s % segMod) — sharded run, level 2: the W source runs of a level-1 bucket share its table
     unsigned long long *minKey;     // optional: global minimum of (kmer | BIT63) (NUCL first-run quirk)
     // optional: histogram of the records by k-mer VALUE (VH_BINS monotone bins of the sort-#1 key): bounds the sort-#1 rank
     // of any record without sorting, which is all the stale-record check (section 7) needs most of the time
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) atomicAdd(&a.count[(a.sharedTable ? 0 : ((uint64_t) seg << a.bits)) + i], c); }
+    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) atomicAdd(&a.count[(a.sharedTable ? 0 : ((uint64_t) (a.segMod ? seg % a.segMod : seg) << a.bits)) + i], c); }
     if (a.valueHist) for (uint32_t i = threadIdx.x; i < VH_BINS; i += PT_BLOCK) { const uint32_t c = shv[i]; if (c) atomicAdd(&a.valueHist[i], c); }
     if (NUCL && a.minKey) {
 #pragma unroll
@@ -742,7 +743,7 @@ __global__ __launch_bounds__(PT_BLOCK) void partScatterKernel(PartArgs a) {
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) sbase[i] = atomicAdd(&a.cursor[(a.sharedTable ? 0 : ((uint64_t) seg << a.bits)) + i], (unsigned long long) c); }
+    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) sbase[i] = atomicAdd(&a.cursor[(a.sharedTable ? 0 : ((uint64_t) (a.segMod ? seg % a.segMod : seg) << a.bits)) + i], (unsigned long long) c); }
     __syncthreads();
 #pragma unroll
     for (int it = 0; it < PT_ITEMS; it++)
@@ -1288,7 +1289,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (N) hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
     if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t total = 0;
-    uint32_t sLo = 0, sHi = N; uint64_t slotBias = 0;
+    uint32_t sLo = 0, sHi = N; uint64_t slotBias = 0, totalAll = 0;
     if (cm) {
         DevBuf dSplit; std::vector<uint64_t> hSplit(2 * (size_t) W + 2);
         if (dSplit.alloc(hSplit.size() * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
@@ -1296,6 +1297,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_COPY_SYNC(st, hSplit.data(), dSplit.p, hSplit.size() * 8, hipMemcpyDeviceToHost);
         sLo = (uint32_t) hSplit[rk]; sHi = (uint32_t) hSplit[rk + 1]; slotBias = hSplit[W + 1 + rk];
         total = hSplit[W + 1 + rk + 1] - slotBias;              // slots of this rank's share
+        totalAll = hSplit[2 * (size_t) W + 1];                  // ... and of all sequences
     } else {
     PH_CHECK(hipMemcpyAsync(&total, dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
@@ -1397,7 +1399,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const int valueShift = std::max(0, keyBits - 12);
     void *bufA = dA.p, *bufB = dB.p;        // level 1 reads bufA (partTotal slots), writes bufB
     uint64_t partTotal = total, NkAll = 0;  // NkAll: records of the whole run (sharded)
-    if (cm) {
+    // Sharded run, W a power of two, two partition levels: level 1 doubles as the partition by owner.  With the bucket geometry
+    // of the WHOLE run (same on every rank) the top log2(W) bits of a level-1 bucket name its owner, so a rank's level-1 output
+    // is already laid out by destination; the receiver runs level 2 over the W source runs of each of its level-1 buckets
+    // (PartArgs::segMod).  Otherwise (W not a power of two, or a single level) a separate pass partitions by owner first.
+    const int lw = ceilLog2((uint64_t) W);
+    const int totalBitsAll = std::max(0, ceilLog2((totalAll + 1535) / 1536));
+    const bool fold = cm && (1 << lw) == W && totalBitsAll > 11 && totalBitsAll - 11 <= 11 && lw <= 11;
+    if (cm && !fold) {
         // exchange 1: records -> owner of the k-mer's hash bucket.  One partition pass by owner (it also drops the sentinels
         // and takes the value histogram / minimum key the single-GPU level 1 takes), then an all-to-all(v) of the W runs.
         const int ob = ceilLog2((uint64_t) W); const uint32_t nbO = 1u << ob;
@@ -1435,13 +1444,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         bufA = dRxA.p; bufB = dRxB.p; partTotal = got;
         PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &partTotal, 8, hipMemcpyHostToDevice, st));
     }
-    const int totalBits = std::max(0, ceilLog2((partTotal + 1535) / 1536));        // ~1000-1500 records per final bucket: the group kernel pays a fixed
-                                                                               // number of block barriers per bucket
+    const int totalBits = fold ? totalBitsAll : std::max(0, ceilLog2((partTotal + 1535) / 1536));   // ~1000-1500 records per final bucket: the group kernel
+                                                                                                    // pays a fixed number of block barriers per bucket
     // coarse level first: few wide buckets => every tile writes long contiguous runs; the fine level then scatters inside a
     // bucket that fits the L2 / Infinity Cache
     const int b2w = (totalBits > 11) ? 11 : 0;
-    const int b1 = std::min(totalBits - b2w, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
+    const int b1 = fold ? std::max(lw, totalBits - 11) : std::min(totalBits - b2w, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
     const uint32_t nB1 = 1u << b1, nB = 1u << (b1 + b2);
+    const uint32_t nbL = fold ? (nB1 >> lw) : nB1;              // level-1 buckets this rank owns (all of them on a single GPU)
     DevBuf dCnt1, dStart1, dCur1, dCnt2, dStart2, dCur2, dSegCnt1;
     if (dCnt1.alloc((size_t) nB1 * 4) != hipSuccess || dStart1.alloc(((size_t) nB1 + 1) * 8) != hipSuccess || dCur1.alloc((size_t) nB1 * 8) != hipSuccess ||
         dSegCnt1.alloc((size_t) nB1 * 8) != hipSuccess ||
@@ -1453,9 +1463,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     pa.in = bufA; pa.out = bufB; pa.segStart = dSeg0Start.as<uint64_t>(); pa.segCount = dSeg0Cnt.as<uint64_t>(); pa.count = dCnt1.as<uint32_t>();
     pa.cursor = dCur1.as<unsigned long long>(); pa.shift = 64 - b1; pa.bits = b1; pa.rangeBits = 0;
     // the owner pass of a sharded run has already dropped the sentinels and taken the histogram and the minimum key
-    pa.dropSentinels = cm ? 0 : 1; pa.minKey = (NUCL && !cm) ? dMinKey.as<unsigned long long>() : nullptr;
+    const bool ownerPassDone = cm && !fold;
+    pa.dropSentinels = ownerPassDone ? 0 : 1; pa.minKey = (NUCL && !ownerPassDone) ? dMinKey.as<unsigned long long>() : nullptr;
     if (b1 == 0) pa.shift = 63;   // single bucket: (key >> 63) & 0 == 0
-    pa.valueHist = cm ? nullptr : dVHist.as<uint32_t>(); pa.valueShift = valueShift;
+    pa.valueHist = ownerPassDone ? nullptr : dVHist.as<uint32_t>(); pa.valueShift = valueShift;
     const unsigned tiles0 = (unsigned) std::max<uint64_t>(1, (partTotal + PT_TILE - 1) / PT_TILE);
     hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
     if (exclusiveScanU32(st, dCnt1.as<uint32_t>(), dStart1.as<uint64_t>(), nB1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
@@ -1469,23 +1480,58 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(hStart1.data(), dStart1.p, ((size_t) nB1 + 1) * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     PH_CHECK(hipGetLastError());
-    const uint64_t Nk = hStart1[nB1];          // records on this rank
-    const uint64_t NkG = cm ? NkAll : Nk;      // ... and of the whole run (the count matrix of exchange 1 has it)
+    uint64_t Nk = hStart1[nB1];                // records on this rank
     void *cur = bufB, *other = bufA;
     const uint64_t *dBucketStart = dStart1.as<uint64_t>();
+    // level 2 reads `l2Segs` segments; segment s accumulates into table (s % l2SegMod)
+    const uint64_t *l2SegStart = dStart1.as<uint64_t>(), *l2SegCount = dSegCnt1.as<uint64_t>();
+    uint32_t l2Segs = nB1, l2SegMod = 0;
+    uint64_t maxSeg = 0; for (uint32_t i = 0; i < nB1; i++) maxSeg = std::max(maxSeg, hStart1[i + 1] - hStart1[i]);
+    DevBuf dSegS, dSegC;
+    if (fold) {
+        // exchange 1 of the folded path: the level-1 output is laid out by destination already
+        std::vector<uint64_t> sendCount(W), myCnt(nB1), allCnt((size_t) W * nB1);
+        for (int r = 0; r < W; r++) sendCount[r] = hStart1[(size_t) (r + 1) * nbL] - hStart1[(size_t) r * nbL];
+        for (uint32_t i = 0; i < nB1; i++) myCnt[i] = hStart1[i + 1] - hStart1[i];
+        int rc = commAllgatherHost(ctx, myCnt.data(), allCnt.data(), (uint64_t) nB1 * 8); if (rc) return rc;
+        uint64_t got = 0;
+        rc = commAlltoallvRecords(ctx, cur, sendCount.data(), sizeof(R), dRxA, &got, 0, &NkAll); if (rc) return rc;
+        PH_TRACE(st, "kmermatch: exchange 1 (level-1 buckets)");
+        dA.release(); dB.release();
+        if (dRxB.alloc(std::max<uint64_t>(got, 1) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; }
+        if (NUCL) {              // the globally smallest key (first-run quirk of the group kernel)
+            uint64_t mk = 0; PH_COPY_SYNC(st, &mk, dMinKey.p, 8, hipMemcpyDeviceToHost);
+            rc = commAllReduceMinU64(ctx, &mk, 1); if (rc) return rc;
+            PH_COPY_SYNC(st, dMinKey.p, &mk, 8, hipMemcpyHostToDevice);
+        }
+        // what arrived: for every source s the records of my level-1 buckets rk*nbL .. rk*nbL + nbL - 1, bucket after bucket
+        std::vector<uint64_t> segS((size_t) W * nbL), segC((size_t) W * nbL); uint64_t o = 0; maxSeg = 0;
+        for (int sr = 0; sr < W; sr++)
+            for (uint32_t j = 0; j < nbL; j++) {
+                const uint64_t c = allCnt[(size_t) sr * nB1 + (size_t) rk * nbL + j];
+                segS[(size_t) sr * nbL + j] = o; segC[(size_t) sr * nbL + j] = c; o += c; maxSeg = std::max(maxSeg, c);
+            }
+        if (o != got) { setError("kmermatch: internal error, exchanged bucket counts do not add up"); return PLASSHIP_ERR_DEVICE; }
+        if (dSegS.alloc(segS.size() * 8) != hipSuccess || dSegC.alloc(segC.size() * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_COPY_SYNC(st, dSegS.p, segS.data(), segS.size() * 8, hipMemcpyHostToDevice);
+        PH_COPY_SYNC(st, dSegC.p, segC.data(), segC.size() * 8, hipMemcpyHostToDevice);
+        l2SegStart = dSegS.as<uint64_t>(); l2SegCount = dSegC.as<uint64_t>(); l2Segs = (uint32_t) W * nbL; l2SegMod = nbL;
+        cur = dRxA.p; other = dRxB.p; Nk = got;
+    }
+    const uint64_t NkG = cm ? NkAll : Nk;      // records of the whole run (the count matrix of exchange 1 has it)
+    const uint32_t nB2 = nbL << b2;            // level-2 tables (= final buckets of this rank)
     if (b2 > 0) {
-        uint64_t maxSeg = 0; for (uint32_t i = 0; i < nB1; i++) maxSeg = std::max(maxSeg, hStart1[i + 1] - hStart1[i]);
-        hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dSegCnt1.as<uint64_t>(), (uint64_t) nB1);
-        PH_CHECK(hipMemsetAsync(dCnt2.p, 0, (size_t) nB * 4, st));
+        if (!fold) hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dSegCnt1.as<uint64_t>(), (uint64_t) nB1);
+        PH_CHECK(hipMemsetAsync(dCnt2.p, 0, (size_t) nB2 * 4, st));
         PartArgs p2; memset(&p2, 0, sizeof(p2));
-        p2.in = cur; p2.out = other; p2.segStart = dStart1.as<uint64_t>(); p2.segCount = dSegCnt1.as<uint64_t>(); p2.count = dCnt2.as<uint32_t>();
-        p2.cursor = dCur2.as<unsigned long long>(); p2.shift = 64 - b1 - b2; p2.bits = b2; p2.dropSentinels = 0;
+        p2.in = cur; p2.out = other; p2.segStart = l2SegStart; p2.segCount = l2SegCount; p2.count = dCnt2.as<uint32_t>();
+        p2.cursor = dCur2.as<unsigned long long>(); p2.shift = 64 - b1 - b2; p2.bits = b2; p2.dropSentinels = 0; p2.segMod = l2SegMod;
         const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxSeg + PT_TILE - 1) / PT_TILE);
-        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), 0, st, p2);
-        if (exclusiveScanU32(st, dCnt2.as<uint32_t>(), dStart2.as<uint64_t>(), nB, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB, 256, 1024)), dim3(256), 0, st, dStart2.as<uint64_t>(), dCur2.as<unsigned long long>(), (uint64_t) nB);
+        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, l2Segs), dim3(PT_BLOCK), 0, st, p2);
+        if (exclusiveScanU32(st, dCnt2.as<uint32_t>(), dStart2.as<uint64_t>(), nB2, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB2, 256, 1024)), dim3(256), 0, st, dStart2.as<uint64_t>(), dCur2.as<unsigned long long>(), (uint64_t) nB2);
         PH_CHECK(hipEventRecord(ctx->ev[10], st));
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, nB1), dim3(PT_BLOCK), (size_t) 12 << p2.bits, st, p2);
+        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, l2Segs), dim3(PT_BLOCK), (size_t) 12 << p2.bits, st, p2);
         PH_CHECK(hipEventRecord(ctx->ev[11], st));
         nScatter = 2;
         std::swap(cur, other);
@@ -1497,7 +1543,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
 
     // ---- assignGroup ----
     tm.start(0);
-    const uint32_t nBuckets = (b2 > 0) ? nB : nB1;
+    const uint32_t nBuckets = (b2 > 0) ? nB2 : nB1;
     const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) ctx->numCU * 8);
     const uint32_t bpb = (nBuckets + gBlocks - 1) / gBlocks;
     const uint32_t gGrid = (nBuckets + bpb - 1) / bpb;

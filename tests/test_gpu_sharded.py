@@ -238,12 +238,14 @@ def test_sharded_findassemblystart_iteration0(ctxs, golden, tmp_path):
         assert_same_db(f"{f}/assembly_0", tmp_path / f"r{r}_as0", f"iteration 0 rank {r}")
 
 
-def test_sharded_synthetic_three_ranks(ctxs, tmp_path):
-    """40 k read pairs (130 k protein fragments), 3 iterations on 3 ranks against the single-context run"""
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_sharded_synthetic(ctxs, tmp_path, world):
+    """40 k read pairs (130 k protein fragments, 7.8 M k-mer record slots: two partition levels), 3 iterations against the
+    single-context run.  2 and 4 ranks take the folded path (level 1 doubles as the partition by owner), 3 ranks the separate
+    owner pass"""
     import plass_amd
     from plass_amd import synth
     data, off, elen, key = synth.protein_fragment_db(40000, seed=5)
-    world = 3
     ref = ctxs[3]
     rdb = ref.upload_seqdb(data, off, elen, key, 0)
     expect = []
