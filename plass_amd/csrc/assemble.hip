@@ -1265,7 +1265,7 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
         setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
-    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, sv, dFlags, dNewLen,
+    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16))), dim3(256), 0, st, sv, dFlags, dNewLen,
                               dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
                               o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
@@ -1473,11 +1473,11 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         for (int e = 4; e <= 7; e++) PH_CHECK(hipEventRecord(ctx->ev[e], st));
     } else {
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
-    if (a.nSmall) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
+    if (a.nSmall) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASM16", 4))), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    if (a.nMid32) hipLaunchKernelGGL(assembleGroupKernel<32>, dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
-    if (a.nMid) hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, a);
+    if (a.nMid32) hipLaunchKernelGGL(assembleGroupKernel<32>, dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASM32", 5))), dim3(256), 0, st, a);
+    if (a.nMid) hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASM64", 5))), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     PH_CHECK(hipEventRecord(ctx->ev[6], st));
     if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(a.nBig, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a);

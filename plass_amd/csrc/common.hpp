@@ -29,6 +29,10 @@ std::string hipErrStr(hipError_t e, const char *what, const char *file, int line
         PH_CHECK(hipStreamSynchronize(st));                                              \
     } while (0)
 
+// launch-geometry knobs (workgroups per CU of a persistent kernel's grid): default unless PLASSHIP_TUNE_<name> is set in the
+// environment (tools/tune_sweep.sh).  The defaults were swept on the 1 M-read set: the best grid is the number of workgroups
+// a CU holds at once, or a small multiple — one more leaves a tail round (extractShortKernel: 18 -> 0.69 ms, 20 -> 0.81 ms)
+int tuneInt(const char *name, int dflt);
 // PLASSHIP_TRACE=1: wait for the stream at every marked stage boundary and say so on stderr (localises a faulting kernel)
 bool traceOn();
 #define PH_TRACE(st, what)                                                                \

@@ -69,6 +69,11 @@ void poolTrim() {
     g_poolFree.clear();
 }
 static thread_local std::string g_err;
+int tuneInt(const char *name, int dflt) {
+    char key[96]; snprintf(key, sizeof(key), "PLASSHIP_TUNE_%s", name);
+    const char *e = getenv(key); const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : dflt;
+}
 bool traceOn() { static const bool v = getenv("PLASSHIP_TRACE") != nullptr; return v; }
 void setError(const std::string &msg) { g_err = msg; }
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {

@@ -1342,7 +1342,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
         sa.waveList = dWaveList.as<uint32_t>(); sa.waveCount = dWaveCount.as<uint32_t>(); sa.kstats = dKStats.as<unsigned long long>();
         sa.idLo = sLo; sa.idHi = sHi; sa.slotBias = slotBias;
-        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * 20)), dim3(64), 0, st, sa);
+        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", 18))), dim3(64), 0, st, sa);
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
@@ -1544,7 +1544,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // ---- assignGroup ----
     tm.start(0);
     const uint32_t nBuckets = (b2 > 0) ? nB2 : nB1;
-    const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) ctx->numCU * 8);
+    const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("GROUP", 6));
     const uint32_t bpb = (nBuckets + gBlocks - 1) / gBlocks;
     const uint32_t gGrid = (nBuckets + bpb - 1) / bpb;
     DevBuf dOutCnt, dArenaStart, dMaxRT;
@@ -1757,7 +1757,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
         PH_CHECK(hipMemcpyAsync(dBigOff.p, bigOff.data(), (size_t) nSortBuckets * 8, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * 16)), dim3(LS_BLOCK), 0, st,
+    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
                        (const void *) cur, other, dSortStart, nSortBuckets, dBigScratch.as<unsigned long long>(), dBigOff.as<uint64_t>(),
                        dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0));
     DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
