@@ -167,6 +167,8 @@ def main():
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pairs", type=int, default=500000, help="read pairs per GPU (500000 = 1 M reads, BASELINE configs[1])")
+    ap.add_argument("--parts", type=int, default=1, help="single GPU: build the read set from this many independently seeded parts of --pairs each "
+                    "(a 50 M-read set as 10 x 2.5 M pairs keeps the generator's host memory at one part)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=40000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["auto", "sharded", "partitions"], default="auto",
@@ -208,6 +210,8 @@ def main():
             comm, mode = None, "partitions"
     if mode == "sharded":
         data, off, elen, key = load_sharded_workload(args.pairs, rank, world, dist)
+    elif args.parts > 1:
+        data, off, elen, key = load_sharded_workload(args.pairs, 0, args.parts, None)
     else:
         data, off, elen, key = load_workload(args.pairs, seed=plan["seeds"][rank])
     ctx.sync(); tu0 = time.perf_counter()
@@ -278,7 +282,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 (integer hash, byte compare; f32 ratios)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: %d synthetic 2x150 bp protein-coding reads per GPU (%d read pairs, %d protein fragments), "
-                                   "--num-iterations %d, k=14, alph 13, kmer-per-seq 60, min-seq-id 0.9, e 1e-5" % (2 * args.pairs, args.pairs, n_frag, args.steps),
+                                   "--num-iterations %d, k=14, alph 13, kmer-per-seq 60, min-seq-id 0.9, e 1e-5" % (
+                                       2 * args.pairs * (args.parts if mode != "sharded" else 1), args.pairs * (args.parts if mode != "sharded" else 1), n_frag, args.steps),
                        "parallelism": ("1 GPU" if world == 1 and mode != "sharded" else
                                        "%d GPUs, one read set of %d fragments sharded by k-mer bucket (RCCL all-to-all(v) of k-mer and grouped records, "
                                        "all-gather of extended sequences), sequence DB replicated" % (world, n_frag) if mode == "sharded" else
