@@ -1690,7 +1690,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // rep ids are sorted relative to the first rep this rank owns (0 on a single GPU); targets are ids of the whole DB
     const int idBits = std::max(1, ceilLog2((uint64_t) N));
     const int repBits = cm ? std::max(1, ceilLog2(std::max<uint64_t>(ownedN, 1))) : idBits;
-    const int wantBits = std::max(0, ceilLog2((NmHere + 511) / 512));
+    // ~512 records per sort bucket, at most 2^22 buckets (two partition levels of 11 bits): beyond 2 G grouped records the buckets
+    // grow instead (the aggregation kernel takes buckets of any size)
+    const int wantBits = std::min(22, std::max(0, ceilLog2((NmHere + 511) / 512)));
     // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
     const int allowedLocal = 62 - idBits - DiagPack<LONG>::BITS;
     const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
