@@ -51,11 +51,16 @@ def load_workload(pairs, seed):
     os.makedirs(cache, exist_ok=True)
     f = os.path.join(cache, "frag_p%d_s%d.npz" % (pairs, seed))
     if os.path.exists(f):
-        z = np.load(f)
-        return z["data"].tobytes(), z["off"], z["elen"], z["key"]
+        try:
+            z = np.load(f)
+            return z["data"].tobytes(), z["off"], z["elen"], z["key"]
+        except Exception:          # a cache file from a run that was killed while writing: regenerate
+            pass
     data, off, elen, key = synth.protein_fragment_db(pairs, seed=seed)
     try:
-        np.savez(f, data=np.frombuffer(data, dtype=np.uint8), off=off, elen=elen, key=key)
+        tmp = os.path.join(cache, "tmp_%d_frag_p%d_s%d.npz" % (os.getpid(), pairs, seed))
+        np.savez(tmp, data=np.frombuffer(data, dtype=np.uint8), off=off, elen=elen, key=key)
+        os.replace(tmp, f)         # atomic: other ranks / later runs never see a partial file
     except OSError:
         pass
     return data, off, elen, key
@@ -202,10 +207,15 @@ def main():
         comm.install(ctx)
         try:
             sharded_preflight(ctx, dist, torch.device("cuda", local))
-        except Exception as e:       # e.g. a collective this RCCL / torch build lacks: say so and fall back, on every rank alike
+        except Exception as e:       # e.g. a collective this RCCL / torch build lacks: say so and fall back
             if args.mode == "sharded":
                 raise
             sharded_error = "%s: %s" % (type(e).__name__, e)
+        # every rank takes the same decision (a rank that failed alone must not leave the others in a collective)
+        ok = torch.tensor([0 if sharded_error else 1], dtype=torch.int64, device=torch.device("cuda", local))
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            sharded_error = sharded_error or "the preflight failed on another rank"
             TorchComm.uninstall(ctx)
             comm, mode = None, "partitions"
     if mode == "sharded":

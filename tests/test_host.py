@@ -63,3 +63,15 @@ def test_synth_deterministic():
     for o, l in zip(off[:50], elen[:50]):
         e = data[int(o):int(o) + int(l)]
         assert e.endswith(b"\n\x00") and b"*" not in e[:-3]
+
+
+def test_bench_workload_parts_concatenate():
+    """bench.py builds the multi-GPU / large single-GPU read set from independently seeded parts: keys stay unique and
+    ascending, offsets consistent, part 0 is the single-GPU workload"""
+    import numpy as np
+    import bench
+    d, o, e, k = bench.load_sharded_workload(1500, 0, 3, None)
+    assert len(set(k.tolist())) == len(k) and np.all(np.diff(k.astype(np.int64)) > 0)
+    assert int(o[-1]) + int(e[-1]) == len(d) and np.all(o[1:] == o[:-1] + e[:-1])
+    p0 = bench.load_workload(1500, seed=1)
+    assert d[:len(p0[0])] == p0[0] and np.array_equal(k[:len(p0[3])], p0[3])
