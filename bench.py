@@ -143,27 +143,32 @@ def stage_table(kst, rst, ast):
 
 
 def cpu_baseline(sample_pairs, iters):
-    """the CPU oracle (port, 1 thread) on a bounded sample of the same workload; module compute time only"""
+    """the CPU oracle (a port of the reference algorithm; OpenMP over the loops the reference threads: extraction, the two sorts,
+    re-scoring, extension) on a bounded sample of the same workload, on the host cores of this box; module compute time only"""
     import __graft_entry__ as g
     from plass_amd import synth
     if not os.path.exists(g.oracle_bin()):
         subprocess.check_call(["make", "-j", "4"], cwd=os.path.join(ROOT, "oracle"))
+    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+    if sample_pairs <= 0:                                    # default: ~10-30 s of CPU work whatever the core count
+        sample_pairs = 40000 if threads < 8 else 120000
     data, off, elen, key = synth.protein_fragment_db(sample_pairs, seed=101)
+    thr = ["--threads", str(threads)]
     tot_t, tot_c = 0.0, 0
     with tempfile.TemporaryDirectory() as td:
         synth.write_db(os.path.join(td, "seq_0"), data, off, elen, key, 0)
         for it in range(iters):
             s, p, a, o = (os.path.join(td, x) for x in ("seq_%d" % it, "pref", "aln", "seq_%d" % (it + 1)))
             e1 = g.run_oracle(["kmermatcher", s, p, "--alph-size", "13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "0", "-k", "14", "-c", "0",
-                               "--hash-shift", str(hash_shift(it)), "--include-only-extendable", "1" if it else "0", "--ignore-multi-kmer", "1"])
-            e2 = g.run_oracle(["rescorediagonal", s, s, p, a, "--min-seq-id", "0.9", "-e", "1e-5", "-c", "0"])
-            e3 = g.run_oracle(["assembleresults", s, a, o, "--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1"])
+                               "--hash-shift", str(hash_shift(it)), "--include-only-extendable", "1" if it else "0", "--ignore-multi-kmer", "1"] + thr)
+            e2 = g.run_oracle(["rescorediagonal", s, s, p, a, "--min-seq-id", "0.9", "-e", "1e-5", "-c", "0"] + thr)
+            e3 = g.run_oracle(["assembleresults", s, a, o, "--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1"] + thr)
             tot_c += int(re.search(r"N_c=(\d+)", e1).group(1))
             for e in (e1, e2, e3):
                 tot_t += float(re.search(r"([0-9.]+) s\s*$", e.strip()).group(1))
-    return {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": 1, "kind": "port",
-            "sample": "%d read pairs (%d protein fragments), %d iterations, oracle module compute time (no DB I/O), 1 thread"
-                      % (sample_pairs, len(key), iters)}
+    return {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
+            "sample": "%d read pairs (%d protein fragments), %d iterations, oracle module compute time (no DB I/O), %d OpenMP threads "
+                      "(grouping and result writing are single-threaded, as in the reference)" % (sample_pairs, len(key), iters, threads)}
 
 
 def main():
@@ -174,7 +179,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=500000, help="read pairs per GPU (500000 = 1 M reads, BASELINE configs[1])")
     ap.add_argument("--parts", type=int, default=1, help="single GPU: build the read set from this many independently seeded parts of --pairs each "
                     "(a 50 M-read set as 10 x 2.5 M pairs keeps the generator's host memory at one part)")
-    ap.add_argument("--cpu-sample-pairs", type=int, default=40000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = 40000 below 8 host cores, 120000 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["auto", "sharded", "partitions"], default="auto",
                     help="N > 1: 'sharded' = one read set over the GPUs with RCCL all-to-all (default), 'partitions' = independent sets")

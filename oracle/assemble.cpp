@@ -97,9 +97,14 @@ static DB doAssembly(const DB &seqDb, const DB &alnDb, const Params &par) {
     Evaluer evaluer(nucl, seqDb.aminoAcidDBSize());
     const size_t N = seqDb.size();
     std::vector<unsigned char> wasExtended(N, 0);
-    std::vector<char> useReverse(N, 0);            // per-thread in the reference; single thread here
+    auto mark = [&](size_t i, unsigned char bits) { __atomic_fetch_or(&wasExtended[i], bits, __ATOMIC_RELAXED); };   // shared between the threads, like the reference's array
     DB out; out.dbtype = seqDb.dbtype;
+    std::vector<std::string> extended(N);          // contig of query id, if it was extended (added in id order below)
+#pragma omp parallel num_threads(std::max(1, par.threads))
+    {
+    std::vector<char> useReverse(N, 0);            // per thread, as in the reference
     std::vector<Result> alignments, tmpAlignments;
+#pragma omp for schedule(dynamic, 64)
     for (size_t id = 0; id < N; id++) {
         unsigned queryKey = seqDb.key[id];
         const char *querySeq = seqDb.entry(id);
@@ -131,7 +136,7 @@ static DB doAssembly(const DB &seqDb, const DB &alnDb, const Params &par) {
                 } else useReverse[tid] = 0;
             }
             alnQueue.push(a);
-            if (alignments.size() > 1) wasExtended[seqDb.getId(a.dbKey)] |= 0x40;
+            if (alignments.size() > 1) mark(seqDb.getId(a.dbKey), 0x40);
         }
         tmpAlignments.clear();
         while (!alnQueue.empty()) {
@@ -147,7 +152,7 @@ static DB doAssembly(const DB &seqDb, const DB &alnDb, const Params &par) {
                 } else if (best.qStartPos == 0) {
                     if (best.dbStartPos <= (int) leftQueryOffset) continue;
                 }
-                wasExtended[targetId] |= 0x10;
+                mark(targetId, 0x10);
                 unsigned dbStartPos = (unsigned) best.dbStartPos, dbEndPos = (unsigned) best.dbEndPos;
                 unsigned qStartPos = (unsigned) best.qStartPos, qEndPos = (unsigned) best.qEndPos;
                 if (dbStartPos == 0 && qEndPos == (querySeqLen - 1)) {             // right extension
@@ -157,7 +162,7 @@ static DB doAssembly(const DB &seqDb, const DB &alnDb, const Params &par) {
                     std::string fragment = useReverse[targetId] ? getRevFragment(targetSeq, fragLen)
                                                                 : std::string(targetSeq + dbEndPos + 1, fragLen);
                     query += fragment; rightQueryOffset += fragLen;
-                    wasExtended[targetId] |= 0x80;
+                    mark(targetId, 0x80);
                 } else if (qStartPos == 0 && dbEndPos == (targetSeqLen - 1)) {     // left extension
                     if (leftQueryOffset > 0) { tmpAlignments.push_back(best); continue; }
                     unsigned fragLen = dbStartPos;
@@ -165,7 +170,7 @@ static DB doAssembly(const DB &seqDb, const DB &alnDb, const Params &par) {
                     std::string fragment = useReverse[targetId] ? getRevFragment(targetSeq + (targetSeqLen - dbStartPos), fragLen)
                                                                 : std::string(targetSeq, fragLen);
                     query = fragment + query; leftQueryOffset += fragLen;
-                    wasExtended[targetId] |= 0x80;
+                    mark(targetId, 0x80);
                 }
             }
             if (leftQueryOffset > 0 || rightQueryOffset > 0) queryCouldBeExtended = true;
@@ -187,10 +192,13 @@ static DB doAssembly(const DB &seqDb, const DB &alnDb, const Params &par) {
         }
         if (queryCouldBeExtended) {
             query.push_back('\n');
-            wasExtended[id] |= 0x20;
-            out.add(queryKey, query.data(), query.size());
+            mark(id, 0x20);
+            extended[id] = std::move(query);
         }
     }
+    }   // omp parallel
+    for (size_t id = 0; id < N; id++)
+        if (wasExtended[id] & 0x20) out.add(seqDb.key[id], extended[id].data(), extended[id].size());
     for (size_t id = 0; id < N; id++) {                                            // :326-342
         bool isNotContig = !(wasExtended[id] & 0x20), wasNotExtended = !(wasExtended[id] & 0x80);
         if (isNotContig && (par.keepTarget || wasNotExtended))

@@ -9,6 +9,8 @@
 // emulated exactly, including what is left behind the compaction point, because
 // writeKmerMatcherResult scans into it.
 #include "oracle.hpp"
+#include <omp.h>
+#include <parallel/algorithm>
 #include <algorithm>
 #include <climits>
 #include <cstring>
@@ -102,6 +104,13 @@ size_t prefilterHitToBuffer(char *buf, const Hit &h) {                   // Quer
     return (size_t) (t - buf);
 }
 
+// the reference sorts with ips4o's parallel sorter (FastSort.h:8-15); both comparators are total orders on the records that
+// occur, so any correct sort gives the same array
+template <typename It, typename Cmp> static void sortRecords(It b, It e, Cmp cmp, int threads) {
+    if (threads > 1) { omp_set_num_threads(threads); __gnu_parallel::sort(b, e, cmp); }
+    else std::sort(b, e, cmp);
+}
+
 template <typename T, bool NUCL>
 static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
     const int k = par.kmerSize;
@@ -126,12 +135,22 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
     memset((void *) arr.data(), 0xFF, sizeof(KPos<T>) * arr.size());
 
     // ---- K1..K3: fillKmerPositionArray ------------------------------------------------------
+    // (the reference runs this loop under OpenMP, kmermatcher.cpp:103-105; here thread t takes the id range [N t / nThr, N (t+1) / nThr)
+    //  into its own buffer and the buffers are concatenated in id order, so the array is the single-threaded one)
+    const int nThr = std::max(1, par.threads);
+    std::vector<std::vector<KPos<T>>> partOut((size_t) nThr);
+#pragma omp parallel num_threads(nThr)
+    {
+    const int tIdx = omp_get_thread_num();
+    std::vector<KPos<T>> &arr = partOut[(size_t) tIdx];
+    arr.resize(1);
     size_t offset = 0;
+    auto put = [&](size_t o) -> KPos<T> & { if (o >= arr.size()) arr.resize(std::max(o + 1, arr.size() * 2)); return arr[o]; };
     std::vector<unsigned char> code;
     std::vector<SeqPos> kmers;
     std::vector<uint16_t> scoreDist(65536);
     uint32_t hier[128];
-    for (size_t id = 0; id < N; id++) {
+    for (size_t id = N * (size_t) tIdx / (size_t) nThr; id < N * ((size_t) tIdx + 1) / (size_t) nThr; id++) {
         std::fill(scoreDist.begin(), scoreDist.end(), 0);
         memset(hier, 0, sizeof(hier));
         const char *s = seqDb.entry(id);
@@ -186,7 +205,7 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
         int tooMuch = (int) (inBins - considered);
 
         // identity record (:241-249)
-        arr[offset].kmer = seqHash; arr[offset].id = seqId; arr[offset].pos = 0; arr[offset].seqLen = (T) L; offset++;
+        { KPos<T> &r = put(offset); r.kmer = seqHash; r.id = seqId; r.pos = 0; r.seqLen = (T) L; offset++; }
 
         if (par.ignoreMultiKmer) {                                                           // :266-272
             std::sort(kmers.begin(), kmers.end(), [](const SeqPos &a, const SeqPos &b) {
@@ -219,16 +238,20 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
                     threshold -= (tooMuch == 0) ? 1 : 0;
                 }
                 selected++;
-                arr[offset].kmer = kmers[i].kmer; arr[offset].id = seqId;
-                arr[offset].pos = (T) kmers[i].pos; arr[offset].seqLen = (T) L; offset++;
+                KPos<T> &r = put(offset); r.kmer = kmers[i].kmer; r.id = seqId;
+                r.pos = (T) kmers[i].pos; r.seqLen = (T) L; offset++;
             }
         }
     }
+    arr.resize(offset);
+    }   // omp parallel
+    size_t offset = 0;
+    for (int t = 0; t < nThr; t++) { memcpy((void *) (arr.data() + offset), (const void *) partOut[(size_t) t].data(), partOut[(size_t) t].size() * sizeof(KPos<T>)); offset += partOut[(size_t) t].size(); partOut[(size_t) t] = std::vector<KPos<T>>(); }
     const size_t elementsToSort = offset;
     if (stats) stats->nKmerRecords = elementsToSort;
 
     // ---- K4: sort #1 (:408-412) ----------------------------------------------------------------
-    std::sort(arr.begin(), arr.begin() + (ptrdiff_t) elementsToSort, cmpKmerLenIdPos<T, NUCL>);
+    sortRecords(arr.begin(), arr.begin() + (ptrdiff_t) elementsToSort, cmpKmerLenIdPos<T, NUCL>, nThr);
 
     // ---- K5: assignGroup (:450-559), exact in-place emulation -----------------------------------
     size_t writePos = 0;
@@ -298,7 +321,7 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
     if (stats) stats->nGrouped = writePos;
 
     // ---- K6: sort #2 (:427-431) ------------------------------------------------------------------
-    std::sort(arr.begin(), arr.begin() + (ptrdiff_t) writePos, cmpRepIdDiag<T, NUCL>);
+    sortRecords(arr.begin(), arr.begin() + (ptrdiff_t) writePos, cmpRepIdDiag<T, NUCL>, nThr);
 
     // ---- K7/K8: writeKmerMatcherResult, threads = 1 (:809-924) -------------------------------------
     DB out; out.dbtype = NUCL ? DBTYPE_PREFILTER_REV_RES : DBTYPE_PREFILTER_RES;

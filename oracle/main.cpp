@@ -61,6 +61,7 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
             else if (a == "--max-seq-len") par.maxSeqLen = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--keep-target") par.keepTarget = atoi(v.c_str()) != 0;
             else if (a == "--chop-cycle") chopCycle = atoi(v.c_str()) != 0;
+            else if (a == "--threads") par.threads = std::max(1, atoi(v.c_str()));
             else if (a == "--oracle-no-stale-scan") par.debugNoStaleScan = atoi(v.c_str()) != 0;
             else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) par.gapOpenNucl = atoi(t.c_str()); }
             else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) par.gapExtendNucl = atoi(t.c_str()); }

@@ -183,8 +183,14 @@ DB rescorediagonal(const DB &qDb, const DB &tDb, bool sameQTDB, const DB &prefDb
     Evaluer evaluer(nucl, tDb.aminoAcidDBSize());
     DB out;
     out.dbtype = (par.rescoreMode >= 2) ? DBTYPE_ALIGNMENT_RES : prefDb.dbtype;
+    // (OpenMP loop over the prefilter entries in the reference, rescorediagonal.cpp:133-135; one result string per entry,
+    //  appended in entry order afterwards)
+    std::vector<std::string> results(prefDb.size());
+#pragma omp parallel num_threads(std::max(1, par.threads))
+    {
     std::string resultBuffer, queryRev;
     std::vector<char> buffer(1024 + 32768 * 4);
+#pragma omp for schedule(dynamic, 256)
     for (size_t id = 0; id < prefDb.size(); id++) {
         const char *data = prefDb.entry(id);
         const uint32_t queryKey = prefDb.key[id];
@@ -256,8 +262,10 @@ DB rescorediagonal(const DB &qDb, const DB &tDb, bool sameQTDB, const DB &prefDb
                 }
             }
         }
-        out.add(queryKey, resultBuffer.data(), resultBuffer.size());
+        results[id] = resultBuffer;
     }
+    }   // omp parallel
+    for (size_t id = 0; id < prefDb.size(); id++) out.add(prefDb.key[id], results[id].data(), results[id].size());
     out.sortByKey();
     return out;
 }
