@@ -172,3 +172,23 @@ def test_oracle_cyclecheck(oracle_bin, golden, tmp_path):
                       (os.path.join(golden, "longnucl", "seq_2"), "longnucl_seq_2")):
         run_oracle(oracle_bin, ["cyclecheck", src, tmp_path / name, "--max-seq-len", "200000", "--chop-cycle", "1"])
         assert_same_db(f"{c}/{name}_cycle", tmp_path / name, f"cyclecheck {name}")
+
+
+@pytest.mark.parametrize("threads", [3, 8])
+def test_oracle_thread_count_independent(oracle_bin, golden, tmp_path, threads):
+    """--threads (OpenMP over extraction, the sorts, re-scoring, extension): the golden DBs whatever the thread count"""
+    s = os.path.join(golden, "aa")
+    t = ["--threads", threads]
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/seq_1", tmp_path / "pref"] + AA_KM + aa_iter_flags(1) + t)
+    assert_same_db(f"{s}/pref_1", tmp_path / "pref", "kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/seq_1", f"{s}/seq_1", f"{s}/pref_1", tmp_path / "aln"] + AA_RS + t)
+    assert_same_db(f"{s}/aln_1", tmp_path / "aln", "rescorediagonal")
+    run_oracle(oracle_bin, ["assembleresults", f"{s}/seq_1", f"{s}/aln_1", tmp_path / "seq"] + AA_AS + t)
+    assert_same_db(f"{s}/seq_2", tmp_path / "seq", "assembleresults")
+    n = os.path.join(golden, "nucl")
+    run_oracle(oracle_bin, ["kmermatcher", f"{n}/seq_1", tmp_path / "npref"] + NUCL_KM + t)
+    assert_same_db(f"{n}/pref_1", tmp_path / "npref", "nucl kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{n}/seq_1", f"{n}/seq_1", f"{n}/pref_1", tmp_path / "naln"] + NUCL_RS + t)
+    assert_same_db(f"{n}/aln_1", tmp_path / "naln", "nucl rescorediagonal")
+    run_oracle(oracle_bin, ["nuclassembleresults", f"{n}/seq_1", f"{n}/aln_1", tmp_path / "nseq"] + NUCL_AS + t)
+    assert_same_db(f"{n}/seq_2", tmp_path / "nseq", "nuclassembleresults")
