@@ -8,6 +8,7 @@
 //   plass_oracle proteinaln2nucl <qNuclDB> <tNuclDB> <qAaDB> <tAaDB> <alnDB> <outAlnDB> [flags]
 //   plass_oracle findassemblystart <seqDB> <alnDB> <outSeqDB>
 //   plass_oracle cyclecheck <seqDB> <outCycleDB> [--max-seq-len N --chop-cycle 0|1]
+//   plass_oracle extractorfs <seqDB> <outDB> [flags] | translatenucs <nuclDB> <outAaDB> [--add-orf-stop 1] | concatdbs <dbA> <dbB> <outDB>
 #include "oracle.hpp"
 #include <chrono>
 #include <cstdio>
@@ -32,6 +33,7 @@ static bool multiParam(const std::string &v, const char *which, std::string &out
     return false;
 }
 
+static oracle::OrfParams orfPar;    // extractorfs / translatenucs flags
 static bool chopCycle = false;      // --chop-cycle (cyclecheck; setCycleCheckDefaults: off unless the workflow passes it)
 static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<std::string> &pos) {
     for (int i = from; i < argc; i++) {
@@ -61,6 +63,20 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
             else if (a == "--max-seq-len") par.maxSeqLen = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--keep-target") par.keepTarget = atoi(v.c_str()) != 0;
             else if (a == "--chop-cycle") chopCycle = atoi(v.c_str()) != 0;
+            else if (a == "--min-length") orfPar.orfMinLength = (size_t) strtoull(v.c_str(), nullptr, 10);
+            else if (a == "--max-length") orfPar.orfMaxLength = (size_t) strtoull(v.c_str(), nullptr, 10);
+            else if (a == "--max-gaps") orfPar.orfMaxGaps = (size_t) strtoull(v.c_str(), nullptr, 10);
+            else if (a == "--contig-start-mode") orfPar.contigStartMode = atoi(v.c_str());
+            else if (a == "--contig-end-mode") orfPar.contigEndMode = atoi(v.c_str());
+            else if (a == "--orf-start-mode") orfPar.orfStartMode = atoi(v.c_str());
+            else if (a == "--forward-frames" || a == "--reverse-frames") {
+                unsigned m = 0; for (char c : v) if (c >= '1' && c <= '3') m |= 1u << (c - '1');
+                (a == "--forward-frames" ? orfPar.forwardFrames : orfPar.reverseFrames) = m;
+            }
+            else if (a == "--translation-table") orfPar.translationTable = atoi(v.c_str());
+            else if (a == "--translate") orfPar.translate = atoi(v.c_str()) != 0;
+            else if (a == "--use-all-table-starts") orfPar.useAllTableStarts = atoi(v.c_str()) != 0;
+            else if (a == "--add-orf-stop") orfPar.addOrfStop = atoi(v.c_str()) != 0;
             else if (a == "--threads") par.threads = std::max(1, atoi(v.c_str()));
             else if (a == "--oracle-no-stale-scan") par.debugNoStaleScan = atoi(v.c_str()) != 0;
             else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) par.gapOpenNucl = atoi(t.c_str()); }
@@ -141,6 +157,31 @@ int main(int argc, char **argv) {
         if (!cyclecheck(seq, par, chopCycle, out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         fprintf(stderr, "oracle cyclecheck: %.3f s\n", now() - t0);
         if (!writeDB(pos[1], out, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "extractorfs") {
+        if (pos.size() != 2) { fprintf(stderr, "extractorfs <seqDB> <outDB>   (writes <outDB> and <outDB>_h)\n"); return 1; }
+        DB seq, o, oh;
+        if (!readDB(pos[0], seq, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        orfPar.maxSeqLen = par.maxSeqLen;
+        double t0 = now();
+        if (!extractorfs(seq, orfPar, o, oh, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        fprintf(stderr, "oracle extractorfs: %zu orfs, %.3f s\n", o.size(), now() - t0);
+        if (!writeDB(pos[1], o, err) || !writeDB(pos[1] + "_h", oh, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "translatenucs") {
+        if (pos.size() != 2) { fprintf(stderr, "translatenucs <nuclDB> <outAaDB>   (--add-orf-stop 1 reads <nuclDB>_h)\n"); return 1; }
+        DB seq, hdr, o;
+        if (!readDB(pos[0], seq, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (orfPar.addOrfStop && !readDB(pos[0] + "_h", hdr, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        orfPar.maxSeqLen = par.maxSeqLen;
+        double t0 = now();
+        if (!translatenucs(seq, orfPar.addOrfStop ? &hdr : nullptr, orfPar, o, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        fprintf(stderr, "oracle translatenucs: %.3f s\n", now() - t0);
+        if (!writeDB(pos[1], o, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    } else if (mod == "concatdbs") {
+        if (pos.size() != 3) { fprintf(stderr, "concatdbs <dbA> <dbB> <outDB>\n"); return 1; }
+        DB a, b, o;
+        if (!readDB(pos[0], a, err) || !readDB(pos[1], b, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!concatdbs(a, b, o, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!writeDB(pos[2], o, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else { fprintf(stderr, "unknown module %s\n", mod.c_str()); return 1; }
     return 0;
 }

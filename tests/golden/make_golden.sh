@@ -159,5 +159,25 @@ for d in nucl/seq_2 longnucl/seq_0 longnucl/seq_2; do
 done
 printf 'in = make_cyclecheck.py; cycle_chop0|1 = penguin cyclecheck in --max-seq-len 50000 --chop-cycle 0|1; <db>_cycle = penguin cyclecheck <db> --max-seq-len 200000 --chop-cycle 1\n' > $C/MANIFEST
 tar -C $W -czf $HERE/cyclecheck.tar.gz cyc
+# ---------- extractorfs / translatenucs (row N2): hostile reads, the two workflow flag sets and two odd ones ----------
+R=$W/orf; mkdir -p $R
+python3 $HERE/make_orfs_input.py $R/in
+cat > $R/FLAGS <<F
+--min-length 20 --max-length 45 --max-gaps 0 --contig-start-mode 1 --contig-end-mode 0 --orf-start-mode 0 --forward-frames 1,2,3 --reverse-frames 1,2,3 --translation-table 1 --translate 0 --use-all-table-starts 0
+--min-length 45 --max-length 32734 --max-gaps 0 --contig-start-mode 2 --contig-end-mode 2 --orf-start-mode 0 --forward-frames 1,2,3 --reverse-frames 1,2,3 --translation-table 1 --translate 0
+--min-length 5 --max-length 100 --max-gaps 3 --contig-start-mode 2 --contig-end-mode 2 --orf-start-mode 2 --forward-frames 1,3 --reverse-frames 2 --translation-table 1 --translate 0
+--min-length 10 --max-length 32734 --max-gaps 1 --contig-start-mode 0 --contig-end-mode 1 --orf-start-mode 0 --forward-frames 1,2,3 --reverse-frames 1,2,3 --translation-table 1 --translate 0
+F
+n=0
+while read -r FL; do
+  n=$((n+1)); i=$(echo "1 2 4 5" | cut -d" " -f$n)
+  $PLASS extractorfs $R/in $W/ro $FL $Q > /dev/null; $CANON $W/ro $R/orfs_$i; $CANON $W/ro_h $R/orfs_${i}_h
+  $PLASS translatenucs $W/ro $W/ra --translation-table 1 --add-orf-stop 1 $Q > /dev/null; $CANON $W/ra $R/aa_stop_$i
+  $PLASS translatenucs $W/ro $W/rb --translation-table 1 --add-orf-stop 0 $Q > /dev/null; $CANON $W/rb $R/aa_$i
+  rm -f $W/ro* $W/ra* $W/rb*
+done < $R/FLAGS
+rm -f $R/in_h $R/in_h.index $R/in_h.dbtype
+printf 'in = make_orfs_input.py; orfs_<i>, orfs_<i>_h = plass extractorfs in <out> <line of FLAGS>; aa_stop_<i> / aa_<i> = plass translatenucs --add-orf-stop 1 / 0\n' > $R/MANIFEST
+tar -C $W -czf $HERE/orfs.tar.gz orf
 ls -la $HERE/*.tar.gz
 rm -rf $W

@@ -192,3 +192,30 @@ def test_oracle_thread_count_independent(oracle_bin, golden, tmp_path, threads):
     assert_same_db(f"{n}/aln_1", tmp_path / "naln", "nucl rescorediagonal")
     run_oracle(oracle_bin, ["nuclassembleresults", f"{n}/seq_1", f"{n}/aln_1", tmp_path / "nseq"] + NUCL_AS + t)
     assert_same_db(f"{n}/seq_2", tmp_path / "nseq", "nuclassembleresults")
+
+
+def test_oracle_orf_preprocessing(oracle_bin, golden, tmp_path):
+    """row N2 (oracle only so far): extractorfs + translatenucs on hostile reads for four flag sets (sequences, headers,
+    translations with and without --add-orf-stop), and the example's whole preprocessing chain — read DB -> two extractorfs
+    passes -> translatenucs -> concatdbs — which must reproduce the protein fragment DB iteration 0 starts from (aa/seq_0)"""
+    o = os.path.join(golden, "orf")
+    flags = [l.split() for l in open(os.path.join(o, "FLAGS")).read().splitlines() if l.strip()]
+    for n, fl in zip((1, 2, 4, 5), flags):
+        run_oracle(oracle_bin, ["extractorfs", f"{o}/in", tmp_path / f"orfs_{n}"] + fl)
+        assert_same_db(f"{o}/orfs_{n}", tmp_path / f"orfs_{n}", f"extractorfs flag set {n}")
+        assert_same_db(f"{o}/orfs_{n}_h", str(tmp_path / f"orfs_{n}") + "_h", f"extractorfs headers, flag set {n}")
+        run_oracle(oracle_bin, ["translatenucs", f"{o}/orfs_{n}", tmp_path / f"aa_stop_{n}", "--translation-table", "1", "--add-orf-stop", "1"])
+        assert_same_db(f"{o}/aa_stop_{n}", tmp_path / f"aa_stop_{n}", f"translatenucs --add-orf-stop 1, flag set {n}")
+        run_oracle(oracle_bin, ["translatenucs", f"{o}/orfs_{n}", tmp_path / f"aa_{n}", "--translation-table", "1", "--add-orf-stop", "0"])
+        assert_same_db(f"{o}/aa_{n}", tmp_path / f"aa_{n}", f"translatenucs --add-orf-stop 0, flag set {n}")
+    reads = os.path.join(golden, "nucl", "seq_0")              # nucl_reads of the bundled example (mergereads output)
+    common = ["--max-gaps", "0", "--orf-start-mode", "0", "--forward-frames", "1,2,3", "--reverse-frames", "1,2,3", "--translation-table", "1",
+              "--translate", "0", "--use-all-table-starts", "0"]
+    run_oracle(oracle_bin, ["extractorfs", reads, tmp_path / "nucl_6f_start", "--min-length", "20", "--max-length", "45", "--contig-start-mode", "1",
+                            "--contig-end-mode", "0"] + common)
+    run_oracle(oracle_bin, ["extractorfs", reads, tmp_path / "nucl_6f_long", "--min-length", "45", "--max-length", "32734", "--contig-start-mode", "2",
+                            "--contig-end-mode", "2"] + common)
+    for n in ("start", "long"):
+        run_oracle(oracle_bin, ["translatenucs", tmp_path / f"nucl_6f_{n}", tmp_path / f"aa_6f_{n}", "--translation-table", "1", "--add-orf-stop", "1"])
+    run_oracle(oracle_bin, ["concatdbs", tmp_path / "aa_6f_long", tmp_path / "aa_6f_start", tmp_path / "aa_6f_start_long"])
+    assert_same_db(os.path.join(golden, "aa", "seq_0"), tmp_path / "aa_6f_start_long", "preprocessing chain -> aa_6f_start_long")
