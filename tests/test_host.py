@@ -75,3 +75,31 @@ def test_bench_workload_parts_concatenate():
     assert int(o[-1]) + int(e[-1]) == len(d) and np.all(o[1:] == o[:-1] + e[:-1])
     p0 = bench.load_workload(1500, seed=1)
     assert d[:len(p0[0])] == p0[0] and np.array_equal(k[:len(p0[3])], p0[3])
+
+
+def test_local_group_host_allgather_threads():
+    """the in-process communicator of the GPU sharding tests (plass_amd.shard.LocalGroup): its host all-gather between
+    three rank threads, driven through the C callback table like libplasship drives it (no GPU needed for this part)"""
+    import ctypes as C
+    import threading
+    from plass_amd.shard import LocalGroup, owned_range
+    g = LocalGroup(3)
+    got = [None] * 3
+
+    def work(r):
+        send = (C.c_uint64 * 2)(r, 100 + r); recv = (C.c_uint64 * 6)()
+        for _ in range(5):                       # several rounds: the barrier is reusable
+            assert g.comms[r].struct.allgather_host(None, C.addressof(send), C.addressof(recv), 16) == 0
+        got[r] = list(recv)
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert all(x == [0, 100, 1, 101, 2, 102] for x in got)
+    # ownership ranges tile [0, n) for any n and world
+    for n in (0, 1, 7, 1000, 1622575):
+        for w in (1, 2, 3, 8):
+            edges = [owned_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
