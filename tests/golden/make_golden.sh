@@ -176,6 +176,22 @@ while read -r FL; do
   $PLASS translatenucs $W/ro $W/rb --translation-table 1 --add-orf-stop 0 $Q > /dev/null; $CANON $W/rb $R/aa_$i
   rm -f $W/ro* $W/ra* $W/rb*
 done < $R/FLAGS
+# a small second input (first 120 entries) for the any-to-stop start mode and extractorfs' own --translate 1
+python3 - "$R" <<'PY'
+import sys
+r = sys.argv[1]
+for suf in ("", "_h"):
+    lines = open(r + "/in" + suf + ".index").read().splitlines()[:120]
+    data = open(r + "/in" + suf, "rb").read()
+    end = int(lines[-1].split()[1]) + int(lines[-1].split()[2])
+    open(r + "/in_small" + suf, "wb").write(data[:end]); open(r + "/in_small" + suf + ".index", "w").write("\n".join(lines) + "\n")
+    open(r + "/in_small" + suf + ".dbtype", "wb").write(open(r + "/in" + suf + ".dbtype", "rb").read())
+PY
+ANY="--min-length 1 --max-length 32734 --max-gaps 2147483647 --contig-start-mode 2 --contig-end-mode 2 --orf-start-mode 1 --forward-frames 1,2,3 --reverse-frames 1,2,3 --translation-table 1"
+printf '%s --translate 0\n%s --translate 1\n' "$ANY" "$ANY" > $R/FLAGS_SMALL
+$PLASS extractorfs $R/in_small $W/ro $ANY --translate 0 $Q > /dev/null; $CANON $W/ro $R/small_orfs_any; $CANON $W/ro_h $R/small_orfs_any_h; rm -f $W/ro*
+$PLASS extractorfs $R/in_small $W/ro $ANY --translate 1 $Q > /dev/null; $CANON $W/ro $R/small_orfs_translated; $CANON $W/ro_h $R/small_orfs_translated_h; rm -f $W/ro*
+rm -f $R/in_small_h $R/in_small_h.index $R/in_small_h.dbtype
 rm -f $R/in_h $R/in_h.index $R/in_h.dbtype
 printf 'in = make_orfs_input.py; orfs_<i>, orfs_<i>_h = plass extractorfs in <out> <line of FLAGS>; aa_stop_<i> / aa_<i> = plass translatenucs --add-orf-stop 1 / 0\n' > $R/MANIFEST
 tar -C $W -czf $HERE/orfs.tar.gz orf

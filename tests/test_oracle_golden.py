@@ -208,6 +208,11 @@ def test_oracle_orf_preprocessing(oracle_bin, golden, tmp_path):
         assert_same_db(f"{o}/aa_stop_{n}", tmp_path / f"aa_stop_{n}", f"translatenucs --add-orf-stop 1, flag set {n}")
         run_oracle(oracle_bin, ["translatenucs", f"{o}/orfs_{n}", tmp_path / f"aa_{n}", "--translation-table", "1", "--add-orf-stop", "0"])
         assert_same_db(f"{o}/aa_{n}", tmp_path / f"aa_{n}", f"translatenucs --add-orf-stop 0, flag set {n}")
+    small = [l.split() for l in open(os.path.join(o, "FLAGS_SMALL")).read().splitlines() if l.strip()]     # any-to-stop; --translate 1
+    for name, fl in zip(("small_orfs_any", "small_orfs_translated"), small):
+        run_oracle(oracle_bin, ["extractorfs", f"{o}/in_small", tmp_path / name] + fl)
+        assert_same_db(f"{o}/{name}", tmp_path / name, f"extractorfs {name}")
+        assert_same_db(f"{o}/{name}_h", str(tmp_path / name) + "_h", f"extractorfs {name} headers")
     reads = os.path.join(golden, "nucl", "seq_0")              # nucl_reads of the bundled example (mergereads output)
     common = ["--max-gaps", "0", "--orf-start-mode", "0", "--forward-frames", "1,2,3", "--reverse-frames", "1,2,3", "--translation-table", "1",
               "--translate", "0", "--use-all-table-starts", "0"]
