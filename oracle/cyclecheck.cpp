@@ -49,43 +49,38 @@ bool cyclecheck(const DB &seqDb, const Params &par, bool chopCycle, DB &out, std
         std::sort(frontKmers.begin(), frontKmers.end(), compareByKmer);
         std::sort(middleKmers.begin(), middleKmers.end(), compareByKmer);
         std::sort(backKmers.begin(), backKmers.end(), compareByKmer);
-        const unsigned int frontKmersCount = frontKmers.size(), middleKmersCount = middleKmers.size(), backKmersCount = backKmers.size();
-        unsigned int kmermatches = 0;
+        unsigned int nMatches = 0;
         diagHits.assign((size_t) 2 * thirdSeqLen + 1, 0);
-        unsigned int idx = 0, jdx = 0, kdx = 0;
-        while (idx < frontKmersCount && (jdx < backKmersCount || kdx < middleKmersCount)) {   // :151-188 front-back, front-middle
-            const size_t kmerIdx = frontKmers[idx].kmer;
-            const unsigned int pos = frontKmers[idx].pos;
-            while (jdx < backKmersCount && backKmers[jdx].kmer < kmerIdx) jdx++;
-            while (kdx < middleKmersCount && middleKmers[kdx].kmer < kmerIdx) kdx++;
-            while (jdx < backKmersCount && kmerIdx == backKmers[jdx].kmer) {
-                const int diag = backKmers[jdx].pos - pos;
-                if (diag >= static_cast<int>(seqLen / 3)) { diagHits[diag - seqLen / 3]++; kmermatches++; }
-                jdx++;
-            }
-            while (kdx < middleKmersCount && kmerIdx == middleKmers[kdx].kmer) {
-                const int diag = middleKmers[kdx].pos - pos;
-                if (diag >= static_cast<int>(seqLen / 3)) { diagHits[diag - seqLen / 3]++; kmermatches++; }
-                kdx++;
-            }
-            idx++;
-            while (idx < frontKmersCount && kmerIdx == frontKmers[idx].kmer) idx++;
+        const int third = static_cast<int>(seqLen / 3);
+        // a match between a k-mer at `lo` (earlier third) and the same k-mer at `hi` (later third) counts when its diagonal is >= L/3
+        auto hit = [&](unsigned int hi, unsigned int lo) {
+            const int diag = hi - lo;
+            if (diag >= third) { diagHits[diag - seqLen / 3]++; nMatches++; }
+        };
+        const size_t nF = frontKmers.size(), nM = middleKmers.size(), nB = backKmers.size();
+        // front against back and middle (:151-188): only the FIRST entry of a run of equal front k-mers (smallest position) is used,
+        // against every back and every middle entry of that k-mer
+        for (size_t f = 0, b = 0, m = 0; f < nF && (b < nB || m < nM); ) {
+            const size_t key = frontKmers[f].kmer;
+            const unsigned int fpos = frontKmers[f].pos;
+            while (b < nB && backKmers[b].kmer < key) b++;
+            while (m < nM && middleKmers[m].kmer < key) m++;
+            for (; b < nB && backKmers[b].kmer == key; b++) hit(backKmers[b].pos, fpos);
+            for (; m < nM && middleKmers[m].kmer == key; m++) hit(middleKmers[m].pos, fpos);
+            do f++; while (f < nF && frontKmers[f].kmer == key);
         }
-        jdx = 0; kdx = 0;
-        while (kdx < middleKmersCount && jdx < backKmersCount) {                           // :191-216 middle-back
-            if (middleKmers[kdx].kmer < backKmers[jdx].kmer) kdx++;
-            else if (middleKmers[kdx].kmer > backKmers[jdx].kmer) jdx++;
+        // middle against back (:191-216): first middle entry of a k-mer against every back entry of it
+        for (size_t m = 0, b = 0; m < nM && b < nB; ) {
+            if (middleKmers[m].kmer < backKmers[b].kmer) m++;
+            else if (middleKmers[m].kmer > backKmers[b].kmer) b++;
             else {
-                const size_t kmerIdx = middleKmers[kdx].kmer;
-                const unsigned int pos = middleKmers[kdx].pos;
-                while (jdx < backKmersCount && kmerIdx == backKmers[jdx].kmer) {
-                    const int diag = backKmers[jdx].pos - pos;
-                    if (diag >= static_cast<int>(seqLen / 3)) { diagHits[diag - seqLen / 3]++; kmermatches++; }
-                    jdx++;
-                }
-                while (kdx < middleKmersCount && kmerIdx == middleKmers[kdx].kmer) kdx++;
+                const size_t key = middleKmers[m].kmer;
+                const unsigned int mpos = middleKmers[m].pos;
+                for (; b < nB && backKmers[b].kmer == key; b++) hit(backKmers[b].pos, mpos);
+                while (m < nM && middleKmers[m].kmer == key) m++;
             }
         }
+        const unsigned int kmermatches = nMatches;
         unsigned int splitDiagonal = 0;                                                    // :241-269 hit rate of diagonal bands
         if (kmermatches > 0) {
             for (unsigned int d = 0; d < 2 * thirdSeqLen; d++) {
