@@ -1,25 +1,34 @@
 #!/usr/bin/env python3
 """bench.py — candidate read-overlaps per second per assembly iteration on MI355X (BASELINE.json metric).
 
-A "step" is one assembly iteration of the hot path — kmermatcher -> rescorediagonal -> assembleresults — over
-the synthetic protein-fragment DB of BASELINE.json configs[1] (1 M synthetic 2x150 bp protein-coding reads,
-500 k pairs, ~1.6 M protein fragments), chained on the device like `plass assemble --num-iterations K`
-(iteration 0: --hash-shift 67 --include-only-extendable 0; later: 68,68,69,… and 1; src/workflow/Assembler.cpp:99-110).
-The input DB is resident in HBM before the timed region; each of the W warm-up steps is one untimed traversal of
-the same K-iteration chain (results discarded), so every iteration's kernels and buffers are warm.  value = sum over the K timed iterations of the candidate overlaps kmermatcher
-emitted (non-self prefilter lines) / wall time, max over ranks, summed over ranks.
+A "step" is ONE assembly iteration of the hot path — kmermatcher -> rescorediagonal -> assembleresults — chained on the
+device like `plass assemble` chains them through DBs (iteration 0: --hash-shift 67 --include-only-extendable 0; later: 68, 68,
+69, … and 1; src/workflow/Assembler.cpp:99-110).  The workload is a CONFIG of BASELINE.json and brings its own iteration
+count (the chain length); --steps K times K iterations: iteration (s mod chain) of the chain, restarting from the input DB
+when the chain is through — so K never changes what an iteration works on.  --warmup W runs the first W iterations of the
+chain untimed.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU), default `--mode sharded`: ONE read set of N x 1 M reads
-(N genomes, one seeded part per rank's worth) is sharded over the N GPUs by k-mer bucket — every rank extracts the k-mers
-of its share of the sequences, the records travel to the owner of their hash bucket and the grouped records to the owner
-of the representative by RCCL all-to-all(v) over xGMI, every rank re-scores and extends the queries it owns and the
-extended sequences are all-gathered (include/plasship.h: plasship_ctx_set_comm).  Per-GPU work is
-fixed as N grows: weak scaling.  `--mode partitions` is the older independent-partitions run (no data-path collective).
+  default (no flags), N = 1: BASELINE configs[2] — 50 M synthetic 2x150 bp metagenomic reads (25 M pairs from a community of
+      200 genomes of 1-5 Mbp with log-normal abundances, sigma 1, seed 2), default parameters (12 iterations, k = 14,
+      alphabet 13, 60 k-mers per sequence, min-seq-id 0.9, e 1e-5).  --config c2 = configs[1] (1 M reads, one 7.5 Mbp
+      genome, seed 1, 6 iterations).  --pairs P scales the community with the reads (same coverage).
+  N > 1 (torch.distributed.run, one rank per GPU): configs[3] — the SAME read set, sharded by k-mer bucket over the N GPUs
+      (RCCL all-to-all(v) of k-mer and grouped records, all-gather of extended sequences; include/plasship.h:
+      plasship_ctx_set_comm).  Total work is fixed as N grows: strong scaling.
 
-Also reported on the same JSON line:
-  roofline     — dominant kernel of the timed run: algorithmic bytes / its HIP-event time
-  cpu_baseline — the CPU oracle (a single-threaded port of the reference algorithm, oracle/) timed on a bounded
-                 sample of the same workload on this host (rank 0, N=1 only)
+The reads are generated in HBM (include/plasship_synth.h) and turned into the protein fragment DB by the GPU versions of the
+workflow's own preprocessing (extractorfs x2, translatenucs x2, concatdbs: data/assemble.sh:41-77) before the timed region;
+every rank generates the identical DB from the seed.  value = candidate overlaps kmermatcher emitted in the K timed
+iterations (non-self prefilter lines) / wall time (max over ranks), inputs resident in HBM.
+
+Also on the JSON line:
+  iterations   — one row per timed step: chain iteration, ms, N_k / N_m / N_c, stage times
+  roofline     — dominant kernel of the timed run: algorithmic bytes / its HIP-event time, per launch;
+                 `traffic` = HBM bytes per launch of that kernel from the stored rocprofv3 PMC pass of the same command
+                 (profiles/r02_pmc_traffic.json), null if that file has no row for it
+  cpu_baseline — the CPU oracle (a port of the reference's algorithm, oracle/) on a bounded sample of the same community
+                 model on this host's cores (rank 0, N = 1), plus the I/O-inclusive rate of the drop-in command line
+                 (plass-hip: DB files in, DB files out) on the same sample
 """
 import argparse
 import json
@@ -33,8 +42,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-WALL = []               # host wall ms per module call (kmermatcher, rescorediagonal, assembleresults)
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+CONFIGS = {
+    # name: (BASELINE.json index, read pairs, genomes, min/max genome length, abundance sigma, seed, chain length)
+    "c3": (2, 25000000, 200, 1000000, 5000000, 1.0, 2, 12),
+    "c2": (1, 500000, 1, 7500000, 7500000, 0.0, 1, 6),
+}
 
 
 def hash_shift(it):
@@ -44,59 +58,36 @@ def hash_shift(it):
     return hs
 
 
-def load_workload(pairs, seed):
-    import numpy as np
-    from plass_amd import synth
-    cache = os.path.join(tempfile.gettempdir(), "plasship_bench_cache")
-    os.makedirs(cache, exist_ok=True)
-    f = os.path.join(cache, "frag_p%d_s%d.npz" % (pairs, seed))
-    if os.path.exists(f):
-        try:
-            z = np.load(f)
-            return z["data"].tobytes(), z["off"], z["elen"], z["key"]
-        except Exception:          # a cache file from a run that was killed while writing: regenerate
-            pass
-    data, off, elen, key = synth.protein_fragment_db(pairs, seed=seed)
-    try:
-        tmp = os.path.join(cache, "tmp_%d_frag_p%d_s%d.npz" % (os.getpid(), pairs, seed))
-        np.savez(tmp, data=np.frombuffer(data, dtype=np.uint8), off=off, elen=elen, key=key)
-        os.replace(tmp, f)         # atomic: other ranks / later runs never see a partial file
-    except OSError:
-        pass
-    return data, off, elen, key
+def synth_params(cfg, pairs=None):
+    """SynthParams of a config; another number of pairs keeps the coverage (the community shrinks / grows with the reads)"""
+    import plass_amd
+    _, p0, g, lo, hi, sigma, seed, _ = CONFIGS[cfg]
+    pairs = p0 if not pairs else pairs
+    if pairs != p0:
+        if g > 1:
+            g = max(1, int(round(g * pairs / p0)))
+            if g == 1:
+                lo = hi = max(30000, int(3000000 * 200 * pairs / p0))
+        else:
+            lo = hi = max(30000, int(lo * pairs / p0))
+    return plass_amd.SynthParams(n_pairs=pairs, seed=seed, n_genomes=g, genome_min_len=lo, genome_max_len=hi, abundance_sigma=sigma)
 
 
-def load_sharded_workload(pairs, rank, world, dist):
-    """ONE read set of `world` parts (part r = the set a single GPU gets with seed 1 + r).  Rank r generates part r into the
-    node-local cache, then everybody loads all parts; keys are made unique by a per-part offset."""
-    import numpy as np
-    load_workload(pairs, seed=1 + rank)
-    if dist is not None:
-        dist.barrier()
-    datas, offs, elens, keys = [], [], [], []
-    base, kbase = 0, 0
-    for r in range(world):
-        d, o, e, k = load_workload(pairs, seed=1 + r)
-        datas.append(d); offs.append(np.asarray(o, dtype=np.uint64) + np.uint64(base)); elens.append(np.asarray(e, dtype=np.uint32))
-        keys.append(np.asarray(k, dtype=np.uint32) + np.uint32(kbase))
-        base += len(d); kbase += int(np.max(k)) + 1 if len(k) else 0
-    return b"".join(datas), np.concatenate(offs), np.concatenate(elens), np.concatenate(keys)
-
-
-def sharded_preflight(ctx, dist, device):
-    """one sharded iteration on a small read set (the same on every rank): every rank must end with the same DB"""
-    import torch
-    from plass_amd import synth
-    data, off, elen, key = synth.protein_fragment_db(3000, seed=7)
-    db = ctx.upload_seqdb(data, off, elen, key, 0)
-    out, kst, _, _ = one_iteration(ctx, db, 0)
-    WALL.pop()
-    i = out.info()
-    t = torch.tensor([i["residues"], -i["residues"], kst.n_candidates], dtype=torch.int64, device=device)
-    mx = t.clone(); dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    if int(mx[0]) != -int(mx[1]):
-        raise RuntimeError("sharded preflight: the ranks ended with different output DBs")
-    out.free(); db.free()
+def build_workload(ctx, cfg, pairs=None):
+    """reads in HBM -> protein fragment DB (the DB iteration 0 starts from); returns (db, description dict)"""
+    t0 = time.perf_counter()
+    sp = synth_params(cfg, pairs)
+    reads, sst = ctx.synth_read_pairs(sp)
+    t1 = time.perf_counter()
+    frag = ctx.plass_fragments(reads)
+    ctx.sync()
+    t2 = time.perf_counter()
+    ri = reads.info(); fi = frag.info()
+    reads.free()
+    return frag, {"read_pairs": sp.n_pairs, "reads": ri["n"], "genomes": sp.n_genomes, "genome_bases": int(sst.genome_bases), "genes": int(sst.n_genes),
+                  "mean_coverage": round(sst.mean_coverage, 2), "max_genome_coverage": round(sst.max_coverage, 1), "seed": sp.seed,
+                  "protein_fragments": fi["n"], "fragment_residues": fi["residues"],
+                  "generate_reads_s": round(t1 - t0, 3), "extractorfs_translatenucs_concatdbs_s": round(t2 - t1, 3)}
 
 
 def one_iteration(ctx, db, it):
@@ -111,28 +102,26 @@ def one_iteration(ctx, db, it):
     out, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
     t3 = time.perf_counter()
     alns.free(); cands.free()
-    WALL.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
-    return out, kst, rst, ast
+    return out, kst, rst, ast, ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3)
 
 
 def stage_table(kst, rst, ast):
-    """per kernel / stage: (HIP-event ms per iteration, algorithmic bytes per SURVEY.md §8d, is_single_kernel, launches per iteration).
-    The hash partition (the reference's sort #1, ideal traffic 2*s*N_k = one read + one write of the records) runs as two
-    partScatterKernel launches (coarse, fine) plus two histogram launches: the scatter kernel is listed on its own with the
-    stage's ideal bytes split over its launches, so the second level counts against the achieved fraction."""
+    """per kernel / stage: (HIP-event ms, algorithmic bytes per SURVEY.md section 8d, is_single_kernel, launches).
+    The hash partition (the reference's sort #1, ideal traffic 2*s*N_k = one read + one write of the records) runs as several
+    partition-kernel launches: the kernel is listed on its own with the stage's ideal bytes split over its launches, so every
+    extra pass counts against the achieved fraction."""
     s = kst.record_bytes
     Nk, Nm, Nc = kst.n_kmer_records, kst.n_grouped, kst.n_candidates
     t = {
-        "extractShortKernel": (kst.ms_extract_short_kernel, kst.short_residues + s * kst.short_records, True),
-        "extractKernel": (kst.ms_extract_wave_kernel, kst.wave_residues + s * kst.wave_records, True),
-        "hash_partition(partHist+partScatter x levels)": (kst.ms_sort1, 2 * s * Nk, False, 1),
-        "partScatterKernel": (kst.ms_part_scatter, 2 * s * Nk, True, max(kst.n_part_scatter, 1)),
+        "extractShortKernel": (kst.ms_extract_short_kernel, kst.short_residues + s * kst.short_records, True, 1),
+        "extractKernel": (kst.ms_extract_wave_kernel, kst.wave_residues + s * kst.wave_records, True, 1),
+        "hash_partition(all passes)": (kst.ms_sort1, 2 * s * Nk, False, 1),
+        "partitionKernel(k-mer records)": (kst.ms_part_scatter, 2 * s * Nk, True, max(kst.n_part_scatter, 1)),
         "groupKernel": (kst.ms_group, s * Nk + s * Nm, True, 1),
         "rep_sort(partition+aggSortKernel)": (kst.ms_sort2, 2 * s * Nm, False, 1),
         "run_reduce(reduceRunsKernel+CSR)": (kst.ms_reduce, s * Nm + 12 * Nc, False, 1),
         "rescoreKernel": (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored, True, 1),
     }
-    t["extractShortKernel"] += (1,); t["extractKernel"] += (1,)
     # whole kmermatcher stage against SURVEY.md section 8d's B_K = R + 4*s*N_k + 4*s*N_m + 12*N_c (every kernel and the host
     # round trips in between count): the number the north star's "achieved HBM bandwidth in kmermatcher" refers to
     t["kmermatcher_stage"] = (kst.ms_extract + kst.ms_sort1 + kst.ms_group + kst.ms_sort2 + kst.ms_reduce,
@@ -142,47 +131,84 @@ def stage_table(kst, rst, ast):
     return t
 
 
-def cpu_baseline(sample_pairs, iters):
-    """the CPU oracle (a port of the reference algorithm; OpenMP over the loops the reference threads: extraction, the two sorts,
-    re-scoring, extension) on a bounded sample of the same workload, on the host cores of this box; module compute time only"""
+def stored_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the stored PMC pass of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two
+    separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None"""
+    f = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    try:
+        rows = json.load(open(f))
+    except (OSError, ValueError):
+        return None
+    key = re.sub(r"[<(].*", "", kernel)
+    for name, row in rows.get("kernels", {}).items():
+        if name.startswith(key):
+            return row.get("hbm_bytes_per_launch")
+    return None
+
+
+def cpu_baseline(ctx, cfg, sample_pairs, iters):
+    """(1) the CPU oracle — a port of the reference algorithm with OpenMP over the loops the reference threads — on a bounded
+    sample of the same community model (same generator, same coverage), module compute time only;
+    (2) the drop-in command line on the same DB files: plass-hip kmermatcher / rescorediagonal / assembleresults, DB files in
+    and out, its own "Time for processing" summed = the I/O-inclusive rate of the GPU path through the module boundary."""
     import __graft_entry__ as g
-    from plass_amd import synth
     if not os.path.exists(g.oracle_bin()):
         subprocess.check_call(["make", "-j", "4"], cwd=os.path.join(ROOT, "oracle"))
     threads = max(1, min(len(os.sched_getaffinity(0)), 64))
-    if sample_pairs <= 0:                                    # default: ~10-30 s of CPU work whatever the core count
+    if sample_pairs <= 0:                                    # ~10-30 s of CPU work whatever the core count
         sample_pairs = 40000 if threads < 8 else 120000
-    data, off, elen, key = synth.protein_fragment_db(sample_pairs, seed=101)
+    db, desc = build_workload(ctx, cfg, sample_pairs)
     thr = ["--threads", str(threads)]
-    tot_t, tot_c = 0.0, 0
+    tot_t, tot_c, cli_t, cli_c = 0.0, 0, 0.0, 0
+    hip = os.path.join(ROOT, "plass_amd", "plass-hip")
     with tempfile.TemporaryDirectory() as td:
-        synth.write_db(os.path.join(td, "seq_0"), data, off, elen, key, 0)
+        db.write(os.path.join(td, "seq_0")); db.free()
         for it in range(iters):
             s, p, a, o = (os.path.join(td, x) for x in ("seq_%d" % it, "pref", "aln", "seq_%d" % (it + 1)))
-            e1 = g.run_oracle(["kmermatcher", s, p, "--alph-size", "13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "0", "-k", "14", "-c", "0",
-                               "--hash-shift", str(hash_shift(it)), "--include-only-extendable", "1" if it else "0", "--ignore-multi-kmer", "1"] + thr)
-            e2 = g.run_oracle(["rescorediagonal", s, s, p, a, "--min-seq-id", "0.9", "-e", "1e-5", "-c", "0"] + thr)
-            e3 = g.run_oracle(["assembleresults", s, a, o, "--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1"] + thr)
+            km = ["--alph-size", "13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "0", "-k", "14", "-c", "0", "--hash-shift", str(hash_shift(it)),
+                  "--include-only-extendable", "1" if it else "0", "--ignore-multi-kmer", "1"]
+            rs = ["--rescore-mode", "3", "--min-seq-id", "0.9", "-e", "1e-5", "-c", "0"]
+            asm = ["--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1", "--rescore-mode", "3"]
+            if os.path.exists(hip):                          # the GPU path through the module boundary, on the same files
+                for args in (["kmermatcher", s, p + "_g"] + km, ["rescorediagonal", s, s, p + "_g", a + "_g"] + rs, ["assembleresults", s, a + "_g", o + "_g"] + asm):
+                    out = subprocess.run([hip] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                    m = re.search(r"Time for processing: ([0-9.]+)s", out.stdout)
+                    if out.returncode != 0 or not m:
+                        raise RuntimeError("plass-hip %s failed: %s" % (args[0], out.stdout[-500:]))
+                    cli_t += float(m.group(1))
+                    m = re.search(r"candidates: (\d+)", out.stdout)
+                    if m:
+                        cli_c += int(m.group(1))
+            e1 = g.run_oracle(["kmermatcher", s, p] + km + thr)
+            e2 = g.run_oracle(["rescorediagonal", s, s, p, a] + rs[2:] + thr)
+            e3 = g.run_oracle(["assembleresults", s, a, o] + asm[:6] + thr)
             tot_c += int(re.search(r"N_c=(\d+)", e1).group(1))
             for e in (e1, e2, e3):
                 tot_t += float(re.search(r"([0-9.]+) s\s*$", e.strip()).group(1))
-    return {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
-            "sample": "%d read pairs (%d protein fragments), %d iterations, oracle module compute time (no DB I/O), %d OpenMP threads "
-                      "(grouping and result writing are single-threaded, as in the reference)" % (sample_pairs, len(key), iters, threads)}
+    res = {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
+           "sample": "%d read pairs of the same community model at the same coverage (%d genomes, %d protein fragments), iterations 0..%d of the chain, "
+                     "oracle module compute time (no DB I/O), %d OpenMP threads (grouping and result writing are single-threaded, as in the reference)"
+                     % (desc["read_pairs"], desc["genomes"], desc["protein_fragments"], iters - 1, threads),
+           # BASELINE.md section 2/3: the unmodified reference (AVX2, 8 threads) against this port in the build container
+           "reference_vs_port_build_container": {"reference_overlaps_per_s": 0.40e6, "port_overlaps_per_s": 0.30e6, "threads": 8,
+                                                 "note": "reference source cannot travel to the GPU box; scale `value` by 0.40/0.30 for the AVX2 reference"}}
+    if cli_t > 0:
+        res["drop_in_cli_same_sample"] = {"value": cli_c / cli_t, "unit": "overlaps/s", "seconds": round(cli_t, 3),
+                                          "what": "plass-hip kmermatcher + rescorediagonal + assembleresults, DB files in / DB files out, sum of `Time for processing`"}
+    return res
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--pairs", type=int, default=500000, help="read pairs per GPU (500000 = 1 M reads, BASELINE configs[1])")
-    ap.add_argument("--parts", type=int, default=1, help="single GPU: build the read set from this many independently seeded parts of --pairs each "
-                    "(a 50 M-read set as 10 x 2.5 M pairs keeps the generator's host memory at one part)")
+    ap.add_argument("--steps", type=int, default=None, help="timed iterations (default: one traversal of the config's chain)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed iterations first (default: one traversal of the chain)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="c3 = BASELINE configs[2]/[3] (50 M reads, default); c2 = configs[1] (1 M reads)")
+    ap.add_argument("--pairs", type=int, default=0, help="read pairs of the whole job (0 = the config's own; the community scales with it)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = 40000 below 8 host cores, 120000 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=["auto", "sharded", "partitions"], default="auto",
-                    help="N > 1: 'sharded' = one read set over the GPUs with RCCL all-to-all (default), 'partitions' = independent sets")
+                    help="N > 1: 'sharded' = the one read set over the GPUs with RCCL all-to-all (default); 'partitions' = N independent sets of 1/N the size")
     args = ap.parse_args()
 
     import torch
@@ -192,14 +218,17 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
+    cfg_idx, cfg_pairs, _, _, _, _, _, chain = CONFIGS[args.config]
+    pairs = args.pairs or cfg_pairs
+    steps = chain if args.steps is None else args.steps
+    warmup = chain if args.warmup is None else args.warmup
     dist = None
     if world > 1 or os.environ.get("PLASS_BENCH_FORCE_DIST"):      # one process per GPU over RCCL ("nccl" backend on ROCm); the env
         # switch runs the same collectives in a 1-rank group (what a 1-GPU box can check of the N > 1 path)
-        dist = pdist.init("nccl", rank, world, device=torch.device("cuda", local), timeout_s=180)
-    plan = pdist.partition_plan(world)
+        dist = pdist.init("nccl", rank, world, device=torch.device("cuda", local), timeout_s=300)
     mode = args.mode
     if mode == "auto":
-        mode = "sharded" if dist is not None else "partitions"
+        mode = "sharded" if dist is not None else "single"
     if mode == "sharded" and dist is None:
         raise SystemExit("--mode sharded needs torch.distributed (launch with torch.distributed.run, or PLASS_BENCH_FORCE_DIST=1 on one GPU)")
 
@@ -216,23 +245,22 @@ def main():
             if args.mode == "sharded":
                 raise
             sharded_error = "%s: %s" % (type(e).__name__, e)
-        # every rank takes the same decision (a rank that failed alone must not leave the others in a collective)
         ok = torch.tensor([0 if sharded_error else 1], dtype=torch.int64, device=torch.device("cuda", local))
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # every rank takes the same decision
         if int(ok.item()) == 0:
             sharded_error = sharded_error or "the preflight failed on another rank"
             TorchComm.uninstall(ctx)
             comm, mode = None, "partitions"
-    if mode == "sharded":
-        data, off, elen, key = load_sharded_workload(args.pairs, rank, world, dist)
-    elif args.parts > 1:
-        data, off, elen, key = load_sharded_workload(args.pairs, 0, args.parts, None)
-    else:
-        data, off, elen, key = load_workload(args.pairs, seed=plan["seeds"][rank])
-    ctx.sync(); tu0 = time.perf_counter()
-    db0 = ctx.upload_seqdb(data, off, elen, key, 0)
-    ctx.sync(); upload_s = time.perf_counter() - tu0            # host buffers -> HBM (PCIe), outside the timed region
-    n_frag = len(key)
+    if mode == "partitions":
+        pairs = max(1000, pairs // world)
+    if comm is not None:
+        TorchComm.uninstall(ctx)                         # the preprocessing is not sharded: every rank builds the identical DB
+    db0, wl = build_workload(ctx, args.config, pairs)
+    if mode == "partitions" and world > 1:
+        wl["note"] = "independent partition of 1/%d of the job per rank (same seed model, no data-path collective)" % world
+    if comm is not None:
+        comm.install(ctx)
+    n_frag = wl["protein_fragments"]
 
     def barrier():
         ctx.sync(); torch.cuda.synchronize()
@@ -240,88 +268,94 @@ def main():
             dist.barrier()
         ctx.sync(); torch.cuda.synchronize()
 
-    # warm-up: W untimed traversals of the same K-iteration chain (iteration i of the chain works on the output of
-    # iteration i-1, so warming with iteration 0 alone would leave the later iterations' kernels, tiers and buffer sizes cold)
-    for _ in range(args.warmup):
-        wdb = db0
-        for it in range(args.steps):
-            out, _, _, _ = one_iteration(ctx, wdb, it)
-            if wdb is not db0:
-                wdb.free()
-            wdb = out
-        if wdb is not db0:
-            wdb.free()
+    def run(n_steps, record):
+        db, rows, total = db0, [], 0
+        for s in range(n_steps):
+            it = s % chain
+            if it == 0 and db is not db0:
+                db.free(); db = db0
+            ts = time.perf_counter()
+            out, kst, rst, ast, wall = one_iteration(ctx, db, it)
+            if record:
+                ctx.sync()
+                rows.append((it, (time.perf_counter() - ts) * 1e3, kst, rst, ast, wall))
+                total += kst.n_candidates
+            if db is not db0:
+                db.free()
+            db = out
+        return db, rows, total
+
+    wdb, _, _ = run(warmup, False)
+    if wdb is not db0:
+        wdb.free()
     barrier()
     if comm is not None:
         comm.bytes_moved = 0; comm.seconds = 0.0; comm.calls = 0
     t0 = time.perf_counter()
-    db = db0
-    stats = []
-    overlaps = 0
-    for it in range(args.steps):
-        out, kst, rst, ast = one_iteration(ctx, db, it)
-        overlaps += kst.n_candidates
-        stats.append(stage_table(kst, rst, ast))
-        if os.environ.get("PLASS_BENCH_VERBOSE") and rank == 0:     # per-iteration counters, to stderr
-            print("it%d kmer: Nk=%d Nm=%d Nc=%d | rescore: scored=%d accepted=%d ov=%d | assemble: aln=%d ext=%d resc=%d rescRes=%d tiers ms=%s aln=%s qres=%s rres=%s | wall %s" % (
-                it, kst.n_kmer_records, kst.n_grouped, kst.n_candidates, rst.n_scored, rst.n_accepted, rst.overlap_residues,
-                ast.n_alignments, ast.n_extended, ast.n_rescored, ast.rescored_residues, ["%.2f" % x for x in ast.ms_tier_kernel],
-                list(ast.tier_alignments), list(ast.tier_query_residues), list(ast.tier_rescored_residues), ["%.2f" % x for x in WALL[-1]]), file=sys.stderr)
-        if db is not db0:
-            db.free()
-        db = out
+    db, rows, overlaps = run(steps, True)
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    td0 = time.perf_counter()
-    final_bytes = len(db.download()[0]) if args.steps else 0     # final contig DB back to host buffers (PCIe), outside the timed region
-    download_s = time.perf_counter() - td0
+    final_info = db.info() if steps else db0.info()
     local_overlaps = overlaps
     elapsed, overlaps = pdist.reduce_step(dist, elapsed, overlaps, device="cuda")
 
     if rank == 0:
-        # dominant kernel over the timed iterations (rank 0's HIP-event times)
+        stats = [stage_table(k, r, a) for (_, _, k, r, a, _) in rows]
         tot = {}
         for st in stats:
             for k, (ms, b, single, launches) in st.items():
                 a = tot.setdefault(k, [0.0, 0, single, 0])
                 a[0] += ms; a[1] += b; a[3] += launches
-        # the kernel with the largest total time over the timed iterations; its numbers are per launch
-        dom = max((k for k in tot if tot[k][2]), key=lambda k: tot[k][0])
-        ms_avg = tot[dom][0] / max(tot[dom][3], 1)
-        bytes_avg = tot[dom][1] / max(tot[dom][3], 1)
-        achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
+        # the single kernel with the largest total time over the timed iterations; its numbers are per launch
+        dom = max((k for k in tot if tot[k][2]), key=lambda k: tot[k][0]) if tot else None
+        roof = None
+        if dom:
+            ms_avg = tot[dom][0] / max(tot[dom][3], 1)
+            bytes_avg = tot[dom][1] / max(tot[dom][3], 1)
+            achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
+            km = tot["kmermatcher_stage"]
+            roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": stored_traffic(dom), "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
+                    "stage_ms_per_step": {k: round(v[0] / len(stats), 4) for k, v in tot.items()},
+                    "kmermatcher_stage": {"algorithmic_bytes_per_step": km[1] / len(stats), "ms_per_step": km[0] / len(stats),
+                                          "frac": (km[1] / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if km[0] > 0 else 0.0},
+                    "module_wall_ms_per_step": [round(sum(r[5][i] for r in rows) / len(rows), 3) for i in range(3)]}
         line = {
-            "metric": "read-overlaps/s per assembly iteration", "value": overlaps / elapsed, "unit": "overlaps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed * 1e3 / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 (integer hash, byte compare; f32 ratios)",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d synthetic 2x150 bp protein-coding reads per GPU (%d read pairs, %d protein fragments), "
-                                   "--num-iterations %d, k=14, alph 13, kmer-per-seq 60, min-seq-id 0.9, e 1e-5" % (
-                                       2 * args.pairs * (args.parts if mode != "sharded" else 1), args.pairs * (args.parts if mode != "sharded" else 1), n_frag, args.steps),
+            "metric": "read-overlaps/s per assembly iteration", "value": overlaps / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s",
+            "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed * 1e3 / max(steps, 1),
+            "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
+            "dtype": "u8/u64 (integer hash, byte compare; f32 ratios)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]%s: %d synthetic 2x150 bp reads (%d read pairs from %d genomes, %.1fx mean coverage, seed %d) -> %d protein fragments; "
+                                   "step s = iteration (s mod %d) of the plass assemble chain (--num-iterations %d, k=14, alph 13, kmer-per-seq 60, min-seq-id 0.9, e 1e-5)"
+                                   % (cfg_idx if world == 1 or args.config != "c3" else 3, "" if not args.pairs else " model at another size", wl["reads"], wl["read_pairs"], wl["genomes"], wl["mean_coverage"], wl["seed"],
+                                      n_frag, chain, chain),
                        "parallelism": ("1 GPU" if world == 1 and mode != "sharded" else
                                        "%d GPUs, one read set of %d fragments sharded by k-mer bucket (RCCL all-to-all(v) of k-mer and grouped records, "
                                        "all-gather of extended sequences), sequence DB replicated" % (world, n_frag) if mode == "sharded" else
                                        "1 process per GPU, independent partitions"),
-                       "candidate_overlaps": overlaps},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
-                         "stage_ms_per_step": {k: v[0] / len(stats) for k, v in tot.items()},
-                         "kmermatcher_stage": {"algorithmic_bytes_per_step": tot["kmermatcher_stage"][1] / len(stats),
-                                               "ms_per_step": tot["kmermatcher_stage"][0] / len(stats),
-                                               "frac": (tot["kmermatcher_stage"][1] / (tot["kmermatcher_stage"][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot["kmermatcher_stage"][0] > 0 else 0.0},
-                         "module_wall_ms_per_step": [round(sum(w[i] for w in WALL[-args.steps:]) / args.steps, 3) for i in range(3)]},
+                       "candidate_overlaps": overlaps, "workload_detail": wl,
+                       "final_db": {"sequences": final_info["n"], "residues": final_info["residues"]}},
+            "iterations": [{"step": i, "iteration": it, "ms": round(ms, 3), "N_k": k.n_kmer_records, "N_m": k.n_grouped, "N_c": k.n_candidates,
+                            "verified": r.n_accepted, "extended": a.n_extended, "residues": k.residues,
+                            "kmermatcher_ms": round(k.ms_extract + k.ms_sort1 + k.ms_group + k.ms_sort2 + k.ms_reduce, 3),
+                            "extract_ms": round(k.ms_extract, 3), "partition_ms": round(k.ms_sort1, 3), "group_ms": round(k.ms_group, 3),
+                            "repsort_ms": round(k.ms_sort2, 3), "reduce_ms": round(k.ms_reduce, 3),
+                            "rescore_ms": round(r.ms_kernel, 3), "assemble_ms": round(a.ms_kernel, 3), "module_wall_ms": [round(x, 3) for x in w]}
+                           for i, (it, ms, k, r, a, w) in enumerate(rows)],
+            "roofline": roof,
         }
-        # what the job costs a caller that hands over host buffers and wants host buffers back (never `value`): rank 0's share
-        line["host_boundary"] = {"upload_ms": upload_s * 1e3, "upload_bytes": len(data), "download_ms": download_s * 1e3, "download_bytes": final_bytes,
-                                 "pcie_inclusive_overlaps_per_s_rank0": local_overlaps / (t1 - t0 + upload_s + download_s)}
         if sharded_error is not None:
             line["sharded_mode_error"] = sharded_error
         if comm is not None:
-            line["exchange"] = {"device_bytes_sent_per_step_rank0": comm.bytes_moved / max(args.steps, 1), "collective_calls_per_step": comm.calls / max(args.steps, 1),
-                                "ms_in_collectives_per_step_rank0": comm.seconds * 1e3 / max(args.steps, 1)}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_pairs, min(args.steps, 3))
+            line["exchange"] = {"device_bytes_sent_per_step_rank0": comm.bytes_moved / max(steps, 1), "collective_calls_per_step": comm.calls / max(steps, 1),
+                                "ms_in_collectives_per_step_rank0": comm.seconds * 1e3 / max(steps, 1)}
+    if db is not db0:
+        db.free()
+    db0.free()
+    if rank == 0:
+        if world == 1 and comm is None and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, min(chain, 3))
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
@@ -329,6 +363,22 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+
+
+def sharded_preflight(ctx, dist, device):
+    """one sharded iteration on a small read set (the same on every rank): every rank must end with the same DB (checksum)"""
+    import hashlib
+    import torch
+    from plass_amd import synth
+    data, off, elen, key = synth.protein_fragment_db(3000, seed=7)
+    db = ctx.upload_seqdb(data, off, elen, key, 0)
+    out, kst, _, _, _ = one_iteration(ctx, db, 0)
+    h = int.from_bytes(hashlib.sha256(out.download()[0]).digest()[:7], "little")
+    t = torch.tensor([h, -h], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if int(t[0]) != -int(t[1]):
+        raise RuntimeError("sharded preflight: the ranks ended with different output DBs")
+    out.free(); db.free()
 
 
 if __name__ == "__main__":

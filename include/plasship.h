@@ -271,6 +271,52 @@ typedef struct plasship_cyclecheck_stats {
 int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_cyclecheck_params *par, plasship_seqdb **out_cycle,
                         plasship_seqdb **out_rest, plasship_cyclecheck_stats *stats);
 
+/* ---- extractorfs / translatenucs / concatdbs  (the once-per-run preprocessing of
+ *      data/assemble.sh:41-77 and data/guidedNuclAssemble.sh:46-72 that makes the DB the hot path uploads).
+ *      replaces int extractorfs(int, const char**, const Command&), mm/util/extractorfs.cpp:20-159 (+ mm/commons/Orf.cpp);
+ *               int translatenucs(…), mm/util/translatenucs.cpp:14-117 (+ mm/commons/TranslateNucl.h);
+ *               int concatdbs(…), mm/util/concatdbs.cpp via DBConcat (mm/commons/DBConcat.cpp:19-145).
+ *      An ORF DB travels with its header DB (<db>_h: "<readKey>\t<from>[+-]<len>[\t<incomplete flags>]\n",
+ *      Orf::writeOrfHeader, Orf.cpp:438-456), kept on the device as a plasship_orfhdr. ------------------------------------ */
+typedef struct plasship_orfhdr plasship_orfhdr;
+typedef struct plasship_orf_params {
+    int32_t min_length;          /* --min-length   (codons)                                                        */
+    int32_t max_length;          /* --max-length   (codons)                                                        */
+    int32_t max_gaps;            /* --max-gaps     (codons with N / unknown letters)                               */
+    int32_t contig_start_mode;   /* --contig-start-mode 0 incomplete, 1 complete, 2 both                           */
+    int32_t contig_end_mode;     /* --contig-end-mode                                                              */
+    int32_t orf_start_mode;      /* --orf-start-mode 0 ATG-to-stop, 1 any-to-stop, 2 last-ATG-to-stop              */
+    int32_t forward_frames;      /* --forward-frames as a bit mask (frame 1 = bit 0)                               */
+    int32_t reverse_frames;      /* --reverse-frames                                                               */
+    int32_t translation_table;   /* --translation-table (1 only)                                                   */
+    int32_t translate;           /* --translate                                                                    */
+    int32_t use_all_table_starts;/* --use-all-table-starts (0 only)                                                */
+    uint64_t max_seq_len;        /* --max-seq-len (only read with --translate)                                     */
+} plasship_orf_params;
+typedef struct plasship_translate_params {
+    int32_t translation_table;   /* --translation-table (1 only)                                                   */
+    int32_t add_orf_stop;        /* --add-orf-stop                                                                 */
+    uint64_t max_seq_len;        /* --max-seq-len                                                                  */
+} plasship_translate_params;
+typedef struct plasship_orf_stats {
+    uint64_t n_out;              /* entries written                                                                */
+    uint64_t in_residues, out_residues;
+    float ms_kernel;
+} plasship_orf_stats;
+/* out_hdr may be NULL.  Keys of the output are 0..M-1 in the reference's order (read key, then position of discovery). */
+int plasship_extract_orfs(plasship_ctx *ctx, const plasship_seqdb *reads, const plasship_orf_params *par, plasship_seqdb **out_orfs,
+                          plasship_orfhdr **out_hdr, plasship_orf_stats *stats);
+/* hdr: the header DB of `orfs` (same keys); only read with add_orf_stop, may be NULL otherwise */
+int plasship_translate_nucs(plasship_ctx *ctx, const plasship_seqdb *orfs, const plasship_orfhdr *hdr, const plasship_translate_params *par,
+                            plasship_seqdb **out_aa, plasship_orf_stats *stats);
+/* concatdbs <A> <B> <out> without --preserve-keys: keys of A kept, entry i of B (in key order) gets key max(keyA) + 1 + i */
+int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a, const plasship_seqdb *b, plasship_seqdb **out);
+int plasship_orfhdr_concat(plasship_ctx *ctx, const plasship_orfhdr *a, const plasship_orfhdr *b, plasship_orfhdr **out);
+int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plasship_orfhdr **out);
+int plasship_orfhdr_write(plasship_ctx *ctx, const plasship_orfhdr *h, const char *db_path);
+int plasship_orfhdr_count(const plasship_orfhdr *h, size_t *n);
+void plasship_orfhdr_free(plasship_ctx *ctx, plasship_orfhdr *h);
+
 #ifdef __cplusplus
 }
 #endif

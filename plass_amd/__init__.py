@@ -7,8 +7,8 @@ in-tree HIP library (plass_amd/libplasship.so) or without a GPU every entry poin
 """
 from ._lib import (  # noqa: F401
     PlasshipError, Context, SeqDB, Candidates, Alignments,
-    KmermatchParams, RescoreParams, AssembleParams, lib_path, load_library,
+    KmermatchParams, RescoreParams, AssembleParams, OrfParams, OrfHeaders, SynthParams, lib_path, load_library,
 )
 
 __all__ = ["PlasshipError", "Context", "SeqDB", "Candidates", "Alignments", "KmermatchParams",
-           "RescoreParams", "AssembleParams", "lib_path", "load_library"]
+           "RescoreParams", "AssembleParams", "OrfParams", "OrfHeaders", "SynthParams", "lib_path", "load_library"]

@@ -70,6 +70,31 @@ class CyclecheckStats(C.Structure):
     _fields_ = [("n_cyclic", C.c_uint64), ("n_wave_small", C.c_uint64), ("n_wave_large", C.c_uint64), ("n_block", C.c_uint64), ("ms_kernel", C.c_float)]
 
 
+class _OrfParams(C.Structure):
+    _fields_ = [("min_length", C.c_int32), ("max_length", C.c_int32), ("max_gaps", C.c_int32), ("contig_start_mode", C.c_int32),
+                ("contig_end_mode", C.c_int32), ("orf_start_mode", C.c_int32), ("forward_frames", C.c_int32), ("reverse_frames", C.c_int32),
+                ("translation_table", C.c_int32), ("translate", C.c_int32), ("use_all_table_starts", C.c_int32), ("max_seq_len", C.c_uint64)]
+
+
+class _TranslateParams(C.Structure):
+    _fields_ = [("translation_table", C.c_int32), ("add_orf_stop", C.c_int32), ("max_seq_len", C.c_uint64)]
+
+
+class OrfStats(C.Structure):
+    _fields_ = [("n_out", C.c_uint64), ("in_residues", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float)]
+
+
+class _SynthParams(C.Structure):
+    _fields_ = [("n_pairs", C.c_uint64), ("seed", C.c_uint64), ("n_genomes", C.c_uint32), ("genome_min_len", C.c_uint64),
+                ("genome_max_len", C.c_uint64), ("abundance_sigma", C.c_float), ("insert_mean", C.c_float), ("insert_sd", C.c_float),
+                ("insert_min", C.c_uint32), ("read_len", C.c_uint32), ("error_rate", C.c_float)]
+
+
+class SynthStats(C.Structure):
+    _fields_ = [("genome_bases", C.c_uint64), ("n_genes", C.c_uint64), ("mean_coverage", C.c_double), ("max_coverage", C.c_double),
+                ("ms_kernel", C.c_float)]
+
+
 class AlnRecord(C.Structure):
     _fields_ = [("query_key", C.c_uint32), ("target_key", C.c_uint32), ("bit_score", C.c_int32), ("raw_score", C.c_int32),
                 ("seq_id", C.c_float), ("q_start", C.c_int32), ("q_end", C.c_int32), ("q_len", C.c_int32),
@@ -110,6 +135,18 @@ SYMBOLS = [
     ("plasship_aln2nucl", C.c_int, [P, P, P, P, P, P, C.POINTER(_Aln2NuclParams), C.POINTER(P), C.POINTER(Aln2NuclStats)]),
     ("plasship_find_assembly_start", C.c_int, [P, P, P, C.POINTER(P), C.POINTER(FindStartStats)]),
     ("plasship_cyclecheck", C.c_int, [P, P, C.POINTER(_CyclecheckParams), C.POINTER(P), C.POINTER(P), C.POINTER(CyclecheckStats)]),
+    ("plasship_extract_orfs", C.c_int, [P, P, C.POINTER(_OrfParams), C.POINTER(P), C.POINTER(P), C.POINTER(OrfStats)]),
+    ("plasship_translate_nucs", C.c_int, [P, P, P, C.POINTER(_TranslateParams), C.POINTER(P), C.POINTER(OrfStats)]),
+    ("plasship_seqdb_concat", C.c_int, [P, P, P, C.POINTER(P)]),
+    ("plasship_orfhdr_concat", C.c_int, [P, P, P, C.POINTER(P)]),
+    ("plasship_orfhdr_read", C.c_int, [P, C.c_char_p, C.POINTER(P)]),
+    ("plasship_orfhdr_write", C.c_int, [P, P, C.c_char_p]),
+    ("plasship_orfhdr_count", C.c_int, [P, C.POINTER(C.c_size_t)]),
+    ("plasship_orfhdr_free", None, [P, P]),
+]
+# include/plasship_synth.h (measurement infrastructure: synthetic read sets generated on the GPU)
+SYNTH_SYMBOLS = [
+    ("plasship_synth_read_pairs", C.c_int, [P, C.POINTER(_SynthParams), C.POINTER(P), C.POINTER(SynthStats)]),
 ]
 
 _lib = None
@@ -125,7 +162,7 @@ def load_library():
         raise PlasshipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(plass_amd has no CPU fallback)" % path)
     lib = C.CDLL(path)
-    for name, res, args in SYMBOLS:
+    for name, res, args in SYMBOLS + SYNTH_SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
@@ -183,6 +220,62 @@ class AssembleParams:
 
     def _c(self):
         return _AssembleParams(self.min_seq_id, self.max_seq_len, int(self.keep_target), self.rescore_mode)
+
+
+@dataclass
+class OrfParams:
+    """extractorfs flags; defaults = the module's own (mm/commons/Parameters.cpp), frames as the reference's "1,2,3" lists"""
+    min_length: int = 30
+    max_length: int = 32734
+    max_gaps: int = 2147483647
+    contig_start_mode: int = 2
+    contig_end_mode: int = 2
+    orf_start_mode: int = 1
+    forward_frames: str = "1,2,3"
+    reverse_frames: str = "1,2,3"
+    translation_table: int = 1
+    translate: bool = False
+    use_all_table_starts: bool = False
+    max_seq_len: int = 65535
+
+    @staticmethod
+    def _frames(v):
+        m = 0
+        for f in str(v).split(","):
+            f = f.strip()
+            if f:
+                m |= 1 << (int(f) - 1)
+        return m
+
+    def _c(self):
+        return _OrfParams(self.min_length, self.max_length, self.max_gaps, self.contig_start_mode, self.contig_end_mode, self.orf_start_mode,
+                          self._frames(self.forward_frames), self._frames(self.reverse_frames), self.translation_table, int(self.translate),
+                          int(self.use_all_table_starts), self.max_seq_len)
+
+
+# the two extractorfs passes of `plass assemble` (src/workflow/Assembler.cpp:116-130; data/assemble.sh:41-63)
+PLASS_ORFS_LONG = dict(min_length=45, max_length=32734, max_gaps=0, contig_start_mode=2, contig_end_mode=2, orf_start_mode=0)
+PLASS_ORFS_START = dict(min_length=20, max_length=45, max_gaps=0, contig_start_mode=1, contig_end_mode=0, orf_start_mode=0)
+
+
+@dataclass
+class SynthParams:
+    """synthetic community + read pairs (include/plasship_synth.h)"""
+    n_pairs: int = 500000
+    seed: int = 1
+    n_genomes: int = 1
+    genome_min_len: int = 7500000
+    genome_max_len: int = 7500000
+    abundance_sigma: float = 0.0
+    insert_mean: float = 320.0
+    insert_sd: float = 40.0
+    insert_min: int = 160
+    read_len: int = 150
+    error_rate: float = 0.002
+
+    def _c(self):
+        return _SynthParams(self.n_pairs, self.seed, self.n_genomes, self.genome_min_len, self.genome_max_len, self.abundance_sigma,
+                            self.insert_mean, self.insert_sd, self.insert_min, self.read_len, self.error_rate)
 
 
 class Context:
@@ -278,6 +371,53 @@ class Context:
         _check(self.lib.plasship_cyclecheck(self.h, db.h, C.byref(cp), C.byref(hc), C.byref(hr) if with_rest else None, C.byref(st)), "plasship_cyclecheck")
         return (SeqDB(self, hc), SeqDB(self, hr), st) if with_rest else (SeqDB(self, hc), st)
 
+    # ---- row N2: the once-per-run preprocessing (data/assemble.sh:41-77) ------------------------------------------
+    def extractorfs(self, reads, par=None):
+        """nucleotide DB -> (ORF DB, its header DB); reference module extractorfs"""
+        par = par or OrfParams()
+        h = P(); hh = P(); st = OrfStats(); cp = par._c()
+        _check(self.lib.plasship_extract_orfs(self.h, reads.h, C.byref(cp), C.byref(h), C.byref(hh), C.byref(st)), "plasship_extract_orfs")
+        return SeqDB(self, h), OrfHeaders(self, hh), st
+
+    def translatenucs(self, orfs, hdr=None, add_orf_stop=False, max_seq_len=65535):
+        """nucleotide ORF DB (+ header DB for --add-orf-stop) -> protein DB; reference module translatenucs"""
+        h = P(); st = OrfStats(); cp = _TranslateParams(1, int(add_orf_stop), max_seq_len)
+        _check(self.lib.plasship_translate_nucs(self.h, orfs.h, hdr.h if hdr is not None else None, C.byref(cp), C.byref(h), C.byref(st)), "plasship_translate_nucs")
+        return SeqDB(self, h), st
+
+    def concatdbs(self, a, b):
+        """reference module concatdbs (keys of A kept, B renumbered behind them); sequence DBs or header DBs"""
+        h = P()
+        if isinstance(a, OrfHeaders):
+            _check(self.lib.plasship_orfhdr_concat(self.h, a.h, b.h, C.byref(h)), "plasship_orfhdr_concat")
+            return OrfHeaders(self, h)
+        _check(self.lib.plasship_seqdb_concat(self.h, a.h, b.h, C.byref(h)), "plasship_seqdb_concat")
+        return SeqDB(self, h)
+
+    def read_orfhdr(self, path):
+        h = P()
+        _check(self.lib.plasship_orfhdr_read(self.h, os.fsencode(path), C.byref(h)), "plasship_orfhdr_read")
+        return OrfHeaders(self, h)
+
+    def plass_fragments(self, reads, keep=False):
+        """the whole preprocessing chain of `plass assemble` on a read DB: two extractorfs passes, translatenucs --add-orf-stop,
+        concatdbs -> aa_6f_start_long, the DB iteration 0 starts from (data/assemble.sh:41-77)"""
+        o_long, h_long, _ = self.extractorfs(reads, OrfParams(**PLASS_ORFS_LONG))
+        aa_long, _ = self.translatenucs(o_long, h_long, add_orf_stop=True)
+        o_long.free(); h_long.free()
+        o_start, h_start, _ = self.extractorfs(reads, OrfParams(**PLASS_ORFS_START))
+        aa_start, _ = self.translatenucs(o_start, h_start, add_orf_stop=True)
+        o_start.free(); h_start.free()
+        out = self.concatdbs(aa_long, aa_start)
+        aa_long.free(); aa_start.free()
+        return out
+
+    def synth_read_pairs(self, par):
+        """synthetic read pairs generated in HBM (include/plasship_synth.h) -> nucleotide read DB"""
+        h = P(); st = SynthStats(); cp = par._c()
+        _check(self.lib.plasship_synth_read_pairs(self.h, C.byref(cp), C.byref(h), C.byref(st)), "plasship_synth_read_pairs")
+        return SeqDB(self, h), st
+
     # the library picks the variant from the DB type; this name mirrors the reference module for nucleotide DBs
     def nuclassembleresults(self, db, alns, par=None):
         if db.info()["dbtype"] != 1:
@@ -308,6 +448,24 @@ class SeqDB:
     def free(self):
         if self.h:
             self.ctx.lib.plasship_seqdb_free(self.ctx.h, self.h); self.h = P()
+
+
+class OrfHeaders:
+    """header DB of an ORF DB (<db>_h), device resident"""
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def count(self):
+        n = C.c_size_t()
+        _check(self.ctx.lib.plasship_orfhdr_count(self.h, C.byref(n)), "plasship_orfhdr_count")
+        return n.value
+
+    def write(self, path):
+        _check(self.ctx.lib.plasship_orfhdr_write(self.ctx.h, self.h, os.fsencode(path)), "plasship_orfhdr_write")
+
+    def free(self):
+        if self.h:
+            self.ctx.lib.plasship_orfhdr_free(self.ctx.h, self.h); self.h = P()
 
 
 class Candidates:

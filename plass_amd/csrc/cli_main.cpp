@@ -1,16 +1,22 @@
 // plass-hip: the reference's module command lines over the plasship C-ABI.
 //
-// The reference workflow scripts run `"$MMSEQS" <module> <dbs…> <flags…>` (data/assemble.sh:92,103,145);
-// pointing $MMSEQS at this binary for the three hot modules makes them run on the MI355X while every
-// database on disk keeps the DBReader/DBWriter format.  Module names, positional arguments and flag names
-// are the reference's (mm/commons/Parameters.cpp:423-439,872-892; src/commons/LocalParameters.h:96-102);
-// flags that do not influence the hot path (--threads, -v, --sub-mat, --db-load-mode …) are accepted and
-// ignored; unsupported values fail loudly like Debug(Debug::ERROR)+EXIT(EXIT_FAILURE) does.
+// The reference workflow scripts run `"$MMSEQS" <module> <dbs…> <flags…>` (data/assemble.sh:43-145); pointing $MMSEQS at this
+// binary for the hot modules makes them run on the MI355X while every database on disk keeps the DBReader/DBWriter format.
+// Module names, positional arguments and flag names are the reference's (mm/commons/Parameters.cpp:423-439,640-655,763-767,
+// 872-892,970-974; src/commons/LocalParameters.h:96-117,171-176).  Parsing follows Parameters::parseParameters
+// (Parameters.cpp:1560-1700): a flag the module does not own is an error, a bool flag without a value toggles its default, and
+// defaults are the MODULE's defaults (Parameters::setDefaults, setLinearFilterDefault), not the assemble workflow's — a call
+// that does not come from createParameterString therefore means the same thing here and there.  Flags that cannot influence
+// the result (--threads, -v, --db-load-mode, --compressed 0 …) are accepted and ignored; values this build cannot honour
+// (another substitution matrix, spaced k-mers, masking, automatic k …) fail loudly like Debug(Debug::ERROR) + EXIT(EXIT_FAILURE).
 #include "../../include/plasship.h"
 #include <chrono>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -26,61 +32,170 @@ static bool multiParam(const std::string &v, const char *which, std::string &out
     }
     return false;
 }
+static std::string baseName(const std::string &p) { const size_t s = p.find_last_of('/'); return s == std::string::npos ? p : p.substr(s + 1); }
+static int frameMask(const std::string &v, bool &ok) {                   // Orf::getFrames: "1,2,3"
+    int m = 0; size_t p = 0; ok = true;
+    while (p <= v.size()) {
+        size_t c = v.find(',', p); if (c == std::string::npos) c = v.size();
+        const std::string t = v.substr(p, c - p);
+        if (!t.empty()) { const int f = atoi(t.c_str()); if (f < 1 || f > 3) ok = false; else m |= 1 << (f - 1); }
+        p = c + 1;
+    }
+    return m;
+}
 
 struct Flags {
-    int k = 14, alph = 13, kps = 60, hashShift = 67, onlyExt = 0, ignoreMulti = 1, covMode = 0;
-    float scaleAA = 0.0f, scaleNucl = 0.2f, covThr = 0.0f, seqIdThr = 0.9f;
-    int rescoreMode = 3, minAlnLen = 0, seqIdMode = 0, addBt = 0, addSelf = 0, keepTarget = 1, wrapped = 0, filterHits = 0, sortResults = 0;
-    double evalThr = 1e-5;
+    // Parameters::setDefaults (Parameters.cpp:2093-2338); kmermatcher additionally setLinearFilterDefault (kmermatcher.cpp:566-573)
+    int k = 0, alph = 21, kps = 21, hashShift = 67, onlyExt = 0, ignoreMulti = 0, covMode = 0;
+    float scaleAA = 0.0f, scaleNucl = 0.2f, covThr = 0.0f, seqIdThr = 0.0f;
+    int rescoreMode = 0, minAlnLen = 0, seqIdMode = 0, addBt = 0, addSelf = 0, keepTarget = 1, wrapped = 0, filterHits = 0, sortResults = 0;
+    double evalThr = 1e-3;
     unsigned long long maxSeqLen = 65535;
     int gapOpenNucl = 5, gapExtendNucl = 2;
-    int chopCycle = 0;                   // cyclecheck: setCycleCheckDefaults (cyclecheck.cpp:25-28); the workflow passes --chop-cycle
+    int chopCycle = 1;                   // LocalParameters.h:202
+    int orfMin = 30, orfMax = 32734, orfGaps = INT_MAX, contigStart = 2, contigEnd = 2, orfStart = 1, fwdFrames = 7, revFrames = 7;
+    int translationTable = 1, translate = 0, allStarts = 0, addOrfStop = 0, preserveKeys = 0, takeLarger = 0;
+    std::set<std::string> seen;
 };
 
 static int fail(const char *what) { fprintf(stdout, "%s: %s\n", what, plasship_last_error()); return EXIT_FAILURE; }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// which flags a module owns (its parameter vector in the reference)
+static const std::map<std::string, std::set<std::string>> &moduleFlags() {
+    static const std::set<std::string> common = {"--threads", "-v", "--compressed"};
+    static std::map<std::string, std::set<std::string>> m;
+    if (m.empty()) {
+        m["kmermatcher"] = {"--sub-mat", "--alph-size", "--min-seq-id", "--kmer-per-seq", "--spaced-kmer-mode", "--spaced-kmer-pattern", "--kmer-per-seq-scale",
+                            "--adjust-kmer-len", "--mask", "--mask-lower-case", "--cov-mode", "-k", "-c", "--max-seq-len", "--hash-shift", "--split-memory-limit",
+                            "--include-only-extendable", "--ignore-multi-kmer"};
+        m["rescorediagonal"] = {"--sub-mat", "--rescore-mode", "--wrapped-scoring", "--filter-hits", "-e", "-c", "-a", "--cov-mode", "--min-seq-id", "--min-aln-len",
+                                "--seq-id-mode", "--add-self-matches", "--sort-results", "--db-load-mode"};
+        m["assembleresults"] = {"--min-seq-id", "--max-seq-len", "--keep-target", "--rescore-mode"};
+        m["nuclassembleresults"] = m["assembleresults"];
+        m["guidedassembleresults"] = m["assembleresults"];
+        m["proteinaln2nucl"] = {"--sub-mat", "--gap-open", "--gap-extend"};
+        m["findassemblystart"] = {};
+        m["cyclecheck"] = {"--max-seq-len", "--chop-cycle"};
+        m["extractorfs"] = {"--min-length", "--max-length", "--max-gaps", "--contig-start-mode", "--contig-end-mode", "--orf-start-mode", "--forward-frames",
+                            "--reverse-frames", "--translation-table", "--translate", "--use-all-table-starts", "--id-offset", "--create-lookup"};
+        m["translatenucs"] = {"--translation-table", "--add-orf-stop"};
+        m["concatdbs"] = {"--preserve-keys", "--take-larger-entry"};
+        for (auto &kv : m) kv.second.insert(common.begin(), common.end());
+    }
+    return m;
+}
+// bool-typed parameters of the reference (typeid(bool)): a missing value toggles the default (Parameters.cpp:1670-1677)
+static const std::set<std::string> &boolFlags() {
+    static const std::set<std::string> b = {"-a", "--add-self-matches", "--wrapped-scoring", "--filter-hits", "--include-only-extendable", "--ignore-multi-kmer",
+                                            "--keep-target", "--chop-cycle", "--adjust-kmer-len", "--use-all-table-starts", "--add-orf-stop", "--preserve-keys",
+                                            "--take-larger-entry"};
+    return b;
+}
+static bool parseBool(const std::string &v, bool &ok) {                 // Parameters::parseBool: TRUE/1 | FALSE/0
+    ok = true;
+    if (v == "1" || v == "TRUE" || v == "true") return true;
+    if (v == "0" || v == "FALSE" || v == "false") return false;
+    ok = false; return false;
+}
+
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl|findassemblystart|cyclecheck> <dbs…> [flags]\n"); return EXIT_FAILURE; }
+    if (argc < 2) {
+        fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl|findassemblystart|"
+                        "cyclecheck|extractorfs|translatenucs|concatdbs> <dbs…> [flags]\n");
+        return EXIT_FAILURE;
+    }
     const std::string mod = argv[1];
+    const auto mf = moduleFlags().find(mod);
+    if (mf == moduleFlags().end()) {
+        fprintf(stdout, "plass-hip: module \"%s\" is not part of the GPU hot path (use the reference binary for it)\n", mod.c_str());
+        return EXIT_FAILURE;
+    }
     Flags f; std::vector<std::string> pos;
-    if (mod == "kmermatcher") f.covThr = 0.8f;   // setLinearFilterDefault (kmermatcher.cpp:566-573); workflows pass -c
+    if (mod == "kmermatcher") { f.covThr = 0.8f; f.alph = 13; f.kps = 0; }                    // setLinearFilterDefault
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
-        if (a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9')) {
-            if (i + 1 >= argc) { fprintf(stdout, "Missing value for %s\n", a.c_str()); return EXIT_FAILURE; }
-            std::string v = argv[++i], t;
-            if (a == "-k") f.k = atoi(v.c_str());
-            else if (a == "--alph-size") { if (multiParam(v, "aa", t)) f.alph = atoi(t.c_str()); }
-            else if (a == "--kmer-per-seq") f.kps = atoi(v.c_str());
-            else if (a == "--kmer-per-seq-scale") { if (multiParam(v, "aa", t)) f.scaleAA = strtof(t.c_str(), nullptr); if (multiParam(v, "nucl", t)) f.scaleNucl = strtof(t.c_str(), nullptr); }
-            else if (a == "--hash-shift") f.hashShift = atoi(v.c_str());
-            else if (a == "--include-only-extendable") f.onlyExt = atoi(v.c_str());
-            else if (a == "--ignore-multi-kmer") f.ignoreMulti = atoi(v.c_str());
-            else if (a == "--cov-mode") f.covMode = atoi(v.c_str());
-            else if (a == "-c") f.covThr = strtof(v.c_str(), nullptr);
-            else if (a == "--rescore-mode") f.rescoreMode = atoi(v.c_str());
-            else if (a == "-e") f.evalThr = strtod(v.c_str(), nullptr);
-            else if (a == "--min-seq-id") f.seqIdThr = strtof(v.c_str(), nullptr);
-            else if (a == "--min-aln-len") f.minAlnLen = atoi(v.c_str());
-            else if (a == "--seq-id-mode") f.seqIdMode = atoi(v.c_str());
-            else if (a == "-a") f.addBt = atoi(v.c_str());
-            else if (a == "--add-self-matches") f.addSelf = atoi(v.c_str());
-            else if (a == "--max-seq-len") f.maxSeqLen = strtoull(v.c_str(), nullptr, 10);
-            else if (a == "--chop-cycle") f.chopCycle = atoi(v.c_str());
-            else if (a == "--keep-target") f.keepTarget = atoi(v.c_str());
-            else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) f.gapOpenNucl = atoi(t.c_str()); }
-            else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) f.gapExtendNucl = atoi(t.c_str()); }
-            else if (a == "--wrapped-scoring") f.wrapped = atoi(v.c_str());
-            else if (a == "--filter-hits") f.filterHits = atoi(v.c_str());
-            else if (a == "--sort-results") f.sortResults = atoi(v.c_str());
-            else if (a == "--spaced-kmer-mode" || a == "--mask" || a == "--mask-lower-case" || a == "--adjust-kmer-len" || a == "--compressed") {
-                if (atoi(v.c_str()) != 0) { fprintf(stdout, "%s %s is not supported by plass-hip\n", a.c_str(), v.c_str()); return EXIT_FAILURE; }
+        if (!(a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9'))) { pos.push_back(a); continue; }
+        if (!mf->second.count(a)) { fprintf(stdout, "Unrecognized parameter \"%s\" for module %s\n", a.c_str(), mod.c_str()); return EXIT_FAILURE; }
+        std::string v, t; bool haveValue = true;
+        if (boolFlags().count(a)) {
+            if (i + 1 >= argc || argv[i + 1][0] == '-') haveValue = false; else v = argv[++i];
+        } else {
+            if (i + 1 >= argc) { fprintf(stdout, "Missing argument %s\n", a.c_str()); return EXIT_FAILURE; }
+            v = argv[++i];
+        }
+        f.seen.insert(a);
+        auto setBool = [&](int &field) -> bool {
+            if (!haveValue) { field = !field; return true; }
+            bool ok; const bool b = parseBool(v, ok);
+            if (!ok) { fprintf(stdout, "Error in argument %s\n", a.c_str()); return false; }
+            field = b ? 1 : 0; return true;
+        };
+        if (a == "-k") f.k = atoi(v.c_str());
+        else if (a == "--alph-size") { if (multiParam(v, "aa", t)) f.alph = atoi(t.c_str()); }
+        else if (a == "--kmer-per-seq") f.kps = atoi(v.c_str());
+        else if (a == "--kmer-per-seq-scale") { if (multiParam(v, "aa", t)) f.scaleAA = strtof(t.c_str(), nullptr); if (multiParam(v, "nucl", t)) f.scaleNucl = strtof(t.c_str(), nullptr); }
+        else if (a == "--hash-shift") f.hashShift = atoi(v.c_str());
+        else if (a == "--include-only-extendable") { if (!setBool(f.onlyExt)) return EXIT_FAILURE; }
+        else if (a == "--ignore-multi-kmer") { if (!setBool(f.ignoreMulti)) return EXIT_FAILURE; }
+        else if (a == "--cov-mode") f.covMode = atoi(v.c_str());
+        else if (a == "-c") f.covThr = strtof(v.c_str(), nullptr);
+        else if (a == "--rescore-mode") f.rescoreMode = atoi(v.c_str());
+        else if (a == "-e") f.evalThr = strtod(v.c_str(), nullptr);
+        else if (a == "--min-seq-id") f.seqIdThr = strtof(v.c_str(), nullptr);
+        else if (a == "--min-aln-len") f.minAlnLen = atoi(v.c_str());
+        else if (a == "--seq-id-mode") f.seqIdMode = atoi(v.c_str());
+        else if (a == "-a") { if (!setBool(f.addBt)) return EXIT_FAILURE; }
+        else if (a == "--add-self-matches") { if (!setBool(f.addSelf)) return EXIT_FAILURE; }
+        else if (a == "--max-seq-len") f.maxSeqLen = strtoull(v.c_str(), nullptr, 10);
+        else if (a == "--chop-cycle") { if (!setBool(f.chopCycle)) return EXIT_FAILURE; }
+        else if (a == "--keep-target") { if (!setBool(f.keepTarget)) return EXIT_FAILURE; }
+        else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) f.gapOpenNucl = atoi(t.c_str()); }
+        else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) f.gapExtendNucl = atoi(t.c_str()); }
+        else if (a == "--wrapped-scoring") { if (!setBool(f.wrapped)) return EXIT_FAILURE; }
+        else if (a == "--filter-hits") { if (!setBool(f.filterHits)) return EXIT_FAILURE; }
+        else if (a == "--sort-results") f.sortResults = atoi(v.c_str());
+        else if (a == "--min-length") f.orfMin = atoi(v.c_str());
+        else if (a == "--max-length") f.orfMax = atoi(v.c_str());
+        else if (a == "--max-gaps") f.orfGaps = atoi(v.c_str());
+        else if (a == "--contig-start-mode") f.contigStart = atoi(v.c_str());
+        else if (a == "--contig-end-mode") f.contigEnd = atoi(v.c_str());
+        else if (a == "--orf-start-mode") f.orfStart = atoi(v.c_str());
+        else if (a == "--forward-frames" || a == "--reverse-frames") {
+            bool ok; const int m = frameMask(v, ok);
+            if (!ok) { fprintf(stdout, "Error in argument %s\n", a.c_str()); return EXIT_FAILURE; }
+            (a == "--forward-frames" ? f.fwdFrames : f.revFrames) = m;
+        }
+        else if (a == "--translation-table") f.translationTable = atoi(v.c_str());
+        else if (a == "--translate") f.translate = atoi(v.c_str());
+        else if (a == "--use-all-table-starts") { if (!setBool(f.allStarts)) return EXIT_FAILURE; }
+        else if (a == "--add-orf-stop") { if (!setBool(f.addOrfStop)) return EXIT_FAILURE; }
+        else if (a == "--preserve-keys") { if (!setBool(f.preserveKeys)) return EXIT_FAILURE; }
+        else if (a == "--take-larger-entry") { if (!setBool(f.takeLarger)) return EXIT_FAILURE; }
+        else if (a == "--sub-mat") {
+            // only the matrices the tables were captured from: blosum62.out (amino acids) and nucleotide.out
+            std::string aa, nu;
+            const bool okA = multiParam(v, "aa", aa), okN = multiParam(v, "nucl", nu);
+            if ((okA && baseName(aa) != "blosum62.out" && v.find(':') != std::string::npos) || (okN && baseName(nu) != "nucleotide.out" && v.find(':') != std::string::npos) ||
+                (v.find(':') == std::string::npos && baseName(v) != "blosum62.out" && baseName(v) != "nucleotide.out")) {
+                fprintf(stdout, "plass-hip: --sub-mat %s is not supported (built for blosum62.out / nucleotide.out)\n", v.c_str()); return EXIT_FAILURE;
             }
-            // everything else (--threads, -v, --sub-mat, --db-load-mode, --split-memory-limit …): ignored
-        } else pos.push_back(a);
+        }
+        else if (a == "--spaced-kmer-mode" || a == "--mask" || a == "--mask-lower-case" || a == "--compressed" || a == "--create-lookup" || a == "--id-offset") {
+            if (atoi(v.c_str()) != 0) { fprintf(stdout, "%s %s is not supported by plass-hip\n", a.c_str(), v.c_str()); return EXIT_FAILURE; }
+        }
+        else if (a == "--adjust-kmer-len") { int x = 0; if (!setBool(x)) return EXIT_FAILURE; if (x) { fprintf(stdout, "--adjust-kmer-len is not supported by plass-hip\n"); return EXIT_FAILURE; } }
+        else if (a == "--spaced-kmer-pattern") { if (!v.empty()) { fprintf(stdout, "--spaced-kmer-pattern is not supported by plass-hip\n"); return EXIT_FAILURE; } }
+        // --threads, -v, --db-load-mode, --split-memory-limit: no influence on the result
     }
     if (f.wrapped || f.filterHits || f.sortResults) { fprintf(stdout, "--wrapped-scoring/--filter-hits/--sort-results are not supported by plass-hip\n"); return EXIT_FAILURE; }
+    if (mod == "kmermatcher") {
+        // the module's own defaults for these two are "choose automatically" (k = 0: from the DB size, kmermatcher.cpp:607-613;
+        // --kmer-per-seq 0): not reproduced — every workflow passes them
+        if (f.k <= 0 || f.kps <= 0) { fprintf(stdout, "plass-hip kmermatcher: -k and --kmer-per-seq must be given (the automatic choice of the reference is not implemented)\n"); return EXIT_FAILURE; }
+        // the reference's module default is spaced k-mers and masking ON unless told otherwise; the workflows run with both off
+        // (setLinearFilterDefault turns them off for kmermatcher itself)
+    }
     plasship_ctx *ctx = nullptr;
     if (plasship_ctx_create(-1, &ctx)) return fail("plass-hip");
     const double t0 = now();
@@ -178,9 +293,50 @@ int main(int argc, char **argv) {
         fprintf(stdout, "circular: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_cyclic, st.ms_kernel);
         if (plasship_seqdb_write(ctx, o, pos[1].c_str())) return fail("cyclecheck");
         plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
-    } else {
-        fprintf(stdout, "plass-hip: module \"%s\" is not part of the GPU hot path (use the reference binary for it)\n", mod.c_str());
-        rc = EXIT_FAILURE;
+    } else if (mod == "extractorfs") {
+        // writes <out> and <out>_h like the reference (extractorfs.cpp:28-32)
+        if (pos.size() != 2) { fprintf(stdout, "extractorfs <i:sequenceDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
+        plasship_seqdb *db = nullptr, *o = nullptr; plasship_orfhdr *h = nullptr;
+        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("extractorfs");
+        plasship_orf_params p; memset(&p, 0, sizeof(p));
+        p.min_length = f.orfMin; p.max_length = f.orfMax; p.max_gaps = f.orfGaps; p.contig_start_mode = f.contigStart; p.contig_end_mode = f.contigEnd;
+        p.orf_start_mode = f.orfStart; p.forward_frames = f.fwdFrames; p.reverse_frames = f.revFrames; p.translation_table = f.translationTable;
+        p.translate = f.translate; p.use_all_table_starts = f.allStarts; p.max_seq_len = f.maxSeqLen;
+        plasship_orf_stats st; memset(&st, 0, sizeof(st));
+        if (plasship_extract_orfs(ctx, db, &p, &o, &h, &st)) return fail("extractorfs");
+        fprintf(stdout, "orfs: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_out, st.ms_kernel);
+        if (plasship_seqdb_write(ctx, o, pos[1].c_str()) || plasship_orfhdr_write(ctx, h, (pos[1] + "_h").c_str())) return fail("extractorfs");
+        plasship_orfhdr_free(ctx, h); plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
+    } else if (mod == "translatenucs") {
+        if (pos.size() != 2) { fprintf(stdout, "translatenucs <i:sequenceDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
+        plasship_seqdb *db = nullptr, *o = nullptr; plasship_orfhdr *h = nullptr;
+        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("translatenucs");
+        if (f.addOrfStop && plasship_orfhdr_read(ctx, (pos[0] + "_h").c_str(), &h)) return fail("translatenucs");      // translatenucs.cpp:29-34
+        plasship_translate_params p; p.translation_table = f.translationTable; p.add_orf_stop = f.addOrfStop; p.max_seq_len = f.maxSeqLen;
+        plasship_orf_stats st; memset(&st, 0, sizeof(st));
+        if (plasship_translate_nucs(ctx, db, h, &p, &o, &st)) return fail("translatenucs");
+        fprintf(stdout, "translated: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_out, st.ms_kernel);
+        if (plasship_seqdb_write(ctx, o, pos[1].c_str())) return fail("translatenucs");
+        plasship_orfhdr_free(ctx, h); plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
+    } else if (mod == "concatdbs") {
+        if (pos.size() != 3) { fprintf(stdout, "concatdbs <i:DB> <i:DB> <o:DB>\n"); return EXIT_FAILURE; }
+        if (f.preserveKeys || f.takeLarger) { fprintf(stdout, "plass-hip concatdbs: --preserve-keys / --take-larger-entry are not supported\n"); return EXIT_FAILURE; }
+        // sequence DBs, or the header DBs of ORF DBs (dbtype 12: data/assemble.sh:75)
+        int dbtype = -1;
+        { std::string tp = pos[0] + ".dbtype"; FILE *ft = fopen(tp.c_str(), "rb"); unsigned ty = 0; if (ft && fread(&ty, 4, 1, ft) == 1) dbtype = (int) (ty & 0x3FFFFFFFu); if (ft) fclose(ft); }
+        if (dbtype == PLASSHIP_DBTYPE_AMINO_ACIDS || dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES) {
+            plasship_seqdb *a = nullptr, *b = nullptr, *o = nullptr;
+            if (plasship_seqdb_read(ctx, pos[0].c_str(), &a) || plasship_seqdb_read(ctx, pos[1].c_str(), &b)) return fail("concatdbs");
+            if (plasship_seqdb_concat(ctx, a, b, &o)) return fail("concatdbs");
+            if (plasship_seqdb_write(ctx, o, pos[2].c_str())) return fail("concatdbs");
+            plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, b); plasship_seqdb_free(ctx, a);
+        } else if (dbtype == 12) {
+            plasship_orfhdr *a = nullptr, *b = nullptr, *o = nullptr;
+            if (plasship_orfhdr_read(ctx, pos[0].c_str(), &a) || plasship_orfhdr_read(ctx, pos[1].c_str(), &b)) return fail("concatdbs");
+            if (plasship_orfhdr_concat(ctx, a, b, &o)) return fail("concatdbs");
+            if (plasship_orfhdr_write(ctx, o, pos[2].c_str())) return fail("concatdbs");
+            plasship_orfhdr_free(ctx, o); plasship_orfhdr_free(ctx, b); plasship_orfhdr_free(ctx, a);
+        } else { fprintf(stdout, "plass-hip concatdbs: database type %d is not supported (sequence DBs and ORF header DBs only)\n", dbtype); return EXIT_FAILURE; }
     }
     fprintf(stdout, "Time for processing: %.3fs\n", now() - t0);
     plasship_ctx_destroy(ctx);

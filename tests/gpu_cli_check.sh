@@ -11,6 +11,7 @@ tar -C "$W" -xzf "$ROOT/tests/golden/example_nucl.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/example_guided.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/findstart.tar.gz"
 tar -C "$W" -xzf "$ROOT/tests/golden/cyclecheck.tar.gz"
+tar -C "$W" -xzf "$ROOT/tests/golden/orfs.tar.gz"
 P="timeout 300 $ROOT/plass_amd/plass-hip"
 D="python3 $ROOT/tools/dbdiff.py"
 fails=0
@@ -64,5 +65,26 @@ for c in 0 1; do
   $P cyclecheck $W/cyc/in $W/o_cyc$c --max-seq-len 50000 --chop-cycle $c --threads 4 | tail -2 || echo "cyclecheck rc=$?"
   check $W/cyc/cycle_chop$c $W/o_cyc$c "cyclecheck --chop-cycle $c"
 done
+# row N2: the once-per-run preprocessing (data/assemble.sh:41-77) on the reference's hostile reads and on the example's reads
+n=0
+while read -r FL; do
+  n=$((n+1)); i=$(echo "1 2 4 5" | cut -d' ' -f$n)
+  $P extractorfs $W/orf/in $W/o_orfs$i $FL --threads 4 | tail -1 || echo "extractorfs rc=$?"
+  check $W/orf/orfs_$i $W/o_orfs$i "extractorfs flag set $i"
+  check $W/orf/orfs_${i}_h $W/o_orfs${i}_h "extractorfs headers flag set $i"
+  $P translatenucs $W/o_orfs$i $W/o_aa$i --translation-table 1 --add-orf-stop 1 | tail -1 || echo "translatenucs rc=$?"
+  check $W/orf/aa_stop_$i $W/o_aa$i "translatenucs --add-orf-stop 1 flag set $i"
+done < $W/orf/FLAGS
+CM="--max-gaps 0 --orf-start-mode 0 --forward-frames 1,2,3 --reverse-frames 1,2,3 --translation-table 1 --translate 0 --use-all-table-starts 0"
+$P extractorfs $W/nucl/seq_0 $W/nucl_6f_start --min-length 20 --max-length 45 --contig-start-mode 1 --contig-end-mode 0 $CM | tail -1
+$P extractorfs $W/nucl/seq_0 $W/nucl_6f_long --min-length 45 --max-length 32734 --contig-start-mode 2 --contig-end-mode 2 $CM | tail -1
+$P translatenucs $W/nucl_6f_start $W/aa_6f_start --translation-table 1 --add-orf-stop | tail -1
+$P translatenucs $W/nucl_6f_long $W/aa_6f_long --translation-table 1 --add-orf-stop 1 | tail -1
+$P concatdbs $W/aa_6f_long $W/aa_6f_start $W/aa_6f_start_long -v 3 | tail -1
+check $W/aa/seq_0 $W/aa_6f_start_long "extractorfs x2 + translatenucs x2 + concatdbs = iteration-0 input"
+$P concatdbs $W/nucl_6f_long_h $W/nucl_6f_start_h $W/aa_6f_start_long_h | tail -1 || echo "concatdbs (headers) rc=$?"
+# the drop-in CLI refuses what it does not know instead of ignoring it
+if $P kmermatcher $W/aa/seq_0 $W/o_bad -k 14 --kmer-per-seq 60 --no-such-flag 1 > $W/bad.log 2>&1; then echo "FAIL unknown flag accepted"; fails=$((fails+1)); else echo "PASS unknown flag refused"; fi
+if $P rescorediagonal $W/aa/seq_0 $W/aa/seq_0 $W/aa/pref_0 $W/o_bad --rescore-mode 3 --sub-mat aa:VTML80.out,nucl:nucleotide.out > $W/bad.log 2>&1; then echo "FAIL foreign matrix accepted"; fails=$((fails+1)); else echo "PASS foreign substitution matrix refused"; fi
 echo "failures: $fails"
 exit $fails

@@ -1,0 +1,130 @@
+"""GPU parity tests of row N2 (`-m gpu`): extractorfs / translatenucs / concatdbs through the C-ABI against DBs written by the
+unmodified reference (tests/golden/orfs.tar.gz; the bundled example's preprocessing chain that must reproduce aa/seq_0),
+and against the CPU oracle on reads made by the GPU read generator (include/plasship_synth.h).  Bit-exact."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import assert_same_db, read_db, run_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import plass_amd
+    c = plass_amd.Context(0)
+    yield c
+    c.close()
+
+
+def orf_params(flags):
+    """reference flag list -> OrfParams"""
+    import plass_amd
+    kw = {}
+    names = {"--min-length": "min_length", "--max-length": "max_length", "--max-gaps": "max_gaps", "--contig-start-mode": "contig_start_mode",
+             "--contig-end-mode": "contig_end_mode", "--orf-start-mode": "orf_start_mode", "--translation-table": "translation_table"}
+    for k, v in zip(flags[0::2], flags[1::2]):
+        if k in names:
+            kw[names[k]] = int(v)
+        elif k == "--forward-frames":
+            kw["forward_frames"] = v
+        elif k == "--reverse-frames":
+            kw["reverse_frames"] = v
+        elif k == "--translate":
+            kw["translate"] = bool(int(v))
+        elif k == "--use-all-table-starts":
+            kw["use_all_table_starts"] = bool(int(v))
+        else:
+            raise AssertionError("unknown flag " + k)
+    return plass_amd.OrfParams(**kw)
+
+
+def test_golden_extractorfs_translatenucs(ctx, golden, tmp_path):
+    """hostile reads (IUPAC, N, lower case, U/u, illegal characters, tiny sequences), the reference's four flag sets: ORF DB,
+    header DB, translations with and without --add-orf-stop"""
+    o = os.path.join(golden, "orf")
+    reads = ctx.read_seqdb(f"{o}/in")
+    flags = [l.split() for l in open(os.path.join(o, "FLAGS")).read().splitlines() if l.strip()]
+    for n, fl in zip((1, 2, 4, 5), flags):
+        orfs, hdr, st = ctx.extractorfs(reads, orf_params(fl))
+        orfs.write(tmp_path / f"orfs_{n}"); hdr.write(str(tmp_path / f"orfs_{n}") + "_h")
+        assert_same_db(f"{o}/orfs_{n}", tmp_path / f"orfs_{n}", f"extractorfs flag set {n}")
+        assert_same_db(f"{o}/orfs_{n}_h", str(tmp_path / f"orfs_{n}") + "_h", f"extractorfs headers, flag set {n}")
+        assert st.n_out == orfs.info()["n"] == hdr.count()
+        aa, _ = ctx.translatenucs(orfs, hdr, add_orf_stop=True)
+        aa.write(tmp_path / f"aa_stop_{n}")
+        assert_same_db(f"{o}/aa_stop_{n}", tmp_path / f"aa_stop_{n}", f"translatenucs --add-orf-stop 1, flag set {n}")
+        aa2, _ = ctx.translatenucs(orfs, None, add_orf_stop=False)
+        aa2.write(tmp_path / f"aa_{n}")
+        assert_same_db(f"{o}/aa_{n}", tmp_path / f"aa_{n}", f"translatenucs --add-orf-stop 0, flag set {n}")
+        # the same through the DB files (what the command line does): header DB parsed from text
+        orfs_f = ctx.read_seqdb(tmp_path / f"orfs_{n}"); hdr_f = ctx.read_orfhdr(str(tmp_path / f"orfs_{n}") + "_h")
+        aa3, _ = ctx.translatenucs(orfs_f, hdr_f, add_orf_stop=True)
+        aa3.write(tmp_path / f"aa_stop_file_{n}")
+        assert_same_db(f"{o}/aa_stop_{n}", tmp_path / f"aa_stop_file_{n}", f"translatenucs from DB files, flag set {n}")
+        for x in (aa, aa2, aa3, orfs_f, hdr_f, orfs, hdr):
+            x.free()
+    small_reads = ctx.read_seqdb(f"{o}/in_small")
+    small = [l.split() for l in open(os.path.join(o, "FLAGS_SMALL")).read().splitlines() if l.strip()]     # any-to-stop; --translate 1
+    for name, fl in zip(("small_orfs_any", "small_orfs_translated"), small):
+        orfs, hdr, _ = ctx.extractorfs(small_reads, orf_params(fl))
+        orfs.write(tmp_path / name); hdr.write(str(tmp_path / name) + "_h")
+        assert_same_db(f"{o}/{name}", tmp_path / name, f"extractorfs {name}")
+        assert_same_db(f"{o}/{name}_h", str(tmp_path / name) + "_h", f"extractorfs {name} headers")
+
+
+def test_golden_preprocessing_chain_reproduces_iteration0_input(ctx, golden, tmp_path):
+    """nucl_reads of the bundled example -> two extractorfs passes -> translatenucs --add-orf-stop -> concatdbs must be the protein
+    fragment DB the hot path's golden vectors start from (aa/seq_0), data/assemble.sh:41-77"""
+    reads = ctx.read_seqdb(os.path.join(golden, "nucl", "seq_0"))
+    frag = ctx.plass_fragments(reads)
+    frag.write(tmp_path / "aa_6f_start_long")
+    assert_same_db(os.path.join(golden, "aa", "seq_0"), tmp_path / "aa_6f_start_long", "preprocessing chain -> aa_6f_start_long")
+
+
+def test_illegal_parameter_combination_fails_loudly(ctx, golden):
+    import plass_amd
+    reads = ctx.read_seqdb(os.path.join(golden, "orf", "in_small"))
+    with pytest.raises(plass_amd.PlasshipError):
+        ctx.extractorfs(reads, plass_amd.OrfParams(orf_start_mode=1, contig_start_mode=1))
+    with pytest.raises(plass_amd.PlasshipError):
+        ctx.extractorfs(reads, plass_amd.OrfParams(translation_table=4))
+
+
+def test_synth_reads_deterministic_and_chain_vs_oracle(ctx, oracle_bin, tmp_path):
+    """GPU read generator: same seed -> same bytes, other seed -> other bytes, pairs are consistent; the preprocessing chain on
+    20 000 generated reads equals the oracle's, module by module"""
+    import plass_amd
+    par = plass_amd.SynthParams(n_pairs=10000, seed=5, n_genomes=6, genome_min_len=40000, genome_max_len=90000, abundance_sigma=1.0)
+    r1, st = ctx.synth_read_pairs(par)
+    r2, _ = ctx.synth_read_pairs(par)
+    d1, o1, e1, k1 = r1.download(); d2 = r2.download()[0]
+    assert d1 == d2 and len(k1) == 20000 and np.all(e1 == 152) and np.array_equal(k1, np.arange(20000, dtype=np.uint32))
+    assert set(d1) <= set(b"ACGT\n\x00") and st.n_genes > 50 and st.genome_bases >= 6 * 40000
+    r3, _ = ctx.synth_read_pairs(plass_amd.SynthParams(n_pairs=10000, seed=6, n_genomes=6, genome_min_len=40000, genome_max_len=90000, abundance_sigma=1.0))
+    assert r3.download()[0] != d1
+    r1.write(tmp_path / "reads")
+    common = ["--max-gaps", "0", "--orf-start-mode", "0", "--forward-frames", "1,2,3", "--reverse-frames", "1,2,3", "--translation-table", "1",
+              "--translate", "0", "--use-all-table-starts", "0"]
+    run_oracle(oracle_bin, ["extractorfs", tmp_path / "reads", tmp_path / "o_start", "--min-length", "20", "--max-length", "45", "--contig-start-mode", "1",
+                            "--contig-end-mode", "0"] + common)
+    run_oracle(oracle_bin, ["extractorfs", tmp_path / "reads", tmp_path / "o_long", "--min-length", "45", "--max-length", "32734", "--contig-start-mode", "2",
+                            "--contig-end-mode", "2"] + common)
+    for n in ("start", "long"):
+        run_oracle(oracle_bin, ["translatenucs", tmp_path / f"o_{n}", tmp_path / f"o_aa_{n}", "--translation-table", "1", "--add-orf-stop", "1"])
+    run_oracle(oracle_bin, ["concatdbs", tmp_path / "o_aa_long", tmp_path / "o_aa_start", tmp_path / "o_frag"])
+    for name, kw in (("long", plass_amd._lib.PLASS_ORFS_LONG), ("start", plass_amd._lib.PLASS_ORFS_START)):
+        orfs, hdr, _ = ctx.extractorfs(r1, plass_amd.OrfParams(**kw))
+        orfs.write(tmp_path / f"g_{name}"); hdr.write(str(tmp_path / f"g_{name}") + "_h")
+        assert_same_db(tmp_path / f"o_{name}", tmp_path / f"g_{name}", f"extractorfs {name} vs oracle")
+        assert_same_db(str(tmp_path / f"o_{name}") + "_h", str(tmp_path / f"g_{name}") + "_h", f"extractorfs {name} headers vs oracle")
+    frag = ctx.plass_fragments(r1)
+    frag.write(tmp_path / "g_frag")
+    assert_same_db(tmp_path / "o_frag", tmp_path / "g_frag", "preprocessing chain vs oracle")
+    i = frag.info()
+    assert i["n"] > 20000 and i["dbtype"] == 0
+    # the fragments are usable by the hot path right away (device-built DB, no host index yet)
+    cands, kst = ctx.kmermatcher(frag, plass_amd.KmermatchParams(hash_shift=67, include_only_extendable=False))
+    assert kst.n_candidates > 0

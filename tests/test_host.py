@@ -65,16 +65,21 @@ def test_synth_deterministic():
         assert e.endswith(b"\n\x00") and b"*" not in e[:-3]
 
 
-def test_bench_workload_parts_concatenate():
-    """bench.py builds the multi-GPU / large single-GPU read set from independently seeded parts: keys stay unique and
-    ascending, offsets consistent, part 0 is the single-GPU workload"""
-    import numpy as np
+def test_bench_configs_and_scaled_workloads():
+    """bench.py's workloads: the configs are BASELINE.json's, --pairs keeps the coverage of the community model, and the
+    per-iteration hash shift is the workflow's (src/workflow/Assembler.cpp:99-110)"""
     import bench
-    d, o, e, k = bench.load_sharded_workload(1500, 0, 3, None)
-    assert len(set(k.tolist())) == len(k) and np.all(np.diff(k.astype(np.int64)) > 0)
-    assert int(o[-1]) + int(e[-1]) == len(d) and np.all(o[1:] == o[:-1] + e[:-1])
-    p0 = bench.load_workload(1500, seed=1)
-    assert d[:len(p0[0])] == p0[0] and np.array_equal(k[:len(p0[3])], p0[3])
+    assert [bench.hash_shift(i) for i in range(6)] == [67, 68, 68, 69, 69, 70]
+    c3 = bench.synth_params("c3")
+    assert (c3.n_pairs, c3.n_genomes, c3.genome_min_len, c3.genome_max_len, c3.abundance_sigma, c3.seed) == (25000000, 200, 1000000, 5000000, 1.0, 2)
+    c2 = bench.synth_params("c2")
+    assert (c2.n_pairs, c2.n_genomes, c2.genome_min_len, c2.seed) == (500000, 1, 7500000, 1)
+    cov = lambda p: 300.0 * p.n_pairs / (p.n_genomes * (p.genome_min_len + p.genome_max_len) / 2)
+    for pairs in (120000, 1000000, 5000000):
+        s = bench.synth_params("c3", pairs)
+        assert s.n_genomes >= 1 and 0.5 * cov(c3) < cov(s) < 2.0 * cov(c3)
+    s = bench.synth_params("c2", 50000)
+    assert abs(cov(s) - cov(c2)) < 0.01 * cov(c2)
 
 
 def test_local_group_host_allgather_threads():
