@@ -42,6 +42,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+VERBOSE = bool(os.environ.get("PLASS_BENCH_VERBOSE"))
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 CONFIGS = {
@@ -275,7 +276,13 @@ def main():
             if it == 0 and db is not db0:
                 db.free(); db = db0
             ts = time.perf_counter()
+            if VERBOSE and rank == 0:
+                i = db.info(); print("step %d iteration %d: %d sequences, %d residues, longest entry %d" % (s, it, i["n"], i["residues"], i["max_entry_len"]), file=sys.stderr, flush=True)
             out, kst, rst, ast, wall = one_iteration(ctx, db, it)
+            if VERBOSE and rank == 0:
+                print("   N_k=%d N_m=%d N_c=%d | scored=%d accepted=%d | aln=%d extended=%d rescored=%d | wall ms %s" % (
+                    kst.n_kmer_records, kst.n_grouped, kst.n_candidates, rst.n_scored, rst.n_accepted, ast.n_alignments, ast.n_extended, ast.n_rescored,
+                    ["%.1f" % x for x in wall]), file=sys.stderr, flush=True)
             if record:
                 ctx.sync()
                 rows.append((it, (time.perf_counter() - ts) * 1e3, kst, rst, ast, wall))

@@ -79,7 +79,7 @@ extern "C" int plasship_aln2nucl(plasship_ctx *ctx, const plasship_seqdb *q_nucl
     if (!HostEvaluer::nuclGapped(par->gap_open, par->gap_extend, t_nucl->residues, ev)) {
         setError("plasship_aln2nucl: Gumbel parameters exist for --gap-open 5 --gap-extend 2 only (the reference simulates others at start-up)"); return PLASSHIP_ERR_UNSUPPORTED;
     }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     bool differ = false;
     int rc = deviceKeysDiffer(ctx, q_nucl->d_key.as<uint32_t>(), q_aa->d_key.as<uint32_t>(), q_nucl->n, &differ); if (rc) return rc;

@@ -1262,7 +1262,8 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
     plasship_seqdb *o = holder.get();
     o->dbtype = db->dbtype; o->n = (size_t) outN; o->dataBytes = outBytes; o->residues = outBytes - 2 * outN; o->hostIndexValid = false;
     if (o->d_data.alloc(outBytes + 64) != hipSuccess || o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
-        setError("plasship_assemble: out of device memory for the output DB"); return PLASSHIP_ERR_DEVICE;
+        size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
+        setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
     if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16))), dim3(256), 0, st, sv, dFlags, dNewLen,
@@ -1358,7 +1359,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     if (!nucl && db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_assemble: the sequence DB is neither amino acids nor nucleotides"); return PLASSHIP_ERR_ARG; }
     if (par->rescore_mode != 3) { setError("plasship_assemble: only --rescore-mode 3"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (al->nQueries != db->n) { setError("plasship_assemble: alignment list does not belong to the DB"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const uint64_t nLines = al->nLines;
@@ -1401,7 +1402,10 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     PH_CHECK(hipMemcpyAsync(&totB, dPosB.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipStreamSynchronize(st));
     const uint32_t cnts[4] = {(uint32_t) totA, (uint32_t) (totA >> 32), (uint32_t) totB, (uint32_t) (totB >> 32)};
-    if (dArena.alloc(arenaBytes + 64) != hipSuccess || (guided && dAaArena.alloc(aaArenaBytes + 64) != hipSuccess)) { setError("plasship_assemble: out of device memory for the extension arena"); return PLASSHIP_ERR_DEVICE; }
+    if (dArena.alloc(arenaBytes + 64) != hipSuccess || (guided && dAaArena.alloc(aaArenaBytes + 64) != hipSuccess)) {
+        size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
+        setError("plasship_assemble: out of device memory for the extension arena (" + std::to_string(arenaBytes) + " bytes; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
+    }
     HostEvaluer ev(nucl, db->residues);
     AsmArgs a; memset(&a, 0, sizeof(a));
     a.s = sv; a.qoff = al->d_qoff.as<uint64_t>(); a.recs = al->d_recs.as<AlnRec>(); a.items = dItems.as<Item>(); a.arenaOff = dArenaOff.as<uint64_t>();
@@ -1534,7 +1538,7 @@ extern "C" int plasship_guided_assemble(plasship_ctx *ctx, const plasship_seqdb 
     if (!ctx || !nucl_db || !aa_db || !al || !par || !out_nucl || !out_aa) { setError("plasship_guided_assemble: bad argument"); return PLASSHIP_ERR_ARG; }
     if (nucl_db->dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES || aa_db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_guided_assemble: needs a nucleotide DB and its protein twin DB"); return PLASSHIP_ERR_ARG; }
     if (nucl_db->n != aa_db->n) { setError("plasship_guided_assemble: the two DBs differ in size"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     // the reference addresses the twin of entry i by the same id (guidedassembleresult.cpp:363): the key sets must be equal
     bool differ = false;
     { const int rc = deviceKeysDiffer(ctx, nucl_db->d_key.as<uint32_t>(), aa_db->d_key.as<uint32_t>(), nucl_db->n, &differ); if (rc) return rc; }

@@ -21,7 +21,7 @@ extern "C" int plasship_ctx_set_comm(plasship_ctx *ctx, const plasship_comm *com
 
 extern "C" int plasship_ctx_copy_d2d(plasship_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     if (!ctx) { setError("plasship_ctx_copy_d2d: ctx is NULL"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     if (bytes) PH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     PH_CHECK(hipStreamSynchronize(ctx->stream));
     return PLASSHIP_OK;

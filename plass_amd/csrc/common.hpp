@@ -47,6 +47,13 @@ bool traceOn();
 // dominate an assembly iteration on a 1 M-read set.  Freed blocks are kept (size classes with <= 12.5 % slack)
 // and handed out again; everything is returned to HIP when the last context is destroyed or on out-of-memory.
 hipError_t poolMalloc(void **p, size_t n);
+// every C-ABI entry that allocates calls this first (PH_ENTER): the stream the calling thread's allocations belong to
+void poolEnter(hipStream_t stream);
+#define PH_ENTER(ctx)                                                                    \
+    do {                                                                                 \
+        PH_CHECK(hipSetDevice((ctx)->device));                                           \
+        plasship::poolEnter((ctx)->stream);                                              \
+    } while (0)
 void poolFree(void *p);
 void poolTrim();
 

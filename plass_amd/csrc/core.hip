@@ -18,8 +18,14 @@ namespace plasship {
 // ---- caching allocator (see common.hpp) -----------------------------------------------------------
 namespace {
 std::mutex g_poolMu;
-std::multimap<size_t, void *> g_poolFree;            // size class -> cached block
-std::unordered_map<void *, size_t> g_poolLive;       // block -> size class
+// A cached block remembers the device it lives on and the stream whose work may still be using it: blocks never cross devices,
+// and a block last used on another stream is handed out only after that stream has drained (several contexts on one GPU — the
+// in-process rank groups of the tests — share the pool; within one stream reuse is ordered by the stream itself).
+struct PoolBlock { void *p; hipStream_t stream; };
+std::map<int, std::multimap<size_t, PoolBlock>> g_poolFree;   // device -> size class -> cached block
+struct PoolLive { size_t cls; int device; };
+std::unordered_map<void *, PoolLive> g_poolLive;     // block -> size class, device
+thread_local hipStream_t tl_poolStream = nullptr;    // stream of the API call this thread is in (poolEnter)
 int g_ctxCount = 0;
 size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
 size_t sizeClass(size_t n) {
@@ -38,35 +44,57 @@ hipError_t poolMalloc(void **p, size_t n) {
     if (e == hipSuccess && poisonByte() >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poisonByte(), n); (void) hipDeviceSynchronize(); }
     return e;
 }
+void poolEnter(hipStream_t stream) { tl_poolStream = stream; }
 static hipError_t poolMallocRaw(void **p, size_t n) {
     const size_t c = sizeClass(n);
+    int dev = 0; (void) hipGetDevice(&dev);
     {
+        hipStream_t waitFor = nullptr; bool hit = false;
+        {
         std::lock_guard<std::mutex> g(g_poolMu);
+        auto &freeMap = g_poolFree[dev];
         // best fit: the smallest cached block that is large enough, as long as it is not absurdly larger
         // (iterations shrink and grow their arrays; an exact-class match would miss and fall into hipMalloc)
-        auto it = g_poolFree.lower_bound(c);
-        if (it != g_poolFree.end() && (it->first <= 8 * c || it->first <= (size_t) 1 << 20)) {
-            *p = it->second; const size_t got = it->first; g_poolFree.erase(it); g_poolLive[*p] = got; g_poolHits++; return hipSuccess;
+        // (small requests may take a block up to 8x their size; a large request only one with <= 25 % slack — at 50 M reads a
+        //  10 GB request that takes a cached 77 GB record array makes the next iteration's record arrays a fresh hipMalloc, and
+        //  the job runs out of HBM with most of it idle inside oversized blocks)
+        auto it = freeMap.lower_bound(c);
+        if (it != freeMap.end() && (it->first <= (size_t) 1 << 20 || (c <= ((size_t) 64 << 20) ? it->first <= 8 * c : it->first <= c + c / 4))) {
+            *p = it->second.p; const size_t got = it->first;
+            if (it->second.stream != tl_poolStream) waitFor = it->second.stream;
+            freeMap.erase(it); g_poolLive[*p] = PoolLive{got, dev}; g_poolHits++; hit = true;
+        }
+        }
+        if (hit) {
+            if (waitFor) (void) hipStreamSynchronize(waitFor);          // the previous user's queued work must be through
+            return hipSuccess;
         }
     }
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, c);
     if (e != hipSuccess) { (void) hipGetLastError(); poolTrim(); e = hipMalloc(p, c); }
     const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (e == hipSuccess) { std::lock_guard<std::mutex> g(g_poolMu); g_poolLive[*p] = c; g_poolMisses++; g_poolMissMs += ms; g_poolMissBytes += (double) c; }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> g(g_poolMu); g_poolLive[*p] = PoolLive{c, dev}; g_poolMisses++; g_poolMissMs += ms; g_poolMissBytes += (double) c; }
     return e;
 }
 void poolFree(void *p) {
     std::lock_guard<std::mutex> g(g_poolMu);
     auto it = g_poolLive.find(p);
     if (it == g_poolLive.end()) { (void) hipFree(p); return; }
-    g_poolFree.emplace(it->second, p);
+    g_poolFree[it->second.device].emplace(it->second.cls, PoolBlock{p, tl_poolStream});
     g_poolLive.erase(it);
 }
 void poolTrim() {
     std::lock_guard<std::mutex> g(g_poolMu);
-    for (auto &kv : g_poolFree) (void) hipFree(kv.second);
-    g_poolFree.clear();
+    // cached blocks may still be referenced by queued work of their last stream: drain it before the memory goes back to HIP
+    int cur = 0; (void) hipGetDevice(&cur);
+    for (auto &dv : g_poolFree) {
+        if (dv.second.empty()) continue;
+        (void) hipSetDevice(dv.first); (void) hipDeviceSynchronize();
+        for (auto &kv : dv.second) (void) hipFree(kv.second.p);
+        dv.second.clear();
+    }
+    (void) hipSetDevice(cur);
 }
 static thread_local std::string g_err;
 int tuneInt(const char *name, int dflt) {
@@ -118,6 +146,7 @@ extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
     PH_CHECK(hipGetDeviceProperties(&prop, device_ordinal));
     c->numCU = prop.multiProcessorCount;
     PH_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    poolEnter(c->stream);
     for (auto &ev : c->ev) PH_CHECK(hipEventCreate(&ev));
     { std::lock_guard<std::mutex> g(g_poolMu); g_ctxCount++; }
     *out = holder.release();
@@ -154,7 +183,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         setError("plasship_seqdb_upload: dbtype must be amino acids (0) or nucleotides (1)"); return PLASSHIP_ERR_UNSUPPORTED;
     }
     if (n >= 0xFFFFFFFFull) { setError("plasship_seqdb_upload: too many sequences"); return PLASSHIP_ERR_UNSUPPORTED; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     // ids are ranks in key order (DBReader::getId); repack the data in id order so that device offsets
     // are monotone and neighbouring ids are neighbours in HBM.
     std::vector<uint32_t> perm(n);
@@ -255,7 +284,7 @@ extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *
                                        uint32_t *elen, uint32_t *key) {
     if (!ctx || !cdb) { setError("plasship_seqdb_download: bad argument"); return PLASSHIP_ERR_ARG; }
     plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
     PH_CHECK(hipStreamSynchronize(ctx->stream));
     if (data && db->dataBytes) PH_COPY_SYNC(ctx->stream, data, db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost);
@@ -268,7 +297,7 @@ extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *
 extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb, const char *db_path) {
     if (!ctx || !cdb || !db_path) { setError("plasship_seqdb_write: bad argument"); return PLASSHIP_ERR_ARG; }
     plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
     std::vector<char> data(db->dataBytes);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
@@ -283,6 +312,6 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
 
 extern "C" void plasship_seqdb_free(plasship_ctx *ctx, plasship_seqdb *db) {
     if (!db) return;
-    if (ctx) (void) hipSetDevice(ctx->device);
+    if (ctx) { (void) hipSetDevice(ctx->device); plasship::poolEnter(ctx->stream); }
     delete db;
 }

@@ -253,7 +253,7 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
     if (!ctx || !db || !par || !out_cycle) { setError("plasship_cyclecheck: bad argument"); return PLASSHIP_ERR_ARG; }
     if (db->dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES) { setError("Module cyclecheck only supports nucleotide input database"); return PLASSHIP_ERR_ARG; }
     if (db->maxEntryLen >= (1u << 30)) { setError("plasship_cyclecheck: sequence too long"); return PLASSHIP_ERR_UNSUPPORTED; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();

@@ -90,7 +90,7 @@ extern "C" int plasship_find_assembly_start(plasship_ctx *ctx, const plasship_se
     if (!ctx || !db || !al || !out) { setError("plasship_find_assembly_start: bad argument"); return PLASSHIP_ERR_ARG; }
     if (db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_find_assembly_start: needs a protein sequence DB"); return PLASSHIP_ERR_ARG; }
     if (al->nQueries != db->n) { setError("plasship_find_assembly_start: alignment list does not belong to the DB"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();

@@ -39,14 +39,14 @@ extern "C" int plasship_cands_count(const plasship_cands *c, uint64_t *n_hits, i
 
 extern "C" void plasship_cands_free(plasship_ctx *ctx, plasship_cands *c) {
     if (!c) return;
-    if (ctx) (void) hipSetDevice(ctx->device);
+    if (ctx) { (void) hipSetDevice(ctx->device); plasship::poolEnter(ctx->stream); }
     delete c;
 }
 
 extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb, const plasship_seqdb *tdb,
                                    const char *db_path, plasship_cands **out) {
     if (!ctx || !qdb || !tdb || !db_path || !out) { setError("plasship_cands_read: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     HostDB h; std::string err;
     if (!readDBFiles(db_path, h, err)) { setError(err); return PLASSHIP_ERR_IO; }
     if (h.dbtype != PLASSHIP_DBTYPE_PREFILTER_RES && h.dbtype != PLASSHIP_DBTYPE_PREFILTER_REV_RES) {
@@ -111,7 +111,7 @@ static int fetchCands(plasship_ctx *ctx, const plasship_cands *c, std::vector<ui
 extern "C" int plasship_cands_write(plasship_ctx *ctx, const plasship_cands *c, const plasship_seqdb *db, const char *db_path) {
     if (!ctx || !c || !db || !db_path) { setError("plasship_cands_write: bad argument"); return PLASSHIP_ERR_ARG; }
     if (c->nQueries != db->n) { setError("plasship_cands_write: DB mismatch"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     const std::vector<uint32_t> *keys; int rc = hostKeys(ctx, db, &keys); if (rc) return rc;
     std::vector<uint64_t> qoff; std::vector<CandHit> hits;
     rc = fetchCands(ctx, c, qoff, hits); if (rc) return rc;
@@ -136,7 +136,7 @@ extern "C" int plasship_cands_download(plasship_ctx *ctx, const plasship_cands *
                                        const plasship_seqdb *tdb, uint32_t *query_key, uint32_t *target_key,
                                        int32_t *pref_score, uint16_t *diagonal) {
     if (!ctx || !c || !qdb || !tdb) { setError("plasship_cands_download: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     const std::vector<uint32_t> *qk, *tk;
     int rc = hostKeys(ctx, qdb, &qk); if (rc) return rc;
     rc = hostKeys(ctx, tdb, &tk); if (rc) return rc;
@@ -162,7 +162,7 @@ extern "C" int plasship_alns_count(const plasship_alns *a, uint64_t *n_lines) {
 }
 extern "C" void plasship_alns_free(plasship_ctx *ctx, plasship_alns *a) {
     if (!a) return;
-    if (ctx) (void) hipSetDevice(ctx->device);
+    if (ctx) { (void) hipSetDevice(ctx->device); plasship::poolEnter(ctx->stream); }
     delete a;
 }
 
@@ -176,7 +176,7 @@ static int fetchAlns(plasship_ctx *ctx, const plasship_alns *a, std::vector<uint
 
 extern "C" int plasship_alns_download(plasship_ctx *ctx, const plasship_alns *a, plasship_aln_record *out) {
     if (!ctx || !a || !out) { setError("plasship_alns_download: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     std::vector<uint64_t> qoff; std::vector<AlnRec> recs;
     int rc = fetchAlns(ctx, a, qoff, recs); if (rc) return rc;
     const std::vector<uint32_t> *qk, *tk;
@@ -203,7 +203,7 @@ static char *fmtSeqId(float seqId, char *p) {
 
 extern "C" int plasship_alns_write(plasship_ctx *ctx, const plasship_alns *a, const char *db_path) {
     if (!ctx || !a || !db_path) { setError("plasship_alns_write: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     std::vector<uint64_t> qoff; std::vector<AlnRec> recs;
     int rc = fetchAlns(ctx, a, qoff, recs); if (rc) return rc;
     const std::vector<uint32_t> *qk, *tk;
@@ -237,7 +237,7 @@ extern "C" int plasship_alns_write(plasship_ctx *ctx, const plasship_alns *a, co
 
 extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, const char *db_path, plasship_alns **out) {
     if (!ctx || !db || !db_path || !out) { setError("plasship_alns_read: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     HostDB h; std::string err;
     if (!readDBFiles(db_path, h, err)) { setError(err); return PLASSHIP_ERR_IO; }
     if (h.dbtype != PLASSHIP_DBTYPE_ALIGNMENT_RES) { setError(std::string("not an alignment DB: ") + db_path); return PLASSHIP_ERR_ARG; }

@@ -25,6 +25,7 @@
 #include "common.hpp"
 #include "device_utils.hpp"
 #include "host_util.hpp"
+#include "linepart.hpp"
 #include <algorithm>
 #include <memory>
 #include <cstdlib>
@@ -32,15 +33,6 @@
 #include <cstring>
 
 namespace plasship {
-
-#define BIT63 (1ULL << 63)
-
-// ---- record layouts (kmermatcher.h:49-55: KmerPosition<short> 16 B, KmerPosition<int> 20 B) -------------
-template <bool LONG> struct Rec;
-template <> struct __attribute__((aligned(16))) Rec<false> { uint64_t kmer; uint32_t id; uint16_t len; int16_t pos; };
-template <> struct __attribute__((aligned(8))) Rec<true> { uint64_t kmer; uint32_t id; int32_t len; int32_t pos; uint32_t pad; };
-
-template <bool LONG> __device__ __forceinline__ bool isSentinel(const Rec<LONG> &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }
 
 // ---- XXH64 of one little-endian u64 (xxhash 0.8.0, call site kmermatcher.cpp:33-38) ---------------------
 __host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
@@ -634,14 +626,9 @@ __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t
 // =====================================================================================================
 // KEY_OWNER_HASH / KEY_OWNER_REP (sharded run): bucket = the rank that owns the record — the k-mer's hash bucket (low bits of
 // the same mix whose top bits pick the grouping bucket, so the owner's buckets stay uniformly filled) or the representative's
-// id range
-enum { KEY_HASH = 0, KEY_RANGE = 1, KEY_OWNER_HASH = 2, KEY_OWNER_REP = 3 };
-template <bool NUCL> __device__ __forceinline__ uint64_t kmerMix(uint64_t kmerField) {
-    const uint64_t K = NUCL ? (kmerField & ~BIT63) : kmerField;
-    uint64_t x = K * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;
-    return x;
-}
-
+// id range.  (Key kinds, kmerMix and the record layouts: linepart.hpp.)  This dense two-pass partition (histogram, then scatter)
+// is what the SHARDED run still uses — its exchanges send contiguous runs per destination; a single GPU takes the line-store
+// partition of linepart.hpp.
 constexpr int PT_BLOCK = 256;
 constexpr int PT_ITEMS = 16;
 constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;
@@ -668,13 +655,6 @@ template <bool NUCL, int MODE> __device__ __forceinline__ uint32_t bucketOf(cons
     if (MODE == KEY_OWNER_HASH) return (uint32_t) (((kmerMix<NUCL>(kmerField) & 0xFFFFFFFFull) * (uint64_t) a.ownerW) >> 32);
     return (uint32_t) (((kmerField & ~BIT63) * (uint64_t) a.ownerW) / a.ownerN);              // owner r <=> id in [ceil(r n / W), ceil((r+1) n / W))
 }
-constexpr uint32_t VH_BINS = 4096;
-template <bool NUCL> __device__ __host__ __forceinline__ uint32_t valueBin(uint64_t kmerField, int shift) {
-    const uint64_t v = NUCL ? (kmerField & ~BIT63) : kmerField;       // sort #1 compares (kmer | bit 63) for nucleotides
-    const uint64_t b = v >> shift;
-    return b < VH_BINS ? (uint32_t) b : VH_BINS - 1;                   // identity records (64-bit hashes) collect in the last bin
-}
-
 template <bool NUCL, bool LONG, int MODE>
 __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
     __shared__ uint32_t sh[4096];
@@ -766,7 +746,8 @@ constexpr uint32_t GR_MAXKEYS = 1536;       // distinct k-mers per sub-pass befo
 
 struct GroupArgs {
     const void *in; void *out;
-    const uint64_t *bucketStart;     // [nBuckets+1]
+    const uint64_t *bucketStart;     // [nBuckets+1] (dense input)
+    const uint32_t *list, *lineBeg, *lineCnt;   // LINES input: bucket b = the lines list[lineBeg[b] .. + lineCnt[b]) of `in` (linepart.hpp)
     uint32_t nBuckets, bucketsPerBlock;
     uint64_t *outCount;              // [gridDim.x] records written by block j at out[bucketStart[j*bucketsPerBlock] ...]
     int includeOnlyExtendable, covMode; float covThr;
@@ -786,7 +767,7 @@ __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q
     }
 }
 
-template <bool NUCL, bool LONG>
+template <bool NUCL, bool LONG, bool LINES>
 __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
     __shared__ unsigned long long hKey[GR_HT];
     __shared__ unsigned long long hBest[GR_HT];
@@ -802,10 +783,14 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
     if (bBegin >= a.nBuckets) { if (threadIdx.x == 0) a.outCount[blockIdx.x] = 0; return; }
     unsigned long long written = 0;                  // block-uniform
     unsigned long long maxRT = 0;
-    const uint64_t arena = a.bucketStart[bBegin];
+    // the workgroup writes its grouped records where its input begins: it never emits more records than it read
+    const uint64_t arena = LINES ? (uint64_t) a.lineBeg[bBegin] * RPL : a.bucketStart[bBegin];
     const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
     for (uint32_t b = bBegin; b < bEnd; b++) {
-        const uint64_t s0 = a.bucketStart[b], s1 = a.bucketStart[b + 1];
+        // records [s0, s1) of the bucket; LINES: positions in the bucket's line list (padding sentinels are skipped)
+        const uint64_t s0 = LINES ? 0ull : a.bucketStart[b], s1 = LINES ? (uint64_t) a.lineCnt[b] * RPL : a.bucketStart[b + 1];
+        const uint32_t lb = LINES ? a.lineBeg[b] : 0u;
+        auto recAt = [&](uint64_t i) -> R { if (LINES) return in[(uint64_t) a.list[lb + (uint32_t) (i / RPL)] * RPL + (i % RPL)]; return in[i]; };
         if (s1 <= s0) continue;
         uint32_t nSub = 1;                           // sub-passes by a secondary hash when too many distinct k-mers
         const unsigned long long writtenAtBucketStart = written;
@@ -817,7 +802,8 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
                 __syncthreads();
                 // phase A: insert keys, count members, longest sequence
                 for (uint64_t i = s0 + threadIdx.x; i < s1; i += GR_BLOCK) {
-                    const R r = in[i];
+                    const R r = recAt(i);
+                    if (LINES && isSentinel(r)) continue;
                     const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
                     const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
                     if (nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub) continue;
@@ -834,7 +820,8 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
                 if (sFlag[1] || sFlag[0] > GR_MAXKEYS) { redo = true; __syncthreads(); break; }
                 // phase B: head of the run = (longest, smallest id, smallest pos[, reverse strand first])
                 for (uint64_t i = s0 + threadIdx.x; i < s1; i += GR_BLOCK) {
-                    const R r = in[i];
+                    const R r = recAt(i);
+                    if (LINES && isSentinel(r)) continue;
                     const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
                     const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
                     if (nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub) continue;
@@ -851,10 +838,10 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
                     const uint64_t i = i0 + threadIdx.x;
                     bool keep = false; R o; memset(&o, 0, sizeof(R));
                     if (i < s1) {
-                        const R r = in[i];
+                        const R r = recAt(i);
                         const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
                         const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
-                        if (!(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
+                        if (!(LINES && isSentinel(r)) && !(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
                             uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
                             while (hKey[slot] != K) slot = (slot + 1) & (GR_HT - 1);
                             if (hCnt[slot] >= 2) {
@@ -933,10 +920,12 @@ constexpr uint32_t AGG_HT = 2048;           // hash slots
 template <bool LONG> struct DiagPack { static constexpr int BITS = LONG ? 22 : 16; static constexpr int64_t BIAS = LONG ? (1 << 21) : 32768; };
 struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag; uint32_t cnt; };   // cnt bit 31: some record of the run is forward-strand
 
-template <bool NUCL, bool LONG>
+// LINES: bucket b = the lines list[lineBeg[b] .. + lineCnt[b]) of `arr` (linepart.hpp); its triples go to outTriples[lineBeg[b] * RPL ...]
+struct AggLines { const uint32_t *list, *lineBeg, *lineCnt; };
+template <bool NUCL, bool LONG, bool LINES>
 __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void *outTriples, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
                                                           unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
-                                                          uint32_t *__restrict__ uniqueCount, int localBits, int idBits, uint64_t repBase) {
+                                                          uint32_t *__restrict__ uniqueCount, int localBits, int idBits, uint64_t repBase, AggLines ln) {
     typedef Rec<LONG> R;
     __shared__ unsigned long long hKey[AGG_HT];
     __shared__ uint32_t hVal[AGG_HT];
@@ -948,8 +937,11 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
     Triple *out = reinterpret_cast<Triple *>(outTriples);
     constexpr int DB = DiagPack<LONG>::BITS;
     for (uint32_t b = blockIdx.x; b < nBuckets; b += gridDim.x) {
-        const uint64_t s0 = bucketStart[b], s1 = bucketStart[b + 1];
-        const uint64_t cnt = s1 - s0;
+        // cnt record positions; LINES: positions in the bucket's line list, padding sentinels are skipped when read
+        const uint64_t s0 = LINES ? (uint64_t) ln.lineBeg[b] * RPL : bucketStart[b];        // where the bucket's triples are written
+        const uint64_t cnt = LINES ? (uint64_t) ln.lineCnt[b] * RPL : bucketStart[b + 1] - s0;
+        const uint32_t lb = LINES ? ln.lineBeg[b] : 0u;
+        auto recAt = [&](uint64_t i) -> R { if (LINES) return g[(uint64_t) ln.list[lb + (uint32_t) (i / RPL)] * RPL + (i % RPL)]; return g[s0 + i]; };
         if (cnt == 0) { if (threadIdx.x == 0) uniqueCount[b] = 0; continue; }
         const uint64_t baseRep = repBase + ((uint64_t) b << localBits);     // repBase: first rep of this rank's range (sharded run), else 0
         auto decode = [&](unsigned long long key, uint32_t val) {
@@ -1012,7 +1004,7 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
         };
         if (cnt <= AGG_CAP) {
             clearTable();
-            for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) { uint32_t v; const unsigned long long key = packRec(g[s0 + i], v); insert(key, v); }
+            for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) { const R r = recAt(i); if (LINES && isSentinel(r)) continue; uint32_t v; const unsigned long long key = packRec(r, v); insert(key, v); }
             __syncthreads();
             sortListAndWrite(extract());
         } else {
@@ -1025,7 +1017,7 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
             for (uint64_t c0 = 0; c0 < cnt; c0 += AGG_CAP) {
                 const uint64_t c1 = min(cnt, c0 + (uint64_t) AGG_CAP);
                 clearTable();
-                for (uint64_t i = c0 + threadIdx.x; i < c1; i += LS_BLOCK) { uint32_t v; const unsigned long long key = packRec(g[s0 + i], v); insert(key, v); }
+                for (uint64_t i = c0 + threadIdx.x; i < c1; i += LS_BLOCK) { const R r = recAt(i); if (LINES && isSentinel(r)) continue; uint32_t v; const unsigned long long key = packRec(r, v); insert(key, v); }
                 __syncthreads();
                 const uint32_t U = extract();
                 for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) { pk[nPart + i] = lKey[i]; pv[nPart + i] = lVal[i]; }
@@ -1099,11 +1091,11 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
     }
 }
 
-__global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__restrict__ in, const uint64_t *__restrict__ bucketStart,
+__global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__restrict__ in, const uint64_t *__restrict__ bucketStart, const uint32_t *__restrict__ lineBeg,
                                                             const uint64_t *__restrict__ tripleStart, uint32_t nBuckets, Triple *__restrict__ out) {
-    // one wave per bucket
+    // one wave per bucket; lineBeg != nullptr: the bucket's triples start at lineBeg[b] * RPL (line-store input of aggSortKernel)
     for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
-        const uint64_t s0 = bucketStart[b], d0 = tripleStart[b], n = tripleStart[b + 1] - d0;
+        const uint64_t s0 = lineBeg ? (uint64_t) lineBeg[b] * RPL : bucketStart[b], d0 = tripleStart[b], n = tripleStart[b + 1] - d0;
         for (uint64_t i = laneId(); i < n; i += 64) out[d0 + i] = in[s0 + i];
     }
 }
@@ -1176,6 +1168,26 @@ __global__ __launch_bounds__(256) void rankKernel(const void *recs, uint64_t n, 
     if (useLds) { for (uint32_t i = threadIdx.x; i <= m; i += 256) sDiff[i] = 0; __syncthreads(); }
     for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t) gridDim.x * 256) {
         const R r = g[i];
+        uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
+        if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
+    }
+    if (useLds) { __syncthreads(); for (uint32_t i = threadIdx.x; i <= m; i += 256) { const uint32_t c = sDiff[i]; if (c) atomicAdd(&diff[i], (unsigned long long) c); } }
+}
+
+// the same over a line store: every written line (tag != TAG_NONE) of the hash-partitioned records, padding sentinels skipped
+template <bool NUCL, bool LONG>
+__global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const uint32_t *__restrict__ tags, uint64_t nLines, const void *tkeys, uint32_t m, unsigned long long *diff) {
+    typedef Rec<LONG> R;
+    const R *g = reinterpret_cast<const R *>(recs);
+    const R *tk = reinterpret_cast<const R *>(tkeys);
+    __shared__ uint32_t sDiff[1025];
+    const bool useLds = m <= 1024;
+    if (useLds) { for (uint32_t i = threadIdx.x; i <= m; i += 256) sDiff[i] = 0; __syncthreads(); }
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < nLines * RPL; i += (uint64_t) gridDim.x * 256) {
+        if (tags[i / RPL] == TAG_NONE) continue;
+        const R r = g[i];
+        if (isSentinel(r)) continue;
         uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
         if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
@@ -1396,7 +1408,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     { uint64_t z = 0; PH_CHECK(hipMemcpyAsync(dSeg0Start.p, &z, 8, hipMemcpyHostToDevice, st)); PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &total, 8, hipMemcpyHostToDevice, st)); }
     int keyBits = 0;
     if (NUCL) keyBits = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
-    const int valueShift = std::max(0, keyBits - 12);
+    const int valueShift = std::max(0, keyBits - 11);      // VH_BINS = 2^11 monotone bins
     void *bufA = dA.p, *bufB = dB.p;        // level 1 reads bufA (partTotal slots), writes bufB
     uint64_t partTotal = total, NkAll = 0;  // NkAll: records of the whole run (sharded)
     // Sharded run, W a power of two, two partition levels: level 1 doubles as the partition by owner.  With the bucket geometry
@@ -1554,7 +1566,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
     ga.maxRepTarget = dMaxRT.as<unsigned long long>();
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
-    hipLaunchKernelGGL((groupKernel<NUCL, LONG>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+    hipLaunchKernelGGL((groupKernel<NUCL, LONG, false>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     std::vector<uint64_t> hOutCnt(gGrid), hBStart(nBuckets + 1);
     DevBuf dLastRun; unsigned long long hLastRun[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
     if (dLastRun.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
@@ -1759,16 +1771,16 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
         PH_CHECK(hipMemcpyAsync(dBigOff.p, bigOff.data(), (size_t) nSortBuckets * 8, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
+    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, false>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
                        (const void *) cur, other, dSortStart, nSortBuckets, dBigScratch.as<unsigned long long>(), dBigOff.as<uint64_t>(),
-                       dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0));
+                       dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0), AggLines{nullptr, nullptr, nullptr});
     DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
     if (dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSortBuckets, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t nTriples = 0;
     PH_CHECK(hipMemcpyAsync(&nTriples, dTripleStart.as<uint64_t>() + nSortBuckets, 8, hipMemcpyDeviceToHost, st));
     hipLaunchKernelGGL(compactTriplesKernel, dim3(std::min<uint32_t>((nSortBuckets + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st,
-                       (const Triple *) other, dSortStart, dTripleStart.as<uint64_t>(), nSortBuckets, (Triple *) cur);
+                       (const Triple *) other, dSortStart, (const uint32_t *) nullptr, dTripleStart.as<uint64_t>(), nSortBuckets, (Triple *) cur);
     msSort2 = tm.stop(1);
     PH_TRACE(st, "kmermatch: rep sort");
     PH_CHECK(hipGetLastError());
@@ -1923,7 +1935,7 @@ extern "C" int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, c
     if (par->kmer_size < 2 || par->kmer_size > (nucl ? 31 : 23)) { setError("plasship_kmermatch: unsupported k"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (!nucl && par->alphabet_size != 13 && par->alphabet_size != 21) { setError("plasship_kmermatch: --alph-size must be 13 or 21"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (db->maxEntryLen >= (1u << 20)) { setError("plasship_kmermatch: sequences of 2^20 residues or more are not supported"); return PLASSHIP_ERR_UNSUPPORTED; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX);     // kmermatcher.cpp:797-802
     if (nucl) return lng ? kmermatchImpl<true, true>(ctx, db, par, out, stats) : kmermatchImpl<true, false>(ctx, db, par, out, stats);
     return lng ? kmermatchImpl<false, true>(ctx, db, par, out, stats) : kmermatchImpl<false, false>(ctx, db, par, out, stats);

@@ -348,7 +348,7 @@ extern "C" int plasship_extract_orfs(plasship_ctx *ctx, const plasship_seqdb *re
     }
     if (par->orf_start_mode < 0 || par->orf_start_mode > 2 || par->min_length < 0 || par->max_length < 0 || par->max_gaps < 0 ||
         (par->forward_frames & ~7) || (par->reverse_frames & ~7) || (par->translate && par->max_seq_len == 0)) { setError("plasship_extract_orfs: bad parameter"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) reads->n;
     const uint64_t nSlots = 2ull * N;
@@ -410,7 +410,7 @@ extern "C" int plasship_translate_nucs(plasship_ctx *ctx, const plasship_seqdb *
     if (par->add_orf_stop && (!hdr || hdr->n != orfs->n)) { setError("plasship_translate_nucs: --add-orf-stop needs the header DB of the ORF DB (same keys)"); return PLASSHIP_ERR_ARG; }
     // Orf::parseOrfHeader leaves the two flags uninitialised when a header is not in ORF format (Orf.cpp:401-405): no defined result to reproduce
     if (par->add_orf_stop && hdr->nUnparsable) { setError("plasship_translate_nucs: --add-orf-stop with headers that are not ORF headers is undefined in the reference; refused"); return PLASSHIP_ERR_UNSUPPORTED; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) orfs->n;
     DevBuf dTab, dBytes, dFlag, dByteBase, dIdxBase, dTmp;
@@ -473,7 +473,7 @@ static int maxKeyOf(plasship_ctx *ctx, const uint32_t *dKey, size_t n, uint32_t 
 }
 extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a, const plasship_seqdb *b, plasship_seqdb **out) {
     if (!ctx || !a || !b || !out) { setError("plasship_seqdb_concat: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     uint32_t maxKeyA = 0; int rc = maxKeyOf(ctx, a->d_key.as<uint32_t>(), a->n, &maxKeyA); if (rc) return rc;
     const uint64_t nn = (uint64_t) a->n + b->n;
@@ -496,7 +496,7 @@ extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a,
 }
 extern "C" int plasship_orfhdr_concat(plasship_ctx *ctx, const plasship_orfhdr *a, const plasship_orfhdr *b, plasship_orfhdr **out) {
     if (!ctx || !a || !b || !out) { setError("plasship_orfhdr_concat: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     uint32_t maxKeyA = 0;
     if (a->n) { OrfInfo last; PH_COPY_SYNC(st, &last, a->d_info.as<OrfInfo>() + (a->n - 1), sizeof(OrfInfo), hipMemcpyDeviceToHost); maxKeyA = last.key; }
@@ -514,7 +514,7 @@ extern "C" int plasship_orfhdr_concat(plasship_ctx *ctx, const plasship_orfhdr *
 // ---- header DB <-> files (Orf::writeOrfHeader / Orf::parseOrfHeader, Orf.cpp:350-456) ------------------------------------------
 extern "C" int plasship_orfhdr_write(plasship_ctx *ctx, const plasship_orfhdr *h, const char *db_path) {
     if (!ctx || !h || !db_path) { setError("plasship_orfhdr_write: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     std::vector<OrfInfo> info(h->n);
     if (h->n) PH_COPY_SYNC(ctx->stream, info.data(), h->d_info.p, h->n * sizeof(OrfInfo), hipMemcpyDeviceToHost);
     std::string err; DBFileWriter w;
@@ -533,7 +533,7 @@ extern "C" int plasship_orfhdr_write(plasship_ctx *ctx, const plasship_orfhdr *h
 }
 extern "C" int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plasship_orfhdr **out) {
     if (!ctx || !db_path || !out) { setError("plasship_orfhdr_read: bad argument"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     HostDB h; std::string err;
     if (!readDBFiles(db_path, h, err)) { setError(err); return PLASSHIP_ERR_IO; }
     const size_t n = h.key.size();
@@ -582,6 +582,6 @@ extern "C" int plasship_orfhdr_count(const plasship_orfhdr *h, size_t *n) {
 }
 extern "C" void plasship_orfhdr_free(plasship_ctx *ctx, plasship_orfhdr *h) {
     if (!h) return;
-    if (ctx) (void) hipSetDevice(ctx->device);
+    if (ctx) { (void) hipSetDevice(ctx->device); plasship::poolEnter(ctx->stream); }
     delete h;
 }

@@ -288,7 +288,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     if (par->rescore_mode != 3) { setError("plasship_rescore: only --rescore-mode 3 (end-to-end) runs on the GPU path"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (c->nQueries != qdb->n) { setError("plasship_rescore: candidate list does not belong to the query DB"); return PLASSHIP_ERR_ARG; }
     if (qdb->dbtype != tdb->dbtype) { setError("plasship_rescore: query and target DB types differ"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     const bool nucl = qdb->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES;
     const uint64_t nHits = c->nHits;
     const uint32_t maxQLen = qdb->maxEntryLen >= 2 ? qdb->maxEntryLen - 2 : 0;

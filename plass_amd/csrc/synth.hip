@@ -112,7 +112,7 @@ extern "C" int plasship_synth_read_pairs(plasship_ctx *ctx, const plasship_synth
     if (par->n_genomes == 0 || par->genome_min_len < 1000 || par->genome_max_len < par->genome_min_len || par->read_len < 8 || par->read_len > 100000 ||
         2 * par->n_pairs >= 0xFFFFFFFFull || par->error_rate < 0 || par->error_rate >= 1 || par->abundance_sigma < 0 ||
         par->genome_min_len < 4ull * (uint64_t) (par->insert_mean + 8 * par->insert_sd + par->read_len)) { setError("plasship_synth_read_pairs: bad parameter"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipSetDevice(ctx->device));
+    PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     // ---- community and gene layout (host, tiny) ----
     uint64_t rs = par->seed * 0x9E3779B97F4A7C15ULL + 0x1234567ull;

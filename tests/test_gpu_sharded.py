@@ -321,7 +321,10 @@ def test_full_size_sharded_equals_single_and_properties(ctxs):
     every sequence of the output contains its input sequence (greedy extension only appends), key set unchanged"""
     import plass_amd
     import bench
-    data, off, elen, key = bench.load_workload(500000, seed=1)
+    # the bench workload of configs[1], made the way bench.py makes it: reads generated in HBM, fragments by the GPU preprocessing
+    frag, _ = bench.build_workload(ctxs[3], "c2")
+    data, off, elen, key = frag.download()
+    frag.free()
     rs, asp = plass_amd.RescoreParams(min_seq_id=0.9), plass_amd.AssembleParams(min_seq_id=0.9)
     ref = ctxs[3]
     rdb = ref.upload_seqdb(data, off, elen, key, 0)
