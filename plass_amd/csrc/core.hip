@@ -45,6 +45,12 @@ hipError_t poolMalloc(void **p, size_t n) {
     return e;
 }
 void poolEnter(hipStream_t stream) { tl_poolStream = stream; }
+// a context goes away (its stream has been drained): its cached blocks no longer wait for anybody
+static void poolForgetStream(hipStream_t stream) {
+    std::lock_guard<std::mutex> g(g_poolMu);
+    for (auto &dv : g_poolFree) for (auto &kv : dv.second) if (kv.second.stream == stream) kv.second.stream = nullptr;
+    if (tl_poolStream == stream) tl_poolStream = nullptr;
+}
 static hipError_t poolMallocRaw(void **p, size_t n) {
     const size_t c = sizeClass(n);
     int dev = 0; (void) hipGetDevice(&dev);
@@ -158,7 +164,7 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
-    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    if (ctx->stream) { poolForgetStream(ctx->stream); (void) hipStreamDestroy(ctx->stream); }
     bool last; { std::lock_guard<std::mutex> g(g_poolMu); last = (--g_ctxCount <= 0); }
     if (last) {
         if (getenv("PLASSHIP_POOL_STATS")) fprintf(stderr, "plasship pool: %zu hits, %zu misses (%.1f ms in hipMalloc, %.1f MB)\n", g_poolHits, g_poolMisses, g_poolMissMs, g_poolMissBytes / 1e6);
