@@ -211,18 +211,25 @@ __device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k,
     return true;
 }
 
-constexpr uint32_t RES_L = 992;     // sequences up to this length keep their codes (and per-window hash scores) resident in LDS
 
-template <bool NUCL, bool LONG, int CAP, bool FALLBACK>
-__global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
+// REGS > 0 (the regular launch): sequences of up to 64 * REGS windows — every read, every contig up to ~1000 residues — keep the
+//   16-bit score of every window in a REGISTER (window p = j * 64 + lane): the k-mers are hashed once, the reference's
+//   65 536-bin threshold walk is a 16-step bisection over the score bits whose counts are wave ballots (no LDS histogram, no
+//   atomics, no barriers), and only the <= ~60 selected windows rebuild their k-mer.  Longer sequences are queued for the next
+//   launch.  REGS == 0: the three-pass path below; RESL = longest sequence whose codes and scores stay resident in LDS.
+template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS > 0 ? 4 : 1))) void extractKernel(ExtractArgs a) {
+    constexpr uint32_t RES_L = RESL;
+    constexpr uint32_t CODES = (RESL > 64 * REGS + 32 ? RESL : 64 * REGS + 32) + 32;
     __shared__ unsigned char sMap[256];
     __shared__ unsigned char sCode[64 + 32];
     __shared__ uint32_t sHist[256];
     __shared__ Cand sCand[FALLBACK ? 1 : CAP];
     __shared__ unsigned long long sSet[FALLBACK ? 1 : 2 * CAP];     // duplicate-k-mer detection without sorting (after the passes)
-    unsigned short *sScore = reinterpret_cast<unsigned short *>(sSet); // per-window hash scores (during the passes; 2*CAP*8 >= RES_L*2 bytes)
-    __shared__ unsigned char sCodeAll[FALLBACK ? 1 : RES_L + 32];     // codes of a resident sequence
-    __shared__ unsigned long long sValid[RES_L / 64 + 2];            // per-tile validity masks
+    __shared__ unsigned short sScoreBig[(RESL > 4 * CAP && !FALLBACK) ? RESL : 1];
+    unsigned short *sScore = (RESL > 4 * CAP) ? sScoreBig : reinterpret_cast<unsigned short *>(sSet); // per-window hash scores (during the passes; aliases the set when 2*CAP*8 >= RESL*2 bytes)
+    __shared__ unsigned char sCodeAll[FALLBACK ? 1 : CODES];          // codes of a resident sequence
+    __shared__ unsigned long long sValid[RESL / 64 + 2];             // per-tile validity masks
     typedef Rec<LONG> R;
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
@@ -283,6 +290,89 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
         uint32_t sStar = 0; int tooMuch = 0; size_t considered = 0;
         uint32_t b1 = 0, cumBefore1 = 0;
 
+        constexpr bool useRegs = REGS > 0 && !FALLBACK;
+        if (useRegs && nWin > 64u * (uint32_t) (REGS > 0 ? REGS : 1)) {     // too long for the register front end: next tier
+            if (lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
+            continue;
+        }
+        if (useRegs) {
+            // ---- codes to LDS (padded with X so that every window read stays inside the staged bytes) ----
+            for (uint32_t i = lane; i < L + 31; i += 64) {
+                const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < L) ? base[i] : (char) 0));      // first 128 bytes were prefetched
+                sCodeAll[i] = (i < L) ? sMap[(unsigned char) ch] : (unsigned char) a.xCode;
+            }
+            __syncthreads();
+            // identity hash, tile-wise Horner: h = h*31^m + sum code[j]*31^(m-1-j) (Util::hash, Util.h:337-345)
+            for (uint32_t t0 = 0; t0 < L; t0 += 64) {
+                const uint32_t p = t0 + lane;
+                const unsigned char c = (p < L) ? sCodeAll[p] : (unsigned char) a.xCode;
+                const uint32_t m = min(64u, L - t0);
+                const uint64_t pw = __shfl(pow31, (int) (m - 1 - min((uint32_t) lane, m - 1)), 64);
+                uint64_t term = ((uint32_t) lane < m) ? (uint64_t) c * pw : 0ull;
+                term = waveReduceSumU64(term);
+                const uint64_t pm = __shfl(pow31, (int) (m - 1), 64) * 31ull;      // 31^m
+                seqHash = seqHash * pm + term;
+            }
+            auto windowKmer = [&](uint32_t p, uint64_t &kmer, uint32_t &pos) -> bool {
+                pos = p; kmer = 0;
+                if (!NUCL && fastIdx) return kmerIndexFast(&sCodeAll[p], k, (unsigned) a.xCode, (uint32_t) a.powers[1], (uint32_t) a.powers[7], kmer);
+                if (NUCL && a.xCode == 4) return kmerNuclCanonical(&sCodeAll[p], k, L, p, kmer, pos);
+                return kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
+            };
+            // ---- one score per window, in registers: 0xFFFFFFFF = no k-mer here ----
+            const uint32_t nWinU = (uint32_t) __builtin_amdgcn_readfirstlane((int) nWin);     // wave-uniform loop guards stay scalar
+            uint32_t sc[REGS > 0 ? REGS : 1];
+#pragma unroll
+            for (int j = 0; j < REGS; j++) {
+                sc[j] = 0xFFFFFFFFu;
+                if ((uint32_t) j * 64u < nWinU) {                   // wave-uniform
+                    const uint32_t p = (uint32_t) j * 64u + (uint32_t) lane;
+                    if (p < nWin) {
+                        uint64_t kmer; uint32_t pos;
+                        if (windowKmer(p, kmer, pos)) sc[j] = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
+                    }
+                    n += (uint32_t) __popcll(__ballot(sc[j] != 0xFFFFFFFFu));
+                }
+            }
+            considered = min(consideredRaw, (size_t) n);
+            if (!allCand && considered > 0) {
+                // the reference walks 65 536 score bins until `considered` k-mers are covered (kmermatcher.cpp:224-239): s* is the
+                // considered-th smallest score = the largest t with fewer than `considered` scores below it
+                uint32_t t = 0;
+#pragma unroll 1
+                for (int bit = 15; bit >= 0; bit--) {
+                    const uint32_t tr = t | (1u << bit);
+                    uint32_t below = 0;
+#pragma unroll
+                    for (int j = 0; j < REGS; j++) if ((uint32_t) j * 64u < nWinU) below += (uint32_t) __popcll(__ballot(sc[j] < tr));
+                    if ((size_t) below < considered) t = tr;
+                }
+                sStar = t;
+                uint32_t upTo = 0;
+#pragma unroll
+                for (int j = 0; j < REGS; j++) if ((uint32_t) j * 64u < nWinU) upTo += (uint32_t) __popcll(__ballot(sc[j] <= t));
+                tooMuch = (int) upTo - (int) considered;
+            }
+            // ---- candidates: every k-mer (allCand) or those with score <= s* ----
+            if (allCand || considered > 0) {
+#pragma unroll
+                for (int j = 0; j < REGS; j++) {
+                    if ((uint32_t) j * 64u < nWinU) {
+                        const bool push = sc[j] != 0xFFFFFFFFu && (allCand || sc[j] <= sStar);
+                        const unsigned long long mask = __ballot(push);
+                        const uint32_t rank = (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL));
+                        const uint32_t cnt = (uint32_t) __popcll(mask);
+                        if (C + cnt > cap) overflow = true;
+                        else if (push) {
+                            Cand cd; uint32_t pos; (void) windowKmer((uint32_t) j * 64u + (uint32_t) lane, cd.kmer, pos);
+                            cd.pos = pos; cd.score = sc[j]; cand[C + rank] = cd;
+                        }
+                        C += cnt;
+                    }
+                }
+            }
+            __syncthreads();
+        } else {
         // pass 0: all candidates pushed / or coarse histogram; pass 1: fine histogram; pass 2: push score <= s*
         const int nPass = allCand ? 1 : 3;
         const bool resident = !FALLBACK && L <= RES_L;      // whole sequence staged once; later passes reuse codes and scores
@@ -385,6 +475,7 @@ __global__ __launch_bounds__(64) void extractKernel(ExtractArgs a) {
                 if (pass == 0 && (considered == 0)) break;     // nothing can be selected (n == 0)
             }
         }
+        }      // three-pass path
         if (overflow) {
             if (!FALLBACK && lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
             __syncthreads();
@@ -1177,8 +1268,10 @@ __global__ __launch_bounds__(256) void rankKernel(const void *recs, uint64_t n, 
 
 // the same over a line store: every written line (tag != TAG_NONE) of the hash-partitioned records, padding sentinels skipped
 template <bool NUCL, bool LONG>
-__global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const uint32_t *__restrict__ tags, uint64_t nLines, const void *tkeys, uint32_t m, unsigned long long *diff) {
+__global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const uint32_t *__restrict__ tags, uint64_t nLines, const uint64_t *__restrict__ nLinesDev,
+                                                       const void *tkeys, uint32_t m, unsigned long long *diff) {
     typedef Rec<LONG> R;
+    if (nLinesDev) nLines = min(nLines, (uint64_t) *nLinesDev);        // lines the last partition level laid out (the rest of the tag array was never written)
     const R *g = reinterpret_cast<const R *>(recs);
     const R *tk = reinterpret_cast<const R *>(tkeys);
     __shared__ uint32_t sDiff[1025];
@@ -1276,6 +1369,475 @@ __global__ void splitIdsKernel(const uint64_t *__restrict__ slotOff, uint32_t n,
     }
 }
 
+// =====================================================================================================
+// single GPU: hash grouping and rep sort over the line store (linepart.hpp)
+// =====================================================================================================
+// geometry of the k-mer side, fixed by the number of record slots (known before the extraction): partition levels, piece sizes,
+// and how many lines the two record buffers must hold
+struct LineGeo {
+    int b1 = 0, b2 = 0; uint32_t nb1 = 1, nb2 = 0, PL1 = 1, PL2 = 0;
+    uint64_t totalLines = 0, nP1 = 0, cap1 = 0, maxP2 = 0, cap2 = 0;
+    uint32_t lastValid = RPL;
+};
+static uint32_t pieceLinesFor(uint64_t lines, uint32_t nb, int numCU, uint32_t minFactor) {
+    // a piece leaves one partial line per bucket: >= minFactor * nb lines per piece bounds that waste; beyond that, enough pieces
+    // to give every CU a few
+    const uint64_t want = (lines + 4ull * (uint64_t) numCU - 1) / (4ull * (uint64_t) numCU);
+    return (uint32_t) std::max<uint64_t>((uint64_t) nb * minFactor, std::min<uint64_t>((uint64_t) nb * 64, std::max<uint64_t>(want, 1)));
+}
+static LineGeo lineGeometry(uint64_t totalSlots, bool lng, int numCU) {
+    LineGeo g;
+    const int maxBits = lng ? 9 : 10;                         // LDS: 2^bits open lines of RPL records
+    const int totalBits = std::min(2 * maxBits, std::max(0, ceilLog2((totalSlots + 1535) / 1536)));   // ~1000-1500 records per final bucket
+    g.b1 = totalBits <= maxBits ? totalBits : (totalBits + 1) / 2; g.b2 = totalBits - g.b1;
+    g.nb1 = 1u << g.b1; g.nb2 = g.b2 ? 1u << g.b2 : 0u;
+    g.totalLines = (totalSlots + RPL - 1) / RPL;
+    g.lastValid = g.totalLines ? (uint32_t) (totalSlots - (g.totalLines - 1) * RPL) : (uint32_t) RPL;
+    g.PL1 = pieceLinesFor(g.totalLines, g.nb1, numCU, 8);
+    g.nP1 = (g.totalLines + g.PL1 - 1) / g.PL1;
+    g.cap1 = std::max<uint64_t>(g.nP1 * ((uint64_t) g.PL1 + g.nb1), 1);
+    if (g.nb2) {
+        // level 2: ONE piece per level-1 bucket (its output range is the bucket's "region"; hash buckets are evenly filled)
+        g.PL2 = 0xFFFFFFFFu; g.maxP2 = g.nb1; g.cap2 = g.cap1 + (uint64_t) g.nb1 * g.nb2;
+    }
+    return g;
+}
+// lines a range partition of `nRec` records in `nSeg` dense segments can need (level 1) and a second level on top of it
+static uint64_t repLevel1Cap(uint64_t nRec, uint64_t nSeg, uint32_t PL, uint32_t nb) {
+    const uint64_t lines = (nRec + RPL - 1) / RPL + nSeg;
+    return lines + (lines / PL + nSeg + 1) * (uint64_t) nb;
+}
+
+__global__ void arenaStartKernel(const uint32_t *__restrict__ lineBeg, uint32_t bpb, uint32_t gGrid, uint32_t nBuckets, uint64_t *__restrict__ arenaStart) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < gGrid; j += gridDim.x * blockDim.x)
+        arenaStart[j] = (uint64_t) lineBeg[std::min(j * bpb, nBuckets - 1)] * RPL;
+}
+// scratch need of the aggregation kernel per bucket (buckets beyond its LDS capacity): 2 * pow2ceil(records) 8-byte words
+__global__ void bigNeedKernel(const uint32_t *__restrict__ lineCnt, uint32_t nBuckets, uint64_t *__restrict__ need) {
+    for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nBuckets; b += gridDim.x * blockDim.x) {
+        const uint64_t c = (uint64_t) lineCnt[b] * RPL;
+        uint64_t v = 0;
+        if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; v = 2 * P; }
+        need[b] = v;
+    }
+}
+__global__ void sumU32Kernel(const uint32_t *__restrict__ v, uint32_t n, unsigned long long *__restrict__ out) {
+    unsigned long long s = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) s += v[i];
+    s = waveReduceSumU64(s);
+    if (laneId() == 0 && s) atomicAdd(out, s);
+}
+
+template <class K> static int setDynLds(K k, size_t bytes) {
+    PH_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+    return PLASSHIP_OK;
+}
+// workgroup geometry of the partition kernel (measured, tools/linepart_bench.hip on 2^30 records): 1024 threads x 4 records with
+// the next tile prefetched for 1024 buckets (one workgroup per CU: 4.8 TB/s read + written at level 1), 512 x 4 with prefetch
+// when two workgroups fit a CU (<= 512 buckets: 4.9 TB/s)
+template <bool NUCL, bool LONG, int MODE, bool LIST, bool EXTRAS>
+static int launchLinePart(plasship_ctx *ctx, const LinePartArgs &a, uint64_t nPiecesBound) {
+    const size_t lds = linePartLdsBytes(a.nb, sizeof(Rec<LONG>), EXTRAS);
+    const bool big = lds > 72 * 1024;
+    const unsigned grid = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>(nPiecesBound, (uint64_t) ctx->numCU * (big ? 1u : 2u)));
+    if (big) {
+        auto k = linePartKernel<NUCL, LONG, MODE, LIST, EXTRAS, 1024, 4, true>;
+        const int rc = setDynLds(k, lds); if (rc) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(1024), lds, ctx->stream, a);
+    } else {
+        auto k = linePartKernel<NUCL, LONG, MODE, LIST, EXTRAS, 512, 4, true>;
+        const int rc = setDynLds(k, lds); if (rc) return rc;
+        hipLaunchKernelGGL(k, dim3(grid), dim3(512), lds, ctx->stream, a);
+    }
+    return PLASSHIP_OK;
+}
+
+// line lists of one partition level over `capLines` output lines: list[start[b] .. start[b + 1]) = lines of bucket b
+static int buildLineLists(plasship_ctx *ctx, const uint32_t *dTags, uint64_t capLines, uint32_t nb, uint32_t *dCount, uint32_t *dStart, uint32_t *dCursor, uint32_t *dList) {
+    hipStream_t st = ctx->stream;
+    PH_CHECK(hipMemsetAsync(dCount, 0, (size_t) nb * 4, st));
+    const unsigned g = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>((capLines + TS_CHUNK - 1) / TS_CHUNK, (uint64_t) ctx->numCU * 8));
+    hipLaunchKernelGGL(tagHistKernel, dim3(g), dim3(256), 0, st, dTags, capLines, nb, dCount);
+    hipLaunchKernelGGL(tagScanKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dCount, nb, dStart, dCursor);
+    hipLaunchKernelGGL(tagScatterKernel, dim3(g), dim3(256), 0, st, dTags, capLines, nb, dCursor, dList);
+    return PLASSHIP_OK;
+}
+
+// What the line path hands to the run reduction
+struct LinesOut { void *triples = nullptr; uint64_t nTriples = 0, Nk = 0, Nm = 0; std::vector<int64_t> stalePos; uint32_t staleT = 0; float msSort1 = 0, msGroup = 0, msSort2 = 0, msPart = 0; int nPart = 1; };
+
+// extraction has filled dA (`total` record slots, sentinels in unused slots).  Buffers dA / dB hold geo.cap2 resp. geo.cap1 lines.
+template <bool NUCL, bool LONG>
+static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, const LineGeo &geo, uint64_t total,
+                          DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res) {
+    typedef Rec<LONG> R;
+    hipStream_t st = ctx->stream;
+    const uint32_t N = (uint32_t) db->n;
+    const int numCU = ctx->numCU;
+    Timer tm{ctx, 0};
+    const int valueShift = std::max(0, keyBits - 11);         // VH_BINS = 2^11 monotone bins
+    // ---- hash partition (replaces sort #1): level 1 over the slot array, level 2 over every level-1 bucket's line list ----
+    tm.start(0);
+    DevBuf dVHist, dMinKey, dTag1, dList1, dCnt1, dStart1, dCur1, dTag2, dList2, dPieces2, dNP2, dRegBeg, dRegEnd, dTot2, dFineBeg, dFineCnt;
+    const uint32_t nBuckets = geo.nb2 ? geo.nb1 * geo.nb2 : geo.nb1;
+    if (dVHist.alloc(VH_BINS * 4) != hipSuccess || dMinKey.alloc(8) != hipSuccess || dTag1.alloc(geo.cap1 * 4) != hipSuccess || dList1.alloc(geo.cap1 * 4) != hipSuccess ||
+        dCnt1.alloc(LP_MAXB * 4) != hipSuccess || dStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dCur1.alloc(LP_MAXB * 4) != hipSuccess ||
+        dFineBeg.alloc((size_t) nBuckets * 4) != hipSuccess || dFineCnt.alloc((size_t) nBuckets * 4) != hipSuccess ||
+        (geo.nb2 && (dTag2.alloc(geo.cap2 * 4) != hipSuccess || dList2.alloc(geo.cap2 * 4) != hipSuccess || dPieces2.alloc((geo.maxP2 + 1) * sizeof(LinePiece)) != hipSuccess ||
+                     dNP2.alloc(4) != hipSuccess || dRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRegEnd.alloc(LP_MAXB * 8) != hipSuccess || dTot2.alloc(8) != hipSuccess))) {
+        setError("kmermatch: out of device memory for the line lists"); return PLASSHIP_ERR_DEVICE;
+    }
+    PH_CHECK(hipMemsetAsync(dVHist.p, 0, VH_BINS * 4, st));
+    PH_CHECK(hipMemsetAsync(dMinKey.p, 0xFF, 8, st));
+    if (geo.nP1 == 0) PH_CHECK(hipMemsetAsync(dTag1.p, 0xFF, geo.cap1 * 4, st));       // no piece will write the (one-line) tag array
+    {
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = dA.p; a.out = dB.p; a.tags = dTag1.as<uint32_t>(); a.totalLines = geo.totalLines; a.lastValidAll = geo.lastValid; a.pieceLines = geo.PL1; a.nb = geo.nb1;
+        a.key.shift = geo.b1 ? 64 - geo.b1 : 63; a.key.rangeBits = 0; a.key.repBase = 0;
+        a.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr; a.valueHist = dVHist.as<uint32_t>(); a.valueShift = valueShift;
+        PH_CHECK(hipEventRecord(ctx->ev[8], st));
+        const int rc = launchLinePart<NUCL, LONG, KEY_HASH, false, true>(ctx, a, geo.nP1); if (rc) return rc;
+        PH_CHECK(hipEventRecord(ctx->ev[9], st));
+    }
+    int rc = buildLineLists(ctx, dTag1.as<uint32_t>(), geo.cap1, geo.nb1, dCnt1.as<uint32_t>(), dStart1.as<uint32_t>(), dCur1.as<uint32_t>(), dList1.as<uint32_t>()); if (rc) return rc;
+    void *finalRecs = dB.p, *otherRecs = dA.p; const uint32_t *finalTags = dTag1.as<uint32_t>(), *finalList = dList1.as<uint32_t>(); uint64_t finalCap = geo.cap1;
+    res.nPart = 1;
+    if (geo.nb2) {
+        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, geo.PL2, geo.nb2, dPieces2.as<LinePiece>(), dNP2.as<uint32_t>(),
+                           dRegBeg.as<uint64_t>(), dRegEnd.as<uint64_t>(), dTot2.as<uint64_t>());
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = dB.p; a.list = dList1.as<uint32_t>(); a.out = dA.p; a.tags = dTag2.as<uint32_t>(); a.pieces = dPieces2.as<LinePiece>(); a.nPieces = dNP2.as<uint32_t>(); a.nb = geo.nb2;
+        a.key.shift = 64 - geo.b1 - geo.b2;
+        PH_CHECK(hipEventRecord(ctx->ev[10], st));
+        rc = launchLinePart<NUCL, LONG, KEY_HASH, true, false>(ctx, a, geo.maxP2); if (rc) return rc;
+        PH_CHECK(hipEventRecord(ctx->ev[11], st));
+        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(geo.nb1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dTag2.as<uint32_t>(), (const uint64_t *) dRegBeg.as<uint64_t>(),
+                           (const uint64_t *) dRegEnd.as<uint64_t>(), geo.nb1, geo.nb2, dList2.as<uint32_t>(), dFineBeg.as<uint32_t>(), dFineCnt.as<uint32_t>());
+        finalRecs = dA.p; otherRecs = dB.p; finalTags = dTag2.as<uint32_t>(); finalList = dList2.as<uint32_t>(); finalCap = geo.cap2;
+        res.nPart = 2;
+    } else {
+        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, dFineBeg.as<uint32_t>(), dFineCnt.as<uint32_t>());
+    }
+    res.msSort1 = tm.stop(1);
+    PH_TRACE(st, "kmermatch: hash partition (line store)");
+    PH_CHECK(hipGetLastError());
+
+    // ---- assignGroup ----
+    tm.start(0);
+    const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 6));
+    const uint32_t bpb = (nBuckets + gBlocks - 1) / gBlocks;
+    const uint32_t gGrid = (nBuckets + bpb - 1) / bpb;
+    DevBuf dOutCnt, dArenaStart, dMaxRT, dLastRun;
+    if (dOutCnt.alloc((size_t) gGrid * 8) != hipSuccess || dArenaStart.alloc((size_t) gGrid * 8) != hipSuccess || dMaxRT.alloc(8) != hipSuccess || dLastRun.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    GroupArgs ga; memset(&ga, 0, sizeof(ga));
+    ga.in = finalRecs; ga.out = otherRecs; ga.list = finalList; ga.lineBeg = dFineBeg.as<uint32_t>(); ga.lineCnt = dFineCnt.as<uint32_t>();
+    ga.nBuckets = nBuckets; ga.bucketsPerBlock = bpb; ga.outCount = dOutCnt.as<uint64_t>();
+    PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
+    ga.maxRepTarget = dMaxRT.as<unsigned long long>();
+    ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
+    hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+    hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
+    std::vector<uint64_t> hOutCnt(gGrid), hArena(gGrid);
+    unsigned long long hLastRun[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
+    hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
+    PH_CHECK(hipMemcpyAsync(hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hVHist.data(), dVHist.p, VH_BINS * 4, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(hArena.data(), dArenaStart.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(ks, dKStats.p, 32, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    uint64_t Nm = 0;
+    for (uint32_t j = 0; j < gGrid; j++) Nm += hOutCnt[j];
+    const uint64_t Nk = ks[1] + ks[3];                       // records the extraction kernels wrote (sentinels excluded)
+    res.Nk = Nk; res.Nm = Nm;
+    res.msGroup = tm.stop(1);
+    PH_TRACE(st, "kmermatch: group (line store)");
+
+    // ---- stale records behind the compaction point that continue the last run (see section 7 above) ----
+    if (Nm > 0 && Nm < Nk) {
+        const unsigned long long maxRT = hLastRun[0];
+        res.staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
+        const uint64_t so[2] = {hLastRun[1], hLastRun[2]}; const uint32_t tLen = (uint32_t) hLastRun[3];
+        const uint32_t tb = (uint32_t) (so[1] - so[0]);
+        DevBuf dTRec, dTId, dTScr, dTOff, dTCap, dDiff;
+        uint32_t cap = 64; while (cap < tLen + 1) cap <<= 1;
+        const uint64_t zero = 0;
+        if (dTRec.alloc((size_t) tb * sizeof(R)) != hipSuccess || dTId.alloc(4) != hipSuccess || dTScr.alloc((size_t) cap * sizeof(Cand)) != hipSuccess ||
+            dTOff.alloc(8) != hipSuccess || dTCap.alloc(4) != hipSuccess || dDiff.alloc(((size_t) tb + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemcpyAsync(dTId.p, &res.staleT, 4, hipMemcpyHostToDevice, st));
+        PH_CHECK(hipMemcpyAsync(dTOff.p, &zero, 8, hipMemcpyHostToDevice, st));
+        PH_CHECK(hipMemcpyAsync(dTCap.p, &cap, 4, hipMemcpyHostToDevice, st));
+        PH_CHECK(hipMemsetAsync(dDiff.p, 0, ((size_t) tb + 1) * 8, st));
+        // re-extract the records of T into a scratch array with the very kernel that produced them
+        ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
+        ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(1), dim3(64), 0, st, ta);
+        std::vector<R> trec(tb);
+        PH_CHECK(hipMemcpyAsync(trec.data(), dTRec.p, (size_t) tb * sizeof(R), hipMemcpyDeviceToHost, st));
+        PH_CHECK(hipStreamSynchronize(st));
+        trec.erase(std::remove_if(trec.begin(), trec.end(), [](const R &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }), trec.end());
+        std::sort(trec.begin(), trec.end(), [](const R &x, const R &y) { return recLess1<NUCL, LONG>(x, y); });
+        const uint32_t m = (uint32_t) trec.size();
+        // cheap exact filter first: the value histogram bounds the sort-#1 rank of every record of T; the scan can only reach
+        // a record of T if rank N_m itself can be one of them
+        bool mayHit = false;
+        if (m) {
+            std::vector<uint64_t> cum(VH_BINS + 1, 0);
+            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + hVHist[b];
+            for (uint32_t j = 0; j < m && !mayHit; j++) { const uint32_t b = valueBin<NUCL>(trec[j].kmer, valueShift); mayHit = Nm >= cum[b] && Nm < cum[b + 1]; }
+        }
+        if (m && mayHit) {
+            PH_CHECK(hipMemcpyAsync(dTRec.p, trec.data(), (size_t) m * sizeof(R), hipMemcpyHostToDevice, st));
+            hipLaunchKernelGGL((rankLinesKernel<NUCL, LONG>), dim3(gridFor(finalCap * RPL, 256, (unsigned) numCU * 8)), dim3(256), 0, st, (const void *) finalRecs, finalTags, finalCap, geo.nb2 ? (const uint64_t *) dTot2.as<uint64_t>() : (const uint64_t *) nullptr,
+                               (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
+            std::vector<unsigned long long> diff((size_t) m + 1);
+            PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
+            PH_CHECK(hipStreamSynchronize(st));
+            unsigned long long rank = 0, expect = Nm;
+            for (uint32_t j = 0; j < m; j++) {
+                rank += diff[j];                         // records strictly before trec[j] in sort-#1 order
+                if (rank == expect) { res.stalePos.push_back((int64_t) trec[j].pos); expect++; }
+                else if (rank > expect) break;
+            }
+        }
+        PH_TRACE(st, "kmermatch: stale-record check (line store)");
+    }
+
+    // ---- sort #2: range partition of the grouped records by rep id over the line store + aggregation / sort per bucket ----
+    tm.start(0);
+    // the hash-bucketed records are dead now: the group kernel's arenas live in `otherRecs`; free the other buffer for the rep side
+    (finalRecs == dA.p ? dA : dB).release();
+    dTag1.release(); dList1.release(); dTag2.release(); dList2.release();
+    const int maxBits = LONG ? 9 : 10;
+    const int idBits = std::max(1, ceilLog2((uint64_t) N));
+    const int repBits = idBits;
+    const int wantBits = std::min(2 * maxBits, std::max(0, ceilLog2((Nm + 511) / 512)));    // ~512 records per sort bucket
+    const int allowedLocal = 62 - idBits - DiagPack<LONG>::BITS;                             // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
+    const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
+    if (sBits > 2 * maxBits) { setError("kmermatch: too many sequences for the packed rep-sort key"); return PLASSHIP_ERR_UNSUPPORTED; }
+    const int s1 = sBits <= maxBits ? sBits : (sBits + 1) / 2, s2 = sBits - s1;
+    const uint32_t nS1 = 1u << s1, nS2 = s2 ? 1u << s2 : 0u, nSort = 1u << sBits;
+    // level-1 pieces: the arenas are dense segments; the table is built here (a few thousand entries at most)
+    uint64_t maxLinesSeg = 0, totLines = 0;
+    for (uint32_t j = 0; j < gGrid; j++) { const uint64_t l = (hOutCnt[j] + RPL - 1) / RPL; maxLinesSeg = std::max(maxLinesSeg, l); totLines += l; }
+    const uint32_t PLr1 = pieceLinesFor(totLines, nS1, numCU, 8);
+    std::vector<LinePiece> hp; uint64_t outLine = 0;
+    for (uint32_t j = 0; j < gGrid; j++) {
+        const uint64_t cnt = hOutCnt[j], lines = (cnt + RPL - 1) / RPL;
+        for (uint64_t l0 = 0; l0 < lines; l0 += PLr1) {
+            LinePiece pc; pc.in0 = hArena[j] / RPL + l0; pc.nLines = (uint32_t) std::min<uint64_t>(PLr1, lines - l0);
+            pc.lastValid = (l0 + pc.nLines == lines) ? (uint32_t) (cnt - (lines - 1) * RPL) : (uint32_t) RPL;
+            pc.out0 = outLine; pc.outCap = pc.nLines + nS1; pc.tagBase = 0;
+            outLine += pc.outCap; hp.push_back(pc);
+        }
+    }
+    const uint64_t capR1 = std::max<uint64_t>(outLine, 1), capR2 = s2 ? capR1 + (uint64_t) nS1 * nS2 : 0;
+    const uint32_t nPR1 = (uint32_t) hp.size();
+    DevBuf dR1, dRTag1, dRList1, dRPieces, dRNP, dRCnt1, dRStart1, dRCur1, dR2, dRTag2, dRList2, dRPieces2, dRNP2, dRRegBeg, dRRegEnd, dRTot2, dSortBeg, dSortCnt;
+    if (dR1.alloc(capR1 * RPL * sizeof(R)) != hipSuccess || dRTag1.alloc(capR1 * 4) != hipSuccess || dRList1.alloc(capR1 * 4) != hipSuccess || dRPieces.alloc(((size_t) nPR1 + 1) * sizeof(LinePiece)) != hipSuccess ||
+        dRNP.alloc(4) != hipSuccess || dRCnt1.alloc(LP_MAXB * 4) != hipSuccess || dRStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dRCur1.alloc(LP_MAXB * 4) != hipSuccess ||
+        dSortBeg.alloc((size_t) nSort * 4) != hipSuccess || dSortCnt.alloc((size_t) nSort * 4) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+    if (nPR1) PH_CHECK(hipMemcpyAsync(dRPieces.p, hp.data(), (size_t) nPR1 * sizeof(LinePiece), hipMemcpyHostToDevice, st));
+    else PH_CHECK(hipMemsetAsync(dRTag1.p, 0xFF, capR1 * 4, st));                       // nothing grouped: no piece will write the tag array
+    PH_CHECK(hipMemcpyAsync(dRNP.p, &nPR1, 4, hipMemcpyHostToDevice, st));
+    LineKey rkey; rkey.rangeBits = repBits; rkey.repBase = 0; rkey.shift = s1 ? 64 - s1 : 63;
+    {
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = otherRecs; a.out = dR1.p; a.tags = dRTag1.as<uint32_t>(); a.pieces = dRPieces.as<LinePiece>(); a.nPieces = dRNP.as<uint32_t>(); a.nb = nS1; a.key = rkey;
+        rc = launchLinePart<NUCL, LONG, KEY_RANGE, false, false>(ctx, a, std::max<uint32_t>(nPR1, 1)); if (rc) return rc;
+    }
+    PH_CHECK(hipStreamSynchronize(st));                     // hp goes out of use (async copy of a pageable host vector)
+    rc = buildLineLists(ctx, dRTag1.as<uint32_t>(), capR1, nS1, dRCnt1.as<uint32_t>(), dRStart1.as<uint32_t>(), dRCur1.as<uint32_t>(), dRList1.as<uint32_t>()); if (rc) return rc;
+    (otherRecs == dA.p ? dA : dB).release();               // the arenas are consumed
+    void *sortRecs = dR1.p; const uint32_t *sortList = dRList1.as<uint32_t>(); uint64_t sortCap = capR1;
+    if (s2) {
+        if (dR2.alloc(capR2 * RPL * sizeof(R)) != hipSuccess || dRTag2.alloc(capR2 * 4) != hipSuccess || dRList2.alloc(capR2 * 4) != hipSuccess || dRPieces2.alloc(((size_t) nS1 + 1) * sizeof(LinePiece)) != hipSuccess ||
+            dRNP2.alloc(4) != hipSuccess || dRRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRRegEnd.alloc(LP_MAXB * 8) != hipSuccess || dRTot2.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, 0xFFFFFFFFu, nS2, dRPieces2.as<LinePiece>(), dRNP2.as<uint32_t>(),
+                           dRRegBeg.as<uint64_t>(), dRRegEnd.as<uint64_t>(), dRTot2.as<uint64_t>());
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = dR1.p; a.list = dRList1.as<uint32_t>(); a.out = dR2.p; a.tags = dRTag2.as<uint32_t>(); a.pieces = dRPieces2.as<LinePiece>(); a.nPieces = dRNP2.as<uint32_t>(); a.nb = nS2;
+        a.key = rkey; a.key.shift = 64 - s1 - s2;
+        rc = launchLinePart<NUCL, LONG, KEY_RANGE, true, false>(ctx, a, nS1); if (rc) return rc;
+        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(nS1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dRTag2.as<uint32_t>(), (const uint64_t *) dRRegBeg.as<uint64_t>(),
+                           (const uint64_t *) dRRegEnd.as<uint64_t>(), nS1, nS2, dRList2.as<uint32_t>(), dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>());
+        sortRecs = dR2.p; sortList = dRList2.as<uint32_t>(); sortCap = capR2;
+    } else {
+        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>());
+    }
+    // aggregate + sort each bucket; buckets beyond the LDS capacity use HBM scratch
+    DevBuf dBigNeed, dBigOff, dBigScratch, dUnique, dTripleStart, dScanTmp3, dSparse;
+    const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSort + 2);
+    if (dBigNeed.alloc(((size_t) nSort + 1) * 8) != hipSuccess || dBigOff.alloc(((size_t) nSort + 2) * 8) != hipSuccess || dUnique.alloc(((size_t) nSort + 1) * 4) != hipSuccess ||
+        dTripleStart.alloc(((size_t) nSort + 2) * 8) != hipSuccess || dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess || dSparse.alloc(sortCap * RPL * sizeof(Triple)) != hipSuccess) {
+        setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE;
+    }
+    hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>());
+    if (exclusiveScanU64(st, dBigNeed.as<uint64_t>(), dBigOff.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t bigTot = 0;
+    PH_COPY_SYNC(st, &bigTot, dBigOff.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
+    PH_CHECK(hipGetLastError());
+    if (dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(std::min<uint32_t>(nSort, (uint32_t) numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
+                       (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort, dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(),
+                       dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, AggLines{sortList, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>()});
+    if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t nTriples = 0;
+    PH_COPY_SYNC(st, &nTriples, dTripleStart.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
+    PH_CHECK(hipGetLastError());
+    // compact triples: into dA (free since the group kernel's arenas were consumed)
+    dR1.release(); dR2.release();
+    if (dA.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(Triple)) != hipSuccess) { setError("kmermatch: out of device memory for the sorted triples"); return PLASSHIP_ERR_DEVICE; }
+    hipLaunchKernelGGL(compactTriplesKernel, dim3(std::min<uint32_t>((nSort + 3) / 4, (uint32_t) numCU * 8)), dim3(256), 0, st,
+                       (const Triple *) dSparse.p, (const uint64_t *) nullptr, (const uint32_t *) dSortBeg.as<uint32_t>(), (const uint64_t *) dTripleStart.as<uint64_t>(), nSort, (Triple *) dA.p);
+    res.msSort2 = tm.stop(1);
+    PH_TRACE(st, "kmermatch: rep sort (line store)");
+    PH_CHECK(hipGetLastError());
+    res.triples = dA.p; res.nTriples = nTriples;
+    { float msS = 0, msS2 = 0; (void) hipEventElapsedTime(&msS, ctx->ev[8], ctx->ev[9]); if (res.nPart == 2) (void) hipEventElapsedTime(&msS2, ctx->ev[10], ctx->ev[11]); res.msPart = msS + msS2; }
+    return PLASSHIP_OK;
+}
+
+constexpr uint64_t HALO_SLACK = 1u << 16;
+
+// ---- best diagonal per (rep, target) run over the sorted weighted triples, CSR of the candidate list (kmermatcher.cpp:809-924) ----
+// `cur`: nTriples triples in (rep, target, diagonal) order (sharded run: room for HALO_SLACK more behind them)
+template <bool NUCL, bool LONG>
+static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void *cur, uint64_t nTriples, const std::vector<int64_t> &stalePos, uint32_t staleT,
+                              std::unique_ptr<plasship_cands> &holder, uint64_t &Nc, float &msReduce) {
+    hipStream_t st = ctx->stream;
+    const uint32_t N = (uint32_t) db->n;
+    Timer tm{ctx, 0};
+    const plasship_comm *cm = commOf(ctx);
+    const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
+    const uint64_t repBase = ownedBegin(N, rk, W), ownedN = ownedBegin(N, rk + 1, W) - repBase;
+    // ---- per-(rep,target) reduction + CSR ----
+    tm.start(0);
+    DevBuf dTmpHits, dEmit, dEpos, dPerRep, dQoff;
+    if (dTmpHits.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc(std::max<uint64_t>(nTriples, 1) * 4) != hipSuccess ||
+        dEpos.alloc((nTriples + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    DevBuf dScanTmp2; const size_t scanTmp2Bytes = exclusiveScanTmpBytes(std::max<uint64_t>(nTriples, N) + 2);
+    if (dScanTmp2.alloc(scanTmp2Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t nHalo = 0;
+    if (cm) {
+        // The reference's run scan tests only the target id (Appendix A.3): the last run of this rank continues into the
+        // triples of the next ranks while they carry the same target, and behind the last rank into the stale records.
+        // Every rank publishes the head of its triples (the leading ones with one target); each rank appends what its last
+        // run can reach behind its own triples.
+        Triple *dTr = reinterpret_cast<Triple *>(cur);
+        std::vector<Triple> head; uint64_t headCnt = 0;
+        if (nTriples) {
+            uint64_t want = std::min<uint64_t>(nTriples, 1024);
+            for (;;) {
+                head.resize(want);
+                PH_COPY_SYNC(st, head.data(), dTr, want * sizeof(Triple), hipMemcpyDeviceToHost);
+                headCnt = 0; while (headCnt < want && head[headCnt].target == head[0].target) headCnt++;
+                if (headCnt < want || want == nTriples) break;
+                want = std::min<uint64_t>(nTriples, want * 2);
+            }
+            head.resize(headCnt);
+        }
+        Triple last; memset(&last, 0, sizeof(last));
+        if (nTriples) PH_COPY_SYNC(st, &last, dTr + (nTriples - 1), sizeof(Triple), hipMemcpyDeviceToHost);
+        uint64_t hdr[2] = {nTriples, headCnt}; std::vector<uint64_t> hdrs(2 * (size_t) W);
+        int rc = commAllgatherHost(ctx, hdr, hdrs.data(), 16); if (rc) return rc;
+        uint64_t maxHead = 0; for (int r = 0; r < W; r++) maxHead = std::max(maxHead, hdrs[2 * (size_t) r + 1]);
+        std::vector<Triple> heads;
+        if (maxHead) {
+            std::vector<Triple> mine(maxHead); memset(mine.data(), 0, maxHead * sizeof(Triple));
+            std::copy(head.begin(), head.end(), mine.begin());
+            heads.resize(maxHead * (size_t) W);
+            rc = commAllgatherHost(ctx, mine.data(), heads.data(), maxHead * sizeof(Triple)); if (rc) return rc;
+        }
+        if (nTriples) {
+            std::vector<Triple> halo; bool open = true;          // open: the scan has not met another target yet
+            for (int r = rk + 1; r < W && open; r++) {
+                const uint64_t nr = hdrs[2 * (size_t) r], hr = hdrs[2 * (size_t) r + 1];
+                if (nr == 0) continue;
+                const Triple *hp = heads.data() + maxHead * (size_t) r;
+                if (hp[0].target != last.target) { open = false; break; }
+                halo.insert(halo.end(), hp, hp + hr);
+                if (hr < nr) open = false;
+            }
+            if (open && !stalePos.empty() && staleT == last.target) {
+                for (int64_t sp : stalePos) {      // stale records: pos = original k-mer position, kmer field = SIZE_T_MAX (forward)
+                    Triple t; t.rep = 0xFFFFFFFFu; t.target = staleT; t.diag = LONG ? (int32_t) sp : (int32_t) (int16_t) sp; t.cnt = 1u | 0x80000000u;
+                    halo.push_back(t);
+                }
+            }
+            nHalo = halo.size();
+            if (nHalo > HALO_SLACK) { setError("kmermatch: a (rep, target) run continues over more than 65536 records of other ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
+            if (nHalo) PH_COPY_SYNC(st, dTr + nTriples, halo.data(), nHalo * sizeof(Triple), hipMemcpyHostToDevice);
+        }
+        PH_CHECK(hipMemsetAsync(dPerRep.p, 0, ((size_t) N + 1) * 4, st));
+        if (ownedN) hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor(ownedN, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>() + repBase, 1u, ownedN);
+    } else
+    hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor((uint64_t) N + 1, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>(), 1u, (uint64_t) N);
+    if (nTriples) hipLaunchKernelGGL((reduceRunsKernel<NUCL>), dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, (const Triple *) cur, nTriples, nTriples + nHalo, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
+    if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    holder.reset(new plasship_cands());                              // released to the caller on success only
+    plasship_cands *c = holder.get();
+    c->reverseCapable = NUCL; c->nQueries = N;
+    if (c->d_qoff.alloc(((size_t) N + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    Nc = 0;
+    PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nTriples, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipStreamSynchronize(st));
+    const uint32_t qLo = cm ? (uint32_t) repBase : 0u, qHi = cm ? (uint32_t) (repBase + ownedN) : N;      // queries with a self line
+    c->nHits = Nc + (qHi - qLo); c->nNonSelf = Nc;
+    if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (qHi > qLo) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(qHi - qLo, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), qLo, qHi, c->d_hits.as<CandHit>());
+    if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
+    msReduce = tm.stop(1);
+    PH_TRACE(st, "kmermatch: reduce");
+    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(hipGetLastError());
+    if (!stalePos.empty() && nTriples > 0 && !cm) {
+        // the runs that end at the very end of the sorted array (the last (rep,T) run, and the T-runs of directly preceding
+        // reps whose scan the reference lets run across the rep boundary) continue into the stale records: redo them
+        const Triple *dTr = reinterpret_cast<const Triple *>(cur);
+        std::vector<Triple> tail; uint64_t want = std::min<uint64_t>(nTriples, 4096);
+        for (;;) {
+            tail.resize(want);
+            PH_COPY_SYNC(st, tail.data(), dTr + (nTriples - want), want * sizeof(Triple), hipMemcpyDeviceToHost);
+            if (tail.front().target != staleT || want == nTriples) break;
+            want = std::min<uint64_t>(nTriples, want * 2);
+        }
+        if (tail.back().target == staleT) {
+            size_t b0 = tail.size(); while (b0 > 0 && tail[b0 - 1].target == staleT) b0--;
+            for (size_t h0 = b0; h0 < tail.size(); h0++) {
+                if (!(h0 == b0 || tail[h0].rep != tail[h0 - 1].rep)) continue;       // not a run head
+                int32_t diagonal = tail[h0].diag, prevDiagonal = tail[h0].diag;
+                uint64_t maxDiagonal = 0, diagonalCnt = 0, topScore = 0;
+                int bestRev = NUCL ? ((tail[h0].cnt & 0x80000000u) == 0) : 0;
+                for (size_t j = h0; j < tail.size(); j++) {
+                    const uint64_t cc = tail[j].cnt & 0x7FFFFFFFu;
+                    if (prevDiagonal == tail[j].diag) diagonalCnt += cc; else diagonalCnt = cc;
+                    if (diagonalCnt >= maxDiagonal) { diagonal = tail[j].diag; maxDiagonal = diagonalCnt; if (NUCL) bestRev = ((tail[j].cnt & 0x80000000u) == 0); }
+                    prevDiagonal = tail[j].diag; topScore += cc;
+                }
+                for (int64_t sp : stalePos) {          // stale records: pos = original k-mer position, kmer field = SIZE_T_MAX (forward)
+                    const int32_t d = LONG ? (int32_t) sp : (int32_t) (int16_t) sp;
+                    if (prevDiagonal == d) diagonalCnt++; else diagonalCnt = 1;
+                    if (diagonalCnt >= maxDiagonal) { diagonal = d; maxDiagonal = diagonalCnt; if (NUCL) bestRev = 0; }
+                    prevDiagonal = d; topScore++;
+                }
+                const uint32_t rep = tail[h0].rep;
+                if (rep == staleT) continue;                                       // self run: scanned but never emitted
+                uint64_t qn = 0;
+                PH_COPY_SYNC(st, &qn, c->d_qoff.as<uint64_t>() + rep + 1, 8, hipMemcpyDeviceToHost);
+                CandHit hh;
+                PH_COPY_SYNC(st, &hh, c->d_hits.as<CandHit>() + (qn - 1), sizeof(CandHit), hipMemcpyDeviceToHost);
+                if (hh.target != staleT || hh.query != rep) { setError("kmermatch: internal error while patching the last run"); return PLASSHIP_ERR_DEVICE; }
+                hh.prefScore = bestRev ? -(int) topScore : (int) topScore; hh.diag16 = (uint32_t) (uint16_t) diagonal;
+                PH_COPY_SYNC(st, c->d_hits.as<CandHit>() + (qn - 1), &hh, sizeof(CandHit), hipMemcpyHostToDevice);
+            }
+        }
+    }
+    return PLASSHIP_OK;
+}
+
 template <bool NUCL, bool LONG>
 int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
                   plasship_kmermatch_stats *stats) {
@@ -1318,8 +1880,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
 
     DevBuf dA, dB;   // ping-pong record arrays
     DevBuf dRxA, dRxB, dRxC, dRxD;   // sharded run: what the two exchanges deliver (and their ping-pong partners)
-    if (dA.alloc(std::max<uint64_t>(total, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(total, 1) * sizeof(R)) != hipSuccess) {
-        setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE;
+    // single GPU: the line-store partition (linepart.hpp; PLASSHIP_LEGACY_PARTITION=1 keeps the dense two-pass partition the
+    // sharded run uses).  Its record buffers hold whole lines plus one partial line per bucket and piece.
+    static const bool legacyPartition = getenv("PLASSHIP_LEGACY_PARTITION") != nullptr;
+    const bool useLines = !cm && !legacyPartition;
+    const LineGeo geo = useLines ? lineGeometry(total, LONG, ctx->numCU) : LineGeo();
+    const uint64_t recCap = useLines ? std::max<uint64_t>(total, (uint64_t) RPL * std::max(geo.cap1, geo.cap2)) : std::max<uint64_t>(total, 1);
+    if (dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess) {
+        setError("kmermatch: out of device memory for the k-mer record arrays (" + std::to_string(2 * recCap * sizeof(R)) + " bytes)"); return PLASSHIP_ERR_DEVICE;
     }
 
     // ---- extraction ----
@@ -1339,7 +1907,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // nucleotide sequence up to ~690 nt (59 + 0.1 L); the 1024-candidate instantiation (35 KB of LDS, one wavefront per SIMD)
     // only sees the longer nucleotide contigs, queued by the first launch; what does not fit there either goes to the
     // HBM-scratch launch.
-    constexpr int CAP = 128, CAP2 = NUCL ? 1024 : 0;
+    constexpr int CAP = 128, CAP2 = NUCL ? 1024 : 128;
     DevBuf dWaveList, dWaveCount, dKStats;
     if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess || dKStats.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dWaveCount.p, 0, 4, st));
@@ -1360,14 +1928,16 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
     static const int waveBlocksPerCU = [] { const char *e = getenv("PLASSHIP_EXTRACT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();     // 32 one-wavefront workgroups per CU: measured best of 12..64 on the 1 M-read set
-    if (nMine) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU)), dim3(64), 0, st, ea);
+    // regular launch: register front end for sequences of up to 1024 windows; longer ones (and candidate sets beyond CAP) are
+    // queued for the next launch, which keeps codes and scores of up to 8160 residues resident in LDS
+    if (nMine) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU)), dim3(64), 0, st, ea);
     DevBuf dOv2Ids, dOv2Cnt;
     if (CAP2 && nMine) {
         if (dOv2Ids.alloc(((size_t) N + 1) * 4) != hipSuccess || dOv2Cnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         PH_CHECK(hipMemsetAsync(dOv2Cnt.p, 0, 4, st));
         ExtractArgs e2 = ea; e2.waveList = dOvIds.as<uint32_t>(); e2.waveCount = dOvCnt.as<uint32_t>();
         e2.overflowIds = dOv2Ids.as<uint32_t>(); e2.overflowCount = dOv2Cnt.as<uint32_t>();
-        hipLaunchKernelGGL((extractKernel<NUCL, LONG, (CAP2 ? CAP2 : 128), false>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * 4)), dim3(64), 0, st, e2);
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 2u : 5u))), dim3(64), 0, st, e2);
         std::swap(dOvIds.p, dOv2Ids.p); std::swap(dOvCnt.p, dOv2Cnt.p);       // the HBM-scratch launch below takes what is left
     }
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
@@ -1398,6 +1968,29 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_TRACE(st, "kmermatch: extraction");
     traceBadIds<LONG>(ctx, "kmermatch: extracted slots", dA.p, total, N);
 
+    if (useLines) {
+        int keyBitsL = 0;
+        if (NUCL) keyBitsL = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBitsL < 63 && (long double) (1ULL << keyBitsL) < v) keyBitsL++; }
+        LinesOut lo;
+        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo);
+        if (rcL) return rcL;
+        std::unique_ptr<plasship_cands> holderL; uint64_t NcL = 0; float msReduceL = 0;
+        rcL = reduceToCandidates<NUCL, LONG>(ctx, db, lo.triples, lo.nTriples, lo.stalePos, lo.staleT, holderL, NcL, msReduceL);
+        if (rcL) return rcL;
+        if (stats) {
+            stats->n_kmer_records = lo.Nk; stats->n_grouped = lo.Nm; stats->n_candidates = NcL; stats->record_bytes = LONG ? 20 : 16;
+            float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
+            stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;
+            stats->ms_part_scatter = lo.msPart; stats->n_part_scatter = lo.nPart;
+            unsigned long long ks[4] = {0, 0, 0, 0};
+            PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost);
+            stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
+            stats->residues = db->residues;
+            stats->ms_extract = msExtract; stats->ms_sort1 = lo.msSort1; stats->ms_group = lo.msGroup; stats->ms_sort2 = lo.msSort2; stats->ms_reduce = msReduceL;
+        }
+        *out = holderL.release();
+        return PLASSHIP_OK;
+    }
     // ---- hash partition (replaces sort #1) ----
     tm.start(0);
     // value histogram for the stale-record check: bins of the k-mer value (real k-mers need keyBits bits)
@@ -1664,7 +2257,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     tm.start(0);
     const uint64_t *segStartP = dArenaStart.as<uint64_t>(), *segCountP = dOutCnt.as<uint64_t>();   // where the grouped records are
     uint32_t nSeg = gGrid; uint64_t maxSeg1 = maxArena, NmHere = NmLocal;
-    const uint64_t haloSlack = 1u << 16;       // room behind the triples for what the last run's scan reaches on later ranks
+    const uint64_t haloSlack = HALO_SLACK;     // room behind the triples for what the last run's scan reaches on later ranks
     if (traceOn()) fprintf(stderr, "[plasship] kmermatch: N=%u Nk=%llu NmLocal=%llu gGrid=%u maxArena=%llu stale=%zu\n", N, (unsigned long long) Nk, (unsigned long long) NmLocal, gGrid, (unsigned long long) maxArena, stalePos.size());
     PH_TRACE(st, "kmermatch: stale-record check");
     if (cm) {
@@ -1785,129 +2378,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_TRACE(st, "kmermatch: rep sort");
     PH_CHECK(hipGetLastError());
 
-    // ---- per-(rep,target) reduction + CSR ----
-    tm.start(0);
-    DevBuf dTmpHits, dEmit, dEpos, dPerRep, dQoff;
-    if (dTmpHits.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc(std::max<uint64_t>(nTriples, 1) * 4) != hipSuccess ||
-        dEpos.alloc((nTriples + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    DevBuf dScanTmp2; const size_t scanTmp2Bytes = exclusiveScanTmpBytes(std::max<uint64_t>(nTriples, N) + 2);
-    if (dScanTmp2.alloc(scanTmp2Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t nHalo = 0;
-    if (cm) {
-        // The reference's run scan tests only the target id (Appendix A.3): the last run of this rank continues into the
-        // triples of the next ranks while they carry the same target, and behind the last rank into the stale records.
-        // Every rank publishes the head of its triples (the leading ones with one target); each rank appends what its last
-        // run can reach behind its own triples.
-        Triple *dTr = reinterpret_cast<Triple *>(cur);
-        std::vector<Triple> head; uint64_t headCnt = 0;
-        if (nTriples) {
-            uint64_t want = std::min<uint64_t>(nTriples, 1024);
-            for (;;) {
-                head.resize(want);
-                PH_COPY_SYNC(st, head.data(), dTr, want * sizeof(Triple), hipMemcpyDeviceToHost);
-                headCnt = 0; while (headCnt < want && head[headCnt].target == head[0].target) headCnt++;
-                if (headCnt < want || want == nTriples) break;
-                want = std::min<uint64_t>(nTriples, want * 2);
-            }
-            head.resize(headCnt);
-        }
-        Triple last; memset(&last, 0, sizeof(last));
-        if (nTriples) PH_COPY_SYNC(st, &last, dTr + (nTriples - 1), sizeof(Triple), hipMemcpyDeviceToHost);
-        uint64_t hdr[2] = {nTriples, headCnt}; std::vector<uint64_t> hdrs(2 * (size_t) W);
-        int rc = commAllgatherHost(ctx, hdr, hdrs.data(), 16); if (rc) return rc;
-        uint64_t maxHead = 0; for (int r = 0; r < W; r++) maxHead = std::max(maxHead, hdrs[2 * (size_t) r + 1]);
-        std::vector<Triple> heads;
-        if (maxHead) {
-            std::vector<Triple> mine(maxHead); memset(mine.data(), 0, maxHead * sizeof(Triple));
-            std::copy(head.begin(), head.end(), mine.begin());
-            heads.resize(maxHead * (size_t) W);
-            rc = commAllgatherHost(ctx, mine.data(), heads.data(), maxHead * sizeof(Triple)); if (rc) return rc;
-        }
-        if (nTriples) {
-            std::vector<Triple> halo; bool open = true;          // open: the scan has not met another target yet
-            for (int r = rk + 1; r < W && open; r++) {
-                const uint64_t nr = hdrs[2 * (size_t) r], hr = hdrs[2 * (size_t) r + 1];
-                if (nr == 0) continue;
-                const Triple *hp = heads.data() + maxHead * (size_t) r;
-                if (hp[0].target != last.target) { open = false; break; }
-                halo.insert(halo.end(), hp, hp + hr);
-                if (hr < nr) open = false;
-            }
-            if (open && !stalePos.empty() && staleT == last.target) {
-                for (int64_t sp : stalePos) {      // stale records: pos = original k-mer position, kmer field = SIZE_T_MAX (forward)
-                    Triple t; t.rep = 0xFFFFFFFFu; t.target = staleT; t.diag = LONG ? (int32_t) sp : (int32_t) (int16_t) sp; t.cnt = 1u | 0x80000000u;
-                    halo.push_back(t);
-                }
-            }
-            nHalo = halo.size();
-            if (nHalo > haloSlack) { setError("kmermatch: a (rep, target) run continues over more than 65536 records of other ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
-            if (nHalo) PH_COPY_SYNC(st, dTr + nTriples, halo.data(), nHalo * sizeof(Triple), hipMemcpyHostToDevice);
-        }
-        PH_CHECK(hipMemsetAsync(dPerRep.p, 0, ((size_t) N + 1) * 4, st));
-        if (ownedN) hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor(ownedN, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>() + repBase, 1u, ownedN);
-    } else
-    hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor((uint64_t) N + 1, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>(), 1u, (uint64_t) N);
-    if (nTriples) hipLaunchKernelGGL((reduceRunsKernel<NUCL>), dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, (const Triple *) cur, nTriples, nTriples + nHalo, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
-    if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    std::unique_ptr<plasship_cands> holder(new plasship_cands());   // released to the caller on success only
-    plasship_cands *c = holder.get();
-    c->reverseCapable = NUCL; c->nQueries = N;
-    if (c->d_qoff.alloc(((size_t) N + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t Nc = 0;
-    PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nTriples, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
-    const uint32_t qLo = cm ? (uint32_t) repBase : 0u, qHi = cm ? (uint32_t) (repBase + ownedN) : N;      // queries with a self line
-    c->nHits = Nc + (qHi - qLo); c->nNonSelf = Nc;
-    if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (qHi > qLo) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(qHi - qLo, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), qLo, qHi, c->d_hits.as<CandHit>());
-    if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
-    msReduce = tm.stop(1);
-    PH_TRACE(st, "kmermatch: reduce");
-    PH_CHECK(hipStreamSynchronize(st));
-    PH_CHECK(hipGetLastError());
-    if (!stalePos.empty() && nTriples > 0 && !cm) {
-        // the runs that end at the very end of the sorted array (the last (rep,T) run, and the T-runs of directly preceding
-        // reps whose scan the reference lets run across the rep boundary) continue into the stale records: redo them
-        const Triple *dTr = reinterpret_cast<const Triple *>(cur);
-        std::vector<Triple> tail; uint64_t want = std::min<uint64_t>(nTriples, 4096);
-        for (;;) {
-            tail.resize(want);
-            PH_COPY_SYNC(st, tail.data(), dTr + (nTriples - want), want * sizeof(Triple), hipMemcpyDeviceToHost);
-            if (tail.front().target != staleT || want == nTriples) break;
-            want = std::min<uint64_t>(nTriples, want * 2);
-        }
-        if (tail.back().target == staleT) {
-            size_t b0 = tail.size(); while (b0 > 0 && tail[b0 - 1].target == staleT) b0--;
-            for (size_t h0 = b0; h0 < tail.size(); h0++) {
-                if (!(h0 == b0 || tail[h0].rep != tail[h0 - 1].rep)) continue;       // not a run head
-                int32_t diagonal = tail[h0].diag, prevDiagonal = tail[h0].diag;
-                uint64_t maxDiagonal = 0, diagonalCnt = 0, topScore = 0;
-                int bestRev = NUCL ? ((tail[h0].cnt & 0x80000000u) == 0) : 0;
-                for (size_t j = h0; j < tail.size(); j++) {
-                    const uint64_t cc = tail[j].cnt & 0x7FFFFFFFu;
-                    if (prevDiagonal == tail[j].diag) diagonalCnt += cc; else diagonalCnt = cc;
-                    if (diagonalCnt >= maxDiagonal) { diagonal = tail[j].diag; maxDiagonal = diagonalCnt; if (NUCL) bestRev = ((tail[j].cnt & 0x80000000u) == 0); }
-                    prevDiagonal = tail[j].diag; topScore += cc;
-                }
-                for (int64_t sp : stalePos) {          // stale records: pos = original k-mer position, kmer field = SIZE_T_MAX (forward)
-                    const int32_t d = LONG ? (int32_t) sp : (int32_t) (int16_t) sp;
-                    if (prevDiagonal == d) diagonalCnt++; else diagonalCnt = 1;
-                    if (diagonalCnt >= maxDiagonal) { diagonal = d; maxDiagonal = diagonalCnt; if (NUCL) bestRev = 0; }
-                    prevDiagonal = d; topScore++;
-                }
-                const uint32_t rep = tail[h0].rep;
-                if (rep == staleT) continue;                                       // self run: scanned but never emitted
-                uint64_t qn = 0;
-                PH_COPY_SYNC(st, &qn, c->d_qoff.as<uint64_t>() + rep + 1, 8, hipMemcpyDeviceToHost);
-                CandHit hh;
-                PH_COPY_SYNC(st, &hh, c->d_hits.as<CandHit>() + (qn - 1), sizeof(CandHit), hipMemcpyDeviceToHost);
-                if (hh.target != staleT || hh.query != rep) { setError("kmermatch: internal error while patching the last run"); return PLASSHIP_ERR_DEVICE; }
-                hh.prefScore = bestRev ? -(int) topScore : (int) topScore; hh.diag16 = (uint32_t) (uint16_t) diagonal;
-                PH_COPY_SYNC(st, c->d_hits.as<CandHit>() + (qn - 1), &hh, sizeof(CandHit), hipMemcpyHostToDevice);
-            }
-        }
-    }
+    std::unique_ptr<plasship_cands> holder; uint64_t Nc = 0;
+    { const int rcR = reduceToCandidates<NUCL, LONG>(ctx, db, cur, nTriples, stalePos, staleT, holder, Nc, msReduce); if (rcR) return rcR; }
     if (stats) {
         // sharded run: what THIS rank's kernels processed (records of its buckets, grouped records of its reps, candidates of its queries)
         stats->n_kmer_records = Nk; stats->n_grouped = NmHere; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;

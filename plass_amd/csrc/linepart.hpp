@@ -323,7 +323,7 @@ __global__ __launch_bounds__(1024) void planListKernel(const uint32_t *__restric
     const uint32_t g = threadIdx.x;                                   // nb1 <= 1024: one level-1 bucket per thread
     const uint32_t s0 = g < nb1 ? start[g] : 0u;
     const uint32_t c = g < nb1 ? start[g + 1] - s0 : 0u;
-    const uint32_t np = (c + pieceLines - 1) / pieceLines;
+    const uint32_t np = (uint32_t) (((uint64_t) c + pieceLines - 1) / pieceLines);      // pieceLines = 0xFFFFFFFF: one piece per bucket
     uint32_t p0, pt; uint64_t o0, ot;
     blockScan1024(np, (uint64_t) c + (uint64_t) np * nb2, p0, o0, pt, ot, sA, sB);
     if (g == 0) { *nPieces = pt; *totalOut = ot; }
@@ -332,7 +332,7 @@ __global__ __launch_bounds__(1024) void planListKernel(const uint32_t *__restric
         for (uint32_t p = 0; p < np; p++) {
             LinePiece pc;
             pc.in0 = (uint64_t) s0 + (uint64_t) p * pieceLines;
-            pc.nLines = min(pieceLines, c - p * pieceLines);
+            pc.nLines = (uint32_t) min((uint64_t) pieceLines, (uint64_t) c - (uint64_t) p * pieceLines);
             pc.lastValid = RPL;
             pc.out0 = o0 + (uint64_t) p * ((uint64_t) pieceLines + nb2);
             pc.outCap = pc.nLines + nb2;
