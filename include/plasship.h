@@ -79,6 +79,10 @@ typedef struct plasship_comm {
     int (*alltoallv_dev)(void *user, const void *d_send, const uint64_t *send_bytes, void *d_recv, const uint64_t *recv_bytes);
     /* device buffers; every rank contributes send_bytes (its own entry of recv_bytes[world]); recv laid out by rank */
     int (*allgatherv_dev)(void *user, const void *d_send, uint64_t send_bytes, void *d_recv, const uint64_t *recv_bytes);
+    /* != 0: the device collectives enqueue their work on the CONTEXT'S stream (plasship_ctx_stream) and may return before it
+     * has run: the library then neither drains its stream before calling them nor assumes completion afterwards — everything is
+     * ordered by the stream (the native RCCL communicator, include/plasship_rccl.h).  0: as described above. */
+    int stream_ordered;
 } plasship_comm;
 /* comm == NULL returns the context to single-GPU operation.  The struct is copied. */
 int plasship_ctx_set_comm(plasship_ctx *ctx, const plasship_comm *comm);

@@ -62,7 +62,7 @@ int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *s
     std::vector<uint64_t> sendBytes(W), recvBytes(W); uint64_t tot = 0;
     for (int r = 0; r < W; r++) { sendBytes[r] = sendCount[r] * recordBytes; const uint64_t c = all[(size_t) r * W + cm->rank]; recvBytes[r] = c * recordBytes; tot += c; }
     if (recv.alloc(std::max<uint64_t>(tot + slackRecords, 1) * recordBytes) != hipSuccess) { setError("sharded run: out of device memory for the receive buffer"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!cm->stream_ordered) PH_CHECK(hipStreamSynchronize(ctx->stream));
     if (cm->alltoallv_dev(cm->user, dSend, sendBytes.data(), recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's alltoallv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     *recvTotal = tot;
     if (allTotal) { uint64_t a = 0; for (uint64_t c : all) a += c; *allTotal = a; }
@@ -85,7 +85,7 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
     if ((int) recvBytes.size() != W || recvBytes[cm->rank] != sendBytes) { setError("sharded run: inconsistent all-gather sizes"); return PLASSHIP_ERR_ARG; }
     uint64_t tot = 0; for (int r = 0; r < W; r++) tot += recvBytes[r];
     if (recv.alloc(tot + 64) != hipSuccess) { setError("sharded run: out of device memory for the gather buffer"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!cm->stream_ordered) PH_CHECK(hipStreamSynchronize(ctx->stream));
     if (cm->allgatherv_dev(cm->user, dSend, sendBytes, recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's allgatherv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     return PLASSHIP_OK;
 }

@@ -15,24 +15,56 @@
 #include <unordered_map>
 
 namespace plasship {
-// ---- caching allocator (see common.hpp) -----------------------------------------------------------
+// ---- device memory arena (see common.hpp) ---------------------------------------------------------------
+// hipMalloc / hipFree synchronise the device and cost ~27 ms per GB on this stack; an assembly iteration on 50 M reads asks for
+// ~40 buffers between a few bytes and 85 GB whose sizes change from iteration to iteration.  Memory therefore comes from SLABS
+// obtained from HIP once and never returned while in use: a request takes the best-fitting free range of any slab and splits
+// it, a release merges the range with its free neighbours.  (Round 1 cached whole blocks by size class: a 10 GB request could
+// occupy a cached 77 GB block, the next 77 GB request went to hipMalloc, and at 50 M reads the job spent two minutes in
+// hipMalloc / hipFree and finally ran out of HBM with most of it idle.)
+// Slabs: small jobs grow in slabs of >= 1 GB; once a process has taken 8 GB (or asks for >= 4 GB at once) the next slab takes
+// 90 % of what the device still has free, so a large job pays one hipMalloc.  A free range remembers the stream whose queued
+// work may still touch it: ranges never cross devices, and a range last used on another stream (several contexts on one GPU:
+// the in-process rank groups of the tests) is handed out only after that stream has drained.
 namespace {
 std::mutex g_poolMu;
-// A cached block remembers the device it lives on and the stream whose work may still be using it: blocks never cross devices,
-// and a block last used on another stream is handed out only after that stream has drained (several contexts on one GPU — the
-// in-process rank groups of the tests — share the pool; within one stream reuse is ordered by the stream itself).
-struct PoolBlock { void *p; hipStream_t stream; };
-std::map<int, std::multimap<size_t, PoolBlock>> g_poolFree;   // device -> size class -> cached block
-struct PoolLive { size_t cls; int device; };
-std::unordered_map<void *, PoolLive> g_poolLive;     // block -> size class, device
+constexpr size_t POOL_ALIGN = 256;
+struct FreeRange { size_t size; hipStream_t stream; bool mixed; };
+struct Slab { char *base; size_t size; size_t used; std::map<size_t, FreeRange> free; };       // free: offset -> range
+struct DevicePool { std::vector<Slab> slabs; size_t total = 0; };
+std::map<int, DevicePool> g_pools;
+struct PoolLive { int device; int slab; size_t off, size; };
+std::unordered_map<void *, PoolLive> g_poolLive;
 thread_local hipStream_t tl_poolStream = nullptr;    // stream of the API call this thread is in (poolEnter)
 int g_ctxCount = 0;
 size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
-size_t sizeClass(size_t n) {
-    if (n < 4096) return 4096;
-    int e = 63 - __builtin_clzll((unsigned long long) n);      // 2^e <= n
-    const size_t step = (size_t) 1 << (e - 3);                 // eight classes per octave
-    return (n + step - 1) / step * step;
+
+// best fit over all free ranges of the device (a few hundred at most)
+bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor, bool *waitAll) {
+    int bs = -1; size_t bo = 0, bsz = ~(size_t) 0;
+    for (size_t i = 0; i < dp.slabs.size(); i++)
+        for (auto &kv : dp.slabs[i].free) if (kv.second.size >= n && kv.second.size < bsz) { bs = (int) i; bo = kv.first; bsz = kv.second.size; }
+    if (bs < 0) return false;
+    Slab &sl = dp.slabs[bs];
+    const FreeRange fr = sl.free[bo];
+    sl.free.erase(bo);
+    if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
+    sl.used += n;
+    *p = sl.base + bo;
+    g_poolLive[*p] = PoolLive{dev, bs, bo, n};
+    *waitAll = fr.mixed; *waitFor = (!fr.mixed && fr.stream != tl_poolStream) ? fr.stream : nullptr;
+    return true;
+}
+void trimLocked(int onlyDevice) {      // give completely free slabs back to HIP
+    int cur = 0; (void) hipGetDevice(&cur);
+    for (auto &dv : g_pools) {
+        if (onlyDevice >= 0 && dv.first != onlyDevice) continue;
+        bool any = false; for (auto &sl : dv.second.slabs) any |= (sl.used == 0 && sl.base != nullptr);
+        if (!any) continue;
+        (void) hipSetDevice(dv.first); (void) hipDeviceSynchronize();          // queued work may still reference released ranges
+        for (auto &sl : dv.second.slabs) if (sl.used == 0 && sl.base) { (void) hipFree(sl.base); dv.second.total -= sl.size; sl.base = nullptr; sl.size = 0; sl.free.clear(); }
+    }
+    (void) hipSetDevice(cur);
 }
 }  // namespace
 // debugging aid: PLASSHIP_POOL_POISON=<0..255> fills every block handed out with that byte, so that a kernel reading
@@ -45,62 +77,85 @@ hipError_t poolMalloc(void **p, size_t n) {
     return e;
 }
 void poolEnter(hipStream_t stream) { tl_poolStream = stream; }
-// a context goes away (its stream has been drained): its cached blocks no longer wait for anybody
+// a context goes away (its stream has been drained): its released ranges no longer wait for anybody
 static void poolForgetStream(hipStream_t stream) {
     std::lock_guard<std::mutex> g(g_poolMu);
-    for (auto &dv : g_poolFree) for (auto &kv : dv.second) if (kv.second.stream == stream) kv.second.stream = nullptr;
+    for (auto &dv : g_pools) for (auto &sl : dv.second.slabs) for (auto &kv : sl.free) if (!kv.second.mixed && kv.second.stream == stream) kv.second.stream = nullptr;
     if (tl_poolStream == stream) tl_poolStream = nullptr;
 }
+static double poolFraction() { static const double v = [] { const char *e = getenv("PLASSHIP_POOL_FRACTION"); const double x = e ? atof(e) : 0.0; return (x > 0.05 && x <= 0.98) ? x : 0.88; }(); return v; }
 static hipError_t poolMallocRaw(void **p, size_t n) {
-    const size_t c = sizeClass(n);
+    n = std::max<size_t>((n + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN, POOL_ALIGN);
     int dev = 0; (void) hipGetDevice(&dev);
-    {
-        hipStream_t waitFor = nullptr; bool hit = false;
+    const size_t MB2 = (size_t) 2 << 20;
+    for (int fails = 0;;) {
+        hipStream_t waitFor = nullptr; bool waitAll = false, hit = false;
+        size_t slabBytes = 0;
         {
-        std::lock_guard<std::mutex> g(g_poolMu);
-        auto &freeMap = g_poolFree[dev];
-        // best fit: the smallest cached block that is large enough, as long as it is not absurdly larger
-        // (iterations shrink and grow their arrays; an exact-class match would miss and fall into hipMalloc)
-        // (small requests may take a block up to 8x their size; a large request only one with <= 25 % slack — at 50 M reads a
-        //  10 GB request that takes a cached 77 GB record array makes the next iteration's record arrays a fresh hipMalloc, and
-        //  the job runs out of HBM with most of it idle inside oversized blocks)
-        auto it = freeMap.lower_bound(c);
-        if (it != freeMap.end() && (it->first <= (size_t) 1 << 20 || (c <= ((size_t) 64 << 20) ? it->first <= 8 * c : it->first <= c + c / 4))) {
-            *p = it->second.p; const size_t got = it->first;
-            if (it->second.stream != tl_poolStream) waitFor = it->second.stream;
-            freeMap.erase(it); g_poolLive[*p] = PoolLive{got, dev}; g_poolHits++; hit = true;
-        }
+            std::lock_guard<std::mutex> g(g_poolMu);
+            DevicePool &dp = g_pools[dev];
+            hit = takeRange(dp, dev, n, p, &waitFor, &waitAll);
+            if (hit) g_poolHits++;
+            else {
+                // a new slab: modest while the process is small, most of the remaining HBM once it is not
+                size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
+                const size_t most = (size_t) ((double) fr * poolFraction());
+                const bool bigJob = dp.total >= ((size_t) 8 << 30) || n >= ((size_t) 4 << 30);
+                slabBytes = bigJob ? most : std::min<size_t>(std::max<size_t>(2 * n, (size_t) 1 << 30), most);
+                if (slabBytes < n || fails) slabBytes = n;                  // last resort: exactly what is asked for
+                slabBytes = (slabBytes + MB2 - 1) / MB2 * MB2;
+            }
         }
         if (hit) {
-            if (waitFor) (void) hipStreamSynchronize(waitFor);          // the previous user's queued work must be through
+            if (waitAll) (void) hipDeviceSynchronize();
+            else if (waitFor) (void) hipStreamSynchronize(waitFor);          // the previous user's queued work must be through
             return hipSuccess;
         }
+        const auto t0 = std::chrono::steady_clock::now();
+        void *base = nullptr;
+        const hipError_t e = hipMalloc(&base, slabBytes);
+        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        std::lock_guard<std::mutex> g(g_poolMu);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            if (++fails >= 3) return e;
+            trimLocked(dev);                                     // completely free slabs go back to HIP, then try again (smaller)
+            continue;
+        }
+        DevicePool &dp = g_pools[dev];
+        Slab sl; sl.base = static_cast<char *>(base); sl.size = slabBytes; sl.used = 0; sl.free[0] = FreeRange{slabBytes, nullptr, false};
+        size_t idx = dp.slabs.size();                            // reuse the table entry of a slab that was given back
+        for (size_t i = 0; i < dp.slabs.size(); i++) if (!dp.slabs[i].base) { idx = i; break; }
+        if (idx == dp.slabs.size()) dp.slabs.push_back(std::move(sl)); else dp.slabs[idx] = std::move(sl);
+        dp.total += slabBytes; g_poolMisses++; g_poolMissMs += ms; g_poolMissBytes += (double) slabBytes;
     }
-    const auto t0 = std::chrono::steady_clock::now();
-    hipError_t e = hipMalloc(p, c);
-    if (e != hipSuccess) { (void) hipGetLastError(); poolTrim(); e = hipMalloc(p, c); }
-    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    if (e == hipSuccess) { std::lock_guard<std::mutex> g(g_poolMu); g_poolLive[*p] = PoolLive{c, dev}; g_poolMisses++; g_poolMissMs += ms; g_poolMissBytes += (double) c; }
-    return e;
 }
 void poolFree(void *p) {
     std::lock_guard<std::mutex> g(g_poolMu);
     auto it = g_poolLive.find(p);
     if (it == g_poolLive.end()) { (void) hipFree(p); return; }
-    g_poolFree[it->second.device].emplace(it->second.cls, PoolBlock{p, tl_poolStream});
+    const PoolLive lv = it->second;
     g_poolLive.erase(it);
+    Slab &sl = g_pools[lv.device].slabs[lv.slab];
+    sl.used -= lv.size;
+    size_t off = lv.off, size = lv.size; hipStream_t stream = tl_poolStream; bool mixed = false;
+    auto nx = sl.free.lower_bound(off);
+    if (nx != sl.free.end() && off + size == nx->first) {        // merge with the range behind
+        if (nx->second.mixed || nx->second.stream != stream) mixed = !(nx->second.stream == nullptr && !nx->second.mixed) || mixed;
+        size += nx->second.size; nx = sl.free.erase(nx);
+    }
+    if (nx != sl.free.begin()) {
+        auto pv = std::prev(nx);
+        if (pv->first + pv->second.size == off) {                // merge with the range in front
+            if (pv->second.mixed || pv->second.stream != stream) mixed = !(pv->second.stream == nullptr && !pv->second.mixed) || mixed;
+            off = pv->first; size += pv->second.size; sl.free.erase(pv);
+        }
+    }
+    sl.free[off] = FreeRange{size, stream, mixed};
 }
 void poolTrim() {
     std::lock_guard<std::mutex> g(g_poolMu);
-    // cached blocks may still be referenced by queued work of their last stream: drain it before the memory goes back to HIP
-    int cur = 0; (void) hipGetDevice(&cur);
-    for (auto &dv : g_poolFree) {
-        if (dv.second.empty()) continue;
-        (void) hipSetDevice(dv.first); (void) hipDeviceSynchronize();
-        for (auto &kv : dv.second) (void) hipFree(kv.second.p);
-        dv.second.clear();
-    }
-    (void) hipSetDevice(cur);
+    trimLocked(-1);
 }
 static thread_local std::string g_err;
 int tuneInt(const char *name, int dflt) {

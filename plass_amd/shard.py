@@ -23,7 +23,7 @@ _AGV_DEV = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, 
 class CommStruct(C.Structure):
     """struct plasship_comm"""
     _fields_ = [("rank", C.c_int), ("world", C.c_int), ("user", C.c_void_p), ("allgather_host", _AG_HOST),
-                ("alltoallv_dev", _A2A_DEV), ("allgatherv_dev", _AGV_DEV)]
+                ("alltoallv_dev", _A2A_DEV), ("allgatherv_dev", _AGV_DEV), ("stream_ordered", C.c_int)]
 
 
 def owned_range(n, rank, world):
@@ -40,7 +40,7 @@ class _CommBase:
         self.bytes_moved, self.seconds, self.calls = 0, 0.0, 0      # device bytes this rank sent, time inside collectives, calls
         self._cbs = (_AG_HOST(self._wrap(self._allgather_host)), _A2A_DEV(self._wrap(self._alltoallv_dev)),
                      _AGV_DEV(self._wrap(self._allgatherv_dev)))
-        self.struct = CommStruct(rank, world, None, *self._cbs)
+        self.struct = CommStruct(rank, world, None, *self._cbs, 0)
 
     def _wrap(self, fn):
         def cb(user, *a):
