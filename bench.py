@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="read pairs of the whole job (0 = the config's own; the community scales with it)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = 40000 below 8 host cores, 120000 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--comm", choices=["auto", "native", "torch"], default="auto",
+                    help="sharded run: 'native' = the library's own RCCL communicator (include/plasship_rccl.h), 'torch' = torch.distributed P2P; auto = native, torch if that fails")
     ap.add_argument("--mode", choices=["auto", "sharded", "partitions"], default="auto",
                     help="N > 1: 'sharded' = the one read set over the GPUs with RCCL all-to-all (default); 'partitions' = N independent sets of 1/N the size")
     args = ap.parse_args()
@@ -234,33 +236,52 @@ def main():
         raise SystemExit("--mode sharded needs torch.distributed (launch with torch.distributed.run, or PLASS_BENCH_FORCE_DIST=1 on one GPU)")
 
     ctx = plass_amd.Context(local)
-    comm = None
+    dev = torch.device("cuda", local)
+    comm = None; native = None
     sharded_error = None
+    # the preprocessing is not sharded: every rank builds the identical DB from the seed (before a communicator is installed)
+    db0, wl = build_workload(ctx, args.config, pairs if mode != "partitions" else max(1000, pairs // world))
     if mode == "sharded":
-        from plass_amd.shard import TorchComm
-        comm = TorchComm(dist, torch.device("cuda", local))
-        comm.install(ctx)
+        from plass_amd.shard import TorchComm, RcclComm, rccl_unique_id
+        comm_error = None
+        if args.comm in ("auto", "native"):
+            try:                     # rank 0 makes the id, torch.distributed carries it (control plane only)
+                box = [rccl_unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0, device=dev)
+                native = RcclComm(ctx, rank, world, box[0])
+            except Exception as e:
+                comm_error = "%s: %s" % (type(e).__name__, e)
+            ok = torch.tensor([0 if comm_error else 1], dtype=torch.int64, device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if native is not None:
+                    native.destroy(); native = None
+                if args.comm == "native":
+                    raise SystemExit("native RCCL communicator failed: %s" % (comm_error or "on another rank"))
+        if native is None:
+            comm = TorchComm(dist, dev)
+            comm.install(ctx)
         try:
-            sharded_preflight(ctx, dist, torch.device("cuda", local))
+            sharded_preflight(ctx, dist, dev)
         except Exception as e:       # e.g. a collective this RCCL / torch build lacks: say so and fall back
             if args.mode == "sharded":
                 raise
             sharded_error = "%s: %s" % (type(e).__name__, e)
-        ok = torch.tensor([0 if sharded_error else 1], dtype=torch.int64, device=torch.device("cuda", local))
+        ok = torch.tensor([0 if sharded_error else 1], dtype=torch.int64, device=dev)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)        # every rank takes the same decision
         if int(ok.item()) == 0:
             sharded_error = sharded_error or "the preflight failed on another rank"
-            TorchComm.uninstall(ctx)
+            if native is not None:
+                native.destroy(); native = None
+            else:
+                TorchComm.uninstall(ctx)
             comm, mode = None, "partitions"
-    if mode == "partitions":
-        pairs = max(1000, pairs // world)
-    if comm is not None:
-        TorchComm.uninstall(ctx)                         # the preprocessing is not sharded: every rank builds the identical DB
-    db0, wl = build_workload(ctx, args.config, pairs)
+            db0.free()
+            db0, wl = build_workload(ctx, args.config, max(1000, pairs // world))
+        elif comm_error:
+            sharded_error = "native communicator unavailable (%s); torch.distributed P2P used" % comm_error
     if mode == "partitions" and world > 1:
         wl["note"] = "independent partition of 1/%d of the job per rank (same seed model, no data-path collective)" % world
-    if comm is not None:
-        comm.install(ctx)
     n_frag = wl["protein_fragments"]
 
     def barrier():
@@ -298,6 +319,8 @@ def main():
     barrier()
     if comm is not None:
         comm.bytes_moved = 0; comm.seconds = 0.0; comm.calls = 0
+    if native is not None:
+        native.stats(reset=True)
     t0 = time.perf_counter()
     db, rows, overlaps = run(steps, True)
     barrier()
@@ -355,17 +378,23 @@ def main():
         if sharded_error is not None:
             line["sharded_mode_error"] = sharded_error
         if comm is not None:
-            line["exchange"] = {"device_bytes_sent_per_step_rank0": comm.bytes_moved / max(steps, 1), "collective_calls_per_step": comm.calls / max(steps, 1),
-                                "ms_in_collectives_per_step_rank0": comm.seconds * 1e3 / max(steps, 1)}
+            line["exchange"] = {"communicator": "torch.distributed P2P (RCCL)", "device_bytes_sent_per_step_rank0": comm.bytes_moved / max(steps, 1),
+                                "collective_calls_per_step": comm.calls / max(steps, 1), "ms_in_collectives_per_step_rank0": comm.seconds * 1e3 / max(steps, 1)}
+        if native is not None:
+            nb, nsec, ncalls = native.stats()
+            line["exchange"] = {"communicator": "native RCCL (plasship_rccl, ncclSend/ncclRecv groups on the context stream)", "device_bytes_sent_per_step_rank0": nb / max(steps, 1),
+                                "collective_calls_per_step": ncalls / max(steps, 1), "host_ms_in_collectives_per_step_rank0": nsec * 1e3 / max(steps, 1)}
     if db is not db0:
         db.free()
     db0.free()
     if rank == 0:
-        if world == 1 and comm is None and not args.no_cpu_baseline:
+        if world == 1 and comm is None and native is None and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, min(chain, 3))
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line))
+    if native is not None:
+        native.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

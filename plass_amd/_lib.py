@@ -144,6 +144,13 @@ SYMBOLS = [
     ("plasship_orfhdr_count", C.c_int, [P, C.POINTER(C.c_size_t)]),
     ("plasship_orfhdr_free", None, [P, P]),
 ]
+# include/plasship_rccl.h (native RCCL communicator of a sharded run)
+RCCL_SYMBOLS = [
+    ("plasship_rccl_get_unique_id", C.c_int, [P]),
+    ("plasship_rccl_comm_create", C.c_int, [P, C.c_int, C.c_int, P, C.POINTER(P)]),
+    ("plasship_rccl_comm_stats", C.c_int, [P, C.POINTER(C.c_uint64), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int]),
+    ("plasship_rccl_comm_destroy", None, [P, P]),
+]
 # include/plasship_synth.h (measurement infrastructure: synthetic read sets generated on the GPU)
 SYNTH_SYMBOLS = [
     ("plasship_synth_read_pairs", C.c_int, [P, C.POINTER(_SynthParams), C.POINTER(P), C.POINTER(SynthStats)]),
@@ -162,7 +169,7 @@ def load_library():
         raise PlasshipError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(plass_amd has no CPU fallback)" % path)
     lib = C.CDLL(path)
-    for name, res, args in SYMBOLS + SYNTH_SYMBOLS:
+    for name, res, args in SYMBOLS + SYNTH_SYMBOLS + RCCL_SYMBOLS:
         fn = getattr(lib, name)          # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args

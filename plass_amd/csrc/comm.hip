@@ -50,6 +50,18 @@ int commAllReduceSumU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allRe
 int commAllReduceMaxU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allReduceU64(ctx, v, n, [](uint64_t a, uint64_t b) { return a > b ? a : b; }); }
 int commAllReduceMinU64(plasship_ctx *ctx, uint64_t *v, size_t n) { return allReduceU64(ctx, v, n, [](uint64_t a, uint64_t b) { return a < b ? a : b; }); }
 
+// a rank-local condition that precedes a collective: all ranks learn whether it held everywhere and leave together if not
+// (a rank that returned alone would leave the others waiting inside the collective)
+int commAgreeOk(plasship_ctx *ctx, bool ok, const char *what) {
+    const plasship_comm *cm = commOf(ctx);
+    if (!cm || cm->world == 1) { if (!ok) { setError(what); return PLASSHIP_ERR_DEVICE; } return PLASSHIP_OK; }
+    uint64_t bad = ok ? 0 : 1;
+    const int rc = commAllReduceMaxU64(ctx, &bad, 1);
+    if (rc) return rc;
+    if (bad) { setError(ok ? std::string(what) + " (on another rank)" : std::string(what)); return PLASSHIP_ERR_DEVICE; }
+    return PLASSHIP_OK;
+}
+
 int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *sendCount, size_t recordBytes, DevBuf &recv,
                          uint64_t *recvTotal, uint64_t slackRecords, uint64_t *allTotal) {
     const plasship_comm *cm = commOf(ctx);
@@ -61,7 +73,8 @@ int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *s
     if (rc) return rc;
     std::vector<uint64_t> sendBytes(W), recvBytes(W); uint64_t tot = 0;
     for (int r = 0; r < W; r++) { sendBytes[r] = sendCount[r] * recordBytes; const uint64_t c = all[(size_t) r * W + cm->rank]; recvBytes[r] = c * recordBytes; tot += c; }
-    if (recv.alloc(std::max<uint64_t>(tot + slackRecords, 1) * recordBytes) != hipSuccess) { setError("sharded run: out of device memory for the receive buffer"); return PLASSHIP_ERR_DEVICE; }
+    rc = commAgreeOk(ctx, recv.alloc(std::max<uint64_t>(tot + slackRecords, 1) * recordBytes) == hipSuccess, "sharded run: out of device memory for the receive buffer");
+    if (rc) return rc;
     if (!cm->stream_ordered) PH_CHECK(hipStreamSynchronize(ctx->stream));
     if (cm->alltoallv_dev(cm->user, dSend, sendBytes.data(), recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's alltoallv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     *recvTotal = tot;
@@ -84,7 +97,8 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
     const int W = cm->world;
     if ((int) recvBytes.size() != W || recvBytes[cm->rank] != sendBytes) { setError("sharded run: inconsistent all-gather sizes"); return PLASSHIP_ERR_ARG; }
     uint64_t tot = 0; for (int r = 0; r < W; r++) tot += recvBytes[r];
-    if (recv.alloc(tot + 64) != hipSuccess) { setError("sharded run: out of device memory for the gather buffer"); return PLASSHIP_ERR_DEVICE; }
+    const int rcA = commAgreeOk(ctx, recv.alloc(tot + 64) == hipSuccess, "sharded run: out of device memory for the gather buffer");
+    if (rcA) return rcA;
     if (!cm->stream_ordered) PH_CHECK(hipStreamSynchronize(ctx->stream));
     if (cm->allgatherv_dev(cm->user, dSend, sendBytes, recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's allgatherv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     return PLASSHIP_OK;

@@ -158,6 +158,7 @@ int commAllgatherHost(plasship_ctx *ctx, const void *send, void *recv, uint64_t 
 int commAllReduceSumU64(plasship_ctx *ctx, uint64_t *v, size_t n);       // in place
 int commAllReduceMaxU64(plasship_ctx *ctx, uint64_t *v, size_t n);
 int commAllReduceMinU64(plasship_ctx *ctx, uint64_t *v, size_t n);
+int commAgreeOk(plasship_ctx *ctx, bool ok, const char *what);          // collective: error on every rank unless `ok` on every rank
 // all-to-all(v) of fixed-size records laid out by destination; allocates `recv` (capacity (total + slackRecords) records)
 // *allTotal (optional): records sent by all ranks together
 int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *sendCount, size_t recordBytes, DevBuf &recv,

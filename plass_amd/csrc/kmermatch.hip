@@ -218,7 +218,7 @@ __device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k,
 //   atomics, no barriers), and only the <= ~60 selected windows rebuild their k-mer.  Longer sequences are queued for the next
 //   launch.  REGS == 0: the three-pass path below; RESL = longest sequence whose codes and scores stay resident in LDS.
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS > 0 ? 4 : 1))) void extractKernel(ExtractArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 2 : 1)))) void extractKernel(ExtractArgs a) {
     constexpr uint32_t RES_L = RESL;
     constexpr uint32_t CODES = (RESL > 64 * REGS + 32 ? RESL : 64 * REGS + 32) + 32;
     __shared__ unsigned char sMap[256];
@@ -248,24 +248,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS > 0 ? 4
     struct Meta { uint32_t L; uint64_t off, slot, slot1; };
     auto loadMeta = [&](uint32_t id) { Meta m; m.L = a.s.len[id]; m.off = a.s.off[id]; m.slot = a.slotOff[id] - a.slotBias; m.slot1 = a.slotOff[id + 1] - a.slotBias; return m; };
     Meta mNext = {0, 0, 0, 0}, mNext2 = {0, 0, 0, 0};
-    char pb0 = 0, pb1 = 0;
+    char pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;       // the next sequence's first 256 bytes (the average contig of a metagenomic run is ~250 residues)
     if (!FALLBACK && blockIdx.x < nWork) {
         mNext = loadMeta(idAt(blockIdx.x));
         if (blockIdx.x + gridDim.x < nWork) mNext2 = loadMeta(idAt(blockIdx.x + gridDim.x));
         if ((uint32_t) lane < mNext.L) pb0 = a.s.data[mNext.off + lane];
         if ((uint32_t) lane + 64 < mNext.L) pb1 = a.s.data[mNext.off + lane + 64];
+        if ((uint32_t) lane + 128 < mNext.L) pb2 = a.s.data[mNext.off + lane + 128];
+        if ((uint32_t) lane + 192 < mNext.L) pb3 = a.s.data[mNext.off + lane + 192];
     }
     for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
         const uint32_t id = FALLBACK ? a.idList[w] : idAt(w);
         Meta cur;
-        char cb0 = 0, cb1 = 0;
+        char cb0 = 0, cb1 = 0, cb2 = 0, cb3 = 0;
         if (FALLBACK) cur = loadMeta(id);
         else {
-            cur = mNext; cb0 = pb0; cb1 = pb1;
+            cur = mNext; cb0 = pb0; cb1 = pb1; cb2 = pb2; cb3 = pb3;
             mNext = mNext2;
             if (w + gridDim.x < nWork) {
                 pb0 = ((uint32_t) lane < mNext.L) ? a.s.data[mNext.off + lane] : (char) 0;
                 pb1 = ((uint32_t) lane + 64 < mNext.L) ? a.s.data[mNext.off + lane + 64] : (char) 0;
+                pb2 = ((uint32_t) lane + 128 < mNext.L) ? a.s.data[mNext.off + lane + 128] : (char) 0;
+                pb3 = ((uint32_t) lane + 192 < mNext.L) ? a.s.data[mNext.off + lane + 192] : (char) 0;
             }
             if (w + 2 * gridDim.x < nWork) mNext2 = loadMeta(idAt(w + 2 * gridDim.x));
         }
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS > 0 ? 4
         if (useRegs) {
             // ---- codes to LDS (padded with X so that every window read stays inside the staged bytes) ----
             for (uint32_t i = lane; i < L + 31; i += 64) {
-                const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < L) ? base[i] : (char) 0));      // first 128 bytes were prefetched
+                const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < 192) ? cb2 : ((i < 256) ? cb3 : ((i < L) ? base[i] : (char) 0))));      // first 256 bytes were prefetched
                 sCodeAll[i] = (i < L) ? sMap[(unsigned char) ch] : (unsigned char) a.xCode;
             }
             __syncthreads();
@@ -379,7 +383,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS > 0 ? 4
         const bool useCache = resident && !allCand;
         if (resident) {
             for (uint32_t i = lane; i < L + 31; i += 64) {
-                const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < L) ? base[i] : (char) 0));      // first 128 bytes were prefetched
+                const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < 192) ? cb2 : ((i < 256) ? cb3 : ((i < L) ? base[i] : (char) 0))));      // first 256 bytes were prefetched
                 sCodeAll[i] = (i < L) ? sMap[(unsigned char) ch] : (unsigned char) a.xCode;
             }
             __syncthreads();
@@ -996,6 +1000,146 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
     if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
 }
 
+// ---- the same over a line store, 16-byte records: the bucket is read ONCE --------------------------------------------------
+// A bucket (~1000-2000 records behind a list of 128-byte lines) stays in REGISTERS (8 records per thread) for both phases, and
+// the run head is ONE atomicMin per record on a packed (longest, smallest id, smallest position, reverse strand first) word —
+// sequences of the KmerPosition<short> layout are shorter than 32 767, so the four fields fit 63 bits.  (The three-phase kernel
+// above reads every record three times and needs a barrier more per bucket; it remains for 24-byte records, dense input and
+// buckets beyond 2048 positions.)
+constexpr int GL_RMAX = 8;
+template <bool NUCL>
+__global__ __launch_bounds__(GR_BLOCK) void groupLinesKernel(GroupArgs a) {
+    typedef Rec<false> R;
+    __shared__ unsigned long long hKey[GR_HT];
+    __shared__ unsigned long long hBest[GR_HT];
+    __shared__ uint32_t hCnt[GR_HT];
+    __shared__ uint32_t sFlag[2];
+    __shared__ uint32_t sCursor;
+    const R *in = reinterpret_cast<const R *>(a.in);
+    R *out = reinterpret_cast<R *>(a.out);
+    const uint32_t bBegin = blockIdx.x * a.bucketsPerBlock;
+    const uint32_t bEnd = min(a.nBuckets, bBegin + a.bucketsPerBlock);
+    if (bBegin >= a.nBuckets) { if (threadIdx.x == 0) a.outCount[blockIdx.x] = 0; return; }
+    unsigned long long written = 0;                  // block-uniform
+    unsigned long long maxRT = 0;
+    const uint64_t arena = (uint64_t) a.lineBeg[bBegin] * RPL;
+    const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
+    for (uint32_t b = bBegin; b < bEnd; b++) {
+        const uint32_t n = a.lineCnt[b] * RPL;       // record positions of the bucket (padding sentinels included)
+        const uint32_t lb = a.lineBeg[b];
+        if (n == 0) continue;
+        auto recAt = [&](uint32_t i) -> R { return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)]; };
+        const bool inRegs = n <= (uint32_t) GL_RMAX * GR_BLOCK;
+        R rg[GL_RMAX];
+        if (inRegs) {
+#pragma unroll
+            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * GR_BLOCK + threadIdx.x; if (i < n) rg[j] = recAt(i); else { rg[j].kmer = ~0ULL; rg[j].id = 0xFFFFFFFFu; rg[j].len = 0; rg[j].pos = 0; } }
+        }
+        // phase A on one record: claim the k-mer's slot, count, and bid for the run head
+        auto phaseA = [&](const R &r, uint32_t nSub, uint32_t sub) {
+            if (isSentinel(r)) return;
+            const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
+            const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
+            if (nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub) return;
+            uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
+            for (uint32_t probe = 0; probe < GR_HT; probe++) {
+                const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, K);
+                if (prev == ~0ULL) atomicAdd(&sFlag[0], 1u);
+                if (prev == ~0ULL || prev == K) {
+                    atomicAdd(&hCnt[slot], 1u);
+                    const unsigned long long packed = ((unsigned long long) (0x7FFFu - (uint32_t) r.len) << 48) | ((unsigned long long) r.id << 16) |
+                                                      ((unsigned long long) ((uint32_t) r.pos & 0x7FFFu) << 1) | (NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL);
+                    atomicMin(&hBest[slot], packed);
+                    return;
+                }
+                slot = (slot + 1) & (GR_HT - 1);
+            }
+            atomicExch(&sFlag[1], 1u);                // table full
+        };
+        // phase C on one record: (rep, member, diagonal) if the run has at least two members and the filter keeps it
+        auto phaseC = [&](const R &r, bool here, uint32_t nSub, uint32_t sub) {
+            bool keep = false; R o; o.kmer = 0; o.id = 0; o.len = 0; o.pos = 0;
+            if (here && !isSentinel(r)) {
+                const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
+                const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
+                if (!(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
+                    uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
+                    while (hKey[slot] != K) slot = (slot + 1) & (GR_HT - 1);
+                    if (hCnt[slot] >= 2) {
+                        const unsigned long long best = hBest[slot];
+                        const uint32_t repId = (uint32_t) (best >> 16);
+                        const int repPos = (int) ((best >> 1) & 0x7FFFu);
+                        const int queryLen = (int) (0x7FFFu - (uint32_t) (best >> 48));
+                        const int mLen = (int) r.len, mPos = (int) r.pos;
+                        int diagonal = repPos - mPos;
+                        unsigned long long rId = repId;
+                        if (NUCL) {
+                            bool repIsReverse = ((best & 1ULL) == 0);
+                            if (K == firstRunKey) repIsReverse = false;       // kmermatcher.cpp:463 (never refreshed for run 0)
+                            const bool targetIsReverse = ((r.kmer & BIT63) == 0);
+                            int qp, tp; bool qRev;
+                            if (repIsReverse && !targetIsReverse) { qp = repPos; tp = mPos; qRev = true; }
+                            else if (repIsReverse && targetIsReverse) { qp = (queryLen - 1) - repPos; tp = (mLen - 1) - mPos; qRev = false; }
+                            else if (!repIsReverse && targetIsReverse) { qp = (queryLen - 1) - repPos; tp = (mLen - 1) - mPos; qRev = true; }
+                            else { qp = repPos; tp = mPos; qRev = false; }
+                            qp = (int) (short) qp; tp = (int) (short) tp;     // positions are truncated to T exactly like the reference's T queryPos/targetPos
+                            diagonal = qp - tp;
+                            rId = qRev ? (rId & ~BIT63) : (rId | BIT63);
+                        }
+                        const bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - mLen));
+                        const bool cov = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) mLen);
+                        keep = (!a.includeOnlyExtendable && cov) || (canBeExtended && a.includeOnlyExtendable);
+                        o.kmer = rId; o.id = r.id; o.len = r.len; o.pos = (int16_t) diagonal;
+                        if (keep) maxRT = max(maxRT, (unsigned long long) (((rId & ~BIT63) << 32) | (unsigned long long) r.id));
+                    }
+                }
+            }
+            const unsigned long long mk = __ballot(keep);
+            const uint32_t wr = (uint32_t) __popcll(mk & ((1ULL << laneId()) - 1ULL));
+            uint32_t wbase = 0;
+            if (mk) {
+                if (laneId() == 0) wbase = atomicAdd(&sCursor, (uint32_t) __popcll(mk));
+                wbase = __shfl(wbase, 0, 64);
+            }
+            if (keep) out[arena + written + wbase + wr] = o;
+        };
+        uint32_t nSub = 1;                           // sub-passes by a secondary hash when too many distinct k-mers
+        const unsigned long long writtenAtBucketStart = written;
+        for (;;) {
+            bool redo = false;
+            for (uint32_t sub = 0; sub < nSub && !redo; sub++) {
+                for (uint32_t i = threadIdx.x; i < GR_HT; i += GR_BLOCK) { hKey[i] = ~0ULL; hBest[i] = ~0ULL; hCnt[i] = 0; }
+                if (threadIdx.x == 0) { sFlag[0] = 0; sFlag[1] = 0; sCursor = 0; }
+                __syncthreads();
+                if (inRegs) {
+#pragma unroll
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * GR_BLOCK < n) phaseA(rg[j], nSub, sub);
+                } else for (uint32_t i = threadIdx.x; i < n; i += GR_BLOCK) phaseA(recAt(i), nSub, sub);
+                __syncthreads();
+                if (sFlag[1] || sFlag[0] > GR_MAXKEYS) { redo = true; __syncthreads(); break; }
+                if (inRegs) {
+#pragma unroll
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * GR_BLOCK < n) phaseC(rg[j], true, nSub, sub);
+                } else for (uint32_t i0 = 0; i0 < n; i0 += GR_BLOCK) { const uint32_t i = i0 + threadIdx.x; R r; if (i < n) r = recAt(i); else { r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; } phaseC(r, i < n, nSub, sub); }
+                __syncthreads();
+                written += sCursor;
+                __syncthreads();
+                if (threadIdx.x == 0) sCursor = 0;
+            }
+            if (!redo) break;
+            nSub *= 2;                               // a retry discards what completed sub-passes of this attempt wrote
+            written = writtenAtBucketStart;
+            __syncthreads();
+        }
+    }
+    if (a.maxRepTarget) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxRT = max(maxRT, (unsigned long long) __shfl_xor(maxRT, o, 64));
+        if (laneId() == 0 && maxRT) atomicMax(a.maxRepTarget, maxRT);
+    }
+    if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
+}
+
 // =====================================================================================================
 // 5. sort #2 + run reduction, per rep-range bucket.
 //    compareRepSequenceAndIdAndDiag[Reverse] (kmermatcher.h:98-130) orders by (rep, target, diagonal); what
@@ -1535,7 +1679,8 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
     ga.maxRepTarget = dMaxRT.as<unsigned long long>();
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
-    hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+    if constexpr (LONG) hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+    else hipLaunchKernelGGL((groupLinesKernel<NUCL>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
     std::vector<uint64_t> hOutCnt(gGrid), hArena(gGrid);
     unsigned long long hLastRun[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
@@ -1632,7 +1777,11 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
             outLine += pc.outCap; hp.push_back(pc);
         }
     }
-    const uint64_t capR1 = std::max<uint64_t>(outLine, 1), capR2 = s2 ? capR1 + (uint64_t) nS1 * nS2 : 0;
+    // level 2 of a RANGE partition: representatives are not evenly spread over the id range (a contig is the representative of
+    // everything it overlaps), so a level-1 bucket is cut into pieces like any other input (hash buckets are even: one piece each)
+    const uint32_t PLr2 = s2 ? pieceLinesFor(std::max<uint64_t>(outLine, 1), nS2, numCU, 16) : 0;
+    const uint64_t maxPR2 = s2 ? std::max<uint64_t>(outLine, 1) / PLr2 + nS1 + 1 : 0;
+    const uint64_t capR1 = std::max<uint64_t>(outLine, 1), capR2 = s2 ? capR1 + maxPR2 * nS2 : 0;
     const uint32_t nPR1 = (uint32_t) hp.size();
     DevBuf dR1, dRTag1, dRList1, dRPieces, dRNP, dRCnt1, dRStart1, dRCur1, dR2, dRTag2, dRList2, dRPieces2, dRNP2, dRRegBeg, dRRegEnd, dRTot2, dSortBeg, dSortCnt;
     if (dR1.alloc(capR1 * RPL * sizeof(R)) != hipSuccess || dRTag1.alloc(capR1 * 4) != hipSuccess || dRList1.alloc(capR1 * 4) != hipSuccess || dRPieces.alloc(((size_t) nPR1 + 1) * sizeof(LinePiece)) != hipSuccess ||
@@ -1652,14 +1801,14 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     (otherRecs == dA.p ? dA : dB).release();               // the arenas are consumed
     void *sortRecs = dR1.p; const uint32_t *sortList = dRList1.as<uint32_t>(); uint64_t sortCap = capR1;
     if (s2) {
-        if (dR2.alloc(capR2 * RPL * sizeof(R)) != hipSuccess || dRTag2.alloc(capR2 * 4) != hipSuccess || dRList2.alloc(capR2 * 4) != hipSuccess || dRPieces2.alloc(((size_t) nS1 + 1) * sizeof(LinePiece)) != hipSuccess ||
+        if (dR2.alloc(capR2 * RPL * sizeof(R)) != hipSuccess || dRTag2.alloc(capR2 * 4) != hipSuccess || dRList2.alloc(capR2 * 4) != hipSuccess || dRPieces2.alloc(((size_t) maxPR2 + 1) * sizeof(LinePiece)) != hipSuccess ||
             dRNP2.alloc(4) != hipSuccess || dRRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRRegEnd.alloc(LP_MAXB * 8) != hipSuccess || dRTot2.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, 0xFFFFFFFFu, nS2, dRPieces2.as<LinePiece>(), dRNP2.as<uint32_t>(),
+        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, PLr2, nS2, dRPieces2.as<LinePiece>(), dRNP2.as<uint32_t>(),
                            dRRegBeg.as<uint64_t>(), dRRegEnd.as<uint64_t>(), dRTot2.as<uint64_t>());
         LinePartArgs a; memset(&a, 0, sizeof(a));
         a.in = dR1.p; a.list = dRList1.as<uint32_t>(); a.out = dR2.p; a.tags = dRTag2.as<uint32_t>(); a.pieces = dRPieces2.as<LinePiece>(); a.nPieces = dRNP2.as<uint32_t>(); a.nb = nS2;
         a.key = rkey; a.key.shift = 64 - s1 - s2;
-        rc = launchLinePart<NUCL, LONG, KEY_RANGE, true, false>(ctx, a, nS1); if (rc) return rc;
+        rc = launchLinePart<NUCL, LONG, KEY_RANGE, true, false>(ctx, a, maxPR2); if (rc) return rc;
         hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(nS1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dRTag2.as<uint32_t>(), (const uint64_t *) dRRegBeg.as<uint64_t>(),
                            (const uint64_t *) dRRegEnd.as<uint64_t>(), nS1, nS2, dRList2.as<uint32_t>(), dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>());
         sortRecs = dR2.p; sortList = dRList2.as<uint32_t>(); sortCap = capR2;
@@ -1742,7 +1891,10 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
         if (nTriples) PH_COPY_SYNC(st, &last, dTr + (nTriples - 1), sizeof(Triple), hipMemcpyDeviceToHost);
         uint64_t hdr[2] = {nTriples, headCnt}; std::vector<uint64_t> hdrs(2 * (size_t) W);
         int rc = commAllgatherHost(ctx, hdr, hdrs.data(), 16); if (rc) return rc;
-        uint64_t maxHead = 0; for (int r = 0; r < W; r++) maxHead = std::max(maxHead, hdrs[2 * (size_t) r + 1]);
+        uint64_t maxHead = 0, sumHead = 0; for (int r = 0; r < W; r++) { maxHead = std::max(maxHead, hdrs[2 * (size_t) r + 1]); sumHead += hdrs[2 * (size_t) r + 1]; }
+        // the halo of any rank is at most all heads plus the stale records: decide on THAT, so every rank takes the same exit
+        // (a rank that fails alone would leave the others waiting in the next collective)
+        if (sumHead + stalePos.size() > HALO_SLACK) { setError("kmermatch: a (rep, target) run continues over more than 65536 records of other ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
         std::vector<Triple> heads;
         if (maxHead) {
             std::vector<Triple> mine(maxHead); memset(mine.data(), 0, maxHead * sizeof(Triple));
@@ -1767,7 +1919,6 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
                 }
             }
             nHalo = halo.size();
-            if (nHalo > HALO_SLACK) { setError("kmermatch: a (rep, target) run continues over more than 65536 records of other ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
             if (nHalo) PH_COPY_SYNC(st, dTr + nTriples, halo.data(), nHalo * sizeof(Triple), hipMemcpyHostToDevice);
         }
         PH_CHECK(hipMemsetAsync(dPerRep.p, 0, ((size_t) N + 1) * 4, st));
@@ -1928,17 +2079,22 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
     static const int waveBlocksPerCU = [] { const char *e = getenv("PLASSHIP_EXTRACT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();     // 32 one-wavefront workgroups per CU: measured best of 12..64 on the 1 M-read set
-    // regular launch: register front end for sequences of up to 1024 windows; longer ones (and candidate sets beyond CAP) are
-    // queued for the next launch, which keeps codes and scores of up to 8160 residues resident in LDS
+    // launch chain, each tier queueing what it cannot hold for the next: (1) register front end, up to 1024 windows (every read,
+    // most contigs); (2) the same with 48 scores per lane, up to 3072 windows (proteins longer than that are rare) and, for
+    // nucleotides, up to 1024 candidates; (3) three-pass path with codes and scores of up to 8160 residues resident in LDS;
+    // (4) the HBM-scratch launch below
     if (nMine) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU)), dim3(64), 0, st, ea);
     DevBuf dOv2Ids, dOv2Cnt;
-    if (CAP2 && nMine) {
+    if (nMine) {
         if (dOv2Ids.alloc(((size_t) N + 1) * 4) != hipSuccess || dOv2Cnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         PH_CHECK(hipMemsetAsync(dOv2Cnt.p, 0, 4, st));
         ExtractArgs e2 = ea; e2.waveList = dOvIds.as<uint32_t>(); e2.waveCount = dOvCnt.as<uint32_t>();
         e2.overflowIds = dOv2Ids.as<uint32_t>(); e2.overflowCount = dOv2Cnt.as<uint32_t>();
-        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 2u : 5u))), dim3(64), 0, st, e2);
-        std::swap(dOvIds.p, dOv2Ids.p); std::swap(dOvCnt.p, dOv2Cnt.p);       // the HBM-scratch launch below takes what is left
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 12u))), dim3(64), 0, st, e2);
+        PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));            // tier 2 has consumed the first queue: it becomes tier 3's output queue
+        ExtractArgs e3 = ea; e3.waveList = dOv2Ids.as<uint32_t>(); e3.waveCount = dOv2Cnt.as<uint32_t>();
+        e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>();
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 2u : 5u))), dim3(64), 0, st, e3);
     }
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     uint32_t nOv = 0;
@@ -2294,7 +2450,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     }
     // rep ids are sorted relative to the first rep this rank owns (0 on a single GPU); targets are ids of the whole DB
     const int idBits = std::max(1, ceilLog2((uint64_t) N));
-    const int repBits = cm ? std::max(1, ceilLog2(std::max<uint64_t>(ownedN, 1))) : idBits;
+    // sharded run: from the LARGEST share of any rank (ceil(N / W)), so that the key layout — and the "too many sequences" exit
+    // below — is the same decision on every rank
+    const int repBits = cm ? std::max(1, ceilLog2(std::max<uint64_t>((N + (uint64_t) W - 1) / (uint64_t) W, 1))) : idBits;
     // ~512 records per sort bucket, at most 2^22 buckets (two partition levels of 11 bits): beyond 2 G grouped records the buckets
     // grow instead (the aggregation kernel takes buckets of any size)
     const int wantBits = std::min(22, std::max(0, ceilLog2((NmHere + 511) / 512)));

@@ -166,6 +166,38 @@ class LocalComm(_CommBase):
 
 
 # ---------------------------------------------------------------------------------------------------
+# native RCCL communicator (include/plasship_rccl.h): the C++ side owns the collectives, Python only distributes the id
+# ---------------------------------------------------------------------------------------------------
+RCCL_ID_BYTES = 128
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the library (rank 0 calls this; every rank must receive the same 128 bytes)"""
+    lib = _lib.load_library()
+    buf = C.create_string_buffer(RCCL_ID_BYTES)
+    _lib._check(lib.plasship_rccl_get_unique_id(buf), "plasship_rccl_get_unique_id")
+    return buf.raw
+
+
+class RcclComm:
+    """plasship_rccl_comm: ncclSend / ncclRecv groups on the context's stream; installs itself on the context (collective)"""
+
+    def __init__(self, ctx, rank, world, unique_id):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        self.h = C.c_void_p()
+        _lib._check(ctx.lib.plasship_rccl_comm_create(ctx.h, rank, world, C.c_char_p(bytes(unique_id)), C.byref(self.h)), "plasship_rccl_comm_create")
+
+    def stats(self, reset=False):
+        b = C.c_uint64(); s = C.c_double(); n = C.c_uint64()
+        _lib._check(self.ctx.lib.plasship_rccl_comm_stats(self.h, C.byref(b), C.byref(s), C.byref(n), int(reset)), "plasship_rccl_comm_stats")
+        return b.value, s.value, n.value
+
+    def destroy(self):
+        if self.h:
+            self.ctx.lib.plasship_rccl_comm_destroy(self.ctx.h, self.h); self.h = C.c_void_p()
+
+
+# ---------------------------------------------------------------------------------------------------
 # torch.distributed (RCCL): one process per GPU
 # ---------------------------------------------------------------------------------------------------
 class _DevPtr:
@@ -176,6 +208,14 @@ class _DevPtr:
 
 
 class TorchComm(_CommBase):
+    def _abort(self):
+        # a collective failed on this rank: tear the group down so that the peers' pending operations fail instead of waiting
+        try:
+            if self.dist.is_initialized():
+                self.dist.destroy_process_group(self.group)
+        except Exception:
+            pass
+
     """collectives over a torch.distributed process group.  device: torch.device of this rank's GPU; None: the "device"
     pointers are host pointers and the tensors CPU tensors (the gloo tests drive the same split arithmetic that way)."""
 

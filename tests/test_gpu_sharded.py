@@ -400,3 +400,36 @@ print("RCCL_OK", comm.bytes_moved)
     assert p.returncode == 0 and "RCCL_OK" in p.stdout, p.stdout[-3000:]
     for it in range(2):
         assert_same_db(os.path.join(golden, "aa", f"seq_{it + 1}"), tmp_path / f"rccl_seq_{it + 1}", f"1-rank RCCL iteration {it}")
+
+
+def test_sharded_one_rank_native_rccl(tmp_path, golden):
+    """the native communicator (include/plasship_rccl.h: RCCL loaded by the library, ncclSend / ncclRecv groups on the context's
+    stream) in a 1-rank communicator: the sharded code path of all three modules, output = the reference's golden DBs"""
+    import subprocess, sys
+    code = r'''
+import os, sys
+sys.path.insert(0, %r)
+import plass_amd
+from plass_amd.shard import RcclComm, rccl_unique_id
+ctx = plass_amd.Context(0)
+s = %r
+comm = RcclComm(ctx, 0, 1, rccl_unique_id())
+db = ctx.read_seqdb(s + "/seq_0")
+for it in range(2):
+    par = plass_amd.KmermatchParams(hash_shift=67 if it == 0 else 68, include_only_extendable=(it > 0))
+    c, _ = ctx.kmermatcher(db, par)
+    a, _ = ctx.rescorediagonal(db, db, c, plass_amd.RescoreParams(min_seq_id=0.9))
+    db, _ = ctx.assembleresults(db, a, plass_amd.AssembleParams(min_seq_id=0.9))
+    db.write(%r + "/native_seq_%%d" %% (it + 1))
+b, sec, n = comm.stats()
+comm.destroy()
+# back to single-GPU operation on the same context
+db = ctx.read_seqdb(s + "/seq_0")
+c, _ = ctx.kmermatcher(db, plass_amd.KmermatchParams(hash_shift=67, include_only_extendable=False))
+print("NATIVE_RCCL_OK", b, n, c.count())
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.join(golden, "aa"), str(tmp_path))
+    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "NATIVE_RCCL_OK" in p.stdout, p.stdout[-3000:]
+    assert int(p.stdout.split("NATIVE_RCCL_OK")[1].split()[1]) > 0            # collectives were called
+    for it in (1, 2):
+        assert_same_db(os.path.join(golden, "aa", "seq_%d" % it), tmp_path / ("native_seq_%d" % it), "native RCCL communicator, iteration %d" % (it - 1))
