@@ -1152,6 +1152,7 @@ __global__ __launch_bounds__(GR_BLOCK) void groupLinesKernel(GroupArgs a) {
 constexpr int LS_BLOCK = 256;
 constexpr uint32_t AGG_CAP = 1024;          // records per bucket handled in LDS (=> at most 1024 distinct triples)
 constexpr uint32_t AGG_HT = 2048;           // hash slots
+constexpr uint32_t AGG_NEEDS_SCRATCH = 0xFFFFFFFFu;   // uniqueCount of a bucket pass 1 left to the chunked pass
 template <bool LONG> struct DiagPack { static constexpr int BITS = LONG ? 22 : 16; static constexpr int64_t BIAS = LONG ? (1 << 21) : 32768; };
 struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag; uint32_t cnt; };   // cnt bit 31: some record of the run is forward-strand
 
@@ -1167,6 +1168,7 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
     __shared__ unsigned long long lKey[AGG_CAP];
     __shared__ uint32_t lVal[AGG_CAP];
     __shared__ uint32_t sCount;
+    __shared__ uint32_t sDistinct, sOver;
     __shared__ uint32_t sWave[LS_BLOCK / 64];
     const R *g = reinterpret_cast<const R *>(arr);
     Triple *out = reinterpret_cast<Triple *>(outTriples);
@@ -1237,12 +1239,39 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
             if (threadIdx.x == 0) uniqueCount[b] = U;
             __syncthreads();
         };
-        if (cnt <= AGG_CAP) {
+        // pass 2 (bigScratch != nullptr) only revisits the buckets pass 1 could not aggregate in LDS
+        if (bigScratch && uniqueCount[b] != AGG_NEEDS_SCRATCH) continue;
+        // What bounds the LDS path is the number of DISTINCT (rep, target, diagonal) triples, not the number of records: overlapping
+        // reads share many k-mers on one diagonal (N_m / N_c is 3..14), so a bucket of several thousand records usually holds a few
+        // hundred triples.  Every bucket is therefore first aggregated straight into the table; only when more than AGG_CAP
+        // distinct triples turn up is it left to the chunked path below (second launch, with HBM scratch).
+        bool done = false;
+        if (!bigScratch && cnt <= (1ull << 22)) {
             clearTable();
-            for (uint64_t i = threadIdx.x; i < cnt; i += LS_BLOCK) { const R r = recAt(i); if (LINES && isSentinel(r)) continue; uint32_t v; const unsigned long long key = packRec(r, v); insert(key, v); }
+            if (threadIdx.x == 0) { sDistinct = 0; sOver = 0; }
             __syncthreads();
-            sortListAndWrite(extract());
-        } else {
+            for (uint64_t i = threadIdx.x; i < cnt && !*(volatile uint32_t *) &sOver; i += LS_BLOCK) {
+                const R r = recAt(i); if (LINES && isSentinel(r)) continue;
+                uint32_t v; const unsigned long long key = packRec(r, v);
+                uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 40) & (AGG_HT - 1);
+                bool placed = false;
+                for (uint32_t probe = 0; probe < AGG_HT; probe++) {
+                    const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, key);
+                    if (prev == ~0ULL) { if (atomicAdd(&sDistinct, 1u) >= AGG_CAP) atomicExch(&sOver, 1u); placed = true; break; }
+                    if (prev == key) { placed = true; break; }
+                    slot = (slot + 1) & (AGG_HT - 1);
+                }
+                if (!placed) { atomicExch(&sOver, 1u); break; }
+                atomicAdd(&hVal[slot], v & 0x7FFFFFFFu);
+                if (v & 0x80000000u) atomicOr(&hVal[slot], 0x80000000u);
+            }
+            __syncthreads();
+            if (!sOver) { sortListAndWrite(extract()); done = true; }
+            __syncthreads();
+        }
+        if (done) continue;
+        if (!bigScratch) { if (threadIdx.x == 0) uniqueCount[b] = AGG_NEEDS_SCRATCH; continue; }
+        {
             // oversized bucket (hot representatives): aggregate chunk by chunk in LDS, spill the partial (key,count)
             // pairs to HBM scratch, then merge the partials — in LDS again when they fit, else by sorting them in HBM
             unsigned long long *pk = bigScratch + bigOff[b];           // [2*P]: keys then values
@@ -1557,11 +1586,11 @@ __global__ void arenaStartKernel(const uint32_t *__restrict__ lineBeg, uint32_t 
         arenaStart[j] = (uint64_t) lineBeg[std::min(j * bpb, nBuckets - 1)] * RPL;
 }
 // scratch need of the aggregation kernel per bucket (buckets beyond its LDS capacity): 2 * pow2ceil(records) 8-byte words
-__global__ void bigNeedKernel(const uint32_t *__restrict__ lineCnt, uint32_t nBuckets, uint64_t *__restrict__ need) {
+__global__ void bigNeedKernel(const uint32_t *__restrict__ lineCnt, const uint32_t *__restrict__ unique, uint32_t nBuckets, uint64_t *__restrict__ need) {
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nBuckets; b += gridDim.x * blockDim.x) {
         const uint64_t c = (uint64_t) lineCnt[b] * RPL;
         uint64_t v = 0;
-        if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; v = 2 * P; }
+        if (unique[b] == AGG_NEEDS_SCRATCH) { uint64_t P = 1; while (P < c) P <<= 1; v = 2 * P; }      // only what pass 1 left over
         need[b] = v;
     }
 }
@@ -1822,15 +1851,21 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         dTripleStart.alloc(((size_t) nSort + 2) * 8) != hipSuccess || dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess || dSparse.alloc(sortCap * RPL * sizeof(Triple)) != hipSuccess) {
         setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE;
     }
-    hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>());
+    // pass 1: every bucket aggregated in LDS (no scratch); pass 2: the few buckets with more distinct triples than LDS holds
+    const AggLines aggLn{sortList, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>()};
+    const unsigned aggGrid = std::min<uint32_t>(nSort, (uint32_t) numCU * (uint32_t) tuneInt("AGGSORT", 16));
+    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
+                       (unsigned long long *) nullptr, (const uint64_t *) nullptr, dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn);
+    hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>());
     if (exclusiveScanU64(st, dBigNeed.as<uint64_t>(), dBigOff.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t bigTot = 0;
     PH_COPY_SYNC(st, &bigTot, dBigOff.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
     PH_CHECK(hipGetLastError());
-    if (dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(std::min<uint32_t>(nSort, (uint32_t) numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
-                       (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort, dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(),
-                       dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, AggLines{sortList, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>()});
+    if (bigTot) {
+        if (dBigScratch.alloc(bigTot * 8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
+                           dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(), dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn);
+    }
     if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t nTriples = 0;
     PH_COPY_SYNC(st, &nTriples, dTripleStart.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
@@ -2002,7 +2037,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // it, and owns the representatives / queries [repBase, repBase + ownedN)
     const plasship_comm *cm = commOf(ctx);
     const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
-    const uint64_t repBase = ownedBegin(N, rk, W), ownedN = ownedBegin(N, rk + 1, W) - repBase;
+    const uint64_t repBase = ownedBegin(N, rk, W);
 
     // ---- slot bounds + offsets ----
     DevBuf dBound, dSlotOff, dScanTmp;
@@ -2522,9 +2557,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
         PH_CHECK(hipMemcpyAsync(dBigOff.p, bigOff.data(), (size_t) nSortBuckets * 8, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, false>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
-                       (const void *) cur, other, dSortStart, nSortBuckets, dBigScratch.as<unsigned long long>(), dBigOff.as<uint64_t>(),
-                       dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0), AggLines{nullptr, nullptr, nullptr});
+    // pass 1 aggregates every bucket in LDS; pass 2 revisits the buckets it flagged (more distinct triples than LDS holds)
+    for (int pass = 0; pass < 2; pass++)
+        hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, false>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
+                           (const void *) cur, other, dSortStart, nSortBuckets, pass ? dBigScratch.as<unsigned long long>() : (unsigned long long *) nullptr, (const uint64_t *) dBigOff.as<uint64_t>(),
+                           dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0), AggLines{nullptr, nullptr, nullptr});
     DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
     if (dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSortBuckets, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
