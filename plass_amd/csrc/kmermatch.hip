@@ -142,8 +142,22 @@ __device__ __forceinline__ bool kmerFromCodes(F codeAt, int k, unsigned char xCo
 // base^i): two unaligned 8-byte LDS reads fetch all k <= 14 codes, an 'X' is found with a SWAR zero-byte test, the sum is two
 // 24-bit Horner halves (base <= 16 keeps every partial sum below 2^24) joined by one 32x32->64 multiply-add.  The window
 // loop is issue bound; this replaces 14 LDS byte reads and 14 64-bit multiply-adds per window.
+__device__ __forceinline__ bool kmerIndexCore(uint64_t w0, uint64_t w1, int k, unsigned xCode, uint32_t base, uint32_t base7, uint64_t &kmer);
 __device__ __forceinline__ bool kmerIndexFast(const unsigned char *w, int k, unsigned xCode, uint32_t base, uint32_t base7, uint64_t &kmer) {
     uint64_t w0, w1; __builtin_memcpy(&w0, w, 8); __builtin_memcpy(&w1, w + 8, 8);
+    return kmerIndexCore(w0, w1, k, xCode, base, base7, kmer);
+}
+// the same from a 4-byte-aligned LDS array: five aligned dword reads and four v_alignbyte_b32 fetch the 16 codes of the window at
+// byte p (a byte pointer makes the compiler read LDS byte by byte: 16 ds_read_u8 and their shifts per window)
+__device__ __forceinline__ bool kmerIndexFastAligned(const unsigned char *codes, uint32_t p, int k, unsigned xCode, uint32_t base, uint32_t base7, uint64_t &kmer) {
+    const uint32_t *w = reinterpret_cast<const uint32_t *>(codes + (p & ~3u));
+    const uint32_t sh = p & 3u;
+    const uint32_t W0 = w[0], W1 = w[1], W2 = w[2], W3 = w[3], W4 = w[4];
+    const uint32_t d0 = __builtin_amdgcn_alignbyte(W1, W0, sh), d1 = __builtin_amdgcn_alignbyte(W2, W1, sh),
+                   d2 = __builtin_amdgcn_alignbyte(W3, W2, sh), d3 = __builtin_amdgcn_alignbyte(W4, W3, sh);
+    return kmerIndexCore((uint64_t) d0 | ((uint64_t) d1 << 32), (uint64_t) d2 | ((uint64_t) d3 << 32), k, xCode, base, base7, kmer);
+}
+__device__ __forceinline__ bool kmerIndexCore(uint64_t w0, uint64_t w1, int k, unsigned xCode, uint32_t base, uint32_t base7, uint64_t &kmer) {
     const uint64_t m0 = (k >= 8) ? ~0ULL : ((1ULL << (8 * k)) - 1ULL);
     const uint64_t m1 = (k <= 8) ? 0ULL : ((1ULL << (8 * (k - 8))) - 1ULL);       // k <= 14
     w0 &= m0; w1 &= m1;
@@ -228,7 +242,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
     __shared__ unsigned long long sSet[FALLBACK ? 1 : 2 * CAP];     // duplicate-k-mer detection without sorting (after the passes)
     __shared__ unsigned short sScoreBig[(RESL > 4 * CAP && !FALLBACK) ? RESL : 1];
     unsigned short *sScore = (RESL > 4 * CAP) ? sScoreBig : reinterpret_cast<unsigned short *>(sSet); // per-window hash scores (during the passes; aliases the set when 2*CAP*8 >= RESL*2 bytes)
-    __shared__ unsigned char sCodeAll[FALLBACK ? 1 : CODES];          // codes of a resident sequence
+    __shared__ __attribute__((aligned(16))) unsigned char sCodeAll[FALLBACK ? 1 : CODES];          // codes of a resident sequence
+    __shared__ unsigned long long sPow64[(REGS > 0 && !FALLBACK) ? REGS + 2 : 1];                  // 31^(64 q) (identity hash of the register front end)
     __shared__ unsigned long long sValid[RESL / 64 + 2];             // per-tile validity masks
     typedef Rec<LONG> R;
     R *arr = reinterpret_cast<R *>(a.arr);
@@ -240,6 +255,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
     uint64_t pow31 = 1;                                    // 31^lane
     unsigned long long stRes = 0, stRec = 0;
     for (int i = 0; i < lane; i++) pow31 *= 31;
+    // register front end: 31^(63 - lane), the inverse of 31^64 modulo 2^64 and 31^(64 q) — the identity hash
+    // h = sum code[p] * 31^(L-1-p) is then one running product per lane and ONE wave reduction per sequence
+    uint64_t pow31rev = 0, inv64 = 0;
+    if (REGS > 0 && !FALLBACK) {
+        pow31rev = __shfl(pow31, 63 - lane, 64);
+        const uint64_t p64 = __shfl(pow31, 63, 64) * 31ull;                       // 31^64 (odd: invertible mod 2^64)
+        uint64_t iv = p64; for (int i = 0; i < 6; i++) iv *= 2ull - p64 * iv;     // Newton: doubles the correct low bits each step
+        inv64 = iv;
+        if (lane == 0) { uint64_t t = 1; for (int q = 0; q < REGS + 2; q++) { sPow64[q] = t; t *= p64; } }
+        __syncthreads();
+    }
 
     const uint32_t nWork = FALLBACK ? a.nIds : (a.waveList ? *a.waveCount : (a.idHi - a.idLo));
     auto idAt = [&](uint32_t w) { return a.waveList ? a.waveList[w] : (a.idLo + w); };
@@ -306,23 +332,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
                 sCodeAll[i] = (i < L) ? sMap[(unsigned char) ch] : (unsigned char) a.xCode;
             }
             __syncthreads();
-            // identity hash, tile-wise Horner: h = h*31^m + sum code[j]*31^(m-1-j) (Util::hash, Util.h:337-345)
-            for (uint32_t t0 = 0; t0 < L; t0 += 64) {
-                const uint32_t p = t0 + lane;
-                const unsigned char c = (p < L) ? sCodeAll[p] : (unsigned char) a.xCode;
-                const uint32_t m = min(64u, L - t0);
-                const uint64_t pw = __shfl(pow31, (int) (m - 1 - min((uint32_t) lane, m - 1)), 64);
-                uint64_t term = ((uint32_t) lane < m) ? (uint64_t) c * pw : 0ull;
-                term = waveReduceSumU64(term);
-                const uint64_t pm = __shfl(pow31, (int) (m - 1), 64) * 31ull;      // 31^m
-                seqHash = seqHash * pm + term;
+            // identity hash (Util::hash, Util.h:337-345: h = h*31 + code, i.e. sum code[p] * 31^(L-1-p) modulo 2^64): lane l owns the
+            // positions l, l + 64, …; its power starts at 31^(L-1-l) and shrinks by 31^64 (a multiplication by the inverse) per step
+            {
+                uint64_t pw;
+                if (L >= 64) { const uint32_t e = L - 64; pw = sPow64[e >> 6] * __shfl(pow31, (int) (e & 63u), 64) * pow31rev; }
+                else pw = ((uint32_t) lane < L) ? __shfl(pow31, (int) (L - 1 - min((uint32_t) lane, L - 1)), 64) : 0ull;
+                uint64_t acc = 0;
+                for (uint32_t t0 = 0; t0 < L; t0 += 64) {
+                    const uint32_t p = t0 + lane;
+                    if (p < L) acc += (uint64_t) sCodeAll[p] * pw;
+                    pw *= inv64;
+                }
+                seqHash = waveReduceSumU64(acc);
             }
             auto windowKmer = [&](uint32_t p, uint64_t &kmer, uint32_t &pos) -> bool {
                 pos = p; kmer = 0;
-                if (!NUCL && fastIdx) return kmerIndexFast(&sCodeAll[p], k, (unsigned) a.xCode, (uint32_t) a.powers[1], (uint32_t) a.powers[7], kmer);
+                if (!NUCL && fastIdx) return kmerIndexFastAligned(sCodeAll, p, k, (unsigned) a.xCode, (uint32_t) a.powers[1], (uint32_t) a.powers[7], kmer);
                 if (NUCL && a.xCode == 4) return kmerNuclCanonical(&sCodeAll[p], k, L, p, kmer, pos);
                 return kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
             };
+            uint32_t *sPick = reinterpret_cast<uint32_t *>(sSet);     // [cap] (score << 16 | window) of the candidates; the set is not in use yet
             // ---- one score per window, in registers: 0xFFFFFFFF = no k-mer here ----
             const uint32_t nWinU = (uint32_t) __builtin_amdgcn_readfirstlane((int) nWin);     // wave-uniform loop guards stay scalar
             uint32_t sc[REGS > 0 ? REGS : 1];
@@ -366,13 +396,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
                         const unsigned long long mask = __ballot(push);
                         const uint32_t rank = (uint32_t) __popcll(mask & ((1ULL << lane) - 1ULL));
                         const uint32_t cnt = (uint32_t) __popcll(mask);
+                        // (window, score) of the candidates first; their k-mers are rebuilt below, once per candidate — under this
+                        // loop the whole wavefront would rebuild them in every round
                         if (C + cnt > cap) overflow = true;
-                        else if (push) {
-                            Cand cd; uint32_t pos; (void) windowKmer((uint32_t) j * 64u + (uint32_t) lane, cd.kmer, pos);
-                            cd.pos = pos; cd.score = sc[j]; cand[C + rank] = cd;
-                        }
+                        else if (push) sPick[C + rank] = (sc[j] << 16) | ((uint32_t) j * 64u + (uint32_t) lane);
                         C += cnt;
                     }
+                }
+            }
+            __syncthreads();
+            if (!overflow) {
+                for (uint32_t i = lane; i < C; i += 64) {
+                    const uint32_t pk = sPick[i];
+                    Cand cd; uint32_t pos; (void) windowKmer(pk & 0xFFFFu, cd.kmer, pos);
+                    cd.pos = pos; cd.score = pk >> 16; cand[i] = cd;
                 }
             }
             __syncthreads();
