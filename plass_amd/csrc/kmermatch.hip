@@ -90,6 +90,8 @@ struct ExtractArgs {
     uint64_t slotBias;              // subtracted from every slot offset (re-extraction of one sequence into a scratch array;
                                     // sharded run: first slot of this rank's id range)
     uint32_t idLo, idHi;            // regular launch without a wave list: ids [idLo, idHi) (sharded run: this rank's share)
+    int dbgSkip;                    // development aid (PLASSHIP_DBG_EXTRACT_SKIP, tools/extract_probe.py): parts of the register front end to
+                                    // leave out when timing it — results are WRONG with any bit set; 0 in every normal run
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
             __syncthreads();
             // identity hash (Util::hash, Util.h:337-345: h = h*31 + code, i.e. sum code[p] * 31^(L-1-p) modulo 2^64): lane l owns the
             // positions l, l + 64, …; its power starts at 31^(L-1-l) and shrinks by 31^64 (a multiplication by the inverse) per step
-            {
+            if (!(a.dbgSkip & 1)) {
                 uint64_t pw;
                 if (L >= 64) { const uint32_t e = L - 64; pw = sPow64[e >> 6] * __shfl(pow31, (int) (e & 63u), 64) * pow31rev; }
                 else pw = ((uint32_t) lane < L) ? __shfl(pow31, (int) (L - 1 - min((uint32_t) lane, L - 1)), 64) : 0ull;
@@ -363,7 +365,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
                     const uint32_t p = (uint32_t) j * 64u + (uint32_t) lane;
                     if (p < nWin) {
                         uint64_t kmer; uint32_t pos;
-                        if (windowKmer(p, kmer, pos)) sc[j] = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
+                        if (a.dbgSkip & 32) sc[j] = (p * 2654435761u) >> 16;
+                        else if (windowKmer(p, kmer, pos)) sc[j] = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
                     }
                     n += (uint32_t) __popcll(__ballot(sc[j] != 0xFFFFFFFFu));
                 }
@@ -373,6 +376,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
                 // the reference walks 65 536 score bins until `considered` k-mers are covered (kmermatcher.cpp:224-239): s* is the
                 // considered-th smallest score = the largest t with fewer than `considered` scores below it
                 uint32_t t = 0;
+                if (a.dbgSkip & 2) t = (uint32_t) ((65536ull * considered) / (n ? n : 1));
+                else
 #pragma unroll 1
                 for (int bit = 15; bit >= 0; bit--) {
                     const uint32_t tr = t | (1u << bit);
@@ -408,11 +413,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
             if (!overflow) {
                 for (uint32_t i = lane; i < C; i += 64) {
                     const uint32_t pk = sPick[i];
-                    Cand cd; uint32_t pos; (void) windowKmer(pk & 0xFFFFu, cd.kmer, pos);
+                    Cand cd; uint32_t pos = 0; cd.kmer = pk;
+                    if (!(a.dbgSkip & 4)) (void) windowKmer(pk & 0xFFFFu, cd.kmer, pos);
                     cd.pos = pos; cd.score = pk >> 16; cand[i] = cd;
                 }
             }
             __syncthreads();
+            if (a.dbgSkip & 64) continue;
         } else {
         // pass 0: all candidates pushed / or coarse histogram; pass 1: fine histogram; pass 2: push score <= s*
         const int nPass = allCand ? 1 : 3;
@@ -531,8 +538,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
         }
         // ---- fast path: when no candidate k-mer repeats and the threshold bin has no surplus, the reference's
         //      sort + walk selects exactly the candidate set (C == considered), in an order that does not matter ----
-        bool needOrder = (tooMuch != 0);
-        if (!needOrder && a.ignoreMulti && C > 1) {
+        bool needOrder = (tooMuch != 0) && !(a.dbgSkip & 8);
+        if (!needOrder && a.ignoreMulti && C > 1 && !(a.dbgSkip & 8)) {
             if (FALLBACK) needOrder = true;
             else {
                 for (uint32_t i = lane; i < 2 * CAP; i += 64) sSet[i] = ~0ULL;
@@ -553,6 +560,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ?
             }
         }
         if (!needOrder) {
+            if (a.dbgSkip & 16) { stRes += L; stRec += 1 + C; __syncthreads(); continue; }
             for (uint32_t i = lane; i < C; i += 64) {
                 const Cand cd = cand[i];
                 R r; r.kmer = cd.kmer; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) cd.pos;
@@ -1198,7 +1206,7 @@ struct AggLines { const uint32_t *list, *lineBeg, *lineCnt; };
 template <bool NUCL, bool LONG, bool LINES>
 __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void *outTriples, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
                                                           unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
-                                                          uint32_t *__restrict__ uniqueCount, int localBits, int idBits, uint64_t repBase, AggLines ln) {
+                                                          uint32_t *__restrict__ uniqueCount, int localBits, int idBits, uint64_t repBase, AggLines ln, int scrambleBits) {
     typedef Rec<LONG> R;
     __shared__ unsigned long long hKey[AGG_HT];
     __shared__ uint32_t hVal[AGG_HT];
@@ -1223,12 +1231,14 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
             t.diag = (int32_t) ((int64_t) (key & ((1ULL << DB) - 1)) - DiagPack<LONG>::BIAS);
             const uint64_t k2 = key >> DB;
             t.target = (uint32_t) (k2 & ((1ULL << idBits) - 1));
-            t.rep = (uint32_t) ((k2 >> idBits) + baseRep);
+            const uint64_t rp = (k2 >> idBits) + baseRep;
+            t.rep = (uint32_t) (scrambleBits ? scrambleRep(rp, scrambleBits) : rp);       // an involution: back to the id
             t.cnt = val;
             return t;
         };
         auto packRec = [&](const R &r, uint32_t &val) {
-            const uint64_t rep = r.kmer & ~BIT63;
+            uint64_t rep = r.kmer & ~BIT63;
+            if (scrambleBits) rep = scrambleRep(rep, scrambleBits);            // buckets are ranges of the bit-reversed id (linepart.hpp)
             val = 1u | ((NUCL && (r.kmer & BIT63)) ? 0x80000000u : 0u);
             return (unsigned long long) (((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS));
         };
@@ -1398,6 +1408,31 @@ __global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__rest
     for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
         const uint64_t s0 = lineBeg ? (uint64_t) lineBeg[b] * RPL : bucketStart[b], d0 = tripleStart[b], n = tripleStart[b + 1] - d0;
         for (uint64_t i = laneId(); i < n; i += 64) out[d0 + i] = in[s0 + i];
+    }
+}
+
+// line-store path: the triples of bucket b lie at in[lineBeg[b] * RPL ...] (unique[b] of them), grouped by representative.  Every
+// representative occurs in exactly one bucket: its run length and position go to cnt[rep] / pos[rep] (cnt is zeroed beforehand).
+__global__ __launch_bounds__(256) void repRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
+                                                     uint32_t *__restrict__ cnt, uint64_t *__restrict__ pos) {
+    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {     // one wave per bucket
+        const uint64_t s0 = (uint64_t) lineBeg[b] * RPL; const uint32_t n = unique[b];
+        for (uint32_t i = laneId(); i < n; i += 64) {
+            const uint32_t rep = in[s0 + i].rep;
+            if (i == 0 || in[s0 + i - 1].rep != rep) {
+                uint32_t len = 1; while (i + len < n && in[s0 + i + len].rep == rep) len++;
+                cnt[rep] = len; pos[rep] = s0 + i;
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void placeRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ pos,
+                                                       const uint64_t *__restrict__ start, uint32_t n, Triple *__restrict__ out) {
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const uint32_t c = cnt[r];
+        if (!c) continue;
+        const uint64_t s = pos[r], d = start[r];
+        for (uint32_t j = 0; j < c; j++) out[d + j] = in[s + j];
     }
 }
 
@@ -1856,7 +1891,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     if (nPR1) PH_CHECK(hipMemcpyAsync(dRPieces.p, hp.data(), (size_t) nPR1 * sizeof(LinePiece), hipMemcpyHostToDevice, st));
     else PH_CHECK(hipMemsetAsync(dRTag1.p, 0xFF, capR1 * 4, st));                       // nothing grouped: no piece will write the tag array
     PH_CHECK(hipMemcpyAsync(dRNP.p, &nPR1, 4, hipMemcpyHostToDevice, st));
-    LineKey rkey; rkey.rangeBits = repBits; rkey.repBase = 0; rkey.shift = s1 ? 64 - s1 : 63;
+    LineKey rkey; rkey.rangeBits = repBits; rkey.repBase = 0; rkey.shift = s1 ? 64 - s1 : 63; rkey.scrambleBits = idBits;      // ranges of the bit-reversed id
     {
         LinePartArgs a; memset(&a, 0, sizeof(a));
         a.in = otherRecs; a.out = dR1.p; a.tags = dRTag1.as<uint32_t>(); a.pieces = dRPieces.as<LinePiece>(); a.nPieces = dRNP.as<uint32_t>(); a.nb = nS1; a.key = rkey;
@@ -1892,7 +1927,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     const AggLines aggLn{sortList, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>()};
     const unsigned aggGrid = std::min<uint32_t>(nSort, (uint32_t) numCU * (uint32_t) tuneInt("AGGSORT", 16));
     hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
-                       (unsigned long long *) nullptr, (const uint64_t *) nullptr, dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn);
+                       (unsigned long long *) nullptr, (const uint64_t *) nullptr, dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn, idBits);
     hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>());
     if (exclusiveScanU64(st, dBigNeed.as<uint64_t>(), dBigOff.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t bigTot = 0;
@@ -1901,17 +1936,26 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     if (bigTot) {
         if (dBigScratch.alloc(bigTot * 8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
-                           dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(), dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn);
+                           dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(), dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn, idBits);
     }
-    if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    // every bucket now holds its representatives' triples, each representative's contiguous and in (target, diagonal) order, but
+    // the buckets are ranges of the bit-reversed id: count the triples per representative, prefix-sum over the ids, and move every
+    // run to its place in id order — the globally (rep, target, diagonal)-sorted array the run reduction walks
+    DevBuf dRepCnt, dRepPos, dRepStart, dScanTmp4;
+    const size_t scanTmp4Bytes = exclusiveScanTmpBytes((size_t) N + 2);
+    if (dRepCnt.alloc(((size_t) N + 1) * 4) != hipSuccess || dRepPos.alloc(((size_t) N + 1) * 8) != hipSuccess || dRepStart.alloc(((size_t) N + 2) * 8) != hipSuccess ||
+        dScanTmp4.alloc(scanTmp4Bytes) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dRepCnt.p, 0, ((size_t) N + 1) * 4, st));
+    hipLaunchKernelGGL(repRunsKernel, dim3(std::min<uint32_t>((nSort + 3) / 4, (uint32_t) numCU * 8)), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(),
+                       (const uint32_t *) dUnique.as<uint32_t>(), nSort, dRepCnt.as<uint32_t>(), dRepPos.as<uint64_t>());
+    if (exclusiveScanU32(st, dRepCnt.as<uint32_t>(), dRepStart.as<uint64_t>(), N, dScanTmp4.p, scanTmp4Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t nTriples = 0;
-    PH_COPY_SYNC(st, &nTriples, dTripleStart.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
+    PH_COPY_SYNC(st, &nTriples, dRepStart.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost);
     PH_CHECK(hipGetLastError());
-    // compact triples: into dA (free since the group kernel's arenas were consumed)
     dR1.release(); dR2.release();
     if (dA.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(Triple)) != hipSuccess) { setError("kmermatch: out of device memory for the sorted triples"); return PLASSHIP_ERR_DEVICE; }
-    hipLaunchKernelGGL(compactTriplesKernel, dim3(std::min<uint32_t>((nSort + 3) / 4, (uint32_t) numCU * 8)), dim3(256), 0, st,
-                       (const Triple *) dSparse.p, (const uint64_t *) nullptr, (const uint32_t *) dSortBeg.as<uint32_t>(), (const uint64_t *) dTripleStart.as<uint64_t>(), nSort, (Triple *) dA.p);
+    if (N) hipLaunchKernelGGL(placeRunsKernel, dim3(gridFor(N, 256, (unsigned) numCU * 32)), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dRepCnt.as<uint32_t>(),
+                              (const uint64_t *) dRepPos.as<uint64_t>(), (const uint64_t *) dRepStart.as<uint64_t>(), N, (Triple *) dA.p);
     res.msSort2 = tm.stop(1);
     PH_TRACE(st, "kmermatch: rep sort (line store)");
     PH_CHECK(hipGetLastError());
@@ -2120,6 +2164,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(dMap.p, map, 256, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));
     ExtractArgs ea; memset(&ea, 0, sizeof(ea));
+    { static const int dbg = [] { const char *e = getenv("PLASSHIP_DBG_EXTRACT_SKIP"); return e ? atoi(e) : 0; }(); ea.dbgSkip = dbg; }
     ea.s = db->view(); ea.slotOff = dSlotOff.as<uint64_t>(); ea.arr = dA.p; ea.map = dMap.as<unsigned char>();
     const int alph = NUCL ? 5 : par->alphabet_size;
     { uint64_t p = 1; for (int i = 0; i < 24; i++) { ea.powers[i] = p; p *= (uint64_t) (alph - 1); } }
@@ -2598,7 +2643,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     for (int pass = 0; pass < 2; pass++)
         hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, false>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
                            (const void *) cur, other, dSortStart, nSortBuckets, pass ? dBigScratch.as<unsigned long long>() : (unsigned long long *) nullptr, (const uint64_t *) dBigOff.as<uint64_t>(),
-                           dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0), AggLines{nullptr, nullptr, nullptr});
+                           dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0), AggLines{nullptr, nullptr, nullptr}, 0);
     DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
     if (dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSortBuckets, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }

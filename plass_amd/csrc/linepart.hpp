@@ -62,10 +62,26 @@ constexpr uint32_t LP_MAXB = 1024;           // buckets per level (LDS: nb * RPL
 struct LineKey {
     int shift, rangeBits;        // KEY_HASH: bucket = (mix >> shift) & (nb - 1);  KEY_RANGE: ((rep - repBase) << (64 - rangeBits)) >> shift
     uint64_t repBase;
+    int scrambleBits;            // KEY_RANGE, != 0: the ranges are taken on the bit-REVERSED rep id (scrambleRep)
 };
+// The representative of a k-mer group is its longest sequence and, among equally long ones, the one with the SMALLEST id
+// (kmermatcher.cpp:450-559).  In iteration 0 all fragments are ~50 residues, so representatives pile up at the low end of the id
+// range (the minimum of ~25 uniform ids) and equal-width id ranges would put half of the grouped records into 3 % of the buckets.
+// The rep sort therefore ranges over the bit-reversed id — a bijection on [0, 2^bits) whose top bits are the id's evenly spread
+// low bits; every representative's triples still end up contiguous and sorted, and are moved to the representative's place in id
+// order afterwards (placeRunsKernel, kmermatch.hip).
+__device__ __host__ __forceinline__ uint64_t scrambleRep(uint64_t rep, int bits) {
+    uint32_t x = (uint32_t) rep;
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1); x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4); x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    x = (x >> 16) | (x << 16);
+    return (uint64_t) (x >> (32 - bits));      // an involution on [0, 2^bits): applying it again gives the id back
+}
 template <bool NUCL, int MODE> __device__ __forceinline__ uint32_t lineBucket(const LineKey &k, uint64_t kmerField, uint32_t nb) {
     if (MODE == KEY_HASH) return (uint32_t) (kmerMix<NUCL>(kmerField) >> k.shift) & (nb - 1);
-    return (uint32_t) ((((kmerField & ~BIT63) - k.repBase) << (64 - k.rangeBits)) >> k.shift) & (nb - 1);   // left-aligned rep id: top bits = id range
+    uint64_t r = (kmerField & ~BIT63) - k.repBase;
+    if (k.scrambleBits) r = scrambleRep(r, k.scrambleBits);
+    return (uint32_t) ((r << (64 - k.rangeBits)) >> k.shift) & (nb - 1);   // left-aligned rep id: top bits = id range
 }
 
 // a piece of input and the output range it owns

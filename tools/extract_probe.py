@@ -22,7 +22,8 @@ def main():
     total = int(float(sys.argv[1])) if len(sys.argv) > 1 else 400_000_000
     ctx = plass_amd.Context(0)
     print("%6s %9s | %10s %10s | %12s %12s | %s" % ("L", "seqs", "short ms", "wave ms", "ns/seq", "ps/window", "stage ms: part group sort reduce"))
-    for L in (48, 60, 80, 100, 150, 250, 400, 700, 1000, 1500, 2500):
+    lens = [int(x) for x in os.environ.get("PROBE_LENGTHS", "48,60,80,100,150,250,400,700,1000,1500,2500").split(",")]
+    for L in lens:
         n = max(1000, total // L)
         data, off, elen, key = make_db(n, L, 7 + L)
         db = ctx.upload_seqdb(data, off, elen, key, 0)
