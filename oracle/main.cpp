@@ -8,8 +8,11 @@
 //   plass_oracle proteinaln2nucl <qNuclDB> <tNuclDB> <qAaDB> <tAaDB> <alnDB> <outAlnDB> [flags]
 //   plass_oracle findassemblystart <seqDB> <alnDB> <outSeqDB>
 //   plass_oracle cyclecheck <seqDB> <outCycleDB> [--max-seq-len N --chop-cycle 0|1]
+//   plass_oracle synthreads <outReadDB> --pairs N [--seed S --genomes G --genome-min-len A --genome-max-len B --abundance-sigma X …]
+//       the synthetic read pairs of include/plasship_synth.h, byte for byte what plasship_synth_read_pairs makes on the GPU
 //   plass_oracle extractorfs <seqDB> <outDB> [flags] | translatenucs <nuclDB> <outAaDB> [--add-orf-stop 1] | concatdbs <dbA> <dbB> <outDB>
 #include "oracle.hpp"
+#include "../plass_amd/csrc/synth_core.hpp"   // the read model of include/plasship_synth.h (measurement infrastructure shared with the GPU generator)
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -89,8 +92,50 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
 
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// synthetic read pairs on the CPU: the same functions the GPU generator runs (plass_amd/csrc/synth_core.hpp), one loop iteration per base / read
+static int synthreads(int argc, char **argv) {
+    uint64_t pairs = 0, seed = 1, gmin = 7500000, gmax = 7500000; uint32_t genomes = 1, insertMin = 160, readLen = 150;
+    float sigma = 0.0f, insertMean = 320.0f, insertSd = 40.0f, errorRate = 0.002f; std::string out;
+    for (int i = 2; i < argc; i++) {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) == 0) {
+            if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); return 1; }
+            const char *v = argv[++i];
+            if (a == "--pairs") pairs = strtoull(v, nullptr, 10); else if (a == "--seed") seed = strtoull(v, nullptr, 10);
+            else if (a == "--genomes") genomes = (uint32_t) strtoul(v, nullptr, 10); else if (a == "--genome-min-len") gmin = strtoull(v, nullptr, 10);
+            else if (a == "--genome-max-len") gmax = strtoull(v, nullptr, 10); else if (a == "--abundance-sigma") sigma = strtof(v, nullptr);
+            else if (a == "--insert-mean") insertMean = strtof(v, nullptr); else if (a == "--insert-sd") insertSd = strtof(v, nullptr);
+            else if (a == "--insert-min") insertMin = (uint32_t) strtoul(v, nullptr, 10); else if (a == "--read-len") readLen = (uint32_t) strtoul(v, nullptr, 10);
+            else if (a == "--error-rate") errorRate = strtof(v, nullptr);
+            else { fprintf(stderr, "synthreads: unknown flag %s\n", a.c_str()); return 1; }
+        } else out = a;
+    }
+    if (out.empty() || pairs == 0 || genomes == 0 || gmax < gmin || gmin < 4ull * (uint64_t) (insertMean + 8 * insertSd + readLen)) { fprintf(stderr, "synthreads <outReadDB> --pairs N [...]\n"); return 1; }
+    plasship::SynthCommunity c; c.build(seed, genomes, gmin, gmax, sigma);
+    std::vector<char> genome(c.total + 64);
+    plasship::SynthGenome sg; sg.geneStart = c.geneStart.data(); sg.geneCodons = c.geneCodons.data(); sg.nGenes = c.geneCodons.size(); sg.totalBases = c.total; sg.seed = seed;
+#pragma omp parallel for schedule(static)
+    for (int64_t x = 0; x < (int64_t) c.total; x++) genome[x] = plasship::synthGenomeBase(sg, (uint64_t) x);
+    const uint64_t nReads = 2 * pairs; const uint32_t entry = readLen + 2;
+    DB db; db.dbtype = DBTYPE_NUCLEOTIDES; db.key.resize(nReads); db.off.resize(nReads + 1); db.elen.resize(nReads); db.data.resize(nReads * entry);
+    std::vector<uint32_t> len(nReads);
+    plasship::SynthReads sr; memset(&sr, 0, sizeof(sr));
+    sr.genome = genome.data(); sr.genomeStart = c.gStart.data(); sr.cum = c.cum.data(); sr.nGenomes = genomes; sr.readLen = readLen; sr.insertMin = insertMin;
+    sr.insertMean = insertMean; sr.insertSd = insertSd; sr.errThresh = (uint32_t) ((double) errorRate * 1073741824.0); sr.nPairs = pairs; sr.seed = seed;
+    sr.out = &db.data[0]; sr.off = db.off.data(); sr.len = len.data(); sr.key = db.key.data();
+#pragma omp parallel for schedule(static)
+    for (int64_t r = 0; r < (int64_t) nReads; r++) plasship::synthRead(sr, (uint64_t) r);
+    db.off.resize(nReads);
+    for (uint64_t r = 0; r < nReads; r++) db.elen[r] = entry;
+    std::string err;
+    if (!writeDB(out, db, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+    fprintf(stderr, "oracle synthreads: %llu reads, %llu genome bases, %zu genes\n", (unsigned long long) nReads, (unsigned long long) c.total, c.geneCodons.size());
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: plass_oracle <module> <dbs…> [flags]\n"); return 1; }
+    if (std::string(argv[1]) == "synthreads") return synthreads(argc, argv);
     std::string mod = argv[1];
     Params par; std::vector<std::string> pos; std::string err;
     // module defaults: kmermatcher's setLinearFilterDefault sets covThr 0.8 (kmermatcher.cpp:566-573);
