@@ -10,6 +10,9 @@
 //   plass_oracle cyclecheck <seqDB> <outCycleDB> [--max-seq-len N --chop-cycle 0|1]
 //   plass_oracle synthreads <outReadDB> --pairs N [--seed S --genomes G --genome-min-len A --genome-max-len B --abundance-sigma X …]
 //       the synthetic read pairs of include/plasship_synth.h, byte for byte what plasship_synth_read_pairs makes on the GPU
+//   plass_oracle dbsum <DB>…   entries, data bytes and an order-independent digest (sum over entries of a 64-bit hash of key, length and
+//       bytes) of each DB: the large parity tests compare DBs of hundreds of megabytes through it, whatever the order of the entries in the
+//       data file
 //   plass_oracle extractorfs <seqDB> <outDB> [flags] | translatenucs <nuclDB> <outAaDB> [--add-orf-stop 1] | concatdbs <dbA> <dbB> <outDB>
 #include "oracle.hpp"
 #include "../plass_amd/csrc/synth_core.hpp"   // the read model of include/plasship_synth.h (measurement infrastructure shared with the GPU generator)
@@ -133,8 +136,28 @@ static int synthreads(int argc, char **argv) {
     return 0;
 }
 
+static int dbsum(int argc, char **argv) {
+    for (int i = 2; i < argc; i++) {
+        DB db; std::string err;
+        if (!readDB(argv[i], db, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        uint64_t sum = 0, bytes = 0;
+        const int64_t n = (int64_t) db.size();
+#pragma omp parallel for schedule(static) reduction(+ : sum, bytes)
+        for (int64_t e = 0; e < n; e++) {
+            const unsigned char *p = (const unsigned char *) db.entry((size_t) e); const uint32_t len = db.elen[e];
+            uint64_t h = 0xCBF29CE484222325ull ^ ((uint64_t) db.key[e] * 0x9E3779B97F4A7C15ull) ^ ((uint64_t) len << 40);
+            for (uint32_t j = 0; j < len; j++) { h ^= p[j]; h *= 0x100000001B3ull; }                 // FNV-1a over the entry as indexed (with its '\0')
+            h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+            sum += h; bytes += len;
+        }
+        printf("%s\tentries=%zu\tbytes=%llu\tdbtype=%d\tdigest=%016llx\n", argv[i], db.size(), (unsigned long long) bytes, db.dbtype, (unsigned long long) sum);
+    }
+    return 0;
+}
+
 int main(int argc, char **argv) {
     if (argc < 2) { fprintf(stderr, "usage: plass_oracle <module> <dbs…> [flags]\n"); return 1; }
+    if (std::string(argv[1]) == "dbsum") return dbsum(argc, argv);
     if (std::string(argv[1]) == "synthreads") return synthreads(argc, argv);
     std::string mod = argv[1];
     Params par; std::vector<std::string> pos; std::string err;

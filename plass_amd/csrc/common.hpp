@@ -4,6 +4,7 @@
 #include <cstdint>
 #include <cstddef>
 #include <cstdio>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/plasship.h"
@@ -106,6 +107,11 @@ struct plasship_ctx {
     plasship::DevBuf d_ambKeys, d_ambVals;
     plasship::DevBuf d_cmpCache;        // memo of the nucleotide comparator's posterior classes (assemble.hip, nuclLess)
     uint32_t ambSlots = 0;              // power of two, 0 = no table yet
+    // host boundary: two pinned staging buffers (allocated on first use) every bulk host<->device copy goes through — a chunk is
+    // packed / consumed on the host threads while the previous one is on the PCIe link (stagedUpload / stagedDownload, core.hip)
+    char *stage[2] = {nullptr, nullptr};
+    hipEvent_t stageEv[2] = {nullptr, nullptr};
+    size_t stageBytes = 0;
     // one read set sharded over several GPUs (plasship_ctx_set_comm); world == 1 and hasComm == false: single GPU
     bool hasComm = false;
     plasship_comm comm = {};
@@ -172,6 +178,16 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
 int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                   const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
                   const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr);
+// ---- host boundary (core.hip): bulk copies through the context's pinned double buffer, on the context stream ----
+// H2D of `total` bytes the caller produces chunk by chunk: produce(dst, byteOffset, bytes) fills a pinned chunk (consecutive chunks,
+// in order; it may use the host threads) while the previous chunk is in flight.  Returns after the last copy has completed.
+int stagedUpload(plasship_ctx *ctx, void *dDst, uint64_t total, const std::function<void(char *, uint64_t, uint64_t)> &produce);
+// D2H: consume(src, byteOffset, bytes) sees consecutive chunks in order (false aborts with PLASSHIP_ERR_IO); the next chunk is
+// already being copied while it runs
+int stagedDownload(plasship_ctx *ctx, const void *dSrc, uint64_t total, const std::function<bool(const char *, uint64_t, uint64_t)> &consume);
+// plain arrays: host -> device / device -> host through the staging buffers (memcpy on the host threads)
+int stagedCopyToDevice(plasship_ctx *ctx, void *dDst, const void *hSrc, uint64_t bytes);
+int stagedCopyToHost(plasship_ctx *ctx, void *hDst, const void *dSrc, uint64_t bytes);
 // sets *differ when two key arrays (device, n entries) are not identical
 int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, size_t n, bool *differ);
 }

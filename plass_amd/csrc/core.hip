@@ -4,6 +4,7 @@
 #include "common.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <chrono>
 #include <cstdio>
@@ -219,6 +220,7 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
+    for (int i = 0; i < 2; i++) { if (ctx->stage[i]) (void) hipHostFree(ctx->stage[i]); if (ctx->stageEv[i]) (void) hipEventDestroy(ctx->stageEv[i]); }
     if (ctx->stream) { poolForgetStream(ctx->stream); (void) hipStreamDestroy(ctx->stream); }
     bool last; { std::lock_guard<std::mutex> g(g_poolMu); last = (--g_ctxCount <= 0); }
     if (last) {
@@ -234,6 +236,71 @@ extern "C" int plasship_ctx_sync(plasship_ctx *ctx) {
     return PLASSHIP_OK;
 }
 extern "C" void *plasship_ctx_stream(plasship_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+// ---- host boundary: pinned staging -------------------------------------------------------------------
+// Pageable memory reaches the GPU through a driver-side bounce buffer, one synchronous chunk at a time; here the bounce buffers are
+// ours (pinned, 2 x 32 MB per context), the host side of a chunk (packing entries into id order, memcpy into a caller's array,
+// fwrite) runs on the host threads while the other chunk is on the link, and nothing is allocated per call.
+namespace plasship {
+static int stageReady(plasship_ctx *ctx) {
+    if (ctx->stageBytes) return PLASSHIP_OK;
+    size_t want = 32u << 20;
+    if (const char *e = getenv("PLASSHIP_STAGE_MB")) { const long v = atol(e); if (v >= 1 && v <= 4096) want = (size_t) v << 20; }
+    for (int i = 0; i < 2; i++) {
+        PH_CHECK(hipHostMalloc((void **) &ctx->stage[i], want, hipHostMallocDefault));
+        PH_CHECK(hipEventCreateWithFlags(&ctx->stageEv[i], hipEventDisableTiming));
+    }
+    ctx->stageBytes = want;
+    return PLASSHIP_OK;
+}
+int stagedUpload(plasship_ctx *ctx, void *dDst, uint64_t total, const std::function<void(char *, uint64_t, uint64_t)> &produce) {
+    if (!total) return PLASSHIP_OK;
+    int rc = stageReady(ctx); if (rc) return rc;
+    const uint64_t CH = ctx->stageBytes; int b = 0; bool used[2] = {false, false};
+    for (uint64_t o = 0; o < total; o += CH, b ^= 1) {
+        const uint64_t n = std::min<uint64_t>(CH, total - o);
+        if (used[b]) PH_CHECK(hipEventSynchronize(ctx->stageEv[b]));            // the copy that read this buffer two chunks ago
+        produce(ctx->stage[b], o, n);
+        PH_CHECK(hipMemcpyAsync((char *) dDst + o, ctx->stage[b], n, hipMemcpyHostToDevice, ctx->stream));
+        PH_CHECK(hipEventRecord(ctx->stageEv[b], ctx->stream)); used[b] = true;
+    }
+    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    return PLASSHIP_OK;
+}
+int stagedDownload(plasship_ctx *ctx, const void *dSrc, uint64_t total, const std::function<bool(const char *, uint64_t, uint64_t)> &consume) {
+    if (!total) return PLASSHIP_OK;
+    int rc = stageReady(ctx); if (rc) return rc;
+    const uint64_t CH = ctx->stageBytes;
+    auto issue = [&](uint64_t o, int b) -> int {
+        const uint64_t n = std::min<uint64_t>(CH, total - o);
+        PH_CHECK(hipMemcpyAsync(ctx->stage[b], (const char *) dSrc + o, n, hipMemcpyDeviceToHost, ctx->stream));
+        PH_CHECK(hipEventRecord(ctx->stageEv[b], ctx->stream));
+        return PLASSHIP_OK;
+    };
+    rc = issue(0, 0); if (rc) return rc;
+    int b = 0;
+    for (uint64_t o = 0; o < total; o += CH, b ^= 1) {
+        if (o + CH < total) { rc = issue(o + CH, b ^ 1); if (rc) return rc; }   // the other buffer was consumed in the previous round
+        PH_CHECK(hipEventSynchronize(ctx->stageEv[b]));
+        if (!consume(ctx->stage[b], o, std::min<uint64_t>(CH, total - o))) { (void) hipStreamSynchronize(ctx->stream); return PLASSHIP_ERR_IO; }
+    }
+    return PLASSHIP_OK;
+}
+static void parallelCopy(char *dst, const char *src, uint64_t n) {
+    const size_t SL = 1u << 20;
+    parallelRanges((size_t) ((n + SL - 1) / SL), [&](int, size_t b, size_t e) {
+        const uint64_t o = (uint64_t) b * SL, end = std::min<uint64_t>(n, (uint64_t) e * SL);
+        if (end > o) memcpy(dst + o, src + o, (size_t) (end - o));
+    }, nullptr, 4);
+}
+int stagedCopyToDevice(plasship_ctx *ctx, void *dDst, const void *hSrc, uint64_t bytes) {
+    return stagedUpload(ctx, dDst, bytes, [&](char *dst, uint64_t o, uint64_t n) { parallelCopy(dst, (const char *) hSrc + o, n); });
+}
+int stagedCopyToHost(plasship_ctx *ctx, void *hDst, const void *dSrc, uint64_t bytes) {
+    return stagedDownload(ctx, dSrc, bytes, [&](const char *src, uint64_t o, uint64_t n) { parallelCopy((char *) hDst + o, src, n); return true; });
+}
+}  // namespace plasship
+using namespace plasship;
 
 // ---- sequence DB ---------------------------------------------------------------------------------
 extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t data_bytes, const uint64_t *off,
@@ -273,33 +340,29 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) db->d_data.p + total, 0, 64, ctx->stream));     // the padding only; the entries are copied below
-    // stage in id order through a pinned-size bounce buffer
+    // entries packed into id order, chunk by chunk, straight into the pinned staging buffers (an entry may straddle two chunks)
     {
-        const size_t CH = 64u << 20;
-        std::vector<char> bounce(std::min<uint64_t>(CH, std::max<uint64_t>(total, 1)));
-        uint64_t done = 0; size_t i = 0;
-        while (i < n) {
-            size_t fill = 0; uint64_t base = db->h_off[i];
-            while (i < n && fill + db->h_elen[i] <= bounce.size()) {
-                memcpy(bounce.data() + fill, data + off[perm[i]], db->h_elen[i]); fill += db->h_elen[i]; i++;
-            }
-            if (fill == 0) {   // single entry larger than the bounce buffer
-                PH_COPY_SYNC(ctx->stream, (char *) db->d_data.p + base, data + off[perm[i]], db->h_elen[i], hipMemcpyHostToDevice);
-                i++;
-            } else {
-                PH_COPY_SYNC(ctx->stream, (char *) db->d_data.p + base, bounce.data(), fill, hipMemcpyHostToDevice);
-            }
-            done = base + fill;
-        }
-        (void) done;
+        const uint64_t *newOff = db->h_off.data();
+        const int rc = stagedUpload(ctx, db->d_data.p, total, [&](char *dst, uint64_t o, uint64_t nb) {
+            const size_t first = (size_t) (std::upper_bound(newOff, newOff + n, o) - newOff) - 1;           // entry holding byte o
+            const size_t last = (size_t) (std::upper_bound(newOff, newOff + n, o + nb - 1) - newOff);      // one past the entry holding the last byte
+            parallelRanges(last - first, [&](int, size_t b, size_t e) {
+                for (size_t i = first + b; i < first + e; i++) {
+                    const uint64_t eb = newOff[i], ee = eb + db->h_elen[i];
+                    const uint64_t cb = std::max(eb, o), ce = std::min(ee, o + nb);
+                    if (ce > cb) memcpy(dst + (cb - o), data + off[perm[i]] + (cb - eb), (size_t) (ce - cb));
+                }
+            }, nullptr, 1024);
+        });
+        if (rc) return rc;
     }
     std::vector<uint64_t> hoff(n + 1);
     for (size_t i = 0; i < n; i++) hoff[i] = db->h_off[i];
     hoff[n] = total;
-    PH_COPY_SYNC(ctx->stream, db->d_off.p, hoff.data(), (n + 1) * 8, hipMemcpyHostToDevice);
+    { int rc = stagedCopyToDevice(ctx, db->d_off.p, hoff.data(), (n + 1) * 8); if (rc) return rc; }
     if (n) {
-        PH_COPY_SYNC(ctx->stream, db->d_len.p, hlen.data(), n * 4, hipMemcpyHostToDevice);
-        PH_COPY_SYNC(ctx->stream, db->d_key.p, db->h_key.data(), n * 4, hipMemcpyHostToDevice);
+        int rc = stagedCopyToDevice(ctx, db->d_len.p, hlen.data(), n * 4); if (rc) return rc;
+        rc = stagedCopyToDevice(ctx, db->d_key.p, db->h_key.data(), n * 4); if (rc) return rc;
     }
     PH_CHECK(hipStreamSynchronize(ctx->stream));
     *out = holder.release();
@@ -319,12 +382,12 @@ static int ensureHostIndex(plasship_ctx *ctx, plasship_seqdb *db) {
     db->h_key.resize(n); db->h_off.resize(n + 1); db->h_elen.resize(n);
     std::vector<uint32_t> len(n);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    PH_COPY_SYNC(ctx->stream, db->h_off.data(), db->d_off.p, (n + 1) * 8, hipMemcpyDeviceToHost);
+    { int rc = stagedCopyToHost(ctx, db->h_off.data(), db->d_off.p, (n + 1) * 8); if (rc) return rc; }
     if (n) {
-        PH_COPY_SYNC(ctx->stream, db->h_key.data(), db->d_key.p, n * 4, hipMemcpyDeviceToHost);
-        PH_COPY_SYNC(ctx->stream, len.data(), db->d_len.p, n * 4, hipMemcpyDeviceToHost);
+        int rc = stagedCopyToHost(ctx, db->h_key.data(), db->d_key.p, n * 4); if (rc) return rc;
+        rc = stagedCopyToHost(ctx, len.data(), db->d_len.p, n * 4); if (rc) return rc;
     }
-    for (size_t i = 0; i < n; i++) db->h_elen[i] = len[i] + 2;
+    parallelRanges(n, [&](int, size_t b, size_t e) { for (size_t i = b; i < e; i++) db->h_elen[i] = len[i] + 2; });
     db->h_off.resize(n);
     db->hostIndexValid = true;
     return PLASSHIP_OK;
@@ -348,7 +411,7 @@ extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *
     PH_ENTER(ctx);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    if (data && db->dataBytes) PH_COPY_SYNC(ctx->stream, data, db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost);
+    if (data && db->dataBytes) { rc = stagedCopyToHost(ctx, data, db->d_data.p, db->dataBytes); if (rc) return rc; }
     if (off) memcpy(off, db->h_off.data(), db->n * 8);
     if (elen) memcpy(elen, db->h_elen.data(), db->n * 4);
     if (key) memcpy(key, db->h_key.data(), db->n * 4);
@@ -360,13 +423,26 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
     plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     PH_ENTER(ctx);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
-    std::vector<char> data(db->dataBytes);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    if (db->dataBytes) PH_COPY_SYNC(ctx->stream, data.data(), db->d_data.p, db->dataBytes, hipMemcpyDeviceToHost);
-    // device layout already is the canonical DB layout: entries in key order, each "SEQ\n\0"
+    // the device layout is the file layout (entries "SEQ\n\0" back to back in key order): the data file is the device buffer, streamed
+    // through the pinned staging buffers while the previous chunk is being written; the index is formatted on the host threads
     std::string err; DBFileWriter w;
     if (!w.open(db_path, db->dbtype, err)) { setError(err); return PLASSHIP_ERR_IO; }
-    for (size_t i = 0; i < db->n; i++) w.add(db->h_key[i], data.data() + db->h_off[i], db->h_elen[i] - 1);
+    std::atomic<bool> packed(true);
+    parallelRanges(db->n, [&](int, size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) if (db->h_off[i] + db->h_elen[i] != (i + 1 < db->n ? db->h_off[i + 1] : db->dataBytes)) { packed = false; return; }
+    });
+    if (packed) {
+        rc = stagedDownload(ctx, db->d_data.p, db->dataBytes, [&](const char *src, uint64_t, uint64_t nb) { w.data(src, (size_t) nb); return !w.failed; });
+        if (rc == PLASSHIP_ERR_IO) setError(std::string("error while writing ") + db_path);
+        if (rc) return rc;
+        w.index(db->h_key.data(), db->h_elen.data(), db->n);
+    } else {                                                  // a DB with gaps between its entries (none of the producers here makes one)
+        HostBytes data;
+        if (!data.alloc(db->dataBytes)) { setError("plasship_seqdb_write: out of host memory"); return PLASSHIP_ERR_IO; }
+        rc = stagedCopyToHost(ctx, data.data(), db->d_data.p, db->dataBytes); if (rc) return rc;
+        for (size_t i = 0; i < db->n; i++) w.add(db->h_key[i], data.data() + db->h_off[i], db->h_elen[i] - 1);
+    }
     if (!w.close(err)) { setError(err); return PLASSHIP_ERR_IO; }
     return PLASSHIP_OK;
 }

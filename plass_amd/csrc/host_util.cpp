@@ -6,20 +6,70 @@
 #include <cstdio>
 #include <cstring>
 #include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+#include <sched.h>
+#include <atomic>
+#include <thread>
 
 namespace plasship {
 
 static bool exists(const std::string &p) { struct stat st; return stat(p.c_str(), &st) == 0; }
 
-static bool appendFile(const std::string &p, std::string &out) {
+int hostThreads() {
+    static const int n = [] {
+        if (const char *e = getenv("PLASSHIP_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 256); }
+        cpu_set_t cs; CPU_ZERO(&cs);
+        int c = (sched_getaffinity(0, sizeof(cs), &cs) == 0) ? CPU_COUNT(&cs) : (int) std::thread::hardware_concurrency();
+        return std::max(1, std::min(c, 16));
+    }();
+    return n;
+}
+
+int parallelRanges(size_t n, const std::function<void(int, size_t, size_t)> &f, const uint64_t *prefix, size_t minPerThread) {
+    int T = hostThreads();
+    if (minPerThread && n / minPerThread < (size_t) T) T = (int) std::max<size_t>(1, n / minPerThread);
+    if (T <= 1) { f(0, 0, n); return 1; }
+    std::vector<size_t> cut((size_t) T + 1, 0);
+    cut[(size_t) T] = n;
+    for (int t = 1; t < T; t++) {
+        if (prefix) {
+            const uint64_t want = prefix[0] + (uint64_t) (((unsigned __int128) (prefix[n] - prefix[0]) * (unsigned) t) / (unsigned) T);
+            cut[(size_t) t] = (size_t) (std::lower_bound(prefix, prefix + n, want) - prefix);
+        } else cut[(size_t) t] = (size_t) (((unsigned __int128) n * (unsigned) t) / (unsigned) T);
+        cut[(size_t) t] = std::max(cut[(size_t) t], cut[(size_t) t - 1]);
+    }
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back([&, t] { f(t, cut[(size_t) t], cut[(size_t) t + 1]); });
+    f(0, cut[0], cut[1]);
+    for (auto &x : th) x.join();
+    return T;
+}
+
+static bool readSmallFile(const std::string &p, std::string &out) {
     FILE *f = fopen(p.c_str(), "rb");
     if (!f) return false;
-    struct stat st; if (fstat(fileno(f), &st) != 0) { fclose(f); return false; }
-    size_t n = (size_t) st.st_size, old = out.size();
-    out.resize(old + n);
-    size_t got = n ? fread(&out[old], 1, n, f) : 0;
+    char buf[256]; size_t got; out.clear();
+    while ((got = fread(buf, 1, sizeof(buf), f)) > 0) out.append(buf, got);
     fclose(f);
-    return got == n;
+    return true;
+}
+static bool fileSize(const std::string &p, uint64_t &n) { struct stat st; if (stat(p.c_str(), &st) != 0) return false; n = (uint64_t) st.st_size; return true; }
+// [dst, dst + n) = bytes [0, n) of the file, read in slices on all host threads
+static bool readInto(const std::string &p, char *dst, uint64_t n) {
+    const int fd = ::open(p.c_str(), O_RDONLY);
+    if (fd < 0) return false;
+    std::atomic<bool> ok(true);
+    const size_t SL = 8u << 20;                                    // slice
+    const size_t nSl = (size_t) ((n + SL - 1) / SL);
+    parallelRanges(nSl, [&](int, size_t b, size_t e) {
+        for (size_t s = b; s < e && ok; s++) {
+            uint64_t o = (uint64_t) s * SL; const uint64_t end = std::min<uint64_t>(n, o + SL);
+            while (o < end) { const ssize_t g = pread(fd, dst + o, (size_t) (end - o), (off_t) o); if (g <= 0) { ok = false; break; } o += (uint64_t) g; }
+        }
+    }, nullptr, 4);
+    ::close(fd);
+    return ok;
 }
 
 // DB layout: NAME or NAME.0..NAME.k data (offsets global over the concatenation, FileUtil.cpp:336-352),
@@ -27,63 +77,150 @@ static bool appendFile(const std::string &p, std::string &out) {
 bool readDBFiles(const std::string &path, HostDB &db, std::string &err) {
     db = HostDB();
     std::string t;
-    if (!appendFile(path + ".dbtype", t) || t.size() < 4) { err = "cannot read " + path + ".dbtype"; return false; }
+    if (!readSmallFile(path + ".dbtype", t) || t.size() < 4) { err = "cannot read " + path + ".dbtype"; return false; }
     uint32_t ty; memcpy(&ty, t.data(), 4);
     if (ty & 0x80000000u) { err = "compressed database not supported: " + path; return false; }
     db.dbtype = (int) (ty & 0x3FFFFFFFu);
-    if (exists(path)) {
-        if (!appendFile(path, db.data)) { err = "cannot read " + path; return false; }
-    } else {
-        int i = 0;
-        for (;; i++) {
-            std::string p = path + "." + std::to_string(i);
-            if (!exists(p)) break;
-            if (!appendFile(p, db.data)) { err = "cannot read " + p; return false; }
+    std::vector<std::pair<std::string, uint64_t>> files; uint64_t total = 0;
+    if (exists(path)) { uint64_t n; if (!fileSize(path, n)) { err = "cannot read " + path; return false; } files.push_back({path, n}); total = n; }
+    else {
+        for (int i = 0;; i++) {
+            const std::string p = path + "." + std::to_string(i);
+            uint64_t n; if (!exists(p) || !fileSize(p, n)) break;
+            files.push_back({p, n}); total += n;
         }
-        if (i == 0) { err = "no data file for " + path; return false; }
+        if (files.empty()) { err = "no data file for " + path; return false; }
     }
-    std::string idx;
-    if (!appendFile(path + ".index", idx)) { err = "cannot read " + path + ".index"; return false; }
-    size_t lines = (size_t) std::count(idx.begin(), idx.end(), '\n');
-    db.key.reserve(lines); db.off.reserve(lines); db.elen.reserve(lines);
-    const char *p = idx.data(), *e = p + idx.size();
-    while (p < e) {
-        uint64_t v[3] = {0, 0, 0};
-        for (int c = 0; c < 3; c++) {
-            while (p < e && (*p == '\t' || *p == ' ')) p++;
-            while (p < e && *p >= '0' && *p <= '9') v[c] = v[c] * 10 + (uint64_t) (*p++ - '0');
+    if (!db.data.alloc((size_t) total)) { err = "out of host memory reading " + path; return false; }
+    { uint64_t o = 0; for (auto &f : files) { if (!readInto(f.first, db.data.data() + o, f.second)) { err = "cannot read " + f.first; return false; } o += f.second; } }
+    uint64_t idxBytes = 0; HostBytes idx;
+    if (!fileSize(path + ".index", idxBytes) || !idx.alloc((size_t) idxBytes) || !readInto(path + ".index", idx.data(), idxBytes)) { err = "cannot read " + path + ".index"; return false; }
+    // parse on all threads: a range of bytes handles the lines that START in it
+    const char *base = idx.data(); const size_t nb = idx.size();
+    const int maxT = hostThreads();
+    struct Part { std::vector<uint32_t> key, elen; std::vector<uint64_t> off; bool bad = false; };
+    std::vector<Part> parts((size_t) maxT);
+    const uint64_t dataSize = total;
+    const int used = parallelRanges(nb, [&](int tix, size_t b, size_t e) {
+        Part &pt = parts[(size_t) tix];
+        const char *p = base + b, *end = base + e, *fileEnd = base + nb;
+        if (b > 0) { while (p < fileEnd && p[-1] != '\n') p++; }              // first line start at or after b
+        while (p < end) {
+            uint64_t v[3] = {0, 0, 0};
+            for (int c = 0; c < 3; c++) {
+                while (p < fileEnd && (*p == '\t' || *p == ' ')) p++;
+                while (p < fileEnd && *p >= '0' && *p <= '9') v[c] = v[c] * 10 + (uint64_t) (*p++ - '0');
+            }
+            while (p < fileEnd && *p != '\n') p++;
+            if (p < fileEnd) p++;
+            if (v[1] + v[2] > dataSize) { pt.bad = true; return; }
+            pt.key.push_back((uint32_t) v[0]); pt.off.push_back(v[1]); pt.elen.push_back((uint32_t) v[2]);
         }
-        while (p < e && *p != '\n') p++;
-        if (p < e) p++;
-        if (v[1] + v[2] > db.data.size()) { err = "index entry points past the data of " + path; return false; }
-        db.key.push_back((uint32_t) v[0]); db.off.push_back(v[1]); db.elen.push_back((uint32_t) v[2]);
+    }, nullptr, 1u << 16);
+    size_t lines = 0;
+    for (int t = 0; t < used; t++) { if (parts[(size_t) t].bad) { err = "index entry points past the data of " + path; return false; } lines += parts[(size_t) t].key.size(); }
+    db.key.resize(lines); db.off.resize(lines); db.elen.resize(lines);
+    size_t at = 0;
+    for (int t = 0; t < used; t++) {
+        const Part &pt = parts[(size_t) t];
+        if (!pt.key.empty()) { memcpy(&db.key[at], pt.key.data(), pt.key.size() * 4); memcpy(&db.off[at], pt.off.data(), pt.off.size() * 8); memcpy(&db.elen[at], pt.elen.data(), pt.elen.size() * 4); }
+        at += pt.key.size();
     }
     return true;
 }
 
+// ---- writer ---------------------------------------------------------------------------------------
+DBFileWriter::~DBFileWriter() {
+    if (!open_) return;                                      // never opened, or closed properly
+    if (fd) fclose(fd);
+    if (fi) fclose(fi);
+    for (const char *sfx : {"", ".index", ".dbtype"}) (void) remove((path + sfx + tmpSuffix).c_str());
+}
 bool DBFileWriter::open(const std::string &p, int type, std::string &err) {
-    path = p; dbtype = type; off = 0;
-    fd = fopen(p.c_str(), "wb"); fi = fopen((p + ".index").c_str(), "wb");
+    path = p; dbtype = type; off = 0; failed = false;
+    tmpSuffix = ".tmp." + std::to_string((long) getpid());
+    fd = fopen((p + tmpSuffix).c_str(), "wb"); fi = fopen((p + ".index" + tmpSuffix).c_str(), "wb");
+    open_ = true;
     if (!fd || !fi) { err = "cannot open " + p + " for writing"; return false; }
     setvbuf(fd, nullptr, _IOFBF, 1 << 22);
     ibuf.clear(); ibuf.reserve(1 << 22);
     return true;
 }
+void DBFileWriter::data(const char *bytes, size_t n) {
+    if (n && fwrite(bytes, 1, n, fd) != n) failed = true;
+}
+void DBFileWriter::index(const uint32_t *keys, const uint32_t *elen, size_t n) {
+    if (!n) return;
+    const int maxT = hostThreads();
+    std::vector<uint64_t> sum((size_t) maxT + 1, 0);
+    std::vector<std::pair<size_t, size_t>> range((size_t) maxT, {0, 0});
+    const int used = parallelRanges(n, [&](int t, size_t b, size_t e) { uint64_t s = 0; for (size_t i = b; i < e; i++) s += elen[i]; sum[(size_t) t + 1] = s; range[(size_t) t] = {b, e}; });
+    sum[0] = off;
+    for (int t = 0; t < used; t++) sum[(size_t) t + 1] += sum[(size_t) t];
+    std::vector<std::string> text((size_t) used);
+    std::vector<std::thread> th;
+    auto work = [&](int t) {
+        std::string &s = text[(size_t) t]; s.reserve((range[(size_t) t].second - range[(size_t) t].first) * 24);
+        uint64_t o = sum[(size_t) t]; char tmp[80];
+        for (size_t i = range[(size_t) t].first; i < range[(size_t) t].second; i++) {
+            char *q = fmtU32(keys[i], tmp); *q++ = '\t'; q = fmtU64(o, q); *q++ = '\t'; q = fmtU64(elen[i], q); *q++ = '\n';
+            s.append(tmp, (size_t) (q - tmp)); o += elen[i];
+        }
+    };
+    for (int t = 1; t < used; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    if (!ibuf.empty()) { if (fwrite(ibuf.data(), 1, ibuf.size(), fi) != ibuf.size()) failed = true; ibuf.clear(); }
+    for (const std::string &s : text) if (!s.empty() && fwrite(s.data(), 1, s.size(), fi) != s.size()) failed = true;
+    off = sum[(size_t) used];
+}
 void DBFileWriter::add(uint32_t key, const char *bytes, size_t n) {
-    fwrite(bytes, 1, n, fd); fputc('\0', fd);
+    if (n && fwrite(bytes, 1, n, fd) != n) failed = true;
+    if (fputc('\0', fd) == EOF) failed = true;
     char tmp[64]; char *q = fmtU32(key, tmp); *q++ = '\t'; q = fmtU64(off, q); *q++ = '\t'; q = fmtU64(n + 1, q); *q++ = '\n';
     ibuf.append(tmp, (size_t) (q - tmp));
-    if (ibuf.size() > (1 << 22) - 128) { fwrite(ibuf.data(), 1, ibuf.size(), fi); ibuf.clear(); }
+    if (ibuf.size() > (1 << 22) - 128) { if (fwrite(ibuf.data(), 1, ibuf.size(), fi) != ibuf.size()) failed = true; ibuf.clear(); }
     off += n + 1;
 }
 bool DBFileWriter::close(std::string &err) {
-    bool ok = true;
-    if (fi) { fwrite(ibuf.data(), 1, ibuf.size(), fi); ok &= (fclose(fi) == 0); fi = nullptr; }
-    if (fd) { ok &= (fclose(fd) == 0); fd = nullptr; }
-    FILE *ft = fopen((path + ".dbtype").c_str(), "wb");
-    if (!ft) ok = false; else { uint32_t ty = (uint32_t) dbtype; fwrite(&ty, 4, 1, ft); fclose(ft); }
-    if (!ok) err = "error while writing " + path;
+    bool ok = !failed;
+    if (fi) { if (!ibuf.empty() && fwrite(ibuf.data(), 1, ibuf.size(), fi) != ibuf.size()) ok = false; ok &= (fflush(fi) == 0); ok &= (fclose(fi) == 0); fi = nullptr; }
+    if (fd) { ok &= (fflush(fd) == 0); ok &= (fclose(fd) == 0); fd = nullptr; }
+    FILE *ft = fopen((path + ".dbtype" + tmpSuffix).c_str(), "wb");
+    if (!ft) ok = false; else { uint32_t ty = (uint32_t) dbtype; ok &= (fwrite(&ty, 4, 1, ft) == 1); ok &= (fclose(ft) == 0); }
+    if (ok) for (const char *sfx : {"", ".index", ".dbtype"}) ok &= (rename((path + sfx + tmpSuffix).c_str(), (path + sfx).c_str()) == 0);
+    if (!ok) { err = "error while writing " + path + " (disk full?)"; for (const char *sfx : {"", ".index", ".dbtype"}) (void) remove((path + sfx + tmpSuffix).c_str()); }
+    open_ = false;
     return ok;
+}
+
+bool writeTextDB(const std::string &path, int dbtype, const uint32_t *keys, size_t n, const uint64_t *prefix,
+                 const std::function<bool(size_t, std::string &)> &fmt, std::string &err) {
+    DBFileWriter w;
+    if (!w.open(path, dbtype, err)) return false;
+    const int maxT = hostThreads();
+    struct Part { std::string text; std::vector<uint32_t> elen; size_t b = 0, e = 0; bool bad = false; };
+    std::vector<Part> parts((size_t) maxT);
+    const int used = parallelRanges(n, [&](int t, size_t b, size_t e) {
+        Part &pt = parts[(size_t) t]; pt.b = b; pt.e = e; pt.elen.reserve(e - b);
+        if (prefix) pt.text.reserve((size_t) (prefix[e] - prefix[b]) * 24 + (e - b));
+        for (size_t q = b; q < e; q++) {
+            const size_t before = pt.text.size();
+            if (!fmt(q, pt.text)) { pt.bad = true; return; }
+            pt.text.push_back('\0');
+            pt.elen.push_back((uint32_t) (pt.text.size() - before));
+        }
+    }, prefix);
+    for (int t = 0; t < used; t++) if (parts[(size_t) t].bad) { err = "formatting failed"; return false; }
+    std::vector<uint32_t> elen(n);
+    for (int t = 0; t < used; t++) {
+        Part &pt = parts[(size_t) t];
+        w.data(pt.text.data(), pt.text.size());
+        if (!pt.elen.empty()) memcpy(&elen[pt.b], pt.elen.data(), pt.elen.size() * 4);
+        std::string().swap(pt.text);
+    }
+    w.index(keys, elen.data(), n);
+    return w.close(err);
 }
 
 char *fmtU64(uint64_t v, char *p) {

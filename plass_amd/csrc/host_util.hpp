@@ -2,27 +2,67 @@
 // Format contracts: SURVEY.md §8b; text formats QueryMatcher.h:114-126, Matcher.cpp:323-370.
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
 #include <string>
 #include <vector>
 
 namespace plasship {
 
+// host threads for file reading, index / text parsing and formatting (PLASSHIP_HOST_THREADS; default: the cores this process may
+// run on, at most 16 — the reference formats and parses on its OpenMP threads)
+int hostThreads();
+// f(t, begin, end) on up to hostThreads() threads over contiguous ranges of [0, n); with `prefix` (n + 1 running weights, e.g. a CSR
+// offset array) the ranges carry about equal weight.  Returns the number of ranges used (range t was given to f exactly once).
+int parallelRanges(size_t n, const std::function<void(int, size_t, size_t)> &f, const uint64_t *prefix = nullptr, size_t minPerThread = 4096);
+
+// uninitialised byte buffer (a std::string would zero-fill gigabytes on one thread before the file is read into it)
+struct HostBytes {
+    char *p = nullptr; size_t n = 0;
+    HostBytes() {}
+    HostBytes(const HostBytes &) = delete; HostBytes &operator=(const HostBytes &) = delete;
+    HostBytes(HostBytes &&o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+    HostBytes &operator=(HostBytes &&o) noexcept { if (this != &o) { free(p); p = o.p; n = o.n; o.p = nullptr; o.n = 0; } return *this; }
+    ~HostBytes() { free(p); }
+    bool alloc(size_t bytes) { free(p); n = bytes; p = (char *) malloc(bytes + 64); if (p) memset(p + bytes, 0, 64); return p != nullptr; }
+    const char *data() const { return p; }
+    char *data() { return p; }
+    size_t size() const { return n; }
+};
+
 struct HostDB {
     int dbtype = 0;
-    std::string data;                       // all data files concatenated
+    HostBytes data;                         // all data files concatenated (64 zero bytes follow)
     std::vector<uint32_t> key, elen;        // index lines in file order
     std::vector<uint64_t> off;
 };
+// NAME or NAME.0 .. NAME.k (the unmerged per-thread files of the reference's DBWriter; offsets run over their concatenation),
+// NAME.index, NAME.dbtype.  The data is read with pread() on all host threads, the index is parsed on all host threads.
 bool readDBFiles(const std::string &path, HostDB &db, std::string &err);
 
-// streaming writer: entries must be appended in key order; writes NAME, NAME.index, NAME.dbtype
+// Writer of NAME, NAME.index, NAME.dbtype.  Everything goes to "<file>.tmp.<pid>" first; close() checks every write and renames
+// the three files into place, so a reader never sees a half-written DB and a failed write never leaves one behind under NAME.
+//   large DBs:  data(bytes…) in file order, then index(keys, entry lengths) — offsets are the running sum, lines are formatted on
+//               all host threads
+//   small DBs:  add(key, bytes) per entry
 struct DBFileWriter {
-    FILE *fd = nullptr, *fi = nullptr; std::string path; uint64_t off = 0; int dbtype = 0;
+    FILE *fd = nullptr, *fi = nullptr; std::string path, tmpSuffix; uint64_t off = 0; int dbtype = 0; bool failed = false, open_ = false;
     std::string ibuf;
+    DBFileWriter() {}
+    DBFileWriter(const DBFileWriter &) = delete; DBFileWriter &operator=(const DBFileWriter &) = delete;
+    ~DBFileWriter();
     bool open(const std::string &p, int type, std::string &err);
+    void data(const char *bytes, size_t n);
+    void index(const uint32_t *keys, const uint32_t *elen, size_t n);   // elen counts the entry's '\0'
     void add(uint32_t key, const char *bytes, size_t n);   // appends '\0'
     bool close(std::string &err);
 };
+// text DB (prefilter / alignment / header DBs): fmt(q, out) appends the lines of entry q; entries are formatted on all host threads
+// (ranges balanced by `prefix`, n + 1 running line counts, if given) and written in key order.  fmt returns false to abort.
+bool writeTextDB(const std::string &path, int dbtype, const uint32_t *keys, size_t n, const uint64_t *prefix,
+                 const std::function<bool(size_t, std::string &)> &fmt, std::string &err);
 
 // decimal formatting without the libc (hot in DB writing)
 char *fmtU32(uint32_t v, char *p);          // returns pointer past last digit (no terminator)

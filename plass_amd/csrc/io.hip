@@ -5,6 +5,7 @@
 #include "common.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <cstdio>
 #include <cstdlib>
@@ -17,7 +18,7 @@ static int hostKeys(plasship_ctx *ctx, const plasship_seqdb *cdb, const std::vec
     if (!db->hostIndexValid && db->h_key.size() != db->n) {
         db->h_key.resize(db->n);
         PH_CHECK(hipStreamSynchronize(ctx->stream));
-        if (db->n) PH_COPY_SYNC(ctx->stream, db->h_key.data(), db->d_key.p, db->n * 4, hipMemcpyDeviceToHost);
+        if (db->n) { const int rc = stagedCopyToHost(ctx, db->h_key.data(), db->d_key.p, db->n * 4); if (rc) return rc; }
     }
     *keys = &db->h_key;
     return PLASSHIP_OK;
@@ -56,37 +57,52 @@ extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb,
     int rc = hostKeys(ctx, qdb, &qk); if (rc) return rc;
     rc = hostKeys(ctx, tdb, &tk); if (rc) return rc;
     const size_t nQ = qdb->n;
+    // entries -> query ids, lines per query, then the lines themselves: all three on the host threads (the reference parses its
+    // prefilter DB on its OpenMP threads, one query at a time)
     std::vector<long> entryOf(nQ, -1);
-    for (size_t e = 0; e < h.key.size(); e++) {
-        long id = keyToId(*qk, h.key[e]);
-        if (id < 0) { setError("prefilter entry for a key that is not in the query DB"); return PLASSHIP_ERR_ARG; }
-        entryOf[(size_t) id] = (long) e;
-    }
+    std::atomic<int> bad(0);
+    parallelRanges(h.key.size(), [&](int, size_t b, size_t e) {
+        for (size_t i = b; i < e; i++) { const long id = keyToId(*qk, h.key[i]); if (id < 0) { bad = 1; return; } entryOf[(size_t) id] = (long) i; }
+    });
+    if (bad) { setError("prefilter entry for a key that is not in the query DB"); return PLASSHIP_ERR_ARG; }
     std::vector<uint64_t> qoff(nQ + 1, 0);
-    std::vector<CandHit> hits;
-    uint64_t nonSelf = 0;
-    for (size_t q = 0; q < nQ; q++) {
-        qoff[q] = hits.size();
-        if (entryOf[q] < 0) continue;
-        const char *p = h.data.data() + h.off[(size_t) entryOf[q]];
-        while (*p != '\0') {
-            uint32_t key = 0; while (*p >= '0' && *p <= '9') key = key * 10 + (uint32_t) (*p++ - '0');
-            while (*p == '\t' || *p == ' ') p++;
-            int sg = 1; if (*p == '-') { sg = -1; p++; }
-            int sc = 0; while (*p >= '0' && *p <= '9') sc = sc * 10 + (*p++ - '0');
-            while (*p == '\t' || *p == ' ') p++;
-            int sg2 = 1; if (*p == '-') { sg2 = -1; p++; }
-            short dg = 0; while (*p >= '0' && *p <= '9') dg = (short) (dg * 10 + (*p++ - '0'));
-            while (*p != '\n' && *p != '\0') p++;
-            if (*p == '\n') p++;
-            long tid = keyToId(*tk, key);
-            if (tid < 0) { setError("prefilter hit for a key that is not in the target DB"); return PLASSHIP_ERR_ARG; }
-            CandHit ch; ch.target = (uint32_t) tid; ch.prefScore = sg * sc; ch.diag16 = (uint32_t) (uint16_t) (short) (sg2 * dg); ch.query = (uint32_t) q;
-            hits.push_back(ch);
-            if (!(qdb == tdb && (size_t) tid == q)) nonSelf++;
+    parallelRanges(nQ, [&](int, size_t b, size_t e) {
+        for (size_t q = b; q < e; q++) {
+            if (entryOf[q] < 0) continue;
+            const char *p = h.data.data() + h.off[(size_t) entryOf[q]]; uint64_t lines = 0;
+            while (*p != '\0') { lines++; while (*p != '\n' && *p != '\0') p++; if (*p == '\n') p++; }
+            qoff[q + 1] = lines;
         }
-    }
-    qoff[nQ] = hits.size();
+    });
+    for (size_t q = 0; q < nQ; q++) qoff[q + 1] += qoff[q];
+    std::vector<CandHit> hits(qoff[nQ]);
+    std::vector<uint64_t> nonSelfPart((size_t) hostThreads(), 0);
+    parallelRanges(nQ, [&](int t, size_t b, size_t e) {
+        uint64_t ns = 0;
+        for (size_t q = b; q < e; q++) {
+            if (entryOf[q] < 0) continue;
+            const char *p = h.data.data() + h.off[(size_t) entryOf[q]]; uint64_t at = qoff[q];
+            while (*p != '\0') {
+                uint32_t key = 0; while (*p >= '0' && *p <= '9') key = key * 10 + (uint32_t) (*p++ - '0');
+                while (*p == '\t' || *p == ' ') p++;
+                int sg = 1; if (*p == '-') { sg = -1; p++; }
+                int sc = 0; while (*p >= '0' && *p <= '9') sc = sc * 10 + (*p++ - '0');
+                while (*p == '\t' || *p == ' ') p++;
+                int sg2 = 1; if (*p == '-') { sg2 = -1; p++; }
+                short dg = 0; while (*p >= '0' && *p <= '9') dg = (short) (dg * 10 + (*p++ - '0'));
+                while (*p != '\n' && *p != '\0') p++;
+                if (*p == '\n') p++;
+                const long tid = keyToId(*tk, key);
+                if (tid < 0) { bad = 2; return; }
+                CandHit ch; ch.target = (uint32_t) tid; ch.prefScore = sg * sc; ch.diag16 = (uint32_t) (uint16_t) (short) (sg2 * dg); ch.query = (uint32_t) q;
+                hits[at++] = ch;
+                if (!(qdb == tdb && (size_t) tid == q)) ns++;
+            }
+        }
+        nonSelfPart[(size_t) t] = ns;
+    }, qoff.data());
+    if (bad) { setError("prefilter hit for a key that is not in the target DB"); return PLASSHIP_ERR_ARG; }
+    uint64_t nonSelf = 0; for (uint64_t v : nonSelfPart) nonSelf += v;
     std::unique_ptr<plasship_cands> holder(new plasship_cands());   // released to the caller on success only
     plasship_cands *c = holder.get();
     c->reverseCapable = (h.dbtype == PLASSHIP_DBTYPE_PREFILTER_REV_RES);
@@ -94,8 +110,8 @@ extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb,
     if (c->d_qoff.alloc((nQ + 1) * 8) != hipSuccess || c->d_hits.alloc(std::max<size_t>(hits.size(), 1) * sizeof(CandHit)) != hipSuccess) {
         setError("plasship_cands_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    PH_COPY_SYNC(ctx->stream, c->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice);
-    if (!hits.empty()) PH_COPY_SYNC(ctx->stream, c->d_hits.p, hits.data(), hits.size() * sizeof(CandHit), hipMemcpyHostToDevice);
+    rc = stagedCopyToDevice(ctx, c->d_qoff.p, qoff.data(), (nQ + 1) * 8); if (rc) return rc;
+    rc = stagedCopyToDevice(ctx, c->d_hits.p, hits.data(), hits.size() * sizeof(CandHit)); if (rc) return rc;
     *out = holder.release();
     return PLASSHIP_OK;
 }
@@ -103,9 +119,8 @@ extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb,
 static int fetchCands(plasship_ctx *ctx, const plasship_cands *c, std::vector<uint64_t> &qoff, std::vector<CandHit> &hits) {
     qoff.resize(c->nQueries + 1); hits.resize(c->nHits);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    PH_COPY_SYNC(ctx->stream, qoff.data(), c->d_qoff.p, (c->nQueries + 1) * 8, hipMemcpyDeviceToHost);
-    if (c->nHits) PH_COPY_SYNC(ctx->stream, hits.data(), c->d_hits.p, c->nHits * sizeof(CandHit), hipMemcpyDeviceToHost);
-    return PLASSHIP_OK;
+    int rc = stagedCopyToHost(ctx, qoff.data(), c->d_qoff.p, (c->nQueries + 1) * 8); if (rc) return rc;
+    return stagedCopyToHost(ctx, hits.data(), c->d_hits.p, c->nHits * sizeof(CandHit));
 }
 
 extern "C" int plasship_cands_write(plasship_ctx *ctx, const plasship_cands *c, const plasship_seqdb *db, const char *db_path) {
@@ -115,20 +130,18 @@ extern "C" int plasship_cands_write(plasship_ctx *ctx, const plasship_cands *c, 
     const std::vector<uint32_t> *keys; int rc = hostKeys(ctx, db, &keys); if (rc) return rc;
     std::vector<uint64_t> qoff; std::vector<CandHit> hits;
     rc = fetchCands(ctx, c, qoff, hits); if (rc) return rc;
-    std::string err; DBFileWriter w;
-    if (!w.open(db_path, c->reverseCapable ? PLASSHIP_DBTYPE_PREFILTER_REV_RES : PLASSHIP_DBTYPE_PREFILTER_RES, err)) { setError(err); return PLASSHIP_ERR_IO; }
-    std::string buf;
-    for (size_t q = 0; q < c->nQueries; q++) {
-        buf.clear();
+    std::string err;
+    const bool ok = writeTextDB(db_path, c->reverseCapable ? PLASSHIP_DBTYPE_PREFILTER_REV_RES : PLASSHIP_DBTYPE_PREFILTER_RES, keys->data(), c->nQueries, qoff.data(),
+                                [&](size_t q, std::string &out) {
         for (uint64_t i = qoff[q]; i < qoff[q + 1]; i++) {
             char tmp[64]; char *p = fmtU32((*keys)[hits[i].target], tmp); *p++ = '\t';
             p = fmtI32(hits[i].prefScore, p); *p++ = '\t';
             p = fmtI32((int32_t) (int16_t) (uint16_t) hits[i].diag16, p); *p++ = '\n';
-            buf.append(tmp, (size_t) (p - tmp));
+            out.append(tmp, (size_t) (p - tmp));
         }
-        w.add((*keys)[q], buf.data(), buf.size());
-    }
-    if (!w.close(err)) { setError(err); return PLASSHIP_ERR_IO; }
+        return true;
+    }, err);
+    if (!ok) { setError(err); return PLASSHIP_ERR_IO; }
     return PLASSHIP_OK;
 }
 
@@ -144,7 +157,7 @@ extern "C" int plasship_cands_download(plasship_ctx *ctx, const plasship_cands *
     rc = fetchCands(ctx, c, qoff, hits); if (rc) return rc;
     uint64_t o = 0;
     for (uint64_t i = 0; i < c->nHits; i++) {
-        if (hits[i].query == hits[i].target && hits[i].prefScore == 0 && hits[i].diag16 == 0) continue;   // implicit self line
+        if (qdb == tdb && hits[i].query == hits[i].target && hits[i].prefScore == 0 && hits[i].diag16 == 0) continue;   // implicit self line (same DB only: ids of two DBs are unrelated)
         if (query_key) query_key[o] = (*qk)[hits[i].query];
         if (target_key) target_key[o] = (*tk)[hits[i].target];
         if (pref_score) pref_score[o] = hits[i].prefScore;
@@ -169,9 +182,8 @@ extern "C" void plasship_alns_free(plasship_ctx *ctx, plasship_alns *a) {
 static int fetchAlns(plasship_ctx *ctx, const plasship_alns *a, std::vector<uint64_t> &qoff, std::vector<AlnRec> &recs) {
     qoff.resize(a->nQueries + 1); recs.resize(a->nLines);
     PH_CHECK(hipStreamSynchronize(ctx->stream));
-    PH_COPY_SYNC(ctx->stream, qoff.data(), a->d_qoff.p, (a->nQueries + 1) * 8, hipMemcpyDeviceToHost);
-    if (a->nLines) PH_COPY_SYNC(ctx->stream, recs.data(), a->d_recs.p, a->nLines * sizeof(AlnRec), hipMemcpyDeviceToHost);
-    return PLASSHIP_OK;
+    int rc = stagedCopyToHost(ctx, qoff.data(), a->d_qoff.p, (a->nQueries + 1) * 8); if (rc) return rc;
+    return stagedCopyToHost(ctx, recs.data(), a->d_recs.p, a->nLines * sizeof(AlnRec));
 }
 
 extern "C" int plasship_alns_download(plasship_ctx *ctx, const plasship_alns *a, plasship_aln_record *out) {
@@ -182,13 +194,13 @@ extern "C" int plasship_alns_download(plasship_ctx *ctx, const plasship_alns *a,
     const std::vector<uint32_t> *qk, *tk;
     rc = hostKeys(ctx, a->qdb, &qk); if (rc) return rc;
     rc = hostKeys(ctx, a->tdb, &tk); if (rc) return rc;
-    for (uint64_t i = 0; i < a->nLines; i++) {
+    parallelRanges(a->nLines, [&](int, size_t b, size_t e) { for (size_t i = b; i < e; i++) {
         const AlnRec &r = recs[i]; plasship_aln_record &o = out[i];
         o.query_key = (*qk)[r.query]; o.target_key = (*tk)[r.target];
         o.bit_score = r.bitScore; o.raw_score = r.rawScore; o.seq_id = r.seqId;
         o.q_start = r.qStart; o.q_end = r.qEnd; o.q_len = r.qLen; o.db_start = r.dbStart; o.db_end = r.dbEnd; o.db_len = r.dbLen;
         o.aln_len = r.alnLen; o.reversed = r.reversed;
-    }
+    } });
     return PLASSHIP_OK;
 }
 
@@ -211,14 +223,12 @@ extern "C" int plasship_alns_write(plasship_ctx *ctx, const plasship_alns *a, co
     rc = hostKeys(ctx, a->tdb, &tk); if (rc) return rc;
     HostEvaluer ev(a->nucl, a->dbResidues);
     if (a->gappedOpen && !HostEvaluer::nuclGapped(a->gappedOpen, a->gappedExtend, a->dbResidues, ev)) { setError("plasship_alns_write: no Gumbel parameters for these gap penalties"); return PLASSHIP_ERR_UNSUPPORTED; }
-    std::string err; DBFileWriter w;
-    if (!w.open(db_path, PLASSHIP_DBTYPE_ALIGNMENT_RES, err)) { setError(err); return PLASSHIP_ERR_IO; }
-    std::string buf;
-    for (size_t q = 0; q < a->nQueries; q++) {
-        buf.clear();
+    std::string err; std::atomic<int> fromText(0);
+    // E-values (erfc / exp per line) and the text are made on the host threads, like the reference's writer threads
+    const bool ok = writeTextDB(db_path, PLASSHIP_DBTYPE_ALIGNMENT_RES, qk->data(), a->nQueries, qoff.data(), [&](size_t q, std::string &out) {
         for (uint64_t i = qoff[q]; i < qoff[q + 1]; i++) {
             const AlnRec &r = recs[i];
-            if (r.fromText) { setError("plasship_alns_write: list was read from text (no raw scores)"); return PLASSHIP_ERR_UNSUPPORTED; }
+            if (r.fromText) { fromText = 1; return false; }
             char tmp[256]; char *p = fmtU32((*tk)[r.target], tmp); *p++ = '\t';
             p = fmtI32(r.bitScore, p); *p++ = '\t';
             p = fmtSeqId(r.seqId, p); *p++ = '\t';
@@ -227,11 +237,12 @@ extern "C" int plasship_alns_write(plasship_ctx *ctx, const plasship_alns *a, co
             p = fmtI32(r.dbStart, p); *p++ = '\t'; p = fmtI32(r.dbEnd, p); *p++ = '\t'; p = fmtI32(r.dbLen, p);
             if (a->addBacktrace) { *p++ = '\t'; p = fmtI32(r.alnLen, p); *p++ = 'M'; }
             *p++ = '\n';
-            buf.append(tmp, (size_t) (p - tmp));
+            out.append(tmp, (size_t) (p - tmp));
         }
-        w.add((*qk)[q], buf.data(), buf.size());
-    }
-    if (!w.close(err)) { setError(err); return PLASSHIP_ERR_IO; }
+        return true;
+    }, err);
+    if (fromText) { setError("plasship_alns_write: list was read from text (no raw scores)"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (!ok) { setError(err); return PLASSHIP_ERR_IO; }
     return PLASSHIP_OK;
 }
 
@@ -244,12 +255,23 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
     const std::vector<uint32_t> *keys; int rc = hostKeys(ctx, db, &keys); if (rc) return rc;
     const size_t nQ = db->n;
     std::vector<long> entryOf(nQ, -1);
-    for (size_t e = 0; e < h.key.size(); e++) { long id = keyToId(*keys, h.key[e]); if (id >= 0) entryOf[(size_t) id] = (long) e; }
-    std::vector<uint64_t> qoff(nQ + 1, 0); std::vector<AlnRec> recs;
-    for (size_t q = 0; q < nQ; q++) {
-        qoff[q] = recs.size();
+    parallelRanges(h.key.size(), [&](int, size_t b, size_t e) { for (size_t i = b; i < e; i++) { const long id = keyToId(*keys, h.key[i]); if (id >= 0) entryOf[(size_t) id] = (long) i; } });
+    std::vector<uint64_t> qoff(nQ + 1, 0);
+    parallelRanges(nQ, [&](int, size_t b, size_t e) {
+        for (size_t q = b; q < e; q++) {
+            if (entryOf[q] < 0) continue;
+            const char *p = h.data.data() + h.off[(size_t) entryOf[q]]; uint64_t lines = 0;
+            while (*p != '\0') { lines++; while (*p != '\n' && *p != '\0') p++; if (*p == '\n') p++; }
+            qoff[q + 1] = lines;
+        }
+    });
+    for (size_t q = 0; q < nQ; q++) qoff[q + 1] += qoff[q];
+    std::vector<AlnRec> recs(qoff[nQ]);
+    std::atomic<int> bad(0);
+    parallelRanges(nQ, [&](int, size_t qb, size_t qe) {
+    for (size_t q = qb; q < qe; q++) {
         if (entryOf[q] < 0) continue;
-        const char *p = h.data.data() + h.off[(size_t) entryOf[q]];
+        const char *p = h.data.data() + h.off[(size_t) entryOf[q]]; uint64_t at = qoff[q];
         while (*p != '\0') {
             const char *f[16]; int nf = 0; const char *s = p;
             while (*s != '\n' && *s != '\0' && nf < 15) {
@@ -257,10 +279,10 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
                 f[nf++] = s;
                 while (*s != ' ' && *s != '\t' && *s != '\n' && *s != '\0') s++;
             }
-            if (nf < 10) { setError("invalid alignment record"); return PLASSHIP_ERR_ARG; }
+            if (nf < 10) { bad = 1; return; }
             AlnRec r; memset(&r, 0, sizeof(r));
             long tid = keyToId(*keys, (uint32_t) strtoul(f[0], nullptr, 10));
-            if (tid < 0) { setError("alignment line for a key that is not in the DB"); return PLASSHIP_ERR_ARG; }
+            if (tid < 0) { bad = 2; return; }
             r.query = (uint32_t) q; r.target = (uint32_t) tid; r.bitScore = atoi(f[1]); r.rawScore = -1;
             r.seqId = (float) strtod(f[2], nullptr);
             r.qStart = atoi(f[4]); r.qEnd = atoi(f[5]); r.qLen = atoi(f[6]); r.dbStart = atoi(f[7]); r.dbEnd = atoi(f[8]); r.dbLen = atoi(f[9]);
@@ -273,12 +295,14 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
                 const bool oneRun = digits && *b == 'M' && (b[1] == '\n' || b[1] == '\0' || b[1] == ' ' || b[1] == '\t');
                 r.btKind = (oneRun && v == r.alnLen) ? 1 : 2;
             }
-            recs.push_back(r);
+            recs[at++] = r;
             while (*p != '\n' && *p != '\0') p++;
             if (*p == '\n') p++;
         }
     }
-    qoff[nQ] = recs.size();
+    }, qoff.data());
+    if (bad == 1) { setError("invalid alignment record"); return PLASSHIP_ERR_ARG; }
+    if (bad == 2) { setError("alignment line for a key that is not in the DB"); return PLASSHIP_ERR_ARG; }
     std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
     plasship_alns *a = holder.get();
     a->nQueries = nQ; a->nLines = recs.size(); a->nucl = db->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES; a->dbResidues = db->residues;
@@ -286,8 +310,8 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
     if (a->d_qoff.alloc((nQ + 1) * 8) != hipSuccess || a->d_recs.alloc(std::max<size_t>(recs.size(), 1) * sizeof(AlnRec)) != hipSuccess) {
         setError("plasship_alns_read: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    PH_COPY_SYNC(ctx->stream, a->d_qoff.p, qoff.data(), (nQ + 1) * 8, hipMemcpyHostToDevice);
-    if (!recs.empty()) PH_COPY_SYNC(ctx->stream, a->d_recs.p, recs.data(), recs.size() * sizeof(AlnRec), hipMemcpyHostToDevice);
+    rc = stagedCopyToDevice(ctx, a->d_qoff.p, qoff.data(), (nQ + 1) * 8); if (rc) return rc;
+    rc = stagedCopyToDevice(ctx, a->d_recs.p, recs.data(), recs.size() * sizeof(AlnRec)); if (rc) return rc;
     *out = holder.release();
     return PLASSHIP_OK;
 }

@@ -23,6 +23,7 @@
 #include "device_utils.hpp"
 #include "host_util.hpp"
 #include <algorithm>
+#include <atomic>
 #include <memory>
 #include <cstring>
 #include <climits>
@@ -516,19 +517,22 @@ extern "C" int plasship_orfhdr_write(plasship_ctx *ctx, const plasship_orfhdr *h
     if (!ctx || !h || !db_path) { setError("plasship_orfhdr_write: bad argument"); return PLASSHIP_ERR_ARG; }
     PH_ENTER(ctx);
     std::vector<OrfInfo> info(h->n);
-    if (h->n) PH_COPY_SYNC(ctx->stream, info.data(), h->d_info.p, h->n * sizeof(OrfInfo), hipMemcpyDeviceToHost);
-    std::string err; DBFileWriter w;
-    if (!w.open(db_path, 12, err)) { setError(err); return PLASSHIP_ERR_IO; }                      // DBTYPE_GENERIC_DB
-    char buf[96];
-    for (const OrfInfo &o : info) {
-        if (o.flags & 4u) { setError("plasship_orfhdr_write: the header DB holds entries that are not ORF headers"); return PLASSHIP_ERR_UNSUPPORTED; }
+    { const int rc = stagedCopyToHost(ctx, info.data(), h->d_info.p, h->n * sizeof(OrfInfo)); if (rc) return rc; }
+    std::vector<uint32_t> keys(h->n);
+    std::atomic<int> foreign(0);
+    parallelRanges(h->n, [&](int, size_t b, size_t e) { for (size_t i = b; i < e; i++) { keys[i] = info[i].key; if (info[i].flags & 4u) foreign = 1; } });
+    if (foreign) { setError("plasship_orfhdr_write: the header DB holds entries that are not ORF headers"); return PLASSHIP_ERR_UNSUPPORTED; }
+    std::string err;
+    const bool ok = writeTextDB(db_path, 12, keys.data(), h->n, nullptr, [&](size_t i, std::string &out) {                    // DBTYPE_GENERIC_DB
+        const OrfInfo &o = info[i]; char buf[96];
         char *q = fmtU32(o.readKey, buf); *q++ = '\t'; q = fmtU32(o.fromPos, q); *q++ = (o.fromPos < o.toPos) ? '+' : '-';
         const int d = (int) o.fromPos - (int) o.toPos; q = fmtI32(d < 0 ? -d : d, q);
         if (o.flags & 3u) { *q++ = '\t'; q = fmtI32((int) (o.flags & 3u), q); }
         *q++ = '\n';
-        w.add(o.key, buf, (size_t) (q - buf));
-    }
-    if (!w.close(err)) { setError(err); return PLASSHIP_ERR_IO; }
+        out.append(buf, (size_t) (q - buf));
+        return true;
+    }, err);
+    if (!ok) { setError(err); return PLASSHIP_ERR_IO; }
     return PLASSHIP_OK;
 }
 extern "C" int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plasship_orfhdr **out) {
@@ -538,9 +542,11 @@ extern "C" int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plas
     if (!readDBFiles(db_path, h, err)) { setError(err); return PLASSHIP_ERR_IO; }
     const size_t n = h.key.size();
     std::vector<uint32_t> perm(n); for (size_t i = 0; i < n; i++) perm[i] = (uint32_t) i;
-    std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return h.key[x] < h.key[y]; });
-    std::vector<OrfInfo> info(n); size_t nBad = 0;
-    for (size_t i = 0; i < n; i++) {
+    if (!std::is_sorted(h.key.begin(), h.key.end())) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return h.key[x] < h.key[y]; });
+    std::vector<OrfInfo> info(n); std::atomic<size_t> nBadAll(0);
+    parallelRanges(n, [&](int, size_t rb, size_t re) {
+    size_t nBad = 0;
+    for (size_t i = rb; i < re; i++) {
         const uint32_t s = perm[i];
         OrfInfo o; o.key = h.key[s]; o.readKey = 0; o.fromPos = 0; o.toPos = 0; o.flags = 4u;
         // "<id>\t<from>[+-]<len>[\t<flags>]": words are separated by blanks / tabs; the flags count only as the third and last word
@@ -569,9 +575,12 @@ extern "C" int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plas
         info[i] = o;
         if (o.flags & 4u) nBad++;
     }
+    nBadAll += nBad;
+    });
+    const size_t nBad = nBadAll;
     std::unique_ptr<plasship_orfhdr> o(new plasship_orfhdr());
     if (o->d_info.alloc((n + 1) * sizeof(OrfInfo)) != hipSuccess) { setError("plasship_orfhdr_read: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (n) PH_COPY_SYNC(ctx->stream, o->d_info.p, info.data(), n * sizeof(OrfInfo), hipMemcpyHostToDevice);
+    { const int rc = stagedCopyToDevice(ctx, o->d_info.p, info.data(), n * sizeof(OrfInfo)); if (rc) return rc; }
     o->n = n; o->nUnparsable = nBad;
     *out = o.release();
     return PLASSHIP_OK;

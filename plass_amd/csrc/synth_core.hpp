@@ -1,6 +1,6 @@
 // plasship_synth core: the synthetic community and read model (include/plasship_synth.h) as plain functions that compile both for
 // the GPU (synth.hip: one thread per base / per read) and for the host — tests regenerate the very same reads on the CPU
-// (`plass_oracle synthreads`, test infrastructure) to pin large GPU runs against CPU-oracle checksums made in a container without a
+// (the test tools' `synthreads` module) to pin large GPU runs against CPU-oracle checksums made in a container without a
 // GPU.  MEASUREMENT INFRASTRUCTURE — no reference counterpart.  Everything is integer arithmetic on a 64-bit mix of
 // (seed, indices), except one float multiply-add for the insert length (single IEEE operations, -ffp-contract=off) and exp() for the
 // abundances, which runs on the host in both cases.

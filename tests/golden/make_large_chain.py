@@ -6,8 +6,9 @@ configs[2] community model (skewed coverage: log-normal abundances, sigma 1), co
     -> extractorfs x2 -> translatenucs --add-orf-stop x2 -> concatdbs          (data/assemble.sh:41-77)
     -> ITERS x (kmermatcher -> rescorediagonal -> assembleresults)                (data/assemble.sh:110-175, without findassemblystart)
 
-tests/test_gpu_large.py regenerates the reads on the GPU, runs the HIP path at the same size and compares md5(data) / md5(index) of the
-read DB, the fragment DB and of pref / aln / seq_{i+1} of every iteration.  Run here (no GPU needed): ~15 min on 8 cores, ~25 GB of /tmp.
+tests/test_gpu_large.py regenerates the reads on the GPU, runs the HIP path at the same size and compares the entry digest
+(`plass_oracle dbsum`: sum over the entries of a 64-bit hash of key, length and bytes) of the read DB, the fragment DB and of
+pref / aln / seq_{i+1} of every iteration.  Run here (no GPU needed): ~15 min on 8 cores, ~25 GB of /tmp.
 
     python tests/golden/make_large_chain.py [--pairs 2500000] [--iters 3]
 """
@@ -26,8 +27,11 @@ def md5(path):
 
 
 def db_sums(path):
-    idx = open(path + ".index", "rb").read()
-    return {"data_md5": md5(path), "index_md5": hashlib.md5(idx).hexdigest(), "entries": idx.count(b"\n"), "data_bytes": os.path.getsize(path)}
+    """order-independent digest of the entries (plass_oracle dbsum) + md5 of the data / index files as the oracle's writer lays them out"""
+    import __graft_entry__ as g
+    out = subprocess.run([g.oracle_bin(), "dbsum", path], stdout=subprocess.PIPE, check=True, text=True).stdout.strip().split("\t")
+    f = dict(x.split("=") for x in out[1:])
+    return {"entries": int(f["entries"]), "bytes": int(f["bytes"]), "digest": f["digest"], "data_md5": md5(path), "index_md5": md5(path + ".index")}
 
 
 def main():

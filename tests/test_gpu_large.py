@@ -1,0 +1,111 @@
+"""Large-scale parity (run with `-m gpu`): the whole protein chain on a 5 M-read sample of the BASELINE.json configs[2] community
+model — skewed coverage (log-normal abundances, sigma 1; the most abundant genome is covered ~100x), reads generated on the GPU —
+against checksums the CPU oracle produced for the same reads in the build container (tests/golden/large_chain.json, made by
+tests/golden/make_large_chain.py: `plass_oracle synthreads` runs the read model on the CPU, then the oracle's extractorfs /
+translatenucs / concatdbs / kmermatcher / rescorediagonal / assembleresults).  Every product of every module is compared: the read
+DB, the fragment DB, and pref / aln / seq_{i+1} of three iterations, through `plass_oracle dbsum` (an order-independent digest of
+(key, length, bytes) over all entries — the oracle tool is the checker here, nothing of it runs in the product path)."""
+import json
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "large_chain.json")
+
+
+def dbsum(path):
+    import __graft_entry__ as g
+    out = subprocess.run([g.oracle_bin(), "dbsum", str(path)], stdout=subprocess.PIPE, check=True, text=True).stdout.strip().split("\t")
+    f = dict(x.split("=") for x in out[1:])
+    return {"entries": int(f["entries"]), "bytes": int(f["bytes"]), "digest": f["digest"]}
+
+
+def check(path, want, what):
+    got = dbsum(path)
+    for k in ("entries", "bytes", "digest"):
+        assert got[k] == want[k], "%s: %s differs from the CPU oracle's (got %s, expected %s)" % (what, k, got[k], want[k])
+    for suffix in ("", ".index", ".dbtype"):
+        if os.path.exists(str(path) + suffix):
+            os.remove(str(path) + suffix)
+
+
+def test_large_chain_against_oracle_checksums(tmp_path):
+    import bench
+    import plass_amd
+    gold = json.load(open(GOLD))
+    sp = bench.synth_params(gold["config"], gold["pairs"])
+    for k, v in gold["synth"].items():                       # the fixture was made for exactly these generator parameters
+        assert getattr(sp, k) == pytest.approx(v), k
+    assert 2 * gold["pairs"] >= 5000000
+    ctx = plass_amd.Context(0)
+    try:
+        reads, sst = ctx.synth_read_pairs(sp)
+        assert sst.max_coverage > 5 * sst.mean_coverage      # skewed: the test is about uneven bucket and group sizes
+        reads.write(tmp_path / "reads")
+        check(tmp_path / "reads", gold["reads"], "synthetic reads (GPU generator against the CPU generator)")
+        db = ctx.plass_fragments(reads)
+        reads.free()
+        db.write(tmp_path / "seq_0")
+        check(tmp_path / "seq_0", gold["fragments"], "extractorfs + translatenucs + concatdbs")
+        for it, want in enumerate(gold["iterations"]):
+            par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=bench.hash_shift(it),
+                                            include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
+            cands, _ = ctx.kmermatcher(db, par)
+            cands.write(tmp_path / "pref")
+            check(tmp_path / "pref", want["pref"], "kmermatcher, iteration %d" % it)
+            alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5))
+            cands.free()
+            alns.write(tmp_path / "aln")
+            check(tmp_path / "aln", want["aln"], "rescorediagonal, iteration %d" % it)
+            out, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
+            alns.free(); db.free()
+            out.write(tmp_path / "seq")
+            check(tmp_path / "seq", want["seq"], "assembleresults, iteration %d" % it)
+            db = out
+        db.free()
+    finally:
+        ctx.close()
+
+
+def test_split_data_files_and_text_round_trips(tmp_path, golden):
+    """host boundary on the GPU box: a sequence DB whose data is split over NAME.0..NAME.2 (the reference's unmerged writer files) loads
+    like the merged one; prefilter / alignment DBs written by the threaded writers parse back to the same lists (write -> read -> write
+    gives identical files)"""
+    import shutil
+    import numpy as np
+    import plass_amd
+    ctx = plass_amd.Context(0)
+    try:
+        src = os.path.join(golden, "aa", "seq_2")
+        db = ctx.read_seqdb(src)
+        db.write(tmp_path / "whole")
+        data = open(tmp_path / "whole", "rb").read()
+        cuts = [0, len(data) // 3 + 7, 2 * len(data) // 3 + 1, len(data)]
+        for i in range(3):
+            open(str(tmp_path / "split") + ".%d" % i, "wb").write(data[cuts[i]:cuts[i + 1]])
+        shutil.copy(str(tmp_path / "whole") + ".index", str(tmp_path / "split") + ".index")
+        shutil.copy(str(tmp_path / "whole") + ".dbtype", str(tmp_path / "split") + ".dbtype")
+        db2 = ctx.read_seqdb(tmp_path / "split")
+        a, b = db.download(), db2.download()
+        assert a[0] == b[0] and all(np.array_equal(x, y) for x, y in zip(a[1:], b[1:]))
+        assert not [f for f in os.listdir(tmp_path) if ".tmp." in f]
+        cands, _ = ctx.kmermatcher(db, plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=68,
+                                                                  include_only_extendable=True, ignore_multi_kmer=True, cov_mode=0, c=0.0))
+        cands.write(tmp_path / "pref")
+        again = ctx.read_prefdb(db, db, tmp_path / "pref")
+        again.write(tmp_path / "pref2")
+        for sfx in ("", ".index", ".dbtype"):
+            assert open(str(tmp_path / "pref") + sfx, "rb").read() == open(str(tmp_path / "pref2") + sfx, "rb").read()
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+        alns.write(tmp_path / "aln")
+        back = ctx.read_alndb(db, tmp_path / "aln")
+        assert back.count() == alns.count()
+        x, y = alns.download(), back.download()
+        for r, s in zip(x[:2000], y[:2000]):
+            assert (r.query_key, r.target_key, r.bit_score, r.q_start, r.q_end, r.db_start, r.db_end) == (s.query_key, s.target_key, s.bit_score, s.q_start, s.q_end, s.db_start, s.db_end)
+    finally:
+        ctx.close()

@@ -10,8 +10,12 @@ from conftest import ROOT
 
 
 def _declared_symbols():
-    hdr = open(os.path.join(ROOT, "include", "plasship.h")).read()
-    return sorted(set(re.findall(r"\b(plasship_[a-z_0-9]+)\s*\(", hdr)))
+    """every function the C-ABI headers declare (include/plasship.h, plasship_synth.h, plasship_rccl.h)"""
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        if h.endswith(".h"):
+            names |= set(re.findall(r"\b(plasship_[a-z_0-9]+)\s*\(", open(os.path.join(ROOT, "include", h)).read()))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -23,11 +27,25 @@ def test_library_exports_every_declared_symbol():
     lib = plass_amd.load_library()
     declared = _declared_symbols()
     assert len(declared) >= 24
-    bound = {s[0] for s in _lib.SYMBOLS}
+    bound = {s[0] for s in _lib.SYMBOLS + _lib.SYNTH_SYMBOLS + _lib.RCCL_SYMBOLS}
     for name in declared:
         assert hasattr(lib, name), "missing export " + name
         assert name in bound, "python binding does not cover " + name
     assert lib.plasship_version().startswith(b"plasship")
+
+
+def test_host_boundary_files(tmp_path):
+    """the threaded DB reader / writers of the product (plass_amd/csrc/host_util.cpp) without a GPU: byte-identical files for 1, 3 and
+    16 host threads, data split over NAME.0..NAME.2 read back, bad indices refused, failed writes leave nothing behind"""
+    import subprocess
+    exe = tmp_path / "host_io_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(ROOT, "tests", "tools", "host_io_check.cpp"),
+                           os.path.join(ROOT, "plass_amd", "csrc", "host_util.cpp"), "-o", str(exe)])
+    for threads in ("1", "3", "16"):
+        d = tmp_path / ("t" + threads)
+        d.mkdir()
+        out = subprocess.run([str(exe), str(d)], env=dict(os.environ, PLASSHIP_HOST_THREADS=threads), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert out.returncode == 0 and "host_io_check ok (%s host threads)" % threads in out.stdout, out.stdout
 
 
 def test_no_cpu_fallback():
