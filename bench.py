@@ -95,15 +95,16 @@ def one_iteration(ctx, db, it):
     import plass_amd
     par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=hash_shift(it),
                                     include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); s0 = ctx.host_syncs()
     cands, kst = ctx.kmermatcher(db, par)
-    t1 = time.perf_counter()
+    t1 = time.perf_counter(); s1 = ctx.host_syncs()
     alns, rst = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5))
-    t2 = time.perf_counter()
+    t2 = time.perf_counter(); s2 = ctx.host_syncs()
     out, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
-    t3 = time.perf_counter()
+    t3 = time.perf_counter(); s3 = ctx.host_syncs()
     alns.free(); cands.free()
-    return out, kst, rst, ast, ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3)
+    # wall: ms per module, then the number of times the host waited for the stream inside each module
+    return out, kst, rst, ast, ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s1 - s0, s2 - s1, s3 - s2)
 
 
 def stage_table(kst, rst, ast):
@@ -172,7 +173,7 @@ def cpu_baseline(ctx, cfg, sample_pairs, iters):
             asm = ["--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1", "--rescore-mode", "3"]
             if os.path.exists(hip):                          # the GPU path through the module boundary, on the same files
                 for args in (["kmermatcher", s, p + "_g"] + km, ["rescorediagonal", s, s, p + "_g", a + "_g"] + rs, ["assembleresults", s, a + "_g", o + "_g"] + asm):
-                    out = subprocess.run([hip] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                    out = subprocess.run([hip] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=g.child_env())
                     m = re.search(r"Time for processing: ([0-9.]+)s", out.stdout)
                     if out.returncode != 0 or not m:
                         raise RuntimeError("plass-hip %s failed: %s" % (args[0], out.stdout[-500:]))
@@ -184,8 +185,8 @@ def cpu_baseline(ctx, cfg, sample_pairs, iters):
             e2 = g.run_oracle(["rescorediagonal", s, s, p, a] + rs[2:] + thr)
             e3 = g.run_oracle(["assembleresults", s, a, o] + asm[:6] + thr)
             tot_c += int(re.search(r"N_c=(\d+)", e1).group(1))
-            for e in (e1, e2, e3):
-                tot_t += float(re.search(r"([0-9.]+) s\s*$", e.strip()).group(1))
+            for e in (e1, e2, e3):                           # "oracle <module>: …, 1.234 s" (other lines may follow: a profiler attached to the child)
+                tot_t += float(re.search(r"^oracle \w+:.*?([0-9.]+) s\s*$", e, re.M).group(1))
     res = {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
            "sample": "%d read pairs of the same community model at the same coverage (%d genomes, %d protein fragments), iterations 0..%d of the chain, "
                      "oracle module compute time (no DB I/O), %d OpenMP threads (grouping and result writing are single-threaded, as in the reference)"
@@ -303,7 +304,7 @@ def main():
             if VERBOSE and rank == 0:
                 print("   N_k=%d N_m=%d N_c=%d | scored=%d accepted=%d | aln=%d extended=%d rescored=%d | wall ms %s" % (
                     kst.n_kmer_records, kst.n_grouped, kst.n_candidates, rst.n_scored, rst.n_accepted, ast.n_alignments, ast.n_extended, ast.n_rescored,
-                    ["%.1f" % x for x in wall]), file=sys.stderr, flush=True)
+                    ["%.1f" % x for x in wall[:3]]), file=sys.stderr, flush=True)
             if record:
                 ctx.sync()
                 rows.append((it, (time.perf_counter() - ts) * 1e3, kst, rst, ast, wall))
@@ -350,7 +351,8 @@ def main():
                     "stage_ms_per_step": {k: round(v[0] / len(stats), 4) for k, v in tot.items()},
                     "kmermatcher_stage": {"algorithmic_bytes_per_step": km[1] / len(stats), "ms_per_step": km[0] / len(stats),
                                           "frac": (km[1] / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if km[0] > 0 else 0.0},
-                    "module_wall_ms_per_step": [round(sum(r[5][i] for r in rows) / len(rows), 3) for i in range(3)]}
+                    "module_wall_ms_per_step": [round(sum(r[5][i] for r in rows) / len(rows), 3) for i in range(3)],
+                    "host_waits_per_step": [round(sum(r[5][3 + i] for r in rows) / len(rows), 1) for i in range(3)]}
         line = {
             "metric": "read-overlaps/s per assembly iteration", "value": overlaps / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s",
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": elapsed * 1e3 / max(steps, 1),
@@ -371,7 +373,7 @@ def main():
                             "kmermatcher_ms": round(k.ms_extract + k.ms_sort1 + k.ms_group + k.ms_sort2 + k.ms_reduce, 3),
                             "extract_ms": round(k.ms_extract, 3), "partition_ms": round(k.ms_sort1, 3), "group_ms": round(k.ms_group, 3),
                             "repsort_ms": round(k.ms_sort2, 3), "reduce_ms": round(k.ms_reduce, 3),
-                            "rescore_ms": round(r.ms_kernel, 3), "assemble_ms": round(a.ms_kernel, 3), "module_wall_ms": [round(x, 3) for x in w]}
+                            "rescore_ms": round(r.ms_kernel, 3), "assemble_ms": round(a.ms_kernel, 3), "module_wall_ms": [round(x, 3) for x in w[:3]], "host_waits": list(w[3:6])}
                            for i, (it, ms, k, r, a, w) in enumerate(rows)],
             "roofline": roof,
         }

@@ -50,6 +50,9 @@ void plasship_ctx_destroy(plasship_ctx *ctx);
 int plasship_ctx_sync(plasship_ctx *ctx);
 /* raw hipStream_t of the context, so a caller can bracket work with its own events */
 void *plasship_ctx_stream(plasship_ctx *ctx);
+/* diagnostic: how often the host has waited for a stream since the library was loaded (all contexts of the process).  A module
+ * call is a chain of kernels on the context stream; the host waits only where it needs a size to allocate the next buffer. */
+unsigned long long plasship_host_syncs(void);
 
 /* ---- one read set sharded over several GPUs (one process / context per GPU) ------------------
  * replaces: the reference's split of kmermatcher over MPI ranks by k-mer hash range

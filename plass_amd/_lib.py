@@ -110,6 +110,7 @@ SYMBOLS = [
     ("plasship_ctx_destroy", None, [P]),
     ("plasship_ctx_sync", C.c_int, [P]),
     ("plasship_ctx_stream", P, [P]),
+    ("plasship_host_syncs", C.c_ulonglong, []),
     ("plasship_ctx_set_comm", C.c_int, [P, P]),
     ("plasship_ctx_copy_d2d", C.c_int, [P, P, P, C.c_uint64]),
     ("plasship_seqdb_upload", C.c_int, [P, C.c_char_p, C.c_size_t, P, P, P, C.c_size_t, C.c_int, C.POINTER(P)]),
@@ -300,6 +301,10 @@ class Context:
 
     def sync(self):
         _check(self.lib.plasship_ctx_sync(self.h), "plasship_ctx_sync")
+
+    def host_syncs(self):
+        """host waits for a stream since the library was loaded (diagnostic; bench.py reports the count per iteration)"""
+        return int(self.lib.plasship_host_syncs())
 
     def __enter__(self):
         return self

@@ -1256,7 +1256,7 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
     uint64_t outBytes = 0, outN = 0;
     PH_CHECK(hipMemcpyAsync(&outBytes, dOutOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&outN, dKeepPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     std::unique_ptr<plasship_seqdb> holder(new plasship_seqdb());   // released to the caller on success only
     plasship_seqdb *o = holder.get();
@@ -1276,7 +1276,7 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
     if (doneEvent) PH_CHECK(hipEventRecord(doneEvent, st));
     PH_CHECK(hipMemcpyAsync(&maxLen, dMaxLen.p, 4, hipMemcpyDeviceToHost, st));
     if (dExtra) PH_CHECK(hipMemcpyAsync(hExtra, dExtra, extraBytes, hipMemcpyDeviceToHost, st));      // the caller's counters ride along
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     o->maxEntryLen = maxLen + 2;
     *out = holder.release();
@@ -1306,7 +1306,7 @@ static int mergeExtended(plasship_ctx *ctx, uint32_t N, bool guided, int keepTar
     PH_CHECK(hipMemcpyAsync(&nExt, dPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&extBytes, dOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     if (guided) PH_CHECK(hipMemcpyAsync(&aaExtBytes, dAaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     DevBuf dMeta, dPacked, dAaPacked;
     if (dMeta.alloc(std::max<uint64_t>(nExt, 1) * sizeof(ExtMeta)) != hipSuccess || dPacked.alloc(extBytes + 64) != hipSuccess || (guided && dAaPacked.alloc(aaExtBytes + 64) != hipSuccess)) {
         setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE;
@@ -1343,9 +1343,9 @@ static int mergeExtended(plasship_ctx *ctx, uint32_t N, bool guided, int keepTar
         DevBuf gFlags;
         rc = commAllgathervBytes(ctx, dFlags, (uint64_t) N * 4, gFlags, rb); if (rc) return rc;
         if (N) hipLaunchKernelGGL(orFlagsKernel, dim3(gridN), dim3(256), 0, st, gFlags.as<uint32_t>(), N, W, dFlags);
-        PH_CHECK(hipStreamSynchronize(st));       // gFlags is released on return
+        PH_CHECK(plasship::streamSync(st));       // gFlags is released on return
     }
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     return PLASSHIP_OK;
 }
@@ -1400,7 +1400,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     PH_CHECK(hipMemcpyAsync(&arenaBytes, dArenaOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&totA, dPosA.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&totB, dPosB.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     const uint32_t cnts[4] = {(uint32_t) totA, (uint32_t) (totA >> 32), (uint32_t) totB, (uint32_t) (totB >> 32)};
     if (dArena.alloc(arenaBytes + 64) != hipSuccess || (guided && dAaArena.alloc(aaArenaBytes + 64) != hipSuccess)) {
         size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
@@ -1462,7 +1462,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
             } else launchWave(dRedo[(pass + 1) & 1].as<uint32_t>(), nWork);
             uint32_t cnt[2] = {0, 0};
             PH_CHECK(hipMemcpyAsync(cnt, dCnt.p, 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(hipStreamSynchronize(st));
+            PH_CHECK(plasship::streamSync(st));
             PH_CHECK(hipGetLastError());
             nWork = cnt[1];
             if (nWork == 0) break;
@@ -1508,7 +1508,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         if (rcOut != PLASSHIP_OK) return rcOut;
         holdAa.reset(oAa);
     }
-    if (guided) { PH_CHECK(hipEventRecord(ctx->ev[1], st)); PH_CHECK(hipStreamSynchronize(st)); }
+    if (guided) { PH_CHECK(hipEventRecord(ctx->ev[1], st)); PH_CHECK(plasship::streamSync(st)); }
     if (hs[12]) { setError("plasship_guided_assemble: an alignment asks for a protein fragment the twin does not have (coordinates are not codon aligned)"); return PLASSHIP_ERR_ARG; }
     if (stats) {
         stats->n_extended = hs[0]; stats->n_rescored = hs[1]; stats->out_residues = o->residues;

@@ -23,7 +23,7 @@ extern "C" int plasship_ctx_copy_d2d(plasship_ctx *ctx, void *dst, const void *s
     if (!ctx) { setError("plasship_ctx_copy_d2d: ctx is NULL"); return PLASSHIP_ERR_ARG; }
     PH_ENTER(ctx);
     if (bytes) PH_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     return PLASSHIP_OK;
 }
 
@@ -32,7 +32,7 @@ namespace plasship {
 int commAllgatherHost(plasship_ctx *ctx, const void *send, void *recv, uint64_t bytesPerRank) {
     const plasship_comm *cm = commOf(ctx);
     if (!cm) { memcpy(recv, send, bytesPerRank); return PLASSHIP_OK; }
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     if (cm->allgather_host(cm->user, send, recv, bytesPerRank) != 0) { setError("sharded run: the caller's allgather_host failed"); return PLASSHIP_ERR_DEVICE; }
     return PLASSHIP_OK;
 }
@@ -75,7 +75,7 @@ int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *s
     for (int r = 0; r < W; r++) { sendBytes[r] = sendCount[r] * recordBytes; const uint64_t c = all[(size_t) r * W + cm->rank]; recvBytes[r] = c * recordBytes; tot += c; }
     rc = commAgreeOk(ctx, recv.alloc(std::max<uint64_t>(tot + slackRecords, 1) * recordBytes) == hipSuccess, "sharded run: out of device memory for the receive buffer");
     if (rc) return rc;
-    if (!cm->stream_ordered) PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!cm->stream_ordered) PH_CHECK(plasship::streamSync(ctx->stream));
     if (cm->alltoallv_dev(cm->user, dSend, sendBytes.data(), recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's alltoallv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     *recvTotal = tot;
     if (allTotal) { uint64_t a = 0; for (uint64_t c : all) a += c; *allTotal = a; }
@@ -99,7 +99,7 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
     uint64_t tot = 0; for (int r = 0; r < W; r++) tot += recvBytes[r];
     const int rcA = commAgreeOk(ctx, recv.alloc(tot + 64) == hipSuccess, "sharded run: out of device memory for the gather buffer");
     if (rcA) return rcA;
-    if (!cm->stream_ordered) PH_CHECK(hipStreamSynchronize(ctx->stream));
+    if (!cm->stream_ordered) PH_CHECK(plasship::streamSync(ctx->stream));
     if (cm->allgatherv_dev(cm->user, dSend, sendBytes, recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's allgatherv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     return PLASSHIP_OK;
 }

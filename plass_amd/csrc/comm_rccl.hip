@@ -90,7 +90,7 @@ int cbAllgatherHost(void *user, const void *send, void *recv, uint64_t n) {
     HC(hipMemcpyAsync(d, h, slot, hipMemcpyHostToDevice, st));
     RC(rccl().AllGather(d, d + slot, slot, NCCL_UINT8, c->comm, st), "ncclAllGather");
     HC(hipMemcpyAsync(h + slot, d + slot, slot * (size_t) c->world, hipMemcpyDeviceToHost, st));
-    HC(hipStreamSynchronize(st));
+    HC(plasship::streamSync(st));
     for (int r = 0; r < c->world; r++) memcpy(static_cast<char *>(recv) + (size_t) r * n, h + slot * (size_t) (r + 1), n);
     return 0;
 }
@@ -170,7 +170,7 @@ extern "C" int plasship_rccl_comm_stats(plasship_rccl_comm *c, uint64_t *bytes_s
 
 extern "C" void plasship_rccl_comm_destroy(plasship_ctx *ctx, plasship_rccl_comm *c) {
     if (!c) return;
-    if (ctx) { (void) hipSetDevice(ctx->device); (void) hipStreamSynchronize(ctx->stream); (void) plasship_ctx_set_comm(ctx, nullptr); }
+    if (ctx) { (void) hipSetDevice(ctx->device); (void) plasship::streamSync(ctx->stream); (void) plasship_ctx_set_comm(ctx, nullptr); }
     Rccl &r = rccl();
     if (c->comm) { if (c->failed && r.CommAbort) (void) r.CommAbort(c->comm); else if (r.CommDestroy) (void) r.CommDestroy(c->comm); }
     if (c->hStage) (void) hipHostFree(c->hStage);

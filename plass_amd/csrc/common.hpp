@@ -12,6 +12,8 @@
 namespace plasship {
 
 void setError(const std::string &msg);
+// every wait of the host for the stream goes through here and is counted (plasship_host_syncs(): bench.py reports waits per iteration)
+hipError_t streamSync(hipStream_t st);
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line);
 
 #define PH_CHECK(call)                                                                   \
@@ -27,7 +29,7 @@ std::string hipErrStr(hipError_t e, const char *what, const char *file, int line
 #define PH_COPY_SYNC(st, dst, src, bytes, kind)                                          \
     do {                                                                                 \
         PH_CHECK(hipMemcpyAsync((dst), (src), (bytes), (kind), (st)));                   \
-        PH_CHECK(hipStreamSynchronize(st));                                              \
+        PH_CHECK(plasship::streamSync(st));                                              \
     } while (0)
 
 // launch-geometry knobs (workgroups per CU of a persistent kernel's grid): default unless PLASSHIP_TUNE_<name> is set in the
@@ -39,7 +41,7 @@ bool traceOn();
 #define PH_TRACE(st, what)                                                                \
     do {                                                                                 \
         if (plasship::traceOn()) {                                                       \
-            hipError_t e_ = hipStreamSynchronize(st);                                    \
+            hipError_t e_ = plasship::streamSync(st);                                    \
             fprintf(stderr, "[plasship] %s: %s\n", (what), hipGetErrorString(e_));       \
         }                                                                                \
     } while (0)

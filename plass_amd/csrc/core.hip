@@ -109,7 +109,7 @@ static hipError_t poolMallocRaw(void **p, size_t n) {
         }
         if (hit) {
             if (waitAll) (void) hipDeviceSynchronize();
-            else if (waitFor) (void) hipStreamSynchronize(waitFor);          // the previous user's queued work must be through
+            else if (waitFor) (void) plasship::streamSync(waitFor);          // the previous user's queued work must be through
             return hipSuccess;
         }
         const auto t0 = std::chrono::steady_clock::now();
@@ -166,6 +166,8 @@ int tuneInt(const char *name, int dflt) {
 }
 bool traceOn() { static const bool v = getenv("PLASSHIP_TRACE") != nullptr; return v; }
 void setError(const std::string &msg) { g_err = msg; }
+static std::atomic<unsigned long long> g_hostSyncs(0);
+hipError_t streamSync(hipStream_t st) { g_hostSyncs++; return hipStreamSynchronize(st); }
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
     return std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
 }
@@ -218,7 +220,7 @@ extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
 extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
-    (void) hipStreamSynchronize(ctx->stream);
+    (void) plasship::streamSync(ctx->stream);
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
     for (int i = 0; i < 2; i++) { if (ctx->stage[i]) (void) hipHostFree(ctx->stage[i]); if (ctx->stageEv[i]) (void) hipEventDestroy(ctx->stageEv[i]); }
     if (ctx->stream) { poolForgetStream(ctx->stream); (void) hipStreamDestroy(ctx->stream); }
@@ -232,9 +234,10 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
 
 extern "C" int plasship_ctx_sync(plasship_ctx *ctx) {
     if (!ctx) { setError("ctx is NULL"); return PLASSHIP_ERR_ARG; }
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     return PLASSHIP_OK;
 }
+extern "C" unsigned long long plasship_host_syncs(void) { return plasship::g_hostSyncs.load(); }
 extern "C" void *plasship_ctx_stream(plasship_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
 
 // ---- host boundary: pinned staging -------------------------------------------------------------------
@@ -264,7 +267,7 @@ int stagedUpload(plasship_ctx *ctx, void *dDst, uint64_t total, const std::funct
         PH_CHECK(hipMemcpyAsync((char *) dDst + o, ctx->stage[b], n, hipMemcpyHostToDevice, ctx->stream));
         PH_CHECK(hipEventRecord(ctx->stageEv[b], ctx->stream)); used[b] = true;
     }
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     return PLASSHIP_OK;
 }
 int stagedDownload(plasship_ctx *ctx, const void *dSrc, uint64_t total, const std::function<bool(const char *, uint64_t, uint64_t)> &consume) {
@@ -282,7 +285,7 @@ int stagedDownload(plasship_ctx *ctx, const void *dSrc, uint64_t total, const st
     for (uint64_t o = 0; o < total; o += CH, b ^= 1) {
         if (o + CH < total) { rc = issue(o + CH, b ^ 1); if (rc) return rc; }   // the other buffer was consumed in the previous round
         PH_CHECK(hipEventSynchronize(ctx->stageEv[b]));
-        if (!consume(ctx->stage[b], o, std::min<uint64_t>(CH, total - o))) { (void) hipStreamSynchronize(ctx->stream); return PLASSHIP_ERR_IO; }
+        if (!consume(ctx->stage[b], o, std::min<uint64_t>(CH, total - o))) { (void) plasship::streamSync(ctx->stream); return PLASSHIP_ERR_IO; }
     }
     return PLASSHIP_OK;
 }
@@ -364,7 +367,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         int rc = stagedCopyToDevice(ctx, db->d_len.p, hlen.data(), n * 4); if (rc) return rc;
         rc = stagedCopyToDevice(ctx, db->d_key.p, db->h_key.data(), n * 4); if (rc) return rc;
     }
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     *out = holder.release();
     return PLASSHIP_OK;
 }
@@ -381,7 +384,7 @@ static int ensureHostIndex(plasship_ctx *ctx, plasship_seqdb *db) {
     size_t n = db->n;
     db->h_key.resize(n); db->h_off.resize(n + 1); db->h_elen.resize(n);
     std::vector<uint32_t> len(n);
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     { int rc = stagedCopyToHost(ctx, db->h_off.data(), db->d_off.p, (n + 1) * 8); if (rc) return rc; }
     if (n) {
         int rc = stagedCopyToHost(ctx, db->h_key.data(), db->d_key.p, n * 4); if (rc) return rc;
@@ -410,7 +413,7 @@ extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *
     plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     PH_ENTER(ctx);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     if (data && db->dataBytes) { rc = stagedCopyToHost(ctx, data, db->d_data.p, db->dataBytes); if (rc) return rc; }
     if (off) memcpy(off, db->h_off.data(), db->n * 8);
     if (elen) memcpy(elen, db->h_elen.data(), db->n * 4);
@@ -423,7 +426,7 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
     plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     PH_ENTER(ctx);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     // the device layout is the file layout (entries "SEQ\n\0" back to back in key order): the data file is the device buffer, streamed
     // through the pinned staging buffers while the previous chunk is being written; the index is formatted on the host threads
     std::string err; DBFileWriter w;

@@ -308,7 +308,7 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
             a.keys = dKeys.as<unsigned long long>(); a.minF = dMinF.as<uint32_t>(); a.minM = dMinM.as<uint32_t>(); a.hits = dHits.as<uint32_t>();
             a.slotOff = dSO.as<uint64_t>(); a.slotCnt = dSC.as<uint32_t>(); a.hitOff = dHO.as<uint64_t>();
             hipLaunchKernelGGL(cycleBlockKernel, dim3(std::min<uint32_t>(nb, (uint32_t) ctx->numCU * 4)), dim3(256), 0, st, a);
-            PH_CHECK(hipStreamSynchronize(st));
+            PH_CHECK(plasship::streamSync(st));
             PH_CHECK(hipGetLastError());
             b0 = b1;
         }

@@ -110,7 +110,7 @@ extern "C" int plasship_find_assembly_start(plasship_ctx *ctx, const plasship_se
         const int rc = commAllgathervBytesKnown(ctx, dStop.p, (uint64_t) N * 4, gAll, rb);
         if (rc) return rc;
         if (N) hipLaunchKernelGGL(maxIntRowsKernel, dim3(grid), dim3(256), 0, st, gAll.as<int>(), N, cm->world, dStop.as<int>());
-        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(plasship::streamSync(st));
     }
     if (N) hipLaunchKernelGGL(findStartLenKernel, dim3(grid), dim3(256), 0, st, sv, dStop.as<int>(), dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dBytes.as<uint64_t>());
     if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dStart.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_find_assembly_start: scan failed"); return PLASSHIP_ERR_DEVICE; }

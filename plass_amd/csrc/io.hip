@@ -17,7 +17,7 @@ static int hostKeys(plasship_ctx *ctx, const plasship_seqdb *cdb, const std::vec
     plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     if (!db->hostIndexValid && db->h_key.size() != db->n) {
         db->h_key.resize(db->n);
-        PH_CHECK(hipStreamSynchronize(ctx->stream));
+        PH_CHECK(plasship::streamSync(ctx->stream));
         if (db->n) { const int rc = stagedCopyToHost(ctx, db->h_key.data(), db->d_key.p, db->n * 4); if (rc) return rc; }
     }
     *keys = &db->h_key;
@@ -118,7 +118,7 @@ extern "C" int plasship_cands_read(plasship_ctx *ctx, const plasship_seqdb *qdb,
 
 static int fetchCands(plasship_ctx *ctx, const plasship_cands *c, std::vector<uint64_t> &qoff, std::vector<CandHit> &hits) {
     qoff.resize(c->nQueries + 1); hits.resize(c->nHits);
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     int rc = stagedCopyToHost(ctx, qoff.data(), c->d_qoff.p, (c->nQueries + 1) * 8); if (rc) return rc;
     return stagedCopyToHost(ctx, hits.data(), c->d_hits.p, c->nHits * sizeof(CandHit));
 }
@@ -181,7 +181,7 @@ extern "C" void plasship_alns_free(plasship_ctx *ctx, plasship_alns *a) {
 
 static int fetchAlns(plasship_ctx *ctx, const plasship_alns *a, std::vector<uint64_t> &qoff, std::vector<AlnRec> &recs) {
     qoff.resize(a->nQueries + 1); recs.resize(a->nLines);
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     int rc = stagedCopyToHost(ctx, qoff.data(), a->d_qoff.p, (a->nQueries + 1) * 8); if (rc) return rc;
     return stagedCopyToHost(ctx, recs.data(), a->d_recs.p, a->nLines * sizeof(AlnRec));
 }

@@ -1051,13 +1051,17 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 // sequences of the KmerPosition<short> layout are shorter than 32 767, so the four fields fit 63 bits.  (The three-phase kernel
 // above reads every record three times and needs a barrier more per bucket; it remains for 24-byte records, dense input and
 // buckets beyond 2048 positions.)
+// BLOCK x HT: 256 threads and 2048 slots hold buckets of up to 2048 positions (~1500 distinct k-mers); the 50 M-read sets fill the
+// 2^20 buckets two partition levels can make with ~4000 positions each, which 512 threads and 4096 slots take in one go (a
+// bucket beyond the registers would be read from HBM once per phase and sub-pass).  "At least two members" is one bit per slot.
 constexpr int GL_RMAX = 8;
-template <bool NUCL>
-__global__ __launch_bounds__(GR_BLOCK) void groupLinesKernel(GroupArgs a) {
+template <bool NUCL, int BLOCK, uint32_t HT, int WPE>
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void groupLinesKernel(GroupArgs a) {
     typedef Rec<false> R;
-    __shared__ unsigned long long hKey[GR_HT];
-    __shared__ unsigned long long hBest[GR_HT];
-    __shared__ uint32_t hCnt[GR_HT];
+    constexpr uint32_t MAXKEYS = HT / 4 * 3;                 // distinct k-mers per sub-pass before splitting further
+    __shared__ unsigned long long hKey[HT];
+    __shared__ unsigned long long hBest[HT];
+    __shared__ uint32_t hMulti[HT / 32];                     // bit = a second record met this slot's k-mer
     __shared__ uint32_t sFlag[2];
     __shared__ uint32_t sCursor;
     const R *in = reinterpret_cast<const R *>(a.in);
@@ -1074,43 +1078,50 @@ __global__ __launch_bounds__(GR_BLOCK) void groupLinesKernel(GroupArgs a) {
         const uint32_t lb = a.lineBeg[b];
         if (n == 0) continue;
         auto recAt = [&](uint32_t i) -> R { return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)]; };
-        const bool inRegs = n <= (uint32_t) GL_RMAX * GR_BLOCK;
+        const R none = [] { R r; r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; return r; }();
+        const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
         R rg[GL_RMAX];
         if (inRegs) {
 #pragma unroll
-            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * GR_BLOCK + threadIdx.x; if (i < n) rg[j] = recAt(i); else { rg[j].kmer = ~0ULL; rg[j].id = 0xFFFFFFFFu; rg[j].len = 0; rg[j].pos = 0; } }
+            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < n) ? recAt(i) : none; }
         }
-        // phase A on one record: claim the k-mer's slot, count, and bid for the run head
+        // phase A on one record: claim the k-mer's slot, mark a second member, and bid for the run head; called by whole wavefronts
+        // (new k-mers are counted once per wavefront, not with one LDS atomic per record on a single word)
         auto phaseA = [&](const R &r, uint32_t nSub, uint32_t sub) {
-            if (isSentinel(r)) return;
+            bool claimed = false, full = false;
             const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
             const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
-            if (nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub) return;
-            uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
-            for (uint32_t probe = 0; probe < GR_HT; probe++) {
-                const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, K);
-                if (prev == ~0ULL) atomicAdd(&sFlag[0], 1u);
-                if (prev == ~0ULL || prev == K) {
-                    atomicAdd(&hCnt[slot], 1u);
-                    const unsigned long long packed = ((unsigned long long) (0x7FFFu - (uint32_t) r.len) << 48) | ((unsigned long long) r.id << 16) |
-                                                      ((unsigned long long) ((uint32_t) r.pos & 0x7FFFu) << 1) | (NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL);
-                    atomicMin(&hBest[slot], packed);
-                    return;
+            if (!isSentinel(r) && !(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
+                uint32_t slot = (uint32_t) (hh >> 32) & (HT - 1);
+                full = true;
+                for (uint32_t probe = 0; probe < HT; probe++) {
+                    const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, K);
+                    if (prev == ~0ULL || prev == K) {
+                        claimed = (prev == ~0ULL);
+                        if (!claimed) atomicOr(&hMulti[slot >> 5], 1u << (slot & 31));
+                        const unsigned long long packed = ((unsigned long long) (0x7FFFu - (uint32_t) r.len) << 48) | ((unsigned long long) r.id << 16) |
+                                                          ((unsigned long long) ((uint32_t) r.pos & 0x7FFFu) << 1) | (NUCL ? ((r.kmer >> 63) & 1ULL) : 0ULL);
+                        atomicMin(&hBest[slot], packed);
+                        full = false;
+                        break;
+                    }
+                    slot = (slot + 1) & (HT - 1);
                 }
-                slot = (slot + 1) & (GR_HT - 1);
             }
-            atomicExch(&sFlag[1], 1u);                // table full
+            const unsigned long long cm = __ballot(claimed);
+            if (cm && laneId() == 0) atomicAdd(&sFlag[0], (uint32_t) __popcll(cm));
+            if (full) atomicExch(&sFlag[1], 1u);      // table full
         };
         // phase C on one record: (rep, member, diagonal) if the run has at least two members and the filter keeps it
-        auto phaseC = [&](const R &r, bool here, uint32_t nSub, uint32_t sub) {
+        auto phaseC = [&](const R &r, uint32_t nSub, uint32_t sub) {
             bool keep = false; R o; o.kmer = 0; o.id = 0; o.len = 0; o.pos = 0;
-            if (here && !isSentinel(r)) {
+            if (!isSentinel(r)) {
                 const unsigned long long K = NUCL ? (r.kmer | BIT63) : r.kmer;
                 const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
                 if (!(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
-                    uint32_t slot = (uint32_t) (hh >> 32) & (GR_HT - 1);
-                    while (hKey[slot] != K) slot = (slot + 1) & (GR_HT - 1);
-                    if (hCnt[slot] >= 2) {
+                    uint32_t slot = (uint32_t) (hh >> 32) & (HT - 1);
+                    while (hKey[slot] != K) slot = (slot + 1) & (HT - 1);
+                    if ((hMulti[slot >> 5] >> (slot & 31)) & 1u) {
                         const unsigned long long best = hBest[slot];
                         const uint32_t repId = (uint32_t) (best >> 16);
                         const int repPos = (int) ((best >> 1) & 0x7FFFu);
@@ -1153,19 +1164,19 @@ __global__ __launch_bounds__(GR_BLOCK) void groupLinesKernel(GroupArgs a) {
         for (;;) {
             bool redo = false;
             for (uint32_t sub = 0; sub < nSub && !redo; sub++) {
-                for (uint32_t i = threadIdx.x; i < GR_HT; i += GR_BLOCK) { hKey[i] = ~0ULL; hBest[i] = ~0ULL; hCnt[i] = 0; }
+                for (uint32_t i = threadIdx.x; i < HT; i += BLOCK) { hKey[i] = ~0ULL; hBest[i] = ~0ULL; if (i < HT / 32) hMulti[i] = 0; }
                 if (threadIdx.x == 0) { sFlag[0] = 0; sFlag[1] = 0; sCursor = 0; }
                 __syncthreads();
                 if (inRegs) {
 #pragma unroll
-                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * GR_BLOCK < n) phaseA(rg[j], nSub, sub);
-                } else for (uint32_t i = threadIdx.x; i < n; i += GR_BLOCK) phaseA(recAt(i), nSub, sub);
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseA(rg[j], nSub, sub);
+                } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseA(i < n ? recAt(i) : none, nSub, sub); }
                 __syncthreads();
-                if (sFlag[1] || sFlag[0] > GR_MAXKEYS) { redo = true; __syncthreads(); break; }
+                if (sFlag[1] || sFlag[0] > MAXKEYS) { redo = true; __syncthreads(); break; }
                 if (inRegs) {
 #pragma unroll
-                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * GR_BLOCK < n) phaseC(rg[j], true, nSub, sub);
-                } else for (uint32_t i0 = 0; i0 < n; i0 += GR_BLOCK) { const uint32_t i = i0 + threadIdx.x; R r; if (i < n) r = recAt(i); else { r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; } phaseC(r, i < n, nSub, sub); }
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseC(rg[j], nSub, sub);
+                } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseC(i < n ? recAt(i) : none, nSub, sub); }
                 __syncthreads();
                 written += sCursor;
                 __syncthreads();
@@ -1596,7 +1607,7 @@ static void traceBadIds(plasship_ctx *ctx, const char *what, const void *recs, u
     (void) hipMemsetAsync(d.p, 0, 16, ctx->stream);
     hipLaunchKernelGGL((countBadIdsKernel<LONG>), dim3(1024), dim3(256), 0, ctx->stream, recs, n, nSeq, d.as<unsigned long long>());
     (void) hipMemcpyAsync(h, d.p, 16, hipMemcpyDeviceToHost, ctx->stream);
-    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    const hipError_t e = plasship::streamSync(ctx->stream);
     fprintf(stderr, "[plasship] %s: %llu records, %llu with an id out of range, %llu sentinels (%s)\n", what, (unsigned long long) n, h[0], h[1], hipGetErrorString(e));
 }
 
@@ -1780,8 +1791,13 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
     ga.maxRepTarget = dMaxRT.as<unsigned long long>();
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
+    // positions per bucket (sentinel padding included) decide the workgroup shape of the 16-byte-record kernel
+    const uint64_t avgPos = finalCap * RPL / std::max<uint32_t>(nBuckets, 1);
+    const bool wideGroup = !LONG && (getenv("PLASSHIP_GROUP_WIDE") ? atoi(getenv("PLASSHIP_GROUP_WIDE")) != 0 : avgPos > 1600);
     if constexpr (LONG) hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-    else hipLaunchKernelGGL((groupLinesKernel<NUCL>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+    else if (wideGroup && tuneInt("GROUP_WPE", 4) == 4) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 4>), dim3(gGrid), dim3(512), 0, st, ga);
+    else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 2>), dim3(gGrid), dim3(512), 0, st, ga);
+    else hipLaunchKernelGGL((groupLinesKernel<NUCL, GR_BLOCK, GR_HT, 3>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
     std::vector<uint64_t> hOutCnt(gGrid), hArena(gGrid);
     unsigned long long hLastRun[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
@@ -1791,7 +1807,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hArena.data(), dArenaStart.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(ks, dKStats.p, 32, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     uint64_t Nm = 0;
     for (uint32_t j = 0; j < gGrid; j++) Nm += hOutCnt[j];
@@ -1821,7 +1837,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(1), dim3(64), 0, st, ta);
         std::vector<R> trec(tb);
         PH_CHECK(hipMemcpyAsync(trec.data(), dTRec.p, (size_t) tb * sizeof(R), hipMemcpyDeviceToHost, st));
-        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(plasship::streamSync(st));
         trec.erase(std::remove_if(trec.begin(), trec.end(), [](const R &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }), trec.end());
         std::sort(trec.begin(), trec.end(), [](const R &x, const R &y) { return recLess1<NUCL, LONG>(x, y); });
         const uint32_t m = (uint32_t) trec.size();
@@ -1839,7 +1855,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
                                (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(hipStreamSynchronize(st));
+            PH_CHECK(plasship::streamSync(st));
             unsigned long long rank = 0, expect = Nm;
             for (uint32_t j = 0; j < m; j++) {
                 rank += diff[j];                         // records strictly before trec[j] in sort-#1 order
@@ -1897,7 +1913,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         a.in = otherRecs; a.out = dR1.p; a.tags = dRTag1.as<uint32_t>(); a.pieces = dRPieces.as<LinePiece>(); a.nPieces = dRNP.as<uint32_t>(); a.nb = nS1; a.key = rkey;
         rc = launchLinePart<NUCL, LONG, KEY_RANGE, false, false>(ctx, a, std::max<uint32_t>(nPR1, 1)); if (rc) return rc;
     }
-    PH_CHECK(hipStreamSynchronize(st));                     // hp goes out of use (async copy of a pageable host vector)
+    PH_CHECK(plasship::streamSync(st));                     // hp goes out of use (async copy of a pageable host vector)
     rc = buildLineLists(ctx, dRTag1.as<uint32_t>(), capR1, nS1, dRCnt1.as<uint32_t>(), dRStart1.as<uint32_t>(), dRCur1.as<uint32_t>(), dRList1.as<uint32_t>()); if (rc) return rc;
     (otherRecs == dA.p ? dA : dB).release();               // the arenas are consumed
     void *sortRecs = dR1.p; const uint32_t *sortList = dRList1.as<uint32_t>(); uint64_t sortCap = capR1;
@@ -2050,7 +2066,7 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
     if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     Nc = 0;
     PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nTriples, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     const uint32_t qLo = cm ? (uint32_t) repBase : 0u, qHi = cm ? (uint32_t) (repBase + ownedN) : N;      // queries with a self line
     c->nHits = Nc + (qHi - qLo); c->nNonSelf = Nc;
     if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
@@ -2058,7 +2074,7 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
     if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
     msReduce = tm.stop(1);
     PH_TRACE(st, "kmermatch: reduce");
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     if (!stalePos.empty() && nTriples > 0 && !cm) {
         // the runs that end at the very end of the sorted array (the last (rep,T) run, and the T-runs of directly preceding
@@ -2141,7 +2157,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         totalAll = hSplit[2 * (size_t) W + 1];                  // ... and of all sequences
     } else {
     PH_CHECK(hipMemcpyAsync(&total, dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     }
     const uint32_t nMine = sHi - sLo;
 
@@ -2216,7 +2232,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     uint32_t nOv = 0;
     PH_CHECK(hipMemcpyAsync(&nOv, dOvCnt.p, 4, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     if (nOv) {   // sequences whose candidate set did not fit LDS: same kernel, candidates in HBM scratch
         std::vector<uint32_t> ids(nOv), lens(nOv);
@@ -2224,7 +2240,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         if (dLens.alloc((size_t) nOv * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(gatherU32Kernel, dim3(gridFor(nOv, 256, 1024)), dim3(256), 0, st, db->d_len.as<uint32_t>(), dOvIds.as<uint32_t>(), nOv, dLens.as<uint32_t>());
         PH_CHECK(hipMemcpyAsync(lens.data(), dLens.p, (size_t) nOv * 4, hipMemcpyDeviceToHost, st));
-        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(plasship::streamSync(st));
         std::vector<uint64_t> soff(nOv); std::vector<uint32_t> scap(nOv); uint64_t tot = 0;
         for (uint32_t i = 0; i < nOv; i++) { uint32_t c = 64; while (c < lens[i] + 1) c <<= 1; scap[i] = c; soff[i] = tot; tot += c; }
         if (dSOff.alloc((size_t) nOv * 8) != hipSuccess || dSCap.alloc((size_t) nOv * 4) != hipSuccess || dScratch.alloc(tot * sizeof(Cand)) != hipSuccess) {
@@ -2234,7 +2250,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_CHECK(hipMemcpyAsync(dSCap.p, scap.data(), (size_t) nOv * 4, hipMemcpyHostToDevice, st));
         ExtractArgs fa = ea; fa.idList = dOvIds.as<uint32_t>(); fa.nIds = nOv; fa.scratch = dScratch.as<Cand>(); fa.scratchOff = dSOff.as<uint64_t>(); fa.scratchCap = dSCap.as<uint32_t>();
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(std::min<uint32_t>(nOv, (uint32_t) ctx->numCU * 8)), dim3(64), 0, st, fa);
-        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(plasship::streamSync(st));
         PH_CHECK(hipGetLastError());
     }
     msExtract = tm.stop(1);
@@ -2356,7 +2372,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     int nScatter = 1;
     std::vector<uint64_t> hStart1(nB1 + 1);
     PH_CHECK(hipMemcpyAsync(hStart1.data(), dStart1.p, ((size_t) nB1 + 1) * 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     uint64_t Nk = hStart1[nB1];                // records on this rank
     void *cur = bufB, *other = bufA;
@@ -2441,7 +2457,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(hVHist.data(), dVHist.p, VH_BINS * 4, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hBStart.data(), dBucketStart, ((size_t) nBuckets + 1) * 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     std::vector<uint64_t> hArena(gGrid); uint64_t Nm = 0, maxArena = 0;
     for (uint32_t j = 0; j < gGrid; j++) { hArena[j] = hBStart[(size_t) j * bpb]; Nm += hOutCnt[j]; maxArena = std::max(maxArena, hOutCnt[j]); }
@@ -2494,7 +2510,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_TRACE(st, "kmermatch: re-extraction of the last run's target");
         std::vector<R> trec(tb);
         PH_CHECK(hipMemcpyAsync(trec.data(), dTRec.p, (size_t) tb * sizeof(R), hipMemcpyDeviceToHost, st));
-        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(plasship::streamSync(st));
         trec.erase(std::remove_if(trec.begin(), trec.end(), [](const R &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }), trec.end());
         std::sort(trec.begin(), trec.end(), [](const R &x, const R &y) { return recLess1<NUCL, LONG>(x, y); });
         const uint32_t m = (uint32_t) trec.size();
@@ -2512,7 +2528,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             PH_TRACE(st, "kmermatch: rank pass");
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(hipStreamSynchronize(st));
+            PH_CHECK(plasship::streamSync(st));
             if (cm) {            // every rank counted the records of its own buckets: the sort-#1 ranks are the sums
                 static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
                 const int rc = commAllReduceSumU64(ctx, reinterpret_cast<uint64_t *>(diff.data()), diff.size()); if (rc) return rc;
@@ -2603,7 +2619,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         std::swap(cur, other);
         std::vector<uint64_t> hS1(nS1 + 1);
         PH_CHECK(hipMemcpyAsync(hS1.data(), dRS1.p, ((size_t) nS1 + 1) * 8, hipMemcpyDeviceToHost, st));
-        PH_CHECK(hipStreamSynchronize(st));
+        PH_CHECK(plasship::streamSync(st));
         PH_CHECK(hipGetLastError());
         dSortStart = dRS1.as<uint64_t>(); nSortBuckets = nS1; hSortStart = hS1;
         if (s2 > 0) {
@@ -2621,7 +2637,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             std::swap(cur, other);
             hSortStart.resize((size_t) nS + 1);
             PH_CHECK(hipMemcpyAsync(hSortStart.data(), dRS2.p, ((size_t) nS + 1) * 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(hipStreamSynchronize(st));
+            PH_CHECK(plasship::streamSync(st));
             dSortStart = dRS2.as<uint64_t>(); nSortBuckets = nS;
         }
     }

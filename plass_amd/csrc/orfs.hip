@@ -374,7 +374,7 @@ extern "C" int plasship_extract_orfs(plasship_ctx *ctx, const plasship_seqdb *re
     uint64_t tot[2] = {0, 0};
     PH_CHECK(hipMemcpyAsync(&tot[0], dOrfBase.as<uint64_t>() + nSlots, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&tot[1], dByteBase.as<uint64_t>() + nSlots, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     const uint64_t M = tot[0], dataBytes = tot[1];
     if (M >= 0xFFFFFFFFull) { setError("plasship_extract_orfs: too many ORFs"); return PLASSHIP_ERR_UNSUPPORTED; }
@@ -390,7 +390,7 @@ extern "C" int plasship_extract_orfs(plasship_ctx *ctx, const plasship_seqdb *re
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
     rc = finishSeqdb(ctx, o.get(), (size_t) M, dataBytes, par->translate ? PLASSHIP_DBTYPE_AMINO_ACIDS : PLASSHIP_DBTYPE_NUCLEOTIDES, o->d_len.as<uint32_t>());
     if (rc) return rc;
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     h->n = (size_t) M;
     if (stats) {
@@ -440,7 +440,7 @@ extern "C" int plasship_translate_nucs(plasship_ctx *ctx, const plasship_seqdb *
     uint64_t tot[2] = {0, 0};
     PH_CHECK(hipMemcpyAsync(&tot[0], dIdxBase.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&tot[1], dByteBase.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     const uint64_t M = tot[0], dataBytes = tot[1];
     std::unique_ptr<plasship_seqdb> o(new plasship_seqdb());
@@ -454,7 +454,7 @@ extern "C" int plasship_translate_nucs(plasship_ctx *ctx, const plasship_seqdb *
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
     rc = finishSeqdb(ctx, o.get(), (size_t) M, dataBytes, PLASSHIP_DBTYPE_AMINO_ACIDS, o->d_len.as<uint32_t>());
     if (rc) return rc;
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     if (stats) {
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
@@ -490,7 +490,7 @@ extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a,
                        b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), (uint32_t) b->n, a->dataBytes, maxKeyA + 1, o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
     o->dbtype = a->dbtype; o->n = (size_t) nn; o->dataBytes = dataBytes; o->residues = a->residues + b->residues;
     o->maxEntryLen = std::max(a->maxEntryLen, b->maxEntryLen); o->hostIndexValid = false;
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     *out = o.release();
     return PLASSHIP_OK;
@@ -506,7 +506,7 @@ extern "C" int plasship_orfhdr_concat(plasship_ctx *ctx, const plasship_orfhdr *
     if (o->d_info.alloc((nn + 1) * sizeof(OrfInfo)) != hipSuccess) { setError("plasship_orfhdr_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (nn) hipLaunchKernelGGL(concatInfoKernel, dim3(gridOf(nn, ctx->numCU)), dim3(256), 0, st, a->d_info.as<OrfInfo>(), (uint32_t) a->n, b->d_info.as<OrfInfo>(), (uint32_t) b->n, maxKeyA + 1, o->d_info.as<OrfInfo>());
     o->n = (size_t) nn; o->nUnparsable = a->nUnparsable + b->nUnparsable;
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     *out = o.release();
     return PLASSHIP_OK;

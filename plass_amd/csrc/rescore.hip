@@ -304,7 +304,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
                                    qdb->d_len.as<uint32_t>(), (uint32_t) qdb->n, dPresent.as<uint32_t>(), tabLen);
     std::vector<uint32_t> present(tabLen), minScore(tabLen, 0xFFFFFFFFu);
     PH_CHECK(hipMemcpyAsync(present.data(), dPresent.p, (size_t) tabLen * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     HostEvaluer ev(nucl, tdb->residues);
     {
         // max raw score of an overlap of length L: max matrix entry (11 for BLOSUM62 W-W, 2 for nucl) * L
@@ -339,7 +339,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), nHits, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t nAcc = 0;
     PH_CHECK(hipMemcpyAsync(&nAcc, dPos.as<uint64_t>() + nHits, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
 
     std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
     plasship_alns *al = holder.get();
@@ -353,7 +353,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
                        c->d_qoff.as<uint64_t>(), dPos.as<uint64_t>(), al->d_qoff.as<uint64_t>(), (uint64_t) qdb->n);
     unsigned long long hs[2] = {0, 0};
     PH_CHECK(hipMemcpyAsync(hs, dStats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
-    PH_CHECK(hipStreamSynchronize(ctx->stream));
+    PH_CHECK(plasship::streamSync(ctx->stream));
     PH_CHECK(hipGetLastError());
     al->qdb = qdb; al->tdb = tdb;
     if (stats) {

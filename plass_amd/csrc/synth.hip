@@ -60,7 +60,7 @@ extern "C" int plasship_synth_read_pairs(plasship_ctx *ctx, const plasship_synth
     sr.nPairs = par->n_pairs; sr.seed = par->seed; sr.out = o->d_data.as<char>(); sr.off = o->d_off.as<uint64_t>(); sr.len = o->d_len.as<uint32_t>(); sr.key = o->d_key.as<uint32_t>();
     if (nReads) hipLaunchKernelGGL(synthReadsKernel, dim3((unsigned) std::min<uint64_t>((nReads + 255) / 256, (uint64_t) ctx->numCU * 64)), dim3(256), 0, st, sr);
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
-    PH_CHECK(hipStreamSynchronize(st));
+    PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     o->dbtype = PLASSHIP_DBTYPE_NUCLEOTIDES; o->n = (size_t) nReads; o->dataBytes = dataBytes; o->residues = nReads * par->read_len; o->maxEntryLen = nReads ? entry : 0; o->hostIndexValid = false;
     if (stats) {

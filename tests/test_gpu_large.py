@@ -44,7 +44,7 @@ def test_large_chain_against_oracle_checksums(tmp_path):
     ctx = plass_amd.Context(0)
     try:
         reads, sst = ctx.synth_read_pairs(sp)
-        assert sst.max_coverage > 5 * sst.mean_coverage      # skewed: the test is about uneven bucket and group sizes
+        assert sst.max_coverage > 3 * sst.mean_coverage      # skewed: the test is about uneven bucket and group sizes
         reads.write(tmp_path / "reads")
         check(tmp_path / "reads", gold["reads"], "synthetic reads (GPU generator against the CPU generator)")
         db = ctx.plass_fragments(reads)
