@@ -133,19 +133,19 @@ def stage_table(kst, rst, ast):
     return t
 
 
-def stored_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the stored PMC pass of this command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two
-    separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), or None"""
+def stored_traffic(kernel, launches_per_step):
+    """HBM bytes per launch of `kernel` (all its instantiations together) from the stored PMC passes of this command (profiles/
+    r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for gfx950), or None.  A stored figure, not measured in this run: PMC collection serialises the kernels."""
     f = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
     try:
         rows = json.load(open(f))
     except (OSError, ValueError):
         return None
     key = re.sub(r"[<(].*", "", kernel)
-    for name, row in rows.get("kernels", {}).items():
-        if name.startswith(key):
-            return row.get("hbm_bytes_per_launch")
-    return None
+    tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for name, r in rows.get("kernels", {}).items() if re.search(r"::%s[<(]" % re.escape(key), name))
+    steps = rows.get("steps", 0)
+    return tot / steps / max(launches_per_step, 1e-9) if tot and steps else None
 
 
 def cpu_baseline(ctx, cfg, sample_pairs, iters):
@@ -347,7 +347,7 @@ def main():
             achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
             km = tot["kmermatcher_stage"]
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": stored_traffic(dom), "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
+                    "traffic": stored_traffic(dom, tot[dom][3] / len(stats)), "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
                     "stage_ms_per_step": {k: round(v[0] / len(stats), 4) for k, v in tot.items()},
                     "kmermatcher_stage": {"algorithmic_bytes_per_step": km[1] / len(stats), "ms_per_step": km[0] / len(stats),
                                           "frac": (km[1] / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if km[0] > 0 else 0.0},

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd databases).
-Usage: tools/rocpd_traffic.py FETCH_results.db WRITE_results.db [N_KERNELS [OUT.json]]
+Usage: tools/rocpd_traffic.py FETCH_results.db WRITE_results.db [N_KERNELS [OUT.json [STEPS]]]
 OUT.json (profiles/r02_pmc_traffic.json) is what bench.py reads `roofline.traffic` from: per kernel, HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE."""
 import collections
 import json
@@ -29,6 +29,7 @@ def main():
 
     if len(sys.argv) > 4:
         out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) of `python bench.py --steps 12 --warmup 0 --no-cpu-baseline`",
+               "steps": int(sys.argv[5]) if len(sys.argv) > 5 else 12,
                "correction": "FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md); WRITE_SIZE as reported; counter unit KB",
                "kernels": {k: {"launches": f[k][1], "fetch_bytes_per_launch": 2 * f[k][0] * 1024, "write_bytes_per_launch": w.get(k, (0, 0))[0] * 1024,
                                "hbm_bytes_per_launch": 2 * f[k][0] * 1024 + w.get(k, (0, 0))[0] * 1024} for k in rows}}
