@@ -31,6 +31,7 @@ typedef struct plasship_alns plasship_alns;     /* alignment result (verified ov
 #define PLASSHIP_ERR_IO (-2)
 #define PLASSHIP_ERR_DEVICE (-3)
 #define PLASSHIP_ERR_UNSUPPORTED (-4)
+#define PLASSHIP_ERR_PEER (-5)        /* sharded run: another rank failed inside this call; every rank returns an error from it */
 
 /* MMseqs2 dbtype codes (mm/commons/Parameters.h:65-84) */
 #define PLASSHIP_DBTYPE_AMINO_ACIDS 0
@@ -53,6 +54,10 @@ void *plasship_ctx_stream(plasship_ctx *ctx);
 /* diagnostic: how often the host has waited for a stream since the library was loaded (all contexts of the process).  A module
  * call is a chain of kernels on the context stream; the host waits only where it needs a size to allocate the next buffer. */
 unsigned long long plasship_host_syncs(void);
+/* test hook: the nth collective this context enters from now on (0 = the next one) fails locally BEFORE anything is exchanged, as
+ * an allocation between two exchanges would; nth < 0 disarms.  tests/test_gpu_sharded.py uses it to check that one failing rank
+ * makes every rank return an error from the same call instead of leaving the others inside a collective. */
+int plasship_ctx_debug_fail_collective(plasship_ctx *ctx, int nth);
 
 /* ---- one read set sharded over several GPUs (one process / context per GPU) ------------------
  * replaces: the reference's split of kmermatcher over MPI ranks by k-mer hash range

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("plasship_ctx_sync", C.c_int, [P]),
     ("plasship_ctx_stream", P, [P]),
     ("plasship_host_syncs", C.c_ulonglong, []),
+    ("plasship_ctx_debug_fail_collective", C.c_int, [P, C.c_int]),
     ("plasship_ctx_set_comm", C.c_int, [P, P]),
     ("plasship_ctx_copy_d2d", C.c_int, [P, P, P, C.c_uint64]),
     ("plasship_seqdb_upload", C.c_int, [P, C.c_char_p, C.c_size_t, P, P, P, C.c_size_t, C.c_int, C.POINTER(P)]),

@@ -288,31 +288,37 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
             querySeqLen = (unsigned) curLen;
             const char *qs = buf + curStart;
             __syncthreads();
-            for (uint32_t i = 0; i < h; i++) {
-                if (it[i].state != 1) continue;                     // wave-uniform (same memory, after barrier)
+            // every lane re-scores its own deferred hits (32 residues per step), all hits of the round in parallel: a queue this long
+            // defers dozens of hits per round, and a 50-150 residue overlap would leave most of a wavefront idle if the hits were
+            // taken one after the other (same arithmetic as the wide register queues of assembleGroupKernel)
+            for (uint32_t i = lane; i < h; i += 64) {
                 Item x = it[i];
+                if (x.state != 1) continue;
                 const char *tSeq = a.s.data + a.s.off[x.target];
                 const unsigned tLen = a.s.len[x.target];
                 const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
-                const Rescored rs = rescoreOnDiagonal(qs, querySeqLen, tSeq, tLen, diag, smat);
-                nResc++; nRescRes += rs.diagonalLen;
+                const unsigned dist = (unsigned) abs(diag);
+                unsigned qo = 0, to = 0, len = 0; bool hit = true;
+                if (diag >= 0 && dist < querySeqLen) { qo = dist; to = 0; len = min(tLen, querySeqLen - dist); }
+                else if (diag < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, querySeqLen); }
+                else hit = false;
+                unsigned first = 0, last = 0; int sc = 0, ids = 0; int startPos = -1, endPos = -1;
+                if (hit && len > 0) { scoreColumnsSerial(qs + qo, tSeq + to, len, smat, first, last, sc, ids); startPos = (int) first; endPos = (int) last; }
+                const unsigned score = (unsigned) max(sc, 0);
+                nResc++; nRescRes += hit ? len : 0;
                 // updateAlignment
-                const int dist = abs(diag);
                 int qS, qE, dS, dE;
-                if (diag >= 0) { qS = rs.startPos + dist; qE = rs.endPos + dist; dS = rs.startPos; dE = rs.endPos; }
-                else { qS = rs.startPos; qE = rs.endPos; dS = rs.startPos + dist; dE = rs.endPos + dist; }
-                const float seqId = (float) rs.idExcl / ((float) qE - (float) qS);
-                x.seqId = seqId; x.qLen = querySeqLen; x.dbLen = tLen; x.alnLength = rs.diagonalLen;
-                const float spc = (float) rs.score / (float) ((double) x.alnLength + 0.5);
+                if (diag >= 0) { qS = startPos + (int) dist; qE = endPos + (int) dist; dS = startPos; dE = endPos; }
+                else { qS = startPos; qE = endPos; dS = startPos + (int) dist; dE = endPos + (int) dist; }
+                const float seqId = (float) ids / ((float) qE - (float) qS);
+                x.seqId = seqId; x.qLen = querySeqLen; x.dbLen = tLen; x.alnLength = hit ? len : 0u;
+                const float spc = (float) score / (float) ((double) x.alnLength + 0.5);
                 x.score = (int) (spc * 100);
                 x.qStart = qS; x.qEnd = qE; x.dbStart = dS; x.dbEnd = dE;
-                const bool requeue = seqId >= a.seqIdThr;
-                x.state = requeue ? 0u : 2u;
-                if (requeue) inQueue++;
-                __syncthreads();
-                if (lane == 0) it[i] = x;
-                __syncthreads();
+                x.state = (seqId >= a.seqIdThr) ? 0u : 2u;
+                it[i] = x;
             }
+            __syncthreads();
             // recount what is really queued (defensive: the loop condition must match the item states)
             {
                 uint32_t c = 0;
@@ -326,6 +332,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
         }
         __syncthreads();
     }
+    nResc = waveReduceSumU64(nResc); nRescRes = waveReduceSumU64(nRescRes);        // counted per lane (every lane re-scores its own hits)
     if (lane == 0) {
         if (nExt) atomicAdd(&a.stats[0], nExt); if (nResc) atomicAdd(&a.stats[1], nResc); if (nRescRes) atomicAdd(&a.stats[2], nRescRes);
         if (nAln) { atomicAdd(&a.stats[9], nAln); atomicAdd(&a.stats[10], nQRes); atomicAdd(&a.stats[11], nRescRes); }
@@ -1129,14 +1136,16 @@ __global__ void outLenKernel(SeqView s, const uint32_t *__restrict__ flags, cons
     }
 }
 
+template <int G>
 __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen,
                                                       const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
                                                       const uint64_t *__restrict__ outOff, const uint32_t *__restrict__ keep,
                                                       const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
                                                       char *__restrict__ outData, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey) {
-    // 16 lanes per sequence, 8 bytes per lane and step (a read fragment is one step); four sequences per wavefront
-    const int G = 16, groupsPerBlock = 256 / G;
+    // G lanes per sequence, 8 bytes per lane and step: 8 lanes take a read fragment (~46 residues) in one step with most lanes busy,
+    // eight sequences per wavefront; contigs take a few steps of contiguous 64-byte pieces
     const int gl = threadIdx.x & (G - 1);
+    constexpr int groupsPerBlock = 256 / G;
     for (uint32_t id = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id < s.n; id += gridDim.x * groupsPerBlock) {
         if (!keep[id]) continue;
         const uint64_t o = outOff[id];
@@ -1266,9 +1275,16 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
         setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
-    if (N) hipLaunchKernelGGL(writeOutKernel, dim3(std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16))), dim3(256), 0, st, sv, dFlags, dNewLen,
+    static const int woG = tuneInt("WRITEOUT_G", 8);
+    if (N) {
+        const unsigned woGrid = std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16));
+        if (woG == 8) hipLaunchKernelGGL((writeOutKernel<8>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
                               dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
                               o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+        else hipLaunchKernelGGL((writeOutKernel<16>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
+                              dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
+                              o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+    }
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
     if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
@@ -1529,7 +1545,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
 extern "C" int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al,
                                  const plasship_assemble_params *par, plasship_seqdb **out, plasship_assemble_stats *stats) {
     if (!ctx || !db || !al || !par || !out) { setError("plasship_assemble: bad argument"); return PLASSHIP_ERR_ARG; }
-    return assembleImpl(ctx, db, nullptr, al, par, out, nullptr, stats);
+    return commFinish(ctx, assembleImpl(ctx, db, nullptr, al, par, out, nullptr, stats));
 }
 
 extern "C" int plasship_guided_assemble(plasship_ctx *ctx, const plasship_seqdb *nucl_db, const plasship_seqdb *aa_db, const plasship_alns *al,
@@ -1543,5 +1559,5 @@ extern "C" int plasship_guided_assemble(plasship_ctx *ctx, const plasship_seqdb 
     bool differ = false;
     { const int rc = deviceKeysDiffer(ctx, nucl_db->d_key.as<uint32_t>(), aa_db->d_key.as<uint32_t>(), nucl_db->n, &differ); if (rc) return rc; }
     if (differ) { setError("plasship_guided_assemble: nucleotide and protein DB have different keys"); return PLASSHIP_ERR_ARG; }
-    return assembleImpl(ctx, nucl_db, aa_db, al, par, out_nucl, out_aa, stats);
+    return commFinish(ctx, assembleImpl(ctx, nucl_db, aa_db, al, par, out_nucl, out_aa, stats));
 }

@@ -5,6 +5,7 @@
 // kmermatch.hip (k-mer records -> bucket owner, grouped records -> rep owner) and assemble.hip (extended sequences).
 #include "common.hpp"
 #include <cstring>
+#include <string>
 
 using namespace plasship;
 
@@ -19,6 +20,12 @@ extern "C" int plasship_ctx_set_comm(plasship_ctx *ctx, const plasship_comm *com
     return PLASSHIP_OK;
 }
 
+extern "C" int plasship_ctx_debug_fail_collective(plasship_ctx *ctx, int nth) {
+    if (!ctx) { setError("plasship_ctx_debug_fail_collective: ctx is NULL"); return PLASSHIP_ERR_ARG; }
+    ctx->debugFailCollective = nth;
+    return PLASSHIP_OK;
+}
+
 extern "C" int plasship_ctx_copy_d2d(plasship_ctx *ctx, void *dst, const void *src, uint64_t bytes) {
     if (!ctx) { setError("plasship_ctx_copy_d2d: ctx is NULL"); return PLASSHIP_ERR_ARG; }
     PH_ENTER(ctx);
@@ -29,10 +36,32 @@ extern "C" int plasship_ctx_copy_d2d(plasship_ctx *ctx, void *dst, const void *s
 
 namespace plasship {
 
+// one status round: every rank contributes 0 (fine) or its error code; a non-zero code of ANY rank ends the call on every rank
+static int commStatus(plasship_ctx *ctx, int myCode) {
+    const plasship_comm *cm = commOf(ctx);
+    if (!cm || cm->world == 1) return PLASSHIP_OK;
+    std::vector<int64_t> all((size_t) cm->world, 0);
+    const int64_t mine = myCode;
+    if (cm->allgather_host(cm->user, &mine, all.data(), 8) != 0) { if (!myCode) setError("sharded run: the caller's allgather_host failed"); return PLASSHIP_ERR_DEVICE; }
+    for (int r = 0; r < cm->world; r++)
+        if (all[(size_t) r] != 0 && r != cm->rank) {
+            if (!myCode) setError("sharded run: rank " + std::to_string(r) + " failed inside this call (code " + std::to_string((long long) all[(size_t) r]) + "); all ranks leave it");
+            return PLASSHIP_ERR_PEER;
+        }
+    return PLASSHIP_OK;
+}
+int commFinish(plasship_ctx *ctx, int rc) {
+    if (rc == PLASSHIP_ERR_PEER) return rc;                  // everybody saw the same status round and is leaving: no further round
+    const int peer = commStatus(ctx, rc);
+    return rc ? rc : peer;
+}
+
 int commAllgatherHost(plasship_ctx *ctx, const void *send, void *recv, uint64_t bytesPerRank) {
     const plasship_comm *cm = commOf(ctx);
     if (!cm) { memcpy(recv, send, bytesPerRank); return PLASSHIP_OK; }
     PH_CHECK(plasship::streamSync(ctx->stream));
+    if (ctx->debugFailCollective >= 0 && ctx->debugFailCollective-- == 0) { setError("sharded run: injected rank-local failure (plasship_ctx_debug_fail_collective)"); return PLASSHIP_ERR_DEVICE; }
+    { const int rc = commStatus(ctx, 0); if (rc) return rc; }
     if (cm->allgather_host(cm->user, send, recv, bytesPerRank) != 0) { setError("sharded run: the caller's allgather_host failed"); return PLASSHIP_ERR_DEVICE; }
     return PLASSHIP_OK;
 }

@@ -117,6 +117,7 @@ struct plasship_ctx {
     // one read set sharded over several GPUs (plasship_ctx_set_comm); world == 1 and hasComm == false: single GPU
     bool hasComm = false;
     plasship_comm comm = {};
+    int debugFailCollective = -1;       // plasship_ctx_debug_fail_collective: countdown to an injected rank-local failure
 };
 
 struct plasship_seqdb {
@@ -167,6 +168,11 @@ int commAllReduceSumU64(plasship_ctx *ctx, uint64_t *v, size_t n);       // in p
 int commAllReduceMaxU64(plasship_ctx *ctx, uint64_t *v, size_t n);
 int commAllReduceMinU64(plasship_ctx *ctx, uint64_t *v, size_t n);
 int commAgreeOk(plasship_ctx *ctx, bool ok, const char *what);          // collective: error on every rank unless `ok` on every rank
+// Failure protocol of a sharded call (comm.hip): every collective starts with an 8-byte status round; a rank that fails on its own
+// between two collectives returns to its C-ABI entry, whose commFinish() sends its error code as the status of ONE more round — the
+// round the other ranks make before their next collective, or their own commFinish() — and every rank leaves the call with an error
+// (PLASSHIP_ERR_PEER on the ranks that did not fail themselves).  Nobody is left waiting inside a collective.
+int commFinish(plasship_ctx *ctx, int rc);                              // last statement of every C-ABI entry that can run sharded
 // all-to-all(v) of fixed-size records laid out by destination; allocates `recv` (capacity (total + slackRecords) records)
 // *allTotal (optional): records sent by all ranks together
 int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *sendCount, size_t recordBytes, DevBuf &recv,

@@ -85,12 +85,16 @@ __global__ void maxIntRowsKernel(const int *__restrict__ all, uint32_t n, int wo
 }  // namespace plasship
 using namespace plasship;
 
+static int findStartImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al, plasship_seqdb **out, plasship_findstart_stats *stats);
 extern "C" int plasship_find_assembly_start(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al, plasship_seqdb **out,
                                             plasship_findstart_stats *stats) {
     if (!ctx || !db || !al || !out) { setError("plasship_find_assembly_start: bad argument"); return PLASSHIP_ERR_ARG; }
     if (db->dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) { setError("plasship_find_assembly_start: needs a protein sequence DB"); return PLASSHIP_ERR_ARG; }
     if (al->nQueries != db->n) { setError("plasship_find_assembly_start: alignment list does not belong to the DB"); return PLASSHIP_ERR_ARG; }
     PH_ENTER(ctx);
+    return commFinish(ctx, findStartImpl(ctx, db, al, out, stats));
+}
+static int findStartImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *al, plasship_seqdb **out, plasship_findstart_stats *stats) {
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();

@@ -433,3 +433,42 @@ print("NATIVE_RCCL_OK", b, n, c.count())
     assert int(p.stdout.split("NATIVE_RCCL_OK")[1].split()[1]) > 0            # collectives were called
     for it in (1, 2):
         assert_same_db(os.path.join(golden, "aa", "seq_%d" % it), tmp_path / ("native_seq_%d" % it), "native RCCL communicator, iteration %d" % (it - 1))
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("nth", [0, 1, 3, 6, 8])
+def test_sharded_rank_local_failure_ends_the_call_on_every_rank(ctxs, golden, tmp_path, nth):
+    """one rank fails on its own between two collectives (injected before its nth collective of the iteration): every rank must
+    return an error from the SAME library call — the failing rank its own, the others PLASSHIP_ERR_PEER (-5) — instead of
+    waiting inside the next collective for a rank that has left (this test would hang); the group stays usable: the next
+    iteration, without injection, gives the reference's DB on every rank"""
+    import plass_amd
+    s = os.path.join(golden, "aa")
+    world, bad = 3, 1
+
+    def iteration(ctx, db):
+        cands, _ = ctx.kmermatcher(db, km_params(0))
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9))
+        return ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9))[0]
+
+    def work(rank, ctx):
+        db = ctx.read_seqdb(f"{s}/seq_0")
+        if rank == bad:
+            plass_amd._lib._check(ctx.lib.plasship_ctx_debug_fail_collective(ctx.h, nth), "plasship_ctx_debug_fail_collective")
+        err = None
+        try:
+            iteration(ctx, db)
+        except plass_amd.PlasshipError as e:                   # no barrier abort, no help from the harness: the library must get everybody out
+            err = str(e)
+        plass_amd._lib._check(ctx.lib.plasship_ctx_debug_fail_collective(ctx.h, -1), "plasship_ctx_debug_fail_collective")
+        out = iteration(ctx, db)
+        out.write(tmp_path / f"r{rank}_seq_1")
+        return err
+
+    errs = _run(ctxs, world, work)
+    assert all(e is not None for e in errs), errs
+    assert "injected rank-local failure" in errs[bad] and "(-3)" in errs[bad]
+    for r in range(world):
+        if r != bad:
+            assert "(-5)" in errs[r] and "rank %d failed" % bad in errs[r], errs[r]
+        assert_same_db(f"{s}/seq_1", tmp_path / f"r{r}_seq_1", f"rank {r} after the failed call")
