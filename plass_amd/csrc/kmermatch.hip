@@ -234,12 +234,12 @@ __device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k,
 //   atomics, no barriers), and only the <= ~60 selected windows rebuild their k-mer.  Longer sequences are queued for the next
 //   launch.  REGS == 0: the three-pass path below; RESL = longest sequence whose codes and scores stay resident in LDS.
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 2 : 1)))) void extractKernel(ExtractArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 && REGS <= 4) ? 6 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 2 : 1))))) void extractKernel(ExtractArgs a) {
     constexpr uint32_t RES_L = RESL;
     constexpr uint32_t CODES = (RESL > 64 * REGS + 32 ? RESL : 64 * REGS + 32) + 32;
     __shared__ unsigned char sMap[256];
     __shared__ unsigned char sCode[64 + 32];
-    __shared__ uint32_t sHist[256];
+    __shared__ uint32_t sHist[(REGS > 0 && !FALLBACK) ? 1 : 256];  // radix select of the three-pass path only
     __shared__ Cand sCand[FALLBACK ? 1 : CAP];
     __shared__ unsigned long long sSet[FALLBACK ? 1 : 2 * CAP];     // duplicate-k-mer detection without sorting (after the passes)
     __shared__ unsigned short sScoreBig[(RESL > 4 * CAP && !FALLBACK) ? RESL : 1];
@@ -661,7 +661,8 @@ struct ShortArgs {
     SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map;
     int k, xCode, kps, ignoreMulti; float scale; uint64_t seed;
     uint64_t base, top, inv; int tz;     // alphabet base; base^(k-1); exact division by base = (x >> tz) * inv
-    uint32_t *waveList, *waveCount;
+    uint32_t *waveList, *waveCount;      // sequences for the wave kernels ...
+    uint32_t *longList, *longCount; uint32_t longWindows;   // ... those with more than longWindows windows go to this list instead (nullptr: one list)
     unsigned long long *kstats;          // [0] residues, [1] records handled by this kernel
     uint32_t idLo, idHi; uint64_t slotBias;   // ids [idLo, idHi) (sharded run: this rank's share), records at arr[slotOff[id] - slotBias]
 };
@@ -745,13 +746,20 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                 }
             }
         }
-        const unsigned long long m = __ballot(toWave);
-        if (m) {
+        // the queued sequences, one atomic per wavefront and list (the wave kernels' tiers are fed from these lists directly: a
+        // queue filled one sequence at a time — one atomic on one counter per sequence — costs more than the tier it feeds)
+        const uint32_t nw = (toWave && active && a.s.len[id] >= (uint32_t) k) ? a.s.len[id] - (uint32_t) k + 1 : 0u;
+        const bool isLong = toWave && a.longList && nw > a.longWindows;
+        auto append = [&](bool mine, uint32_t *list, uint32_t *count) {
+            const unsigned long long m = __ballot(mine);
+            if (!m) return;
             uint32_t basePos = 0;
-            if (lane == 0) basePos = atomicAdd(a.waveCount, (uint32_t) __popcll(m));
+            if (lane == 0) basePos = atomicAdd(count, (uint32_t) __popcll(m));
             basePos = __shfl(basePos, 0, 64);
-            if (toWave) a.waveList[basePos + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL))] = id;
-        }
+            if (mine) list[basePos + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL))] = id;
+        };
+        append(toWave && !isLong, a.waveList, a.waveCount);
+        if (a.longList) append(isLong, a.longList, a.longCount);
     }
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
@@ -1073,18 +1081,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     unsigned long long maxRT = 0;
     const uint64_t arena = (uint64_t) a.lineBeg[bBegin] * RPL;
     const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
-    for (uint32_t b = bBegin; b < bEnd; b++) {
-        const uint32_t n = a.lineCnt[b] * RPL;       // record positions of the bucket (padding sentinels included)
-        const uint32_t lb = a.lineBeg[b];
-        if (n == 0) continue;
-        auto recAt = [&](uint32_t i) -> R { return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)]; };
-        const R none = [] { R r; r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; return r; }();
-        const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
-        R rg[GL_RMAX];
-        if (inRegs) {
+    const R none = [] { R r; r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; return r; }();
+    // the records of a bucket are fetched (line list entry, then the record: two dependent round trips) as soon as the registers
+    // of the previous bucket are dead — behind its last phase, ahead of the barriers that close it and of the table reset
+    R rg[GL_RMAX];
+    uint32_t nNext = 0, lbNext = 0;
+    auto fetch = [&](uint32_t b) {
+        nNext = (b < bEnd) ? a.lineCnt[b] * RPL : 0u; lbNext = (b < bEnd) ? a.lineBeg[b] : 0u;
+        if (nNext && nNext <= (uint32_t) GL_RMAX * BLOCK) {
 #pragma unroll
-            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < n) ? recAt(i) : none; }
+            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? in[(uint64_t) a.list[lbNext + i / RPL] * RPL + (i % RPL)] : none; }
         }
+    };
+    fetch(bBegin);
+    for (uint32_t b = bBegin; b < bEnd; b++) {
+        const uint32_t n = nNext;                    // record positions of the bucket (padding sentinels included)
+        const uint32_t lb = lbNext;
+        if (n == 0) { fetch(b + 1); continue; }
+        auto recAt = [&](uint32_t i) -> R { return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)]; };
+        const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
+        bool fetched = false;
         // phase A on one record: claim the k-mer's slot, mark a second member, and bid for the run head; called by whole wavefronts
         // (new k-mers are counted once per wavefront, not with one LDS atomic per record on a single word)
         auto phaseA = [&](const R &r, uint32_t nSub, uint32_t sub) {
@@ -1177,6 +1193,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 #pragma unroll
                     for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseC(rg[j], nSub, sub);
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseC(i < n ? recAt(i) : none, nSub, sub); }
+                if (sub + 1 == nSub) { fetch(b + 1); fetched = true; }     // last sub-pass: nothing reads this bucket's registers again
                 __syncthreads();
                 written += sCursor;
                 __syncthreads();
@@ -1187,6 +1204,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             written = writtenAtBucketStart;
             __syncthreads();
         }
+        if (!fetched) fetch(b + 1);                  // (cannot happen: the last sub-pass always completes; kept for the invariant)
     }
     if (a.maxRepTarget) {
 #pragma unroll
@@ -2192,19 +2210,25 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // only sees the longer nucleotide contigs, queued by the first launch; what does not fit there either goes to the
     // HBM-scratch launch.
     constexpr int CAP = 128, CAP2 = NUCL ? 1024 : 128;
-    DevBuf dWaveList, dWaveCount, dKStats;
-    if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess || dKStats.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    DevBuf dWaveList, dWaveCount, dLongList, dLongCount, dKStats;
+    static const bool tier0 = [] { const char *e = getenv("PLASSHIP_TIER0"); return e ? atoi(e) != 0 : true; }();
+    constexpr uint32_t TIER0_WINDOWS = 256;                  // 4 scores per lane (an 8-scores tier at 5 wavefronts per SIMD gained 0.3 %: not kept)
+    if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess || dLongList.alloc(((size_t) N + 1) * 4) != hipSuccess || dLongCount.alloc(4) != hipSuccess ||
+        dKStats.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dWaveCount.p, 0, 4, st));
+    PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 4, st));
     PH_CHECK(hipMemsetAsync(dKStats.p, 0, 32, st));
     ea.kstats = dKStats.as<unsigned long long>();
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
+    bool twoLists = false;
     if (!NUCL && k <= 16 && nMine) {
-        // short sequences: one thread each; everything else is queued for the wave-per-sequence kernel
+        // short sequences: one thread each; everything else is queued for the wave-per-sequence kernels, in two lists by length
         ShortArgs sa; memset(&sa, 0, sizeof(sa));
         sa.s = ea.s; sa.slotOff = ea.slotOff; sa.arr = ea.arr; sa.map = ea.map; sa.k = k; sa.xCode = ea.xCode; sa.kps = ea.kps; sa.ignoreMulti = ea.ignoreMulti;
         sa.scale = ea.scale; sa.seed = ea.seed; sa.base = (uint64_t) (alph - 1); sa.top = ea.powers[k - 1];
         { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
         sa.waveList = dWaveList.as<uint32_t>(); sa.waveCount = dWaveCount.as<uint32_t>(); sa.kstats = dKStats.as<unsigned long long>();
+        if (tier0) { sa.longList = dLongList.as<uint32_t>(); sa.longCount = dLongCount.as<uint32_t>(); sa.longWindows = TIER0_WINDOWS; twoLists = true; }
         sa.idLo = sLo; sa.idHi = sHi; sa.slotBias = slotBias;
         hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", 18))), dim3(64), 0, st, sa);
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
@@ -2216,11 +2240,23 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // most contigs); (2) the same with 48 scores per lane, up to 3072 windows (proteins longer than that are rare) and, for
     // nucleotides, up to 1024 candidates; (3) three-pass path with codes and scores of up to 8160 residues resident in LDS;
     // (4) the HBM-scratch launch below
-    if (nMine) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU)), dim3(64), 0, st, ea);
+    // (0) the same register front end with 4 scores per lane (up to 256 windows: merged read fragments and young contigs) at six
+    // wavefronts per SIMD instead of four: the per-sequence steps (staging, ballots, LDS round trips between barriers) are what a
+    // 100-250 residue sequence mostly consists of, and more resident wavefronts hide them (2.1 instead of 2.8 ns per sequence).
+    // Tiers 0 and 1 take their sequences from the two lists of the thread-per-sequence kernel; what either cannot hold goes to
+    // one queue for tier 2, and on to tier 3.
     DevBuf dOv2Ids, dOv2Cnt;
+    DevBuf *lastIds = &dOvIds, *lastCnt = &dOvCnt;
     if (nMine) {
         if (dOv2Ids.alloc(((size_t) N + 1) * 4) != hipSuccess || dOv2Cnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         PH_CHECK(hipMemsetAsync(dOv2Cnt.p, 0, 4, st));
+        const uint32_t wide = std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU);
+        // tiers 0 and 1 both queue into dOvIds
+        if (twoLists) {
+            hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256>), dim3(wide), dim3(64), 0, st, ea);
+            ExtractArgs e1 = ea; e1.waveList = dLongList.as<uint32_t>(); e1.waveCount = dLongCount.as<uint32_t>();
+            hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, e1);
+        } else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, ea);
         ExtractArgs e2 = ea; e2.waveList = dOvIds.as<uint32_t>(); e2.waveCount = dOvCnt.as<uint32_t>();
         e2.overflowIds = dOv2Ids.as<uint32_t>(); e2.overflowCount = dOv2Cnt.as<uint32_t>();
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 12u))), dim3(64), 0, st, e2);
@@ -2229,16 +2265,18 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>();
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 2u : 5u))), dim3(64), 0, st, e3);
     }
+    // what the last stage could not hold either (candidate sets beyond LDS)
+    DevBuf &dLastIds = *lastIds, &dLastCnt = *lastCnt;
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     uint32_t nOv = 0;
-    PH_CHECK(hipMemcpyAsync(&nOv, dOvCnt.p, 4, hipMemcpyDeviceToHost, st));
+    if (nMine) PH_CHECK(hipMemcpyAsync(&nOv, dLastCnt.p, 4, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     if (nOv) {   // sequences whose candidate set did not fit LDS: same kernel, candidates in HBM scratch
         std::vector<uint32_t> ids(nOv), lens(nOv);
         DevBuf dLens, dSOff, dSCap, dScratch;
         if (dLens.alloc((size_t) nOv * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(gatherU32Kernel, dim3(gridFor(nOv, 256, 1024)), dim3(256), 0, st, db->d_len.as<uint32_t>(), dOvIds.as<uint32_t>(), nOv, dLens.as<uint32_t>());
+        hipLaunchKernelGGL(gatherU32Kernel, dim3(gridFor(nOv, 256, 1024)), dim3(256), 0, st, db->d_len.as<uint32_t>(), dLastIds.as<uint32_t>(), nOv, dLens.as<uint32_t>());
         PH_CHECK(hipMemcpyAsync(lens.data(), dLens.p, (size_t) nOv * 4, hipMemcpyDeviceToHost, st));
         PH_CHECK(plasship::streamSync(st));
         std::vector<uint64_t> soff(nOv); std::vector<uint32_t> scap(nOv); uint64_t tot = 0;
@@ -2248,7 +2286,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
         PH_CHECK(hipMemcpyAsync(dSOff.p, soff.data(), (size_t) nOv * 8, hipMemcpyHostToDevice, st));
         PH_CHECK(hipMemcpyAsync(dSCap.p, scap.data(), (size_t) nOv * 4, hipMemcpyHostToDevice, st));
-        ExtractArgs fa = ea; fa.idList = dOvIds.as<uint32_t>(); fa.nIds = nOv; fa.scratch = dScratch.as<Cand>(); fa.scratchOff = dSOff.as<uint64_t>(); fa.scratchCap = dSCap.as<uint32_t>();
+        ExtractArgs fa = ea; fa.idList = dLastIds.as<uint32_t>(); fa.nIds = nOv; fa.scratch = dScratch.as<Cand>(); fa.scratchOff = dSOff.as<uint64_t>(); fa.scratchCap = dSCap.as<uint32_t>();
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(std::min<uint32_t>(nOv, (uint32_t) ctx->numCU * 8)), dim3(64), 0, st, fa);
         PH_CHECK(plasship::streamSync(st));
         PH_CHECK(hipGetLastError());
