@@ -394,13 +394,19 @@ def main():
             line["cpu_baseline"] = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, min(chain, 3))
         else:
             line["cpu_baseline"] = None
-        print(json.dumps(line))
     if native is not None:
         native.destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
+    if rank == 0:
+        # the ONE JSON line is the last thing on stdout: RCCL prints a version banner through C stdio, which (redirected to a file or a
+        # pipe) would otherwise be flushed at exit, behind the line
+        import ctypes
+        sys.stderr.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(line), flush=True)
 
 
 def sharded_preflight(ctx, dist, device):

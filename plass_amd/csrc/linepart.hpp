@@ -297,7 +297,14 @@ __global__ __launch_bounds__(512) void tagSortRegionKernel(const uint32_t *__res
         const uint32_t base = g * nb2;
         for (uint32_t i = threadIdx.x; i < nb2; i += 512) sh[i] = 0;
         __syncthreads();
-        for (uint64_t i = r0 + threadIdx.x; i < r1; i += 512) { const uint32_t t = tags[i]; if (t != TAG_NONE) atomicAdd(&sh[t - base], 1u); }
+        // four independent tags per thread and round: the loop is a chain of global load -> LDS atomic, bound by latency
+        for (uint64_t i = r0 + threadIdx.x; i < r1; i += 2048) {
+            uint32_t t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] = (i + 512u * u < r1) ? tags[i + 512u * u] : TAG_NONE;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (t[u] != TAG_NONE) atomicAdd(&sh[t[u] - base], 1u);
+        }
         __syncthreads();
         // exclusive scan of the nb2 <= 1024 counts: two per thread
         const uint32_t i0 = 2 * threadIdx.x, i1 = i0 + 1;
@@ -311,7 +318,13 @@ __global__ __launch_bounds__(512) void tagSortRegionKernel(const uint32_t *__res
         if (i0 < nb2) { fineBeg[base + i0] = ex; fineCnt[base + i0] = c0; sh[i0] = ex; }
         if (i1 < nb2) { fineBeg[base + i1] = ex + c0; fineCnt[base + i1] = c1; sh[i1] = ex + c0; }
         __syncthreads();
-        for (uint64_t i = r0 + threadIdx.x; i < r1; i += 512) { const uint32_t t = tags[i]; if (t != TAG_NONE) list[atomicAdd(&sh[t - base], 1u)] = (uint32_t) i; }
+        for (uint64_t i = r0 + threadIdx.x; i < r1; i += 2048) {
+            uint32_t t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) t[u] = (i + 512u * u < r1) ? tags[i + 512u * u] : TAG_NONE;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (t[u] != TAG_NONE) list[atomicAdd(&sh[t[u] - base], 1u)] = (uint32_t) (i + 512u * u);
+        }
         __syncthreads();
     }
 }
