@@ -90,8 +90,6 @@ struct ExtractArgs {
     uint64_t slotBias;              // subtracted from every slot offset (re-extraction of one sequence into a scratch array;
                                     // sharded run: first slot of this rank's id range)
     uint32_t idLo, idHi;            // regular launch without a wave list: ids [idLo, idHi) (sharded run: this rank's share)
-    int dbgSkip;                    // development aid (PLASSHIP_DBG_EXTRACT_SKIP, tools/extract_probe.py): parts of the register front end to
-                                    // leave out when timing it — results are WRONG with any bit set; 0 in every normal run
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 &&
             __syncthreads();
             // identity hash (Util::hash, Util.h:337-345: h = h*31 + code, i.e. sum code[p] * 31^(L-1-p) modulo 2^64): lane l owns the
             // positions l, l + 64, …; its power starts at 31^(L-1-l) and shrinks by 31^64 (a multiplication by the inverse) per step
-            if (!(a.dbgSkip & 1)) {
+            {
                 uint64_t pw;
                 if (L >= 64) { const uint32_t e = L - 64; pw = sPow64[e >> 6] * __shfl(pow31, (int) (e & 63u), 64) * pow31rev; }
                 else pw = ((uint32_t) lane < L) ? __shfl(pow31, (int) (L - 1 - min((uint32_t) lane, L - 1)), 64) : 0ull;
@@ -365,8 +363,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 &&
                     const uint32_t p = (uint32_t) j * 64u + (uint32_t) lane;
                     if (p < nWin) {
                         uint64_t kmer; uint32_t pos;
-                        if (a.dbgSkip & 32) sc[j] = (p * 2654435761u) >> 16;
-                        else if (windowKmer(p, kmer, pos)) sc[j] = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
+                        if (windowKmer(p, kmer, pos)) sc[j] = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
                     }
                     n += (uint32_t) __popcll(__ballot(sc[j] != 0xFFFFFFFFu));
                 }
@@ -376,8 +373,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 &&
                 // the reference walks 65 536 score bins until `considered` k-mers are covered (kmermatcher.cpp:224-239): s* is the
                 // considered-th smallest score = the largest t with fewer than `considered` scores below it
                 uint32_t t = 0;
-                if (a.dbgSkip & 2) t = (uint32_t) ((65536ull * considered) / (n ? n : 1));
-                else
 #pragma unroll 1
                 for (int bit = 15; bit >= 0; bit--) {
                     const uint32_t tr = t | (1u << bit);
@@ -414,12 +409,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 &&
                 for (uint32_t i = lane; i < C; i += 64) {
                     const uint32_t pk = sPick[i];
                     Cand cd; uint32_t pos = 0; cd.kmer = pk;
-                    if (!(a.dbgSkip & 4)) (void) windowKmer(pk & 0xFFFFu, cd.kmer, pos);
+                    (void) windowKmer(pk & 0xFFFFu, cd.kmer, pos);
                     cd.pos = pos; cd.score = pk >> 16; cand[i] = cd;
                 }
             }
             __syncthreads();
-            if (a.dbgSkip & 64) continue;
         } else {
         // pass 0: all candidates pushed / or coarse histogram; pass 1: fine histogram; pass 2: push score <= s*
         const int nPass = allCand ? 1 : 3;
@@ -538,8 +532,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 &&
         }
         // ---- fast path: when no candidate k-mer repeats and the threshold bin has no surplus, the reference's
         //      sort + walk selects exactly the candidate set (C == considered), in an order that does not matter ----
-        bool needOrder = (tooMuch != 0) && !(a.dbgSkip & 8);
-        if (!needOrder && a.ignoreMulti && C > 1 && !(a.dbgSkip & 8)) {
+        bool needOrder = (tooMuch != 0);
+        if (!needOrder && a.ignoreMulti && C > 1) {
             if (FALLBACK) needOrder = true;
             else {
                 for (uint32_t i = lane; i < 2 * CAP; i += 64) sSet[i] = ~0ULL;
@@ -560,7 +554,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 &&
             }
         }
         if (!needOrder) {
-            if (a.dbgSkip & 16) { stRes += L; stRec += 1 + C; __syncthreads(); continue; }
             for (uint32_t i = lane; i < C; i += 64) {
                 const Cand cd = cand[i];
                 R r; r.kmer = cd.kmer; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) cd.pos;
@@ -1925,10 +1918,13 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     if (nPR1) PH_CHECK(hipMemcpyAsync(dRPieces.p, hp.data(), (size_t) nPR1 * sizeof(LinePiece), hipMemcpyHostToDevice, st));
     else PH_CHECK(hipMemsetAsync(dRTag1.p, 0xFF, capR1 * 4, st));                       // nothing grouped: no piece will write the tag array
     PH_CHECK(hipMemcpyAsync(dRNP.p, &nPR1, 4, hipMemcpyHostToDevice, st));
+    // grouped records arrive with many records per representative: lines that complete inside a tile are written directly (linepart.hpp)
+    static const int directLines = [] { const char *e = getenv("PLASSHIP_DIRECT_LINES"); return e ? atoi(e) : 1; }();
     LineKey rkey; rkey.rangeBits = repBits; rkey.repBase = 0; rkey.shift = s1 ? 64 - s1 : 63; rkey.scrambleBits = idBits;      // ranges of the bit-reversed id
     {
         LinePartArgs a; memset(&a, 0, sizeof(a));
         a.in = otherRecs; a.out = dR1.p; a.tags = dRTag1.as<uint32_t>(); a.pieces = dRPieces.as<LinePiece>(); a.nPieces = dRNP.as<uint32_t>(); a.nb = nS1; a.key = rkey;
+        a.direct = directLines;
         rc = launchLinePart<NUCL, LONG, KEY_RANGE, false, false>(ctx, a, std::max<uint32_t>(nPR1, 1)); if (rc) return rc;
     }
     PH_CHECK(plasship::streamSync(st));                     // hp goes out of use (async copy of a pageable host vector)
@@ -1942,6 +1938,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
                            dRRegBeg.as<uint64_t>(), dRRegEnd.as<uint64_t>(), dRTot2.as<uint64_t>());
         LinePartArgs a; memset(&a, 0, sizeof(a));
         a.in = dR1.p; a.list = dRList1.as<uint32_t>(); a.out = dR2.p; a.tags = dRTag2.as<uint32_t>(); a.pieces = dRPieces2.as<LinePiece>(); a.nPieces = dRNP2.as<uint32_t>(); a.nb = nS2;
+        a.direct = directLines;
         a.key = rkey; a.key.shift = 64 - s1 - s2;
         rc = launchLinePart<NUCL, LONG, KEY_RANGE, true, false>(ctx, a, maxPR2); if (rc) return rc;
         hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(nS1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dRTag2.as<uint32_t>(), (const uint64_t *) dRRegBeg.as<uint64_t>(),
@@ -2198,7 +2195,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(dMap.p, map, 256, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));
     ExtractArgs ea; memset(&ea, 0, sizeof(ea));
-    { static const int dbg = [] { const char *e = getenv("PLASSHIP_DBG_EXTRACT_SKIP"); return e ? atoi(e) : 0; }(); ea.dbgSkip = dbg; }
     ea.s = db->view(); ea.slotOff = dSlotOff.as<uint64_t>(); ea.arr = dA.p; ea.map = dMap.as<unsigned char>();
     const int alph = NUCL ? 5 : par->alphabet_size;
     { uint64_t p = 1; for (int i = 0; i < 24; i++) { ea.powers[i] = p; p *= (uint64_t) (alph - 1); } }

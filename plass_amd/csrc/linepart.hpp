@@ -101,12 +101,13 @@ struct LinePartArgs {
     uint64_t totalLines; uint32_t lastValidAll, pieceLines;   //   piece p = input lines [p * pieceLines, …), output lines [p * (pieceLines + nb), …)
     uint32_t *pieceOut;                          // optional: output lines a piece used
     LineKey key; uint32_t nb;
+    int direct;                                  // records of lines that complete inside a tile go straight to HBM (see linePartKernel)
     unsigned long long *minKey;                  // optional (EXTRAS, NUCL): global minimum of (kmer | BIT63) (first-run quirk)
     uint32_t *valueHist; int valueShift;         // optional (EXTRAS)
 };
 
 static inline size_t linePartLdsBytes(uint32_t nb, size_t recBytes, bool extras) {
-    return (size_t) nb * RPL * recBytes + (size_t) nb * 8 + (extras ? VH_BINS * 4 : 0) + (size_t) nb * 2 + 16;
+    return (size_t) nb * RPL * recBytes + (size_t) nb * 8 + (extras ? VH_BINS * 4 : 0) + (size_t) nb * 2 + (size_t) nb * 4 + 16;
 }
 
 template <bool NUCL, bool LONG, int MODE, bool LIST, bool EXTRAS, int LP_BLOCK, int LP_ITEMS, bool PREFETCH>
@@ -119,8 +120,10 @@ __global__ __launch_bounds__(LP_BLOCK) void linePartKernel(LinePartArgs a) {
     uint32_t *cnt = reinterpret_cast<uint32_t *>(lpDyn + (size_t) nb * RPL * sizeof(R));      // [nb] records seen of the bucket (this piece)
     uint32_t *flushed = cnt + nb;                                                             // [nb] lines written of the bucket (this piece)
     uint32_t *vh = flushed + nb;                                                              // [VH_BINS] (EXTRAS)
-    unsigned short *queue = reinterpret_cast<unsigned short *>(vh + (EXTRAS ? VH_BINS : 0));  // [nb] buckets whose line completed this round
+    uint32_t *lbase = vh + (EXTRAS ? VH_BINS : 0);                                            // [nb] (direct) first output line of the bucket's lines of this tile
+    unsigned short *queue = reinterpret_cast<unsigned short *>(lbase + nb);                   // [nb] buckets whose line completed this round
     __shared__ uint32_t sQ[2];
+    __shared__ uint32_t sScan[LP_BLOCK / 64 + 1];
     const uint32_t tid = threadIdx.x;
     const R *in = reinterpret_cast<const R *>(a.in);
     R *out = reinterpret_cast<R *>(a.out);
@@ -176,6 +179,51 @@ __global__ __launch_bounds__(LP_BLOCK) void linePartKernel(LinePartArgs a) {
                     }
                 }
             }
+            // DIRECT (range partitions of grouped records): a tile of grouped records names few representatives with many records
+            // each, so a bucket completes many lines per tile and the round scheme below (one line per bucket and round) would take
+            // 2-13 rounds per tile.  Here `flushed` holds the record COUNT at the start of the tile; the lines a bucket completes in
+            // this tile get consecutive output lines (one scan over the buckets), their records go straight from registers to HBM
+            // (the 16-byte pieces of a line are written within the same tile and merge in L2), what was waiting in the open line
+            // goes with them, and only the new open line stays in LDS: one round per tile whatever the distribution.
+            if (MODE == KEY_RANGE && a.direct) {                    // (compiled into the range-partition instantiations only: hash partitions
+                                                                    //  are evenly filled and gain nothing from it — measured)
+                __syncthreads();
+                uint32_t mine = 0;
+                for (uint32_t b = tid; b < nb; b += LP_BLOCK) mine += cnt[b] / RPL - flushed[b] / RPL;
+                const uint32_t incl = waveInclusiveScan(mine);
+                if (laneId() == 63) sScan[tid >> 6] = incl;
+                __syncthreads();
+                uint32_t woff = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < LP_BLOCK / 64; w++) { const uint32_t v = sScan[w]; if (w < (int) (tid >> 6)) woff += v; total += v; }
+                uint32_t run = woff + incl - mine;
+                for (uint32_t b = tid; b < nb; b += LP_BLOCK) {
+                    const uint32_t oldC = flushed[b], done = cnt[b] / RPL - oldC / RPL;
+                    lbase[b] = run;
+                    if (done && (oldC % RPL)) {                      // the open line completes: its earlier records wait in LDS
+                        const uint64_t ol = outLine + run;
+                        for (uint32_t r = 0; r < oldC % RPL; r++) out[ol * RPL + r] = buf[(size_t) b * RPL + r];
+                        a.tags[ol] = pc.tagBase + b;
+                    }
+                    run += done;
+                }
+                __syncthreads();
+#pragma unroll
+                for (int u = 0; u < LP_ITEMS; u++) {
+                    if ((pending >> u) & 1u) {
+                        const uint32_t b = bk[u], L = sq[u] / RPL, oldL = flushed[b] / RPL, newL = cnt[b] / RPL;
+                        if (L < newL) {
+                            const uint64_t ol = outLine + lbase[b] + (L - oldL);
+                            out[ol * RPL + (sq[u] % RPL)] = rec[u];
+                            if (sq[u] % RPL == 0) a.tags[ol] = pc.tagBase + b;
+                        } else buf[(size_t) b * RPL + (sq[u] % RPL)] = rec[u];
+                    }
+                }
+                __syncthreads();
+                for (uint32_t b = tid; b < nb; b += LP_BLOCK) flushed[b] = cnt[b];
+                outLine += total;
+                continue;                                           // (the next tile's barrier orders these writes before its reads)
+            }
             // rounds: a record joins the open line of its bucket when that line is the one it belongs to (its running number / 8);
             // a round closes at most one line per bucket, the workgroup then writes the closed lines as one contiguous run
             for (;;) {
@@ -205,11 +253,13 @@ __global__ __launch_bounds__(LP_BLOCK) void linePartKernel(LinePartArgs a) {
         // the open lines of the piece, padded with sentinels
         {
             const uint32_t par = round & 1u;
-            for (uint32_t b = tid; b < nb; b += LP_BLOCK) if (cnt[b] != flushed[b] * RPL) { const uint32_t q = atomicAdd(&sQ[par], 1u); queue[q] = (unsigned short) b; }
+            __syncthreads();
+            auto openRecords = [&](uint32_t b) { return (MODE == KEY_RANGE && a.direct) ? cnt[b] % RPL : cnt[b] - flushed[b] * RPL; };
+            for (uint32_t b = tid; b < nb; b += LP_BLOCK) if (openRecords(b)) { const uint32_t q = atomicAdd(&sQ[par], 1u); queue[q] = (unsigned short) b; }
             __syncthreads();
             const uint32_t nQ = sQ[par];
             for (uint32_t j = tid; j < nQ * RPL; j += LP_BLOCK) {
-                const uint32_t b = queue[j / RPL]; const uint32_t r = cnt[b] - flushed[b] * RPL;
+                const uint32_t b = queue[j / RPL]; const uint32_t r = openRecords(b);
                 out[(outLine + j / RPL) * RPL + (j % RPL)] = ((j % RPL) < r) ? buf[(size_t) b * RPL + (j % RPL)] : sen;
             }
             for (uint32_t j = tid; j < nQ; j += LP_BLOCK) a.tags[outLine + j] = pc.tagBase + queue[j];
