@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libplasship.so")
+    """the in-tree C-ABI library; PLASSHIP_LIB names another build of it (A/B runs of kernel variants)"""
+    return os.environ.get("PLASSHIP_LIB") or os.path.join(_HERE, "libplasship.so")
 
 
 class PlasshipError(RuntimeError):
