@@ -156,13 +156,19 @@ __device__ __forceinline__ Rescored rescoreOnDiagonal(const char *q, unsigned qL
     return r;
 }
 
-__global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
+__device__ __forceinline__ void waveMemSync() {   // make this wave's global stores visible to its own later loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+// Four wavefronts per workgroup share the 15 KB score table (one wavefront per workgroup let LDS cap the CU at 10 wavefronts); a
+// wavefront works on its own queries and orders its own memory operations with fences — there is no workgroup barrier in the loop.
+__global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
-    for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
+    for (int i = threadIdx.x; i < 123 * 123; i += 256) smat[i] = a.mat[i];
     __syncthreads();
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
-    for (uint32_t w = blockIdx.x; w < a.nBig; w += gridDim.x) {
+    for (uint32_t w = blockIdx.x * 4 + (threadIdx.x >> 6); w < a.nBig; w += gridDim.x * 4) {
         const uint32_t id = a.bigList[w];
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
         const uint32_t h = (uint32_t) (h1 - h0);
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
         uint64_t curStart = a.leftCap[id];
         copyBytesG<64>(buf + curStart, orig, querySeqLen, lane);
         uint64_t curLen = querySeqLen;
-        __syncthreads();
+        waveMemSync();
         bool couldExtend = false;
         uint32_t inQueue = h;
         while (inQueue > 0) {
@@ -235,7 +241,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
             const bool haveR = idxR != 0xFFFFFFFFu, haveL = idxL != 0xFFFFFFFFu;
             // full priority order between the two: (score, alnLength) then the smaller target id wins
             const bool rFirst = haveR && (!haveL || bestR > bestL || (bestR == bestL && tgtR < tgtL));
-            __syncthreads();
+            waveMemSync();
             auto extendRight = [&]() {
                 const Item x = it[idxR];
                 const char *tSeq = a.s.data + a.s.off[x.target];
@@ -258,7 +264,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
                 }
             }
             if (haveR && !rFirst && !brokeOut) extendRight();
-            __syncthreads();
+            waveMemSync();
             uint32_t still = 0;
             for (uint32_t i = lane; i < h; i += 64) {
                 const Item x = it[i];
@@ -281,13 +287,13 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
                 it[i].state = st;
             }
             inQueue = (uint32_t) waveReduceSum((int) still);
-            __syncthreads();
+            waveMemSync();
             if (leftOff > 0 || rightOff > 0) couldExtend = true;
             if (brokeOut && inQueue > 0) break;
             // ---- re-score deferred hits on the extended query (assembleresult.cpp:288-313) ----
             querySeqLen = (unsigned) curLen;
             const char *qs = buf + curStart;
-            __syncthreads();
+            waveMemSync();
             // every lane re-scores its own deferred hits (32 residues per step), all hits of the round in parallel: a queue this long
             // defers dozens of hits per round, and a 50-150 residue overlap would leave most of a wavefront idle if the hits were
             // taken one after the other (same arithmetic as the wide register queues of assembleGroupKernel)
@@ -318,7 +324,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
                 x.state = (seqId >= a.seqIdThr) ? 0u : 2u;
                 it[i] = x;
             }
-            __syncthreads();
+            waveMemSync();
             // recount what is really queued (defensive: the loop condition must match the item states)
             {
                 uint32_t c = 0;
@@ -330,7 +336,7 @@ __global__ __launch_bounds__(64) void assembleBigKernel(AsmArgs a) {
             if (lane == 0) { atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart; }
             nExt++;
         }
-        __syncthreads();
+        waveMemSync();
     }
     nResc = waveReduceSumU64(nResc); nRescRes = waveReduceSumU64(nRescRes);        // counted per lane (every lane re-scores its own hits)
     if (lane == 0) {
@@ -857,10 +863,6 @@ __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs 
 // ---- the common cases: the whole queue of a query lives in registers, one alignment per lane.
 //      G = 16: four queries per wavefront (a read has a handful of overlaps); G = 64: one query per wavefront.
 //      Sixteen/four independent groups per block share the LDS score table; no block barriers in the loop. ----
-__device__ __forceinline__ void waveMemSync() {   // make this wave's global stores visible to its own later loads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 // reductions over a group: inside a row of 16 lanes on the VALU (DPP), across rows with shuffles
 template <int G> __device__ __forceinline__ int groupSum(int v) {
     v = rowSum16(v);
@@ -906,8 +908,8 @@ __device__ __forceinline__ Rescored rescoreOnDiagonalG(const char *q, unsigned q
     return r;
 }
 
-template <int G>
-__global__ __launch_bounds__(256) void assembleGroupKernel(AsmArgs a) {
+template <int G, int WPE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void assembleGroupKernel(AsmArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
     for (int i = threadIdx.x; i < 123 * 123; i += 256) smat[i] = a.mat[i];
     __syncthreads();
@@ -1493,14 +1495,25 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         for (int e = 4; e <= 7; e++) PH_CHECK(hipEventRecord(ctx->ev[e], st));
     } else {
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
-    if (a.nSmall) hipLaunchKernelGGL(assembleGroupKernel<16>, dim3(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASM16", 4))), dim3(256), 0, st, a);
+    // wavefronts per SIMD of the register-queue kernels (PLASSHIP_TUNE_ASM16 / ASM64): the grid is what the CUs hold at once
+    const int w16 = tuneInt("ASM16", 4), w64 = tuneInt("ASM64", 3);
+    const dim3 g16(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) w16)), g64(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) w64));
+    if (a.nSmall) {
+        if (w16 == 6) hipLaunchKernelGGL((assembleGroupKernel<16, 6>), g16, dim3(256), 0, st, a);
+        else if (w16 == 5) hipLaunchKernelGGL((assembleGroupKernel<16, 5>), g16, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((assembleGroupKernel<16, 4>), g16, dim3(256), 0, st, a);
+    }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    if (a.nMid32) hipLaunchKernelGGL(assembleGroupKernel<32>, dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASM32", 5))), dim3(256), 0, st, a);
-    if (a.nMid) hipLaunchKernelGGL(assembleGroupKernel<64>, dim3(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASM64", 5))), dim3(256), 0, st, a);
+    if (a.nMid32) hipLaunchKernelGGL((assembleGroupKernel<32, 5>), dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * 5u)), dim3(256), 0, st, a);
+    if (a.nMid) {
+        if (w64 == 5) hipLaunchKernelGGL((assembleGroupKernel<64, 5>), g64, dim3(256), 0, st, a);
+        else if (w64 == 4) hipLaunchKernelGGL((assembleGroupKernel<64, 4>), g64, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((assembleGroupKernel<64, 3>), g64, dim3(256), 0, st, a);
+    }
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     PH_CHECK(hipEventRecord(ctx->ev[6], st));
-    if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>(a.nBig, (uint32_t) ctx->numCU * 10)), dim3(64), 0, st, a);
+    if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>((a.nBig + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASMBIG", 6))), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[7], st));
     }
     PH_TRACE(st, "assemble: extension kernels");

@@ -231,8 +231,12 @@ __device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k,
 //   65 536-bin threshold walk is a 16-step bisection over the score bits whose counts are wave ballots (no LDS histogram, no
 //   atomics, no barriers), and only the <= ~60 selected windows rebuild their k-mer.  Longer sequences are queued for the next
 //   launch.  REGS == 0: the three-pass path below; RESL = longest sequence whose codes and scores stay resident in LDS.
+//   Wavefronts per SIMD (amdgpu_waves_per_eu), measured with tools/extract_probe.py: the per-sequence phases are chains of LDS round
+//   trips, so resident wavefronts count for more than registers — 8 for the 4-scores tier (64 VGPRs, 144 bytes of scratch per
+//   lane; 6: +4 %, 4: +30 % time), 4 for the 16-scores tier (5 gains nothing), 4 for the 48-scores tier of protein runs (128 VGPRs
+//   and 200+ bytes of scratch, yet 3.0 instead of 4.7 ms per 120 k sequences of 2500 residues at 2 wavefronts).
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 && REGS <= 4) ? 6 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 2 : 1))))) void extractKernel(ExtractArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 && REGS <= 4) ? 8 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 4 : 1))))) void extractKernel(ExtractArgs a) {
     constexpr uint32_t RES_L = RESL;
     constexpr uint32_t CODES = (RESL > 64 * REGS + 32 ? RESL : 64 * REGS + 32) + 32;
     __shared__ unsigned char sMap[256];
@@ -2272,7 +2276,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         } else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, ea);
         ExtractArgs e2 = ea; e2.waveList = dOvIds.as<uint32_t>(); e2.waveCount = dOvCnt.as<uint32_t>();
         e2.overflowIds = dOv2Ids.as<uint32_t>(); e2.overflowCount = dOv2Cnt.as<uint32_t>();
-        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 12u))), dim3(64), 0, st, e2);
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 16u))), dim3(64), 0, st, e2);
         PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));            // tier 2 has consumed the first queue: it becomes tier 3's output queue
         ExtractArgs e3 = ea; e3.waveList = dOv2Ids.as<uint32_t>(); e3.waveCount = dOv2Cnt.as<uint32_t>();
         e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>();
