@@ -1496,7 +1496,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     } else {
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     // wavefronts per SIMD of the register-queue kernels (PLASSHIP_TUNE_ASM16 / ASM64): the grid is what the CUs hold at once
-    const int w16 = tuneInt("ASM16", 4), w64 = tuneInt("ASM64", 3);
+    const int w16 = tuneInt("ASM16", 6), w64 = tuneInt("ASM64", 4);
     const dim3 g16(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) w16)), g64(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) w64));
     if (a.nSmall) {
         if (w16 == 6) hipLaunchKernelGGL((assembleGroupKernel<16, 6>), g16, dim3(256), 0, st, a);
@@ -1513,7 +1513,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     }
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     PH_CHECK(hipEventRecord(ctx->ev[6], st));
-    if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>((a.nBig + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASMBIG", 6))), dim3(256), 0, st, a);
+    if (a.nBig) hipLaunchKernelGGL(assembleBigKernel, dim3(std::min<uint32_t>((a.nBig + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ASMBIG", 4))), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[7], st));
     }
     PH_TRACE(st, "assemble: extension kernels");
