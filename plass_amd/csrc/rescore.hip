@@ -331,7 +331,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     if (dLongList.alloc(std::max<uint64_t>(nHits, 1) * 8) != hipSuccess || dLongCount.alloc(8) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 8, ctx->stream));
     a.longList = dLongList.as<unsigned long long>(); a.longCount = dLongCount.as<unsigned long long>();
-    const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * (uint64_t) tuneInt("RESCORE", 12));
+    const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * (uint64_t) tuneInt("RESCORE", nHits > 50000000ull ? 32 : 12));   // large lists: smaller shares per workgroup even out the tail (37.8 -> 35.9 ms at 250 M pairs)
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
     hipLaunchKernelGGL(rescoreKernel<1>, dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL(rescoreKernel<16>, dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
