@@ -127,6 +127,15 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
                 wide = rem >= 16;
                 if (wide) __builtin_memcpy(qw, q + (qLen - 1 - (qo + p)) - 15, 16);
             } else __builtin_memcpy(qw, q + qo + p, 16);
+            if (!REV) {
+                // identities of the 16 columns at once: bytes equal up to the case bit are zero bytes of (q ^ t) & 0xDF..; exact
+                // zero-byte test, columns beyond n masked off (4 instructions per residue less than comparing byte by byte)
+                const uint64_t lo7 = 0x7F7F7F7F7F7F7F7FULL;
+                const uint64_t x0 = (qw[0] ^ tw[0]) & 0xDFDFDFDFDFDFDFDFULL, x1 = (qw[1] ^ tw[1]) & 0xDFDFDFDFDFDFDFDFULL;
+                uint64_t z0 = ~(((x0 & lo7) + lo7) | x0 | lo7), z1 = ~(((x1 & lo7) + lo7) | x1 | lo7);     // 0x80 in every zero byte
+                if (n < 8) { z0 &= (1ULL << (8 * n)) - 1ULL; z1 = 0; } else if (n < 16) z1 &= (1ULL << (8 * (n - 8))) - 1ULL;
+                ids += __popcll(z0) + __popcll(z1);
+            }
 #pragma unroll
             for (unsigned j = 0; j < 16; j++) {
                 if (j < n) {
@@ -139,7 +148,7 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
                     }
                     const unsigned b = (unsigned) (tw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
                     s += (int) smat[a * 123 + b];
-                    ids += ((a & ~0x20u) == (b & ~0x20u)) ? 1 : 0;
+                    if (REV) ids += ((a & ~0x20u) == (b & ~0x20u)) ? 1 : 0;
                 }
             }
         }
