@@ -232,11 +232,11 @@ __device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k,
 //   atomics, no barriers), and only the <= ~60 selected windows rebuild their k-mer.  Longer sequences are queued for the next
 //   launch.  REGS == 0: the three-pass path below; RESL = longest sequence whose codes and scores stay resident in LDS.
 //   Wavefronts per SIMD (amdgpu_waves_per_eu), measured with tools/extract_probe.py: the per-sequence phases are chains of LDS round
-//   trips, so resident wavefronts count for more than registers — 8 for the 4-scores tier (64 VGPRs, 144 bytes of scratch per
-//   lane; 6: +4 %, 4: +30 % time), 4 for the 16-scores tier (5 gains nothing), 4 for the 48-scores tier of protein runs (128 VGPRs
+//   trips, so resident wavefronts count for more than registers — 6 for the 4-scores tier (80 VGPRs; 4: +30 % time; 8 would gain
+//   another 4 % but its 144 bytes of scratch per lane turn into 90 GB of memory traffic per launch), 4 for the 16-scores tier (5 gains nothing), 4 for the 48-scores tier of protein runs (128 VGPRs
 //   and 200+ bytes of scratch, yet 3.0 instead of 4.7 ms per 120 k sequences of 2500 residues at 2 wavefronts).
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 && REGS <= 4) ? 8 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 4 : 1))))) void extractKernel(ExtractArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 && REGS <= 4) ? 6 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 4 : 1))))) void extractKernel(ExtractArgs a) {
     constexpr uint32_t RES_L = RESL;
     constexpr uint32_t CODES = (RESL > 64 * REGS + 32 ? RESL : 64 * REGS + 32) + 32;
     __shared__ unsigned char sMap[256];
