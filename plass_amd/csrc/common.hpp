@@ -114,6 +114,7 @@ struct plasship_ctx {
     char *stage[2] = {nullptr, nullptr};
     hipEvent_t stageEv[2] = {nullptr, nullptr};
     size_t stageBytes = 0;
+    void *pinnedTable = nullptr;        // 1 MB of pinned host memory for small tables a kernel chain reads (ctxPinnedTable, core.hip)
     // one read set sharded over several GPUs (plasship_ctx_set_comm); world == 1 and hasComm == false: single GPU
     bool hasComm = false;
     plasship_comm comm = {};
@@ -193,6 +194,10 @@ int stagedUpload(plasship_ctx *ctx, void *dDst, uint64_t total, const std::funct
 // D2H: consume(src, byteOffset, bytes) sees consecutive chunks in order (false aborts with PLASSHIP_ERR_IO); the next chunk is
 // already being copied while it runs
 int stagedDownload(plasship_ctx *ctx, const void *dSrc, uint64_t total, const std::function<bool(const char *, uint64_t, uint64_t)> &consume);
+// 1 MB of pinned host memory owned by the context (nullptr if `bytes` does not fit or it cannot be allocated): a table copied from
+// it with hipMemcpyAsync needs no wait before the host moves on.  One user per module call; the next call's use comes after that
+// call's own waits, by which time the copy has long completed.
+void *ctxPinnedTable(plasship_ctx *ctx, size_t bytes);
 // plain arrays: host -> device / device -> host through the staging buffers (memcpy on the host threads)
 int stagedCopyToDevice(plasship_ctx *ctx, void *dDst, const void *hSrc, uint64_t bytes);
 int stagedCopyToHost(plasship_ctx *ctx, void *hDst, const void *dSrc, uint64_t bytes);

@@ -223,6 +223,7 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     (void) plasship::streamSync(ctx->stream);
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
     for (int i = 0; i < 2; i++) { if (ctx->stage[i]) (void) hipHostFree(ctx->stage[i]); if (ctx->stageEv[i]) (void) hipEventDestroy(ctx->stageEv[i]); }
+    if (ctx->pinnedTable) (void) hipHostFree(ctx->pinnedTable);
     if (ctx->stream) { poolForgetStream(ctx->stream); (void) hipStreamDestroy(ctx->stream); }
     bool last; { std::lock_guard<std::mutex> g(g_poolMu); last = (--g_ctxCount <= 0); }
     if (last) {
@@ -255,6 +256,11 @@ static int stageReady(plasship_ctx *ctx) {
     }
     ctx->stageBytes = want;
     return PLASSHIP_OK;
+}
+void *ctxPinnedTable(plasship_ctx *ctx, size_t bytes) {
+    if (bytes > (1u << 20)) return nullptr;
+    if (!ctx->pinnedTable && hipHostMalloc(&ctx->pinnedTable, 1u << 20, hipHostMallocDefault) != hipSuccess) { ctx->pinnedTable = nullptr; (void) hipGetLastError(); }
+    return ctx->pinnedTable;
 }
 int stagedUpload(plasship_ctx *ctx, void *dDst, uint64_t total, const std::function<void(char *, uint64_t, uint64_t)> &produce) {
     if (!total) return PLASSHIP_OK;

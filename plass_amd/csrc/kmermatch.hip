@@ -1931,7 +1931,10 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     if (dR1.alloc(capR1 * RPL * sizeof(R)) != hipSuccess || dRTag1.alloc(capR1 * 4) != hipSuccess || dRList1.alloc(capR1 * 4) != hipSuccess || dRPieces.alloc(((size_t) nPR1 + 1) * sizeof(LinePiece)) != hipSuccess ||
         dRNP.alloc(4) != hipSuccess || dRCnt1.alloc(LP_MAXB * 4) != hipSuccess || dRStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dRCur1.alloc(LP_MAXB * 4) != hipSuccess ||
         dSortBeg.alloc((size_t) nSort * 4) != hipSuccess || dSortCnt.alloc((size_t) nSort * 4) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-    if (nPR1) PH_CHECK(hipMemcpyAsync(dRPieces.p, hp.data(), (size_t) nPR1 * sizeof(LinePiece), hipMemcpyHostToDevice, st));
+    // the piece table travels from pinned memory when it fits (no wait for the copy), else from the vector (waited for below)
+    void *hpPinned = nPR1 ? ctxPinnedTable(ctx, (size_t) nPR1 * sizeof(LinePiece)) : nullptr;
+    if (hpPinned) memcpy(hpPinned, hp.data(), (size_t) nPR1 * sizeof(LinePiece));
+    if (nPR1) PH_CHECK(hipMemcpyAsync(dRPieces.p, hpPinned ? hpPinned : (const void *) hp.data(), (size_t) nPR1 * sizeof(LinePiece), hipMemcpyHostToDevice, st));
     else PH_CHECK(hipMemsetAsync(dRTag1.p, 0xFF, capR1 * 4, st));                       // nothing grouped: no piece will write the tag array
     PH_CHECK(hipMemcpyAsync(dRNP.p, &nPR1, 4, hipMemcpyHostToDevice, st));
     // grouped records arrive with many records per representative: lines that complete inside a tile are written directly (linepart.hpp)
@@ -1943,7 +1946,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         a.direct = directLines;
         rc = launchLinePart<NUCL, LONG, KEY_RANGE, false, false>(ctx, a, std::max<uint32_t>(nPR1, 1)); if (rc) return rc;
     }
-    PH_CHECK(plasship::streamSync(st));                     // hp goes out of use (async copy of a pageable host vector)
+    if (nPR1 && !hpPinned) PH_CHECK(plasship::streamSync(st));   // hp goes out of use (async copy of a pageable host vector)
     rc = buildLineLists(ctx, dRTag1.as<uint32_t>(), capR1, nS1, dRCnt1.as<uint32_t>(), dRStart1.as<uint32_t>(), dRCur1.as<uint32_t>(), dRList1.as<uint32_t>()); if (rc) return rc;
     (otherRecs == dA.p ? dA : dB).release();               // the arenas are consumed
     void *sortRecs = dR1.p; const uint32_t *sortList = dRList1.as<uint32_t>(); uint64_t sortCap = capR1;

@@ -346,14 +346,15 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     hipLaunchKernelGGL(rescoreKernel<16>, dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), nHits, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
+    // the accepted alignments are compacted into a buffer sized for ALL pairs (nearly all candidates of an assembly iteration are
+    // accepted): their number is read with the statistics at the end instead of costing a wait of its own here
     uint64_t nAcc = 0;
     PH_CHECK(hipMemcpyAsync(&nAcc, dPos.as<uint64_t>() + nHits, 8, hipMemcpyDeviceToHost, ctx->stream));
-    PH_CHECK(plasship::streamSync(ctx->stream));
 
     std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
     plasship_alns *al = holder.get();
-    al->nQueries = qdb->n; al->nLines = nAcc; al->nucl = nucl; al->addBacktrace = par->add_backtrace != 0; al->dbResidues = tdb->residues;
-    if (al->d_qoff.alloc((qdb->n + 1) * 8) != hipSuccess || al->d_recs.alloc(std::max<uint64_t>(nAcc, 1) * sizeof(AlnRec)) != hipSuccess) {
+    al->nQueries = qdb->n; al->nucl = nucl; al->addBacktrace = par->add_backtrace != 0; al->dbResidues = tdb->residues;
+    if (al->d_qoff.alloc((qdb->n + 1) * 8) != hipSuccess || al->d_recs.alloc(std::max<uint64_t>(nHits, 1) * sizeof(AlnRec)) != hipSuccess) {
         setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     if (nHits) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((nHits + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
@@ -364,6 +365,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     PH_CHECK(hipMemcpyAsync(hs, dStats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     PH_CHECK(plasship::streamSync(ctx->stream));
     PH_CHECK(hipGetLastError());
+    al->nLines = nAcc;
     al->qdb = qdb; al->tdb = tdb;
     if (stats) {
         stats->n_scored = nHits; stats->n_accepted = nAcc; stats->overlap_residues = hs[1];
