@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     __shared__ unsigned long long hBest[HT];
     __shared__ uint32_t hMulti[HT / 32];                     // bit = a second record met this slot's k-mer
     __shared__ uint32_t sFlag[2];
-    __shared__ uint32_t sCursor;
+    __shared__ uint32_t sCursor[2];                          // arena cursor of a sub-pass; two, used alternately, save a barrier per sub-pass
     const R *in = reinterpret_cast<const R *>(a.in);
     R *out = reinterpret_cast<R *>(a.out);
     const uint32_t bBegin = blockIdx.x * a.bucketsPerBlock;
@@ -1102,6 +1102,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? in[(uint64_t) a.list[lbNext + i / RPL] * RPL + (i % RPL)] : none; }
         }
     };
+    uint32_t par = 0;                                // which cursor the current sub-pass uses (workgroup-uniform)
     fetch(bBegin);
     for (uint32_t b = bBegin; b < bEnd; b++) {
         const uint32_t n = nNext;                    // record positions of the bucket (padding sentinels included)
@@ -1179,7 +1180,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             const uint32_t wr = (uint32_t) __popcll(mk & ((1ULL << laneId()) - 1ULL));
             uint32_t wbase = 0;
             if (mk) {
-                if (laneId() == 0) wbase = atomicAdd(&sCursor, (uint32_t) __popcll(mk));
+                if (laneId() == 0) wbase = atomicAdd(&sCursor[par], (uint32_t) __popcll(mk));
                 wbase = __shfl(wbase, 0, 64);
             }
             if (keep) out[arena + written + wbase + wr] = o;
@@ -1190,7 +1191,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             bool redo = false;
             for (uint32_t sub = 0; sub < nSub && !redo; sub++) {
                 for (uint32_t i = threadIdx.x; i < HT; i += BLOCK) { hKey[i] = ~0ULL; hBest[i] = ~0ULL; if (i < HT / 32) hMulti[i] = 0; }
-                if (threadIdx.x == 0) { sFlag[0] = 0; sFlag[1] = 0; sCursor = 0; }
+                if (threadIdx.x == 0) { sFlag[0] = 0; sFlag[1] = 0; sCursor[par] = 0; }   // (the other cursor may still be being read)
                 __syncthreads();
                 if (inRegs) {
 #pragma unroll
@@ -1204,9 +1205,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseC(i < n ? recAt(i) : none, nSub, sub); }
                 if (sub + 1 == nSub) { fetch(b + 1); fetched = true; }     // last sub-pass: nothing reads this bucket's registers again
                 __syncthreads();
-                written += sCursor;
-                __syncthreads();
-                if (threadIdx.x == 0) sCursor = 0;
+                written += sCursor[par];
+                par ^= 1u;
             }
             if (!redo) break;
             nSub *= 2;                               // a retry discards what completed sub-passes of this attempt wrote
