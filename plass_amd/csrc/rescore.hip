@@ -117,16 +117,21 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
         // The loop is bound by the number of memory requests, not by bytes: every lane streams its own two sequences.
         // REV: the aligned query is the reverse complement of the stored one — the 16 stored bytes that end at the mirrored
         // position are loaded and walked backwards (never reading before the start of the buffer).
+        // (forward strand: the next 16 residues of both sequences are requested before the current ones are scored — the walk is a
+        // chain of dependent round trips per lane, and the score lookups of one step hide most of the next step's latency)
+        uint64_t qn[2] = {0, 0}, tn[2] = {0, 0};
+        if (!REV && first <= last) { __builtin_memcpy(tn, t + to + first, 16); __builtin_memcpy(qn, q + qo + first, 16); }
         for (unsigned p = first; p <= last; p += 16u) {
             uint64_t qw[2], tw[2];
-            __builtin_memcpy(tw, t + to + p, 16);
+            if (!REV) { tw[0] = tn[0]; tw[1] = tn[1]; qw[0] = qn[0]; qw[1] = qn[1]; if (p + 16u <= last) { __builtin_memcpy(tn, t + to + p + 16, 16); __builtin_memcpy(qn, q + qo + p + 16, 16); } }
+            else __builtin_memcpy(tw, t + to + p, 16);
             const unsigned n = min(16u, last - p + 1);
             bool wide = true;
             if (REV) {
                 const unsigned rem = qLen - (qo + p);            // stored residues left of (and including) the mirrored position
                 wide = rem >= 16;
                 if (wide) __builtin_memcpy(qw, q + (qLen - 1 - (qo + p)) - 15, 16);
-            } else __builtin_memcpy(qw, q + qo + p, 16);
+            }
             if (!REV) {
                 // identities of the 16 columns at once: bytes equal up to the case bit are zero bytes of (q ^ t) & 0xDF..; exact
                 // zero-byte test, columns beyond n masked off (4 instructions per residue less than comparing byte by byte)
