@@ -90,7 +90,7 @@ template <int G> __device__ __forceinline__ int groupReduceSumG(int v) {
 }
 __device__ __forceinline__ uint32_t loadU32Unaligned(const char *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }
 
-// Scores ONE diagonal with a 16-lane group (4 residues per lane and step); returns (all lanes of the group)
+// Scores ONE diagonal with a 16-lane group (8 residues per lane and step); returns (all lanes of the group)
 // score/first/last/idCnt; valid=false if the diagonal does not intersect.  Mode 3 only.
 struct DiagScore { bool valid; unsigned score; int first, last; unsigned diagLen; int idCnt; };
 
@@ -158,19 +158,19 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
             }
         }
     } else
-    for (unsigned p = first + 4u * (unsigned) sl; p <= last; p += 4u * G) {
-        // 4 consecutive residues of both sequences (unaligned dword loads; the DB buffer is padded past its end)
-        uint32_t tw = loadU32Unaligned(t + to + p);
-        uint32_t qw;
+    for (unsigned p = first + 8u * (unsigned) sl; p <= last; p += 8u * G) {
+        // 8 consecutive residues of both sequences (unaligned 8-byte loads; the DB buffer is padded past its end)
+        uint64_t tw; __builtin_memcpy(&tw, t + to + p, 8);
+        uint64_t qw;
         if (REV) {
             const unsigned rem = qLen - (qo + p);            // stored residues left of (and including) this one
-            if (rem >= 4) qw = __builtin_bswap32(loadU32Unaligned(q + (qLen - 1 - (qo + p)) - 3));
-            else { qw = 0; for (unsigned j = 0; j < rem; j++) qw |= (uint32_t) (unsigned char) q[qLen - 1 - (qo + p + j)] << (8 * j); }   // never read before the buffer
+            if (rem >= 8) { uint64_t v; __builtin_memcpy(&v, q + (qLen - 1 - (qo + p)) - 7, 8); qw = __builtin_bswap64(v); }
+            else { qw = 0; for (unsigned j = 0; j < rem; j++) qw |= (uint64_t) (unsigned char) q[qLen - 1 - (qo + p + j)] << (8 * j); }   // never read before the buffer
         }
-        else qw = loadU32Unaligned(q + qo + p);
-        const unsigned n = min(4u, last - p + 1);
+        else __builtin_memcpy(&qw, q + qo + p, 8);
+        const unsigned n = min(8u, last - p + 1);
 #pragma unroll
-        for (unsigned j = 0; j < 4; j++) {
+        for (unsigned j = 0; j < 8; j++) {
             if (j < n) {
                 char a = (char) (qw >> (8 * j)), b = (char) (tw >> (8 * j));
                 if (REV) a = (char) comp[(unsigned char) a];
