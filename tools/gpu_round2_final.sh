@@ -8,6 +8,8 @@ timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_cmd
 timeout 600 python bench.py --steps 12 --warmup 0 --no-cpu-baseline > $O/bench_c3_12steps.log 2>/dev/null
 timeout 300 python bench.py --config c2 > $O/bench_c2.log 2>/dev/null
 PROBE_LENGTHS=48,60,80,100,150,250,400,700,1000,1500,2500 timeout 200 python tools/extract_probe.py 3e8 > $O/extract_probe.log 2>&1
+timeout 300 python tools/bench_nucl.py 500000 3 > $O/bench_nucl.log 2>&1
+timeout 300 python tools/io_probe.py 2500000 > $O/io_probe.log 2>&1
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/$O/prof -o driver -- python $R/bench.py --gpus 1 --steps 20 --warmup 5 > $R/$O/bench_driver_cmd_rocprof.log 2> $R/$O/bench_driver_cmd_rocprof.err
