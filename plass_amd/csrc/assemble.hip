@@ -10,12 +10,14 @@
 //   lib/mmseqs/src/alignment/Matcher.cpp:248-320  the text round trip the reference reads its input through:
 //       seqId has 3 truncated decimals ("1.00" for 1.0), alnLength = max(|qE-qS|,|tE-tS|)+1, score = bit score
 //
-// Kernel design: one wavefront per query.  The greedy loop is control flow on a handful of integers
-// (wave-uniform); the data-parallel parts — arg-max over the remaining hits, fragment copies, ungapped
-// re-scoring — use all 64 lanes.  The growing query lives in an HBM arena sized by an exact upper bound
-// (query + every target that could ever be attached on either side), so no allocation happens in the loop.
-// Because the comparator is a strict total order, std::priority_queue's pop order is "max of what is in
-// the queue", which is what the wave arg-max computes.
+// Kernel design: the queue of a query lives in registers, one alignment per lane — 16, 32 or 64 lanes per query by queue size
+// (assembleGroupKernel<16/32/64>; work lists by prefix sums after an exact pre-screen), an HBM-resident queue above 64 alignments
+// (assembleBigKernel, one wavefront per query).  A ROUND of the reference's pop loop is computed from the queued set: the comparator
+// is a strict total order, so std::priority_queue's pop order is "max of what is in the queue", the best right-extendable and the
+// best left-extendable hit (two arg-max reductions on a packed priority) are the round's two extensions, and every other hit is
+// dropped or deferred by the geometry tests with the final offsets, in parallel; deferred hits are re-scored by their own lane
+// (wide queues) or by the 16-lane group.  The growing query lives in an HBM arena sized by an exact upper bound (query + every
+// target that could ever be attached on either side), so no allocation happens in the loop.
 // The nucleotide variant (non-strict Bayesian comparator, heap-order dependent) has its own kernel below that
 // replays libstdc++'s heap operations (assembleNuclKernel).
 #include "common.hpp"

@@ -8,12 +8,13 @@
 //   alignment/DistanceCalculator.h:204-220  mode 3 end-to-end score, '*' trimmed at either end
 //   alignment/rescorediagonal.cpp:251-297   alnLen, coordinates, identity count, seqId, coverage
 //
-// Kernel design: one wavefront per candidate pair.  The 123x123 ASCII-indexed score table
-// (SubstitutionMatrix.h:56-73; 15 KB) lives in LDS; lanes stride over the overlap, one byte of query
-// and target each (HBM-resident packed sequence data, both reads coalesced across the wave), the
-// table lookup is an LDS gather, and score / identity counts are reduced with wave shuffles.  Lane 0
-// finishes the integer and IEEE-exact fp arithmetic (float divisions, double fma/div for the bit
-// score); the only transcendental piece — the E-value — is replaced by a host-built per-query-length
+// Kernel design: ONE THREAD per candidate pair whenever the shorter sequence has at most 512 residues (rescoreKernel<1>: a read
+// overlap is 30-150 columns; a wavefront per pair would idle most lanes and pay two reductions per pair), 16 lanes per pair on a
+// list of the rest (rescoreKernel<16>, 8 residues per lane and step).  The 123x123 ASCII-indexed score table
+// (SubstitutionMatrix.h:56-73; 15 KB) lives in LDS; a thread streams 16 residues of both sequences per round trip (unaligned
+// 16-byte loads, the next 16 requested before the current ones are scored), looks the scores up in LDS and counts the identities
+// of the 16 columns with one zero-byte test.  The integer and IEEE-exact fp arithmetic (float divisions, double fma/div for the
+// bit score) follows per pair; the only transcendental piece — the E-value — is replaced by a host-built per-query-length
 // minimum-score table, which is exact because E(score) is monotone (host_util.cpp).
 // -ffp-contract=off: no float expression here may be fused behind our back.
 #include "common.hpp"
