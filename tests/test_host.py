@@ -126,3 +126,31 @@ def test_local_group_host_allgather_threads():
         for w in (1, 2, 3, 8):
             edges = [owned_range(n, r, w) for r in range(w)]
             assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+
+
+def test_large_fixture_matches_the_generator(tmp_path):
+    """tests/golden/large_chain.json (CPU-oracle checksums of the 5 M-read chain) was made for exactly the parameters bench.py
+    derives for that size, and the CPU read generator (`plass_oracle synthreads`, the read model shared with the GPU generator) is
+    deterministic: same parameters, same digest; another seed, another digest"""
+    import json
+    import subprocess
+    import bench
+    import __graft_entry__ as g
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "large_chain.json")))
+    sp = bench.synth_params(gold["config"], gold["pairs"])
+    for k, v in gold["synth"].items():
+        assert getattr(sp, k) == pytest.approx(v), k
+    assert gold["reads"]["entries"] == 2 * gold["pairs"] and gold["reads"]["bytes"] == 2 * gold["pairs"] * (sp.read_len + 2)
+    assert len(gold["iterations"]) >= 3 and all(it["seq"]["entries"] == gold["fragments"]["entries"] for it in gold["iterations"])
+    if not os.path.exists(g.oracle_bin()):
+        subprocess.check_call(["make", "-j", "4"], cwd=os.path.join(ROOT, "oracle"))
+
+    def digest(name, seed):
+        p = str(tmp_path / name)
+        g.run_oracle(["synthreads", p, "--pairs", "3000", "--seed", str(seed), "--genomes", "2", "--genome-min-len", "30000", "--genome-max-len", "60000",
+                      "--abundance-sigma", "1.0"])
+        out = subprocess.run([g.oracle_bin(), "dbsum", p], stdout=subprocess.PIPE, check=True, text=True).stdout
+        return dict(x.split("=") for x in out.strip().split("\t")[1:])
+
+    a, b, c = digest("a", 2), digest("b", 2), digest("c", 3)
+    assert a == b and a["entries"] == "6000" and a["digest"] != c["digest"]
