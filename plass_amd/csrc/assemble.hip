@@ -1572,7 +1572,8 @@ extern "C" int plasship_guided_assemble(plasship_ctx *ctx, const plasship_seqdb 
     PH_ENTER(ctx);
     // the reference addresses the twin of entry i by the same id (guidedassembleresult.cpp:363): the key sets must be equal
     bool differ = false;
-    { const int rc = deviceKeysDiffer(ctx, nucl_db->d_key.as<uint32_t>(), aa_db->d_key.as<uint32_t>(), nucl_db->n, &differ); if (rc) return rc; }
-    if (differ) { setError("plasship_guided_assemble: nucleotide and protein DB have different keys"); return PLASSHIP_ERR_ARG; }
+    // (every return behind PH_ENTER goes through commFinish: a rank that left alone would leave its peers waiting in their next collective)
+    { const int rc = deviceKeysDiffer(ctx, nucl_db->d_key.as<uint32_t>(), aa_db->d_key.as<uint32_t>(), nucl_db->n, &differ); if (rc) return commFinish(ctx, rc); }
+    if (differ) { setError("plasship_guided_assemble: nucleotide and protein DB have different keys"); return commFinish(ctx, PLASSHIP_ERR_ARG); }
     return commFinish(ctx, assembleImpl(ctx, nucl_db, aa_db, al, par, out_nucl, out_aa, stats));
 }

@@ -34,7 +34,7 @@ Rccl &rccl() {
         const char *env = getenv("PLASSHIP_RCCL_LIB");
         const char *names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char *n : names) { if (!n || !*n) continue; r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (r.lib) break; }
-        if (!r.lib) { r.error = std::string("cannot load RCCL (librccl.so.1): ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!r.lib) { const char *e = dlerror(); r.error = std::string("cannot load RCCL (librccl.so.1): ") + (e ? e : "?"); return; }   // dlerror() clears the message: call it once
         auto sym = [&](const char *n) { void *p = dlsym(r.lib, n); if (!p && r.error.empty()) r.error = std::string("RCCL symbol missing: ") + n; return p; };
         r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
         r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
@@ -100,17 +100,21 @@ int exchange(plasship_rccl_comm *c, const char *send, const uint64_t *soff, cons
     if (sb[me]) HC(hipMemcpyAsync(recv + roff[me], send + soff[me], sb[me], hipMemcpyDeviceToDevice, st));
     uint64_t rounds = 0;
     for (int r = 0; r < W; r++) if (r != me) rounds = std::max(rounds, (std::max(sb[r], rb[r]) + PIECE - 1) / PIECE);
+    // a failing call inside an open group closes the group before it returns (the thread must not stay in group mode: the
+    // ncclCommAbort of the destroy path runs on it)
+#define RCG(call, what) do { const int e_ = (call); if (e_ != 0) { (void) rccl().GroupEnd(); RC(e_, what); } } while (0)
     for (uint64_t k = 0; k < rounds; k++) {
         RC(rccl().GroupStart(), "ncclGroupStart");
         for (int r = 0; r < W; r++) {
             if (r == me) continue;
             uint64_t lo = std::min(k * PIECE, sb[r]), hi = std::min((k + 1) * PIECE, sb[r]);
-            if (hi > lo) { RC(rccl().Send(send + soff[r] + lo, hi - lo, NCCL_UINT8, r, c->comm, st), "ncclSend"); c->bytesSent += hi - lo; }
+            if (hi > lo) { RCG(rccl().Send(send + soff[r] + lo, hi - lo, NCCL_UINT8, r, c->comm, st), "ncclSend"); c->bytesSent += hi - lo; }
             lo = std::min(k * PIECE, rb[r]); hi = std::min((k + 1) * PIECE, rb[r]);
-            if (hi > lo) RC(rccl().Recv(recv + roff[r] + lo, hi - lo, NCCL_UINT8, r, c->comm, st), "ncclRecv");
+            if (hi > lo) RCG(rccl().Recv(recv + roff[r] + lo, hi - lo, NCCL_UINT8, r, c->comm, st), "ncclRecv");
         }
         RC(rccl().GroupEnd(), "ncclGroupEnd");
     }
+#undef RCG
     return 0;
 }
 int cbAlltoallv(void *user, const void *dSend, const uint64_t *sb, void *dRecv, const uint64_t *rb) {

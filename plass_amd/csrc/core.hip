@@ -34,7 +34,7 @@ struct FreeRange { size_t size; hipStream_t stream; bool mixed; };
 struct Slab { char *base; size_t size; size_t used; std::map<size_t, FreeRange> free; };       // free: offset -> range
 struct DevicePool { std::vector<Slab> slabs; size_t total = 0; };
 std::map<int, DevicePool> g_pools;
-struct PoolLive { int device; int slab; size_t off, size; };
+struct PoolLive { int device; int slab; size_t off, size; hipStream_t stream; };   // stream: the one the block was handed out on (its user)
 std::unordered_map<void *, PoolLive> g_poolLive;
 thread_local hipStream_t tl_poolStream = nullptr;    // stream of the API call this thread is in (poolEnter)
 int g_ctxCount = 0;
@@ -52,7 +52,7 @@ bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor
     if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
     sl.used += n;
     *p = sl.base + bo;
-    g_poolLive[*p] = PoolLive{dev, bs, bo, n};
+    g_poolLive[*p] = PoolLive{dev, bs, bo, n, tl_poolStream};
     *waitAll = fr.mixed; *waitFor = (!fr.mixed && fr.stream != tl_poolStream) ? fr.stream : nullptr;
     return true;
 }
@@ -139,7 +139,10 @@ void poolFree(void *p) {
     g_poolLive.erase(it);
     Slab &sl = g_pools[lv.device].slabs[lv.slab];
     sl.used -= lv.size;
-    size_t off = lv.off, size = lv.size; hipStream_t stream = tl_poolStream; bool mixed = false;
+    // the range is tagged with the stream that USED the block (recorded when it was handed out), not with whatever stream the
+    // releasing thread entered last: `*_free(NULL, h)` and frees from another context's thread are legal.  A release from a
+    // thread that is inside another context's call marks the range `mixed` (reuse waits for the whole device).
+    size_t off = lv.off, size = lv.size; hipStream_t stream = lv.stream; bool mixed = (tl_poolStream != nullptr && tl_poolStream != lv.stream);
     auto nx = sl.free.lower_bound(off);
     if (nx != sl.free.end() && off + size == nx->first) {        // merge with the range behind
         if (nx->second.mixed || nx->second.stream != stream) mixed = !(nx->second.stream == nullptr && !nx->second.mixed) || mixed;

@@ -154,3 +154,18 @@ def test_large_fixture_matches_the_generator(tmp_path):
 
     a, b, c = digest("a", 2), digest("b", 2), digest("c", 3)
     assert a == b and a["entries"] == "6000" and a["digest"] != c["digest"]
+
+
+def test_rccl_stub_exports_what_the_native_communicator_resolves():
+    """tests/tools/rccl_stub.cpp (the in-process librccl stand-in of the multi-rank tests) exports every nccl* symbol
+    plass_amd/csrc/comm_rccl.hip looks up with dlsym — so a W > 1 run through it executes the product's exchange() unchanged"""
+    import ctypes
+    import __graft_entry__ as g
+    stub = os.path.join(ROOT, "tests", "tools", "librccl_stub.so")
+    if not os.path.exists(stub):
+        g.build()
+    wanted = set(re.findall(r'sym\("(nccl[A-Za-z]+)"\)', open(os.path.join(ROOT, "plass_amd", "csrc", "comm_rccl.hip")).read()))
+    assert len(wanted) == 10
+    lib = ctypes.CDLL(stub)
+    for name in sorted(wanted):
+        assert hasattr(lib, name), "the stub lacks " + name
