@@ -49,6 +49,9 @@ CONFIGS = {
     # name: (BASELINE.json index, read pairs, genomes, min/max genome length, abundance sigma, seed, chain length)
     "c3": (2, 25000000, 200, 1000000, 5000000, 1.0, 2, 12),
     "c2": (1, 500000, 1, 7500000, 7500000, 0.0, 1, 6),
+    # configs[4]: PenguiN's nucleotide-level chains (kmermatcher k=22 -> rescorediagonal -> nuclassembleresults -> cyclecheck, and the
+    # protein-guided chain) on 20 M reads of the same community model, seed 3; chain = nucleotide iterations timed
+    "c5": (4, 10000000, 200, 1000000, 5000000, 1.0, 3, 5),
 }
 
 
@@ -209,6 +212,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="read pairs of the whole job (0 = the config's own; the community scales with it)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = 40000 below 8 host cores, 120000 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the untimed traversal that digests every iteration's output DB")
     ap.add_argument("--comm", choices=["auto", "native", "torch"], default="auto",
                     help="sharded run: 'native' = the library's own RCCL communicator (include/plasship_rccl.h), 'torch' = torch.distributed P2P; auto = native, torch if that fails")
     ap.add_argument("--mode", choices=["auto", "sharded", "partitions"], default="auto",
@@ -388,8 +392,32 @@ def main():
                                 "collective_calls_per_step": ncalls / max(steps, 1), "host_ms_in_collectives_per_step_rank0": nsec * 1e3 / max(steps, 1)}
     if db is not db0:
         db.free()
+    # ---- untimed verification: one more traversal of the chain, digest of every iteration's output DB (include/plasship.h:
+    # plasship_seqdb_digest, the number the CPU oracle's `dbsum` computes from DB files) against the committed digests of this
+    # workload (tests/golden/c3_chain_digests.json: agreed on by the line-store, the dense-partition and the sharded path,
+    # tests/test_gpu_large.py).  A 32-bit slip above 2^32 record slots can no longer print a plausible rate unnoticed.
+    verify = None
+    if not args.no_verify:
+        vdb, digests = db0, []
+        for it in range(chain):
+            out, _, _, _, _ = one_iteration(ctx, vdb, it)
+            digests.append(out.digest()[0])
+            if vdb is not db0:
+                vdb.free()
+            vdb = out
+        if vdb is not db0:
+            vdb.free()
+        verify = {"seq_digests": digests, "reference": None, "match": None}
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "%s_chain_digests.json" % args.config)))
+        except (OSError, ValueError):
+            gold = None
+        if gold and gold.get("pairs") == wl["read_pairs"] and mode != "partitions":
+            verify["reference"] = "tests/golden/%s_chain_digests.json" % args.config
+            verify["match"] = digests == gold["digests"][:len(digests)]
     db0.free()
     if rank == 0:
+        line["verify"] = verify
         if world == 1 and comm is None and native is None and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, min(chain, 3))
         else:

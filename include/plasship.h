@@ -109,6 +109,11 @@ int plasship_seqdb_read(plasship_ctx *ctx, const char *db_path, plasship_seqdb *
 int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *db, const char *db_path);
 int plasship_seqdb_info(const plasship_seqdb *db, size_t *n, uint64_t *residues, uint32_t *max_entry_len,
                         int *dbtype, uint64_t *data_bytes);
+/* Order-independent digest of a resident sequence DB: sum over the entries of a 64-bit hash of (key, entry length, entry bytes
+ * with the trailing "\n\0") — FNV-1a over the bytes, seeded with key and length, then a 64-bit finaliser.  Not a reference
+ * interface: it is how DBs too large to write out are compared (bench.py puts the digest of every iteration's output DB on its
+ * JSON line; the CPU oracle's `plass_oracle dbsum` computes the same number from DB files, tests/golden/large_chain.json). */
+int plasship_seqdb_digest(plasship_ctx *ctx, const plasship_seqdb *db, uint64_t *digest, uint64_t *entry_bytes);
 /* download in key order; any pointer may be NULL */
 int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *db, char *data, uint64_t *off,
                             uint32_t *elen, uint32_t *key);

@@ -119,6 +119,7 @@ SYMBOLS = [
     ("plasship_seqdb_read", C.c_int, [P, C.c_char_p, C.POINTER(P)]),
     ("plasship_seqdb_write", C.c_int, [P, P, C.c_char_p]),
     ("plasship_seqdb_info", C.c_int, [P, C.POINTER(C.c_size_t), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    ("plasship_seqdb_digest", C.c_int, [P, P, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("plasship_seqdb_download", C.c_int, [P, P, P, P, P, P]),
     ("plasship_seqdb_free", None, [P, P]),
     ("plasship_kmermatch", C.c_int, [P, P, C.POINTER(_KmermatchParams), C.POINTER(P), C.POINTER(KmermatchStats)]),
@@ -426,6 +427,19 @@ class Context:
         aa_long.free(); aa_start.free()
         return out
 
+    def penguin_guided_inputs(self, reads):
+        """the preprocessing of `penguin guided_nuclassemble` on a read DB (data/guidedNuclAssemble.sh:44-75): two extractorfs passes,
+        concatdbs of the ORFs and of their headers, translatenucs --add-orf-stop -> (nucl_6f_start_long, aa_6f_start_long)"""
+        o_long, h_long, _ = self.extractorfs(reads, OrfParams(**PLASS_ORFS_LONG))
+        o_start, h_start, _ = self.extractorfs(reads, OrfParams(**PLASS_ORFS_START))
+        nucl = self.concatdbs(o_long, o_start)
+        hdr = self.concatdbs(h_long, h_start)
+        for x in (o_long, o_start, h_long, h_start):
+            x.free()
+        aa, _ = self.translatenucs(nucl, hdr, add_orf_stop=True)
+        hdr.free()
+        return nucl, aa
+
     def synth_read_pairs(self, par):
         """synthetic read pairs generated in HBM (include/plasship_synth.h) -> nucleotide read DB"""
         h = P(); st = SynthStats(); cp = par._c()
@@ -450,6 +464,12 @@ class SeqDB:
 
     def write(self, path):
         _check(self.ctx.lib.plasship_seqdb_write(self.ctx.h, self.h, os.fsencode(path)), "plasship_seqdb_write")
+
+    def digest(self):
+        """(digest as 16 hex digits, entry bytes): order-independent digest of the resident DB (include/plasship.h: plasship_seqdb_digest)"""
+        d = C.c_uint64(); b = C.c_uint64()
+        _check(self.ctx.lib.plasship_seqdb_digest(self.ctx.h, self.h, C.byref(d), C.byref(b)), "plasship_seqdb_digest")
+        return "%016x" % d.value, b.value
 
     def download(self):
         import numpy as np

@@ -102,7 +102,7 @@ int exchange(plasship_rccl_comm *c, const char *send, const uint64_t *soff, cons
     for (int r = 0; r < W; r++) if (r != me) rounds = std::max(rounds, (std::max(sb[r], rb[r]) + PIECE - 1) / PIECE);
     // a failing call inside an open group closes the group before it returns (the thread must not stay in group mode: the
     // ncclCommAbort of the destroy path runs on it)
-#define RCG(call, what) do { const int e_ = (call); if (e_ != 0) { (void) rccl().GroupEnd(); RC(e_, what); } } while (0)
+#define RCG(call, what) do { const int g_ = (call); if (g_ != 0) { (void) rccl().GroupEnd(); RC(g_, what); } } while (0)
     for (uint64_t k = 0; k < rounds; k++) {
         RC(rccl().GroupStart(), "ncclGroupStart");
         for (int r = 0; r < W; r++) {

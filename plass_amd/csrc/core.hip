@@ -459,6 +459,46 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
     return PLASSHIP_OK;
 }
 
+// ---- digest of a resident DB (include/plasship.h): one thread per entry, FNV-1a is a serial chain per entry ----
+namespace plasship {
+__global__ __launch_bounds__(256) void digestKernel(const char *__restrict__ data, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len, const uint32_t *__restrict__ key,
+                                                    uint32_t n, unsigned long long *__restrict__ out) {
+    unsigned long long sum = 0, bytes = 0;
+    for (uint32_t e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+        const uint32_t el = len[e] + 2;                                       // the entry as indexed: sequence + "\n\0"
+        const unsigned char *p = reinterpret_cast<const unsigned char *>(data) + off[e];
+        uint64_t h = 0xCBF29CE484222325ull ^ ((uint64_t) key[e] * 0x9E3779B97F4A7C15ull) ^ ((uint64_t) el << 40);
+        uint32_t j = 0;
+        // eight bytes per load once the address is aligned (entries start anywhere)
+        for (; j < el && ((reinterpret_cast<uintptr_t>(p + j)) & 7u); j++) { h ^= p[j]; h *= 0x100000001B3ull; }
+        for (; j + 8 <= el; j += 8) {
+            uint64_t w = *reinterpret_cast<const uint64_t *>(p + j);
+#pragma unroll
+            for (int b = 0; b < 8; b++) { h ^= (w & 0xFFu); h *= 0x100000001B3ull; w >>= 8; }
+        }
+        for (; j < el; j++) { h ^= p[j]; h *= 0x100000001B3ull; }
+        h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 27; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+        sum += h; bytes += el;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); bytes += __shfl_xor(bytes, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], sum); atomicAdd(&out[1], bytes); }
+}
+}  // namespace plasship
+extern "C" int plasship_seqdb_digest(plasship_ctx *ctx, const plasship_seqdb *db, uint64_t *digest, uint64_t *entry_bytes) {
+    if (!ctx || !db || !digest) { setError("plasship_seqdb_digest: bad argument"); return PLASSHIP_ERR_ARG; }
+    PH_ENTER(ctx);
+    DevBuf d; unsigned long long h[2] = {0, 0};
+    if (d.alloc(16) != hipSuccess) { setError("plasship_seqdb_digest: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(d.p, 0, 16, ctx->stream));
+    if (db->n) hipLaunchKernelGGL(digestKernel, dim3((unsigned) std::min<size_t>((db->n + 255) / 256, (size_t) ctx->numCU * 64)), dim3(256), 0, ctx->stream,
+                                  db->d_data.as<char>(), db->d_off.as<uint64_t>(), db->d_len.as<uint32_t>(), db->d_key.as<uint32_t>(), (uint32_t) db->n, d.as<unsigned long long>());
+    PH_COPY_SYNC(ctx->stream, h, d.p, 16, hipMemcpyDeviceToHost);
+    PH_CHECK(hipGetLastError());
+    *digest = h[0]; if (entry_bytes) *entry_bytes = h[1];
+    return PLASSHIP_OK;
+}
+
 extern "C" void plasship_seqdb_free(plasship_ctx *ctx, plasship_seqdb *db) {
     if (!db) return;
     if (ctx) { (void) hipSetDevice(ctx->device); plasship::poolEnter(ctx->stream); }

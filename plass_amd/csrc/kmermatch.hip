@@ -28,6 +28,7 @@
 #include "linepart.hpp"
 #include <algorithm>
 #include <memory>
+#include <type_traits>
 #include <cstdlib>
 #include <climits>
 #include <cstring>
@@ -781,11 +782,9 @@ __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t
 // =====================================================================================================
 // 3. segmented, unstable bucket partition (used for the hash grouping and for the rep-range sort)
 // =====================================================================================================
-// KEY_OWNER_HASH / KEY_OWNER_REP (sharded run): bucket = the rank that owns the record — the k-mer's hash bucket (low bits of
-// the same mix whose top bits pick the grouping bucket, so the owner's buckets stay uniformly filled) or the representative's
-// id range.  (Key kinds, kmerMix and the record layouts: linepart.hpp.)  This dense two-pass partition (histogram, then scatter)
-// is what the SHARDED run still uses — its exchanges send contiguous runs per destination; a single GPU takes the line-store
-// partition of linepart.hpp.
+// (Key kinds, kmerMix and the record layouts: linepart.hpp.)  This dense two-pass partition (histogram, then scatter) was round 1's
+// path; single-GPU and sharded runs take the line-store partition of linepart.hpp now.  It stays behind PLASSHIP_LEGACY_PARTITION=1
+// (single GPU) as an independent implementation for cross-checks at sizes no CPU oracle can follow (tests/test_gpu_large.py).
 constexpr int PT_BLOCK = 256;
 constexpr int PT_ITEMS = 16;
 constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;
@@ -804,13 +803,11 @@ struct PartArgs {
     // of any record without sorting, which is all the stale-record check (section 7) needs most of the time
     uint32_t *valueHist; int valueShift;
     uint64_t repBase;               // KEY_RANGE: subtracted from the rep id (sharded run: first rep this rank owns)
-    uint32_t ownerW; uint64_t ownerN;   // KEY_OWNER_*: number of ranks; KEY_OWNER_REP: number of sequences
 };
 template <bool NUCL, int MODE> __device__ __forceinline__ uint32_t bucketOf(const PartArgs &a, uint64_t kmerField, uint32_t nb) {
     if (MODE == KEY_HASH) return (uint32_t) (kmerMix<NUCL>(kmerField) >> a.shift) & (nb - 1);
     if (MODE == KEY_RANGE) return (uint32_t) ((((kmerField & ~BIT63) - a.repBase) << (64 - a.rangeBits)) >> a.shift) & (nb - 1);   // left-aligned rep id: top bits = id range
-    if (MODE == KEY_OWNER_HASH) return (uint32_t) (((kmerMix<NUCL>(kmerField) & 0xFFFFFFFFull) * (uint64_t) a.ownerW) >> 32);
-    return (uint32_t) (((kmerField & ~BIT63) * (uint64_t) a.ownerW) / a.ownerN);              // owner r <=> id in [ceil(r n / W), ceil((r+1) n / W))
+    return 0;
 }
 template <bool NUCL, bool LONG, int MODE>
 __global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
@@ -1241,11 +1238,15 @@ struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag;
 
 // LINES: bucket b = the lines list[lineBeg[b] .. + lineCnt[b]) of `arr` (linepart.hpp); its triples go to outTriples[lineBeg[b] * RPL ...]
 struct AggLines { const uint32_t *list, *lineBeg, *lineCnt; };
-template <bool NUCL, bool LONG, bool LINES>
+__device__ __forceinline__ bool isSentinel(const Triple &t) { return t.rep == 0xFFFFFFFFu && t.target == 0xFFFFFFFFu; }   // a padding slot of a line of triples
+// TRIPLES (sharded run, owner side): the input elements are weighted triples other ranks aggregated from THEIR k-mer buckets (16 bytes,
+// lines of RPL like the 16-byte records); equal (rep, target, diagonal) triples of several ranks merge here, counts add, strand flags OR.
+// A representative is keyed by (rep - repBase) [bit-reversed over scrambleBits when != 0] relative to its bucket's first key.
+template <bool NUCL, bool LONG, bool LINES, bool TRIPLES = false>
 __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void *outTriples, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
                                                           unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
                                                           uint32_t *__restrict__ uniqueCount, int localBits, int idBits, uint64_t repBase, AggLines ln, int scrambleBits) {
-    typedef Rec<LONG> R;
+    typedef typename std::conditional<TRIPLES, Triple, Rec<LONG>>::type R;
     __shared__ unsigned long long hKey[AGG_HT];
     __shared__ uint32_t hVal[AGG_HT];
     __shared__ unsigned long long lKey[AGG_CAP];
@@ -1263,22 +1264,24 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
         const uint32_t lb = LINES ? ln.lineBeg[b] : 0u;
         auto recAt = [&](uint64_t i) -> R { if (LINES) return g[(uint64_t) ln.list[lb + (uint32_t) (i / RPL)] * RPL + (i % RPL)]; return g[s0 + i]; };
         if (cnt == 0) { if (threadIdx.x == 0) uniqueCount[b] = 0; continue; }
-        const uint64_t baseRep = repBase + ((uint64_t) b << localBits);     // repBase: first rep of this rank's range (sharded run), else 0
+        const uint64_t bucketBase = (uint64_t) b << localBits;             // first (relative, possibly bit-reversed) rep key of the bucket
         auto decode = [&](unsigned long long key, uint32_t val) {
             Triple t;
             t.diag = (int32_t) ((int64_t) (key & ((1ULL << DB) - 1)) - DiagPack<LONG>::BIAS);
             const uint64_t k2 = key >> DB;
             t.target = (uint32_t) (k2 & ((1ULL << idBits) - 1));
-            const uint64_t rp = (k2 >> idBits) + baseRep;
-            t.rep = (uint32_t) (scrambleBits ? scrambleRep(rp, scrambleBits) : rp);       // an involution: back to the id
+            const uint64_t rp = (k2 >> idBits) + bucketBase;
+            t.rep = (uint32_t) ((scrambleBits ? scrambleRep(rp, scrambleBits) : rp) + repBase);       // an involution: back to the id
             t.cnt = val;
             return t;
         };
         auto packRec = [&](const R &r, uint32_t &val) {
-            uint64_t rep = r.kmer & ~BIT63;
+            uint64_t rep, target; int64_t diag;
+            if constexpr (TRIPLES) { rep = r.rep; target = r.target; diag = r.diag; val = r.cnt; }
+            else { rep = r.kmer & ~BIT63; target = r.id; diag = r.pos; val = 1u | ((NUCL && (r.kmer & BIT63)) ? 0x80000000u : 0u); }
+            rep -= repBase;                                                    // repBase: first rep of this rank's range (sharded run, owner side), else 0
             if (scrambleBits) rep = scrambleRep(rep, scrambleBits);            // buckets are ranges of the bit-reversed id (linepart.hpp)
-            val = 1u | ((NUCL && (r.kmer & BIT63)) ? 0x80000000u : 0u);
-            return (unsigned long long) (((((rep - baseRep) << idBits) | (uint64_t) r.id) << DB) | (uint64_t) ((int64_t) r.pos + DiagPack<LONG>::BIAS));
+            return (unsigned long long) (((((rep - bucketBase) << idBits) | target) << DB) | (uint64_t) (diag + DiagPack<LONG>::BIAS));
         };
         auto clearTable = [&]() {
             for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) { hKey[i] = ~0ULL; hVal[i] = 0; }
@@ -1450,28 +1453,56 @@ __global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__rest
 }
 
 // line-store path: the triples of bucket b lie at in[lineBeg[b] * RPL ...] (unique[b] of them), grouped by representative.  Every
-// representative occurs in exactly one bucket: its run length and position go to cnt[rep] / pos[rep] (cnt is zeroed beforehand).
+// representative occurs in exactly one bucket: the number of its triples and the position of the first go to cnt[rep - repBase] /
+// pos[rep - repBase] (cnt is zeroed beforehand).  One wavefront per bucket; a representative's triples are counted 64 at a time
+// (a long contig is the representative of 10^5..10^6 triples: neither a serial walk per run nor one atomic per triple would do).
 __global__ __launch_bounds__(256) void repRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
-                                                     uint32_t *__restrict__ cnt, uint64_t *__restrict__ pos) {
-    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {     // one wave per bucket
+                                                     uint32_t repBase, uint32_t *__restrict__ cnt, uint64_t *__restrict__ pos) {
+    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
         const uint64_t s0 = (uint64_t) lineBeg[b] * RPL; const uint32_t n = unique[b];
-        for (uint32_t i = laneId(); i < n; i += 64) {
-            const uint32_t rep = in[s0 + i].rep;
-            if (i == 0 || in[s0 + i - 1].rep != rep) {
-                uint32_t len = 1; while (i + len < n && in[s0 + i + len].rep == rep) len++;
-                cnt[rep] = len; pos[rep] = s0 + i;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + laneId();
+            const bool valid = i < n;
+            const uint32_t rep = valid ? in[s0 + i].rep : 0xFFFFFFFFu;
+            const bool runHead = valid && (i == 0 || in[s0 + i - 1].rep != rep);          // first triple of the representative
+            const uint32_t prevLane = __shfl_up(rep, 1, 64);
+            const bool segHead = valid && (laneId() == 0 || prevLane != rep);            // first of its triples within these 64
+            const unsigned long long heads = __ballot(segHead), vmask = __ballot(valid);
+            if (runHead) pos[rep - repBase] = s0 + i;
+            if (segHead) {
+                const unsigned long long later = heads & ~((2ULL << laneId()) - 1ULL);   // heads behind this lane
+                const int end = later ? __ffsll((long long) later) - 1 : (int) __popcll(vmask);
+                atomicAdd(&cnt[rep - repBase], (uint32_t) (end - laneId()));
             }
         }
     }
 }
-__global__ __launch_bounds__(256) void placeRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ cnt, const uint64_t *__restrict__ pos,
-                                                       const uint64_t *__restrict__ start, uint32_t n, Triple *__restrict__ out) {
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const uint32_t c = cnt[r];
-        if (!c) continue;
-        const uint64_t s = pos[r], d = start[r];
-        for (uint32_t j = 0; j < c; j++) out[d + j] = in[s + j];
+// every triple to its place in representative order: start[rep - repBase] + its offset within the representative's run
+__global__ __launch_bounds__(256) void placeRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
+                                                       uint32_t repBase, const uint64_t *__restrict__ pos, const uint64_t *__restrict__ start, Triple *__restrict__ out) {
+    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
+        const uint64_t s0 = (uint64_t) lineBeg[b] * RPL; const uint32_t n = unique[b];
+        for (uint32_t i = laneId(); i < n; i += 64) {
+            const Triple t = in[s0 + i];
+            const uint32_t rel = t.rep - repBase;
+            out[start[rel] + (s0 + i - pos[rel])] = t;
+        }
     }
+}
+// sharded run: the first triple of every rank's share of the (rep-ordered) triples: out[r] = start[first rep rank r owns], r = 0..W
+__global__ void ownerBoundsKernel(const uint64_t *__restrict__ start, uint64_t n, int W, uint64_t *__restrict__ out) {
+    for (int r = threadIdx.x; r <= W; r += blockDim.x) out[r] = start[((uint64_t) r * n + (uint64_t) W - 1) / (uint64_t) W];
+}
+// sharded run: the lines of the level-1 buckets in list order, packed for the exchange (16-byte chunks; a line is 128 or 192 bytes)
+__global__ __launch_bounds__(256) void gatherLinesKernel(const uint4 *__restrict__ in, const uint32_t *__restrict__ list, uint64_t nLines, uint32_t chunksPerLine, uint4 *__restrict__ out) {
+    const uint64_t total = nLines * chunksPerLine;
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t) gridDim.x * blockDim.x)
+        out[i] = in[(uint64_t) list[i / chunksPerLine] * chunksPerLine + (i % chunksPerLine)];
+}
+// sharded run: line list over the receive buffer — the lines of own bucket j from source s are a contiguous run of it
+struct RxSeg { uint64_t src; uint32_t cnt, dst; };      // first line in the receive buffer, lines, first position in the list
+__global__ __launch_bounds__(256) void rxListKernel(const RxSeg *__restrict__ segs, uint32_t nSegs, uint32_t *__restrict__ list) {
+    for (uint32_t q = blockIdx.x; q < nSegs; q += gridDim.x) { const RxSeg g = segs[q]; for (uint32_t i = threadIdx.x; i < g.cnt; i += 256) list[g.dst + i] = (uint32_t) (g.src + i); }
 }
 
 // =====================================================================================================
@@ -1561,7 +1592,7 @@ __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const u
     const bool useLds = m <= 1024;
     if (useLds) { for (uint32_t i = threadIdx.x; i <= m; i += 256) sDiff[i] = 0; __syncthreads(); }
     for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < nLines * RPL; i += (uint64_t) gridDim.x * 256) {
-        if (tags[i / RPL] == TAG_NONE) continue;
+        if (tags && tags[i / RPL] == TAG_NONE) continue;                // tags == nullptr: every line is valid (received lines of a sharded run)
         const R r = g[i];
         if (isSentinel(r)) continue;
         uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
@@ -1668,11 +1699,14 @@ static uint32_t pieceLinesFor(uint64_t lines, uint32_t nb, int numCU, uint32_t m
     const uint64_t want = (lines + 4ull * (uint64_t) numCU - 1) / (4ull * (uint64_t) numCU);
     return (uint32_t) std::max<uint64_t>((uint64_t) nb * minFactor, std::min<uint64_t>((uint64_t) nb * 64, std::max<uint64_t>(want, 1)));
 }
-static LineGeo lineGeometry(uint64_t totalSlots, bool lng, int numCU) {
+// totalSlots: slots of THIS rank's sequences (what level 1 reads); sharded run: slotsAll = slots of all ranks — the bucket bits are
+// those of the whole run, the same on every rank, and there are at least W level-1 buckets (rank r owns a contiguous range of them)
+static LineGeo lineGeometry(uint64_t totalSlots, bool lng, int numCU, uint64_t slotsAll = 0, int W = 1) {
     LineGeo g;
     const int maxBits = lng ? 9 : 10;                         // LDS: 2^bits open lines of RPL records
-    const int totalBits = std::min(2 * maxBits, std::max(0, ceilLog2((totalSlots + 1535) / 1536)));   // ~1000-1500 records per final bucket
-    g.b1 = totalBits <= maxBits ? totalBits : (totalBits + 1) / 2; g.b2 = totalBits - g.b1;
+    const int lw = ceilLog2((uint64_t) std::max(W, 1));
+    const int totalBits = std::min(2 * maxBits, std::max(lw, std::max(0, ceilLog2(((slotsAll ? slotsAll : totalSlots) + 1535) / 1536))));   // ~1000-1500 records per final bucket
+    g.b1 = totalBits <= maxBits ? totalBits : std::max((totalBits + 1) / 2, lw); g.b2 = totalBits - g.b1;
     g.nb1 = 1u << g.b1; g.nb2 = g.b2 ? 1u << g.b2 : 0u;
     g.totalLines = (totalSlots + RPL - 1) / RPL;
     g.lastValid = g.totalLines ? (uint32_t) (totalSlots - (g.totalLines - 1) * RPL) : (uint32_t) RPL;
@@ -1681,7 +1715,7 @@ static LineGeo lineGeometry(uint64_t totalSlots, bool lng, int numCU) {
     g.cap1 = std::max<uint64_t>(g.nP1 * ((uint64_t) g.PL1 + g.nb1), 1);
     if (g.nb2) {
         // level 2: ONE piece per level-1 bucket (its output range is the bucket's "region"; hash buckets are evenly filled)
-        g.PL2 = 0xFFFFFFFFu; g.maxP2 = g.nb1; g.cap2 = g.cap1 + (uint64_t) g.nb1 * g.nb2;
+        g.PL2 = 0xFFFFFFFFu; g.maxP2 = g.nb1; g.cap2 = g.cap1 + (uint64_t) g.nb1 * g.nb2;     // (sharded run: cap2 follows from what the exchange delivers)
     }
     return g;
 }
@@ -1747,9 +1781,149 @@ static int buildLineLists(plasship_ctx *ctx, const uint32_t *dTags, uint64_t cap
 }
 
 // What the line path hands to the run reduction
-struct LinesOut { void *triples = nullptr; uint64_t nTriples = 0, Nk = 0, Nm = 0; std::vector<int64_t> stalePos; uint32_t staleT = 0; float msSort1 = 0, msGroup = 0, msSort2 = 0, msPart = 0; int nPart = 1; };
+struct LinesOut { void *triples = nullptr; uint64_t nTriples = 0, Nk = 0, Nm = 0; std::vector<int64_t> stalePos; uint32_t staleT = 0; float msSort1 = 0, msGroup = 0, msSort2 = 0, msPart = 0; int nPart = 1;
+                  uint64_t exchangedRecordBytes = 0, exchangedTripleBytes = 0; };
 
-// extraction has filled dA (`total` record slots, sentinels in unused slots).  Buffers dA / dB hold geo.cap2 resp. geo.cap1 lines.
+constexpr uint64_t HALO_SLACK = 1u << 16;
+
+// ---- sort #2 over the line store: range partition of `in` (the level-1 pieces `hp` with `outLine` output lines in total) by ranges of
+// the bit-reversed (rep - repBase), aggregation + sort per bucket, then every representative's triples to their place in
+// representative order.  TRIPLES: `in` holds weighted triples (owner side of a sharded run), else grouped records.
+// out: `dOut` = nTriples triples in (rep, target, diagonal) order (+ slackTriples of room behind them); dRepStart[nReps + 1] (optional)
+template <bool NUCL, bool LONG, bool TRIPLES>
+static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std::pair<uint64_t, uint64_t>> &segs, uint64_t nIn, uint32_t nReps, uint32_t repBase, uint32_t nTargets,
+                        uint64_t slackTriples, const std::function<void()> &inputConsumed, DevBuf &dOut, uint64_t &nTriples, DevBuf *dRepStartOut) {
+    constexpr bool PL = TRIPLES ? false : LONG;                // record layout the partition kernels move: triples are 16 bytes like Rec<false>
+    typedef Rec<PL> R;
+    hipStream_t st = ctx->stream;
+    const int numCU = ctx->numCU;
+    const int maxBits = PL ? 9 : 10;
+    const int idBits = std::max(1, ceilLog2((uint64_t) nTargets));
+    const int repBits = std::max(1, ceilLog2((uint64_t) std::max<uint32_t>(nReps, 1)));
+    const int wantBits = std::min(2 * maxBits, std::max(0, ceilLog2((nIn + 511) / 512)));    // ~512 records per sort bucket
+    const int allowedLocal = 62 - idBits - DiagPack<LONG>::BITS;                             // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
+    const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
+    if (sBits > 2 * maxBits) { setError("kmermatch: too many sequences for the packed rep-sort key"); return PLASSHIP_ERR_UNSUPPORTED; }
+    const int s1 = sBits <= maxBits ? sBits : (sBits + 1) / 2, s2 = sBits - s1;
+    const uint32_t nS1 = 1u << s1, nS2 = s2 ? 1u << s2 : 0u, nSort = 1u << sBits;
+    // level-1 pieces: `segs` = dense runs (first line, elements) of `in` — the group kernel's arenas, or one run of received triples;
+    // the table is built here (a few thousand entries at most)
+    std::vector<LinePiece> hp; uint64_t outLine = 0;
+    {
+        uint64_t totLines = 0; for (const auto &sg : segs) totLines += (sg.second + RPL - 1) / RPL;
+        const uint32_t PLr1 = pieceLinesFor(totLines, nS1, numCU, 8);
+        for (const auto &sg : segs) {
+            const uint64_t cnt = sg.second, lines = (cnt + RPL - 1) / RPL;
+            for (uint64_t l0 = 0; l0 < lines; l0 += PLr1) {
+                LinePiece pc; pc.in0 = sg.first + l0; pc.nLines = (uint32_t) std::min<uint64_t>(PLr1, lines - l0);
+                pc.lastValid = (l0 + pc.nLines == lines) ? (uint32_t) (cnt - (lines - 1) * RPL) : (uint32_t) RPL;
+                pc.out0 = outLine; pc.outCap = pc.nLines + nS1; pc.tagBase = 0;
+                outLine += pc.outCap; hp.push_back(pc);
+            }
+        }
+    }
+    // level 2 of a RANGE partition: representatives are not evenly spread over the id range (a contig is the representative of
+    // everything it overlaps), so a level-1 bucket is cut into pieces like any other input (hash buckets are even: one piece each)
+    const uint32_t PLr2 = s2 ? pieceLinesFor(std::max<uint64_t>(outLine, 1), nS2, numCU, 16) : 0;
+    const uint64_t maxPR2 = s2 ? std::max<uint64_t>(outLine, 1) / PLr2 + nS1 + 1 : 0;
+    const uint64_t capR1 = std::max<uint64_t>(outLine, 1), capR2 = s2 ? capR1 + maxPR2 * nS2 : 0;
+    const uint32_t nPR1 = (uint32_t) hp.size();
+    DevBuf dR1, dRTag1, dRList1, dRPieces, dRNP, dRCnt1, dRStart1, dRCur1, dR2, dRTag2, dRList2, dRPieces2, dRNP2, dRRegBeg, dRRegEnd, dRTot2, dSortBeg, dSortCnt;
+    if (dR1.alloc(capR1 * RPL * sizeof(R)) != hipSuccess || dRTag1.alloc(capR1 * 4) != hipSuccess || dRList1.alloc(capR1 * 4) != hipSuccess || dRPieces.alloc(((size_t) nPR1 + 1) * sizeof(LinePiece)) != hipSuccess ||
+        dRNP.alloc(4) != hipSuccess || dRCnt1.alloc(LP_MAXB * 4) != hipSuccess || dRStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dRCur1.alloc(LP_MAXB * 4) != hipSuccess ||
+        dSortBeg.alloc((size_t) nSort * 4) != hipSuccess || dSortCnt.alloc((size_t) nSort * 4) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+    // the piece table travels from pinned memory when it fits (no wait for the copy), else from the vector (waited for below)
+    void *hpPinned = nPR1 ? ctxPinnedTable(ctx, (size_t) nPR1 * sizeof(LinePiece)) : nullptr;
+    if (hpPinned) memcpy(hpPinned, hp.data(), (size_t) nPR1 * sizeof(LinePiece));
+    if (nPR1) PH_CHECK(hipMemcpyAsync(dRPieces.p, hpPinned ? hpPinned : (const void *) hp.data(), (size_t) nPR1 * sizeof(LinePiece), hipMemcpyHostToDevice, st));
+    else PH_CHECK(hipMemsetAsync(dRTag1.p, 0xFF, capR1 * 4, st));                       // nothing to sort: no piece will write the tag array
+    PH_CHECK(hipMemcpyAsync(dRNP.p, &nPR1, 4, hipMemcpyHostToDevice, st));
+    // grouped records arrive with many records per representative: lines that complete inside a tile are written directly (linepart.hpp)
+    static const int directLines = [] { const char *e = getenv("PLASSHIP_DIRECT_LINES"); return e ? atoi(e) : 1; }();
+    LineKey rkey; rkey.rangeBits = repBits; rkey.repBase = repBase; rkey.shift = s1 ? 64 - s1 : 63; rkey.scrambleBits = repBits;      // ranges of the bit-reversed id
+    int rc;
+    {
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = in; a.out = dR1.p; a.tags = dRTag1.as<uint32_t>(); a.pieces = dRPieces.as<LinePiece>(); a.nPieces = dRNP.as<uint32_t>(); a.nb = nS1; a.key = rkey;
+        a.direct = directLines;
+        rc = launchLinePart<NUCL, PL, KEY_RANGE, false, false>(ctx, a, std::max<uint32_t>(nPR1, 1)); if (rc) return rc;
+    }
+    if (nPR1 && !hpPinned) PH_CHECK(plasship::streamSync(st));   // hp goes out of use (async copy of a pageable host vector)
+    rc = buildLineLists(ctx, dRTag1.as<uint32_t>(), capR1, nS1, dRCnt1.as<uint32_t>(), dRStart1.as<uint32_t>(), dRCur1.as<uint32_t>(), dRList1.as<uint32_t>()); if (rc) return rc;
+    inputConsumed();                                        // the caller's input buffer is dead (stream order): it may release it
+    const void *sortRecs = dR1.p; const uint32_t *sortList = dRList1.as<uint32_t>(); uint64_t sortCap = capR1;
+    if (s2) {
+        if (dR2.alloc(capR2 * RPL * sizeof(R)) != hipSuccess || dRTag2.alloc(capR2 * 4) != hipSuccess || dRList2.alloc(capR2 * 4) != hipSuccess || dRPieces2.alloc(((size_t) maxPR2 + 1) * sizeof(LinePiece)) != hipSuccess ||
+            dRNP2.alloc(4) != hipSuccess || dRRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRRegEnd.alloc(LP_MAXB * 8) != hipSuccess || dRTot2.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, PLr2, nS2, dRPieces2.as<LinePiece>(), dRNP2.as<uint32_t>(),
+                           dRRegBeg.as<uint64_t>(), dRRegEnd.as<uint64_t>(), dRTot2.as<uint64_t>());
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = dR1.p; a.list = dRList1.as<uint32_t>(); a.out = dR2.p; a.tags = dRTag2.as<uint32_t>(); a.pieces = dRPieces2.as<LinePiece>(); a.nPieces = dRNP2.as<uint32_t>(); a.nb = nS2;
+        a.direct = directLines;
+        a.key = rkey; a.key.shift = 64 - s1 - s2;
+        rc = launchLinePart<NUCL, PL, KEY_RANGE, true, false>(ctx, a, maxPR2); if (rc) return rc;
+        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(nS1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dRTag2.as<uint32_t>(), (const uint64_t *) dRRegBeg.as<uint64_t>(),
+                           (const uint64_t *) dRRegEnd.as<uint64_t>(), nS1, nS2, dRList2.as<uint32_t>(), dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>());
+        sortRecs = dR2.p; sortList = dRList2.as<uint32_t>(); sortCap = capR2;
+    } else {
+        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>());
+    }
+    // aggregate + sort each bucket; buckets beyond the LDS capacity use HBM scratch
+    DevBuf dBigNeed, dBigOff, dBigScratch, dUnique, dScanTmp3, dSparse;
+    const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSort + 2);
+    if (dBigNeed.alloc(((size_t) nSort + 1) * 8) != hipSuccess || dBigOff.alloc(((size_t) nSort + 2) * 8) != hipSuccess || dUnique.alloc(((size_t) nSort + 1) * 4) != hipSuccess ||
+        dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess || dSparse.alloc(sortCap * RPL * sizeof(Triple)) != hipSuccess) {
+        setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE;
+    }
+    // pass 1: every bucket aggregated in LDS (no scratch); pass 2: the few buckets with more distinct triples than LDS holds
+    const AggLines aggLn{sortList, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>()};
+    const unsigned aggGrid = std::min<uint32_t>(nSort, (uint32_t) numCU * (uint32_t) tuneInt("AGGSORT", 16));
+    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true, TRIPLES>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
+                       (unsigned long long *) nullptr, (const uint64_t *) nullptr, dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) repBase, aggLn, repBits);
+    hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>());
+    if (exclusiveScanU64(st, dBigNeed.as<uint64_t>(), dBigOff.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t bigTot = 0;
+    PH_COPY_SYNC(st, &bigTot, dBigOff.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
+    PH_CHECK(hipGetLastError());
+    if (bigTot) {
+        if (dBigScratch.alloc(bigTot * 8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true, TRIPLES>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
+                           dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(), dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) repBase, aggLn, repBits);
+    }
+    // every bucket now holds its representatives' triples, each representative's contiguous and in (target, diagonal) order, but
+    // the buckets are ranges of the bit-reversed id: count the triples per representative, prefix-sum over the ids, and move every
+    // triple to its place in id order — the (rep, target, diagonal)-sorted array the run reduction walks
+    DevBuf dRepCnt, dRepPos, dRepStartLocal, dScanTmp4;
+    DevBuf &dRepStart = dRepStartOut ? *dRepStartOut : dRepStartLocal;
+    const size_t scanTmp4Bytes = exclusiveScanTmpBytes((size_t) nReps + 2);
+    if (dRepCnt.alloc(((size_t) nReps + 1) * 4) != hipSuccess || dRepPos.alloc(((size_t) nReps + 1) * 8) != hipSuccess || dRepStart.alloc(((size_t) nReps + 2) * 8) != hipSuccess ||
+        dScanTmp4.alloc(scanTmp4Bytes) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dRepCnt.p, 0, ((size_t) nReps + 1) * 4, st));
+    const unsigned runGrid = std::min<uint32_t>((nSort + 3) / 4, (uint32_t) numCU * 8);
+    hipLaunchKernelGGL(repRunsKernel, dim3(runGrid), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(),
+                       (const uint32_t *) dUnique.as<uint32_t>(), nSort, repBase, dRepCnt.as<uint32_t>(), dRepPos.as<uint64_t>());
+    if (exclusiveScanU32(st, dRepCnt.as<uint32_t>(), dRepStart.as<uint64_t>(), nReps, dScanTmp4.p, scanTmp4Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    nTriples = 0;
+    PH_COPY_SYNC(st, &nTriples, dRepStart.as<uint64_t>() + nReps, 8, hipMemcpyDeviceToHost);
+    PH_CHECK(hipGetLastError());
+    dR1.release(); dR2.release();
+    if (dOut.alloc((std::max<uint64_t>(nTriples, 1) + slackTriples) * sizeof(Triple)) != hipSuccess) { setError("kmermatch: out of device memory for the sorted triples"); return PLASSHIP_ERR_DEVICE; }
+    if (nTriples) hipLaunchKernelGGL(placeRunsKernel, dim3(runGrid), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort,
+                                     repBase, (const uint64_t *) dRepPos.as<uint64_t>(), (const uint64_t *) dRepStart.as<uint64_t>(), (Triple *) dOut.p);
+    PH_CHECK(hipGetLastError());
+    return PLASSHIP_OK;
+}
+
+static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; dst.bytes = src.bytes; src.p = nullptr; src.bytes = 0; }
+
+// extraction has filled dA (`total` record slots of this rank's sequences, sentinels in unused slots).  Buffers dA / dB hold geo.cap2
+// resp. geo.cap1 lines (single GPU) or geo.cap1 lines each (sharded run).
+// Sharded run (commOf(ctx) != nullptr; `totalAll` = slots of all ranks): the bucket geometry is that of the WHOLE run, rank r owns the
+// level-1 buckets [ceil(r nb1 / W), ceil((r+1) nb1 / W)).  Exchange 1 ships the level-1 LINES of the other ranks' buckets (gathered by
+// destination through the line list: one extra pass over this rank's records), the receiver builds a line list over what arrived and
+// runs level 2 and the group kernel exactly as a single GPU does.  Exchange 2 ships AGGREGATED (rep, target, diagonal, count) triples —
+// every rank first runs the whole rep sort on the grouped records of its own buckets — and the owner of a representative merges the
+// triples of all ranks with the same kernels (aggSortKernel<TRIPLES>).
 template <bool NUCL, bool LONG>
 static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, const LineGeo &geo, uint64_t total,
                           DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res) {
@@ -1757,16 +1931,21 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const int numCU = ctx->numCU;
+    const plasship_comm *cm = commOf(ctx);
+    const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
     Timer tm{ctx, 0};
     const int valueShift = std::max(0, keyBits - 11);         // VH_BINS = 2^11 monotone bins
     // ---- hash partition (replaces sort #1): level 1 over the slot array, level 2 over every level-1 bucket's line list ----
     tm.start(0);
+    const uint32_t bLo = cm ? (uint32_t) ownedBegin(geo.nb1, rk, W) : 0u, bHi = cm ? (uint32_t) ownedBegin(geo.nb1, rk + 1, W) : geo.nb1;
+    const uint32_t nbL = bHi - bLo;                           // level-1 buckets this rank groups (all of them on a single GPU)
     DevBuf dVHist, dMinKey, dTag1, dList1, dCnt1, dStart1, dCur1, dTag2, dList2, dPieces2, dNP2, dRegBeg, dRegEnd, dTot2, dFineBeg, dFineCnt;
-    const uint32_t nBuckets = geo.nb2 ? geo.nb1 * geo.nb2 : geo.nb1;
+    DevBuf dRx, dRxList, dRxSegs, dRxStart;                   // sharded run: received lines, their list, per-bucket list offsets
+    const uint32_t nBuckets = geo.nb2 ? nbL * geo.nb2 : nbL;
     if (dVHist.alloc(VH_BINS * 4) != hipSuccess || dMinKey.alloc(8) != hipSuccess || dTag1.alloc(geo.cap1 * 4) != hipSuccess || dList1.alloc(geo.cap1 * 4) != hipSuccess ||
         dCnt1.alloc(LP_MAXB * 4) != hipSuccess || dStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dCur1.alloc(LP_MAXB * 4) != hipSuccess ||
-        dFineBeg.alloc((size_t) nBuckets * 4) != hipSuccess || dFineCnt.alloc((size_t) nBuckets * 4) != hipSuccess ||
-        (geo.nb2 && (dTag2.alloc(geo.cap2 * 4) != hipSuccess || dList2.alloc(geo.cap2 * 4) != hipSuccess || dPieces2.alloc((geo.maxP2 + 1) * sizeof(LinePiece)) != hipSuccess ||
+        dFineBeg.alloc((size_t) std::max<uint32_t>(nBuckets, 1) * 4) != hipSuccess || dFineCnt.alloc((size_t) std::max<uint32_t>(nBuckets, 1) * 4) != hipSuccess ||
+        (geo.nb2 && (dPieces2.alloc((geo.maxP2 + 1) * sizeof(LinePiece)) != hipSuccess ||
                      dNP2.alloc(4) != hipSuccess || dRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRegEnd.alloc(LP_MAXB * 8) != hipSuccess || dTot2.alloc(8) != hipSuccess))) {
         setError("kmermatch: out of device memory for the line lists"); return PLASSHIP_ERR_DEVICE;
     }
@@ -1783,37 +1962,99 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_CHECK(hipEventRecord(ctx->ev[9], st));
     }
     int rc = buildLineLists(ctx, dTag1.as<uint32_t>(), geo.cap1, geo.nb1, dCnt1.as<uint32_t>(), dStart1.as<uint32_t>(), dCur1.as<uint32_t>(), dList1.as<uint32_t>()); if (rc) return rc;
-    void *finalRecs = dB.p, *otherRecs = dA.p; const uint32_t *finalTags = dTag1.as<uint32_t>(), *finalList = dList1.as<uint32_t>(); uint64_t finalCap = geo.cap1;
+    // what level 2 (or, with a single level, the group kernel) reads: records, their line list, the list offsets of the nbL buckets
+    void *l1Recs = dB.p; const uint32_t *l1List = dList1.as<uint32_t>(); const uint32_t *l1Start = dStart1.as<uint32_t>() + bLo; uint64_t l1Lines = geo.cap1;
+    const uint32_t *l1Tags = dTag1.as<uint32_t>();
+    uint64_t NkAll = 0;
+    if (cm) {
+        // ---- exchange 1: the lines of every level-1 bucket to the bucket's owner ----
+        std::vector<uint32_t> hStart1(geo.nb1 + 1);
+        PH_COPY_SYNC(st, hStart1.data(), dStart1.p, ((size_t) geo.nb1 + 1) * 4, hipMemcpyDeviceToHost);
+        PH_CHECK(hipGetLastError());
+        const uint64_t myLines = hStart1[geo.nb1];
+        // lines in list order = by bucket = by destination, packed into a send buffer of exactly their size (the slot array is
+        // consumed: it goes first, the receive buffer will need the room)
+        dA.release();
+        if (dA.alloc(std::max<uint64_t>(myLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the send buffer"); return PLASSHIP_ERR_DEVICE; }
+        if (myLines) hipLaunchKernelGGL(gatherLinesKernel, dim3(gridFor(myLines * (RPL * sizeof(R) / 16), 256, (unsigned) numCU * 16)), dim3(256), 0, st, (const uint4 *) dB.p, (const uint32_t *) dList1.as<uint32_t>(),
+                                        myLines, (uint32_t) (RPL * sizeof(R) / 16), (uint4 *) dA.p);
+        dB.release(); dTag1.release(); dList1.release();    // (stream order: the gather has read them before anything reuses the memory)
+        // per-bucket line counts of every rank + the records this rank extracted
+        std::vector<uint64_t> mine((size_t) geo.nb1 + 1), all(((size_t) geo.nb1 + 1) * (size_t) W);
+        for (uint32_t j = 0; j < geo.nb1; j++) mine[j] = hStart1[j + 1] - hStart1[j];
+        { unsigned long long ks[4] = {0, 0, 0, 0}; PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost); mine[geo.nb1] = ks[1] + ks[3]; }
+        rc = commAllgatherHost(ctx, mine.data(), all.data(), mine.size() * 8); if (rc) return rc;
+        std::vector<uint64_t> sendCount(W);
+        for (int r = 0; r < W; r++) { sendCount[r] = hStart1[ownedBegin(geo.nb1, r + 1, W)] - hStart1[ownedBegin(geo.nb1, r, W)]; NkAll += all[(size_t) r * mine.size() + geo.nb1]; }
+        uint64_t gotLines = 0;
+        // (room behind the received lines: the group kernel's arenas are addressed by level-2 line numbers, up to nbL * nb2 beyond)
+        rc = commAlltoallvRecords(ctx, dA.p, sendCount.data(), RPL * sizeof(R), dRx, &gotLines, (uint64_t) nbL * geo.nb2 + 1); if (rc) return rc;
+        res.exchangedRecordBytes = (myLines - sendCount[rk]) * RPL * sizeof(R);
+        PH_TRACE(st, "kmermatch: exchange 1 (level-1 lines)");
+        dA.release();
+        if (gotLines >= 0xFFFFFFFFull) { rc = PLASSHIP_ERR_UNSUPPORTED; setError("kmermatch: more than 2^32 lines on one rank"); }
+        rc = commAgreeOk(ctx, rc == 0, "kmermatch: more than 2^32 lines on one rank"); if (rc) return rc;
+        // what arrived: from every source s the lines of my buckets bLo .. bHi-1, bucket after bucket.  List: bucket-major, source-minor.
+        std::vector<RxSeg> segs((size_t) nbL * W); std::vector<uint32_t> rxStart((size_t) nbL + 1);
+        std::vector<uint64_t> srcBase(W); { uint64_t o = 0; for (int s = 0; s < W; s++) { srcBase[s] = o; for (uint32_t j = bLo; j < bHi; j++) o += all[(size_t) s * mine.size() + j]; } if (o != gotLines) { setError("kmermatch: internal error, exchanged line counts do not add up"); return PLASSHIP_ERR_DEVICE; } }
+        { uint64_t d = 0; std::vector<uint64_t> run(srcBase);
+          for (uint32_t j = 0; j < nbL; j++) { rxStart[j] = (uint32_t) d; for (int s = 0; s < W; s++) { const uint64_t c = all[(size_t) s * mine.size() + bLo + j]; segs[(size_t) j * W + s] = RxSeg{run[s], (uint32_t) c, (uint32_t) d}; run[s] += c; d += c; } }
+          rxStart[nbL] = (uint32_t) d; }
+        if (dRxList.alloc(std::max<uint64_t>(gotLines, 1) * 4) != hipSuccess || dRxSegs.alloc(std::max<size_t>(segs.size(), 1) * sizeof(RxSeg)) != hipSuccess || dRxStart.alloc(((size_t) nbL + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory for the received line list"); return PLASSHIP_ERR_DEVICE; }
+        PH_COPY_SYNC(st, dRxSegs.p, segs.data(), segs.size() * sizeof(RxSeg), hipMemcpyHostToDevice);
+        PH_COPY_SYNC(st, dRxStart.p, rxStart.data(), ((size_t) nbL + 1) * 4, hipMemcpyHostToDevice);
+        if (!segs.empty()) hipLaunchKernelGGL(rxListKernel, dim3((unsigned) std::min<size_t>(segs.size(), (size_t) numCU * 8)), dim3(256), 0, st, (const RxSeg *) dRxSegs.p, (uint32_t) segs.size(), dRxList.as<uint32_t>());
+        if (NUCL) {              // the globally smallest key (first-run quirk of the group kernel)
+            uint64_t mk = 0; PH_COPY_SYNC(st, &mk, dMinKey.p, 8, hipMemcpyDeviceToHost);
+            rc = commAllReduceMinU64(ctx, &mk, 1); if (rc) return rc;
+            PH_COPY_SYNC(st, dMinKey.p, &mk, 8, hipMemcpyHostToDevice);
+        }
+        l1Recs = dRx.p; l1List = dRxList.as<uint32_t>(); l1Start = dRxStart.as<uint32_t>(); l1Lines = gotLines; l1Tags = nullptr;
+    }
+    void *finalRecs = l1Recs; const uint32_t *finalTags = l1Tags, *finalList = l1List; uint64_t finalCap = l1Lines;
+    DevBuf dL2;                                               // sharded run: level-2 output (a single GPU writes level 2 into dA)
     res.nPart = 1;
     if (geo.nb2) {
-        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, geo.PL2, geo.nb2, dPieces2.as<LinePiece>(), dNP2.as<uint32_t>(),
+        const uint64_t cap2 = cm ? l1Lines + (uint64_t) nbL * geo.nb2 : geo.cap2;
+        void *l2Out = dA.p;
+        if (cm) { if (dL2.alloc(std::max<uint64_t>(cap2, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; } l2Out = dL2.p; }
+        if (dTag2.alloc(std::max<uint64_t>(cap2, 1) * 4) != hipSuccess || dList2.alloc(std::max<uint64_t>(cap2, 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory for the line lists"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, l1Start, nbL, geo.PL2, geo.nb2, dPieces2.as<LinePiece>(), dNP2.as<uint32_t>(),
                            dRegBeg.as<uint64_t>(), dRegEnd.as<uint64_t>(), dTot2.as<uint64_t>());
         LinePartArgs a; memset(&a, 0, sizeof(a));
-        a.in = dB.p; a.list = dList1.as<uint32_t>(); a.out = dA.p; a.tags = dTag2.as<uint32_t>(); a.pieces = dPieces2.as<LinePiece>(); a.nPieces = dNP2.as<uint32_t>(); a.nb = geo.nb2;
+        a.in = l1Recs; a.list = l1List; a.out = l2Out; a.tags = dTag2.as<uint32_t>(); a.pieces = dPieces2.as<LinePiece>(); a.nPieces = dNP2.as<uint32_t>(); a.nb = geo.nb2;
         a.key.shift = 64 - geo.b1 - geo.b2;
         PH_CHECK(hipEventRecord(ctx->ev[10], st));
         rc = launchLinePart<NUCL, LONG, KEY_HASH, true, false>(ctx, a, geo.maxP2); if (rc) return rc;
         PH_CHECK(hipEventRecord(ctx->ev[11], st));
-        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(geo.nb1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dTag2.as<uint32_t>(), (const uint64_t *) dRegBeg.as<uint64_t>(),
-                           (const uint64_t *) dRegEnd.as<uint64_t>(), geo.nb1, geo.nb2, dList2.as<uint32_t>(), dFineBeg.as<uint32_t>(), dFineCnt.as<uint32_t>());
-        finalRecs = dA.p; otherRecs = dB.p; finalTags = dTag2.as<uint32_t>(); finalList = dList2.as<uint32_t>(); finalCap = geo.cap2;
+        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(nbL, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dTag2.as<uint32_t>(), (const uint64_t *) dRegBeg.as<uint64_t>(),
+                           (const uint64_t *) dRegEnd.as<uint64_t>(), nbL, geo.nb2, dList2.as<uint32_t>(), dFineBeg.as<uint32_t>(), dFineCnt.as<uint32_t>());
+        finalRecs = l2Out; finalTags = dTag2.as<uint32_t>(); finalList = dList2.as<uint32_t>(); finalCap = cap2;
         res.nPart = 2;
     } else {
-        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, dFineBeg.as<uint32_t>(), dFineCnt.as<uint32_t>());
+        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, l1Start, nbL, dFineBeg.as<uint32_t>(), dFineCnt.as<uint32_t>());
     }
     res.msSort1 = tm.stop(1);
     PH_TRACE(st, "kmermatch: hash partition (line store)");
     PH_CHECK(hipGetLastError());
 
-    // ---- assignGroup ----
+    // ---- assignGroup: every workgroup writes its grouped records into an arena that begins where its first bucket's lines begin ----
     tm.start(0);
-    const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 6));
-    const uint32_t bpb = (nBuckets + gBlocks - 1) / gBlocks;
-    const uint32_t gGrid = (nBuckets + bpb - 1) / bpb;
+    // the arenas: the buffer level 2 read (dead now).  single GPU: dB (level 1's output) when there are two levels, else dA (the slot
+    // array); sharded run: the receive buffer when there are two levels, else a buffer of its own
+    DevBuf dArena;
+    void *arenaBuf;
+    if (cm) {
+        if (geo.nb2) arenaBuf = dRx.p;
+        else { if (dArena.alloc(std::max<uint64_t>(finalCap, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; } arenaBuf = dArena.p; }
+    } else arenaBuf = geo.nb2 ? dB.p : dA.p;
+    const uint32_t gBlocks = std::max<uint32_t>(1, std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 6)));
+    const uint32_t bpb = (std::max<uint32_t>(nBuckets, 1) + gBlocks - 1) / gBlocks;
+    const uint32_t gGrid = (std::max<uint32_t>(nBuckets, 1) + bpb - 1) / bpb;
     DevBuf dOutCnt, dArenaStart, dMaxRT, dLastRun;
     if (dOutCnt.alloc((size_t) gGrid * 8) != hipSuccess || dArenaStart.alloc((size_t) gGrid * 8) != hipSuccess || dMaxRT.alloc(8) != hipSuccess || dLastRun.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     GroupArgs ga; memset(&ga, 0, sizeof(ga));
-    ga.in = finalRecs; ga.out = otherRecs; ga.list = finalList; ga.lineBeg = dFineBeg.as<uint32_t>(); ga.lineCnt = dFineCnt.as<uint32_t>();
+    ga.in = finalRecs; ga.out = arenaBuf; ga.list = finalList; ga.lineBeg = dFineBeg.as<uint32_t>(); ga.lineCnt = dFineCnt.as<uint32_t>();
     ga.nBuckets = nBuckets; ga.bucketsPerBlock = bpb; ga.outCount = dOutCnt.as<uint64_t>();
     PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
     ga.maxRepTarget = dMaxRT.as<unsigned long long>();
@@ -1821,11 +2062,13 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     // positions per bucket (sentinel padding included) decide the workgroup shape of the 16-byte-record kernel
     const uint64_t avgPos = finalCap * RPL / std::max<uint32_t>(nBuckets, 1);
     const bool wideGroup = !LONG && (getenv("PLASSHIP_GROUP_WIDE") ? atoi(getenv("PLASSHIP_GROUP_WIDE")) != 0 : avgPos > 1600);
-    if constexpr (LONG) hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+    if (nBuckets == 0) PH_CHECK(hipMemsetAsync(dOutCnt.p, 0, (size_t) gGrid * 8, st));
+    else if constexpr (LONG) hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     else if (wideGroup && tuneInt("GROUP_WPE", 4) == 4) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 4>), dim3(gGrid), dim3(512), 0, st, ga);
     else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 2>), dim3(gGrid), dim3(512), 0, st, ga);
     else hipLaunchKernelGGL((groupLinesKernel<NUCL, GR_BLOCK, GR_HT, 3>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-    hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
+    if (nBuckets) hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
+    else PH_CHECK(hipMemsetAsync(dArenaStart.p, 0, (size_t) gGrid * 8, st));
     std::vector<uint64_t> hOutCnt(gGrid), hArena(gGrid);
     unsigned long long hLastRun[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
     hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
@@ -1836,10 +2079,30 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipMemcpyAsync(ks, dKStats.p, 32, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
-    uint64_t Nm = 0;
-    for (uint32_t j = 0; j < gGrid; j++) Nm += hOutCnt[j];
-    const uint64_t Nk = ks[1] + ks[3];                       // records the extraction kernels wrote (sentinels excluded)
-    res.Nk = Nk; res.Nm = Nm;
+    uint64_t NmLocal = 0;
+    for (uint32_t j = 0; j < gGrid; j++) NmLocal += hOutCnt[j];
+    uint64_t Nm = NmLocal;
+    const uint64_t NkLocal = ks[1] + ks[3];                  // records the extraction kernels of this rank wrote (sentinels excluded)
+    const uint64_t Nk = cm ? NkAll : NkLocal;                // ... and of the whole run
+    std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
+    if (cm) {
+        // the stale-record check below is a property of the WHOLE run: N_m, the last (rep, target) run and the value histogram are
+        // reduced over the ranks; every rank then takes the same decisions (and the same collectives)
+        std::vector<uint64_t> mine(2 + (size_t) VH_BINS), all((2 + (size_t) VH_BINS) * (size_t) W);
+        mine[0] = NmLocal; mine[1] = hLastRun[0]; std::copy(hVHistG.begin(), hVHistG.end(), mine.begin() + 2);
+        rc = commAllgatherHost(ctx, mine.data(), all.data(), mine.size() * 8); if (rc) return rc;
+        uint64_t mx = 0; Nm = 0; std::fill(hVHistG.begin(), hVHistG.end(), 0);
+        for (int r = 0; r < W; r++) {
+            const uint64_t *row = all.data() + (size_t) r * mine.size();
+            Nm += row[0]; mx = std::max(mx, row[1]);
+            for (uint32_t b = 0; b < VH_BINS; b++) hVHistG[b] += row[2 + b];
+        }
+        PH_CHECK(hipMemcpyAsync(dMaxRT.p, &mx, 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
+        PH_COPY_SYNC(st, hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost);
+    }
+    res.Nk = NkLocal;                                         // sharded run: the records THIS rank extracted (the ranks' sum is the run's N_k)
+    res.Nm = NmLocal;
     res.msGroup = tm.stop(1);
     PH_TRACE(st, "kmermatch: group (line store)");
 
@@ -1873,7 +2136,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         bool mayHit = false;
         if (m) {
             std::vector<uint64_t> cum(VH_BINS + 1, 0);
-            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + hVHist[b];
+            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + hVHistG[b];
             for (uint32_t j = 0; j < m && !mayHit; j++) { const uint32_t b = valueBin<NUCL>(trec[j].kmer, valueShift); mayHit = Nm >= cum[b] && Nm < cum[b + 1]; }
         }
         if (m && mayHit) {
@@ -1883,6 +2146,10 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(plasship::streamSync(st));
+            if (cm) {            // every rank counted the records of its own buckets: the sort-#1 ranks are the sums
+                static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
+                rc = commAllReduceSumU64(ctx, reinterpret_cast<uint64_t *>(diff.data()), diff.size()); if (rc) return rc;
+            }
             unsigned long long rank = 0, expect = Nm;
             for (uint32_t j = 0; j < m; j++) {
                 rank += diff[j];                         // records strictly before trec[j] in sort-#1 order
@@ -1895,117 +2162,36 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
 
     // ---- sort #2: range partition of the grouped records by rep id over the line store + aggregation / sort per bucket ----
     tm.start(0);
-    // the hash-bucketed records are dead now: the group kernel's arenas live in `otherRecs`; free the other buffer for the rep side
-    (finalRecs == dA.p ? dA : dB).release();
-    dTag1.release(); dList1.release(); dTag2.release(); dList2.release();
-    const int maxBits = LONG ? 9 : 10;
-    const int idBits = std::max(1, ceilLog2((uint64_t) N));
-    const int repBits = idBits;
-    const int wantBits = std::min(2 * maxBits, std::max(0, ceilLog2((Nm + 511) / 512)));    // ~512 records per sort bucket
-    const int allowedLocal = 62 - idBits - DiagPack<LONG>::BITS;                             // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
-    const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
-    if (sBits > 2 * maxBits) { setError("kmermatch: too many sequences for the packed rep-sort key"); return PLASSHIP_ERR_UNSUPPORTED; }
-    const int s1 = sBits <= maxBits ? sBits : (sBits + 1) / 2, s2 = sBits - s1;
-    const uint32_t nS1 = 1u << s1, nS2 = s2 ? 1u << s2 : 0u, nSort = 1u << sBits;
-    // level-1 pieces: the arenas are dense segments; the table is built here (a few thousand entries at most)
-    uint64_t maxLinesSeg = 0, totLines = 0;
-    for (uint32_t j = 0; j < gGrid; j++) { const uint64_t l = (hOutCnt[j] + RPL - 1) / RPL; maxLinesSeg = std::max(maxLinesSeg, l); totLines += l; }
-    const uint32_t PLr1 = pieceLinesFor(totLines, nS1, numCU, 8);
-    std::vector<LinePiece> hp; uint64_t outLine = 0;
-    for (uint32_t j = 0; j < gGrid; j++) {
-        const uint64_t cnt = hOutCnt[j], lines = (cnt + RPL - 1) / RPL;
-        for (uint64_t l0 = 0; l0 < lines; l0 += PLr1) {
-            LinePiece pc; pc.in0 = hArena[j] / RPL + l0; pc.nLines = (uint32_t) std::min<uint64_t>(PLr1, lines - l0);
-            pc.lastValid = (l0 + pc.nLines == lines) ? (uint32_t) (cnt - (lines - 1) * RPL) : (uint32_t) RPL;
-            pc.out0 = outLine; pc.outCap = pc.nLines + nS1; pc.tagBase = 0;
-            outLine += pc.outCap; hp.push_back(pc);
-        }
-    }
-    // level 2 of a RANGE partition: representatives are not evenly spread over the id range (a contig is the representative of
-    // everything it overlaps), so a level-1 bucket is cut into pieces like any other input (hash buckets are even: one piece each)
-    const uint32_t PLr2 = s2 ? pieceLinesFor(std::max<uint64_t>(outLine, 1), nS2, numCU, 16) : 0;
-    const uint64_t maxPR2 = s2 ? std::max<uint64_t>(outLine, 1) / PLr2 + nS1 + 1 : 0;
-    const uint64_t capR1 = std::max<uint64_t>(outLine, 1), capR2 = s2 ? capR1 + maxPR2 * nS2 : 0;
-    const uint32_t nPR1 = (uint32_t) hp.size();
-    DevBuf dR1, dRTag1, dRList1, dRPieces, dRNP, dRCnt1, dRStart1, dRCur1, dR2, dRTag2, dRList2, dRPieces2, dRNP2, dRRegBeg, dRRegEnd, dRTot2, dSortBeg, dSortCnt;
-    if (dR1.alloc(capR1 * RPL * sizeof(R)) != hipSuccess || dRTag1.alloc(capR1 * 4) != hipSuccess || dRList1.alloc(capR1 * 4) != hipSuccess || dRPieces.alloc(((size_t) nPR1 + 1) * sizeof(LinePiece)) != hipSuccess ||
-        dRNP.alloc(4) != hipSuccess || dRCnt1.alloc(LP_MAXB * 4) != hipSuccess || dRStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dRCur1.alloc(LP_MAXB * 4) != hipSuccess ||
-        dSortBeg.alloc((size_t) nSort * 4) != hipSuccess || dSortCnt.alloc((size_t) nSort * 4) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-    // the piece table travels from pinned memory when it fits (no wait for the copy), else from the vector (waited for below)
-    void *hpPinned = nPR1 ? ctxPinnedTable(ctx, (size_t) nPR1 * sizeof(LinePiece)) : nullptr;
-    if (hpPinned) memcpy(hpPinned, hp.data(), (size_t) nPR1 * sizeof(LinePiece));
-    if (nPR1) PH_CHECK(hipMemcpyAsync(dRPieces.p, hpPinned ? hpPinned : (const void *) hp.data(), (size_t) nPR1 * sizeof(LinePiece), hipMemcpyHostToDevice, st));
-    else PH_CHECK(hipMemsetAsync(dRTag1.p, 0xFF, capR1 * 4, st));                       // nothing grouped: no piece will write the tag array
-    PH_CHECK(hipMemcpyAsync(dRNP.p, &nPR1, 4, hipMemcpyHostToDevice, st));
-    // grouped records arrive with many records per representative: lines that complete inside a tile are written directly (linepart.hpp)
-    static const int directLines = [] { const char *e = getenv("PLASSHIP_DIRECT_LINES"); return e ? atoi(e) : 1; }();
-    LineKey rkey; rkey.rangeBits = repBits; rkey.repBase = 0; rkey.shift = s1 ? 64 - s1 : 63; rkey.scrambleBits = idBits;      // ranges of the bit-reversed id
-    {
-        LinePartArgs a; memset(&a, 0, sizeof(a));
-        a.in = otherRecs; a.out = dR1.p; a.tags = dRTag1.as<uint32_t>(); a.pieces = dRPieces.as<LinePiece>(); a.nPieces = dRNP.as<uint32_t>(); a.nb = nS1; a.key = rkey;
-        a.direct = directLines;
-        rc = launchLinePart<NUCL, LONG, KEY_RANGE, false, false>(ctx, a, std::max<uint32_t>(nPR1, 1)); if (rc) return rc;
-    }
-    if (nPR1 && !hpPinned) PH_CHECK(plasship::streamSync(st));   // hp goes out of use (async copy of a pageable host vector)
-    rc = buildLineLists(ctx, dRTag1.as<uint32_t>(), capR1, nS1, dRCnt1.as<uint32_t>(), dRStart1.as<uint32_t>(), dRCur1.as<uint32_t>(), dRList1.as<uint32_t>()); if (rc) return rc;
-    (otherRecs == dA.p ? dA : dB).release();               // the arenas are consumed
-    void *sortRecs = dR1.p; const uint32_t *sortList = dRList1.as<uint32_t>(); uint64_t sortCap = capR1;
-    if (s2) {
-        if (dR2.alloc(capR2 * RPL * sizeof(R)) != hipSuccess || dRTag2.alloc(capR2 * 4) != hipSuccess || dRList2.alloc(capR2 * 4) != hipSuccess || dRPieces2.alloc(((size_t) maxPR2 + 1) * sizeof(LinePiece)) != hipSuccess ||
-            dRNP2.alloc(4) != hipSuccess || dRRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRRegEnd.alloc(LP_MAXB * 8) != hipSuccess || dRTot2.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, PLr2, nS2, dRPieces2.as<LinePiece>(), dRNP2.as<uint32_t>(),
-                           dRRegBeg.as<uint64_t>(), dRRegEnd.as<uint64_t>(), dRTot2.as<uint64_t>());
-        LinePartArgs a; memset(&a, 0, sizeof(a));
-        a.in = dR1.p; a.list = dRList1.as<uint32_t>(); a.out = dR2.p; a.tags = dRTag2.as<uint32_t>(); a.pieces = dRPieces2.as<LinePiece>(); a.nPieces = dRNP2.as<uint32_t>(); a.nb = nS2;
-        a.direct = directLines;
-        a.key = rkey; a.key.shift = 64 - s1 - s2;
-        rc = launchLinePart<NUCL, LONG, KEY_RANGE, true, false>(ctx, a, maxPR2); if (rc) return rc;
-        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(nS1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) dRTag2.as<uint32_t>(), (const uint64_t *) dRRegBeg.as<uint64_t>(),
-                           (const uint64_t *) dRRegEnd.as<uint64_t>(), nS1, nS2, dRList2.as<uint32_t>(), dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>());
-        sortRecs = dR2.p; sortList = dRList2.as<uint32_t>(); sortCap = capR2;
-    } else {
-        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, (const uint32_t *) dRStart1.as<uint32_t>(), nS1, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>());
-    }
-    // aggregate + sort each bucket; buckets beyond the LDS capacity use HBM scratch
-    DevBuf dBigNeed, dBigOff, dBigScratch, dUnique, dTripleStart, dScanTmp3, dSparse;
-    const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSort + 2);
-    if (dBigNeed.alloc(((size_t) nSort + 1) * 8) != hipSuccess || dBigOff.alloc(((size_t) nSort + 2) * 8) != hipSuccess || dUnique.alloc(((size_t) nSort + 1) * 4) != hipSuccess ||
-        dTripleStart.alloc(((size_t) nSort + 2) * 8) != hipSuccess || dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess || dSparse.alloc(sortCap * RPL * sizeof(Triple)) != hipSuccess) {
-        setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE;
-    }
-    // pass 1: every bucket aggregated in LDS (no scratch); pass 2: the few buckets with more distinct triples than LDS holds
-    const AggLines aggLn{sortList, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>()};
-    const unsigned aggGrid = std::min<uint32_t>(nSort, (uint32_t) numCU * (uint32_t) tuneInt("AGGSORT", 16));
-    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
-                       (unsigned long long *) nullptr, (const uint64_t *) nullptr, dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn, idBits);
-    hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>());
-    if (exclusiveScanU64(st, dBigNeed.as<uint64_t>(), dBigOff.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t bigTot = 0;
-    PH_COPY_SYNC(st, &bigTot, dBigOff.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
-    PH_CHECK(hipGetLastError());
-    if (bigTot) {
-        if (dBigScratch.alloc(bigTot * 8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, (const void *) sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
-                           dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(), dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, aggLn, idBits);
-    }
-    // every bucket now holds its representatives' triples, each representative's contiguous and in (target, diagonal) order, but
-    // the buckets are ranges of the bit-reversed id: count the triples per representative, prefix-sum over the ids, and move every
-    // run to its place in id order — the globally (rep, target, diagonal)-sorted array the run reduction walks
-    DevBuf dRepCnt, dRepPos, dRepStart, dScanTmp4;
-    const size_t scanTmp4Bytes = exclusiveScanTmpBytes((size_t) N + 2);
-    if (dRepCnt.alloc(((size_t) N + 1) * 4) != hipSuccess || dRepPos.alloc(((size_t) N + 1) * 8) != hipSuccess || dRepStart.alloc(((size_t) N + 2) * 8) != hipSuccess ||
-        dScanTmp4.alloc(scanTmp4Bytes) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(dRepCnt.p, 0, ((size_t) N + 1) * 4, st));
-    hipLaunchKernelGGL(repRunsKernel, dim3(std::min<uint32_t>((nSort + 3) / 4, (uint32_t) numCU * 8)), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(),
-                       (const uint32_t *) dUnique.as<uint32_t>(), nSort, dRepCnt.as<uint32_t>(), dRepPos.as<uint64_t>());
-    if (exclusiveScanU32(st, dRepCnt.as<uint32_t>(), dRepStart.as<uint64_t>(), N, dScanTmp4.p, scanTmp4Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t nTriples = 0;
-    PH_COPY_SYNC(st, &nTriples, dRepStart.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost);
-    PH_CHECK(hipGetLastError());
-    dR1.release(); dR2.release();
-    if (dA.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(Triple)) != hipSuccess) { setError("kmermatch: out of device memory for the sorted triples"); return PLASSHIP_ERR_DEVICE; }
-    if (N) hipLaunchKernelGGL(placeRunsKernel, dim3(gridFor(N, 256, (unsigned) numCU * 32)), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dRepCnt.as<uint32_t>(),
-                              (const uint64_t *) dRepPos.as<uint64_t>(), (const uint64_t *) dRepStart.as<uint64_t>(), N, (Triple *) dA.p);
+    // the hash-bucketed records are dead now (the group kernel's arenas live in another buffer): free them for the rep side
+    if (cm) { dL2.release(); if (!geo.nb2) dRx.release(); }
+    else (finalRecs == dA.p ? dA : dB).release();
+    dTag1.release(); dList1.release(); dTag2.release(); dList2.release(); dRxList.release();
+    std::vector<std::pair<uint64_t, uint64_t>> arenas(gGrid);                 // the arenas are dense segments: (first line, records)
+    for (uint32_t j = 0; j < gGrid; j++) arenas[j] = std::make_pair(hArena[j] / RPL, hOutCnt[j]);
+    DevBuf dTriples, dRepStart; uint64_t nTriples = 0;
+    auto arenasConsumed = [&]() { if (cm) { if (geo.nb2) dRx.release(); else dArena.release(); } else (arenaBuf == dA.p ? dA : dB).release(); };
+    rc = repSortLines<NUCL, LONG, false>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, cm ? &dRepStart : nullptr);
+    if (rc) return rc;
+    if (cm) {
+        // ---- exchange 2: every representative's aggregated triples to the representative's owner (contiguous id ranges: the triples
+        //      are in id order, so a rank's share is one run), merged there with the triples of the other ranks ----
+        DevBuf dOB; std::vector<uint64_t> ob((size_t) W + 1), sendCount(W);
+        if (dOB.alloc(((size_t) W + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(ownerBoundsKernel, dim3(1), dim3(256), 0, st, (const uint64_t *) dRepStart.as<uint64_t>(), (uint64_t) N, W, dOB.as<uint64_t>());
+        PH_COPY_SYNC(st, ob.data(), dOB.p, ((size_t) W + 1) * 8, hipMemcpyDeviceToHost);
+        for (int r = 0; r < W; r++) sendCount[r] = ob[r + 1] - ob[r];
+        DevBuf dRxT; uint64_t gotT = 0;
+        rc = commAlltoallvRecords(ctx, dTriples.p, sendCount.data(), sizeof(Triple), dRxT, &gotT, RPL); if (rc) return rc;
+        res.exchangedTripleBytes = (nTriples - sendCount[rk]) * sizeof(Triple);
+        PH_TRACE(st, "kmermatch: exchange 2 (aggregated triples)");
+        dTriples.release(); dRepStart.release();
+        const uint32_t repBase = (uint32_t) ownedBegin(N, rk, W), ownedN = (uint32_t) (ownedBegin(N, rk + 1, W) - repBase);
+        DevBuf dMerged; uint64_t nMerged = 0;
+        rc = repSortLines<NUCL, LONG, true>(ctx, dRxT.p, {std::make_pair((uint64_t) 0, gotT)}, gotT, ownedN, repBase, N, HALO_SLACK, [&]() { dRxT.release(); }, dMerged, nMerged, nullptr);
+        if (rc) return rc;
+        moveBuf(dA, dMerged);                                 // the caller's dA owns the result
+        nTriples = nMerged;
+    } else moveBuf(dA, dTriples);
     res.msSort2 = tm.stop(1);
     PH_TRACE(st, "kmermatch: rep sort (line store)");
     PH_CHECK(hipGetLastError());
@@ -2014,7 +2200,6 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     return PLASSHIP_OK;
 }
 
-constexpr uint64_t HALO_SLACK = 1u << 16;
 
 // ---- best diagonal per (rep, target) run over the sorted weighted triples, CSR of the candidate list (kmermatcher.cpp:809-924) ----
 // `cur`: nTriples triples in (rep, target, diagonal) order (sharded run: room for HALO_SLACK more behind them)
@@ -2168,7 +2353,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // it, and owns the representatives / queries [repBase, repBase + ownedN)
     const plasship_comm *cm = commOf(ctx);
     const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
-    const uint64_t repBase = ownedBegin(N, rk, W);
 
     // ---- slot bounds + offsets ----
     DevBuf dBound, dSlotOff, dScanTmp;
@@ -2196,13 +2380,15 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const uint32_t nMine = sHi - sLo;
 
     DevBuf dA, dB;   // ping-pong record arrays
-    DevBuf dRxA, dRxB, dRxC, dRxD;   // sharded run: what the two exchanges deliver (and their ping-pong partners)
     // single GPU: the line-store partition (linepart.hpp; PLASSHIP_LEGACY_PARTITION=1 keeps the dense two-pass partition the
     // sharded run uses).  Its record buffers hold whole lines plus one partial line per bucket and piece.
     static const bool legacyPartition = getenv("PLASSHIP_LEGACY_PARTITION") != nullptr;
-    const bool useLines = !cm && !legacyPartition;
-    const LineGeo geo = useLines ? lineGeometry(total, LONG, ctx->numCU) : LineGeo();
-    const uint64_t recCap = useLines ? std::max<uint64_t>(total, (uint64_t) RPL * std::max(geo.cap1, geo.cap2)) : std::max<uint64_t>(total, 1);
+    const bool useLines = cm || !legacyPartition;            // (the dense partition below is a single-GPU cross-check path)
+    if (cm && W > 1024) { setError("kmermatch: more than 1024 ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
+    const LineGeo geo = useLines ? lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W) : LineGeo();
+    // single GPU: both buffers serve level 1 and level 2 (and the group kernel's arenas); sharded run: the slot array / level-1 output,
+    // and the packed send buffer of exchange 1 (at most cap1 lines)
+    const uint64_t recCap = useLines ? std::max<uint64_t>(total, (uint64_t) RPL * (cm ? geo.cap1 : std::max(geo.cap1, geo.cap2))) : std::max<uint64_t>(total, 1);
     if (dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess) {
         setError("kmermatch: out of device memory for the k-mer record arrays (" + std::to_string(2 * recCap * sizeof(R)) + " bytes)"); return PLASSHIP_ERR_DEVICE;
     }
@@ -2338,6 +2524,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         *out = holderL.release();
         return PLASSHIP_OK;
     }
+    // ---- the dense partition (PLASSHIP_LEGACY_PARTITION=1, single GPU only): round 1's histogram + scatter passes and the three-phase
+    //      group kernel, kept as an independent implementation the line-store path is cross-checked against (tests/test_gpu_large.py) ----
     // ---- hash partition (replaces sort #1) ----
     tm.start(0);
     // value histogram for the stale-record check: bins of the k-mer value (real k-mers need keyBits bits)
@@ -2350,60 +2538,15 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (NUCL) keyBits = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
     const int valueShift = std::max(0, keyBits - 11);      // VH_BINS = 2^11 monotone bins
     void *bufA = dA.p, *bufB = dB.p;        // level 1 reads bufA (partTotal slots), writes bufB
-    uint64_t partTotal = total, NkAll = 0;  // NkAll: records of the whole run (sharded)
-    // Sharded run, W a power of two, two partition levels: level 1 doubles as the partition by owner.  With the bucket geometry
-    // of the WHOLE run (same on every rank) the top log2(W) bits of a level-1 bucket name its owner, so a rank's level-1 output
-    // is already laid out by destination; the receiver runs level 2 over the W source runs of each of its level-1 buckets
-    // (PartArgs::segMod).  Otherwise (W not a power of two, or a single level) a separate pass partitions by owner first.
-    const int lw = ceilLog2((uint64_t) W);
-    const int totalBitsAll = std::max(0, ceilLog2((totalAll + 1535) / 1536));
-    const bool fold = cm && (1 << lw) == W && totalBitsAll > 11 && totalBitsAll - 11 <= 11 && lw <= 11;
-    if (cm && !fold) {
-        // exchange 1: records -> owner of the k-mer's hash bucket.  One partition pass by owner (it also drops the sentinels
-        // and takes the value histogram / minimum key the single-GPU level 1 takes), then an all-to-all(v) of the W runs.
-        const int ob = ceilLog2((uint64_t) W); const uint32_t nbO = 1u << ob;
-        DevBuf dCntO, dStartO, dCurO;
-        if (dCntO.alloc((size_t) nbO * 4) != hipSuccess || dStartO.alloc(((size_t) nbO + 1) * 8) != hipSuccess || dCurO.alloc((size_t) nbO * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        PH_CHECK(hipMemsetAsync(dCntO.p, 0, (size_t) nbO * 4, st));
-        PartArgs po; memset(&po, 0, sizeof(po));
-        po.in = dA.p; po.out = dB.p; po.segStart = dSeg0Start.as<uint64_t>(); po.segCount = dSeg0Cnt.as<uint64_t>(); po.count = dCntO.as<uint32_t>();
-        po.cursor = dCurO.as<unsigned long long>(); po.bits = ob; po.dropSentinels = 1; po.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
-        po.valueHist = dVHist.as<uint32_t>(); po.valueShift = valueShift; po.ownerW = (uint32_t) W; po.ownerN = N;
-        const unsigned tilesO = (unsigned) std::max<uint64_t>(1, (total + PT_TILE - 1) / PT_TILE);
-        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_OWNER_HASH>), dim3(tilesO, 1), dim3(PT_BLOCK), 0, st, po);
-        if (exclusiveScanU32(st, dCntO.as<uint32_t>(), dStartO.as<uint64_t>(), nbO, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(copyU64Kernel, dim3(1), dim3(256), 0, st, dStartO.as<uint64_t>(), dCurO.as<unsigned long long>(), (uint64_t) nbO);
-        po.minKey = nullptr; po.valueHist = nullptr;
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_OWNER_HASH>), dim3(tilesO, 1), dim3(PT_BLOCK), (size_t) 12 << po.bits, st, po);
-        std::vector<uint64_t> hStartO(nbO + 1), sendCount(W);
-        PH_COPY_SYNC(st, hStartO.data(), dStartO.p, ((size_t) nbO + 1) * 8, hipMemcpyDeviceToHost);
-        PH_CHECK(hipGetLastError());
-        for (int r = 0; r < W; r++) sendCount[r] = hStartO[r + 1] - hStartO[r];
-        PH_TRACE(st, "kmermatch: owner partition of the k-mer records");
-        traceBadIds<LONG>(ctx, "kmermatch: owner-partitioned records", dB.p, hStartO[nbO], N);
-        uint64_t got = 0;
-        int rc = commAlltoallvRecords(ctx, dB.p, sendCount.data(), sizeof(R), dRxA, &got, 0, &NkAll);
-        if (rc) return rc;
-        PH_TRACE(st, "kmermatch: exchange 1");
-        traceBadIds<LONG>(ctx, "kmermatch: received records", dRxA.p, got, N);
-        dA.release(); dB.release();
-        if (dRxB.alloc(std::max<uint64_t>(got, 1) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; }
-        if (NUCL) {              // the globally smallest key (first-run quirk of the group kernel)
-            uint64_t mk = 0; PH_COPY_SYNC(st, &mk, dMinKey.p, 8, hipMemcpyDeviceToHost);
-            rc = commAllReduceMinU64(ctx, &mk, 1); if (rc) return rc;
-            PH_COPY_SYNC(st, dMinKey.p, &mk, 8, hipMemcpyHostToDevice);
-        }
-        bufA = dRxA.p; bufB = dRxB.p; partTotal = got;
-        PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &partTotal, 8, hipMemcpyHostToDevice, st));
-    }
-    const int totalBits = fold ? totalBitsAll : std::max(0, ceilLog2((partTotal + 1535) / 1536));   // ~1000-1500 records per final bucket: the group kernel
+    uint64_t partTotal = total;
+    const int totalBits = std::max(0, ceilLog2((partTotal + 1535) / 1536));   // ~1000-1500 records per final bucket: the group kernel
                                                                                                     // pays a fixed number of block barriers per bucket
     // coarse level first: few wide buckets => every tile writes long contiguous runs; the fine level then scatters inside a
     // bucket that fits the L2 / Infinity Cache
     const int b2w = (totalBits > 11) ? 11 : 0;
-    const int b1 = fold ? std::max(lw, totalBits - 11) : std::min(totalBits - b2w, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
+    const int b1 = std::min(totalBits - b2w, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
     const uint32_t nB1 = 1u << b1, nB = 1u << (b1 + b2);
-    const uint32_t nbL = fold ? (nB1 >> lw) : nB1;              // level-1 buckets this rank owns (all of them on a single GPU)
+    const uint32_t nbL = nB1;
     DevBuf dCnt1, dStart1, dCur1, dCnt2, dStart2, dCur2, dSegCnt1;
     if (dCnt1.alloc((size_t) nB1 * 4) != hipSuccess || dStart1.alloc(((size_t) nB1 + 1) * 8) != hipSuccess || dCur1.alloc((size_t) nB1 * 8) != hipSuccess ||
         dSegCnt1.alloc((size_t) nB1 * 8) != hipSuccess ||
@@ -2414,11 +2557,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PartArgs pa; memset(&pa, 0, sizeof(pa));
     pa.in = bufA; pa.out = bufB; pa.segStart = dSeg0Start.as<uint64_t>(); pa.segCount = dSeg0Cnt.as<uint64_t>(); pa.count = dCnt1.as<uint32_t>();
     pa.cursor = dCur1.as<unsigned long long>(); pa.shift = 64 - b1; pa.bits = b1; pa.rangeBits = 0;
-    // the owner pass of a sharded run has already dropped the sentinels and taken the histogram and the minimum key
-    const bool ownerPassDone = cm && !fold;
-    pa.dropSentinels = ownerPassDone ? 0 : 1; pa.minKey = (NUCL && !ownerPassDone) ? dMinKey.as<unsigned long long>() : nullptr;
+    pa.dropSentinels = 1; pa.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
     if (b1 == 0) pa.shift = 63;   // single bucket: (key >> 63) & 0 == 0
-    pa.valueHist = ownerPassDone ? nullptr : dVHist.as<uint32_t>(); pa.valueShift = valueShift;
+    pa.valueHist = dVHist.as<uint32_t>(); pa.valueShift = valueShift;
     const unsigned tiles0 = (unsigned) std::max<uint64_t>(1, (partTotal + PT_TILE - 1) / PT_TILE);
     hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
     if (exclusiveScanU32(st, dCnt1.as<uint32_t>(), dStart1.as<uint64_t>(), nB1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
@@ -2440,40 +2581,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     uint32_t l2Segs = nB1, l2SegMod = 0;
     uint64_t maxSeg = 0; for (uint32_t i = 0; i < nB1; i++) maxSeg = std::max(maxSeg, hStart1[i + 1] - hStart1[i]);
     DevBuf dSegS, dSegC;
-    if (fold) {
-        // exchange 1 of the folded path: the level-1 output is laid out by destination already
-        std::vector<uint64_t> sendCount(W), myCnt(nB1), allCnt((size_t) W * nB1);
-        for (int r = 0; r < W; r++) sendCount[r] = hStart1[(size_t) (r + 1) * nbL] - hStart1[(size_t) r * nbL];
-        for (uint32_t i = 0; i < nB1; i++) myCnt[i] = hStart1[i + 1] - hStart1[i];
-        int rc = commAllgatherHost(ctx, myCnt.data(), allCnt.data(), (uint64_t) nB1 * 8); if (rc) return rc;
-        uint64_t got = 0;
-        rc = commAlltoallvRecords(ctx, cur, sendCount.data(), sizeof(R), dRxA, &got, 0, &NkAll); if (rc) return rc;
-        PH_TRACE(st, "kmermatch: exchange 1 (level-1 buckets)");
-        dA.release(); dB.release();
-        if (dRxB.alloc(std::max<uint64_t>(got, 1) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; }
-        if (NUCL) {              // the globally smallest key (first-run quirk of the group kernel)
-            uint64_t mk = 0; PH_COPY_SYNC(st, &mk, dMinKey.p, 8, hipMemcpyDeviceToHost);
-            rc = commAllReduceMinU64(ctx, &mk, 1); if (rc) return rc;
-            PH_COPY_SYNC(st, dMinKey.p, &mk, 8, hipMemcpyHostToDevice);
-        }
-        // what arrived: for every source s the records of my level-1 buckets rk*nbL .. rk*nbL + nbL - 1, bucket after bucket
-        std::vector<uint64_t> segS((size_t) W * nbL), segC((size_t) W * nbL); uint64_t o = 0; maxSeg = 0;
-        for (int sr = 0; sr < W; sr++)
-            for (uint32_t j = 0; j < nbL; j++) {
-                const uint64_t c = allCnt[(size_t) sr * nB1 + (size_t) rk * nbL + j];
-                segS[(size_t) sr * nbL + j] = o; segC[(size_t) sr * nbL + j] = c; o += c; maxSeg = std::max(maxSeg, c);
-            }
-        if (o != got) { setError("kmermatch: internal error, exchanged bucket counts do not add up"); return PLASSHIP_ERR_DEVICE; }
-        if (dSegS.alloc(segS.size() * 8) != hipSuccess || dSegC.alloc(segC.size() * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        PH_COPY_SYNC(st, dSegS.p, segS.data(), segS.size() * 8, hipMemcpyHostToDevice);
-        PH_COPY_SYNC(st, dSegC.p, segC.data(), segC.size() * 8, hipMemcpyHostToDevice);
-        l2SegStart = dSegS.as<uint64_t>(); l2SegCount = dSegC.as<uint64_t>(); l2Segs = (uint32_t) W * nbL; l2SegMod = nbL;
-        cur = dRxA.p; other = dRxB.p; Nk = got;
-    }
-    const uint64_t NkG = cm ? NkAll : Nk;      // records of the whole run (the count matrix of exchange 1 has it)
+    const uint64_t NkG = Nk;
     const uint32_t nB2 = nbL << b2;            // level-2 tables (= final buckets of this rank)
     if (b2 > 0) {
-        if (!fold) hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dSegCnt1.as<uint64_t>(), (uint64_t) nB1);
+        hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dSegCnt1.as<uint64_t>(), (uint64_t) nB1);
         PH_CHECK(hipMemsetAsync(dCnt2.p, 0, (size_t) nB2 * 4, st));
         PartArgs p2; memset(&p2, 0, sizeof(p2));
         p2.in = cur; p2.out = other; p2.segStart = l2SegStart; p2.segCount = l2SegCount; p2.count = dCnt2.as<uint32_t>();
@@ -2522,23 +2633,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(dArenaStart.p, hArena.data(), (size_t) gGrid * 8, hipMemcpyHostToDevice, st));
     const uint64_t NmLocal = Nm;               // grouped records this rank produced
     std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
-    if (cm) {
-        // the stale-record check below is a property of the WHOLE run: N_m, N_k, the last (rep, target) run and the value
-        // histogram are reduced over the ranks; every rank then takes the same decisions (and the same collectives)
-        // (one all-gather: [N_m, last run, histogram])
-        std::vector<uint64_t> mine(2 + (size_t) VH_BINS), all((2 + (size_t) VH_BINS) * (size_t) W);
-        mine[0] = Nm; mine[1] = hLastRun[0]; std::copy(hVHistG.begin(), hVHistG.end(), mine.begin() + 2);
-        const int rc = commAllgatherHost(ctx, mine.data(), all.data(), mine.size() * 8); if (rc) return rc;
-        uint64_t mx = 0; Nm = 0; std::fill(hVHistG.begin(), hVHistG.end(), 0);
-        for (int r = 0; r < W; r++) {
-            const uint64_t *row = all.data() + (size_t) r * mine.size();
-            Nm += row[0]; mx = std::max(mx, row[1]);
-            for (uint32_t b = 0; b < VH_BINS; b++) hVHistG[b] += row[2 + b];
-        }
-        PH_CHECK(hipMemcpyAsync(dMaxRT.p, &mx, 8, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
-        PH_COPY_SYNC(st, hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost);
-    }
     std::swap(cur, other);   // cur = grouped records, scattered in arenas; other = the N_k hash-bucketed records (dense)
     msGroup = tm.stop(1);
     PH_TRACE(st, "kmermatch: group");
@@ -2587,10 +2681,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(plasship::streamSync(st));
-            if (cm) {            // every rank counted the records of its own buckets: the sort-#1 ranks are the sums
-                static_assert(sizeof(unsigned long long) == sizeof(uint64_t), "");
-                const int rc = commAllReduceSumU64(ctx, reinterpret_cast<uint64_t *>(diff.data()), diff.size()); if (rc) return rc;
-            }
             unsigned long long rank = 0, expect = Nm;
             for (uint32_t j = 0; j < m; j++) {
                 rank += diff[j];                         // records strictly before trec[j] in sort-#1 order
@@ -2604,46 +2694,13 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     tm.start(0);
     const uint64_t *segStartP = dArenaStart.as<uint64_t>(), *segCountP = dOutCnt.as<uint64_t>();   // where the grouped records are
     uint32_t nSeg = gGrid; uint64_t maxSeg1 = maxArena, NmHere = NmLocal;
-    const uint64_t haloSlack = HALO_SLACK;     // room behind the triples for what the last run's scan reaches on later ranks
     if (traceOn()) fprintf(stderr, "[plasship] kmermatch: N=%u Nk=%llu NmLocal=%llu gGrid=%u maxArena=%llu stale=%zu\n", N, (unsigned long long) Nk, (unsigned long long) NmLocal, gGrid, (unsigned long long) maxArena, stalePos.size());
     PH_TRACE(st, "kmermatch: stale-record check");
-    if (cm) {
-        // exchange 2: grouped (rep, member, diagonal) records -> owner of the rep.  Same recipe: one partition pass by owner
-        // straight out of the group kernel's arenas, then an all-to-all(v).
-        const int ob = ceilLog2((uint64_t) W); const uint32_t nbO = 1u << ob;
-        DevBuf dCntO, dStartO, dCurO;
-        if (dCntO.alloc((size_t) nbO * 4) != hipSuccess || dStartO.alloc(((size_t) nbO + 1) * 8) != hipSuccess || dCurO.alloc((size_t) nbO * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        PH_CHECK(hipMemsetAsync(dCntO.p, 0, (size_t) nbO * 4, st));
-        PartArgs po; memset(&po, 0, sizeof(po));
-        po.in = cur; po.out = other; po.segStart = segStartP; po.segCount = segCountP; po.count = dCntO.as<uint32_t>();
-        po.cursor = dCurO.as<unsigned long long>(); po.bits = ob; po.sharedTable = 1; po.ownerW = (uint32_t) W; po.ownerN = std::max<uint64_t>(N, 1);
-        const unsigned tilesO = (unsigned) std::max<uint64_t>(1, (maxArena + PT_TILE - 1) / PT_TILE);
-        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_OWNER_REP>), dim3(tilesO, gGrid), dim3(PT_BLOCK), 0, st, po);
-        PH_TRACE(st, "kmermatch: owner histogram of the grouped records");
-        if (exclusiveScanU32(st, dCntO.as<uint32_t>(), dStartO.as<uint64_t>(), nbO, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(copyU64Kernel, dim3(1), dim3(256), 0, st, dStartO.as<uint64_t>(), dCurO.as<unsigned long long>(), (uint64_t) nbO);
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_OWNER_REP>), dim3(tilesO, gGrid), dim3(PT_BLOCK), (size_t) 12 << po.bits, st, po);
-        std::vector<uint64_t> hStartO(nbO + 1), sendCount(W);
-        PH_COPY_SYNC(st, hStartO.data(), dStartO.p, ((size_t) nbO + 1) * 8, hipMemcpyDeviceToHost);
-        PH_CHECK(hipGetLastError());
-        for (int r = 0; r < W; r++) sendCount[r] = hStartO[r + 1] - hStartO[r];
-        PH_TRACE(st, "kmermatch: owner partition of the grouped records");
-        uint64_t got = 0;
-        const int rc = commAlltoallvRecords(ctx, other, sendCount.data(), sizeof(R), dRxC, &got, haloSlack);
-        if (rc) return rc;
-        PH_TRACE(st, "kmermatch: exchange 2");
-        dRxA.release(); dRxB.release();
-        if (dRxD.alloc((got + haloSlack) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; }
-        cur = dRxC.p; other = dRxD.p;
-        NmHere = got; maxSeg1 = got; nSeg = 1;
-        PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &NmHere, 8, hipMemcpyHostToDevice, st));
-        segStartP = dSeg0Start.as<uint64_t>(); segCountP = dSeg0Cnt.as<uint64_t>();
-    }
     // rep ids are sorted relative to the first rep this rank owns (0 on a single GPU); targets are ids of the whole DB
     const int idBits = std::max(1, ceilLog2((uint64_t) N));
     // sharded run: from the LARGEST share of any rank (ceil(N / W)), so that the key layout — and the "too many sequences" exit
     // below — is the same decision on every rank
-    const int repBits = cm ? std::max(1, ceilLog2(std::max<uint64_t>((N + (uint64_t) W - 1) / (uint64_t) W, 1))) : idBits;
+    const int repBits = idBits;
     // ~512 records per sort bucket, at most 2^22 buckets (two partition levels of 11 bits): beyond 2 G grouped records the buckets
     // grow instead (the aggregation kernel takes buckets of any size)
     const int wantBits = std::min(22, std::max(0, ceilLog2((NmHere + 511) / 512)));
@@ -2667,7 +2724,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PartArgs p1; memset(&p1, 0, sizeof(p1));
         p1.in = cur; p1.out = other; p1.segStart = segStartP; p1.segCount = segCountP; p1.count = dRC1.as<uint32_t>();
         p1.cursor = dRCur1.as<unsigned long long>(); p1.shift = 64 - s1; p1.bits = s1; p1.rangeBits = repBits; p1.dropSentinels = 0; p1.sharedTable = 1;
-        p1.repBase = cm ? repBase : 0;
+        p1.repBase = 0;
         if (s1 == 0) p1.shift = 63;
         const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxSeg1 + PT_TILE - 1) / PT_TILE);
         hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, nSeg), dim3(PT_BLOCK), 0, st, p1);
@@ -2686,7 +2743,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             PH_CHECK(hipMemsetAsync(dRC2.p, 0, (size_t) nS * 4, st));
             PartArgs p2; memset(&p2, 0, sizeof(p2));
             p2.in = cur; p2.out = other; p2.segStart = dRS1.as<uint64_t>(); p2.segCount = dRSegCnt.as<uint64_t>(); p2.count = dRC2.as<uint32_t>();
-            p2.cursor = dRCur2.as<unsigned long long>(); p2.shift = 64 - s1 - s2; p2.bits = s2; p2.rangeBits = repBits; p2.dropSentinels = 0; p2.repBase = cm ? repBase : 0;
+            p2.cursor = dRCur2.as<unsigned long long>(); p2.shift = 64 - s1 - s2; p2.bits = s2; p2.rangeBits = repBits; p2.dropSentinels = 0; p2.repBase = 0;
             const unsigned tiles2 = (unsigned) std::max<uint64_t>(1, (maxSeg + PT_TILE - 1) / PT_TILE);
             hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), 0, st, p2);
             if (exclusiveScanU32(st, dRC2.as<uint32_t>(), dRS2.as<uint64_t>(), nS, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
@@ -2717,7 +2774,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     for (int pass = 0; pass < 2; pass++)
         hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, false>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
                            (const void *) cur, other, dSortStart, nSortBuckets, pass ? dBigScratch.as<unsigned long long>() : (unsigned long long *) nullptr, (const uint64_t *) dBigOff.as<uint64_t>(),
-                           dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) (cm ? repBase : 0), AggLines{nullptr, nullptr, nullptr}, 0);
+                           dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, AggLines{nullptr, nullptr, nullptr}, 0);
     DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
     if (dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSortBuckets, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }

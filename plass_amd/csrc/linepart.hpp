@@ -31,7 +31,7 @@ template <> struct __attribute__((aligned(8))) Rec<true> { uint64_t kmer; uint32
 
 template <bool LONG> __device__ __forceinline__ bool isSentinel(const Rec<LONG> &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }
 
-enum { KEY_HASH = 0, KEY_RANGE = 1, KEY_OWNER_HASH = 2, KEY_OWNER_REP = 3 };
+enum { KEY_HASH = 0, KEY_RANGE = 1 };
 template <bool NUCL> __device__ __forceinline__ uint64_t kmerMix(uint64_t kmerField) {
     const uint64_t K = NUCL ? (kmerField & ~BIT63) : kmerField;
     uint64_t x = K * 0x9E3779B97F4A7C15ULL; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ULL; x ^= x >> 32;

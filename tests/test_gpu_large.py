@@ -50,6 +50,7 @@ def test_large_chain_against_oracle_checksums(tmp_path):
         db = ctx.plass_fragments(reads)
         reads.free()
         db.write(tmp_path / "seq_0")
+        assert db.digest() == (gold["fragments"]["digest"], gold["fragments"]["bytes"])     # the device digest is the oracle's dbsum
         check(tmp_path / "seq_0", gold["fragments"], "extractorfs + translatenucs + concatdbs")
         for it, want in enumerate(gold["iterations"]):
             par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=bench.hash_shift(it),
@@ -64,6 +65,7 @@ def test_large_chain_against_oracle_checksums(tmp_path):
             out, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
             alns.free(); db.free()
             out.write(tmp_path / "seq")
+            assert out.digest() == (want["seq"]["digest"], want["seq"]["bytes"]), "device digest of seq_%d" % (it + 1)
             check(tmp_path / "seq", want["seq"], "assembleresults, iteration %d" % it)
             db = out
         db.free()
@@ -109,3 +111,34 @@ def test_split_data_files_and_text_round_trips(tmp_path, golden):
             assert (r.query_key, r.target_key, r.bit_score, r.q_start, r.q_end, r.db_start, r.db_end) == (s.query_key, s.target_key, s.bit_score, s.q_start, s.q_end, s.db_start, s.db_end)
     finally:
         ctx.close()
+
+
+def _chain_digests(cfg, pairs, iters, mode):
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(HERE, "tools", "chain_digests.py"), cfg, str(pairs), str(iters), mode],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=1500)
+    assert p.returncode == 0 and "CHAIN_DIGESTS " in p.stdout, "%s: %s" % (mode, p.stdout[-3000:])
+    return json.loads(p.stdout.split("CHAIN_DIGESTS ", 1)[1].splitlines()[0])
+
+
+@pytest.mark.timeout(3000)
+def test_headline_size_three_implementations_agree():
+    """BASELINE.json configs[2] at FULL size (25 M read pairs = 50 M reads -> 88 M protein fragments, 5.3 G k-mer record slots:
+    beyond 2^32, ten times what the CPU oracle can follow): iterations 0-2 run three ways — the line-store path, the dense
+    histogram/scatter partition with the three-phase group kernel (PLASSHIP_LEGACY_PARTITION=1) and the sharded orchestration in a
+    1-rank group — must give identical counts and identical digests of seq_1..seq_3.  PLASS_TEST_HEADLINE_PAIRS scales it down."""
+    pairs = int(os.environ.get("PLASS_TEST_HEADLINE_PAIRS", "25000000"))
+    runs = [_chain_digests("c3", pairs, 3, m) for m in ("lines", "legacy", "sharded1")]
+    if pairs >= 25000000:
+        assert runs[0]["iterations"][0]["N_k"] > 2.9e9 and runs[0]["fragments"] > 80e6
+    for r in runs[1:]:
+        assert r["fragments_digest"] == runs[0]["fragments_digest"]
+        for it, (a, b) in enumerate(zip(runs[0]["iterations"], r["iterations"])):
+            for k in ("N_c", "verified", "extended", "residues", "digest"):
+                assert a[k] == b[k], "iteration %d: %s of the %s path is %s, of the line-store path %s" % (it, k, r["mode"], b[k], a[k])
+            if r["mode"] == "legacy":
+                assert (a["N_k"], a["N_m"]) == (b["N_k"], b["N_m"])
+    committed = json.load(open(os.path.join(HERE, "golden", "c3_chain_digests.json")))
+    if committed.get("pairs") == pairs:                      # the digests bench.py prints and checks for this workload
+        for it, a in enumerate(runs[0]["iterations"]):
+            assert a["digest"] == committed["digests"][it], "iteration %d differs from tests/golden/c3_chain_digests.json" % it
