@@ -231,12 +231,20 @@ bool translatenucs(const DB &seqDb, const DB *hdrDb, const OrfParams &op, DB &ou
     return true;
 }
 
-bool concatdbs(const DB &a, const DB &b, DB &out, std::string &) {        // DBConcat.cpp:63-135 with preserveKeysA, !preserveKeysB
+// concatdbs = DBConcat with preserveKeysA = true, preserveKeysB = --preserve-keys (DBConcat.cpp:379-382): A's entries keep their keys;
+// B is opened LINEAR_ACCCESS (DBConcat.cpp:46-47), i.e. its ids run in DATA FILE order (DBReader.cpp:335-360 sorts the index by
+// offset), and entry id of B becomes key id + max(keyA) + 1 (DBConcat.cpp:113-118).  For a B whose data lies in key order that is
+// "B renumbered behind A in key order"; translatenucs run on several threads leaves its data in thread order, and B's new keys then
+// follow the FILE (tests/golden/concat_noncanonical.tar.gz: written by the reference with 8 threads).
+bool concatdbs(const DB &a, const DB &b, DB &out, std::string &) {
     out = DB(); out.dbtype = a.dbtype;
     unsigned maxKeyA = 0;
     for (size_t i = 0; i < a.size(); i++) { out.add(a.key[i], a.entry(i), a.elen[i] - 1); maxKeyA = std::max(maxKeyA, a.key[i]); }
     maxKeyA++;
-    for (size_t i = 0; i < b.size(); i++) out.add((unsigned) i + maxKeyA, b.entry(i), b.elen[i] - 1);
+    std::vector<size_t> ob(b.size());
+    for (size_t i = 0; i < ob.size(); i++) ob[i] = i;
+    std::stable_sort(ob.begin(), ob.end(), [&](size_t x, size_t y) { return b.off[x] < b.off[y]; });
+    for (size_t i = 0; i < ob.size(); i++) out.add((unsigned) i + maxKeyA, b.entry(ob[i]), b.elen[ob[i]] - 1);
     out.sortByKey();
     return true;
 }

@@ -127,6 +127,9 @@ struct plasship_seqdb {
     uint64_t dataBytes = 0, residues = 0;
     uint32_t maxEntryLen = 0;
     plasship::DevBuf d_data, d_off, d_len, d_key;
+    // rank of every entry in DATA FILE order (empty: the file lay in key order, rank == id).  Only DBs read from files written by
+    // several threads have one; concatdbs renumbers its second DB by it (DBConcat.cpp:46-47,113-118 opens it LINEAR_ACCCESS).
+    plasship::DevBuf d_fileRank;
     // host mirror of the index (lazily filled for device-produced DBs)
     bool hostIndexValid = false;
     std::vector<uint32_t> h_key, h_elen;

@@ -82,6 +82,7 @@ void poolEnter(hipStream_t stream) { tl_poolStream = stream; }
 static void poolForgetStream(hipStream_t stream) {
     std::lock_guard<std::mutex> g(g_poolMu);
     for (auto &dv : g_pools) for (auto &sl : dv.second.slabs) for (auto &kv : sl.free) if (!kv.second.mixed && kv.second.stream == stream) kv.second.stream = nullptr;
+    for (auto &kv : g_poolLive) if (kv.second.stream == stream) kv.second.stream = nullptr;     // blocks that outlive their context: its queued work is through
     if (tl_poolStream == stream) tl_poolStream = nullptr;
 }
 static double poolFraction() { static const double v = [] { const char *e = getenv("PLASSHIP_POOL_FRACTION"); const double x = e ? atof(e) : 0.0; return (x > 0.05 && x <= 0.98) ? x : 0.88; }(); return v; }
@@ -367,6 +368,19 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
             }, nullptr, 1024);
         });
         if (rc) return rc;
+    }
+    // file order != key order (a DB several writer threads left behind): remember every entry's rank in the data file
+    {
+        bool fileSorted = true;
+        for (size_t i = 1; i < n && fileSorted; i++) fileSorted = off[perm[i - 1]] <= off[perm[i]];
+        if (!fileSorted) {
+            std::vector<uint32_t> byOff(n), rank(n);
+            std::iota(byOff.begin(), byOff.end(), 0u);
+            std::stable_sort(byOff.begin(), byOff.end(), [&](uint32_t x, uint32_t y) { return off[perm[x]] < off[perm[y]]; });
+            for (size_t r = 0; r < n; r++) rank[byOff[r]] = (uint32_t) r;
+            if (db->d_fileRank.alloc(n * 4) != hipSuccess) { setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            const int rc = stagedCopyToDevice(ctx, db->d_fileRank.p, rank.data(), n * 4); if (rc) return rc;
+        }
     }
     std::vector<uint64_t> hoff(n + 1);
     for (size_t i = 0; i < n; i++) hoff[i] = db->h_off[i];

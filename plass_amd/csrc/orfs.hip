@@ -300,6 +300,19 @@ __global__ void concatIndexKernel(const uint64_t *__restrict__ offA, const uint3
         else off[i] = bytesA + (nB ? offB[nB] : 0);
     }
 }
+// B in data file order (a DB read from thread-written files, plasship_seqdb::d_fileRank): entry j of B goes to position nA + rank[j]
+__global__ void concatRankLenKernel(const uint32_t *__restrict__ lenB, const uint32_t *__restrict__ rank, uint32_t nB, uint32_t *__restrict__ lenOut, uint64_t *__restrict__ bytesOut) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nB; j += gridDim.x * blockDim.x) { lenOut[rank[j]] = lenB[j]; bytesOut[rank[j]] = (uint64_t) lenB[j] + 2; }
+}
+__global__ __launch_bounds__(256) void concatRankCopyKernel(const char *__restrict__ dataB, const uint64_t *__restrict__ offB, const uint32_t *__restrict__ lenB, const uint32_t *__restrict__ rank, uint32_t nB,
+                                                            const uint64_t *__restrict__ newOff, uint64_t bytesA, uint32_t nA, uint32_t keyBase, char *__restrict__ data, uint64_t *__restrict__ off, uint32_t *__restrict__ key) {
+    const int G = 16, gl = threadIdx.x & (G - 1);
+    for (uint32_t j = blockIdx.x * (256 / G) + threadIdx.x / G; j < nB; j += gridDim.x * (256 / G)) {
+        const uint32_t r = rank[j], el = lenB[j] + 2; const uint64_t d = bytesA + newOff[r], s = offB[j];
+        for (uint32_t i = gl; i < el; i += G) data[d + i] = dataB[s + i];
+        if (gl == 0) { off[nA + r] = d; key[nA + r] = keyBase + r; }
+    }
+}
 __global__ void concatInfoKernel(const OrfInfo *__restrict__ a, uint32_t nA, const OrfInfo *__restrict__ b, uint32_t nB, uint32_t keyBase, OrfInfo *__restrict__ out) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB; i += gridDim.x * blockDim.x) {
         if (i < nA) out[i] = a[i]; else { OrfInfo o = b[i - nA]; o.key = keyBase + (i - nA); out[i] = o; }
@@ -464,8 +477,9 @@ extern "C" int plasship_translate_nucs(plasship_ctx *ctx, const plasship_seqdb *
     return PLASSHIP_OK;
 }
 
-// concatdbs <A> <B> <out> (DBConcat.cpp:63-135, preserveKeysA, !preserveKeysB): both handles are in key order, so the result is
-// A's entries followed by B's with keys max(keyA) + 1 + i
+// concatdbs <A> <B> <out> (DBConcat.cpp:63-135 with preserveKeysA, !preserveKeysB, DBConcat.cpp:379-382): A's entries with their keys,
+// followed by B's with keys max(keyA) + 1 + i where i runs over B in DATA FILE order (B is opened LINEAR_ACCCESS: DBConcat.cpp:46-47,
+// 113-118).  Handles hold their entries in key order; one whose file order was different carries d_fileRank (common.hpp)
 static int maxKeyOf(plasship_ctx *ctx, const uint32_t *dKey, size_t n, uint32_t *out) {
     *out = 0;
     if (!n) return PLASSHIP_OK;
@@ -484,10 +498,21 @@ extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a,
     if (o->d_data.alloc(dataBytes + 64) != hipSuccess || o->d_off.alloc((nn + 1) * 8) != hipSuccess || o->d_len.alloc((nn + 1) * 4) != hipSuccess ||
         o->d_key.alloc((nn + 1) * 4) != hipSuccess) { setError("plasship_seqdb_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (a->dataBytes) PH_CHECK(hipMemcpyAsync(o->d_data.p, a->d_data.p, a->dataBytes, hipMemcpyDeviceToDevice, st));
-    if (b->dataBytes) PH_CHECK(hipMemcpyAsync((char *) o->d_data.p + a->dataBytes, b->d_data.p, b->dataBytes, hipMemcpyDeviceToDevice, st));
+    if (b->dataBytes && !b->d_fileRank.p) PH_CHECK(hipMemcpyAsync((char *) o->d_data.p + a->dataBytes, b->d_data.p, b->dataBytes, hipMemcpyDeviceToDevice, st));
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + dataBytes, 0, 64, st));
     hipLaunchKernelGGL(concatIndexKernel, dim3(gridOf(nn + 1, ctx->numCU)), dim3(256), 0, st, a->d_off.as<uint64_t>(), a->d_len.as<uint32_t>(), a->d_key.as<uint32_t>(), (uint32_t) a->n,
                        b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), (uint32_t) b->n, a->dataBytes, maxKeyA + 1, o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+    if (b->d_fileRank.p && b->n) {
+        // B was read from files whose data is not in key order: the reference numbers B's entries in FILE order (see common.hpp),
+        // so the B half of the output is B permuted by its file rank (lengths scattered, offsets by a prefix sum, entries copied)
+        DevBuf dBytes, dNewOff, dTmp; const size_t tmpBytes = exclusiveScanTmpBytes(b->n + 2);
+        if (dBytes.alloc((b->n + 1) * 8) != hipSuccess || dNewOff.alloc((b->n + 2) * 8) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship_seqdb_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(concatRankLenKernel, dim3(gridOf(b->n, ctx->numCU)), dim3(256), 0, st, b->d_len.as<uint32_t>(), b->d_fileRank.as<uint32_t>(), (uint32_t) b->n, o->d_len.as<uint32_t>() + a->n, dBytes.as<uint64_t>());
+        if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dNewOff.as<uint64_t>(), b->n, dTmp.p, tmpBytes)) { setError("plasship_seqdb_concat: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(concatRankCopyKernel, dim3(gridOf((b->n + 15) / 16, ctx->numCU)), dim3(256), 0, st, b->d_data.as<char>(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->d_fileRank.as<uint32_t>(), (uint32_t) b->n,
+                           dNewOff.as<uint64_t>(), a->dataBytes, (uint32_t) a->n, maxKeyA + 1, o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_key.as<uint32_t>());
+        PH_CHECK(plasship::streamSync(st));
+    }
     o->dbtype = a->dbtype; o->n = (size_t) nn; o->dataBytes = dataBytes; o->residues = a->residues + b->residues;
     o->maxEntryLen = std::max(a->maxEntryLen, b->maxEntryLen); o->hostIndexValid = false;
     PH_CHECK(plasship::streamSync(st));

@@ -128,3 +128,27 @@ def test_synth_reads_deterministic_and_chain_vs_oracle(ctx, oracle_bin, tmp_path
     # the fragments are usable by the hot path right away (device-built DB, no host index yet)
     cands, kst = ctx.kmermatcher(frag, plass_amd.KmermatchParams(hash_shift=67, include_only_extendable=False))
     assert kst.n_candidates > 0
+
+
+def test_concatdbs_numbers_b_in_file_order(ctx, golden, tmp_path):
+    """concatdbs on DBs whose data files are in thread order (written by the reference's translatenucs on 8 threads, raw files): the
+    handles keep every entry's rank in the data file, and B's new keys follow it like the reference's LINEAR_ACCCESS reader
+    (DBConcat.cpp:46-47,113-118); through the C-ABI and through the command line"""
+    import subprocess
+    c = os.path.join(golden, "concat")
+    a = ctx.read_seqdb(f"{c}/aaA"); b = ctx.read_seqdb(f"{c}/aaB")
+    out = ctx.concatdbs(a, b)
+    out.write(tmp_path / "out")
+    assert_same_db(f"{c}/aaC", tmp_path / "out", "concatdbs on thread-ordered inputs")
+    # a DB this library wrote is in key order: concatenating the rewritten copies numbers B by key — equal to the reference only where
+    # file order and key order agree, i.e. the distinction is real
+    b.write(tmp_path / "b_canon"); b2 = ctx.read_seqdb(tmp_path / "b_canon")
+    out2 = ctx.concatdbs(a, b2); out2.write(tmp_path / "out2")
+    from conftest import read_db
+    assert read_db(tmp_path / "out2")[1] != read_db(f"{c}/aaC")[1]
+    for x in (a, b, b2, out, out2):
+        x.free()
+    hip = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plass_amd", "plass-hip")
+    p = subprocess.run([hip, "concatdbs", f"{c}/aaA", f"{c}/aaB", str(tmp_path / "cli")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    assert_same_db(f"{c}/aaC", tmp_path / "cli", "plass-hip concatdbs on thread-ordered inputs")

@@ -224,3 +224,13 @@ def test_oracle_orf_preprocessing(oracle_bin, golden, tmp_path):
         run_oracle(oracle_bin, ["translatenucs", tmp_path / f"nucl_6f_{n}", tmp_path / f"aa_6f_{n}", "--translation-table", "1", "--add-orf-stop", "1"])
     run_oracle(oracle_bin, ["concatdbs", tmp_path / "aa_6f_long", tmp_path / "aa_6f_start", tmp_path / "aa_6f_start_long"])
     assert_same_db(os.path.join(golden, "aa", "seq_0"), tmp_path / "aa_6f_start_long", "preprocessing chain -> aa_6f_start_long")
+
+
+def test_oracle_concatdbs_follows_the_data_file_order(oracle_bin, golden, tmp_path):
+    """concatdbs numbers its SECOND DB in data-file order (DBConcat.cpp:46-47,113-118): inputs the reference's translatenucs wrote
+    on 8 threads (data in thread order, raw files — not canonicalised) and the reference's own concatenation"""
+    c = os.path.join(golden, "concat")
+    idx = [tuple(int(x) for x in l.split()[:3]) for l in open(os.path.join(c, "aaB.index"))]
+    assert any(a[1] > b[1] for a, b in zip(idx, idx[1:])), "the fixture must hold a DB whose file order is not its key order"
+    run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "aaA"), os.path.join(c, "aaB"), tmp_path / "out"])
+    assert_same_db(os.path.join(c, "aaC"), tmp_path / "out", "concatdbs on thread-ordered inputs")
