@@ -18,6 +18,7 @@
 #include <map>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 static bool multiParam(const std::string &v, const char *which, std::string &out) {
@@ -55,6 +56,7 @@ struct Flags {
     int chopCycle = 1;                   // LocalParameters.h:202
     int orfMin = 30, orfMax = 32734, orfGaps = INT_MAX, contigStart = 2, contigEnd = 2, orfStart = 1, fwdFrames = 7, revFrames = 7;
     int translationTable = 1, translate = 0, allStarts = 0, addOrfStop = 0, preserveKeys = 0, takeLarger = 0;
+    int numIterations = 0, fromReads = 0; std::string writeIntermediate; float seqIdThrNucl = 0.99f;
     std::set<std::string> seen;
 };
 
@@ -81,6 +83,12 @@ static const std::map<std::string, std::set<std::string>> &moduleFlags() {
                             "--reverse-frames", "--translation-table", "--translate", "--use-all-table-starts", "--id-offset", "--create-lookup"};
         m["translatenucs"] = {"--translation-table", "--add-orf-stop"};
         m["concatdbs"] = {"--preserve-keys", "--take-larger-entry"};
+        // the fused drivers (not reference modules: the iteration loops of data/assemble.sh:85-156, nuclassemble.sh:95-137 and
+        // guidedNuclAssemble.sh:77-126 with the DBs chained in HBM); flags = the workflow's own, defaults = the workflow's
+        m["assemble-chain"] = {"--num-iterations", "--write-intermediate", "--from-reads", "-k", "--alph-size", "--kmer-per-seq", "--kmer-per-seq-scale", "--min-seq-id", "-e", "-c",
+                               "--cov-mode", "--max-seq-len", "--keep-target", "--hash-shift", "--ignore-multi-kmer", "--rescore-mode", "--min-aln-len", "--seq-id-mode"};
+        m["nuclassemble-chain"] = m["assemble-chain"]; m["nuclassemble-chain"].insert("--chop-cycle");
+        m["guidedassemble-chain"] = m["assemble-chain"];
         for (auto &kv : m) kv.second.insert(common.begin(), common.end());
     }
     return m;
@@ -102,7 +110,10 @@ static bool parseBool(const std::string &v, bool &ok) {                 // Param
 int main(int argc, char **argv) {
     if (argc < 2) {
         fprintf(stdout, "usage: plass-hip <kmermatcher|rescorediagonal|assembleresults|nuclassembleresults|guidedassembleresults|proteinaln2nucl|findassemblystart|"
-                        "cyclecheck|extractorfs|translatenucs|concatdbs> <dbs…> [flags]\n");
+                        "cyclecheck|extractorfs|translatenucs|concatdbs> <dbs…> [flags]\n"
+                        "       plass-hip assemble-chain <i:fragmentDB|readDB> <o:assemblyDB> [--num-iterations 12] [--from-reads 1] [--write-intermediate DIR]\n"
+                        "       plass-hip nuclassemble-chain <i:nuclDB> <o:assemblyDB> [--num-iterations 8]        (writes <o>_cycle_<i> for circular contigs)\n"
+                        "       plass-hip guidedassemble-chain <i:readDB> <o:nuclAssemblyDB> <o:aaAssemblyDB> [--num-iterations 5]\n");
         return EXIT_FAILURE;
     }
     const std::string mod = argv[1];
@@ -113,6 +124,15 @@ int main(int argc, char **argv) {
     }
     Flags f; std::vector<std::string> pos;
     if (mod == "kmermatcher") { f.covThr = 0.8f; f.alph = 13; f.kps = 0; }                    // setLinearFilterDefault
+    const bool chain = mod == "assemble-chain" || mod == "nuclassemble-chain" || mod == "guidedassemble-chain";
+    if (chain) {
+        // the workflows' defaults: src/workflow/Assembler.cpp:10-27 (plass assemble), Nuclassembler.cpp:10-31 (penguin nuclassemble),
+        // GuidedNuclassembler.cpp:10-41 (penguin guided_nuclassemble, protein-guided stage)
+        f.alph = 13; f.kps = 60; f.ignoreMulti = 1; f.covThr = 0.0f; f.covMode = 0; f.evalThr = 1e-5; f.rescoreMode = 3; f.keepTarget = 1; f.hashShift = 67;
+        if (mod == "assemble-chain") { f.k = 14; f.scaleAA = 0.0f; f.seqIdThr = 0.9f; f.maxSeqLen = 65535; f.numIterations = 12; }
+        else if (mod == "nuclassemble-chain") { f.k = 22; f.scaleNucl = 0.1f; f.seqIdThr = 0.99f; f.maxSeqLen = 200000; f.numIterations = 8; f.onlyExt = 1; f.chopCycle = 1; }
+        else { f.k = 14; f.scaleAA = 0.1f; f.seqIdThr = 0.97f; f.maxSeqLen = 200000; f.numIterations = 5; f.onlyExt = 1; f.covMode = 1; f.addBt = 1; }
+    }
     for (int i = 2; i < argc; i++) {
         std::string a = argv[i];
         if (!(a.size() > 1 && a[0] == '-' && !(a[1] >= '0' && a[1] <= '9'))) { pos.push_back(a); continue; }
@@ -132,6 +152,9 @@ int main(int argc, char **argv) {
             field = b ? 1 : 0; return true;
         };
         if (a == "-k") f.k = atoi(v.c_str());
+        else if (a == "--num-iterations") { std::string t2; f.numIterations = atoi((multiParam(v, mod == "assemble-chain" || mod == "guidedassemble-chain" ? "aa" : "nucl", t2) ? t2 : v).c_str()); }
+        else if (a == "--write-intermediate") f.writeIntermediate = v;
+        else if (a == "--from-reads") f.fromReads = atoi(v.c_str());
         else if (a == "--alph-size") { if (multiParam(v, "aa", t)) f.alph = atoi(t.c_str()); }
         else if (a == "--kmer-per-seq") f.kps = atoi(v.c_str());
         else if (a == "--kmer-per-seq-scale") { if (multiParam(v, "aa", t)) f.scaleAA = strtof(t.c_str(), nullptr); if (multiParam(v, "nucl", t)) f.scaleNucl = strtof(t.c_str(), nullptr); }
@@ -142,7 +165,12 @@ int main(int argc, char **argv) {
         else if (a == "-c") f.covThr = strtof(v.c_str(), nullptr);
         else if (a == "--rescore-mode") f.rescoreMode = atoi(v.c_str());
         else if (a == "-e") f.evalThr = strtod(v.c_str(), nullptr);
-        else if (a == "--min-seq-id") f.seqIdThr = strtof(v.c_str(), nullptr);
+        else if (a == "--min-seq-id") {
+            if (mod == "guidedassemble-chain") { if (multiParam(v, "aa", t)) f.seqIdThr = strtof(t.c_str(), nullptr); if (multiParam(v, "nucl", t)) f.seqIdThrNucl = strtof(t.c_str(), nullptr); }
+            else if (mod == "nuclassemble-chain") { if (multiParam(v, "nucl", t)) f.seqIdThr = strtof(t.c_str(), nullptr); }
+            else if (mod == "assemble-chain") { if (multiParam(v, "aa", t)) f.seqIdThr = strtof(t.c_str(), nullptr); }
+            else f.seqIdThr = strtof(v.c_str(), nullptr);
+        }
         else if (a == "--min-aln-len") f.minAlnLen = atoi(v.c_str());
         else if (a == "--seq-id-mode") f.seqIdMode = atoi(v.c_str());
         else if (a == "-a") { if (!setBool(f.addBt)) return EXIT_FAILURE; }
@@ -337,6 +365,107 @@ int main(int argc, char **argv) {
             if (plasship_orfhdr_write(ctx, o, pos[2].c_str())) return fail("concatdbs");
             plasship_orfhdr_free(ctx, o); plasship_orfhdr_free(ctx, b); plasship_orfhdr_free(ctx, a);
         } else { fprintf(stdout, "plass-hip concatdbs: database type %d is not supported (sequence DBs and ORF header DBs only)\n", dbtype); return EXIT_FAILURE; }
+    } else if (chain) {
+        // ---- fused drivers: the iteration loop of a workflow script with every DB of the loop resident in HBM; only the first DB is
+        //      read from disk and only the last one written (plus, with --write-intermediate DIR, every iteration's assembly by a host
+        //      thread on a second context while the next iteration runs, with the workflow's .done sentinels) ----
+        const bool prot = mod == "assemble-chain", nuc = mod == "nuclassemble-chain", gd = mod == "guidedassemble-chain";
+        if (pos.size() != (gd ? 3u : 2u)) { fprintf(stdout, "%s: wrong number of databases\n", mod.c_str()); return EXIT_FAILURE; }
+        if (f.numIterations < 1) { fprintf(stdout, "--num-iterations must be at least 1\n"); return EXIT_FAILURE; }
+        plasship_ctx *wctx = nullptr; std::thread writer; int writerRc = 0;
+        if (!f.writeIntermediate.empty() && plasship_ctx_create(-1, &wctx)) return fail(mod.c_str());
+        auto joinWriter = [&]() { if (writer.joinable()) writer.join(); return writerRc; };
+        auto writeAsync = [&](const plasship_seqdb *d, const std::string &name) {
+            if (!wctx) return;
+            joinWriter();
+            const std::string path = f.writeIntermediate + "/" + name;
+            writer = std::thread([&, d, path]() {
+                if (plasship_seqdb_write(wctx, d, path.c_str())) { writerRc = 1; return; }
+                FILE *fd = fopen((path + ".done").c_str(), "w"); if (fd) fclose(fd); else writerRc = 1;     // data/assemble.sh:147 `touch assembly_$STEP.done`
+            });
+        };
+        plasship_seqdb *in = nullptr;
+        if (plasship_seqdb_read(ctx, pos[0].c_str(), &in)) return fail(mod.c_str());
+        const double tRead = now();
+        int dbtype = -1; plasship_seqdb_info(in, nullptr, nullptr, nullptr, &dbtype, nullptr);
+        auto orfPar = [&](bool start) {       // the two extractorfs passes (Assembler.cpp:116-130, GuidedNuclassembler.cpp:133-145)
+            plasship_orf_params p; memset(&p, 0, sizeof(p));
+            p.min_length = start ? 20 : 45; p.max_length = start ? 45 : 32734; p.max_gaps = 0; p.contig_start_mode = start ? 1 : 2; p.contig_end_mode = start ? 0 : 2;
+            p.orf_start_mode = 0; p.forward_frames = 7; p.reverse_frames = 7; p.translation_table = 1; p.max_seq_len = 65535;
+            return p;
+        };
+        plasship_translate_params tp; tp.translation_table = 1; tp.add_orf_stop = 1; tp.max_seq_len = 65535;
+        plasship_seqdb *db = in, *aa = nullptr;          // protein / nucleotide chain: db; guided chain: db = nucleotide ORFs, aa = their twins
+        if (gd || (prot && (f.fromReads || dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES))) {
+            if (dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES) { fprintf(stdout, "%s: the input must be a nucleotide read DB\n", mod.c_str()); return EXIT_FAILURE; }
+            plasship_seqdb *ol = nullptr, *os = nullptr; plasship_orfhdr *hl = nullptr, *hs = nullptr; plasship_orf_stats ost;
+            const plasship_orf_params pl = orfPar(false), ps = orfPar(true);
+            if (plasship_extract_orfs(ctx, in, &pl, &ol, &hl, &ost) || plasship_extract_orfs(ctx, in, &ps, &os, &hs, &ost)) return fail(mod.c_str());
+            if (gd) {      // concatdbs of ORFs and headers, then one translatenucs (data/guidedNuclAssemble.sh:56-75)
+                plasship_seqdb *nu = nullptr; plasship_orfhdr *hh = nullptr;
+                if (plasship_seqdb_concat(ctx, ol, os, &nu) || plasship_orfhdr_concat(ctx, hl, hs, &hh) || plasship_translate_nucs(ctx, nu, hh, &tp, &aa, &ost)) return fail(mod.c_str());
+                plasship_orfhdr_free(ctx, hh); db = nu;
+            } else {       // translatenucs x2, then concatdbs (data/assemble.sh:41-77)
+                plasship_seqdb *al = nullptr, *as = nullptr;
+                if (plasship_translate_nucs(ctx, ol, hl, &tp, &al, &ost) || plasship_translate_nucs(ctx, os, hs, &tp, &as, &ost) || plasship_seqdb_concat(ctx, al, as, &db)) return fail(mod.c_str());
+                plasship_seqdb_free(ctx, al); plasship_seqdb_free(ctx, as);
+            }
+            plasship_orfhdr_free(ctx, hl); plasship_orfhdr_free(ctx, hs); plasship_seqdb_free(ctx, ol); plasship_seqdb_free(ctx, os); plasship_seqdb_free(ctx, in);
+        } else if ((prot && dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS) || (nuc && dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES)) {
+            fprintf(stdout, "%s: wrong input DB type %d\n", mod.c_str(), dbtype); return EXIT_FAILURE;
+        }
+        const double tPrep = now();
+        plasship_rescore_params rp; memset(&rp, 0, sizeof(rp));
+        rp.rescore_mode = f.rescoreMode; rp.eval_thr = f.evalThr; rp.seq_id_thr = f.seqIdThr; rp.cov_mode = f.covMode; rp.cov_thr = f.covThr; rp.min_aln_len = f.minAlnLen;
+        rp.seq_id_mode = f.seqIdMode; rp.add_backtrace = gd ? 1 : 0;
+        plasship_assemble_params ap; memset(&ap, 0, sizeof(ap));
+        ap.seq_id_thr = gd ? f.seqIdThrNucl : f.seqIdThr; ap.max_seq_len = f.maxSeqLen; ap.keep_target = f.keepTarget; ap.rescore_mode = f.rescoreMode;
+        unsigned long long overlaps = 0; double kernelMs = 0;
+        int hashShift = f.hashShift;
+        for (int it = 0; it < f.numIterations; it++) {
+            plasship_kmermatch_params kp; memset(&kp, 0, sizeof(kp));
+            kp.kmer_size = f.k; kp.alphabet_size = f.alph; kp.kmers_per_seq = f.kps; kp.kmers_per_seq_scale = nuc ? f.scaleNucl : f.scaleAA; kp.ignore_multi_kmer = f.ignoreMulti;
+            kp.cov_mode = f.covMode; kp.cov_thr = f.covThr;
+            // plass assemble: --hash-shift grows with every second iteration, iteration 0 keeps non-extendable matches (Assembler.cpp:99-110)
+            if (prot) { hashShift += it % 2; kp.hash_shift = hashShift; kp.include_only_extendable = it > 0; } else { kp.hash_shift = f.hashShift; kp.include_only_extendable = 1; }
+            plasship_seqdb *q = gd ? aa : db;
+            plasship_cands *c = nullptr; plasship_alns *al = nullptr; plasship_kmermatch_stats ks; plasship_rescore_stats rs; plasship_assemble_stats as;
+            if (plasship_kmermatch(ctx, q, &kp, &c, &ks) || plasship_rescore(ctx, q, q, c, &rp, &al, &rs)) return fail(mod.c_str());
+            if (prot && it == 0) {         // data/assemble.sh:110-141: findassemblystart, then k-mer matching and re-scoring again on the corrected sequences
+                plasship_seqdb *corr = nullptr; plasship_findstart_stats fs;
+                if (plasship_find_assembly_start(ctx, db, al, &corr, &fs)) return fail(mod.c_str());
+                plasship_alns_free(ctx, al); plasship_cands_free(ctx, c); plasship_seqdb_free(ctx, db); db = corr; q = db;
+                if (plasship_kmermatch(ctx, q, &kp, &c, &ks) || plasship_rescore(ctx, q, q, c, &rp, &al, &rs)) return fail(mod.c_str());
+            }
+            overlaps += ks.n_candidates; kernelMs += ks.ms_extract + ks.ms_sort1 + ks.ms_group + ks.ms_sort2 + ks.ms_reduce + rs.ms_kernel;
+            plasship_seqdb *next = nullptr, *nextAa = nullptr;
+            if (gd) {
+                plasship_alns *na = nullptr; plasship_aln2nucl_params np; np.gap_open = f.gapOpenNucl; np.gap_extend = f.gapExtendNucl; plasship_aln2nucl_stats ns;
+                if (plasship_aln2nucl(ctx, db, db, aa, aa, al, &np, &na, &ns) || plasship_guided_assemble(ctx, db, aa, na, &ap, &next, &nextAa, &as)) return fail(mod.c_str());
+                plasship_alns_free(ctx, na);
+            } else if (plasship_assemble(ctx, db, al, &ap, &next, &as)) return fail(mod.c_str());
+            kernelMs += as.ms_kernel;
+            plasship_alns_free(ctx, al); plasship_cands_free(ctx, c);
+            if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), plasship_last_error()); return EXIT_FAILURE; }   // the writer read `db`
+            plasship_seqdb_free(ctx, db); if (gd) plasship_seqdb_free(ctx, aa);
+            db = next; aa = nextAa;
+            if (nuc) {     // data/nuclassemble.sh:19-61,132: circular contigs leave the loop, the rest goes on
+                plasship_seqdb *cyc = nullptr, *rest = nullptr; plasship_cyclecheck_params cp; cp.max_seq_len = f.maxSeqLen; cp.chop_cycle = f.chopCycle; plasship_cyclecheck_stats cs;
+                if (plasship_cyclecheck(ctx, db, &cp, &cyc, &rest, &cs)) return fail(mod.c_str());
+                if (cs.n_cyclic && plasship_seqdb_write(ctx, cyc, (pos[1] + "_cycle_" + std::to_string(it)).c_str())) return fail(mod.c_str());
+                plasship_seqdb_free(ctx, cyc); plasship_seqdb_free(ctx, db); db = rest;
+            }
+            fprintf(stdout, "iteration %d: candidates %llu verified %llu extended %llu\n", it, (unsigned long long) ks.n_candidates, (unsigned long long) rs.n_accepted, (unsigned long long) as.n_extended);
+            if (it + 1 < f.numIterations) writeAsync(db, (gd ? "assembly_nucl_" : "assembly_") + std::to_string(it));
+        }
+        const double tLoop = now();
+        if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), plasship_last_error()); return EXIT_FAILURE; }
+        if (plasship_seqdb_write(ctx, db, pos[1].c_str()) || (gd && plasship_seqdb_write(ctx, aa, pos[2].c_str()))) return fail(mod.c_str());
+        const double tEnd = now();
+        fprintf(stdout, "chain: %d iterations, %llu candidate overlaps | read %.3fs preprocessing %.3fs iterations %.3fs (kernels %.3fs) write %.3fs\n", f.numIterations, overlaps,
+                tRead - t0, tPrep - tRead, tLoop - tPrep, kernelMs * 1e-3, tEnd - tLoop);
+        plasship_seqdb_free(ctx, db); if (gd) plasship_seqdb_free(ctx, aa);
+        if (wctx) plasship_ctx_destroy(wctx);
     }
     fprintf(stdout, "Time for processing: %.3fs\n", now() - t0);
     plasship_ctx_destroy(ctx);
