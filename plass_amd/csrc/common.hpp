@@ -11,6 +11,9 @@
 
 namespace plasship {
 
+uint64_t nextDbUid();                       // identity of a sequence DB handle (core.hip)
+struct KmerCache;                           // record cache of plasship_kmermatch (kmermatch.hip, section 8)
+void kmerCacheFree(plasship_ctx *ctx);
 void setError(const std::string &msg);
 // every wait of the host for the stream goes through here and is counted (plasship_host_syncs(): bench.py reports waits per iteration)
 hipError_t streamSync(hipStream_t st);
@@ -119,9 +122,14 @@ struct plasship_ctx {
     bool hasComm = false;
     plasship_comm comm = {};
     int debugFailCollective = -1;       // plasship_ctx_debug_fail_collective: countdown to an injected rank-local failure
+    plasship::KmerCache *kcache = nullptr;   // k-mer records of the unchanged short sequences, kept between calls (kmermatch.hip, section 8)
 };
 
 struct plasship_seqdb {
+    // identity and lineage (k-mer record cache of plasship_kmermatch, kmermatch.hip): every handle has its own uid; a DB an extension
+    // module made from another one with the SAME ids (keepTarget) names its parent and says which sequences differ from it
+    uint64_t uid = plasship::nextDbUid(), parentUid = 0;
+    plasship::DevBuf d_changed;   // uint8 [n]: 1 = the bytes of this sequence differ from the parent's (empty: no lineage)
     int dbtype = 0;
     size_t n = 0;
     uint64_t dataBytes = 0, residues = 0;

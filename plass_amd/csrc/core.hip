@@ -171,6 +171,8 @@ int tuneInt(const char *name, int dflt) {
 bool traceOn() { static const bool v = getenv("PLASSHIP_TRACE") != nullptr; return v; }
 void setError(const std::string &msg) { g_err = msg; }
 static std::atomic<unsigned long long> g_hostSyncs(0);
+static std::atomic<unsigned long long> g_dbUid(0);
+uint64_t nextDbUid() { return ++g_dbUid; }
 hipError_t streamSync(hipStream_t st) { g_hostSyncs++; return hipStreamSynchronize(st); }
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
     return std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
@@ -225,6 +227,8 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     (void) plasship::streamSync(ctx->stream);
+    plasship::poolEnter(ctx->stream);
+    plasship::kmerCacheFree(ctx);
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
     for (int i = 0; i < 2; i++) { if (ctx->stage[i]) (void) hipHostFree(ctx->stage[i]); if (ctx->stageEv[i]) (void) hipEventDestroy(ctx->stageEv[i]); }
     if (ctx->pinnedTable) (void) hipHostFree(ctx->pinnedTable);

@@ -673,7 +673,11 @@ struct ShortArgs {
     uint32_t *hugeList, *hugeCount; uint32_t hugeWindows;   //     and those with more than hugeWindows to this one (nullptr: no such list)
     unsigned long long *kstats;          // [0] residues, [1] records handled by this kernel
     uint32_t idLo, idHi; uint64_t slotBias;   // ids [idLo, idHi) (sharded run: this rank's share), records at arr[slotOff[id] - slotBias]
+    // STATIC mode (state != nullptr; building the record cache, section 8): slotOff counts k-mer records only (no identity record, no
+    // slots for sequences this kernel cannot take); a sequence it handles gets state 1 and its Util::hash, nothing is queued
+    uint8_t *state; uint64_t *seqHashOut;
 };
+constexpr uint16_t KILL_LEN = 0xFFFFu;          // `len` of a KILL record (section 8; real lengths of the 16-byte layout are below 32 767)
 
 template <bool LONG>
 __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
@@ -699,8 +703,8 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
             if (L > SHORT_MAXL || (size_t) nWin > consideredRaw) toWave = true;
             else {
                 const char *base = a.s.data + a.s.off[id];
-                const uint64_t slot = a.slotOff[id] - a.slotBias;
-                const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
+                const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]) + (a.state ? 1u : 0u);
+                const uint64_t slot = a.slotOff[id] - a.slotBias - (a.state ? 1ull : 0ull);     // static mode: no identity slot in front of the records
                 if (a.ignoreMulti) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 8; i++) q[i] = z; }
                 uint64_t idx = 0, seqHash = 0, fifoLo = 0, fifoHi = 0;   // fifo: the k codes of the current window, 8 bits each
                 uint64_t pw = 1;
@@ -745,17 +749,23 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                 }
                 if (!toWave) {
                     { R *d = arr + slot + 1 + (nOut & ~3u); const uint32_t rem = nOut & 3u; if (rem > 0) d[0] = pend0; if (rem > 1) d[1] = pend1; if (rem > 2) d[2] = pend2; }
-                    R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
-                    if constexpr (LONG) r.pad = 0;
-                    arr[slot] = r;
+                    if (!a.state) {
+                        R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
+                        if constexpr (LONG) r.pad = 0;
+                        arr[slot] = r;
+                    } else { a.state[id] = 1; a.seqHashOut[id] = seqHash; }
                     R sen; memset(&sen, 0xFF, sizeof(R));
                     for (uint32_t i = 1 + nOut; i < bound; i++) arr[slot + i] = sen;
-                    stRes += L; stRec += 1 + nOut;
+                    stRes += L; stRec += (a.state ? 0u : 1u) + nOut;
+                } else if (a.state) {                   // static mode: a possible repeat — the sequence stays dynamic, its slots stay empty
+                    R sen; memset(&sen, 0xFF, sizeof(R));
+                    for (uint32_t i = 1; i < bound; i++) arr[slot + i] = sen;
                 }
             }
         }
         // the queued sequences, one atomic per wavefront and list (the wave kernels' tiers are fed from these lists directly: a
         // queue filled one sequence at a time — one atomic on one counter per sequence — costs more than the tier it feeds)
+        if (a.state) continue;                              // static mode: nothing is queued (wave-uniform)
         const uint32_t nw = (toWave && active && a.s.len[id] >= (uint32_t) k) ? a.s.len[id] - (uint32_t) k + 1 : 0u;
         const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
         const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
@@ -773,6 +783,139 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
     }
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
+}
+
+// =====================================================================================================
+// 8. the record cache (single GPU, protein DBs, 16-byte records): kernels.  Orchestration and rationale: kmermatchCached below.
+// =====================================================================================================
+// slot bounds of the STATIC store: a sequence the thread-per-sequence kernel can take (every window is selected whatever the seed)
+// owns one slot per window; everything else none
+__global__ void staticBoundsKernel(const uint32_t *__restrict__ len, uint32_t n, int k, int kps, float scale, uint32_t *__restrict__ bound) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t L = len[i];
+        const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
+        const size_t consideredRaw = (size_t) ((float) (kps - 1) + (scale * (float) L));
+        bound[i] = (L <= SHORT_MAXL && (size_t) nWin <= consideredRaw) ? nWin : 0u;
+    }
+}
+// a static sequence whose bytes changed since the store was built (state 1 -> 2: its records must be killed, it becomes dynamic)
+__global__ void markChangedKernel(const uint8_t *__restrict__ changed, uint32_t n, uint8_t *__restrict__ state) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (changed[i] && state[i] == 1) state[i] = 2;
+}
+// slot bounds of a call with a valid store: static sequences own their identity record only; a sequence that has just changed also
+// owns kill slots (one per window of its OLD bytes, offsets from the store's copy of the DB it was built from)
+__global__ void dynBoundsKernel(const uint32_t *__restrict__ len, const uint8_t *__restrict__ state, const uint64_t *__restrict__ oldOff, uint32_t n, int k, int kps, float scale,
+                                uint32_t *__restrict__ bound, uint32_t *__restrict__ killBound) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int L = (int) len[i];
+        const uint8_t st = state[i];
+        bound[i] = (st == 1) ? 1u : (uint32_t) min(max(1, L - k + 2), (int) ((float) (size_t) kps + (scale * (float) L)));
+        uint32_t kb = 0;
+        if (st == 2) { const uint32_t oldL = (uint32_t) (oldOff[i + 1] - oldOff[i]) - 2u; kb = (oldL >= (uint32_t) k) ? oldL - (uint32_t) k + 1 : 0u; }
+        killBound[i] = kb;
+    }
+}
+struct ClassifyArgs {
+    SeqView s; const uint8_t *state; const uint64_t *seqHash; const uint64_t *slotOff; void *arr; uint64_t seed; int k;
+    uint32_t *waveList, *waveCount, *longList, *longCount, *hugeList, *hugeCount, *killList, *killCount; uint32_t longWindows, hugeWindows;
+    unsigned long long *kstats;
+};
+// what extractShortKernel does on a call without a store, for a call with one: static sequences get their identity record (the seed
+// changes it, kmermatcher.cpp:241-249), all others are queued for the wave-per-sequence tiers by window count
+__global__ __launch_bounds__(256) void classifyKernel(ClassifyArgs a) {
+    typedef Rec<false> R;
+    R *arr = reinterpret_cast<R *>(a.arr);
+    unsigned long long stRes = 0, stRec = 0;
+    const int lane = laneId();
+    for (uint32_t b0 = blockIdx.x * 256; b0 < a.s.n; b0 += gridDim.x * 256) {
+        const uint32_t id = b0 + threadIdx.x;
+        const bool active = id < a.s.n;
+        const uint8_t st = active ? a.state[id] : 1;
+        const uint32_t L = active ? a.s.len[id] : 0;
+        if (active && st == 1) {
+            R r; r.kmer = xxh64U64(a.seqHash[id], a.seed); r.id = id; r.len = (uint16_t) L; r.pos = 0;
+            arr[a.slotOff[id]] = r;
+            stRes += L; stRec += 1;
+        }
+        const bool dyn = active && st != 1;
+        const uint32_t nw = (dyn && L >= (uint32_t) a.k) ? L - (uint32_t) a.k + 1 : 0u;
+        const bool isHuge = dyn && nw > a.hugeWindows, isLong = dyn && !isHuge && nw > a.longWindows;
+        auto append = [&](bool mine, uint32_t *list, uint32_t *count) {
+            const unsigned long long m = __ballot(mine);
+            if (!m) return;
+            uint32_t basePos = 0;
+            if (lane == 0) basePos = atomicAdd(count, (uint32_t) __popcll(m));
+            basePos = __shfl(basePos, 0, 64);
+            if (mine) list[basePos + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL))] = id;
+        };
+        append(dyn && !isLong && !isHuge, a.waveList, a.waveCount);
+        append(isLong, a.longList, a.longCount);
+        append(isHuge, a.hugeList, a.hugeCount);
+        append(active && st == 2, a.killList, a.killCount);
+    }
+    stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
+    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
+}
+struct KillArgs {
+    const char *oldData; const uint64_t *oldOff; const uint32_t *killList, *killCount; const uint64_t *killOff; uint64_t killBase; void *arr; const unsigned char *map;
+    int k, xCode; uint64_t base, top, inv; int tz;
+    uint8_t *state; uint32_t *valueHist; int valueShift; unsigned long long *alive;
+};
+// KILL records of the sequences that have just changed: one per record the store holds for them — every window of the OLD bytes
+// without an X (the store only holds sequences in which no k-mer repeats) — with the record's k-mer, id and position and
+// len = KILL_LEN.  They travel through the partition like any record and remove their twin in the group kernel (groupLinesKernel<TWO>).
+__global__ __launch_bounds__(64) void killKernel(KillArgs a) {
+    typedef Rec<false> R;
+    __shared__ unsigned char sMap[256];
+    __shared__ uint32_t sHist[VH_BINS];
+    R *arr = reinterpret_cast<R *>(a.arr);
+    for (int i = threadIdx.x; i < 256; i += 64) sMap[i] = a.map[i];
+    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) sHist[i] = 0;
+    __syncthreads();
+    const uint32_t n = *a.killCount;
+    unsigned long long killed = 0;
+    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < n; w += gridDim.x * 64) {
+        const uint32_t id = a.killList[w];
+        const uint64_t o = a.oldOff[id]; const uint32_t L = (uint32_t) (a.oldOff[id + 1] - o) - 2u;
+        const char *base = a.oldData + o;
+        const uint64_t slot = a.killBase + a.killOff[id]; const uint32_t bound = (uint32_t) (a.killOff[id + 1] - a.killOff[id]);
+        uint64_t idx = 0, fifoLo = 0, fifoHi = 0, pw = 1; int lastX = -1; uint32_t nOut = 0;
+        for (uint32_t i = 0; i < L; i++) {
+            const unsigned char c = sMap[(unsigned char) base[i]];
+            if (c == (unsigned char) a.xCode) lastX = (int) i;
+            if (i < (uint32_t) a.k) {
+                idx += (uint64_t) c * pw; pw *= a.base;
+                if (i < 8) fifoLo |= (uint64_t) c << (8 * i); else fifoHi |= (uint64_t) c << (8 * (i - 8));
+            } else {
+                const uint64_t cOut = fifoLo & 0xFF;
+                idx = (((idx - cOut) >> a.tz) * a.inv) + (uint64_t) c * a.top;
+                fifoLo = (fifoLo >> 8) | (fifoHi << 56); fifoHi >>= 8;
+                if (a.k - 1 < 8) fifoLo |= (uint64_t) c << (8 * (a.k - 1)); else fifoHi |= (uint64_t) c << (8 * (a.k - 1 - 8));
+            }
+            if (i + 1 >= (uint32_t) a.k) {
+                const uint32_t p = i + 1 - a.k;
+                if (lastX < (int) p) {
+                    R r; r.kmer = idx; r.id = id; r.len = KILL_LEN; r.pos = (int16_t) p;
+                    arr[slot + nOut] = r; nOut++;
+                    atomicAdd(&sHist[valueBin<false>(idx, a.valueShift)], 1u);
+                }
+            }
+        }
+        R sen; memset(&sen, 0xFF, sizeof(R));
+        for (uint32_t i = nOut; i < bound; i++) arr[slot + i] = sen;
+        killed += nOut;
+        a.state[id] = 0;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) { const uint32_t c = sHist[i]; if (c) atomicSub(&a.valueHist[i], c); }
+    killed = waveReduceSumU64(killed);
+    if (threadIdx.x == 0 && killed) atomicAdd(a.alive, (unsigned long long) (0ull - killed));
+}
+__global__ void arenaStart2Kernel(const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ lineBeg2, uint32_t bpb, uint32_t gGrid, uint32_t nBuckets, uint64_t *__restrict__ arenaStart) {
+    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < gGrid; j += gridDim.x * blockDim.x) {
+        const uint32_t b = min(j * bpb, nBuckets - 1);
+        arenaStart[j] = ((uint64_t) lineBeg[b] + (uint64_t) lineBeg2[b]) * RPL;
+    }
 }
 
 __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
@@ -907,6 +1050,8 @@ struct GroupArgs {
     int includeOnlyExtendable, covMode; float covThr;
     const unsigned long long *minKey;   // NUCL: K of the globally first run
     unsigned long long *maxRepTarget;   // max over emitted records of (rep << 32 | member): the last run of sort #2
+    // groupLinesKernel<TWO> (record cache): the static store in front of `in`; [0] records grouped, [1] kill-set overflow flag
+    const void *in2; const uint32_t *list2, *lineBeg2, *lineCnt2; int hasKills; unsigned long long *cacheCounters; uint32_t killMax;
 };
 
 __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -1069,7 +1214,12 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 // 2^20 buckets two partition levels can make with ~4000 positions each, which 512 threads and 4096 slots take in one go (a
 // bucket beyond the registers would be read from HBM once per phase and sub-pass).  "At least two members" is one bit per slot.
 constexpr int GL_RMAX = 8;
-template <bool NUCL, int BLOCK, uint32_t HT, int WPE>
+// TWO (record cache, section 8): a bucket = the lines of the STATIC store (list2 / lineBeg2 / lineCnt2 over in2) followed by the lines
+// of this call's dynamic records.  KILL records among the latter (len == KILL_LEN) name static records of sequences that have
+// changed: they enter a small LDS set first, every static record found there is dropped and overwritten with a sentinel in the
+// store (so the kill is needed once), and the kill records themselves take no part in the grouping.
+constexpr uint32_t KILL_HT = 1024, KILL_MAX = 896;
+template <bool NUCL, int BLOCK, uint32_t HT, int WPE, bool TWO = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void groupLinesKernel(GroupArgs a) {
     typedef Rec<false> R;
     constexpr uint32_t MAXKEYS = HT / 4 * 3;                 // distinct k-mers per sub-pass before splitting further
@@ -1078,36 +1228,88 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     __shared__ uint32_t hMulti[HT / 32];                     // bit = a second record met this slot's k-mer
     __shared__ uint32_t sFlag[2];
     __shared__ uint32_t sCursor[2];                          // arena cursor of a sub-pass; two, used alternately, save a barrier per sub-pass
+    __shared__ unsigned long long sKill[TWO ? KILL_HT : 1];  // (id << 16 | pos) of the bucket's kill records
+    __shared__ uint32_t sKillCnt;
     const R *in = reinterpret_cast<const R *>(a.in);
+    const R *in2 = reinterpret_cast<const R *>(a.in2);
+    R *store = const_cast<R *>(in2);
+    unsigned long long seen = 0;                     // records that took part in the grouping (TWO: the call's N_k)
     R *out = reinterpret_cast<R *>(a.out);
     const uint32_t bBegin = blockIdx.x * a.bucketsPerBlock;
     const uint32_t bEnd = min(a.nBuckets, bBegin + a.bucketsPerBlock);
     if (bBegin >= a.nBuckets) { if (threadIdx.x == 0) a.outCount[blockIdx.x] = 0; return; }
     unsigned long long written = 0;                  // block-uniform
     unsigned long long maxRT = 0;
-    const uint64_t arena = (uint64_t) a.lineBeg[bBegin] * RPL;
+    const uint64_t arena = ((uint64_t) a.lineBeg[bBegin] + (TWO ? (uint64_t) a.lineBeg2[bBegin] : 0ull)) * RPL;
     const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
     const R none = [] { R r; r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; return r; }();
     // the records of a bucket are fetched (line list entry, then the record: two dependent round trips) as soon as the registers
     // of the previous bucket are dead — behind its last phase, ahead of the barriers that close it and of the table reset
     R rg[GL_RMAX];
-    uint32_t nNext = 0, lbNext = 0;
+    uint32_t nNext = 0, lbNext = 0, nSNext = 0, lb2Next = 0;       // nS: positions of the static store in front of the dynamic ones
+    auto recOf = [&](uint32_t i, uint32_t nS, uint32_t lb, uint32_t lb2) -> R {
+        if (TWO && i < nS) return in2[(uint64_t) a.list2[lb2 + i / RPL] * RPL + (i % RPL)];
+        const uint32_t d = i - nS;
+        return in[(uint64_t) a.list[lb + d / RPL] * RPL + (d % RPL)];
+    };
     auto fetch = [&](uint32_t b) {
-        nNext = (b < bEnd) ? a.lineCnt[b] * RPL : 0u; lbNext = (b < bEnd) ? a.lineBeg[b] : 0u;
+        nSNext = (TWO && b < bEnd) ? a.lineCnt2[b] * RPL : 0u; lb2Next = (TWO && b < bEnd) ? a.lineBeg2[b] : 0u;
+        nNext = nSNext + ((b < bEnd) ? a.lineCnt[b] * RPL : 0u); lbNext = (b < bEnd) ? a.lineBeg[b] : 0u;
         if (nNext && nNext <= (uint32_t) GL_RMAX * BLOCK) {
 #pragma unroll
-            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? in[(uint64_t) a.list[lbNext + i / RPL] * RPL + (i % RPL)] : none; }
+            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? recOf(i, nSNext, lbNext, lb2Next) : none; }
         }
     };
     uint32_t par = 0;                                // which cursor the current sub-pass uses (workgroup-uniform)
     fetch(bBegin);
     for (uint32_t b = bBegin; b < bEnd; b++) {
         const uint32_t n = nNext;                    // record positions of the bucket (padding sentinels included)
-        const uint32_t lb = lbNext;
+        const uint32_t lb = lbNext, nS = nSNext, lb2 = lb2Next;
         if (n == 0) { fetch(b + 1); continue; }
-        auto recAt = [&](uint32_t i) -> R { return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)]; };
         const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
         bool fetched = false;
+        bool killsHere = false;                      // this bucket has kill records: sKill holds their (id, position)
+        auto killKey = [](const R &r) { return ((unsigned long long) r.id << 16) | (unsigned long long) ((uint32_t) r.pos & 0xFFFFu); };
+        auto killed = [&](const R &r) {
+            if (isSentinel(r)) return false;
+            const unsigned long long key = killKey(r);
+            uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 54) & (KILL_HT - 1);
+            for (;;) { const unsigned long long v = sKill[slot]; if (v == key) return true; if (v == ~0ULL) return false; slot = (slot + 1) & (KILL_HT - 1); }
+        };
+        // (buckets beyond the registers are re-read in every phase: kill records take no part, killed static records are recognised by the set)
+        auto recAt = [&](uint32_t i) -> R { R r = recOf(i, nS, lb, lb2); if (TWO && (r.len == KILL_LEN || (killsHere && i < nS && killed(r)))) r = none; return r; };
+        if (TWO && a.hasKills) {
+            // ---- kill records first: their (id, position) into the LDS set, then every static record of the bucket is looked up ----
+            for (uint32_t i = threadIdx.x; i < KILL_HT; i += BLOCK) sKill[i] = ~0ULL;
+            if (threadIdx.x == 0) sKillCnt = 0;
+            __syncthreads();
+            auto killInsert = [&](const R &r) {
+                if (isSentinel(r) || r.len != KILL_LEN) return;
+                if (atomicAdd(&sKillCnt, 1u) >= a.killMax) { atomicExch(a.cacheCounters + 1, 1ull); return; }     // the host falls back to a full run
+                const unsigned long long key = killKey(r);
+                uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 54) & (KILL_HT - 1);
+                while (atomicCAS(&sKill[slot], ~0ULL, key) != ~0ULL) slot = (slot + 1) & (KILL_HT - 1);
+            };
+            if (inRegs) {
+#pragma unroll
+                for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; if (i >= nS && i < n) { killInsert(rg[j]); if (rg[j].len == KILL_LEN) rg[j] = none; } }
+            } else for (uint32_t i = nS + threadIdx.x; i < n; i += BLOCK) killInsert(recOf(i, nS, lb, lb2));
+            __syncthreads();
+            killsHere = sKillCnt != 0;
+            if (killsHere) {
+                // a killed record leaves the store for good (a sentinel in its place): the kill is needed once
+                if (inRegs) {
+#pragma unroll
+                    for (int j = 0; j < GL_RMAX; j++) {
+                        const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x;
+                        if (i < nS && killed(rg[j])) { rg[j] = none; store[(uint64_t) a.list2[lb2 + i / RPL] * RPL + (i % RPL)] = none; }
+                    }
+                } else for (uint32_t i = threadIdx.x; i < nS; i += BLOCK) if (killed(recOf(i, nS, lb, lb2))) store[(uint64_t) a.list2[lb2 + i / RPL] * RPL + (i % RPL)] = none;
+            }
+        } else if (TWO && inRegs) {
+#pragma unroll
+            for (int j = 0; j < GL_RMAX; j++) if (rg[j].len == KILL_LEN) rg[j] = none;
+        }
         // phase A on one record: claim the k-mer's slot, mark a second member, and bid for the run head; called by whole wavefronts
         // (new k-mers are counted once per wavefront, not with one LDS atomic per record on a single word)
         auto phaseA = [&](const R &r, uint32_t nSub, uint32_t sub) {
@@ -1117,6 +1319,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             if (!isSentinel(r) && !(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
                 uint32_t slot = (uint32_t) (hh >> 32) & (HT - 1);
                 full = true;
+                if (TWO) seen++;
                 for (uint32_t probe = 0; probe < HT; probe++) {
                     const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, K);
                     if (prev == ~0ULL || prev == K) {
@@ -1183,7 +1386,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             if (keep) out[arena + written + wbase + wr] = o;
         };
         uint32_t nSub = 1;                           // sub-passes by a secondary hash when too many distinct k-mers
-        const unsigned long long writtenAtBucketStart = written;
+        const unsigned long long writtenAtBucketStart = written, seenAtBucketStart = seen;
         for (;;) {
             bool redo = false;
             for (uint32_t sub = 0; sub < nSub && !redo; sub++) {
@@ -1207,7 +1410,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             }
             if (!redo) break;
             nSub *= 2;                               // a retry discards what completed sub-passes of this attempt wrote
-            written = writtenAtBucketStart;
+            written = writtenAtBucketStart; if (TWO) seen = seenAtBucketStart;
             __syncthreads();
         }
         if (!fetched) fetch(b + 1);                  // (cannot happen: the last sub-pass always completes; kept for the invariant)
@@ -1218,6 +1421,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         if (laneId() == 0 && maxRT) atomicMax(a.maxRepTarget, maxRT);
     }
     if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
+    if (TWO) { seen = waveReduceSumU64(seen); if (laneId() == 0 && seen) atomicAdd(a.cacheCounters, seen); }
 }
 
 // =====================================================================================================
@@ -1595,6 +1799,7 @@ __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const u
         if (tags && tags[i / RPL] == TAG_NONE) continue;                // tags == nullptr: every line is valid (received lines of a sharded run)
         const R r = g[i];
         if (isSentinel(r)) continue;
+        if constexpr (!LONG) { if (r.len == KILL_LEN) continue; }          // a KILL record of the record cache (section 8) is not a record
         uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
         if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
@@ -1782,7 +1987,7 @@ static int buildLineLists(plasship_ctx *ctx, const uint32_t *dTags, uint64_t cap
 
 // What the line path hands to the run reduction
 struct LinesOut { void *triples = nullptr; uint64_t nTriples = 0, Nk = 0, Nm = 0; std::vector<int64_t> stalePos; uint32_t staleT = 0; float msSort1 = 0, msGroup = 0, msSort2 = 0, msPart = 0; int nPart = 1;
-                  uint64_t exchangedRecordBytes = 0, exchangedTripleBytes = 0; };
+                  uint64_t exchangedRecordBytes = 0, exchangedTripleBytes = 0; bool cacheOverflow = false; };
 
 constexpr uint64_t HALO_SLACK = 1u << 16;
 
@@ -1916,6 +2121,131 @@ static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std
 
 static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; dst.bytes = src.bytes; src.p = nullptr; src.bytes = 0; }
 
+// =====================================================================================================
+// 8. THE RECORD CACHE (single GPU, protein DBs, 16-byte records).
+//    `plass assemble` calls kmermatcher once per iteration on a DB in which most sequences have not changed since the last call: an
+//    iteration extends 10-18 % of the 88 M sequences of a 50 M-read set, and a read fragment of up to ~72 residues contributes EVERY
+//    window whatever the hash seed (kmermatcher.cpp:223: n <= kmer-per-seq - 1), so its k-mer records are the same in every iteration.
+//    The reference recomputes and re-sorts them twelve times.  Here they are extracted and hash-partitioned ONCE into a STATIC STORE
+//    (the final-level line lists of linepart.hpp, kept in the context); later calls extract and partition only the DYNAMIC records —
+//    identity records (their key depends on the seed), sequences that have changed, long sequences — and the group kernel reads a
+//    bucket's static and dynamic lines together (groupLinesKernel<TWO>).
+//      * Which sequences are unchanged is not guessed: an output DB of the extension modules names its parent DB and carries a
+//        per-sequence `changed` byte (buildOutputDB, assemble.hip); a DB without that lineage rebuilds the store.
+//      * A static sequence that changes becomes dynamic for good; its records in the store are removed by KILL records — one per
+//        stored record, regenerated from the store's copy of the sequence's old bytes — that travel through the dynamic partition
+//        to the record's bucket, where the group kernel drops the record and overwrites it with a sentinel (once).
+//      * What the rest of the path needs from "all records" is kept exact: the count (alive static + dynamic), the value histogram of
+//        the stale-record check (static histogram minus kills + dynamic), the rank pass (both stores).
+//    The result is the reference's, bit for bit, by construction: the multiset of records a bucket's grouping sees is unchanged.
+//    PLASSHIP_KMER_CACHE=0 turns it off.
+// =====================================================================================================
+}  // namespace (anonymous)
+namespace plasship {
+struct KmerCache {
+    bool valid = false; uint64_t dbUid = 0; uint32_t N = 0;
+    int k = 0, alph = 0, kps = 0, ignoreMulti = 0; float scale = 0;
+    int b1 = 0, b2 = 0; uint32_t nBuckets = 0;              // bucket bits of the store = of every dynamic partition while it lives
+    DevBuf recs, list, tags, tot2, fineBeg, fineCnt; uint64_t capLines = 0;
+    DevBuf state, seqHash, data, off, vhist, counters;       // counters: [0] records grouped in the last call, [1] kill overflow, [2] alive static records
+    void clear() { valid = false; for (DevBuf *b : {&recs, &list, &tags, &tot2, &fineBeg, &fineCnt, &state, &seqHash, &data, &off, &vhist, &counters}) b->release(); }
+};
+void kmerCacheFree(plasship_ctx *ctx) { if (ctx && ctx->kcache) { ctx->kcache->clear(); delete ctx->kcache; ctx->kcache = nullptr; } }
+}  // namespace plasship
+namespace {
+// what kmermatchLines needs of the store
+struct StaticStoreView { const void *recs; const uint32_t *list, *tags, *fineBeg, *fineCnt; const uint64_t *totLines; uint64_t capLines; uint32_t *vhist; unsigned long long *counters; int hasKills; };
+
+static LineGeo lineGeometryBits(uint64_t totalSlots, int b1, int b2, int numCU) {       // caps for `totalSlots` with given bucket bits
+    LineGeo g; g.b1 = b1; g.b2 = b2; g.nb1 = 1u << b1; g.nb2 = b2 ? 1u << b2 : 0u;
+    g.totalLines = (totalSlots + RPL - 1) / RPL;
+    g.lastValid = g.totalLines ? (uint32_t) (totalSlots - (g.totalLines - 1) * RPL) : (uint32_t) RPL;
+    g.PL1 = pieceLinesFor(g.totalLines, g.nb1, numCU, 8);
+    g.nP1 = (g.totalLines + g.PL1 - 1) / g.PL1;
+    g.cap1 = std::max<uint64_t>(g.nP1 * ((uint64_t) g.PL1 + g.nb1), 1);
+    if (g.nb2) { g.PL2 = 0xFFFFFFFFu; g.maxP2 = g.nb1; g.cap2 = g.cap1 + (uint64_t) g.nb1 * g.nb2; }
+    return g;
+}
+
+// (re)builds the store from `db`: the thread-per-sequence kernel in static mode, then both partition levels; the result stays in `kc`
+static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, KmerCache &kc, const unsigned char *dMap, int xCode, int keyBits) {
+    typedef Rec<false> R;
+    hipStream_t st = ctx->stream;
+    const uint32_t N = (uint32_t) db->n; const int k = par->kmer_size, numCU = ctx->numCU;
+    kc.clear();
+    DevBuf dBound, dSlotOff, dScanTmp, dKS;
+    const size_t scanTmpBytes = exclusiveScanTmpBytes((size_t) N + 2) + (1u << 20);
+    if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess || dKS.alloc(32) != hipSuccess ||
+        kc.state.alloc((size_t) N + 1) != hipSuccess || kc.seqHash.alloc(((size_t) N + 1) * 8) != hipSuccess || kc.data.alloc(db->dataBytes + 64) != hipSuccess || kc.off.alloc(((size_t) N + 1) * 8) != hipSuccess ||
+        kc.vhist.alloc(VH_BINS * 4) != hipSuccess || kc.counters.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(kc.state.p, 0, (size_t) N + 1, st));
+    PH_CHECK(hipMemsetAsync(kc.vhist.p, 0, VH_BINS * 4, st));
+    PH_CHECK(hipMemsetAsync(kc.counters.p, 0, 32, st));
+    PH_CHECK(hipMemsetAsync(dKS.p, 0, 32, st));
+    PH_CHECK(hipMemcpyAsync(kc.data.p, db->d_data.p, db->dataBytes, hipMemcpyDeviceToDevice, st));
+    PH_CHECK(hipMemcpyAsync(kc.off.p, db->d_off.p, ((size_t) N + 1) * 8, hipMemcpyDeviceToDevice, st));
+    // bucket bits from ALL record slots of the DB (what a call without a store would use), slots of the store from the static bounds
+    uint64_t totals[2] = {0, 0};
+    hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
+    if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemcpyAsync(&totals[0], dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(staticBoundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
+    PH_CHECK(plasship::streamSync(st));                       // (the first total has to be on the host before the scan output is overwritten)
+    if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    PH_COPY_SYNC(st, &totals[1], dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost);
+    const LineGeo bits = lineGeometry(totals[0], false, numCU);
+    const LineGeo geo = lineGeometryBits(totals[1], bits.b1, bits.b2, numCU);
+    const uint64_t recCap = std::max<uint64_t>(totals[1], (uint64_t) RPL * std::max(geo.cap1, geo.cap2));
+    DevBuf dA, dB;
+    if (dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+    {
+        ShortArgs sa; memset(&sa, 0, sizeof(sa));
+        sa.s = db->view(); sa.slotOff = dSlotOff.as<uint64_t>(); sa.arr = dA.p; sa.map = dMap; sa.k = k; sa.xCode = xCode; sa.kps = par->kmers_per_seq; sa.ignoreMulti = par->ignore_multi_kmer;
+        sa.scale = par->kmers_per_seq_scale; sa.seed = 0; sa.base = (uint64_t) (par->alphabet_size - 1);
+        { uint64_t p = 1; for (int i = 0; i < k - 1; i++) p *= sa.base; sa.top = p; }
+        { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
+        sa.kstats = dKS.as<unsigned long long>(); sa.idLo = 0; sa.idHi = N; sa.slotBias = 0; sa.state = kc.state.as<uint8_t>(); sa.seqHashOut = kc.seqHash.as<uint64_t>();
+        if (N) hipLaunchKernelGGL((extractShortKernel<false>), dim3(std::min<uint32_t>((N + 63) / 64, (uint32_t) numCU * (uint32_t) tuneInt("SHORT", N > 20000000u ? 36 : 18))), dim3(64), 0, st, sa);
+    }
+    PH_CHECK(hipMemcpyAsync(kc.counters.as<unsigned long long>() + 2, dKS.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToDevice, st));      // alive static records
+    // ---- both partition levels (as in kmermatchLines, single GPU) ----
+    DevBuf dTag1, dList1, dCnt1, dStart1, dCur1, dPieces2, dNP2, dRegBeg, dRegEnd;
+    kc.nBuckets = geo.nb2 ? geo.nb1 * geo.nb2 : geo.nb1;
+    if (dTag1.alloc(geo.cap1 * 4) != hipSuccess || dList1.alloc(geo.cap1 * 4) != hipSuccess || dCnt1.alloc(LP_MAXB * 4) != hipSuccess || dStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dCur1.alloc(LP_MAXB * 4) != hipSuccess ||
+        kc.fineBeg.alloc((size_t) kc.nBuckets * 4) != hipSuccess || kc.fineCnt.alloc((size_t) kc.nBuckets * 4) != hipSuccess || kc.tot2.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+    if (geo.nP1 == 0) PH_CHECK(hipMemsetAsync(dTag1.p, 0xFF, geo.cap1 * 4, st));
+    {
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = dA.p; a.out = dB.p; a.tags = dTag1.as<uint32_t>(); a.totalLines = geo.totalLines; a.lastValidAll = geo.lastValid; a.pieceLines = geo.PL1; a.nb = geo.nb1;
+        a.key.shift = geo.b1 ? 64 - geo.b1 : 63; a.valueHist = kc.vhist.as<uint32_t>(); a.valueShift = std::max(0, keyBits - 11);
+        const int rc = launchLinePart<false, false, KEY_HASH, false, true>(ctx, a, geo.nP1); if (rc) return rc;
+    }
+    int rc = buildLineLists(ctx, dTag1.as<uint32_t>(), geo.cap1, geo.nb1, dCnt1.as<uint32_t>(), dStart1.as<uint32_t>(), dCur1.as<uint32_t>(), dList1.as<uint32_t>()); if (rc) return rc;
+    if (geo.nb2) {
+        if (kc.tags.alloc(geo.cap2 * 4) != hipSuccess || kc.list.alloc(geo.cap2 * 4) != hipSuccess || dPieces2.alloc((geo.maxP2 + 1) * sizeof(LinePiece)) != hipSuccess || dNP2.alloc(4) != hipSuccess ||
+            dRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRegEnd.alloc(LP_MAXB * 8) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, geo.PL2, geo.nb2, dPieces2.as<LinePiece>(), dNP2.as<uint32_t>(),
+                           dRegBeg.as<uint64_t>(), dRegEnd.as<uint64_t>(), kc.tot2.as<uint64_t>());
+        LinePartArgs a; memset(&a, 0, sizeof(a));
+        a.in = dB.p; a.list = dList1.as<uint32_t>(); a.out = dA.p; a.tags = kc.tags.as<uint32_t>(); a.pieces = dPieces2.as<LinePiece>(); a.nPieces = dNP2.as<uint32_t>(); a.nb = geo.nb2;
+        a.key.shift = 64 - geo.b1 - geo.b2;
+        rc = launchLinePart<false, false, KEY_HASH, true, false>(ctx, a, geo.maxP2); if (rc) return rc;
+        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(geo.nb1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) kc.tags.as<uint32_t>(), (const uint64_t *) dRegBeg.as<uint64_t>(),
+                           (const uint64_t *) dRegEnd.as<uint64_t>(), geo.nb1, geo.nb2, kc.list.as<uint32_t>(), kc.fineBeg.as<uint32_t>(), kc.fineCnt.as<uint32_t>());
+        moveBuf(kc.recs, dA); kc.capLines = geo.cap2;
+    } else {
+        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, kc.fineBeg.as<uint32_t>(), kc.fineCnt.as<uint32_t>());
+        const uint64_t cap = geo.cap1;
+        PH_CHECK(hipMemcpyAsync(kc.tot2.p, &cap, 8, hipMemcpyHostToDevice, st));
+        moveBuf(kc.recs, dB); moveBuf(kc.tags, dTag1); moveBuf(kc.list, dList1); kc.capLines = geo.cap1;
+    }
+    PH_CHECK(plasship::streamSync(st));                       // (`cap` and the temporaries go out of scope)
+    PH_CHECK(hipGetLastError());
+    kc.b1 = geo.b1; kc.b2 = geo.b2; kc.N = N; kc.k = k; kc.alph = par->alphabet_size; kc.kps = par->kmers_per_seq; kc.scale = par->kmers_per_seq_scale; kc.ignoreMulti = par->ignore_multi_kmer;
+    kc.dbUid = db->uid; kc.valid = true;
+    return PLASSHIP_OK;
+}
+
 // extraction has filled dA (`total` record slots of this rank's sequences, sentinels in unused slots).  Buffers dA / dB hold geo.cap2
 // resp. geo.cap1 lines (single GPU) or geo.cap1 lines each (sharded run).
 // Sharded run (commOf(ctx) != nullptr; `totalAll` = slots of all ranks): the bucket geometry is that of the WHOLE run, rank r owns the
@@ -1926,7 +2256,10 @@ static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; ds
 // triples of all ranks with the same kernels (aggSortKernel<TRIPLES>).
 template <bool NUCL, bool LONG>
 static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, const LineGeo &geo, uint64_t total,
-                          DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res) {
+                          DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res,
+                          const StaticStoreView *ss = nullptr) {
+    // ss (record cache, section 8; single GPU, protein, 16-byte records): dA holds only the call's DYNAMIC records (and KILL records);
+    // the group kernel reads every bucket's static lines in front of them
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
@@ -1956,7 +2289,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         LinePartArgs a; memset(&a, 0, sizeof(a));
         a.in = dA.p; a.out = dB.p; a.tags = dTag1.as<uint32_t>(); a.totalLines = geo.totalLines; a.lastValidAll = geo.lastValid; a.pieceLines = geo.PL1; a.nb = geo.nb1;
         a.key.shift = geo.b1 ? 64 - geo.b1 : 63; a.key.rangeBits = 0; a.key.repBase = 0;
-        a.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr; a.valueHist = dVHist.as<uint32_t>(); a.valueShift = valueShift;
+        a.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr; a.valueHist = dVHist.as<uint32_t>(); a.valueShift = valueShift; a.killAware = ss ? 1 : 0;
         PH_CHECK(hipEventRecord(ctx->ev[8], st));
         const int rc = launchLinePart<NUCL, LONG, KEY_HASH, false, true>(ctx, a, geo.nP1); if (rc) return rc;
         PH_CHECK(hipEventRecord(ctx->ev[9], st));
@@ -2047,6 +2380,10 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     if (cm) {
         if (geo.nb2) arenaBuf = dRx.p;
         else { if (dArena.alloc(std::max<uint64_t>(finalCap, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; } arenaBuf = dArena.p; }
+    } else if (ss) {
+        // static and dynamic lines of a workgroup's buckets together bound what it emits: arenas addressed by the sum of both line numbers
+        if (dArena.alloc(std::max<uint64_t>(finalCap + ss->capLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; }
+        arenaBuf = dArena.p;
     } else arenaBuf = geo.nb2 ? dB.p : dA.p;
     const uint32_t gBlocks = std::max<uint32_t>(1, std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 6)));
     const uint32_t bpb = (std::max<uint32_t>(nBuckets, 1) + gBlocks - 1) / gBlocks;
@@ -2060,14 +2397,27 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     ga.maxRepTarget = dMaxRT.as<unsigned long long>();
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
     // positions per bucket (sentinel padding included) decide the workgroup shape of the 16-byte-record kernel
-    const uint64_t avgPos = finalCap * RPL / std::max<uint32_t>(nBuckets, 1);
+    const uint64_t avgPos = (finalCap + (ss ? ss->capLines : 0)) * RPL / std::max<uint32_t>(nBuckets, 1);
     const bool wideGroup = !LONG && (getenv("PLASSHIP_GROUP_WIDE") ? atoi(getenv("PLASSHIP_GROUP_WIDE")) != 0 : avgPos > 1600);
-    if (nBuckets == 0) PH_CHECK(hipMemsetAsync(dOutCnt.p, 0, (size_t) gGrid * 8, st));
+    bool launchedTwo = false;
+    if constexpr (!NUCL && !LONG) {
+        if (ss && nBuckets) {
+            ga.in2 = ss->recs; ga.list2 = ss->list; ga.lineBeg2 = ss->fineBeg; ga.lineCnt2 = ss->fineCnt; ga.hasKills = ss->hasKills; ga.cacheCounters = ss->counters;
+            ga.killMax = std::min<uint32_t>(KILL_MAX, (uint32_t) tuneInt("KILL_MAX", (int) KILL_MAX));       // (PLASSHIP_TUNE_KILL_MAX: the tests force the overflow fallback with it)
+            if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
+            else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+            hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
+            launchedTwo = true;
+        }
+    }
+    if (launchedTwo) {}
+    else if (nBuckets == 0) PH_CHECK(hipMemsetAsync(dOutCnt.p, 0, (size_t) gGrid * 8, st));
     else if constexpr (LONG) hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     else if (wideGroup && tuneInt("GROUP_WPE", 4) == 4) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 4>), dim3(gGrid), dim3(512), 0, st, ga);
     else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 2>), dim3(gGrid), dim3(512), 0, st, ga);
     else hipLaunchKernelGGL((groupLinesKernel<NUCL, GR_BLOCK, GR_HT, 3>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-    if (nBuckets) hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
+    if (launchedTwo) {}
+    else if (nBuckets) hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
     else PH_CHECK(hipMemsetAsync(dArenaStart.p, 0, (size_t) gGrid * 8, st));
     std::vector<uint64_t> hOutCnt(gGrid), hArena(gGrid);
     unsigned long long hLastRun[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
@@ -2077,14 +2427,18 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hArena.data(), dArenaStart.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(ks, dKStats.p, 32, hipMemcpyDeviceToHost, st));
+    unsigned long long hCache[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHistS(ss ? VH_BINS : 0);
+    if (ss) { PH_CHECK(hipMemcpyAsync(hCache, ss->counters, 32, hipMemcpyDeviceToHost, st)); PH_CHECK(hipMemcpyAsync(hVHistS.data(), ss->vhist, VH_BINS * 4, hipMemcpyDeviceToHost, st)); }
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
+    if (ss && hCache[1]) { res.cacheOverflow = true; return PLASSHIP_OK; }       // a bucket held more kill records than its set takes: the caller runs without the store
     uint64_t NmLocal = 0;
     for (uint32_t j = 0; j < gGrid; j++) NmLocal += hOutCnt[j];
     uint64_t Nm = NmLocal;
-    const uint64_t NkLocal = ks[1] + ks[3];                  // records the extraction kernels of this rank wrote (sentinels excluded)
+    const uint64_t NkLocal = ss ? (uint64_t) hCache[0] : ks[1] + ks[3];   // records the extraction kernels of this rank wrote (sentinels excluded); with a store: records the group kernel met
     const uint64_t Nk = cm ? NkAll : NkLocal;                // ... and of the whole run
     std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
+    if (ss) for (uint32_t b = 0; b < VH_BINS; b++) hVHistG[b] += hVHistS[b];
     if (cm) {
         // the stale-record check below is a property of the WHOLE run: N_m, the last (rep, target) run and the value histogram are
         // reduced over the ranks; every rank then takes the same decisions (and the same collectives)
@@ -2111,7 +2465,8 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         const unsigned long long maxRT = hLastRun[0];
         res.staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
         const uint64_t so[2] = {hLastRun[1], hLastRun[2]}; const uint32_t tLen = (uint32_t) hLastRun[3];
-        const uint32_t tb = (uint32_t) (so[1] - so[0]);
+        // slots of T in a slot array WITHOUT a store (with one, a static T owns its identity slot only): computeKmerCount's bound
+        const uint32_t tb = (uint32_t) std::min(std::max(1, (int) tLen - par->kmer_size + 2), (int) ((float) (size_t) par->kmers_per_seq + (par->kmers_per_seq_scale * (float) tLen)));
         DevBuf dTRec, dTId, dTScr, dTOff, dTCap, dDiff;
         uint32_t cap = 64; while (cap < tLen + 1) cap <<= 1;
         const uint64_t zero = 0;
@@ -2121,6 +2476,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_CHECK(hipMemcpyAsync(dTOff.p, &zero, 8, hipMemcpyHostToDevice, st));
         PH_CHECK(hipMemcpyAsync(dTCap.p, &cap, 4, hipMemcpyHostToDevice, st));
         PH_CHECK(hipMemsetAsync(dDiff.p, 0, ((size_t) tb + 1) * 8, st));
+        PH_CHECK(hipMemsetAsync(dTRec.p, 0xFF, (size_t) tb * sizeof(R), st));
         // re-extract the records of T into a scratch array with the very kernel that produced them
         ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
         ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
@@ -2143,6 +2499,8 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
             PH_CHECK(hipMemcpyAsync(dTRec.p, trec.data(), (size_t) m * sizeof(R), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((rankLinesKernel<NUCL, LONG>), dim3(gridFor(finalCap * RPL, 256, (unsigned) numCU * 8)), dim3(256), 0, st, (const void *) finalRecs, finalTags, finalCap, geo.nb2 ? (const uint64_t *) dTot2.as<uint64_t>() : (const uint64_t *) nullptr,
                                (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
+            if (ss) hipLaunchKernelGGL((rankLinesKernel<NUCL, LONG>), dim3(gridFor(ss->capLines * RPL, 256, (unsigned) numCU * 8)), dim3(256), 0, st, ss->recs, ss->tags, ss->capLines, ss->totLines,
+                                       (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(plasship::streamSync(st));
@@ -2164,12 +2522,13 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     tm.start(0);
     // the hash-bucketed records are dead now (the group kernel's arenas live in another buffer): free them for the rep side
     if (cm) { dL2.release(); if (!geo.nb2) dRx.release(); }
+    else if (ss) { dA.release(); dB.release(); }
     else (finalRecs == dA.p ? dA : dB).release();
     dTag1.release(); dList1.release(); dTag2.release(); dList2.release(); dRxList.release();
     std::vector<std::pair<uint64_t, uint64_t>> arenas(gGrid);                 // the arenas are dense segments: (first line, records)
     for (uint32_t j = 0; j < gGrid; j++) arenas[j] = std::make_pair(hArena[j] / RPL, hOutCnt[j]);
     DevBuf dTriples, dRepStart; uint64_t nTriples = 0;
-    auto arenasConsumed = [&]() { if (cm) { if (geo.nb2) dRx.release(); else dArena.release(); } else (arenaBuf == dA.p ? dA : dB).release(); };
+    auto arenasConsumed = [&]() { if (cm) { if (geo.nb2) dRx.release(); else dArena.release(); } else if (ss) dArena.release(); else (arenaBuf == dA.p ? dA : dB).release(); };
     rc = repSortLines<NUCL, LONG, false>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, cm ? &dRepStart : nullptr);
     if (rc) return rc;
     if (cm) {
@@ -2342,7 +2701,9 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
 
 template <bool NUCL, bool LONG>
 int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
-                  plasship_kmermatch_stats *stats) {
+                  plasship_kmermatch_stats *stats, KmerCache *kc = nullptr, bool *cacheOverflow = nullptr) {
+    // kc (record cache, section 8: single GPU, protein DB, 16-byte records, store valid for THIS db): the slot array holds the dynamic
+    // records only — identity records of the static sequences, the sequences queued for the wave tiers, KILL records behind them
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
@@ -2361,6 +2722,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     tm.start(0);
+    DevBuf dKillBound, dKillOff; uint64_t killTotal = 0, dynTotal = 0;
+    if (kc) {
+        if (dKillBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dKillOff.alloc(((size_t) N + 2) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        if (N) hipLaunchKernelGGL(dynBoundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), kc->state.as<uint8_t>(), kc->off.as<uint64_t>(), N, k, par->kmers_per_seq,
+                                  par->kmers_per_seq_scale, dBound.as<uint32_t>(), dKillBound.as<uint32_t>());
+        if (exclusiveScanU32(st, dKillBound.as<uint32_t>(), dKillOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemcpyAsync(&killTotal, dKillOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    } else
     if (N) hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
     if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t total = 0;
@@ -2377,6 +2746,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(&total, dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
     }
+    if (kc) { dynTotal = total; total += killTotal; }            // the kill slots lie behind the sequences' own slots
     const uint32_t nMine = sHi - sLo;
 
     DevBuf dA, dB;   // ping-pong record arrays
@@ -2385,7 +2755,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     static const bool legacyPartition = getenv("PLASSHIP_LEGACY_PARTITION") != nullptr;
     const bool useLines = cm || !legacyPartition;            // (the dense partition below is a single-GPU cross-check path)
     if (cm && W > 1024) { setError("kmermatch: more than 1024 ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
-    const LineGeo geo = useLines ? lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W) : LineGeo();
+    const LineGeo geo = kc ? lineGeometryBits(total, kc->b1, kc->b2, ctx->numCU) : (useLines ? lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W) : LineGeo());
     // single GPU: both buffers serve level 1 and level 2 (and the group kernel's arenas); sharded run: the slot array / level-1 output,
     // and the packed send buffer of exchange 1 (at most cap1 lines)
     const uint64_t recCap = useLines ? std::max<uint64_t>(total, (uint64_t) RPL * (cm ? geo.cap1 : std::max(geo.cap1, geo.cap2))) : std::max<uint64_t>(total, 1);
@@ -2422,7 +2792,34 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     ea.kstats = dKStats.as<unsigned long long>();
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     bool twoLists = false;
-    if (!NUCL && k <= 16 && nMine) {
+    if constexpr (!NUCL && !LONG) {
+    if (kc && nMine) {
+        // the store holds the records of the static sequences: they get their identity record, everything else is queued for the tiers
+        DevBuf dKillList, dKillCount;
+        if (dKillList.alloc(((size_t) N + 1) * 4) != hipSuccess || dKillCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemsetAsync(dKillCount.p, 0, 4, st));
+        ClassifyArgs ca; memset(&ca, 0, sizeof(ca));
+        ca.s = ea.s; ca.state = kc->state.as<uint8_t>(); ca.seqHash = kc->seqHash.as<uint64_t>(); ca.slotOff = ea.slotOff; ca.arr = ea.arr; ca.seed = ea.seed; ca.k = k;
+        ca.waveList = dWaveList.as<uint32_t>(); ca.waveCount = dWaveCount.as<uint32_t>(); ca.longList = dLongList.as<uint32_t>(); ca.longCount = dLongCount.as<uint32_t>();
+        ca.hugeList = dOvIds.as<uint32_t>(); ca.hugeCount = dOvCnt.as<uint32_t>(); ca.killList = dKillList.as<uint32_t>(); ca.killCount = dKillCount.as<uint32_t>();
+        ca.longWindows = TIER0_WINDOWS; ca.hugeWindows = 64 * 16; ca.kstats = dKStats.as<unsigned long long>();
+        hipLaunchKernelGGL(classifyKernel, dim3(std::min<uint32_t>((N + 255) / 256, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, ca);
+        if (killTotal) {
+            KillArgs ka; memset(&ka, 0, sizeof(ka));
+            ka.oldData = kc->data.as<char>(); ka.oldOff = kc->off.as<uint64_t>(); ka.killList = dKillList.as<uint32_t>(); ka.killCount = dKillCount.as<uint32_t>(); ka.killOff = dKillOff.as<uint64_t>();
+            ka.killBase = dynTotal; ka.arr = ea.arr; ka.map = ea.map; ka.k = k; ka.xCode = ea.xCode; ka.base = (uint64_t) (alph - 1); ka.top = ea.powers[k - 1];
+            { uint64_t b = ka.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; ka.tz = tz; ka.inv = inv; }
+            ka.state = kc->state.as<uint8_t>(); ka.valueHist = kc->vhist.as<uint32_t>();
+            { int kb = 0; long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (kb < 63 && (long double) (1ULL << kb) < v) kb++; ka.valueShift = std::max(0, kb - 11); }
+            ka.alive = kc->counters.as<unsigned long long>() + 2;
+            hipLaunchKernelGGL(killKernel, dim3((unsigned) std::min<uint64_t>((N + 63) / 64, (uint64_t) ctx->numCU * 16)), dim3(64), 0, st, ka);
+        }
+        PH_CHECK(plasship::streamSync(st));                  // (the two lists above go out of scope; the tiers below read device counters only)
+        twoLists = true;
+        ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
+    }
+    }
+    if (!kc && !NUCL && k <= 16 && nMine) {
         // short sequences: one thread each; everything else is queued for the wave-per-sequence kernels, in two lists by length
         ShortArgs sa; memset(&sa, 0, sizeof(sa));
         sa.s = ea.s; sa.slotOff = ea.slotOff; sa.arr = ea.arr; sa.map = ea.map; sa.k = k; sa.xCode = ea.xCode; sa.kps = ea.kps; sa.ignoreMulti = ea.ignoreMulti;
@@ -2505,8 +2902,15 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         int keyBitsL = 0;
         if (NUCL) keyBitsL = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBitsL < 63 && (long double) (1ULL << keyBitsL) < v) keyBitsL++; }
         LinesOut lo;
-        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo);
+        StaticStoreView sv; memset(&sv, 0, sizeof(sv));
+        if (kc) {
+            sv.recs = kc->recs.p; sv.list = kc->list.as<uint32_t>(); sv.tags = kc->tags.as<uint32_t>(); sv.fineBeg = kc->fineBeg.as<uint32_t>(); sv.fineCnt = kc->fineCnt.as<uint32_t>();
+            sv.totLines = kc->tot2.as<uint64_t>(); sv.capLines = kc->capLines; sv.vhist = kc->vhist.as<uint32_t>(); sv.counters = kc->counters.as<unsigned long long>(); sv.hasKills = killTotal ? 1 : 0;
+            PH_CHECK(hipMemsetAsync(kc->counters.p, 0, 16, st));        // [0] records grouped, [1] overflow flag; [2] (alive static records) stays
+        }
+        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, kc ? &sv : nullptr);
         if (rcL) return rcL;
+        if (lo.cacheOverflow) { if (cacheOverflow) *cacheOverflow = true; return PLASSHIP_OK; }
         std::unique_ptr<plasship_cands> holderL; uint64_t NcL = 0; float msReduceL = 0;
         rcL = reduceToCandidates<NUCL, LONG>(ctx, db, lo.triples, lo.nTriples, lo.stalePos, lo.staleT, holderL, NcL, msReduceL);
         if (rcL) return rcL;
@@ -2818,5 +3222,32 @@ extern "C" int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, c
     PH_ENTER(ctx);
     const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX);     // kmermatcher.cpp:797-802
     if (nucl) return commFinish(ctx, lng ? kmermatchImpl<true, true>(ctx, db, par, out, stats) : kmermatchImpl<true, false>(ctx, db, par, out, stats));
+    // ---- the record cache (section 8): single GPU, protein, 16-byte records ----
+    static const bool cacheOn = [] { const char *e = getenv("PLASSHIP_KMER_CACHE"); return e ? atoi(e) != 0 : true; }();
+    static const bool legacy = getenv("PLASSHIP_LEGACY_PARTITION") != nullptr;
+    if (cacheOn && !legacy && !lng && !commOf(ctx) && par->kmer_size <= 16 && db->n > 0) {
+        if (!ctx->kcache) ctx->kcache = new KmerCache();
+        KmerCache &kc = *ctx->kcache;
+        const bool same = kc.valid && kc.N == (uint32_t) db->n && kc.k == par->kmer_size && kc.alph == par->alphabet_size && kc.kps == par->kmers_per_seq &&
+                          kc.scale == par->kmers_per_seq_scale && kc.ignoreMulti == par->ignore_multi_kmer;
+        const bool hit = same && kc.dbUid == db->uid, child = same && !hit && db->parentUid == kc.dbUid && db->d_changed.p != nullptr;
+        hipStream_t st = ctx->stream;
+        if (!hit && !child) {
+            const unsigned char *map = aa2numTable(false, par->alphabet_size);
+            DevBuf dMap; if (dMap.alloc(256) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            PH_CHECK(hipMemcpyAsync(dMap.p, map, 256, hipMemcpyHostToDevice, st));
+            int keyBits = 0; { long double v = 1; for (int i = 0; i < par->kmer_size; i++) v *= (long double) (par->alphabet_size - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
+            const int rc = buildStaticStore(ctx, db, par, kc, dMap.as<unsigned char>(), map[(int) 'X'], keyBits);
+            if (rc) { kc.clear(); return rc; }
+        } else if (child) {
+            hipLaunchKernelGGL(markChangedKernel, dim3(gridFor(db->n, 256, 4096)), dim3(256), 0, st, db->d_changed.as<uint8_t>(), (uint32_t) db->n, kc.state.as<uint8_t>());
+            kc.dbUid = db->uid;
+        }
+        bool overflow = false;
+        const int rc = kmermatchImpl<false, false>(ctx, db, par, out, stats, &kc, &overflow);
+        if (rc) { kc.clear(); return rc; }                    // (a failed call may have consumed kill records half-way: the store is rebuilt next time)
+        if (!overflow) return PLASSHIP_OK;
+        kc.clear();                                           // more kill records in a bucket than its set takes: this call runs without a store, the next one rebuilds it
+    } else if (ctx->kcache) ctx->kcache->clear();
     return commFinish(ctx, lng ? kmermatchImpl<false, true>(ctx, db, par, out, stats) : kmermatchImpl<false, false>(ctx, db, par, out, stats));
 }

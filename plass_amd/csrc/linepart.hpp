@@ -104,6 +104,7 @@ struct LinePartArgs {
     int direct;                                  // records of lines that complete inside a tile go straight to HBM (see linePartKernel)
     unsigned long long *minKey;                  // optional (EXTRAS, NUCL): global minimum of (kmer | BIT63) (first-run quirk)
     uint32_t *valueHist; int valueShift;         // optional (EXTRAS)
+    int killAware;                               // EXTRAS, 16-byte records: records with len == 0xFFFF (KILL records of the record cache) stay out of the value histogram
 };
 
 static inline size_t linePartLdsBytes(uint32_t nb, size_t recBytes, bool extras) {
@@ -173,7 +174,9 @@ __global__ __launch_bounds__(LP_BLOCK) void linePartKernel(LinePartArgs a) {
                         const uint32_t b = lineBucket<NUCL, MODE>(a.key, rec[u].kmer, nb);
                         bk[u] = b; sq[u] = atomicAdd(&cnt[b], 1u); pending |= 1u << u;
                         if (EXTRAS) {
-                            if (a.valueHist) atomicAdd(&vh[valueBin<NUCL>(rec[u].kmer, a.valueShift)], 1u);
+                            bool counts = true;
+                            if constexpr (!LONG) counts = !(a.killAware && rec[u].len == 0xFFFFu);
+                            if (a.valueHist && counts) atomicAdd(&vh[valueBin<NUCL>(rec[u].kmer, a.valueShift)], 1u);
                             if (NUCL && a.minKey) mn = min(mn, (unsigned long long) (rec[u].kmer | BIT63));
                         }
                     }
