@@ -62,25 +62,31 @@ def hash_shift(it):
     return hs
 
 
-def synth_params(cfg, pairs=None):
-    """SynthParams of a config; another number of pairs keeps the coverage (the community shrinks / grows with the reads)"""
+def synth_params(cfg, pairs=None, min_genomes=0):
+    """SynthParams of a config; another number of pairs keeps the coverage (the community shrinks / grows with the reads).
+    min_genomes: a small sample of a community config keeps at least that many genomes (shorter ones, same total bases), so that
+    its coverage stays SKEWED like the full workload's (the CPU baseline's sample)"""
     import plass_amd
     _, p0, g, lo, hi, sigma, seed, _ = CONFIGS[cfg]
     pairs = p0 if not pairs else pairs
     if pairs != p0:
         if g > 1:
+            bases = (lo + hi) / 2.0 * g * pairs / p0                  # total genome bases at the config's coverage
             g = max(1, int(round(g * pairs / p0)))
-            if g == 1:
+            if g < min_genomes:
+                g = min_genomes
+                lo, hi = max(20000, int(0.5 * bases / g)), max(30000, int(1.5 * bases / g))
+            elif g == 1:
                 lo = hi = max(30000, int(3000000 * 200 * pairs / p0))
         else:
             lo = hi = max(30000, int(lo * pairs / p0))
     return plass_amd.SynthParams(n_pairs=pairs, seed=seed, n_genomes=g, genome_min_len=lo, genome_max_len=hi, abundance_sigma=sigma)
 
 
-def build_workload(ctx, cfg, pairs=None):
+def build_workload(ctx, cfg, pairs=None, min_genomes=0):
     """reads in HBM -> protein fragment DB (the DB iteration 0 starts from); returns (db, description dict)"""
     t0 = time.perf_counter()
-    sp = synth_params(cfg, pairs)
+    sp = synth_params(cfg, pairs, min_genomes)
     reads, sst = ctx.synth_read_pairs(sp)
     t1 = time.perf_counter()
     frag = ctx.plass_fragments(reads)
@@ -133,22 +139,46 @@ def stage_table(kst, rst, ast):
                               kst.residues + 4 * s * Nk + 4 * s * Nm + 12 * Nc, False, 1)
     for i, (name, single) in enumerate((("assembleGroupKernel<16>", True), ("assembleGroupKernel<32>+<64>", False), ("assembleBigKernel", True))):
         t[name] = (ast.ms_tier_kernel[i], 32 * ast.tier_alignments[i] + 2 * ast.tier_query_residues[i] + 2 * ast.tier_rescored_residues[i], single, 1)
+    # the other two modules as whole stages, against SURVEY.md section 8d's B_R = (12 + 2 ov + 32) N_c and B_A = 32 N_aln + 2 R + 2 ov N_resc
+    # (every kernel of the module: work lists, compaction, the extension tiers, writing the next DB)
+    t["rescore_stage"] = (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored, False, 1)
+    t["assemble_stage"] = (ast.ms_kernel, 32 * ast.n_alignments + 2 * kst.residues + 2 * ast.rescored_residues, False, 1)
     return t
 
 
+def source_sha():
+    """sha256 over the product sources the library is built from (plass_amd/csrc, include/): a stored profile is only quoted for
+    the code it was taken from (there is no .git on the GPU box to ask)"""
+    import hashlib
+    h = hashlib.sha256()
+    for d in (os.path.join(ROOT, "plass_amd", "csrc"), os.path.join(ROOT, "include")):
+        for f in sorted(os.listdir(d)):
+            if f.endswith((".hip", ".hpp", ".cpp", ".h")):
+                h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+# rocprofv3 names of the kernels behind a row of the stage table (all instantiations of a template are one row)
+KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShortKernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
+                  "partitionKernel(k-mer records)": "linePartKernel<.*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel"}
+
+
 def stored_traffic(kernel, launches_per_step):
-    """HBM bytes per launch of `kernel` (all its instantiations together) from the stored PMC passes of this command (profiles/
-    r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md
-    prescribes for gfx950), or None.  A stored figure, not measured in this run: PMC collection serialises the kernels."""
-    f = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+    """(HBM bytes per launch of `kernel` — all its instantiations together — from the stored PMC passes of the driver's command, note).
+    profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950; the file records the hash of the sources it was measured on and is refused for any
+    other code.  A stored figure, not measured in this run: PMC collection serialises the kernels."""
+    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
     try:
         rows = json.load(open(f))
     except (OSError, ValueError):
-        return None
-    key = re.sub(r"[<(].*", "", kernel)
-    tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for name, r in rows.get("kernels", {}).items() if re.search(r"::%s[<(]" % re.escape(key), name))
+        return None, "no stored PMC profile (profiles/r03_pmc_traffic.json)"
+    if rows.get("source_sha") != source_sha():
+        return None, "profiles/r03_pmc_traffic.json was taken from other sources (%s, this build %s): not quoted" % (rows.get("source_sha"), source_sha())
+    pat = KERNEL_SYMBOLS.get(kernel, re.escape(re.sub(r"[<(].*", "", kernel)) + "[<(]")
+    tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for name, r in rows.get("kernels", {}).items() if re.search(pat, name))
     steps = rows.get("steps", 0)
-    return tot / steps / max(launches_per_step, 1e-9) if tot and steps else None
+    return (tot / steps / max(launches_per_step, 1e-9), rows.get("source", "")) if tot and steps else (None, "the stored profile has no row for " + kernel)
 
 
 def cpu_baseline(ctx, cfg, sample_pairs, iters):
@@ -162,7 +192,7 @@ def cpu_baseline(ctx, cfg, sample_pairs, iters):
     threads = max(1, min(len(os.sched_getaffinity(0)), 64))
     if sample_pairs <= 0:                                    # ~10-30 s of CPU work whatever the core count
         sample_pairs = 40000 if threads < 8 else 120000
-    db, desc = build_workload(ctx, cfg, sample_pairs)
+    db, desc = build_workload(ctx, cfg, sample_pairs, min_genomes=5)      # >= 5 genomes with log-normal abundances: skewed like the GPU workload
     thr = ["--threads", str(threads)]
     tot_t, tot_c, cli_t, cli_c = 0.0, 0, 0.0, 0
     hip = os.path.join(ROOT, "plass_amd", "plass-hip")
@@ -191,7 +221,7 @@ def cpu_baseline(ctx, cfg, sample_pairs, iters):
             for e in (e1, e2, e3):                           # "oracle <module>: …, 1.234 s" (other lines may follow: a profiler attached to the child)
                 tot_t += float(re.search(r"^oracle \w+:.*?([0-9.]+) s\s*$", e, re.M).group(1))
     res = {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
-           "sample": "%d read pairs of the same community model at the same coverage (%d genomes, %d protein fragments), iterations 0..%d of the chain, "
+           "sample": "%d read pairs of the same community model at the same mean coverage, skewed (%d genomes, log-normal abundances sigma 1; %d protein fragments), iterations 0..%d of the chain, "
                      "oracle module compute time (no DB I/O), %d OpenMP threads (grouping and result writing are single-threaded, as in the reference)"
                      % (desc["read_pairs"], desc["genomes"], desc["protein_fragments"], iters - 1, threads),
            # the unmodified reference (AVX2, 8 threads) against this port in the build container
@@ -208,7 +238,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="timed iterations (default: one traversal of the config's chain)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed iterations first (default: one traversal of the chain)")
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="c3 = BASELINE configs[2]/[3] (50 M reads, default); c2 = configs[1] (1 M reads)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c3", help="c3 = BASELINE configs[2]/[3] (50 M reads, default); c2 = configs[1] (1 M reads); c5 = configs[4] (PenguiN chains, 20 M reads, one GPU)")
     ap.add_argument("--pairs", type=int, default=0, help="read pairs of the whole job (0 = the config's own; the community scales with it)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="0 = 40000 below 8 host cores, 120000 otherwise")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -219,6 +249,8 @@ def main():
     ap.add_argument("--mode", choices=["auto", "sharded", "partitions"], default="auto",
                     help="N > 1: 'sharded' = the one read set over the GPUs with RCCL all-to-all (default); 'partitions' = N independent sets of 1/N the size")
     args = ap.parse_args()
+    if args.config == "c5":
+        return main_c5(args)
 
     import torch
     import plass_amd
@@ -351,8 +383,13 @@ def main():
             bytes_avg = tot[dom][1] / max(tot[dom][3], 1)
             achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
             km = tot["kmermatcher_stage"]
+            traffic, traffic_note = stored_traffic(dom, tot[dom][3] / len(stats))
+            stage = lambda key: {"algorithmic_bytes_per_step": tot[key][1] / len(stats), "ms_per_step": tot[key][0] / len(stats),
+                                 "frac": (tot[key][1] / (tot[key][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot[key][0] > 0 else 0.0}
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": stored_traffic(dom, tot[dom][3] / len(stats)), "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
+                    "kernel_note": "`%s` = every instantiation of that kernel template launched in a step, timed together with HIP events on the library's stream "
+                                   "(rocprofv3 lists the instantiations as separate symbols: profiles/r03_kernel_stats_driver_cmd.txt)" % dom,
+                    "traffic": traffic, "traffic_note": traffic_note, "rescore_stage": stage("rescore_stage"), "assemble_stage": stage("assemble_stage"), "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
                     "stage_ms_per_step": {k: round(v[0] / len(stats), 4) for k, v in tot.items()},
                     "kmermatcher_stage": {"algorithmic_bytes_per_step": km[1] / len(stats), "ms_per_step": km[0] / len(stats),
                                           "frac": (km[1] / (km[0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if km[0] > 0 else 0.0},
@@ -472,6 +509,176 @@ def main():
         sys.stderr.flush()
         ctypes.CDLL(None).fflush(None)
         print(json.dumps(line), flush=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# --config c5: BASELINE configs[4] — PenguiN's nucleotide-level chains on the 20 M-read set (single GPU)
+# ---------------------------------------------------------------------------------------------------------------------------
+def penguin_step(ctx, st, it, gd_iters):
+    """one step of the c5 chain: iterations 0..gd_iters-1 = protein-guided (kmermatcher on the ORFs' protein twins, rescorediagonal -a 1,
+    proteinaln2nucl, guidedassembleresults: data/guidedNuclAssemble.sh:77-126), the rest = nucleotide (kmermatcher -k 22, rescorediagonal,
+    nuclassembleresults, cyclecheck --chop-cycle: data/nuclassemble.sh:95-137) on the reads.  Returns (kst, rst, ast, extra ms, kind)"""
+    import plass_amd
+    if it < gd_iters:
+        if it == 0:
+            st["nu"], st["aa"] = st["nu0"], st["aa0"]
+        nu, aa = st["nu"], st["aa"]
+        c, kst = ctx.kmermatcher(aa, plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.1, hash_shift=67, include_only_extendable=True,
+                                                             ignore_multi_kmer=True, cov_mode=1, c=0.0))
+        a, rst = ctx.rescorediagonal(aa, aa, c, plass_amd.RescoreParams(min_seq_id=0.97, cov_mode=1, a=True))
+        na, nst = ctx.proteinaln2nucl(nu, aa, a)
+        nu2, aa2, ast = ctx.guidedassembleresults(nu, aa, na)
+        for x in (na, a, c):
+            x.free()
+        if nu is not st["nu0"]:
+            nu.free(); aa.free()
+        st["nu"], st["aa"] = nu2, aa2
+        return kst, rst, ast, nst.ms_kernel, "guided"
+    if it == gd_iters:
+        if st.get("nu") is not None and st["nu"] is not st["nu0"]:
+            st["nu"].free(); st["aa"].free()
+        st["nu"] = st["aa"] = None
+        if st.get("db") is not None and st["db"] is not st["reads"]:
+            st["db"].free()                                  # the rest of the previous traversal
+        st["db"] = st["reads"]
+    db = st["db"]
+    c, kst = ctx.kmermatcher(db, plass_amd.KmermatchParams(k=22, alph_size=5, kmer_per_seq=60, kmer_per_seq_scale=0.1, hash_shift=67, include_only_extendable=True,
+                                                         ignore_multi_kmer=True, cov_mode=0, c=0.0))
+    a, rst = ctx.rescorediagonal(db, db, c, plass_amd.RescoreParams(min_seq_id=0.99))
+    out, ast = ctx.assembleresults(db, a, plass_amd.AssembleParams(min_seq_id=0.99, max_seq_len=200000))
+    cyc, rest, cst = ctx.cyclecheck(out, max_seq_len=200000, chop_cycle=True, with_rest=True)
+    for x in (a, c, cyc, out):
+        x.free()
+    if db is not st["reads"]:
+        db.free()
+    st["db"] = rest
+    return kst, rst, ast, cst.ms_kernel, "nucleotide"
+
+
+def main_c5(args):
+    import torch
+    import plass_amd
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.gpus > 1:
+        raise SystemExit("--config c5 runs on one GPU (the sharded bench is --config c3)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    cfg_idx, cfg_pairs, _, _, _, _, _, chain = CONFIGS["c5"]
+    chain, gd_iters = 10, 5                                   # 5 protein-guided + 5 nucleotide iterations
+    pairs = args.pairs or cfg_pairs
+    steps = chain if args.steps is None else args.steps
+    warmup = chain if args.warmup is None else args.warmup
+    ctx = plass_amd.Context(0)
+    sp = synth_params("c5", pairs)
+    reads, sst = ctx.synth_read_pairs(sp)
+    nu0, aa0 = ctx.penguin_guided_inputs(reads)
+    st = {"reads": reads, "nu0": nu0, "aa0": aa0}
+    ri, ni = reads.info(), nu0.info()
+
+    def run(n, record):
+        rows, total = [], 0
+        for s_ in range(n):
+            it = s_ % chain
+            ts = time.perf_counter()
+            kst, rst, ast, extra, kind = penguin_step(ctx, st, it, gd_iters)
+            if record:
+                ctx.sync()
+                rows.append((it, (time.perf_counter() - ts) * 1e3, kst, rst, ast, extra, kind)); total += kst.n_candidates
+        return rows, total
+
+    run(warmup, False)
+    ctx.sync(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rows, overlaps = run(steps, True)
+    ctx.sync(); torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    tot = {}
+    for (_, _, k, r, a, extra, kind) in rows:
+        tab = stage_table(k, r, a)
+        tab["proteinaln2nucl / cyclecheck"] = (extra, 0, False, 1)
+        for key, (ms, b, single, launches) in tab.items():
+            v = tot.setdefault(key, [0.0, 0, single, 0]); v[0] += ms; v[1] += b; v[3] += launches
+    dom = max((k for k in tot if tot[k][2]), key=lambda k: tot[k][0])
+    ms_avg = tot[dom][0] / max(tot[dom][3], 1); bytes_avg = tot[dom][1] / max(tot[dom][3], 1)
+    achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
+    stage = lambda key: {"algorithmic_bytes_per_step": tot[key][1] / len(rows), "ms_per_step": tot[key][0] / len(rows),
+                         "frac": (tot[key][1] / (tot[key][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot[key][0] > 0 else 0.0}
+    line = {"metric": "read-overlaps/s per assembly iteration", "value": overlaps / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
+            "ms_per_step": elapsed * 1e3 / max(steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8/u64 (integer hash, byte compare; f32/f64 comparator)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4] on ONE GPU: %d synthetic 2x150 nt reads (%d pairs from %d genomes, %.1fx mean coverage, seed %d); step s = iteration (s mod 10) of: "
+                                   "5 protein-guided iterations on the %d ORFs of the reads and their protein twins (kmermatcher k=14 -> rescorediagonal -a 1 -> proteinaln2nucl -> "
+                                   "guidedassembleresults), then 5 nucleotide iterations on the reads (kmermatcher k=22 -> rescorediagonal -> nuclassembleresults -> cyclecheck --chop-cycle). "
+                                   "The workflow's own nucleotide stage starts from the extended ORFs + the reads (an index filter of the workflow script, not a hot-path module)"
+                                   % (ri["n"], sp.n_pairs, sp.n_genomes, sst.mean_coverage, sp.seed, ni["n"]),
+                       "parallelism": "1 GPU", "candidate_overlaps": overlaps},
+            "iterations": [{"step": i, "iteration": it, "kind": kind, "ms": round(ms, 3), "N_k": k.n_kmer_records, "N_m": k.n_grouped, "N_c": k.n_candidates, "verified": r.n_accepted,
+                            "extended": a.n_extended, "kmermatcher_ms": round(k.ms_extract + k.ms_sort1 + k.ms_group + k.ms_sort2 + k.ms_reduce, 3), "extract_ms": round(k.ms_extract, 3),
+                            "partition_ms": round(k.ms_sort1, 3), "group_ms": round(k.ms_group, 3), "repsort_ms": round(k.ms_sort2, 3), "reduce_ms": round(k.ms_reduce, 3),
+                            "rescore_ms": round(r.ms_kernel, 3), "assemble_ms": round(a.ms_kernel, 3), "aln2nucl_or_cyclecheck_ms": round(extra, 3)}
+                           for i, (it, ms, k, r, a, extra, kind) in enumerate(rows)],
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "traffic_note": "no PMC pass stored for --config c5", "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg,
+                         "stage_ms_per_step": {k: round(v[0] / len(rows), 4) for k, v in tot.items()},
+                         "kmermatcher_stage": stage("kmermatcher_stage"), "rescore_stage": stage("rescore_stage"), "assemble_stage": stage("assemble_stage")}}
+    for key in ("nu", "aa", "db"):
+        x = st.get(key)
+        if x is not None and x is not reads and x is not nu0 and x is not aa0:
+            x.free()
+    nu0.free(); aa0.free(); reads.free()
+    ctx.close()
+    line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_c5(args.cpu_sample_pairs)
+    import ctypes
+    sys.stderr.flush(); ctypes.CDLL(None).fflush(None)
+    print(json.dumps(line), flush=True)
+
+
+def cpu_baseline_c5(sample_pairs):
+    """the CPU oracle on a bounded sample of the c5 community (>= 5 genomes, skewed): 2 nucleotide and 2 protein-guided iterations,
+    candidate overlaps / module compute time"""
+    import __graft_entry__ as g
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import conftest as T
+    from plass_amd import _lib
+    if not os.path.exists(g.oracle_bin()):
+        subprocess.check_call(["make", "-j", "4"], cwd=os.path.join(ROOT, "oracle"))
+    threads = max(1, min(len(os.sched_getaffinity(0)), 64))
+    pairs = sample_pairs or (20000 if threads < 8 else 60000)
+    sp = synth_params("c5", pairs, min_genomes=5)
+    thr = ["--threads", str(threads)]
+    tot_t, tot_c = 0.0, 0
+
+    def timed(args):
+        nonlocal tot_t, tot_c
+        e = g.run_oracle(args + thr)
+        tot_t += float(re.search(r"^oracle \w+:.*?([0-9.]+) s\s*$", e, re.M).group(1))
+        m = re.search(r"N_c=(\d+)", e)
+        if m:
+            tot_c += int(m.group(1))
+
+    with tempfile.TemporaryDirectory() as td:
+        P = lambda n: os.path.join(td, n)
+        g.run_oracle(["synthreads", P("reads"), "--pairs", str(sp.n_pairs), "--seed", str(sp.seed), "--genomes", str(sp.n_genomes), "--genome-min-len", str(sp.genome_min_len),
+                      "--genome-max-len", str(sp.genome_max_len), "--abundance-sigma", repr(sp.abundance_sigma), "--insert-mean", repr(sp.insert_mean), "--insert-sd", repr(sp.insert_sd),
+                      "--insert-min", str(sp.insert_min), "--read-len", str(sp.read_len), "--error-rate", repr(sp.error_rate)])
+        src = P("reads")
+        for it in range(2):
+            timed(["kmermatcher", src, P("p")] + T.NUCL_KM); timed(["rescorediagonal", src, src, P("p"), P("a")] + T.NUCL_RS)
+            timed(["nuclassembleresults", src, P("a"), P("s%d" % it)] + T.NUCL_AS[:6]); timed(["cyclecheck", P("s%d" % it), P("c"), "--max-seq-len", "200000", "--chop-cycle", "1"])
+            src = P("s%d" % it)
+        for name, par in (("long", _lib.PLASS_ORFS_LONG), ("start", _lib.PLASS_ORFS_START)):
+            fl = []
+            for k, v in par.items():
+                fl += ["--" + k.replace("_", "-"), str(v)]
+            g.run_oracle(["extractorfs", P("reads"), P("n_" + name)] + fl)
+        g.run_oracle(["concatdbs", P("n_long"), P("n_start"), P("nu0")]); g.run_oracle(["concatdbs", P("n_long_h"), P("n_start_h"), P("nu0_h")])
+        g.run_oracle(["translatenucs", P("nu0"), P("aa0"), "--add-orf-stop", "1"])
+        for it in range(2):
+            nu, aa = P("nu%d" % it), P("aa%d" % it)
+            timed(["kmermatcher", aa, P("p")] + T.GD_KM); timed(["rescorediagonal", aa, aa, P("p"), P("a")] + T.GD_RS)
+            timed(["proteinaln2nucl", nu, nu, aa, aa, P("a"), P("an")] + T.GD_P2N); timed(["guidedassembleresults", nu, aa, P("an"), P("nu%d" % (it + 1)), P("aa%d" % (it + 1))] + T.GD_AS[:6])
+    return {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
+            "sample": "%d read pairs of the c5 community model at the same mean coverage, skewed (%d genomes, sigma 1): 2 nucleotide iterations (incl. cyclecheck) and 2 protein-guided "
+                      "iterations (incl. proteinaln2nucl), oracle module compute time (no DB I/O), %d OpenMP threads" % (sp.n_pairs, sp.n_genomes, threads)}
 
 
 def sharded_preflight(ctx, dist, device):

@@ -911,10 +911,11 @@ __global__ __launch_bounds__(64) void killKernel(KillArgs a) {
     killed = waveReduceSumU64(killed);
     if (threadIdx.x == 0 && killed) atomicAdd(a.alive, (unsigned long long) (0ull - killed));
 }
-__global__ void arenaStart2Kernel(const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ lineBeg2, uint32_t bpb, uint32_t gGrid, uint32_t nBuckets, uint64_t *__restrict__ arenaStart) {
+__global__ void arenaStart2Kernel(const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ lineBeg2, uint32_t bpb, uint32_t gGrid, uint32_t nBuckets, uint32_t num, uint32_t den,
+                                  uint64_t *__restrict__ arenaStart) {
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < gGrid; j += gridDim.x * blockDim.x) {
         const uint32_t b = min(j * bpb, nBuckets - 1);
-        arenaStart[j] = ((uint64_t) lineBeg[b] + (uint64_t) lineBeg2[b]) * RPL;
+        arenaStart[j] = (((uint64_t) lineBeg[b] + (uint64_t) lineBeg2[b]) * num / den) * RPL;
     }
 }
 
@@ -1052,6 +1053,9 @@ struct GroupArgs {
     unsigned long long *maxRepTarget;   // max over emitted records of (rep << 32 | member): the last run of sort #2
     // groupLinesKernel<TWO> (record cache): the static store in front of `in`; [0] records grouped, [1] kill-set overflow flag
     const void *in2; const uint32_t *list2, *lineBeg2, *lineCnt2; int hasKills; unsigned long long *cacheCounters; uint32_t killMax;
+    // TWO: a workgroup's arena begins at line (arenaNum * (lineBeg + lineBeg2) / arenaDen) and ends where the next one begins (allLines for the
+    // last): with arenaNum / arenaDen < 1 the arenas hold less than the workgroup reads — cacheCounters[3] is set if one does not suffice
+    uint32_t arenaNum, arenaDen; uint64_t allLines;
 };
 
 __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -1240,7 +1244,10 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     if (bBegin >= a.nBuckets) { if (threadIdx.x == 0) a.outCount[blockIdx.x] = 0; return; }
     unsigned long long written = 0;                  // block-uniform
     unsigned long long maxRT = 0;
-    const uint64_t arena = ((uint64_t) a.lineBeg[bBegin] + (TWO ? (uint64_t) a.lineBeg2[bBegin] : 0ull)) * RPL;
+    auto arenaLine = [&](uint32_t b) { return b < a.nBuckets ? ((uint64_t) a.lineBeg[b] + (uint64_t) a.lineBeg2[b]) * a.arenaNum / a.arenaDen : a.allLines * a.arenaNum / a.arenaDen; };
+    const uint64_t arena = TWO ? arenaLine(bBegin) * RPL : (uint64_t) a.lineBeg[bBegin] * RPL;
+    const uint64_t arenaCap = TWO ? (arenaLine(bEnd) - arenaLine(bBegin)) * RPL : ~0ull;         // records the arena holds
+    bool arenaFull = false;
     const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
     const R none = [] { R r; r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; return r; }();
     // the records of a bucket are fetched (line list entry, then the record: two dependent round trips) as soon as the registers
@@ -1383,7 +1390,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 if (laneId() == 0) wbase = atomicAdd(&sCursor[par], (uint32_t) __popcll(mk));
                 wbase = __shfl(wbase, 0, 64);
             }
-            if (keep) out[arena + written + wbase + wr] = o;
+            if (keep) { const unsigned long long at = written + wbase + wr; if (!TWO || at < arenaCap) out[arena + at] = o; else arenaFull = true; }
         };
         uint32_t nSub = 1;                           // sub-passes by a secondary hash when too many distinct k-mers
         const unsigned long long writtenAtBucketStart = written, seenAtBucketStart = seen;
@@ -1421,7 +1428,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         if (laneId() == 0 && maxRT) atomicMax(a.maxRepTarget, maxRT);
     }
     if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
-    if (TWO) { seen = waveReduceSumU64(seen); if (laneId() == 0 && seen) atomicAdd(a.cacheCounters, seen); }
+    if (TWO) { seen = waveReduceSumU64(seen); if (laneId() == 0 && seen) atomicAdd(a.cacheCounters, seen); if (arenaFull) atomicExch(a.cacheCounters + 3, 1ull); }
 }
 
 // =====================================================================================================
@@ -2266,10 +2273,10 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     const int numCU = ctx->numCU;
     const plasship_comm *cm = commOf(ctx);
     const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
-    Timer tm{ctx, 0};
+    // stage boundaries are events read when the call is over (kmermatchImpl): nobody waits for the stream just to time a stage
     const int valueShift = std::max(0, keyBits - 11);         // VH_BINS = 2^11 monotone bins
     // ---- hash partition (replaces sort #1): level 1 over the slot array, level 2 over every level-1 bucket's line list ----
-    tm.start(0);
+    PH_CHECK(hipEventRecord(ctx->ev[1], st));
     const uint32_t bLo = cm ? (uint32_t) ownedBegin(geo.nb1, rk, W) : 0u, bHi = cm ? (uint32_t) ownedBegin(geo.nb1, rk + 1, W) : geo.nb1;
     const uint32_t nbL = bHi - bLo;                           // level-1 buckets this rank groups (all of them on a single GPU)
     DevBuf dVHist, dMinKey, dTag1, dList1, dCnt1, dStart1, dCur1, dTag2, dList2, dPieces2, dNP2, dRegBeg, dRegEnd, dTot2, dFineBeg, dFineCnt;
@@ -2367,22 +2374,28 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     } else {
         hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, l1Start, nbL, dFineBeg.as<uint32_t>(), dFineCnt.as<uint32_t>());
     }
-    res.msSort1 = tm.stop(1);
+    PH_CHECK(hipEventRecord(ctx->ev[6], st));
     PH_TRACE(st, "kmermatch: hash partition (line store)");
     PH_CHECK(hipGetLastError());
 
     // ---- assignGroup: every workgroup writes its grouped records into an arena that begins where its first bucket's lines begin ----
-    tm.start(0);
+
     // the arenas: the buffer level 2 read (dead now).  single GPU: dB (level 1's output) when there are two levels, else dA (the slot
     // array); sharded run: the receive buffer when there are two levels, else a buffer of its own
     DevBuf dArena;
-    void *arenaBuf;
+    void *arenaBuf; uint32_t arenaNum = 2;                    // (record cache) arenas hold arenaNum / 2 of what their workgroup reads
     if (cm) {
         if (geo.nb2) arenaBuf = dRx.p;
         else { if (dArena.alloc(std::max<uint64_t>(finalCap, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; } arenaBuf = dArena.p; }
     } else if (ss) {
-        // static and dynamic lines of a workgroup's buckets together bound what it emits: arenas addressed by the sum of both line numbers
-        if (dArena.alloc(std::max<uint64_t>(finalCap + ss->capLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; }
+        // Static and dynamic lines of a workgroup's buckets together bound what it emits: arenas addressed by the sum of both line
+        // numbers.  At 50 M reads that bound is 85 GB for the 6 GB an extendable-only iteration emits (N_m / N_k is 0.1-0.3 there), next
+        // to the 49 GB store: such iterations get HALF the bound, and a workgroup whose arena does not suffice says so — the group
+        // kernel then runs again with full arenas (it changes nothing it reads except store records it has already killed).
+        if (geo.nb2) dB.release(); else dA.release();        // level 1's output / the slot array: dead, the arenas need the room
+        arenaNum = par->include_only_extendable ? 1u : 2u;
+        if (dArena.alloc(std::max<uint64_t>((finalCap + ss->capLines) * arenaNum / 2 + 1, 1) * RPL * sizeof(R)) != hipSuccess) {
+            setError("kmermatch: out of device memory for the grouped records (" + std::to_string((finalCap + ss->capLines) * arenaNum / 2 * RPL * sizeof(R)) + " bytes)"); return PLASSHIP_ERR_DEVICE; }
         arenaBuf = dArena.p;
     } else arenaBuf = geo.nb2 ? dB.p : dA.p;
     const uint32_t gBlocks = std::max<uint32_t>(1, std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 6)));
@@ -2404,9 +2417,11 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         if (ss && nBuckets) {
             ga.in2 = ss->recs; ga.list2 = ss->list; ga.lineBeg2 = ss->fineBeg; ga.lineCnt2 = ss->fineCnt; ga.hasKills = ss->hasKills; ga.cacheCounters = ss->counters;
             ga.killMax = std::min<uint32_t>(KILL_MAX, (uint32_t) tuneInt("KILL_MAX", (int) KILL_MAX));       // (PLASSHIP_TUNE_KILL_MAX: the tests force the overflow fallback with it)
+            if (tuneInt("ARENA_QUARTERS", 0)) arenaNum = 1;                                                 // (tests: force the retry with full arenas)
+            ga.arenaNum = arenaNum; ga.arenaDen = 2; ga.allLines = finalCap + ss->capLines;
             if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
             else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-            hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
+            hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, arenaNum, 2u, dArenaStart.as<uint64_t>());
             launchedTwo = true;
         }
     }
@@ -2432,6 +2447,26 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     if (ss && hCache[1]) { res.cacheOverflow = true; return PLASSHIP_OK; }       // a bucket held more kill records than its set takes: the caller runs without the store
+    if constexpr (!NUCL && !LONG) {
+        if (ss && hCache[3]) {
+            // an arena of half the bound did not suffice somewhere: once more with full arenas (the kills of the first run have been
+            // applied to the store already; applying them again finds nothing)
+            dArena.release();
+            if (dArena.alloc(std::max<uint64_t>(finalCap + ss->capLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records (full arenas)"); return PLASSHIP_ERR_DEVICE; }
+            arenaBuf = dArena.p; ga.out = arenaBuf; ga.arenaNum = 2;
+            PH_CHECK(hipMemsetAsync(ss->counters, 0, 8, st)); PH_CHECK(hipMemsetAsync(ss->counters + 3, 0, 8, st)); PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
+            if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
+            else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
+            hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, 2u, 2u, dArenaStart.as<uint64_t>());
+            hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
+            PH_CHECK(hipMemcpyAsync(hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost, st));
+            PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
+            PH_CHECK(hipMemcpyAsync(hArena.data(), dArenaStart.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
+            PH_CHECK(hipMemcpyAsync(hCache, ss->counters, 32, hipMemcpyDeviceToHost, st));
+            PH_CHECK(plasship::streamSync(st));
+            PH_CHECK(hipGetLastError());
+        }
+    }
     uint64_t NmLocal = 0;
     for (uint32_t j = 0; j < gGrid; j++) NmLocal += hOutCnt[j];
     uint64_t Nm = NmLocal;
@@ -2457,7 +2492,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     }
     res.Nk = NkLocal;                                         // sharded run: the records THIS rank extracted (the ranks' sum is the run's N_k)
     res.Nm = NmLocal;
-    res.msGroup = tm.stop(1);
+    PH_CHECK(hipEventRecord(ctx->ev[7], st));
     PH_TRACE(st, "kmermatch: group (line store)");
 
     // ---- stale records behind the compaction point that continue the last run (see section 7 above) ----
@@ -2519,7 +2554,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     }
 
     // ---- sort #2: range partition of the grouped records by rep id over the line store + aggregation / sort per bucket ----
-    tm.start(0);
+    PH_CHECK(hipEventRecord(ctx->ev[12], st));
     // the hash-bucketed records are dead now (the group kernel's arenas live in another buffer): free them for the rep side
     if (cm) { dL2.release(); if (!geo.nb2) dRx.release(); }
     else if (ss) { dA.release(); dB.release(); }
@@ -2551,7 +2586,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         moveBuf(dA, dMerged);                                 // the caller's dA owns the result
         nTriples = nMerged;
     } else moveBuf(dA, dTriples);
-    res.msSort2 = tm.stop(1);
+    PH_CHECK(hipEventRecord(ctx->ev[13], st));
     PH_TRACE(st, "kmermatch: rep sort (line store)");
     PH_CHECK(hipGetLastError());
     res.triples = dA.p; res.nTriples = nTriples;
@@ -2564,7 +2599,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
 // `cur`: nTriples triples in (rep, target, diagonal) order (sharded run: room for HALO_SLACK more behind them)
 template <bool NUCL, bool LONG>
 static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void *cur, uint64_t nTriples, const std::vector<int64_t> &stalePos, uint32_t staleT,
-                              std::unique_ptr<plasship_cands> &holder, uint64_t &Nc, float &msReduce) {
+                              std::unique_ptr<plasship_cands> &holder, uint64_t &Nc, float &msReduce, bool lazyClock = false) {
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     Timer tm{ctx, 0};
@@ -2572,7 +2607,7 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
     const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
     const uint64_t repBase = ownedBegin(N, rk, W), ownedN = ownedBegin(N, rk + 1, W) - repBase;
     // ---- per-(rep,target) reduction + CSR ----
-    tm.start(0);
+    if (!lazyClock) tm.start(0);                             // (lazyClock: the caller recorded ev[13] and reads ev[13] .. ev[14] when the call is over)
     DevBuf dTmpHits, dEmit, dEpos, dPerRep, dQoff;
     if (dTmpHits.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc(std::max<uint64_t>(nTriples, 1) * 4) != hipSuccess ||
         dEpos.alloc((nTriples + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
@@ -2650,7 +2685,7 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
     if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (qHi > qLo) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(qHi - qLo, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), qLo, qHi, c->d_hits.as<CandHit>());
     if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
-    msReduce = tm.stop(1);
+    if (lazyClock) PH_CHECK(hipEventRecord(ctx->ev[14], st)); else msReduce = tm.stop(1);
     PH_TRACE(st, "kmermatch: reduce");
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
@@ -2714,6 +2749,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // it, and owns the representatives / queries [repBase, repBase + ownedN)
     const plasship_comm *cm = commOf(ctx);
     const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
+    const bool useLinesEarly = cm || getenv("PLASSHIP_LEGACY_PARTITION") == nullptr;      // == useLines below
 
     // ---- slot bounds + offsets ----
     DevBuf dBound, dSlotOff, dScanTmp;
@@ -2721,7 +2757,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess) {
         setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    tm.start(0);
+    if (useLinesEarly) PH_CHECK(hipEventRecord(ctx->ev[0], st)); else tm.start(0);
     DevBuf dKillBound, dKillOff; uint64_t killTotal = 0, dynTotal = 0;
     if (kc) {
         if (dKillBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dKillOff.alloc(((size_t) N + 2) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
@@ -2792,10 +2828,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     ea.kstats = dKStats.as<unsigned long long>();
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     bool twoLists = false;
+    DevBuf dKillList, dKillCount;                            // (record cache) ids of the sequences that have just changed
     if constexpr (!NUCL && !LONG) {
     if (kc && nMine) {
         // the store holds the records of the static sequences: they get their identity record, everything else is queued for the tiers
-        DevBuf dKillList, dKillCount;
         if (dKillList.alloc(((size_t) N + 1) * 4) != hipSuccess || dKillCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         PH_CHECK(hipMemsetAsync(dKillCount.p, 0, 4, st));
         ClassifyArgs ca; memset(&ca, 0, sizeof(ca));
@@ -2814,7 +2850,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             ka.alive = kc->counters.as<unsigned long long>() + 2;
             hipLaunchKernelGGL(killKernel, dim3((unsigned) std::min<uint64_t>((N + 63) / 64, (uint64_t) ctx->numCU * 16)), dim3(64), 0, st, ka);
         }
-        PH_CHECK(plasship::streamSync(st));                  // (the two lists above go out of scope; the tiers below read device counters only)
         twoLists = true;
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
     }
@@ -2872,8 +2907,13 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     DevBuf &dLastIds = *lastIds, &dLastCnt = *lastCnt;
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     uint32_t nOv = 0;
-    if (nMine) PH_CHECK(hipMemcpyAsync(&nOv, dLastCnt.p, 4, hipMemcpyDeviceToHost, st));
-    PH_CHECK(plasship::streamSync(st));
+    // protein DBs: a candidate set never exceeds the tiers' 128 entries (59 considered k-mers), and the last tier keeps up to 8160
+    // residues in LDS — nothing can be left over then, and nobody has to wait to learn that
+    const bool overflowPossible = NUCL || db->maxEntryLen > 8160u || par->kmers_per_seq > 120 || par->kmers_per_seq_scale != 0.0f;
+    if (nMine && overflowPossible) {
+        PH_CHECK(hipMemcpyAsync(&nOv, dLastCnt.p, 4, hipMemcpyDeviceToHost, st));
+        PH_CHECK(plasship::streamSync(st));
+    }
     PH_CHECK(hipGetLastError());
     if (nOv) {   // sequences whose candidate set did not fit LDS: same kernel, candidates in HBM scratch
         std::vector<uint32_t> ids(nOv), lens(nOv);
@@ -2894,7 +2934,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_CHECK(plasship::streamSync(st));
         PH_CHECK(hipGetLastError());
     }
-    msExtract = tm.stop(1);
+    if (!useLinesEarly) msExtract = tm.stop(1);              // (line-store path: the next boundary event is recorded by kmermatchLines)
     PH_TRACE(st, "kmermatch: extraction");
     traceBadIds<LONG>(ctx, "kmermatch: extracted slots", dA.p, total, N);
 
@@ -2906,14 +2946,19 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         if (kc) {
             sv.recs = kc->recs.p; sv.list = kc->list.as<uint32_t>(); sv.tags = kc->tags.as<uint32_t>(); sv.fineBeg = kc->fineBeg.as<uint32_t>(); sv.fineCnt = kc->fineCnt.as<uint32_t>();
             sv.totLines = kc->tot2.as<uint64_t>(); sv.capLines = kc->capLines; sv.vhist = kc->vhist.as<uint32_t>(); sv.counters = kc->counters.as<unsigned long long>(); sv.hasKills = killTotal ? 1 : 0;
-            PH_CHECK(hipMemsetAsync(kc->counters.p, 0, 16, st));        // [0] records grouped, [1] overflow flag; [2] (alive static records) stays
+            PH_CHECK(hipMemsetAsync(kc->counters.p, 0, 16, st));        // [0] records grouped, [1] kill-set overflow; [2] (alive static records) stays
+            PH_CHECK(hipMemsetAsync(kc->counters.as<unsigned long long>() + 3, 0, 8, st));   // [3] an arena was too small
         }
         int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, kc ? &sv : nullptr);
         if (rcL) return rcL;
         if (lo.cacheOverflow) { if (cacheOverflow) *cacheOverflow = true; return PLASSHIP_OK; }
         std::unique_ptr<plasship_cands> holderL; uint64_t NcL = 0; float msReduceL = 0;
-        rcL = reduceToCandidates<NUCL, LONG>(ctx, db, lo.triples, lo.nTriples, lo.stalePos, lo.staleT, holderL, NcL, msReduceL);
+        rcL = reduceToCandidates<NUCL, LONG>(ctx, db, lo.triples, lo.nTriples, lo.stalePos, lo.staleT, holderL, NcL, msReduceL, true);
         if (rcL) return rcL;
+        {   // the stage boundaries (all recorded, all complete: reduceToCandidates ended with a wait for the stream)
+            auto ms = [&](int a, int b) { float v = 0; (void) hipEventElapsedTime(&v, ctx->ev[a], ctx->ev[b]); return v; };
+            msExtract = ms(0, 1); lo.msSort1 = ms(1, 6); lo.msGroup = ms(6, 7); lo.msSort2 = ms(12, 13); msReduceL = ms(13, 14);
+        }
         if (stats) {
             stats->n_kmer_records = lo.Nk; stats->n_grouped = lo.Nm; stats->n_candidates = NcL; stats->record_bytes = LONG ? 20 : 16;
             float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel from two separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; rocpd databases).
-Usage: tools/rocpd_traffic.py FETCH_results.db WRITE_results.db [N_KERNELS [OUT.json [STEPS]]]
-OUT.json (profiles/r02_pmc_traffic.json) is what bench.py reads `roofline.traffic` from: per kernel, HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE."""
+Usage: tools/rocpd_traffic.py FETCH_results.db WRITE_results.db [N_KERNELS [OUT.json [STEPS [COMMAND]]]]
+OUT.json (profiles/r03_pmc_traffic.json) is what bench.py reads `roofline.traffic` from: per kernel, HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE.
+STEPS = assembly iterations the profiled command ran (warm-up, timed and verification iterations together); the file records the hash
+of the product sources (bench.source_sha) and bench.py refuses it for any other code."""
 import collections
 import json
 import sqlite3
@@ -28,7 +30,12 @@ def main():
 
 
     if len(sys.argv) > 4:
-        out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) of `python bench.py --steps 12 --warmup 0 --no-cpu-baseline`",
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        cmd = sys.argv[6] if len(sys.argv) > 6 else "python bench.py --gpus 1 --steps 20 --warmup 5"
+        out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) of `%s`" % cmd,
+               "source_sha": bench.source_sha(),
                "steps": int(sys.argv[5]) if len(sys.argv) > 5 else 12,
                "correction": "FETCH_SIZE doubled (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md); WRITE_SIZE as reported; counter unit KB",
                "kernels": {k: {"launches": f[k][1], "fetch_bytes_per_launch": 2 * f[k][0] * 1024, "write_bytes_per_launch": w.get(k, (0, 0))[0] * 1024,
