@@ -52,7 +52,8 @@ bool traceOn();
 // Caching device allocator: hipMalloc/hipFree synchronise the device and cost 0.1–1 ms each, which would
 // dominate an assembly iteration on a 1 M-read set.  Freed blocks are kept (size classes with <= 12.5 % slack)
 // and handed out again; everything is returned to HIP when the last context is destroyed or on out-of-memory.
-hipError_t poolMalloc(void **p, size_t n);
+hipError_t poolMalloc(void **p, size_t n, bool high = false);   // high: a LONG-LIVED block — taken from the top end of the highest free range that
+                                                                  // fits, so that the transient giants of an iteration keep one contiguous region below it
 // every C-ABI entry that allocates calls this first (PH_ENTER): the stream the calling thread's allocations belong to
 void poolEnter(hipStream_t stream);
 #define PH_ENTER(ctx)                                                                    \
@@ -70,6 +71,7 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     hipError_t alloc(size_t n) { release(); bytes = n; if (n == 0) { p = nullptr; return hipSuccess; } return poolMalloc(&p, n); }
+    hipError_t allocHigh(size_t n) { release(); bytes = n; if (n == 0) { p = nullptr; return hipSuccess; } return poolMalloc(&p, n, true); }
     void release() { if (p) { poolFree(p); p = nullptr; } bytes = 0; }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };

@@ -41,18 +41,24 @@ int g_ctxCount = 0;
 size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
 
 // best fit over all free ranges of the device (a few hundred at most)
-bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor, bool *waitAll) {
-    int bs = -1; size_t bo = 0, bsz = ~(size_t) 0;
+bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor, bool *waitAll, bool high) {
+    int bs = -1; size_t bo = 0, bsz = ~(size_t) 0; const char *bestEnd = nullptr;
     for (size_t i = 0; i < dp.slabs.size(); i++)
-        for (auto &kv : dp.slabs[i].free) if (kv.second.size >= n && kv.second.size < bsz) { bs = (int) i; bo = kv.first; bsz = kv.second.size; }
+        for (auto &kv : dp.slabs[i].free) {
+            if (kv.second.size < n) continue;
+            if (high) { const char *end = dp.slabs[i].base + kv.first + kv.second.size; if (end > bestEnd) { bestEnd = end; bs = (int) i; bo = kv.first; bsz = kv.second.size; } }
+            else if (kv.second.size < bsz) { bs = (int) i; bo = kv.first; bsz = kv.second.size; }
+        }
     if (bs < 0) return false;
     Slab &sl = dp.slabs[bs];
     const FreeRange fr = sl.free[bo];
     sl.free.erase(bo);
-    if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
+    size_t at = bo;
+    if (high) { at = bo + (fr.size - n); if (fr.size > n) sl.free[bo] = FreeRange{fr.size - n, fr.stream, fr.mixed}; }      // the top end of the range
+    else if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
     sl.used += n;
-    *p = sl.base + bo;
-    g_poolLive[*p] = PoolLive{dev, bs, bo, n, tl_poolStream};
+    *p = sl.base + at;
+    g_poolLive[*p] = PoolLive{dev, bs, at, n, tl_poolStream};
     *waitAll = fr.mixed; *waitFor = (!fr.mixed && fr.stream != tl_poolStream) ? fr.stream : nullptr;
     return true;
 }
@@ -71,9 +77,9 @@ void trimLocked(int onlyDevice) {      // give completely free slabs back to HIP
 // debugging aid: PLASSHIP_POOL_POISON=<0..255> fills every block handed out with that byte, so that a kernel reading
 // memory it did not write fails the same way on every run (recycled blocks otherwise hold the previous call's data)
 static int poisonByte() { static const int v = [] { const char *e = getenv("PLASSHIP_POOL_POISON"); return e ? atoi(e) : -1; }(); return v; }
-static hipError_t poolMallocRaw(void **p, size_t n);
-hipError_t poolMalloc(void **p, size_t n) {
-    const hipError_t e = poolMallocRaw(p, n);
+static hipError_t poolMallocRaw(void **p, size_t n, bool high);
+hipError_t poolMalloc(void **p, size_t n, bool high) {
+    const hipError_t e = poolMallocRaw(p, n, high);
     if (e == hipSuccess && poisonByte() >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poisonByte(), n); (void) hipDeviceSynchronize(); }
     return e;
 }
@@ -86,7 +92,7 @@ static void poolForgetStream(hipStream_t stream) {
     if (tl_poolStream == stream) tl_poolStream = nullptr;
 }
 static double poolFraction() { static const double v = [] { const char *e = getenv("PLASSHIP_POOL_FRACTION"); const double x = e ? atof(e) : 0.0; return (x > 0.05 && x <= 0.98) ? x : 0.88; }(); return v; }
-static hipError_t poolMallocRaw(void **p, size_t n) {
+static hipError_t poolMallocRaw(void **p, size_t n, bool high) {
     n = std::max<size_t>((n + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN, POOL_ALIGN);
     int dev = 0; (void) hipGetDevice(&dev);
     const size_t MB2 = (size_t) 2 << 20;
@@ -96,7 +102,7 @@ static hipError_t poolMallocRaw(void **p, size_t n) {
         {
             std::lock_guard<std::mutex> g(g_poolMu);
             DevicePool &dp = g_pools[dev];
-            hit = takeRange(dp, dev, n, p, &waitFor, &waitAll);
+            hit = takeRange(dp, dev, n, p, &waitFor, &waitAll, high);
             if (hit) g_poolHits++;
             else {
                 // a new slab: modest while the process is small, most of the remaining HBM once it is not

@@ -2183,8 +2183,8 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
     DevBuf dBound, dSlotOff, dScanTmp, dKS;
     const size_t scanTmpBytes = exclusiveScanTmpBytes((size_t) N + 2) + (1u << 20);
     if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess || dKS.alloc(32) != hipSuccess ||
-        kc.state.alloc((size_t) N + 1) != hipSuccess || kc.seqHash.alloc(((size_t) N + 1) * 8) != hipSuccess || kc.data.alloc(db->dataBytes + 64) != hipSuccess || kc.off.alloc(((size_t) N + 1) * 8) != hipSuccess ||
-        kc.vhist.alloc(VH_BINS * 4) != hipSuccess || kc.counters.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+        kc.state.allocHigh((size_t) N + 1) != hipSuccess || kc.seqHash.allocHigh(((size_t) N + 1) * 8) != hipSuccess || kc.data.allocHigh(db->dataBytes + 64) != hipSuccess || kc.off.allocHigh(((size_t) N + 1) * 8) != hipSuccess ||
+        kc.vhist.allocHigh(VH_BINS * 4) != hipSuccess || kc.counters.allocHigh(32) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(kc.state.p, 0, (size_t) N + 1, st));
     PH_CHECK(hipMemsetAsync(kc.vhist.p, 0, VH_BINS * 4, st));
     PH_CHECK(hipMemsetAsync(kc.counters.p, 0, 32, st));
@@ -2203,8 +2203,13 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
     const LineGeo bits = lineGeometry(totals[0], false, numCU);
     const LineGeo geo = lineGeometryBits(totals[1], bits.b1, bits.b2, numCU);
     const uint64_t recCap = std::max<uint64_t>(totals[1], (uint64_t) RPL * std::max(geo.cap1, geo.cap2));
+    // the store stays for the whole chain: it (and its lists) go to the TOP of the arena (DevBuf::allocHigh), so that the transient
+    // giants of the iterations — record arrays, arenas, the extension arena — keep one contiguous region below (a 49 GB block in the
+    // middle of the slab left the 76 GB extension arena of iteration 0 without a range that fits, with 170 GB free)
     DevBuf dA, dB;
-    if (dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+    const bool twoLevels = geo.nb2 != 0;                      // the level that ends in the store: dA with two levels, dB with one
+    if ((twoLevels ? dA.allocHigh(std::max<uint64_t>(recCap, 1) * sizeof(R)) : dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R))) != hipSuccess ||
+        (twoLevels ? dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) : dB.allocHigh(std::max<uint64_t>(recCap, 1) * sizeof(R))) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
     {
         ShortArgs sa; memset(&sa, 0, sizeof(sa));
         sa.s = db->view(); sa.slotOff = dSlotOff.as<uint64_t>(); sa.arr = dA.p; sa.map = dMap; sa.k = k; sa.xCode = xCode; sa.kps = par->kmers_per_seq; sa.ignoreMulti = par->ignore_multi_kmer;
@@ -2219,7 +2224,7 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
     DevBuf dTag1, dList1, dCnt1, dStart1, dCur1, dPieces2, dNP2, dRegBeg, dRegEnd;
     kc.nBuckets = geo.nb2 ? geo.nb1 * geo.nb2 : geo.nb1;
     if (dTag1.alloc(geo.cap1 * 4) != hipSuccess || dList1.alloc(geo.cap1 * 4) != hipSuccess || dCnt1.alloc(LP_MAXB * 4) != hipSuccess || dStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dCur1.alloc(LP_MAXB * 4) != hipSuccess ||
-        kc.fineBeg.alloc((size_t) kc.nBuckets * 4) != hipSuccess || kc.fineCnt.alloc((size_t) kc.nBuckets * 4) != hipSuccess || kc.tot2.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+        kc.fineBeg.allocHigh((size_t) kc.nBuckets * 4) != hipSuccess || kc.fineCnt.allocHigh((size_t) kc.nBuckets * 4) != hipSuccess || kc.tot2.allocHigh(8) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
     if (geo.nP1 == 0) PH_CHECK(hipMemsetAsync(dTag1.p, 0xFF, geo.cap1 * 4, st));
     {
         LinePartArgs a; memset(&a, 0, sizeof(a));
@@ -2229,7 +2234,7 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
     }
     int rc = buildLineLists(ctx, dTag1.as<uint32_t>(), geo.cap1, geo.nb1, dCnt1.as<uint32_t>(), dStart1.as<uint32_t>(), dCur1.as<uint32_t>(), dList1.as<uint32_t>()); if (rc) return rc;
     if (geo.nb2) {
-        if (kc.tags.alloc(geo.cap2 * 4) != hipSuccess || kc.list.alloc(geo.cap2 * 4) != hipSuccess || dPieces2.alloc((geo.maxP2 + 1) * sizeof(LinePiece)) != hipSuccess || dNP2.alloc(4) != hipSuccess ||
+        if (kc.tags.allocHigh(geo.cap2 * 4) != hipSuccess || kc.list.allocHigh(geo.cap2 * 4) != hipSuccess || dPieces2.alloc((geo.maxP2 + 1) * sizeof(LinePiece)) != hipSuccess || dNP2.alloc(4) != hipSuccess ||
             dRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRegEnd.alloc(LP_MAXB * 8) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, geo.PL2, geo.nb2, dPieces2.as<LinePiece>(), dNP2.as<uint32_t>(),
                            dRegBeg.as<uint64_t>(), dRegEnd.as<uint64_t>(), kc.tot2.as<uint64_t>());
