@@ -677,7 +677,6 @@ struct ShortArgs {
     // slots for sequences this kernel cannot take); a sequence it handles gets state 1 and its Util::hash, nothing is queued
     uint8_t *state; uint64_t *seqHashOut;
 };
-constexpr uint16_t KILL_LEN = 0xFFFFu;          // `len` of a KILL record (section 8; real lengths of the 16-byte layout are below 32 767)
 
 template <bool LONG>
 __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
@@ -802,17 +801,11 @@ __global__ void staticBoundsKernel(const uint32_t *__restrict__ len, uint32_t n,
 __global__ void markChangedKernel(const uint8_t *__restrict__ changed, uint32_t n, uint8_t *__restrict__ state) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (changed[i] && state[i] == 1) state[i] = 2;
 }
-// slot bounds of a call with a valid store: static sequences own their identity record only; a sequence that has just changed also
-// owns kill slots (one per window of its OLD bytes, offsets from the store's copy of the DB it was built from)
-__global__ void dynBoundsKernel(const uint32_t *__restrict__ len, const uint8_t *__restrict__ state, const uint64_t *__restrict__ oldOff, uint32_t n, int k, int kps, float scale,
-                                uint32_t *__restrict__ bound, uint32_t *__restrict__ killBound) {
+// slot bounds of a call with a valid store: a static sequence owns its identity record only
+__global__ void dynBoundsKernel(const uint32_t *__restrict__ len, const uint8_t *__restrict__ state, uint32_t n, int k, int kps, float scale, uint32_t *__restrict__ bound) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const int L = (int) len[i];
-        const uint8_t st = state[i];
-        bound[i] = (st == 1) ? 1u : (uint32_t) min(max(1, L - k + 2), (int) ((float) (size_t) kps + (scale * (float) L)));
-        uint32_t kb = 0;
-        if (st == 2) { const uint32_t oldL = (uint32_t) (oldOff[i + 1] - oldOff[i]) - 2u; kb = (oldL >= (uint32_t) k) ? oldL - (uint32_t) k + 1 : 0u; }
-        killBound[i] = kb;
+        bound[i] = (state[i] == 1) ? 1u : (uint32_t) min(max(1, L - k + 2), (int) ((float) (size_t) kps + (scale * (float) L)));
     }
 }
 struct ClassifyArgs {
@@ -856,60 +849,50 @@ __global__ __launch_bounds__(256) void classifyKernel(ClassifyArgs a) {
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
 }
+// where every record of the store lies: locMap[slotOff[id] + pos] = line * RPL + slot (slotOff = the static slot offsets: one slot per
+// window).  One pass over the finished store; the map is what lets a sequence that changes later remove its records directly.
+constexpr uint32_t LOC_NONE = 0xFFFFFFFFu;
+__global__ __launch_bounds__(256) void locMapKernel(const Rec<false> *__restrict__ recs, const uint32_t *__restrict__ tags, uint64_t nLines, const uint64_t *__restrict__ nLinesDev,
+                                                    const uint64_t *__restrict__ slotOff, uint32_t *__restrict__ locMap) {
+    if (nLinesDev) nLines = min(nLines, (uint64_t) *nLinesDev);
+    for (uint64_t g = (uint64_t) blockIdx.x * 256 + threadIdx.x; g < nLines * RPL; g += (uint64_t) gridDim.x * 256) {
+        if (tags[g / RPL] == TAG_NONE) continue;
+        const Rec<false> r = recs[g];
+        if (!isSentinel(r)) locMap[slotOff[r.id] + (uint32_t) r.pos] = (uint32_t) g;
+    }
+}
 struct KillArgs {
-    const char *oldData; const uint64_t *oldOff; const uint32_t *killList, *killCount; const uint64_t *killOff; uint64_t killBase; void *arr; const unsigned char *map;
-    int k, xCode; uint64_t base, top, inv; int tz;
+    const uint32_t *killList, *killCount; const uint64_t *slotOff; const uint32_t *locMap; Rec<false> *store;
     uint8_t *state; uint32_t *valueHist; int valueShift; unsigned long long *alive;
 };
-// KILL records of the sequences that have just changed: one per record the store holds for them — every window of the OLD bytes
-// without an X (the store only holds sequences in which no k-mer repeats) — with the record's k-mer, id and position and
-// len = KILL_LEN.  They travel through the partition like any record and remove their twin in the group kernel (groupLinesKernel<TWO>).
-__global__ __launch_bounds__(64) void killKernel(KillArgs a) {
-    typedef Rec<false> R;
-    __shared__ unsigned char sMap[256];
+// a static sequence whose bytes have changed leaves the store: every record the location map names for it becomes a sentinel (the group
+// kernel skips sentinels), the value histogram and the count of alive records follow; the sequence is dynamic from now on
+__global__ __launch_bounds__(256) void killKernel(KillArgs a) {
     __shared__ uint32_t sHist[VH_BINS];
-    R *arr = reinterpret_cast<R *>(a.arr);
-    for (int i = threadIdx.x; i < 256; i += 64) sMap[i] = a.map[i];
-    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) sHist[i] = 0;
+    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 256) sHist[i] = 0;
     __syncthreads();
     const uint32_t n = *a.killCount;
     unsigned long long killed = 0;
-    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < n; w += gridDim.x * 64) {
+    Rec<false> sen; memset(&sen, 0xFF, sizeof(sen)); sen.len = 0; sen.pos = 0;
+    // 16 lanes per sequence: its <= 128 windows are independent random accesses
+    const int gl = threadIdx.x & 15;
+    for (uint32_t w = blockIdx.x * 16 + (threadIdx.x >> 4); w < n; w += gridDim.x * 16) {
         const uint32_t id = a.killList[w];
-        const uint64_t o = a.oldOff[id]; const uint32_t L = (uint32_t) (a.oldOff[id + 1] - o) - 2u;
-        const char *base = a.oldData + o;
-        const uint64_t slot = a.killBase + a.killOff[id]; const uint32_t bound = (uint32_t) (a.killOff[id + 1] - a.killOff[id]);
-        uint64_t idx = 0, fifoLo = 0, fifoHi = 0, pw = 1; int lastX = -1; uint32_t nOut = 0;
-        for (uint32_t i = 0; i < L; i++) {
-            const unsigned char c = sMap[(unsigned char) base[i]];
-            if (c == (unsigned char) a.xCode) lastX = (int) i;
-            if (i < (uint32_t) a.k) {
-                idx += (uint64_t) c * pw; pw *= a.base;
-                if (i < 8) fifoLo |= (uint64_t) c << (8 * i); else fifoHi |= (uint64_t) c << (8 * (i - 8));
-            } else {
-                const uint64_t cOut = fifoLo & 0xFF;
-                idx = (((idx - cOut) >> a.tz) * a.inv) + (uint64_t) c * a.top;
-                fifoLo = (fifoLo >> 8) | (fifoHi << 56); fifoHi >>= 8;
-                if (a.k - 1 < 8) fifoLo |= (uint64_t) c << (8 * (a.k - 1)); else fifoHi |= (uint64_t) c << (8 * (a.k - 1 - 8));
-            }
-            if (i + 1 >= (uint32_t) a.k) {
-                const uint32_t p = i + 1 - a.k;
-                if (lastX < (int) p) {
-                    R r; r.kmer = idx; r.id = id; r.len = KILL_LEN; r.pos = (int16_t) p;
-                    arr[slot + nOut] = r; nOut++;
-                    atomicAdd(&sHist[valueBin<false>(idx, a.valueShift)], 1u);
-                }
-            }
+        const uint64_t s0 = a.slotOff[id]; const uint32_t nw = (uint32_t) (a.slotOff[id + 1] - s0);
+        for (uint32_t p = gl; p < nw; p += 16) {
+            const uint32_t g = a.locMap[s0 + p];
+            if (g == LOC_NONE) continue;
+            const Rec<false> r = a.store[g];
+            if (r.id != id) continue;                        // (cannot happen: the map names this sequence's records only)
+            atomicAdd(&sHist[valueBin<false>(r.kmer, a.valueShift)], 1u);
+            a.store[g] = sen; killed++;
         }
-        R sen; memset(&sen, 0xFF, sizeof(R));
-        for (uint32_t i = nOut; i < bound; i++) arr[slot + i] = sen;
-        killed += nOut;
-        a.state[id] = 0;
+        if (gl == 0) a.state[id] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) { const uint32_t c = sHist[i]; if (c) atomicSub(&a.valueHist[i], c); }
+    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 256) { const uint32_t c = sHist[i]; if (c) atomicSub(&a.valueHist[i], c); }
     killed = waveReduceSumU64(killed);
-    if (threadIdx.x == 0 && killed) atomicAdd(a.alive, (unsigned long long) (0ull - killed));
+    if (laneId() == 0 && killed) atomicAdd(a.alive, (unsigned long long) (0ull - killed));
 }
 __global__ void arenaStart2Kernel(const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ lineBeg2, uint32_t bpb, uint32_t gGrid, uint32_t nBuckets, uint32_t num, uint32_t den,
                                   uint64_t *__restrict__ arenaStart) {
@@ -1051,8 +1034,8 @@ struct GroupArgs {
     int includeOnlyExtendable, covMode; float covThr;
     const unsigned long long *minKey;   // NUCL: K of the globally first run
     unsigned long long *maxRepTarget;   // max over emitted records of (rep << 32 | member): the last run of sort #2
-    // groupLinesKernel<TWO> (record cache): the static store in front of `in`; [0] records grouped, [1] kill-set overflow flag
-    const void *in2; const uint32_t *list2, *lineBeg2, *lineCnt2; int hasKills; unsigned long long *cacheCounters; uint32_t killMax;
+    // groupLinesKernel<TWO> (record cache): the static store's line lists in front of the call's own; cacheCounters[3]: an arena was too small
+    const uint32_t *list2, *lineBeg2, *lineCnt2; uint64_t delta1, delta2; unsigned long long *cacheCounters;
     // TWO: a workgroup's arena begins at line (arenaNum * (lineBeg + lineBeg2) / arenaDen) and ends where the next one begins (allLines for the
     // last): with arenaNum / arenaDen < 1 the arenas hold less than the workgroup reads — cacheCounters[3] is set if one does not suffice
     uint32_t arenaNum, arenaDen; uint64_t allLines;
@@ -1218,11 +1201,9 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 // 2^20 buckets two partition levels can make with ~4000 positions each, which 512 threads and 4096 slots take in one go (a
 // bucket beyond the registers would be read from HBM once per phase and sub-pass).  "At least two members" is one bit per slot.
 constexpr int GL_RMAX = 8;
-// TWO (record cache, section 8): a bucket = the lines of the STATIC store (list2 / lineBeg2 / lineCnt2 over in2) followed by the lines
-// of this call's dynamic records.  KILL records among the latter (len == KILL_LEN) name static records of sequences that have
-// changed: they enter a small LDS set first, every static record found there is dropped and overwritten with a sentinel in the
-// store (so the kill is needed once), and the kill records themselves take no part in the grouping.
-constexpr uint32_t KILL_HT = 1024, KILL_MAX = 896;
+// TWO (record cache, section 8): a bucket = the lines of the STATIC store (list2 / lineBeg2 / lineCnt2) followed by the lines of this
+// call's dynamic records.  Both line lists index ONE address space: `in` is the lower of the two buffers, the other one's lines are
+// offset by their distance from it (delta1 for the call's own list, delta2 for the store's; one of them is zero).
 template <bool NUCL, int BLOCK, uint32_t HT, int WPE, bool TWO = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void groupLinesKernel(GroupArgs a) {
     typedef Rec<false> R;
@@ -1232,12 +1213,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     __shared__ uint32_t hMulti[HT / 32];                     // bit = a second record met this slot's k-mer
     __shared__ uint32_t sFlag[2];
     __shared__ uint32_t sCursor[2];                          // arena cursor of a sub-pass; two, used alternately, save a barrier per sub-pass
-    __shared__ unsigned long long sKill[TWO ? KILL_HT : 1];  // (id << 16 | pos) of the bucket's kill records
-    __shared__ uint32_t sKillCnt;
     const R *in = reinterpret_cast<const R *>(a.in);
-    const R *in2 = reinterpret_cast<const R *>(a.in2);
-    R *store = const_cast<R *>(in2);
-    unsigned long long seen = 0;                     // records that took part in the grouping (TWO: the call's N_k)
     R *out = reinterpret_cast<R *>(a.out);
     const uint32_t bBegin = blockIdx.x * a.bucketsPerBlock;
     const uint32_t bEnd = min(a.nBuckets, bBegin + a.bucketsPerBlock);
@@ -1255,9 +1231,11 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     R rg[GL_RMAX];
     uint32_t nNext = 0, lbNext = 0, nSNext = 0, lb2Next = 0;       // nS: positions of the static store in front of the dynamic ones
     auto recOf = [&](uint32_t i, uint32_t nS, uint32_t lb, uint32_t lb2) -> R {
-        if (TWO && i < nS) return in2[(uint64_t) a.list2[lb2 + i / RPL] * RPL + (i % RPL)];
-        const uint32_t d = i - nS;
-        return in[(uint64_t) a.list[lb + d / RPL] * RPL + (d % RPL)];
+        if (!TWO) return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)];
+        const bool st = i < nS;                      // static lines first; one base pointer, the upper buffer's lines carry an offset
+        const uint32_t j = st ? lb2 + i / RPL : lb + (i - nS) / RPL;
+        const uint64_t line = (uint64_t) (st ? a.list2[j] : a.list[j]) + (st ? a.delta2 : a.delta1);
+        return in[line * RPL + (i % RPL)];
     };
     auto fetch = [&](uint32_t b) {
         nSNext = (TWO && b < bEnd) ? a.lineCnt2[b] * RPL : 0u; lb2Next = (TWO && b < bEnd) ? a.lineBeg2[b] : 0u;
@@ -1275,48 +1253,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         if (n == 0) { fetch(b + 1); continue; }
         const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
         bool fetched = false;
-        bool killsHere = false;                      // this bucket has kill records: sKill holds their (id, position)
-        auto killKey = [](const R &r) { return ((unsigned long long) r.id << 16) | (unsigned long long) ((uint32_t) r.pos & 0xFFFFu); };
-        auto killed = [&](const R &r) {
-            if (isSentinel(r)) return false;
-            const unsigned long long key = killKey(r);
-            uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 54) & (KILL_HT - 1);
-            for (;;) { const unsigned long long v = sKill[slot]; if (v == key) return true; if (v == ~0ULL) return false; slot = (slot + 1) & (KILL_HT - 1); }
-        };
-        // (buckets beyond the registers are re-read in every phase: kill records take no part, killed static records are recognised by the set)
-        auto recAt = [&](uint32_t i) -> R { R r = recOf(i, nS, lb, lb2); if (TWO && (r.len == KILL_LEN || (killsHere && i < nS && killed(r)))) r = none; return r; };
-        if (TWO && a.hasKills) {
-            // ---- kill records first: their (id, position) into the LDS set, then every static record of the bucket is looked up ----
-            for (uint32_t i = threadIdx.x; i < KILL_HT; i += BLOCK) sKill[i] = ~0ULL;
-            if (threadIdx.x == 0) sKillCnt = 0;
-            __syncthreads();
-            auto killInsert = [&](const R &r) {
-                if (isSentinel(r) || r.len != KILL_LEN) return;
-                if (atomicAdd(&sKillCnt, 1u) >= a.killMax) { atomicExch(a.cacheCounters + 1, 1ull); return; }     // the host falls back to a full run
-                const unsigned long long key = killKey(r);
-                uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 54) & (KILL_HT - 1);
-                while (atomicCAS(&sKill[slot], ~0ULL, key) != ~0ULL) slot = (slot + 1) & (KILL_HT - 1);
-            };
-            if (inRegs) {
-#pragma unroll
-                for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; if (i >= nS && i < n) { killInsert(rg[j]); if (rg[j].len == KILL_LEN) rg[j] = none; } }
-            } else for (uint32_t i = nS + threadIdx.x; i < n; i += BLOCK) killInsert(recOf(i, nS, lb, lb2));
-            __syncthreads();
-            killsHere = sKillCnt != 0;
-            if (killsHere) {
-                // a killed record leaves the store for good (a sentinel in its place): the kill is needed once
-                if (inRegs) {
-#pragma unroll
-                    for (int j = 0; j < GL_RMAX; j++) {
-                        const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x;
-                        if (i < nS && killed(rg[j])) { rg[j] = none; store[(uint64_t) a.list2[lb2 + i / RPL] * RPL + (i % RPL)] = none; }
-                    }
-                } else for (uint32_t i = threadIdx.x; i < nS; i += BLOCK) if (killed(recOf(i, nS, lb, lb2))) store[(uint64_t) a.list2[lb2 + i / RPL] * RPL + (i % RPL)] = none;
-            }
-        } else if (TWO && inRegs) {
-#pragma unroll
-            for (int j = 0; j < GL_RMAX; j++) if (rg[j].len == KILL_LEN) rg[j] = none;
-        }
+        auto recAt = [&](uint32_t i) -> R { return recOf(i, nS, lb, lb2); };
         // phase A on one record: claim the k-mer's slot, mark a second member, and bid for the run head; called by whole wavefronts
         // (new k-mers are counted once per wavefront, not with one LDS atomic per record on a single word)
         auto phaseA = [&](const R &r, uint32_t nSub, uint32_t sub) {
@@ -1326,7 +1263,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             if (!isSentinel(r) && !(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
                 uint32_t slot = (uint32_t) (hh >> 32) & (HT - 1);
                 full = true;
-                if (TWO) seen++;
                 for (uint32_t probe = 0; probe < HT; probe++) {
                     const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, K);
                     if (prev == ~0ULL || prev == K) {
@@ -1393,7 +1329,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             if (keep) { const unsigned long long at = written + wbase + wr; if (!TWO || at < arenaCap) out[arena + at] = o; else arenaFull = true; }
         };
         uint32_t nSub = 1;                           // sub-passes by a secondary hash when too many distinct k-mers
-        const unsigned long long writtenAtBucketStart = written, seenAtBucketStart = seen;
+        const unsigned long long writtenAtBucketStart = written;
         for (;;) {
             bool redo = false;
             for (uint32_t sub = 0; sub < nSub && !redo; sub++) {
@@ -1417,7 +1353,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             }
             if (!redo) break;
             nSub *= 2;                               // a retry discards what completed sub-passes of this attempt wrote
-            written = writtenAtBucketStart; if (TWO) seen = seenAtBucketStart;
+            written = writtenAtBucketStart;
             __syncthreads();
         }
         if (!fetched) fetch(b + 1);                  // (cannot happen: the last sub-pass always completes; kept for the invariant)
@@ -1428,7 +1364,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         if (laneId() == 0 && maxRT) atomicMax(a.maxRepTarget, maxRT);
     }
     if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
-    if (TWO) { seen = waveReduceSumU64(seen); if (laneId() == 0 && seen) atomicAdd(a.cacheCounters, seen); if (arenaFull) atomicExch(a.cacheCounters + 3, 1ull); }
+    if (TWO && arenaFull) atomicExch(a.cacheCounters + 3, 1ull);
 }
 
 // =====================================================================================================
@@ -1806,7 +1742,6 @@ __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const u
         if (tags && tags[i / RPL] == TAG_NONE) continue;                // tags == nullptr: every line is valid (received lines of a sharded run)
         const R r = g[i];
         if (isSentinel(r)) continue;
-        if constexpr (!LONG) { if (r.len == KILL_LEN) continue; }          // a KILL record of the record cache (section 8) is not a record
         uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
         if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
@@ -2139,9 +2074,11 @@ static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; ds
 //    bucket's static and dynamic lines together (groupLinesKernel<TWO>).
 //      * Which sequences are unchanged is not guessed: an output DB of the extension modules names its parent DB and carries a
 //        per-sequence `changed` byte (buildOutputDB, assemble.hip); a DB without that lineage rebuilds the store.
-//      * A static sequence that changes becomes dynamic for good; its records in the store are removed by KILL records — one per
-//        stored record, regenerated from the store's copy of the sequence's old bytes — that travel through the dynamic partition
-//        to the record's bucket, where the group kernel drops the record and overwrites it with a sentinel (once).
+//      * A static sequence that changes becomes dynamic for good and its records leave the store: a LOCATION MAP (one 32-bit position
+//        per window of every static sequence, filled by one pass over the finished store) says where they lie, and killKernel overwrites
+//        them with sentinels — no search, nothing extra through the partition, nothing in the group kernel.  (A first version sent KILL
+//        records through the dynamic partition and matched them in an LDS set inside the group kernel: every static record of a bucket
+//        paid a probe, the kernel spilled 70 VGPRs, and grouping went from 38 to 117 ms per iteration at 50 M reads.)
 //      * What the rest of the path needs from "all records" is kept exact: the count (alive static + dynamic), the value histogram of
 //        the stale-record check (static histogram minus kills + dynamic), the rank pass (both stores).
 //    The result is the reference's, bit for bit, by construction: the multiset of records a bucket's grouping sees is unchanged.
@@ -2154,14 +2091,14 @@ struct KmerCache {
     int k = 0, alph = 0, kps = 0, ignoreMulti = 0; float scale = 0;
     int b1 = 0, b2 = 0; uint32_t nBuckets = 0;              // bucket bits of the store = of every dynamic partition while it lives
     DevBuf recs, list, tags, tot2, fineBeg, fineCnt; uint64_t capLines = 0;
-    DevBuf state, seqHash, data, off, vhist, counters;       // counters: [0] records grouped in the last call, [1] kill overflow, [2] alive static records
-    void clear() { valid = false; for (DevBuf *b : {&recs, &list, &tags, &tot2, &fineBeg, &fineCnt, &state, &seqHash, &data, &off, &vhist, &counters}) b->release(); }
+    DevBuf state, seqHash, slotOff, locMap, vhist, counters;  // counters: [2] alive static records, [3] "an arena was too small" flag of the last call
+    void clear() { valid = false; for (DevBuf *b : {&recs, &list, &tags, &tot2, &fineBeg, &fineCnt, &state, &seqHash, &slotOff, &locMap, &vhist, &counters}) b->release(); }
 };
 void kmerCacheFree(plasship_ctx *ctx) { if (ctx && ctx->kcache) { ctx->kcache->clear(); delete ctx->kcache; ctx->kcache = nullptr; } }
 }  // namespace plasship
 namespace {
 // what kmermatchLines needs of the store
-struct StaticStoreView { const void *recs; const uint32_t *list, *tags, *fineBeg, *fineCnt; const uint64_t *totLines; uint64_t capLines; uint32_t *vhist; unsigned long long *counters; int hasKills; };
+struct StaticStoreView { const void *recs; const uint32_t *list, *tags, *fineBeg, *fineCnt; const uint64_t *totLines; uint64_t capLines; uint32_t *vhist; unsigned long long *counters; };
 
 static LineGeo lineGeometryBits(uint64_t totalSlots, int b1, int b2, int numCU) {       // caps for `totalSlots` with given bucket bits
     LineGeo g; g.b1 = b1; g.b2 = b2; g.nb1 = 1u << b1; g.nb2 = b2 ? 1u << b2 : 0u;
@@ -2180,17 +2117,15 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n; const int k = par->kmer_size, numCU = ctx->numCU;
     kc.clear();
-    DevBuf dBound, dSlotOff, dScanTmp, dKS;
+    DevBuf dBound, dScanTmp, dKS; DevBuf &dSlotOff = kc.slotOff;
     const size_t scanTmpBytes = exclusiveScanTmpBytes((size_t) N + 2) + (1u << 20);
-    if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess || dKS.alloc(32) != hipSuccess ||
-        kc.state.allocHigh((size_t) N + 1) != hipSuccess || kc.seqHash.allocHigh(((size_t) N + 1) * 8) != hipSuccess || kc.data.allocHigh(db->dataBytes + 64) != hipSuccess || kc.off.allocHigh(((size_t) N + 1) * 8) != hipSuccess ||
+    if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.allocHigh(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess || dKS.alloc(32) != hipSuccess ||
+        kc.state.allocHigh((size_t) N + 1) != hipSuccess || kc.seqHash.allocHigh(((size_t) N + 1) * 8) != hipSuccess ||
         kc.vhist.allocHigh(VH_BINS * 4) != hipSuccess || kc.counters.allocHigh(32) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(kc.state.p, 0, (size_t) N + 1, st));
     PH_CHECK(hipMemsetAsync(kc.vhist.p, 0, VH_BINS * 4, st));
     PH_CHECK(hipMemsetAsync(kc.counters.p, 0, 32, st));
     PH_CHECK(hipMemsetAsync(dKS.p, 0, 32, st));
-    PH_CHECK(hipMemcpyAsync(kc.data.p, db->d_data.p, db->dataBytes, hipMemcpyDeviceToDevice, st));
-    PH_CHECK(hipMemcpyAsync(kc.off.p, db->d_off.p, ((size_t) N + 1) * 8, hipMemcpyDeviceToDevice, st));
     // bucket bits from ALL record slots of the DB (what a call without a store would use), slots of the store from the static bounds
     uint64_t totals[2] = {0, 0};
     hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
@@ -2251,6 +2186,12 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
         PH_CHECK(hipMemcpyAsync(kc.tot2.p, &cap, 8, hipMemcpyHostToDevice, st));
         moveBuf(kc.recs, dB); moveBuf(kc.tags, dTag1); moveBuf(kc.list, dList1); kc.capLines = geo.cap1;
     }
+    // where every record lies (killKernel); positions are 32-bit
+    if (kc.capLines * RPL >= 0xFFFFFFFFull) { setError("kmermatch: the record store is too large for 32-bit positions"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (kc.locMap.allocHigh(std::max<uint64_t>(totals[1], 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(kc.locMap.p, 0xFF, std::max<uint64_t>(totals[1], 1) * 4, st));
+    hipLaunchKernelGGL(locMapKernel, dim3(gridFor(kc.capLines * RPL, 256, (unsigned) numCU * 16)), dim3(256), 0, st, (const Rec<false> *) kc.recs.p, (const uint32_t *) kc.tags.as<uint32_t>(), kc.capLines,
+                       (const uint64_t *) kc.tot2.as<uint64_t>(), (const uint64_t *) kc.slotOff.as<uint64_t>(), kc.locMap.as<uint32_t>());
     PH_CHECK(plasship::streamSync(st));                       // (`cap` and the temporaries go out of scope)
     PH_CHECK(hipGetLastError());
     kc.b1 = geo.b1; kc.b2 = geo.b2; kc.N = N; kc.k = k; kc.alph = par->alphabet_size; kc.kps = par->kmers_per_seq; kc.scale = par->kmers_per_seq_scale; kc.ignoreMulti = par->ignore_multi_kmer;
@@ -2270,7 +2211,7 @@ template <bool NUCL, bool LONG>
 static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, const LineGeo &geo, uint64_t total,
                           DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res,
                           const StaticStoreView *ss = nullptr) {
-    // ss (record cache, section 8; single GPU, protein, 16-byte records): dA holds only the call's DYNAMIC records (and KILL records);
+    // ss (record cache, section 8; single GPU, protein, 16-byte records): dA holds only the call's DYNAMIC records;
     // the group kernel reads every bucket's static lines in front of them
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
@@ -2301,7 +2242,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         LinePartArgs a; memset(&a, 0, sizeof(a));
         a.in = dA.p; a.out = dB.p; a.tags = dTag1.as<uint32_t>(); a.totalLines = geo.totalLines; a.lastValidAll = geo.lastValid; a.pieceLines = geo.PL1; a.nb = geo.nb1;
         a.key.shift = geo.b1 ? 64 - geo.b1 : 63; a.key.rangeBits = 0; a.key.repBase = 0;
-        a.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr; a.valueHist = dVHist.as<uint32_t>(); a.valueShift = valueShift; a.killAware = ss ? 1 : 0;
+        a.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr; a.valueHist = dVHist.as<uint32_t>(); a.valueShift = valueShift;
         PH_CHECK(hipEventRecord(ctx->ev[8], st));
         const int rc = launchLinePart<NUCL, LONG, KEY_HASH, false, true>(ctx, a, geo.nP1); if (rc) return rc;
         PH_CHECK(hipEventRecord(ctx->ev[9], st));
@@ -2420,8 +2361,11 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     bool launchedTwo = false;
     if constexpr (!NUCL && !LONG) {
         if (ss && nBuckets) {
-            ga.in2 = ss->recs; ga.list2 = ss->list; ga.lineBeg2 = ss->fineBeg; ga.lineCnt2 = ss->fineCnt; ga.hasKills = ss->hasKills; ga.cacheCounters = ss->counters;
-            ga.killMax = std::min<uint32_t>(KILL_MAX, (uint32_t) tuneInt("KILL_MAX", (int) KILL_MAX));       // (PLASSHIP_TUNE_KILL_MAX: the tests force the overflow fallback with it)
+            // one address space for both line lists: the lower buffer is the base, the other one's lines are offset by the distance (whole lines:
+            // the arena hands out 256-byte aligned blocks)
+            const char *pd = (const char *) finalRecs, *ps = (const char *) ss->recs; const size_t lineBytes = RPL * sizeof(R);
+            ga.in = pd < ps ? pd : ps; ga.delta1 = (uint64_t) (pd - (const char *) ga.in) / lineBytes; ga.delta2 = (uint64_t) (ps - (const char *) ga.in) / lineBytes;
+            ga.list2 = ss->list; ga.lineBeg2 = ss->fineBeg; ga.lineCnt2 = ss->fineCnt; ga.cacheCounters = ss->counters;
             if (tuneInt("ARENA_QUARTERS", 0)) arenaNum = 1;                                                 // (tests: force the retry with full arenas)
             ga.arenaNum = arenaNum; ga.arenaDen = 2; ga.allLines = finalCap + ss->capLines;
             if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
@@ -2451,7 +2395,6 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     if (ss) { PH_CHECK(hipMemcpyAsync(hCache, ss->counters, 32, hipMemcpyDeviceToHost, st)); PH_CHECK(hipMemcpyAsync(hVHistS.data(), ss->vhist, VH_BINS * 4, hipMemcpyDeviceToHost, st)); }
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
-    if (ss && hCache[1]) { res.cacheOverflow = true; return PLASSHIP_OK; }       // a bucket held more kill records than its set takes: the caller runs without the store
     if constexpr (!NUCL && !LONG) {
         if (ss && hCache[3]) {
             // an arena of half the bound did not suffice somewhere: once more with full arenas (the kills of the first run have been
@@ -2459,7 +2402,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
             dArena.release();
             if (dArena.alloc(std::max<uint64_t>(finalCap + ss->capLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records (full arenas)"); return PLASSHIP_ERR_DEVICE; }
             arenaBuf = dArena.p; ga.out = arenaBuf; ga.arenaNum = 2;
-            PH_CHECK(hipMemsetAsync(ss->counters, 0, 8, st)); PH_CHECK(hipMemsetAsync(ss->counters + 3, 0, 8, st)); PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
+            PH_CHECK(hipMemsetAsync(ss->counters + 3, 0, 8, st)); PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
             if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
             else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
             hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, 2u, 2u, dArenaStart.as<uint64_t>());
@@ -2475,7 +2418,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     uint64_t NmLocal = 0;
     for (uint32_t j = 0; j < gGrid; j++) NmLocal += hOutCnt[j];
     uint64_t Nm = NmLocal;
-    const uint64_t NkLocal = ss ? (uint64_t) hCache[0] : ks[1] + ks[3];   // records the extraction kernels of this rank wrote (sentinels excluded); with a store: records the group kernel met
+    const uint64_t NkLocal = ks[1] + ks[3] + (ss ? (uint64_t) hCache[2] : 0ull);   // records the extraction kernels of this rank wrote (sentinels excluded) + the store's alive records
     const uint64_t Nk = cm ? NkAll : NkLocal;                // ... and of the whole run
     std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
     if (ss) for (uint32_t b = 0; b < VH_BINS; b++) hVHistG[b] += hVHistS[b];
@@ -2743,7 +2686,7 @@ template <bool NUCL, bool LONG>
 int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
                   plasship_kmermatch_stats *stats, KmerCache *kc = nullptr, bool *cacheOverflow = nullptr) {
     // kc (record cache, section 8: single GPU, protein DB, 16-byte records, store valid for THIS db): the slot array holds the dynamic
-    // records only — identity records of the static sequences, the sequences queued for the wave tiers, KILL records behind them
+    // records only — identity records of the static sequences and the records of the sequences queued for the wave tiers
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
@@ -2763,13 +2706,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     if (useLinesEarly) PH_CHECK(hipEventRecord(ctx->ev[0], st)); else tm.start(0);
-    DevBuf dKillBound, dKillOff; uint64_t killTotal = 0, dynTotal = 0;
     if (kc) {
-        if (dKillBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dKillOff.alloc(((size_t) N + 2) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        if (N) hipLaunchKernelGGL(dynBoundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), kc->state.as<uint8_t>(), kc->off.as<uint64_t>(), N, k, par->kmers_per_seq,
-                                  par->kmers_per_seq_scale, dBound.as<uint32_t>(), dKillBound.as<uint32_t>());
-        if (exclusiveScanU32(st, dKillBound.as<uint32_t>(), dKillOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-        PH_CHECK(hipMemcpyAsync(&killTotal, dKillOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+        if (N) hipLaunchKernelGGL(dynBoundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), kc->state.as<uint8_t>(), N, k, par->kmers_per_seq,
+                                  par->kmers_per_seq_scale, dBound.as<uint32_t>());
     } else
     if (N) hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
     if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
@@ -2787,7 +2726,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemcpyAsync(&total, dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
     }
-    if (kc) { dynTotal = total; total += killTotal; }            // the kill slots lie behind the sequences' own slots
     const uint32_t nMine = sHi - sLo;
 
     DevBuf dA, dB;   // ping-pong record arrays
@@ -2845,15 +2783,13 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         ca.hugeList = dOvIds.as<uint32_t>(); ca.hugeCount = dOvCnt.as<uint32_t>(); ca.killList = dKillList.as<uint32_t>(); ca.killCount = dKillCount.as<uint32_t>();
         ca.longWindows = TIER0_WINDOWS; ca.hugeWindows = 64 * 16; ca.kstats = dKStats.as<unsigned long long>();
         hipLaunchKernelGGL(classifyKernel, dim3(std::min<uint32_t>((N + 255) / 256, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, ca);
-        if (killTotal) {
+        {   // the sequences that have just changed leave the store (the list is on the device: no wait to learn whether it is empty)
             KillArgs ka; memset(&ka, 0, sizeof(ka));
-            ka.oldData = kc->data.as<char>(); ka.oldOff = kc->off.as<uint64_t>(); ka.killList = dKillList.as<uint32_t>(); ka.killCount = dKillCount.as<uint32_t>(); ka.killOff = dKillOff.as<uint64_t>();
-            ka.killBase = dynTotal; ka.arr = ea.arr; ka.map = ea.map; ka.k = k; ka.xCode = ea.xCode; ka.base = (uint64_t) (alph - 1); ka.top = ea.powers[k - 1];
-            { uint64_t b = ka.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; ka.tz = tz; ka.inv = inv; }
-            ka.state = kc->state.as<uint8_t>(); ka.valueHist = kc->vhist.as<uint32_t>();
+            ka.killList = dKillList.as<uint32_t>(); ka.killCount = dKillCount.as<uint32_t>(); ka.slotOff = kc->slotOff.as<uint64_t>(); ka.locMap = kc->locMap.as<uint32_t>();
+            ka.store = reinterpret_cast<Rec<false> *>(kc->recs.p); ka.state = kc->state.as<uint8_t>(); ka.valueHist = kc->vhist.as<uint32_t>();
             { int kb = 0; long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (kb < 63 && (long double) (1ULL << kb) < v) kb++; ka.valueShift = std::max(0, kb - 11); }
             ka.alive = kc->counters.as<unsigned long long>() + 2;
-            hipLaunchKernelGGL(killKernel, dim3((unsigned) std::min<uint64_t>((N + 63) / 64, (uint64_t) ctx->numCU * 16)), dim3(64), 0, st, ka);
+            hipLaunchKernelGGL(killKernel, dim3((unsigned) std::min<uint64_t>(((uint64_t) N + 15) / 16, (uint64_t) ctx->numCU * 16)), dim3(256), 0, st, ka);
         }
         twoLists = true;
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
@@ -2950,9 +2886,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         StaticStoreView sv; memset(&sv, 0, sizeof(sv));
         if (kc) {
             sv.recs = kc->recs.p; sv.list = kc->list.as<uint32_t>(); sv.tags = kc->tags.as<uint32_t>(); sv.fineBeg = kc->fineBeg.as<uint32_t>(); sv.fineCnt = kc->fineCnt.as<uint32_t>();
-            sv.totLines = kc->tot2.as<uint64_t>(); sv.capLines = kc->capLines; sv.vhist = kc->vhist.as<uint32_t>(); sv.counters = kc->counters.as<unsigned long long>(); sv.hasKills = killTotal ? 1 : 0;
-            PH_CHECK(hipMemsetAsync(kc->counters.p, 0, 16, st));        // [0] records grouped, [1] kill-set overflow; [2] (alive static records) stays
-            PH_CHECK(hipMemsetAsync(kc->counters.as<unsigned long long>() + 3, 0, 8, st));   // [3] an arena was too small
+            sv.totLines = kc->tot2.as<uint64_t>(); sv.capLines = kc->capLines; sv.vhist = kc->vhist.as<uint32_t>(); sv.counters = kc->counters.as<unsigned long long>();
+            PH_CHECK(hipMemsetAsync(kc->counters.as<unsigned long long>() + 3, 0, 8, st));   // [3] an arena was too small ([2], the alive static records, stays)
         }
         int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, kc ? &sv : nullptr);
         if (rcL) return rcL;
@@ -3295,9 +3230,9 @@ extern "C" int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, c
         }
         bool overflow = false;
         const int rc = kmermatchImpl<false, false>(ctx, db, par, out, stats, &kc, &overflow);
-        if (rc) { kc.clear(); return rc; }                    // (a failed call may have consumed kill records half-way: the store is rebuilt next time)
+        if (rc) { kc.clear(); return rc; }                    // (a failed call may have removed records of changed sequences already: the store is rebuilt next time)
         if (!overflow) return PLASSHIP_OK;
-        kc.clear();                                           // more kill records in a bucket than its set takes: this call runs without a store, the next one rebuilds it
+        kc.clear();                                           // (no path sets `overflow` today: kept as the way out for a store that cannot serve a call)
     } else if (ctx->kcache) ctx->kcache->clear();
     return commFinish(ctx, lng ? kmermatchImpl<false, true>(ctx, db, par, out, stats) : kmermatchImpl<false, false>(ctx, db, par, out, stats));
 }

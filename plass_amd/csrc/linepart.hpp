@@ -104,7 +104,6 @@ struct LinePartArgs {
     int direct;                                  // records of lines that complete inside a tile go straight to HBM (see linePartKernel)
     unsigned long long *minKey;                  // optional (EXTRAS, NUCL): global minimum of (kmer | BIT63) (first-run quirk)
     uint32_t *valueHist; int valueShift;         // optional (EXTRAS)
-    int killAware;                               // EXTRAS, 16-byte records: records with len == 0xFFFF (KILL records of the record cache) stay out of the value histogram
 };
 
 static inline size_t linePartLdsBytes(uint32_t nb, size_t recBytes, bool extras) {
@@ -174,9 +173,7 @@ __global__ __launch_bounds__(LP_BLOCK) void linePartKernel(LinePartArgs a) {
                         const uint32_t b = lineBucket<NUCL, MODE>(a.key, rec[u].kmer, nb);
                         bk[u] = b; sq[u] = atomicAdd(&cnt[b], 1u); pending |= 1u << u;
                         if (EXTRAS) {
-                            bool counts = true;
-                            if constexpr (!LONG) counts = !(a.killAware && rec[u].len == 0xFFFFu);
-                            if (a.valueHist && counts) atomicAdd(&vh[valueBin<NUCL>(rec[u].kmer, a.valueShift)], 1u);
+                            if (a.valueHist) atomicAdd(&vh[valueBin<NUCL>(rec[u].kmer, a.valueShift)], 1u);
                             if (NUCL && a.minKey) mn = min(mn, (unsigned long long) (rec[u].kmer | BIT63));
                         }
                     }
@@ -225,7 +222,13 @@ __global__ __launch_bounds__(LP_BLOCK) void linePartKernel(LinePartArgs a) {
                 __syncthreads();
                 for (uint32_t b = tid; b < nb; b += LP_BLOCK) flushed[b] = cnt[b];
                 outLine += total;
-                continue;                                           // (the next tile's barrier orders these writes before its reads)
+                // The next tile's first step is an atomicAdd on cnt[]: it must not run ahead of another wavefront's copy above, or that
+                // wavefront files the next tile's records under "flushed" and the line accounting of the bucket is off for the rest of
+                // the piece (lines written twice or beyond the piece's range).  Round 2 had no barrier here; the window only opened when
+                // another stream's kernels shared the CUs — the two rank threads of tests/test_gpu_sharded.py::test_full_size… at
+                // 1 M reads faulted in this kernel (profiles/r03_call3_gdb_fault.log).
+                __syncthreads();
+                continue;
             }
             // rounds: a record joins the open line of its bucket when that line is the one it belongs to (its running number / 8);
             // a round closes at most one line per bucket, the workgroup then writes the closed lines as one contiguous run

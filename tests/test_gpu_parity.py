@@ -635,12 +635,12 @@ print("CHAIN_OK")
 
 
 def test_record_cache_is_invisible(tmp_path):
-    """the record cache of plasship_kmermatch (static store of the unchanged short sequences, KILL records for the ones that change:
-    kmermatch.hip section 8) against the same chain without it: identical N_k / N_m / N_c, candidate DBs and output DBs in all six
-    iterations — once more with a kill set of 4 entries, which overflows in nearly every bucket and must fall back to a full run, and
-    once more with arenas too small for iteration 0, which must run the group kernel again with full arenas"""
+    """the record cache of plasship_kmermatch (static store of the unchanged short sequences; the records of a sequence that changes
+    are removed through the location map: kmermatch.hip section 8) against the same chain without it: identical N_k / N_m / N_c,
+    candidate DBs and output DBs in all six iterations — and once more with arenas too small for iteration 0, which must run the group
+    kernel again with full arenas"""
     ref = _cache_chain(tmp_path, "off", {"PLASSHIP_KMER_CACHE": "0"})
-    for tag, env in (("on", {"PLASSHIP_KMER_CACHE": "1"}), ("ovf", {"PLASSHIP_KMER_CACHE": "1", "PLASSHIP_TUNE_KILL_MAX": "4"}),
+    for tag, env in (("on", {"PLASSHIP_KMER_CACHE": "1"}),
                      ("arena", {"PLASSHIP_KMER_CACHE": "1", "PLASSHIP_TUNE_ARENA_QUARTERS": "1"})):     # half-size arenas everywhere: iteration 0 overflows them and runs again with full ones
         got = _cache_chain(tmp_path, tag, env)
         assert got == ref, (tag, got, ref)
