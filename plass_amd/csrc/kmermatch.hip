@@ -236,8 +236,8 @@ __device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k,
 //   trips, so resident wavefronts count for more than registers — 6 for the 4-scores tier (80 VGPRs; 4: +30 % time; 8 would gain
 //   another 4 % but its 144 bytes of scratch per lane turn into 90 GB of memory traffic per launch), 4 for the 16-scores tier (5 gains nothing), 4 for the 48-scores tier of protein runs (128 VGPRs
 //   and 200+ bytes of scratch, yet 3.0 instead of 4.7 ms per 120 k sequences of 2500 residues at 2 wavefronts).
-template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((REGS > 0 && REGS <= 4) ? 6 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 4 : 1))))) void extractKernel(ExtractArgs a) {
+template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992, int WPE = 0>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : ((REGS > 0 && REGS <= 4) ? 6 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 4 : 1)))))) void extractKernel(ExtractArgs a) {
     constexpr uint32_t RES_L = RESL;
     constexpr uint32_t CODES = (RESL > 64 * REGS + 32 ? RESL : 64 * REGS + 32) + 32;
     __shared__ unsigned char sMap[256];
@@ -849,50 +849,57 @@ __global__ __launch_bounds__(256) void classifyKernel(ClassifyArgs a) {
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
 }
-// where every record of the store lies: locMap[slotOff[id] + pos] = line * RPL + slot (slotOff = the static slot offsets: one slot per
-// window).  One pass over the finished store; the map is what lets a sequence that changes later remove its records directly.
-constexpr uint32_t LOC_NONE = 0xFFFFFFFFu;
-__global__ __launch_bounds__(256) void locMapKernel(const Rec<false> *__restrict__ recs, const uint32_t *__restrict__ tags, uint64_t nLines, const uint64_t *__restrict__ nLinesDev,
-                                                    const uint64_t *__restrict__ slotOff, uint32_t *__restrict__ locMap) {
-    if (nLinesDev) nLines = min(nLines, (uint64_t) *nLinesDev);
-    for (uint64_t g = (uint64_t) blockIdx.x * 256 + threadIdx.x; g < nLines * RPL; g += (uint64_t) gridDim.x * 256) {
-        if (tags[g / RPL] == TAG_NONE) continue;
-        const Rec<false> r = recs[g];
-        if (!isSentinel(r)) locMap[slotOff[r.id] + (uint32_t) r.pos] = (uint32_t) g;
+// bit i of the ALIVE bitmap: the store's records of sequence i are valid (set for the sequences the static-mode kernel took)
+__global__ void aliveBitsKernel(const uint8_t *__restrict__ state, uint32_t n, uint32_t *__restrict__ bits) {
+    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < (n + 31) / 32; w += gridDim.x * blockDim.x) {
+        uint32_t v = 0;
+        for (uint32_t j = 0; j < 32 && w * 32 + j < n; j++) v |= (state[w * 32 + j] == 1 ? 1u : 0u) << j;
+        bits[w] = v;
     }
 }
-struct KillArgs {
-    const uint32_t *killList, *killCount; const uint64_t *slotOff; const uint32_t *locMap; Rec<false> *store;
-    uint8_t *state; uint32_t *valueHist; int valueShift; unsigned long long *alive;
+struct RetireArgs {
+    const char *oldData; const uint64_t *oldOff; const uint32_t *killList, *killCount; const unsigned char *map;
+    int k, xCode; uint64_t base, top, inv; int tz;
+    uint8_t *state; uint32_t *aliveBits; uint32_t *valueHist; int valueShift; unsigned long long *alive;
 };
-// a static sequence whose bytes have changed leaves the store: every record the location map names for it becomes a sentinel (the group
-// kernel skips sentinels), the value histogram and the count of alive records follow; the sequence is dynamic from now on
-__global__ __launch_bounds__(256) void killKernel(KillArgs a) {
+// A static sequence whose bytes have changed leaves the store: its alive bit goes (the group kernel ignores the store's records of a
+// sequence without one — the store itself is never written after it is built), and what the store contributed for it is taken out of
+// the books: the k-mers of its OLD bytes (the store's copy of the DB it was built from; every window without an X, the store only
+// holds sequences without repeats) leave the value histogram, their number leaves the count of alive records.
+__global__ __launch_bounds__(64) void retireKernel(RetireArgs a) {
+    __shared__ unsigned char sMap[256];
     __shared__ uint32_t sHist[VH_BINS];
-    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 256) sHist[i] = 0;
+    for (int i = threadIdx.x; i < 256; i += 64) sMap[i] = a.map[i];
+    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) sHist[i] = 0;
     __syncthreads();
     const uint32_t n = *a.killCount;
-    unsigned long long killed = 0;
-    Rec<false> sen; memset(&sen, 0xFF, sizeof(sen)); sen.len = 0; sen.pos = 0;
-    // 16 lanes per sequence: its <= 128 windows are independent random accesses
-    const int gl = threadIdx.x & 15;
-    for (uint32_t w = blockIdx.x * 16 + (threadIdx.x >> 4); w < n; w += gridDim.x * 16) {
+    unsigned long long retired = 0;
+    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < n; w += gridDim.x * 64) {
         const uint32_t id = a.killList[w];
-        const uint64_t s0 = a.slotOff[id]; const uint32_t nw = (uint32_t) (a.slotOff[id + 1] - s0);
-        for (uint32_t p = gl; p < nw; p += 16) {
-            const uint32_t g = a.locMap[s0 + p];
-            if (g == LOC_NONE) continue;
-            const Rec<false> r = a.store[g];
-            if (r.id != id) continue;                        // (cannot happen: the map names this sequence's records only)
-            atomicAdd(&sHist[valueBin<false>(r.kmer, a.valueShift)], 1u);
-            a.store[g] = sen; killed++;
+        const uint64_t o = a.oldOff[id]; const uint32_t L = (uint32_t) (a.oldOff[id + 1] - o) - 2u;
+        const char *base = a.oldData + o;
+        uint64_t idx = 0, fifoLo = 0, fifoHi = 0, pw = 1; int lastX = -1;
+        for (uint32_t i = 0; i < L; i++) {
+            const unsigned char c = sMap[(unsigned char) base[i]];
+            if (c == (unsigned char) a.xCode) lastX = (int) i;
+            if (i < (uint32_t) a.k) {
+                idx += (uint64_t) c * pw; pw *= a.base;
+                if (i < 8) fifoLo |= (uint64_t) c << (8 * i); else fifoHi |= (uint64_t) c << (8 * (i - 8));
+            } else {
+                const uint64_t cOut = fifoLo & 0xFF;
+                idx = (((idx - cOut) >> a.tz) * a.inv) + (uint64_t) c * a.top;
+                fifoLo = (fifoLo >> 8) | (fifoHi << 56); fifoHi >>= 8;
+                if (a.k - 1 < 8) fifoLo |= (uint64_t) c << (8 * (a.k - 1)); else fifoHi |= (uint64_t) c << (8 * (a.k - 1 - 8));
+            }
+            if (i + 1 >= (uint32_t) a.k && lastX < (int) (i + 1 - a.k)) { atomicAdd(&sHist[valueBin<false>(idx, a.valueShift)], 1u); retired++; }
         }
-        if (gl == 0) a.state[id] = 0;
+        atomicAnd(&a.aliveBits[id >> 5], ~(1u << (id & 31)));
+        a.state[id] = 0;
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 256) { const uint32_t c = sHist[i]; if (c) atomicSub(&a.valueHist[i], c); }
-    killed = waveReduceSumU64(killed);
-    if (laneId() == 0 && killed) atomicAdd(a.alive, (unsigned long long) (0ull - killed));
+    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) { const uint32_t c = sHist[i]; if (c) atomicSub(&a.valueHist[i], c); }
+    retired = waveReduceSumU64(retired);
+    if (threadIdx.x == 0 && retired) atomicAdd(a.alive, (unsigned long long) (0ull - retired));
 }
 __global__ void arenaStart2Kernel(const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ lineBeg2, uint32_t bpb, uint32_t gGrid, uint32_t nBuckets, uint32_t num, uint32_t den,
                                   uint64_t *__restrict__ arenaStart) {
@@ -1035,7 +1042,7 @@ struct GroupArgs {
     const unsigned long long *minKey;   // NUCL: K of the globally first run
     unsigned long long *maxRepTarget;   // max over emitted records of (rep << 32 | member): the last run of sort #2
     // groupLinesKernel<TWO> (record cache): the static store's line lists in front of the call's own; cacheCounters[3]: an arena was too small
-    const uint32_t *list2, *lineBeg2, *lineCnt2; uint64_t delta1, delta2; unsigned long long *cacheCounters;
+    const uint32_t *list2, *lineBeg2, *lineCnt2, *aliveBits; uint64_t delta1, delta2; unsigned long long *cacheCounters;
     // TWO: a workgroup's arena begins at line (arenaNum * (lineBeg + lineBeg2) / arenaDen) and ends where the next one begins (allLines for the
     // last): with arenaNum / arenaDen < 1 the arenas hold less than the workgroup reads — cacheCounters[3] is set if one does not suffice
     uint32_t arenaNum, arenaDen; uint64_t allLines;
@@ -1237,23 +1244,32 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         const uint64_t line = (uint64_t) (st ? a.list2[j] : a.list[j]) + (st ? a.delta2 : a.delta1);
         return in[line * RPL + (i % RPL)];
     };
+    // The store is immutable: a record of it counts while its sequence's ALIVE bit stands (11 MB of bits for 88 M sequences: L2 / MALL
+    // resident).  One bit per register slot says which of the thread's records belong to a retired sequence.
+    auto retired = [&](const R &r) { return !isSentinel(r) && !((a.aliveBits[r.id >> 5] >> (r.id & 31)) & 1u); };
+    uint32_t deadNext = 0;
     auto fetch = [&](uint32_t b) {
         nSNext = (TWO && b < bEnd) ? a.lineCnt2[b] * RPL : 0u; lb2Next = (TWO && b < bEnd) ? a.lineBeg2[b] : 0u;
         nNext = nSNext + ((b < bEnd) ? a.lineCnt[b] * RPL : 0u); lbNext = (b < bEnd) ? a.lineBeg[b] : 0u;
+        deadNext = 0;
         if (nNext && nNext <= (uint32_t) GL_RMAX * BLOCK) {
 #pragma unroll
             for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? recOf(i, nSNext, lbNext, lb2Next) : none; }
+            if (TWO) {
+#pragma unroll
+                for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; if (i < nSNext && retired(rg[j])) deadNext |= 1u << j; }
+            }
         }
     };
     uint32_t par = 0;                                // which cursor the current sub-pass uses (workgroup-uniform)
     fetch(bBegin);
     for (uint32_t b = bBegin; b < bEnd; b++) {
         const uint32_t n = nNext;                    // record positions of the bucket (padding sentinels included)
-        const uint32_t lb = lbNext, nS = nSNext, lb2 = lb2Next;
+        const uint32_t lb = lbNext, nS = nSNext, lb2 = lb2Next, dead = deadNext;
         if (n == 0) { fetch(b + 1); continue; }
         const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
         bool fetched = false;
-        auto recAt = [&](uint32_t i) -> R { return recOf(i, nS, lb, lb2); };
+        auto recAt = [&](uint32_t i) -> R { R r = recOf(i, nS, lb, lb2); if (TWO && i < nS && retired(r)) r = none; return r; };
         // phase A on one record: claim the k-mer's slot, mark a second member, and bid for the run head; called by whole wavefronts
         // (new k-mers are counted once per wavefront, not with one LDS atomic per record on a single word)
         auto phaseA = [&](const R &r, uint32_t nSub, uint32_t sub) {
@@ -1338,13 +1354,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 __syncthreads();
                 if (inRegs) {
 #pragma unroll
-                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseA(rg[j], nSub, sub);
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseA((TWO && ((dead >> j) & 1u)) ? none : rg[j], nSub, sub);
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseA(i < n ? recAt(i) : none, nSub, sub); }
                 __syncthreads();
                 if (sFlag[1] || sFlag[0] > MAXKEYS) { redo = true; __syncthreads(); break; }
                 if (inRegs) {
 #pragma unroll
-                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseC(rg[j], nSub, sub);
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseC((TWO && ((dead >> j) & 1u)) ? none : rg[j], nSub, sub);
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseC(i < n ? recAt(i) : none, nSub, sub); }
                 if (sub + 1 == nSub) { fetch(b + 1); fetched = true; }     // last sub-pass: nothing reads this bucket's registers again
                 __syncthreads();
@@ -1730,7 +1746,7 @@ __global__ __launch_bounds__(256) void rankKernel(const void *recs, uint64_t n, 
 // the same over a line store: every written line (tag != TAG_NONE) of the hash-partitioned records, padding sentinels skipped
 template <bool NUCL, bool LONG>
 __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const uint32_t *__restrict__ tags, uint64_t nLines, const uint64_t *__restrict__ nLinesDev,
-                                                       const void *tkeys, uint32_t m, unsigned long long *diff) {
+                                                       const void *tkeys, uint32_t m, unsigned long long *diff, const uint32_t *__restrict__ aliveBits = nullptr) {
     typedef Rec<LONG> R;
     if (nLinesDev) nLines = min(nLines, (uint64_t) *nLinesDev);        // lines the last partition level laid out (the rest of the tag array was never written)
     const R *g = reinterpret_cast<const R *>(recs);
@@ -1742,6 +1758,7 @@ __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const u
         if (tags && tags[i / RPL] == TAG_NONE) continue;                // tags == nullptr: every line is valid (received lines of a sharded run)
         const R r = g[i];
         if (isSentinel(r)) continue;
+        if (aliveBits && !((aliveBits[r.id >> 5] >> (r.id & 31)) & 1u)) continue;      // (record cache: the store's records of a retired sequence)
         uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
         if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
@@ -2074,11 +2091,12 @@ static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; ds
 //    bucket's static and dynamic lines together (groupLinesKernel<TWO>).
 //      * Which sequences are unchanged is not guessed: an output DB of the extension modules names its parent DB and carries a
 //        per-sequence `changed` byte (buildOutputDB, assemble.hip); a DB without that lineage rebuilds the store.
-//      * A static sequence that changes becomes dynamic for good and its records leave the store: a LOCATION MAP (one 32-bit position
-//        per window of every static sequence, filled by one pass over the finished store) says where they lie, and killKernel overwrites
-//        them with sentinels — no search, nothing extra through the partition, nothing in the group kernel.  (A first version sent KILL
-//        records through the dynamic partition and matched them in an LDS set inside the group kernel: every static record of a bucket
-//        paid a probe, the kernel spilled 70 VGPRs, and grouping went from 38 to 117 ms per iteration at 50 M reads.)
+//      * The store is IMMUTABLE.  A static sequence that changes becomes dynamic for good; its records stay where they are and stop
+//        counting: an ALIVE bit per sequence (11 MB for 88 M sequences: L2 / Infinity Cache resident) is cleared, and the group kernel
+//        drops the store's records of a sequence without one as it loads them.  (Two earlier versions removed the records instead —
+//        KILL records matched in an LDS set inside the group kernel: every static record paid a probe and the kernel spilled 70 VGPRs,
+//        grouping went from 38 to 117 ms per iteration at 50 M reads; then a location map (one position per window) filled by a pass
+//        over the finished store: 3 G random 4-byte stores made building the store cost 255 ms.  profiles/r03_call4_*, r03_call5_*.)
 //      * What the rest of the path needs from "all records" is kept exact: the count (alive static + dynamic), the value histogram of
 //        the stale-record check (static histogram minus kills + dynamic), the rank pass (both stores).
 //    The result is the reference's, bit for bit, by construction: the multiset of records a bucket's grouping sees is unchanged.
@@ -2091,14 +2109,14 @@ struct KmerCache {
     int k = 0, alph = 0, kps = 0, ignoreMulti = 0; float scale = 0;
     int b1 = 0, b2 = 0; uint32_t nBuckets = 0;              // bucket bits of the store = of every dynamic partition while it lives
     DevBuf recs, list, tags, tot2, fineBeg, fineCnt; uint64_t capLines = 0;
-    DevBuf state, seqHash, slotOff, locMap, vhist, counters;  // counters: [2] alive static records, [3] "an arena was too small" flag of the last call
-    void clear() { valid = false; for (DevBuf *b : {&recs, &list, &tags, &tot2, &fineBeg, &fineCnt, &state, &seqHash, &slotOff, &locMap, &vhist, &counters}) b->release(); }
+    DevBuf state, seqHash, aliveBits, data, off, vhist, counters;  // counters: [2] alive static records, [3] "an arena was too small" flag of the last call
+    void clear() { valid = false; for (DevBuf *b : {&recs, &list, &tags, &tot2, &fineBeg, &fineCnt, &state, &seqHash, &aliveBits, &data, &off, &vhist, &counters}) b->release(); }
 };
 void kmerCacheFree(plasship_ctx *ctx) { if (ctx && ctx->kcache) { ctx->kcache->clear(); delete ctx->kcache; ctx->kcache = nullptr; } }
 }  // namespace plasship
 namespace {
 // what kmermatchLines needs of the store
-struct StaticStoreView { const void *recs; const uint32_t *list, *tags, *fineBeg, *fineCnt; const uint64_t *totLines; uint64_t capLines; uint32_t *vhist; unsigned long long *counters; };
+struct StaticStoreView { const void *recs; const uint32_t *list, *tags, *fineBeg, *fineCnt, *aliveBits; const uint64_t *totLines; uint64_t capLines; uint32_t *vhist; unsigned long long *counters; };
 
 static LineGeo lineGeometryBits(uint64_t totalSlots, int b1, int b2, int numCU) {       // caps for `totalSlots` with given bucket bits
     LineGeo g; g.b1 = b1; g.b2 = b2; g.nb1 = 1u << b1; g.nb2 = b2 ? 1u << b2 : 0u;
@@ -2117,15 +2135,18 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n; const int k = par->kmer_size, numCU = ctx->numCU;
     kc.clear();
-    DevBuf dBound, dScanTmp, dKS; DevBuf &dSlotOff = kc.slotOff;
+    DevBuf dBound, dSlotOff, dScanTmp, dKS;
     const size_t scanTmpBytes = exclusiveScanTmpBytes((size_t) N + 2) + (1u << 20);
-    if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.allocHigh(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess || dKS.alloc(32) != hipSuccess ||
-        kc.state.allocHigh((size_t) N + 1) != hipSuccess || kc.seqHash.allocHigh(((size_t) N + 1) * 8) != hipSuccess ||
+    if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess || dKS.alloc(32) != hipSuccess ||
+        kc.state.allocHigh((size_t) N + 1) != hipSuccess || kc.seqHash.allocHigh(((size_t) N + 1) * 8) != hipSuccess || kc.aliveBits.allocHigh(((size_t) N / 32 + 2) * 4) != hipSuccess ||
+        kc.data.allocHigh(db->dataBytes + 64) != hipSuccess || kc.off.allocHigh(((size_t) N + 1) * 8) != hipSuccess ||
         kc.vhist.allocHigh(VH_BINS * 4) != hipSuccess || kc.counters.allocHigh(32) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(kc.state.p, 0, (size_t) N + 1, st));
     PH_CHECK(hipMemsetAsync(kc.vhist.p, 0, VH_BINS * 4, st));
     PH_CHECK(hipMemsetAsync(kc.counters.p, 0, 32, st));
     PH_CHECK(hipMemsetAsync(dKS.p, 0, 32, st));
+    PH_CHECK(hipMemcpyAsync(kc.data.p, db->d_data.p, db->dataBytes, hipMemcpyDeviceToDevice, st));        // the bytes the store's records were made from (retireKernel)
+    PH_CHECK(hipMemcpyAsync(kc.off.p, db->d_off.p, ((size_t) N + 1) * 8, hipMemcpyDeviceToDevice, st));
     // bucket bits from ALL record slots of the DB (what a call without a store would use), slots of the store from the static bounds
     uint64_t totals[2] = {0, 0};
     hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
@@ -2186,12 +2207,7 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
         PH_CHECK(hipMemcpyAsync(kc.tot2.p, &cap, 8, hipMemcpyHostToDevice, st));
         moveBuf(kc.recs, dB); moveBuf(kc.tags, dTag1); moveBuf(kc.list, dList1); kc.capLines = geo.cap1;
     }
-    // where every record lies (killKernel); positions are 32-bit
-    if (kc.capLines * RPL >= 0xFFFFFFFFull) { setError("kmermatch: the record store is too large for 32-bit positions"); return PLASSHIP_ERR_UNSUPPORTED; }
-    if (kc.locMap.allocHigh(std::max<uint64_t>(totals[1], 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(kc.locMap.p, 0xFF, std::max<uint64_t>(totals[1], 1) * 4, st));
-    hipLaunchKernelGGL(locMapKernel, dim3(gridFor(kc.capLines * RPL, 256, (unsigned) numCU * 16)), dim3(256), 0, st, (const Rec<false> *) kc.recs.p, (const uint32_t *) kc.tags.as<uint32_t>(), kc.capLines,
-                       (const uint64_t *) kc.tot2.as<uint64_t>(), (const uint64_t *) kc.slotOff.as<uint64_t>(), kc.locMap.as<uint32_t>());
+    hipLaunchKernelGGL(aliveBitsKernel, dim3(gridFor(N / 32 + 1, 256, 4096)), dim3(256), 0, st, (const uint8_t *) kc.state.as<uint8_t>(), N, kc.aliveBits.as<uint32_t>());
     PH_CHECK(plasship::streamSync(st));                       // (`cap` and the temporaries go out of scope)
     PH_CHECK(hipGetLastError());
     kc.b1 = geo.b1; kc.b2 = geo.b2; kc.N = N; kc.k = k; kc.alph = par->alphabet_size; kc.kps = par->kmers_per_seq; kc.scale = par->kmers_per_seq_scale; kc.ignoreMulti = par->ignore_multi_kmer;
@@ -2337,7 +2353,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         // Static and dynamic lines of a workgroup's buckets together bound what it emits: arenas addressed by the sum of both line
         // numbers.  At 50 M reads that bound is 85 GB for the 6 GB an extendable-only iteration emits (N_m / N_k is 0.1-0.3 there), next
         // to the 49 GB store: such iterations get HALF the bound, and a workgroup whose arena does not suffice says so — the group
-        // kernel then runs again with full arenas (it changes nothing it reads except store records it has already killed).
+        // kernel then runs again with full arenas.
         if (geo.nb2) dB.release(); else dA.release();        // level 1's output / the slot array: dead, the arenas need the room
         arenaNum = par->include_only_extendable ? 1u : 2u;
         if (dArena.alloc(std::max<uint64_t>((finalCap + ss->capLines) * arenaNum / 2 + 1, 1) * RPL * sizeof(R)) != hipSuccess) {
@@ -2365,10 +2381,13 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
             // the arena hands out 256-byte aligned blocks)
             const char *pd = (const char *) finalRecs, *ps = (const char *) ss->recs; const size_t lineBytes = RPL * sizeof(R);
             ga.in = pd < ps ? pd : ps; ga.delta1 = (uint64_t) (pd - (const char *) ga.in) / lineBytes; ga.delta2 = (uint64_t) (ps - (const char *) ga.in) / lineBytes;
-            ga.list2 = ss->list; ga.lineBeg2 = ss->fineBeg; ga.lineCnt2 = ss->fineCnt; ga.cacheCounters = ss->counters;
+            ga.list2 = ss->list; ga.lineBeg2 = ss->fineBeg; ga.lineCnt2 = ss->fineCnt; ga.cacheCounters = ss->counters; ga.aliveBits = ss->aliveBits;
             if (tuneInt("ARENA_QUARTERS", 0)) arenaNum = 1;                                                 // (tests: force the retry with full arenas)
             ga.arenaNum = arenaNum; ga.arenaDen = 2; ga.allLines = finalCap + ss->capLines;
-            if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
+            // the store keeps the positions of retired sequences: late iterations have more than 4096 positions per bucket (3 000 of the
+            // store + 2 000 dynamic at 50 M reads) — 1024 threads hold 8192 in registers (one workgroup per CU: the same 4 wavefronts per SIMD)
+            if (wideGroup && avgPos > 3700 && tuneInt("GROUP_1024", 1)) hipLaunchKernelGGL((groupLinesKernel<false, 1024, 8192, 4, true>), dim3(gGrid), dim3(1024), 0, st, ga);
+            else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
             else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
             hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, arenaNum, 2u, dArenaStart.as<uint64_t>());
             launchedTwo = true;
@@ -2397,13 +2416,15 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipGetLastError());
     if constexpr (!NUCL && !LONG) {
         if (ss && hCache[3]) {
-            // an arena of half the bound did not suffice somewhere: once more with full arenas (the kills of the first run have been
-            // applied to the store already; applying them again finds nothing)
+            // an arena of half the bound did not suffice somewhere: once more with full arenas (the kernel writes nothing but its arenas)
             dArena.release();
             if (dArena.alloc(std::max<uint64_t>(finalCap + ss->capLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records (full arenas)"); return PLASSHIP_ERR_DEVICE; }
             arenaBuf = dArena.p; ga.out = arenaBuf; ga.arenaNum = 2;
             PH_CHECK(hipMemsetAsync(ss->counters + 3, 0, 8, st)); PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
-            if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
+            // the store keeps the positions of retired sequences: late iterations have more than 4096 positions per bucket (3 000 of the
+            // store + 2 000 dynamic at 50 M reads) — 1024 threads hold 8192 in registers (one workgroup per CU: the same 4 wavefronts per SIMD)
+            if (wideGroup && avgPos > 3700 && tuneInt("GROUP_1024", 1)) hipLaunchKernelGGL((groupLinesKernel<false, 1024, 8192, 4, true>), dim3(gGrid), dim3(1024), 0, st, ga);
+            else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
             else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
             hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, 2u, 2u, dArenaStart.as<uint64_t>());
             hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
@@ -2483,7 +2504,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
             hipLaunchKernelGGL((rankLinesKernel<NUCL, LONG>), dim3(gridFor(finalCap * RPL, 256, (unsigned) numCU * 8)), dim3(256), 0, st, (const void *) finalRecs, finalTags, finalCap, geo.nb2 ? (const uint64_t *) dTot2.as<uint64_t>() : (const uint64_t *) nullptr,
                                (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
             if (ss) hipLaunchKernelGGL((rankLinesKernel<NUCL, LONG>), dim3(gridFor(ss->capLines * RPL, 256, (unsigned) numCU * 8)), dim3(256), 0, st, ss->recs, ss->tags, ss->capLines, ss->totLines,
-                                       (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
+                                       (const void *) dTRec.p, m, dDiff.as<unsigned long long>(), ss->aliveBits);
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(plasship::streamSync(st));
@@ -2784,12 +2805,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         ca.longWindows = TIER0_WINDOWS; ca.hugeWindows = 64 * 16; ca.kstats = dKStats.as<unsigned long long>();
         hipLaunchKernelGGL(classifyKernel, dim3(std::min<uint32_t>((N + 255) / 256, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, ca);
         {   // the sequences that have just changed leave the store (the list is on the device: no wait to learn whether it is empty)
-            KillArgs ka; memset(&ka, 0, sizeof(ka));
-            ka.killList = dKillList.as<uint32_t>(); ka.killCount = dKillCount.as<uint32_t>(); ka.slotOff = kc->slotOff.as<uint64_t>(); ka.locMap = kc->locMap.as<uint32_t>();
-            ka.store = reinterpret_cast<Rec<false> *>(kc->recs.p); ka.state = kc->state.as<uint8_t>(); ka.valueHist = kc->vhist.as<uint32_t>();
-            { int kb = 0; long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (kb < 63 && (long double) (1ULL << kb) < v) kb++; ka.valueShift = std::max(0, kb - 11); }
-            ka.alive = kc->counters.as<unsigned long long>() + 2;
-            hipLaunchKernelGGL(killKernel, dim3((unsigned) std::min<uint64_t>(((uint64_t) N + 15) / 16, (uint64_t) ctx->numCU * 16)), dim3(256), 0, st, ka);
+            RetireArgs ra; memset(&ra, 0, sizeof(ra));
+            ra.oldData = kc->data.as<char>(); ra.oldOff = kc->off.as<uint64_t>(); ra.killList = dKillList.as<uint32_t>(); ra.killCount = dKillCount.as<uint32_t>(); ra.map = ea.map;
+            ra.k = k; ra.xCode = ea.xCode; ra.base = (uint64_t) (alph - 1); ra.top = ea.powers[k - 1];
+            { uint64_t b = ra.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; ra.tz = tz; ra.inv = inv; }
+            ra.state = kc->state.as<uint8_t>(); ra.aliveBits = kc->aliveBits.as<uint32_t>(); ra.valueHist = kc->vhist.as<uint32_t>();
+            { int kb = 0; long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (kb < 63 && (long double) (1ULL << kb) < v) kb++; ra.valueShift = std::max(0, kb - 11); }
+            ra.alive = kc->counters.as<unsigned long long>() + 2;
+            hipLaunchKernelGGL(retireKernel, dim3((unsigned) std::min<uint64_t>(((uint64_t) N + 63) / 64, (uint64_t) ctx->numCU * 16)), dim3(64), 0, st, ra);
         }
         twoLists = true;
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
@@ -2832,7 +2855,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         const uint32_t wide = std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU);
         // tiers 0 and 1 both queue into dOvIds
         if (twoLists) {
-            hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256>), dim3(wide), dim3(64), 0, st, ea);
+            if (tuneInt("TIER0_WPE", 6) == 5) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 5>), dim3(wide), dim3(64), 0, st, ea);
+            else if (tuneInt("TIER0_WPE", 6) == 7) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 7>), dim3(wide), dim3(64), 0, st, ea);
+            else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256>), dim3(wide), dim3(64), 0, st, ea);
             ExtractArgs e1 = ea; e1.waveList = dLongList.as<uint32_t>(); e1.waveCount = dLongCount.as<uint32_t>();
             hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, e1);
         } else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, ea);
@@ -2887,6 +2912,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         if (kc) {
             sv.recs = kc->recs.p; sv.list = kc->list.as<uint32_t>(); sv.tags = kc->tags.as<uint32_t>(); sv.fineBeg = kc->fineBeg.as<uint32_t>(); sv.fineCnt = kc->fineCnt.as<uint32_t>();
             sv.totLines = kc->tot2.as<uint64_t>(); sv.capLines = kc->capLines; sv.vhist = kc->vhist.as<uint32_t>(); sv.counters = kc->counters.as<unsigned long long>();
+            sv.aliveBits = kc->aliveBits.as<uint32_t>();
             PH_CHECK(hipMemsetAsync(kc->counters.as<unsigned long long>() + 3, 0, 8, st));   // [3] an arena was too small ([2], the alive static records, stays)
         }
         int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, kc ? &sv : nullptr);
