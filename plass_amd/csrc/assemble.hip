@@ -1129,9 +1129,6 @@ __global__ void listKernel(uint32_t n, const uint64_t *__restrict__ tierA, const
     }
 }
 
-__global__ void changedKernel(const uint32_t *__restrict__ flags, uint32_t n, uint8_t *__restrict__ changed) {
-    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < n; id += gridDim.x * blockDim.x) changed[id] = (flags[id] & 0x20u) ? 1 : 0;
-}
 __global__ void outLenKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen, int keepTarget,
                              uint64_t *__restrict__ outBytes, uint32_t *__restrict__ keep) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
@@ -1293,11 +1290,6 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
                               o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
     }
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
-    if (outN == N && N) {          // same ids as the input: the output names its parent and the sequences that differ from it
-        if (o->d_changed.alloc(N) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(changedKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, dFlags, N, o->d_changed.as<uint8_t>());
-        o->parentUid = db->uid;
-    }
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
     if (outN) hipLaunchKernelGGL(maxU32Kernel, dim3(std::min<uint64_t>((outN + 255) / 256, 1024)), dim3(256), 0, st, o->d_len.as<uint32_t>(), outN, dMaxLen.as<uint32_t>());
     uint32_t maxLen = 0;

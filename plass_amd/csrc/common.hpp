@@ -11,9 +11,6 @@
 
 namespace plasship {
 
-uint64_t nextDbUid();                       // identity of a sequence DB handle (core.hip)
-struct KmerCache;                           // record cache of plasship_kmermatch (kmermatch.hip, section 8)
-void kmerCacheFree(plasship_ctx *ctx);
 void setError(const std::string &msg);
 // every wait of the host for the stream goes through here and is counted (plasship_host_syncs(): bench.py reports waits per iteration)
 hipError_t streamSync(hipStream_t st);
@@ -52,8 +49,7 @@ bool traceOn();
 // Caching device allocator: hipMalloc/hipFree synchronise the device and cost 0.1–1 ms each, which would
 // dominate an assembly iteration on a 1 M-read set.  Freed blocks are kept (size classes with <= 12.5 % slack)
 // and handed out again; everything is returned to HIP when the last context is destroyed or on out-of-memory.
-hipError_t poolMalloc(void **p, size_t n, bool high = false);   // high: a LONG-LIVED block — taken from the top end of the highest free range that
-                                                                  // fits, so that the transient giants of an iteration keep one contiguous region below it
+hipError_t poolMalloc(void **p, size_t n);
 // every C-ABI entry that allocates calls this first (PH_ENTER): the stream the calling thread's allocations belong to
 void poolEnter(hipStream_t stream);
 #define PH_ENTER(ctx)                                                                    \
@@ -71,7 +67,6 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     hipError_t alloc(size_t n) { release(); bytes = n; if (n == 0) { p = nullptr; return hipSuccess; } return poolMalloc(&p, n); }
-    hipError_t allocHigh(size_t n) { release(); bytes = n; if (n == 0) { p = nullptr; return hipSuccess; } return poolMalloc(&p, n, true); }
     void release() { if (p) { poolFree(p); p = nullptr; } bytes = 0; }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
@@ -124,14 +119,9 @@ struct plasship_ctx {
     bool hasComm = false;
     plasship_comm comm = {};
     int debugFailCollective = -1;       // plasship_ctx_debug_fail_collective: countdown to an injected rank-local failure
-    plasship::KmerCache *kcache = nullptr;   // k-mer records of the unchanged short sequences, kept between calls (kmermatch.hip, section 8)
 };
 
 struct plasship_seqdb {
-    // identity and lineage (k-mer record cache of plasship_kmermatch, kmermatch.hip): every handle has its own uid; a DB an extension
-    // module made from another one with the SAME ids (keepTarget) names its parent and says which sequences differ from it
-    uint64_t uid = plasship::nextDbUid(), parentUid = 0;
-    plasship::DevBuf d_changed;   // uint8 [n]: 1 = the bytes of this sequence differ from the parent's (empty: no lineage)
     int dbtype = 0;
     size_t n = 0;
     uint64_t dataBytes = 0, residues = 0;

@@ -41,24 +41,18 @@ int g_ctxCount = 0;
 size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
 
 // best fit over all free ranges of the device (a few hundred at most)
-bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor, bool *waitAll, bool high) {
-    int bs = -1; size_t bo = 0, bsz = ~(size_t) 0; const char *bestEnd = nullptr;
+bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor, bool *waitAll) {
+    int bs = -1; size_t bo = 0, bsz = ~(size_t) 0;
     for (size_t i = 0; i < dp.slabs.size(); i++)
-        for (auto &kv : dp.slabs[i].free) {
-            if (kv.second.size < n) continue;
-            if (high) { const char *end = dp.slabs[i].base + kv.first + kv.second.size; if (end > bestEnd) { bestEnd = end; bs = (int) i; bo = kv.first; bsz = kv.second.size; } }
-            else if (kv.second.size < bsz) { bs = (int) i; bo = kv.first; bsz = kv.second.size; }
-        }
+        for (auto &kv : dp.slabs[i].free) if (kv.second.size >= n && kv.second.size < bsz) { bs = (int) i; bo = kv.first; bsz = kv.second.size; }
     if (bs < 0) return false;
     Slab &sl = dp.slabs[bs];
     const FreeRange fr = sl.free[bo];
     sl.free.erase(bo);
-    size_t at = bo;
-    if (high) { at = bo + (fr.size - n); if (fr.size > n) sl.free[bo] = FreeRange{fr.size - n, fr.stream, fr.mixed}; }      // the top end of the range
-    else if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
+    if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
     sl.used += n;
-    *p = sl.base + at;
-    g_poolLive[*p] = PoolLive{dev, bs, at, n, tl_poolStream};
+    *p = sl.base + bo;
+    g_poolLive[*p] = PoolLive{dev, bs, bo, n, tl_poolStream};
     *waitAll = fr.mixed; *waitFor = (!fr.mixed && fr.stream != tl_poolStream) ? fr.stream : nullptr;
     return true;
 }
@@ -77,9 +71,9 @@ void trimLocked(int onlyDevice) {      // give completely free slabs back to HIP
 // debugging aid: PLASSHIP_POOL_POISON=<0..255> fills every block handed out with that byte, so that a kernel reading
 // memory it did not write fails the same way on every run (recycled blocks otherwise hold the previous call's data)
 static int poisonByte() { static const int v = [] { const char *e = getenv("PLASSHIP_POOL_POISON"); return e ? atoi(e) : -1; }(); return v; }
-static hipError_t poolMallocRaw(void **p, size_t n, bool high);
-hipError_t poolMalloc(void **p, size_t n, bool high) {
-    const hipError_t e = poolMallocRaw(p, n, high);
+static hipError_t poolMallocRaw(void **p, size_t n);
+hipError_t poolMalloc(void **p, size_t n) {
+    const hipError_t e = poolMallocRaw(p, n);
     if (e == hipSuccess && poisonByte() >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poisonByte(), n); (void) hipDeviceSynchronize(); }
     return e;
 }
@@ -92,7 +86,7 @@ static void poolForgetStream(hipStream_t stream) {
     if (tl_poolStream == stream) tl_poolStream = nullptr;
 }
 static double poolFraction() { static const double v = [] { const char *e = getenv("PLASSHIP_POOL_FRACTION"); const double x = e ? atof(e) : 0.0; return (x > 0.05 && x <= 0.98) ? x : 0.88; }(); return v; }
-static hipError_t poolMallocRaw(void **p, size_t n, bool high) {
+static hipError_t poolMallocRaw(void **p, size_t n) {
     n = std::max<size_t>((n + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN, POOL_ALIGN);
     int dev = 0; (void) hipGetDevice(&dev);
     const size_t MB2 = (size_t) 2 << 20;
@@ -102,7 +96,7 @@ static hipError_t poolMallocRaw(void **p, size_t n, bool high) {
         {
             std::lock_guard<std::mutex> g(g_poolMu);
             DevicePool &dp = g_pools[dev];
-            hit = takeRange(dp, dev, n, p, &waitFor, &waitAll, high);
+            hit = takeRange(dp, dev, n, p, &waitFor, &waitAll);
             if (hit) g_poolHits++;
             else {
                 // a new slab: modest while the process is small, most of the remaining HBM once it is not
@@ -177,8 +171,6 @@ int tuneInt(const char *name, int dflt) {
 bool traceOn() { static const bool v = getenv("PLASSHIP_TRACE") != nullptr; return v; }
 void setError(const std::string &msg) { g_err = msg; }
 static std::atomic<unsigned long long> g_hostSyncs(0);
-static std::atomic<unsigned long long> g_dbUid(0);
-uint64_t nextDbUid() { return ++g_dbUid; }
 hipError_t streamSync(hipStream_t st) { g_hostSyncs++; return hipStreamSynchronize(st); }
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
     return std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
@@ -233,8 +225,6 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
     (void) plasship::streamSync(ctx->stream);
-    plasship::poolEnter(ctx->stream);
-    plasship::kmerCacheFree(ctx);
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
     for (int i = 0; i < 2; i++) { if (ctx->stage[i]) (void) hipHostFree(ctx->stage[i]); if (ctx->stageEv[i]) (void) hipEventDestroy(ctx->stageEv[i]); }
     if (ctx->pinnedTable) (void) hipHostFree(ctx->pinnedTable);

@@ -236,8 +236,11 @@ __device__ __forceinline__ bool kmerNuclCanonical(const unsigned char *w, int k,
 //   trips, so resident wavefronts count for more than registers — 6 for the 4-scores tier (80 VGPRs; 4: +30 % time; 8 would gain
 //   another 4 % but its 144 bytes of scratch per lane turn into 90 GB of memory traffic per launch), 4 for the 16-scores tier (5 gains nothing), 4 for the 48-scores tier of protein runs (128 VGPRs
 //   and 200+ bytes of scratch, yet 3.0 instead of 4.7 ms per 120 k sequences of 2500 residues at 2 wavefronts).
+//   Round 3 (kernel-resource-usage remarks of the compiler + an A/B run, profiles/r03_ab_tier0_wpe.log): at 6 wavefronts the 4-scores tier
+//   has 80 VGPRs and spills 17 of them (64 bytes of scratch per lane — half of the tier's HBM traffic in round 2's PMC pass); at 5 it has
+//   96, spills one, and the wave-per-sequence extraction of the 50 M-read chain is 9 % faster (85.8 -> 78.0 ms per iteration).
 template <bool NUCL, bool LONG, int CAP, bool FALLBACK, int REGS = 0, int RESL = 992, int WPE = 0>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : ((REGS > 0 && REGS <= 4) ? 6 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 4 : 1)))))) void extractKernel(ExtractArgs a) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : ((REGS > 0 && REGS <= 4) ? 5 : (REGS == 16 ? 4 : ((REGS > 16 && !NUCL) ? 4 : 1)))))) void extractKernel(ExtractArgs a) {
     constexpr uint32_t RES_L = RESL;
     constexpr uint32_t CODES = (RESL > 64 * REGS + 32 ? RESL : 64 * REGS + 32) + 32;
     __shared__ unsigned char sMap[256];
@@ -673,9 +676,6 @@ struct ShortArgs {
     uint32_t *hugeList, *hugeCount; uint32_t hugeWindows;   //     and those with more than hugeWindows to this one (nullptr: no such list)
     unsigned long long *kstats;          // [0] residues, [1] records handled by this kernel
     uint32_t idLo, idHi; uint64_t slotBias;   // ids [idLo, idHi) (sharded run: this rank's share), records at arr[slotOff[id] - slotBias]
-    // STATIC mode (state != nullptr; building the record cache, section 8): slotOff counts k-mer records only (no identity record, no
-    // slots for sequences this kernel cannot take); a sequence it handles gets state 1 and its Util::hash, nothing is queued
-    uint8_t *state; uint64_t *seqHashOut;
 };
 
 template <bool LONG>
@@ -702,8 +702,8 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
             if (L > SHORT_MAXL || (size_t) nWin > consideredRaw) toWave = true;
             else {
                 const char *base = a.s.data + a.s.off[id];
-                const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]) + (a.state ? 1u : 0u);
-                const uint64_t slot = a.slotOff[id] - a.slotBias - (a.state ? 1ull : 0ull);     // static mode: no identity slot in front of the records
+                const uint64_t slot = a.slotOff[id] - a.slotBias;
+                const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
                 if (a.ignoreMulti) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 8; i++) q[i] = z; }
                 uint64_t idx = 0, seqHash = 0, fifoLo = 0, fifoHi = 0;   // fifo: the k codes of the current window, 8 bits each
                 uint64_t pw = 1;
@@ -728,7 +728,10 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                     if (i + 1 >= (uint32_t) k) {
                         const uint32_t p = i + 1 - k;
                         if (lastX < (int) p) {
-                            const uint32_t score = (uint32_t) (xxh64U64(idx, a.seed) & 0xFFFFu);
+                            // every window of such a sequence is selected whatever its XXH64 score, so the score is not needed here: the
+                            // per-lane set only has to notice a POSSIBLE repeat (equal k-mers give equal tags), and any 16-bit function of
+                            // the k-mer does that — one multiplication instead of XXH64's five (round 3: the kernel is issue bound)
+                            const uint32_t score = (uint32_t) ((idx * 0x9E3779B97F4A7C15ULL) >> 48);
                             if (a.ignoreMulti) {
                                 const unsigned short tag = (unsigned short) (score + 1);
                                 if (tag == 0 || nOut >= 48) toWave = true;      // table nearly full: let the wave kernel do this one
@@ -748,23 +751,17 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
                 }
                 if (!toWave) {
                     { R *d = arr + slot + 1 + (nOut & ~3u); const uint32_t rem = nOut & 3u; if (rem > 0) d[0] = pend0; if (rem > 1) d[1] = pend1; if (rem > 2) d[2] = pend2; }
-                    if (!a.state) {
-                        R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
-                        if constexpr (LONG) r.pad = 0;
-                        arr[slot] = r;
-                    } else { a.state[id] = 1; a.seqHashOut[id] = seqHash; }
+                    R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
+                    if constexpr (LONG) r.pad = 0;
+                    arr[slot] = r;
                     R sen; memset(&sen, 0xFF, sizeof(R));
                     for (uint32_t i = 1 + nOut; i < bound; i++) arr[slot + i] = sen;
-                    stRes += L; stRec += (a.state ? 0u : 1u) + nOut;
-                } else if (a.state) {                   // static mode: a possible repeat — the sequence stays dynamic, its slots stay empty
-                    R sen; memset(&sen, 0xFF, sizeof(R));
-                    for (uint32_t i = 1; i < bound; i++) arr[slot + i] = sen;
+                    stRes += L; stRec += 1 + nOut;
                 }
             }
         }
         // the queued sequences, one atomic per wavefront and list (the wave kernels' tiers are fed from these lists directly: a
         // queue filled one sequence at a time — one atomic on one counter per sequence — costs more than the tier it feeds)
-        if (a.state) continue;                              // static mode: nothing is queued (wave-uniform)
         const uint32_t nw = (toWave && active && a.s.len[id] >= (uint32_t) k) ? a.s.len[id] - (uint32_t) k + 1 : 0u;
         const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
         const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
@@ -782,131 +779,6 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
     }
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
-}
-
-// =====================================================================================================
-// 8. the record cache (single GPU, protein DBs, 16-byte records): kernels.  Orchestration and rationale: kmermatchCached below.
-// =====================================================================================================
-// slot bounds of the STATIC store: a sequence the thread-per-sequence kernel can take (every window is selected whatever the seed)
-// owns one slot per window; everything else none
-__global__ void staticBoundsKernel(const uint32_t *__restrict__ len, uint32_t n, int k, int kps, float scale, uint32_t *__restrict__ bound) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t L = len[i];
-        const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
-        const size_t consideredRaw = (size_t) ((float) (kps - 1) + (scale * (float) L));
-        bound[i] = (L <= SHORT_MAXL && (size_t) nWin <= consideredRaw) ? nWin : 0u;
-    }
-}
-// a static sequence whose bytes changed since the store was built (state 1 -> 2: its records must be killed, it becomes dynamic)
-__global__ void markChangedKernel(const uint8_t *__restrict__ changed, uint32_t n, uint8_t *__restrict__ state) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (changed[i] && state[i] == 1) state[i] = 2;
-}
-// slot bounds of a call with a valid store: a static sequence owns its identity record only
-__global__ void dynBoundsKernel(const uint32_t *__restrict__ len, const uint8_t *__restrict__ state, uint32_t n, int k, int kps, float scale, uint32_t *__restrict__ bound) {
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const int L = (int) len[i];
-        bound[i] = (state[i] == 1) ? 1u : (uint32_t) min(max(1, L - k + 2), (int) ((float) (size_t) kps + (scale * (float) L)));
-    }
-}
-struct ClassifyArgs {
-    SeqView s; const uint8_t *state; const uint64_t *seqHash; const uint64_t *slotOff; void *arr; uint64_t seed; int k;
-    uint32_t *waveList, *waveCount, *longList, *longCount, *hugeList, *hugeCount, *killList, *killCount; uint32_t longWindows, hugeWindows;
-    unsigned long long *kstats;
-};
-// what extractShortKernel does on a call without a store, for a call with one: static sequences get their identity record (the seed
-// changes it, kmermatcher.cpp:241-249), all others are queued for the wave-per-sequence tiers by window count
-__global__ __launch_bounds__(256) void classifyKernel(ClassifyArgs a) {
-    typedef Rec<false> R;
-    R *arr = reinterpret_cast<R *>(a.arr);
-    unsigned long long stRes = 0, stRec = 0;
-    const int lane = laneId();
-    for (uint32_t b0 = blockIdx.x * 256; b0 < a.s.n; b0 += gridDim.x * 256) {
-        const uint32_t id = b0 + threadIdx.x;
-        const bool active = id < a.s.n;
-        const uint8_t st = active ? a.state[id] : 1;
-        const uint32_t L = active ? a.s.len[id] : 0;
-        if (active && st == 1) {
-            R r; r.kmer = xxh64U64(a.seqHash[id], a.seed); r.id = id; r.len = (uint16_t) L; r.pos = 0;
-            arr[a.slotOff[id]] = r;
-            stRes += L; stRec += 1;
-        }
-        const bool dyn = active && st != 1;
-        const uint32_t nw = (dyn && L >= (uint32_t) a.k) ? L - (uint32_t) a.k + 1 : 0u;
-        const bool isHuge = dyn && nw > a.hugeWindows, isLong = dyn && !isHuge && nw > a.longWindows;
-        auto append = [&](bool mine, uint32_t *list, uint32_t *count) {
-            const unsigned long long m = __ballot(mine);
-            if (!m) return;
-            uint32_t basePos = 0;
-            if (lane == 0) basePos = atomicAdd(count, (uint32_t) __popcll(m));
-            basePos = __shfl(basePos, 0, 64);
-            if (mine) list[basePos + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL))] = id;
-        };
-        append(dyn && !isLong && !isHuge, a.waveList, a.waveCount);
-        append(isLong, a.longList, a.longCount);
-        append(isHuge, a.hugeList, a.hugeCount);
-        append(active && st == 2, a.killList, a.killCount);
-    }
-    stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
-    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
-}
-// bit i of the ALIVE bitmap: the store's records of sequence i are valid (set for the sequences the static-mode kernel took)
-__global__ void aliveBitsKernel(const uint8_t *__restrict__ state, uint32_t n, uint32_t *__restrict__ bits) {
-    for (uint32_t w = blockIdx.x * blockDim.x + threadIdx.x; w < (n + 31) / 32; w += gridDim.x * blockDim.x) {
-        uint32_t v = 0;
-        for (uint32_t j = 0; j < 32 && w * 32 + j < n; j++) v |= (state[w * 32 + j] == 1 ? 1u : 0u) << j;
-        bits[w] = v;
-    }
-}
-struct RetireArgs {
-    const char *oldData; const uint64_t *oldOff; const uint32_t *killList, *killCount; const unsigned char *map;
-    int k, xCode; uint64_t base, top, inv; int tz;
-    uint8_t *state; uint32_t *aliveBits; uint32_t *valueHist; int valueShift; unsigned long long *alive;
-};
-// A static sequence whose bytes have changed leaves the store: its alive bit goes (the group kernel ignores the store's records of a
-// sequence without one — the store itself is never written after it is built), and what the store contributed for it is taken out of
-// the books: the k-mers of its OLD bytes (the store's copy of the DB it was built from; every window without an X, the store only
-// holds sequences without repeats) leave the value histogram, their number leaves the count of alive records.
-__global__ __launch_bounds__(64) void retireKernel(RetireArgs a) {
-    __shared__ unsigned char sMap[256];
-    __shared__ uint32_t sHist[VH_BINS];
-    for (int i = threadIdx.x; i < 256; i += 64) sMap[i] = a.map[i];
-    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) sHist[i] = 0;
-    __syncthreads();
-    const uint32_t n = *a.killCount;
-    unsigned long long retired = 0;
-    for (uint32_t w = blockIdx.x * 64 + threadIdx.x; w < n; w += gridDim.x * 64) {
-        const uint32_t id = a.killList[w];
-        const uint64_t o = a.oldOff[id]; const uint32_t L = (uint32_t) (a.oldOff[id + 1] - o) - 2u;
-        const char *base = a.oldData + o;
-        uint64_t idx = 0, fifoLo = 0, fifoHi = 0, pw = 1; int lastX = -1;
-        for (uint32_t i = 0; i < L; i++) {
-            const unsigned char c = sMap[(unsigned char) base[i]];
-            if (c == (unsigned char) a.xCode) lastX = (int) i;
-            if (i < (uint32_t) a.k) {
-                idx += (uint64_t) c * pw; pw *= a.base;
-                if (i < 8) fifoLo |= (uint64_t) c << (8 * i); else fifoHi |= (uint64_t) c << (8 * (i - 8));
-            } else {
-                const uint64_t cOut = fifoLo & 0xFF;
-                idx = (((idx - cOut) >> a.tz) * a.inv) + (uint64_t) c * a.top;
-                fifoLo = (fifoLo >> 8) | (fifoHi << 56); fifoHi >>= 8;
-                if (a.k - 1 < 8) fifoLo |= (uint64_t) c << (8 * (a.k - 1)); else fifoHi |= (uint64_t) c << (8 * (a.k - 1 - 8));
-            }
-            if (i + 1 >= (uint32_t) a.k && lastX < (int) (i + 1 - a.k)) { atomicAdd(&sHist[valueBin<false>(idx, a.valueShift)], 1u); retired++; }
-        }
-        atomicAnd(&a.aliveBits[id >> 5], ~(1u << (id & 31)));
-        a.state[id] = 0;
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < VH_BINS; i += 64) { const uint32_t c = sHist[i]; if (c) atomicSub(&a.valueHist[i], c); }
-    retired = waveReduceSumU64(retired);
-    if (threadIdx.x == 0 && retired) atomicAdd(a.alive, (unsigned long long) (0ull - retired));
-}
-__global__ void arenaStart2Kernel(const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ lineBeg2, uint32_t bpb, uint32_t gGrid, uint32_t nBuckets, uint32_t num, uint32_t den,
-                                  uint64_t *__restrict__ arenaStart) {
-    for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < gGrid; j += gridDim.x * blockDim.x) {
-        const uint32_t b = min(j * bpb, nBuckets - 1);
-        arenaStart[j] = (((uint64_t) lineBeg[b] + (uint64_t) lineBeg2[b]) * num / den) * RPL;
-    }
 }
 
 __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
@@ -1041,11 +913,6 @@ struct GroupArgs {
     int includeOnlyExtendable, covMode; float covThr;
     const unsigned long long *minKey;   // NUCL: K of the globally first run
     unsigned long long *maxRepTarget;   // max over emitted records of (rep << 32 | member): the last run of sort #2
-    // groupLinesKernel<TWO> (record cache): the static store's line lists in front of the call's own; cacheCounters[3]: an arena was too small
-    const uint32_t *list2, *lineBeg2, *lineCnt2, *aliveBits; uint64_t delta1, delta2; unsigned long long *cacheCounters;
-    // TWO: a workgroup's arena begins at line (arenaNum * (lineBeg + lineBeg2) / arenaDen) and ends where the next one begins (allLines for the
-    // last): with arenaNum / arenaDen < 1 the arenas hold less than the workgroup reads — cacheCounters[3] is set if one does not suffice
-    uint32_t arenaNum, arenaDen; uint64_t allLines;
 };
 
 __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -1208,10 +1075,7 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 // 2^20 buckets two partition levels can make with ~4000 positions each, which 512 threads and 4096 slots take in one go (a
 // bucket beyond the registers would be read from HBM once per phase and sub-pass).  "At least two members" is one bit per slot.
 constexpr int GL_RMAX = 8;
-// TWO (record cache, section 8): a bucket = the lines of the STATIC store (list2 / lineBeg2 / lineCnt2) followed by the lines of this
-// call's dynamic records.  Both line lists index ONE address space: `in` is the lower of the two buffers, the other one's lines are
-// offset by their distance from it (delta1 for the call's own list, delta2 for the store's; one of them is zero).
-template <bool NUCL, int BLOCK, uint32_t HT, int WPE, bool TWO = false>
+template <bool NUCL, int BLOCK, uint32_t HT, int WPE>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void groupLinesKernel(GroupArgs a) {
     typedef Rec<false> R;
     constexpr uint32_t MAXKEYS = HT / 4 * 3;                 // distinct k-mers per sub-pass before splitting further
@@ -1227,49 +1091,29 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     if (bBegin >= a.nBuckets) { if (threadIdx.x == 0) a.outCount[blockIdx.x] = 0; return; }
     unsigned long long written = 0;                  // block-uniform
     unsigned long long maxRT = 0;
-    auto arenaLine = [&](uint32_t b) { return b < a.nBuckets ? ((uint64_t) a.lineBeg[b] + (uint64_t) a.lineBeg2[b]) * a.arenaNum / a.arenaDen : a.allLines * a.arenaNum / a.arenaDen; };
-    const uint64_t arena = TWO ? arenaLine(bBegin) * RPL : (uint64_t) a.lineBeg[bBegin] * RPL;
-    const uint64_t arenaCap = TWO ? (arenaLine(bEnd) - arenaLine(bBegin)) * RPL : ~0ull;         // records the arena holds
-    bool arenaFull = false;
+    const uint64_t arena = (uint64_t) a.lineBeg[bBegin] * RPL;
     const unsigned long long firstRunKey = (NUCL && a.minKey) ? *a.minKey : 0ull;
     const R none = [] { R r; r.kmer = ~0ULL; r.id = 0xFFFFFFFFu; r.len = 0; r.pos = 0; return r; }();
     // the records of a bucket are fetched (line list entry, then the record: two dependent round trips) as soon as the registers
     // of the previous bucket are dead — behind its last phase, ahead of the barriers that close it and of the table reset
     R rg[GL_RMAX];
-    uint32_t nNext = 0, lbNext = 0, nSNext = 0, lb2Next = 0;       // nS: positions of the static store in front of the dynamic ones
-    auto recOf = [&](uint32_t i, uint32_t nS, uint32_t lb, uint32_t lb2) -> R {
-        if (!TWO) return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)];
-        const bool st = i < nS;                      // static lines first; one base pointer, the upper buffer's lines carry an offset
-        const uint32_t j = st ? lb2 + i / RPL : lb + (i - nS) / RPL;
-        const uint64_t line = (uint64_t) (st ? a.list2[j] : a.list[j]) + (st ? a.delta2 : a.delta1);
-        return in[line * RPL + (i % RPL)];
-    };
-    // The store is immutable: a record of it counts while its sequence's ALIVE bit stands (11 MB of bits for 88 M sequences: L2 / MALL
-    // resident).  One bit per register slot says which of the thread's records belong to a retired sequence.
-    auto retired = [&](const R &r) { return !isSentinel(r) && !((a.aliveBits[r.id >> 5] >> (r.id & 31)) & 1u); };
-    uint32_t deadNext = 0;
+    uint32_t nNext = 0, lbNext = 0;
     auto fetch = [&](uint32_t b) {
-        nSNext = (TWO && b < bEnd) ? a.lineCnt2[b] * RPL : 0u; lb2Next = (TWO && b < bEnd) ? a.lineBeg2[b] : 0u;
-        nNext = nSNext + ((b < bEnd) ? a.lineCnt[b] * RPL : 0u); lbNext = (b < bEnd) ? a.lineBeg[b] : 0u;
-        deadNext = 0;
+        nNext = (b < bEnd) ? a.lineCnt[b] * RPL : 0u; lbNext = (b < bEnd) ? a.lineBeg[b] : 0u;
         if (nNext && nNext <= (uint32_t) GL_RMAX * BLOCK) {
 #pragma unroll
-            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? recOf(i, nSNext, lbNext, lb2Next) : none; }
-            if (TWO) {
-#pragma unroll
-                for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; if (i < nSNext && retired(rg[j])) deadNext |= 1u << j; }
-            }
+            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? in[(uint64_t) a.list[lbNext + i / RPL] * RPL + (i % RPL)] : none; }
         }
     };
     uint32_t par = 0;                                // which cursor the current sub-pass uses (workgroup-uniform)
     fetch(bBegin);
     for (uint32_t b = bBegin; b < bEnd; b++) {
         const uint32_t n = nNext;                    // record positions of the bucket (padding sentinels included)
-        const uint32_t lb = lbNext, nS = nSNext, lb2 = lb2Next, dead = deadNext;
+        const uint32_t lb = lbNext;
         if (n == 0) { fetch(b + 1); continue; }
+        auto recAt = [&](uint32_t i) -> R { return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)]; };
         const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
         bool fetched = false;
-        auto recAt = [&](uint32_t i) -> R { R r = recOf(i, nS, lb, lb2); if (TWO && i < nS && retired(r)) r = none; return r; };
         // phase A on one record: claim the k-mer's slot, mark a second member, and bid for the run head; called by whole wavefronts
         // (new k-mers are counted once per wavefront, not with one LDS atomic per record on a single word)
         auto phaseA = [&](const R &r, uint32_t nSub, uint32_t sub) {
@@ -1342,7 +1186,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 if (laneId() == 0) wbase = atomicAdd(&sCursor[par], (uint32_t) __popcll(mk));
                 wbase = __shfl(wbase, 0, 64);
             }
-            if (keep) { const unsigned long long at = written + wbase + wr; if (!TWO || at < arenaCap) out[arena + at] = o; else arenaFull = true; }
+            if (keep) out[arena + written + wbase + wr] = o;
         };
         uint32_t nSub = 1;                           // sub-passes by a secondary hash when too many distinct k-mers
         const unsigned long long writtenAtBucketStart = written;
@@ -1354,13 +1198,13 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 __syncthreads();
                 if (inRegs) {
 #pragma unroll
-                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseA((TWO && ((dead >> j) & 1u)) ? none : rg[j], nSub, sub);
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseA(rg[j], nSub, sub);
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseA(i < n ? recAt(i) : none, nSub, sub); }
                 __syncthreads();
                 if (sFlag[1] || sFlag[0] > MAXKEYS) { redo = true; __syncthreads(); break; }
                 if (inRegs) {
 #pragma unroll
-                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseC((TWO && ((dead >> j) & 1u)) ? none : rg[j], nSub, sub);
+                    for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseC(rg[j], nSub, sub);
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseC(i < n ? recAt(i) : none, nSub, sub); }
                 if (sub + 1 == nSub) { fetch(b + 1); fetched = true; }     // last sub-pass: nothing reads this bucket's registers again
                 __syncthreads();
@@ -1380,7 +1224,6 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
         if (laneId() == 0 && maxRT) atomicMax(a.maxRepTarget, maxRT);
     }
     if (threadIdx.x == 0) a.outCount[blockIdx.x] = written;
-    if (TWO && arenaFull) atomicExch(a.cacheCounters + 3, 1ull);
 }
 
 // =====================================================================================================
@@ -1746,7 +1589,7 @@ __global__ __launch_bounds__(256) void rankKernel(const void *recs, uint64_t n, 
 // the same over a line store: every written line (tag != TAG_NONE) of the hash-partitioned records, padding sentinels skipped
 template <bool NUCL, bool LONG>
 __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const uint32_t *__restrict__ tags, uint64_t nLines, const uint64_t *__restrict__ nLinesDev,
-                                                       const void *tkeys, uint32_t m, unsigned long long *diff, const uint32_t *__restrict__ aliveBits = nullptr) {
+                                                       const void *tkeys, uint32_t m, unsigned long long *diff) {
     typedef Rec<LONG> R;
     if (nLinesDev) nLines = min(nLines, (uint64_t) *nLinesDev);        // lines the last partition level laid out (the rest of the tag array was never written)
     const R *g = reinterpret_cast<const R *>(recs);
@@ -1758,7 +1601,6 @@ __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const u
         if (tags && tags[i / RPL] == TAG_NONE) continue;                // tags == nullptr: every line is valid (received lines of a sharded run)
         const R r = g[i];
         if (isSentinel(r)) continue;
-        if (aliveBits && !((aliveBits[r.id >> 5] >> (r.id & 31)) & 1u)) continue;      // (record cache: the store's records of a retired sequence)
         uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
         if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
@@ -1946,7 +1788,7 @@ static int buildLineLists(plasship_ctx *ctx, const uint32_t *dTags, uint64_t cap
 
 // What the line path hands to the run reduction
 struct LinesOut { void *triples = nullptr; uint64_t nTriples = 0, Nk = 0, Nm = 0; std::vector<int64_t> stalePos; uint32_t staleT = 0; float msSort1 = 0, msGroup = 0, msSort2 = 0, msPart = 0; int nPart = 1;
-                  uint64_t exchangedRecordBytes = 0, exchangedTripleBytes = 0; bool cacheOverflow = false; };
+                  uint64_t exchangedRecordBytes = 0, exchangedTripleBytes = 0; };
 
 constexpr uint64_t HALO_SLACK = 1u << 16;
 
@@ -2080,141 +1922,6 @@ static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std
 
 static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; dst.bytes = src.bytes; src.p = nullptr; src.bytes = 0; }
 
-// =====================================================================================================
-// 8. THE RECORD CACHE (single GPU, protein DBs, 16-byte records).
-//    `plass assemble` calls kmermatcher once per iteration on a DB in which most sequences have not changed since the last call: an
-//    iteration extends 10-18 % of the 88 M sequences of a 50 M-read set, and a read fragment of up to ~72 residues contributes EVERY
-//    window whatever the hash seed (kmermatcher.cpp:223: n <= kmer-per-seq - 1), so its k-mer records are the same in every iteration.
-//    The reference recomputes and re-sorts them twelve times.  Here they are extracted and hash-partitioned ONCE into a STATIC STORE
-//    (the final-level line lists of linepart.hpp, kept in the context); later calls extract and partition only the DYNAMIC records —
-//    identity records (their key depends on the seed), sequences that have changed, long sequences — and the group kernel reads a
-//    bucket's static and dynamic lines together (groupLinesKernel<TWO>).
-//      * Which sequences are unchanged is not guessed: an output DB of the extension modules names its parent DB and carries a
-//        per-sequence `changed` byte (buildOutputDB, assemble.hip); a DB without that lineage rebuilds the store.
-//      * The store is IMMUTABLE.  A static sequence that changes becomes dynamic for good; its records stay where they are and stop
-//        counting: an ALIVE bit per sequence (11 MB for 88 M sequences: L2 / Infinity Cache resident) is cleared, and the group kernel
-//        drops the store's records of a sequence without one as it loads them.  (Two earlier versions removed the records instead —
-//        KILL records matched in an LDS set inside the group kernel: every static record paid a probe and the kernel spilled 70 VGPRs,
-//        grouping went from 38 to 117 ms per iteration at 50 M reads; then a location map (one position per window) filled by a pass
-//        over the finished store: 3 G random 4-byte stores made building the store cost 255 ms.  profiles/r03_call4_*, r03_call5_*.)
-//      * What the rest of the path needs from "all records" is kept exact: the count (alive static + dynamic), the value histogram of
-//        the stale-record check (static histogram minus kills + dynamic), the rank pass (both stores).
-//    The result is the reference's, bit for bit, by construction: the multiset of records a bucket's grouping sees is unchanged.
-//    PLASSHIP_KMER_CACHE=0 turns it off.
-// =====================================================================================================
-}  // namespace (anonymous)
-namespace plasship {
-struct KmerCache {
-    bool valid = false; uint64_t dbUid = 0; uint32_t N = 0;
-    int k = 0, alph = 0, kps = 0, ignoreMulti = 0; float scale = 0;
-    int b1 = 0, b2 = 0; uint32_t nBuckets = 0;              // bucket bits of the store = of every dynamic partition while it lives
-    DevBuf recs, list, tags, tot2, fineBeg, fineCnt; uint64_t capLines = 0;
-    DevBuf state, seqHash, aliveBits, data, off, vhist, counters;  // counters: [2] alive static records, [3] "an arena was too small" flag of the last call
-    void clear() { valid = false; for (DevBuf *b : {&recs, &list, &tags, &tot2, &fineBeg, &fineCnt, &state, &seqHash, &aliveBits, &data, &off, &vhist, &counters}) b->release(); }
-};
-void kmerCacheFree(plasship_ctx *ctx) { if (ctx && ctx->kcache) { ctx->kcache->clear(); delete ctx->kcache; ctx->kcache = nullptr; } }
-}  // namespace plasship
-namespace {
-// what kmermatchLines needs of the store
-struct StaticStoreView { const void *recs; const uint32_t *list, *tags, *fineBeg, *fineCnt, *aliveBits; const uint64_t *totLines; uint64_t capLines; uint32_t *vhist; unsigned long long *counters; };
-
-static LineGeo lineGeometryBits(uint64_t totalSlots, int b1, int b2, int numCU) {       // caps for `totalSlots` with given bucket bits
-    LineGeo g; g.b1 = b1; g.b2 = b2; g.nb1 = 1u << b1; g.nb2 = b2 ? 1u << b2 : 0u;
-    g.totalLines = (totalSlots + RPL - 1) / RPL;
-    g.lastValid = g.totalLines ? (uint32_t) (totalSlots - (g.totalLines - 1) * RPL) : (uint32_t) RPL;
-    g.PL1 = pieceLinesFor(g.totalLines, g.nb1, numCU, 8);
-    g.nP1 = (g.totalLines + g.PL1 - 1) / g.PL1;
-    g.cap1 = std::max<uint64_t>(g.nP1 * ((uint64_t) g.PL1 + g.nb1), 1);
-    if (g.nb2) { g.PL2 = 0xFFFFFFFFu; g.maxP2 = g.nb1; g.cap2 = g.cap1 + (uint64_t) g.nb1 * g.nb2; }
-    return g;
-}
-
-// (re)builds the store from `db`: the thread-per-sequence kernel in static mode, then both partition levels; the result stays in `kc`
-static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, KmerCache &kc, const unsigned char *dMap, int xCode, int keyBits) {
-    typedef Rec<false> R;
-    hipStream_t st = ctx->stream;
-    const uint32_t N = (uint32_t) db->n; const int k = par->kmer_size, numCU = ctx->numCU;
-    kc.clear();
-    DevBuf dBound, dSlotOff, dScanTmp, dKS;
-    const size_t scanTmpBytes = exclusiveScanTmpBytes((size_t) N + 2) + (1u << 20);
-    if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess || dKS.alloc(32) != hipSuccess ||
-        kc.state.allocHigh((size_t) N + 1) != hipSuccess || kc.seqHash.allocHigh(((size_t) N + 1) * 8) != hipSuccess || kc.aliveBits.allocHigh(((size_t) N / 32 + 2) * 4) != hipSuccess ||
-        kc.data.allocHigh(db->dataBytes + 64) != hipSuccess || kc.off.allocHigh(((size_t) N + 1) * 8) != hipSuccess ||
-        kc.vhist.allocHigh(VH_BINS * 4) != hipSuccess || kc.counters.allocHigh(32) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(kc.state.p, 0, (size_t) N + 1, st));
-    PH_CHECK(hipMemsetAsync(kc.vhist.p, 0, VH_BINS * 4, st));
-    PH_CHECK(hipMemsetAsync(kc.counters.p, 0, 32, st));
-    PH_CHECK(hipMemsetAsync(dKS.p, 0, 32, st));
-    PH_CHECK(hipMemcpyAsync(kc.data.p, db->d_data.p, db->dataBytes, hipMemcpyDeviceToDevice, st));        // the bytes the store's records were made from (retireKernel)
-    PH_CHECK(hipMemcpyAsync(kc.off.p, db->d_off.p, ((size_t) N + 1) * 8, hipMemcpyDeviceToDevice, st));
-    // bucket bits from ALL record slots of the DB (what a call without a store would use), slots of the store from the static bounds
-    uint64_t totals[2] = {0, 0};
-    hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
-    if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemcpyAsync(&totals[0], dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(staticBoundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
-    PH_CHECK(plasship::streamSync(st));                       // (the first total has to be on the host before the scan output is overwritten)
-    if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    PH_COPY_SYNC(st, &totals[1], dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost);
-    const LineGeo bits = lineGeometry(totals[0], false, numCU);
-    const LineGeo geo = lineGeometryBits(totals[1], bits.b1, bits.b2, numCU);
-    const uint64_t recCap = std::max<uint64_t>(totals[1], (uint64_t) RPL * std::max(geo.cap1, geo.cap2));
-    // the store stays for the whole chain: it (and its lists) go to the TOP of the arena (DevBuf::allocHigh), so that the transient
-    // giants of the iterations — record arrays, arenas, the extension arena — keep one contiguous region below (a 49 GB block in the
-    // middle of the slab left the 76 GB extension arena of iteration 0 without a range that fits, with 170 GB free)
-    DevBuf dA, dB;
-    const bool twoLevels = geo.nb2 != 0;                      // the level that ends in the store: dA with two levels, dB with one
-    if ((twoLevels ? dA.allocHigh(std::max<uint64_t>(recCap, 1) * sizeof(R)) : dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R))) != hipSuccess ||
-        (twoLevels ? dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) : dB.allocHigh(std::max<uint64_t>(recCap, 1) * sizeof(R))) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
-    {
-        ShortArgs sa; memset(&sa, 0, sizeof(sa));
-        sa.s = db->view(); sa.slotOff = dSlotOff.as<uint64_t>(); sa.arr = dA.p; sa.map = dMap; sa.k = k; sa.xCode = xCode; sa.kps = par->kmers_per_seq; sa.ignoreMulti = par->ignore_multi_kmer;
-        sa.scale = par->kmers_per_seq_scale; sa.seed = 0; sa.base = (uint64_t) (par->alphabet_size - 1);
-        { uint64_t p = 1; for (int i = 0; i < k - 1; i++) p *= sa.base; sa.top = p; }
-        { uint64_t b = sa.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; sa.tz = tz; sa.inv = inv; }
-        sa.kstats = dKS.as<unsigned long long>(); sa.idLo = 0; sa.idHi = N; sa.slotBias = 0; sa.state = kc.state.as<uint8_t>(); sa.seqHashOut = kc.seqHash.as<uint64_t>();
-        if (N) hipLaunchKernelGGL((extractShortKernel<false>), dim3(std::min<uint32_t>((N + 63) / 64, (uint32_t) numCU * (uint32_t) tuneInt("SHORT", N > 20000000u ? 36 : 18))), dim3(64), 0, st, sa);
-    }
-    PH_CHECK(hipMemcpyAsync(kc.counters.as<unsigned long long>() + 2, dKS.as<unsigned long long>() + 1, 8, hipMemcpyDeviceToDevice, st));      // alive static records
-    // ---- both partition levels (as in kmermatchLines, single GPU) ----
-    DevBuf dTag1, dList1, dCnt1, dStart1, dCur1, dPieces2, dNP2, dRegBeg, dRegEnd;
-    kc.nBuckets = geo.nb2 ? geo.nb1 * geo.nb2 : geo.nb1;
-    if (dTag1.alloc(geo.cap1 * 4) != hipSuccess || dList1.alloc(geo.cap1 * 4) != hipSuccess || dCnt1.alloc(LP_MAXB * 4) != hipSuccess || dStart1.alloc((LP_MAXB + 1) * 4) != hipSuccess || dCur1.alloc(LP_MAXB * 4) != hipSuccess ||
-        kc.fineBeg.allocHigh((size_t) kc.nBuckets * 4) != hipSuccess || kc.fineCnt.allocHigh((size_t) kc.nBuckets * 4) != hipSuccess || kc.tot2.allocHigh(8) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
-    if (geo.nP1 == 0) PH_CHECK(hipMemsetAsync(dTag1.p, 0xFF, geo.cap1 * 4, st));
-    {
-        LinePartArgs a; memset(&a, 0, sizeof(a));
-        a.in = dA.p; a.out = dB.p; a.tags = dTag1.as<uint32_t>(); a.totalLines = geo.totalLines; a.lastValidAll = geo.lastValid; a.pieceLines = geo.PL1; a.nb = geo.nb1;
-        a.key.shift = geo.b1 ? 64 - geo.b1 : 63; a.valueHist = kc.vhist.as<uint32_t>(); a.valueShift = std::max(0, keyBits - 11);
-        const int rc = launchLinePart<false, false, KEY_HASH, false, true>(ctx, a, geo.nP1); if (rc) return rc;
-    }
-    int rc = buildLineLists(ctx, dTag1.as<uint32_t>(), geo.cap1, geo.nb1, dCnt1.as<uint32_t>(), dStart1.as<uint32_t>(), dCur1.as<uint32_t>(), dList1.as<uint32_t>()); if (rc) return rc;
-    if (geo.nb2) {
-        if (kc.tags.allocHigh(geo.cap2 * 4) != hipSuccess || kc.list.allocHigh(geo.cap2 * 4) != hipSuccess || dPieces2.alloc((geo.maxP2 + 1) * sizeof(LinePiece)) != hipSuccess || dNP2.alloc(4) != hipSuccess ||
-            dRegBeg.alloc(LP_MAXB * 8) != hipSuccess || dRegEnd.alloc(LP_MAXB * 8) != hipSuccess) { setError("kmermatch: out of device memory for the record cache"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, geo.PL2, geo.nb2, dPieces2.as<LinePiece>(), dNP2.as<uint32_t>(),
-                           dRegBeg.as<uint64_t>(), dRegEnd.as<uint64_t>(), kc.tot2.as<uint64_t>());
-        LinePartArgs a; memset(&a, 0, sizeof(a));
-        a.in = dB.p; a.list = dList1.as<uint32_t>(); a.out = dA.p; a.tags = kc.tags.as<uint32_t>(); a.pieces = dPieces2.as<LinePiece>(); a.nPieces = dNP2.as<uint32_t>(); a.nb = geo.nb2;
-        a.key.shift = 64 - geo.b1 - geo.b2;
-        rc = launchLinePart<false, false, KEY_HASH, true, false>(ctx, a, geo.maxP2); if (rc) return rc;
-        hipLaunchKernelGGL(tagSortRegionKernel, dim3(std::min<uint32_t>(geo.nb1, (uint32_t) numCU * 4)), dim3(512), 0, st, (const uint32_t *) kc.tags.as<uint32_t>(), (const uint64_t *) dRegBeg.as<uint64_t>(),
-                           (const uint64_t *) dRegEnd.as<uint64_t>(), geo.nb1, geo.nb2, kc.list.as<uint32_t>(), kc.fineBeg.as<uint32_t>(), kc.fineCnt.as<uint32_t>());
-        moveBuf(kc.recs, dA); kc.capLines = geo.cap2;
-    } else {
-        hipLaunchKernelGGL(listRangesKernel, dim3(4), dim3(256), 0, st, (const uint32_t *) dStart1.as<uint32_t>(), geo.nb1, kc.fineBeg.as<uint32_t>(), kc.fineCnt.as<uint32_t>());
-        const uint64_t cap = geo.cap1;
-        PH_CHECK(hipMemcpyAsync(kc.tot2.p, &cap, 8, hipMemcpyHostToDevice, st));
-        moveBuf(kc.recs, dB); moveBuf(kc.tags, dTag1); moveBuf(kc.list, dList1); kc.capLines = geo.cap1;
-    }
-    hipLaunchKernelGGL(aliveBitsKernel, dim3(gridFor(N / 32 + 1, 256, 4096)), dim3(256), 0, st, (const uint8_t *) kc.state.as<uint8_t>(), N, kc.aliveBits.as<uint32_t>());
-    PH_CHECK(plasship::streamSync(st));                       // (`cap` and the temporaries go out of scope)
-    PH_CHECK(hipGetLastError());
-    kc.b1 = geo.b1; kc.b2 = geo.b2; kc.N = N; kc.k = k; kc.alph = par->alphabet_size; kc.kps = par->kmers_per_seq; kc.scale = par->kmers_per_seq_scale; kc.ignoreMulti = par->ignore_multi_kmer;
-    kc.dbUid = db->uid; kc.valid = true;
-    return PLASSHIP_OK;
-}
-
 // extraction has filled dA (`total` record slots of this rank's sequences, sentinels in unused slots).  Buffers dA / dB hold geo.cap2
 // resp. geo.cap1 lines (single GPU) or geo.cap1 lines each (sharded run).
 // Sharded run (commOf(ctx) != nullptr; `totalAll` = slots of all ranks): the bucket geometry is that of the WHOLE run, rank r owns the
@@ -2225,10 +1932,7 @@ static int buildStaticStore(plasship_ctx *ctx, const plasship_seqdb *db, const p
 // triples of all ranks with the same kernels (aggSortKernel<TRIPLES>).
 template <bool NUCL, bool LONG>
 static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, const LineGeo &geo, uint64_t total,
-                          DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res,
-                          const StaticStoreView *ss = nullptr) {
-    // ss (record cache, section 8; single GPU, protein, 16-byte records): dA holds only the call's DYNAMIC records;
-    // the group kernel reads every bucket's static lines in front of them
+                          DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res) {
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
@@ -2345,20 +2049,10 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     // the arenas: the buffer level 2 read (dead now).  single GPU: dB (level 1's output) when there are two levels, else dA (the slot
     // array); sharded run: the receive buffer when there are two levels, else a buffer of its own
     DevBuf dArena;
-    void *arenaBuf; uint32_t arenaNum = 2;                    // (record cache) arenas hold arenaNum / 2 of what their workgroup reads
+    void *arenaBuf;
     if (cm) {
         if (geo.nb2) arenaBuf = dRx.p;
         else { if (dArena.alloc(std::max<uint64_t>(finalCap, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; } arenaBuf = dArena.p; }
-    } else if (ss) {
-        // Static and dynamic lines of a workgroup's buckets together bound what it emits: arenas addressed by the sum of both line
-        // numbers.  At 50 M reads that bound is 85 GB for the 6 GB an extendable-only iteration emits (N_m / N_k is 0.1-0.3 there), next
-        // to the 49 GB store: such iterations get HALF the bound, and a workgroup whose arena does not suffice says so — the group
-        // kernel then runs again with full arenas.
-        if (geo.nb2) dB.release(); else dA.release();        // level 1's output / the slot array: dead, the arenas need the room
-        arenaNum = par->include_only_extendable ? 1u : 2u;
-        if (dArena.alloc(std::max<uint64_t>((finalCap + ss->capLines) * arenaNum / 2 + 1, 1) * RPL * sizeof(R)) != hipSuccess) {
-            setError("kmermatch: out of device memory for the grouped records (" + std::to_string((finalCap + ss->capLines) * arenaNum / 2 * RPL * sizeof(R)) + " bytes)"); return PLASSHIP_ERR_DEVICE; }
-        arenaBuf = dArena.p;
     } else arenaBuf = geo.nb2 ? dB.p : dA.p;
     const uint32_t gBlocks = std::max<uint32_t>(1, std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 6)));
     const uint32_t bpb = (std::max<uint32_t>(nBuckets, 1) + gBlocks - 1) / gBlocks;
@@ -2372,35 +2066,14 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     ga.maxRepTarget = dMaxRT.as<unsigned long long>();
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
     // positions per bucket (sentinel padding included) decide the workgroup shape of the 16-byte-record kernel
-    const uint64_t avgPos = (finalCap + (ss ? ss->capLines : 0)) * RPL / std::max<uint32_t>(nBuckets, 1);
+    const uint64_t avgPos = finalCap * RPL / std::max<uint32_t>(nBuckets, 1);
     const bool wideGroup = !LONG && (getenv("PLASSHIP_GROUP_WIDE") ? atoi(getenv("PLASSHIP_GROUP_WIDE")) != 0 : avgPos > 1600);
-    bool launchedTwo = false;
-    if constexpr (!NUCL && !LONG) {
-        if (ss && nBuckets) {
-            // one address space for both line lists: the lower buffer is the base, the other one's lines are offset by the distance (whole lines:
-            // the arena hands out 256-byte aligned blocks)
-            const char *pd = (const char *) finalRecs, *ps = (const char *) ss->recs; const size_t lineBytes = RPL * sizeof(R);
-            ga.in = pd < ps ? pd : ps; ga.delta1 = (uint64_t) (pd - (const char *) ga.in) / lineBytes; ga.delta2 = (uint64_t) (ps - (const char *) ga.in) / lineBytes;
-            ga.list2 = ss->list; ga.lineBeg2 = ss->fineBeg; ga.lineCnt2 = ss->fineCnt; ga.cacheCounters = ss->counters; ga.aliveBits = ss->aliveBits;
-            if (tuneInt("ARENA_QUARTERS", 0)) arenaNum = 1;                                                 // (tests: force the retry with full arenas)
-            ga.arenaNum = arenaNum; ga.arenaDen = 2; ga.allLines = finalCap + ss->capLines;
-            // the store keeps the positions of retired sequences: late iterations have more than 4096 positions per bucket (3 000 of the
-            // store + 2 000 dynamic at 50 M reads) — 1024 threads hold 8192 in registers (one workgroup per CU: the same 4 wavefronts per SIMD)
-            if (wideGroup && avgPos > 3700 && tuneInt("GROUP_1024", 1)) hipLaunchKernelGGL((groupLinesKernel<false, 1024, 8192, 4, true>), dim3(gGrid), dim3(1024), 0, st, ga);
-            else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
-            else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-            hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, arenaNum, 2u, dArenaStart.as<uint64_t>());
-            launchedTwo = true;
-        }
-    }
-    if (launchedTwo) {}
-    else if (nBuckets == 0) PH_CHECK(hipMemsetAsync(dOutCnt.p, 0, (size_t) gGrid * 8, st));
+    if (nBuckets == 0) PH_CHECK(hipMemsetAsync(dOutCnt.p, 0, (size_t) gGrid * 8, st));
     else if constexpr (LONG) hipLaunchKernelGGL((groupKernel<NUCL, LONG, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
     else if (wideGroup && tuneInt("GROUP_WPE", 4) == 4) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 4>), dim3(gGrid), dim3(512), 0, st, ga);
     else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<NUCL, 512, 4096, 2>), dim3(gGrid), dim3(512), 0, st, ga);
     else hipLaunchKernelGGL((groupLinesKernel<NUCL, GR_BLOCK, GR_HT, 3>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-    if (launchedTwo) {}
-    else if (nBuckets) hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
+    if (nBuckets) hipLaunchKernelGGL(arenaStartKernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), bpb, gGrid, nBuckets, dArenaStart.as<uint64_t>());
     else PH_CHECK(hipMemsetAsync(dArenaStart.p, 0, (size_t) gGrid * 8, st));
     std::vector<uint64_t> hOutCnt(gGrid), hArena(gGrid);
     unsigned long long hLastRun[4] = {0, 0, 0, 0}, ks[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
@@ -2410,39 +2083,14 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hArena.data(), dArenaStart.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(ks, dKStats.p, 32, hipMemcpyDeviceToHost, st));
-    unsigned long long hCache[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHistS(ss ? VH_BINS : 0);
-    if (ss) { PH_CHECK(hipMemcpyAsync(hCache, ss->counters, 32, hipMemcpyDeviceToHost, st)); PH_CHECK(hipMemcpyAsync(hVHistS.data(), ss->vhist, VH_BINS * 4, hipMemcpyDeviceToHost, st)); }
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
-    if constexpr (!NUCL && !LONG) {
-        if (ss && hCache[3]) {
-            // an arena of half the bound did not suffice somewhere: once more with full arenas (the kernel writes nothing but its arenas)
-            dArena.release();
-            if (dArena.alloc(std::max<uint64_t>(finalCap + ss->capLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records (full arenas)"); return PLASSHIP_ERR_DEVICE; }
-            arenaBuf = dArena.p; ga.out = arenaBuf; ga.arenaNum = 2;
-            PH_CHECK(hipMemsetAsync(ss->counters + 3, 0, 8, st)); PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
-            // the store keeps the positions of retired sequences: late iterations have more than 4096 positions per bucket (3 000 of the
-            // store + 2 000 dynamic at 50 M reads) — 1024 threads hold 8192 in registers (one workgroup per CU: the same 4 wavefronts per SIMD)
-            if (wideGroup && avgPos > 3700 && tuneInt("GROUP_1024", 1)) hipLaunchKernelGGL((groupLinesKernel<false, 1024, 8192, 4, true>), dim3(gGrid), dim3(1024), 0, st, ga);
-            else if (wideGroup) hipLaunchKernelGGL((groupLinesKernel<false, 512, 4096, 4, true>), dim3(gGrid), dim3(512), 0, st, ga);
-            else hipLaunchKernelGGL((groupLinesKernel<false, GR_BLOCK, GR_HT, 3, true>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-            hipLaunchKernelGGL(arenaStart2Kernel, dim3(gridFor(gGrid, 256, 64)), dim3(256), 0, st, (const uint32_t *) dFineBeg.as<uint32_t>(), ss->fineBeg, bpb, gGrid, nBuckets, 2u, 2u, dArenaStart.as<uint64_t>());
-            hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
-            PH_CHECK(hipMemcpyAsync(hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost, st));
-            PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(hipMemcpyAsync(hArena.data(), dArenaStart.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(hipMemcpyAsync(hCache, ss->counters, 32, hipMemcpyDeviceToHost, st));
-            PH_CHECK(plasship::streamSync(st));
-            PH_CHECK(hipGetLastError());
-        }
-    }
     uint64_t NmLocal = 0;
     for (uint32_t j = 0; j < gGrid; j++) NmLocal += hOutCnt[j];
     uint64_t Nm = NmLocal;
-    const uint64_t NkLocal = ks[1] + ks[3] + (ss ? (uint64_t) hCache[2] : 0ull);   // records the extraction kernels of this rank wrote (sentinels excluded) + the store's alive records
+    const uint64_t NkLocal = ks[1] + ks[3];                  // records the extraction kernels of this rank wrote (sentinels excluded)
     const uint64_t Nk = cm ? NkAll : NkLocal;                // ... and of the whole run
     std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
-    if (ss) for (uint32_t b = 0; b < VH_BINS; b++) hVHistG[b] += hVHistS[b];
     if (cm) {
         // the stale-record check below is a property of the WHOLE run: N_m, the last (rep, target) run and the value histogram are
         // reduced over the ranks; every rank then takes the same decisions (and the same collectives)
@@ -2469,8 +2117,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         const unsigned long long maxRT = hLastRun[0];
         res.staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
         const uint64_t so[2] = {hLastRun[1], hLastRun[2]}; const uint32_t tLen = (uint32_t) hLastRun[3];
-        // slots of T in a slot array WITHOUT a store (with one, a static T owns its identity slot only): computeKmerCount's bound
-        const uint32_t tb = (uint32_t) std::min(std::max(1, (int) tLen - par->kmer_size + 2), (int) ((float) (size_t) par->kmers_per_seq + (par->kmers_per_seq_scale * (float) tLen)));
+        const uint32_t tb = (uint32_t) (so[1] - so[0]);
         DevBuf dTRec, dTId, dTScr, dTOff, dTCap, dDiff;
         uint32_t cap = 64; while (cap < tLen + 1) cap <<= 1;
         const uint64_t zero = 0;
@@ -2480,7 +2127,6 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_CHECK(hipMemcpyAsync(dTOff.p, &zero, 8, hipMemcpyHostToDevice, st));
         PH_CHECK(hipMemcpyAsync(dTCap.p, &cap, 4, hipMemcpyHostToDevice, st));
         PH_CHECK(hipMemsetAsync(dDiff.p, 0, ((size_t) tb + 1) * 8, st));
-        PH_CHECK(hipMemsetAsync(dTRec.p, 0xFF, (size_t) tb * sizeof(R), st));
         // re-extract the records of T into a scratch array with the very kernel that produced them
         ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
         ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
@@ -2503,8 +2149,6 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
             PH_CHECK(hipMemcpyAsync(dTRec.p, trec.data(), (size_t) m * sizeof(R), hipMemcpyHostToDevice, st));
             hipLaunchKernelGGL((rankLinesKernel<NUCL, LONG>), dim3(gridFor(finalCap * RPL, 256, (unsigned) numCU * 8)), dim3(256), 0, st, (const void *) finalRecs, finalTags, finalCap, geo.nb2 ? (const uint64_t *) dTot2.as<uint64_t>() : (const uint64_t *) nullptr,
                                (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
-            if (ss) hipLaunchKernelGGL((rankLinesKernel<NUCL, LONG>), dim3(gridFor(ss->capLines * RPL, 256, (unsigned) numCU * 8)), dim3(256), 0, st, ss->recs, ss->tags, ss->capLines, ss->totLines,
-                                       (const void *) dTRec.p, m, dDiff.as<unsigned long long>(), ss->aliveBits);
             std::vector<unsigned long long> diff((size_t) m + 1);
             PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
             PH_CHECK(plasship::streamSync(st));
@@ -2526,13 +2170,12 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipEventRecord(ctx->ev[12], st));
     // the hash-bucketed records are dead now (the group kernel's arenas live in another buffer): free them for the rep side
     if (cm) { dL2.release(); if (!geo.nb2) dRx.release(); }
-    else if (ss) { dA.release(); dB.release(); }
     else (finalRecs == dA.p ? dA : dB).release();
     dTag1.release(); dList1.release(); dTag2.release(); dList2.release(); dRxList.release();
     std::vector<std::pair<uint64_t, uint64_t>> arenas(gGrid);                 // the arenas are dense segments: (first line, records)
     for (uint32_t j = 0; j < gGrid; j++) arenas[j] = std::make_pair(hArena[j] / RPL, hOutCnt[j]);
     DevBuf dTriples, dRepStart; uint64_t nTriples = 0;
-    auto arenasConsumed = [&]() { if (cm) { if (geo.nb2) dRx.release(); else dArena.release(); } else if (ss) dArena.release(); else (arenaBuf == dA.p ? dA : dB).release(); };
+    auto arenasConsumed = [&]() { if (cm) { if (geo.nb2) dRx.release(); else dArena.release(); } else (arenaBuf == dA.p ? dA : dB).release(); };
     rc = repSortLines<NUCL, LONG, false>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, cm ? &dRepStart : nullptr);
     if (rc) return rc;
     if (cm) {
@@ -2705,9 +2348,7 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
 
 template <bool NUCL, bool LONG>
 int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
-                  plasship_kmermatch_stats *stats, KmerCache *kc = nullptr, bool *cacheOverflow = nullptr) {
-    // kc (record cache, section 8: single GPU, protein DB, 16-byte records, store valid for THIS db): the slot array holds the dynamic
-    // records only — identity records of the static sequences and the records of the sequences queued for the wave tiers
+                  plasship_kmermatch_stats *stats) {
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
@@ -2727,10 +2368,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     if (useLinesEarly) PH_CHECK(hipEventRecord(ctx->ev[0], st)); else tm.start(0);
-    if (kc) {
-        if (N) hipLaunchKernelGGL(dynBoundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), kc->state.as<uint8_t>(), N, k, par->kmers_per_seq,
-                                  par->kmers_per_seq_scale, dBound.as<uint32_t>());
-    } else
     if (N) hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
     if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t total = 0;
@@ -2755,7 +2392,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     static const bool legacyPartition = getenv("PLASSHIP_LEGACY_PARTITION") != nullptr;
     const bool useLines = cm || !legacyPartition;            // (the dense partition below is a single-GPU cross-check path)
     if (cm && W > 1024) { setError("kmermatch: more than 1024 ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
-    const LineGeo geo = kc ? lineGeometryBits(total, kc->b1, kc->b2, ctx->numCU) : (useLines ? lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W) : LineGeo());
+    const LineGeo geo = useLines ? lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W) : LineGeo();
     // single GPU: both buffers serve level 1 and level 2 (and the group kernel's arenas); sharded run: the slot array / level-1 output,
     // and the packed send buffer of exchange 1 (at most cap1 lines)
     const uint64_t recCap = useLines ? std::max<uint64_t>(total, (uint64_t) RPL * (cm ? geo.cap1 : std::max(geo.cap1, geo.cap2))) : std::max<uint64_t>(total, 1);
@@ -2792,33 +2429,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     ea.kstats = dKStats.as<unsigned long long>();
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     bool twoLists = false;
-    DevBuf dKillList, dKillCount;                            // (record cache) ids of the sequences that have just changed
-    if constexpr (!NUCL && !LONG) {
-    if (kc && nMine) {
-        // the store holds the records of the static sequences: they get their identity record, everything else is queued for the tiers
-        if (dKillList.alloc(((size_t) N + 1) * 4) != hipSuccess || dKillCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        PH_CHECK(hipMemsetAsync(dKillCount.p, 0, 4, st));
-        ClassifyArgs ca; memset(&ca, 0, sizeof(ca));
-        ca.s = ea.s; ca.state = kc->state.as<uint8_t>(); ca.seqHash = kc->seqHash.as<uint64_t>(); ca.slotOff = ea.slotOff; ca.arr = ea.arr; ca.seed = ea.seed; ca.k = k;
-        ca.waveList = dWaveList.as<uint32_t>(); ca.waveCount = dWaveCount.as<uint32_t>(); ca.longList = dLongList.as<uint32_t>(); ca.longCount = dLongCount.as<uint32_t>();
-        ca.hugeList = dOvIds.as<uint32_t>(); ca.hugeCount = dOvCnt.as<uint32_t>(); ca.killList = dKillList.as<uint32_t>(); ca.killCount = dKillCount.as<uint32_t>();
-        ca.longWindows = TIER0_WINDOWS; ca.hugeWindows = 64 * 16; ca.kstats = dKStats.as<unsigned long long>();
-        hipLaunchKernelGGL(classifyKernel, dim3(std::min<uint32_t>((N + 255) / 256, (uint32_t) ctx->numCU * 16)), dim3(256), 0, st, ca);
-        {   // the sequences that have just changed leave the store (the list is on the device: no wait to learn whether it is empty)
-            RetireArgs ra; memset(&ra, 0, sizeof(ra));
-            ra.oldData = kc->data.as<char>(); ra.oldOff = kc->off.as<uint64_t>(); ra.killList = dKillList.as<uint32_t>(); ra.killCount = dKillCount.as<uint32_t>(); ra.map = ea.map;
-            ra.k = k; ra.xCode = ea.xCode; ra.base = (uint64_t) (alph - 1); ra.top = ea.powers[k - 1];
-            { uint64_t b = ra.base; int tz = 0; while ((b & 1) == 0) { b >>= 1; tz++; } uint64_t inv = b; for (int i = 0; i < 6; i++) inv *= 2 - b * inv; ra.tz = tz; ra.inv = inv; }
-            ra.state = kc->state.as<uint8_t>(); ra.aliveBits = kc->aliveBits.as<uint32_t>(); ra.valueHist = kc->vhist.as<uint32_t>();
-            { int kb = 0; long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (kb < 63 && (long double) (1ULL << kb) < v) kb++; ra.valueShift = std::max(0, kb - 11); }
-            ra.alive = kc->counters.as<unsigned long long>() + 2;
-            hipLaunchKernelGGL(retireKernel, dim3((unsigned) std::min<uint64_t>(((uint64_t) N + 63) / 64, (uint64_t) ctx->numCU * 16)), dim3(64), 0, st, ra);
-        }
-        twoLists = true;
-        ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
-    }
-    }
-    if (!kc && !NUCL && k <= 16 && nMine) {
+    if (!NUCL && k <= 16 && nMine) {
         // short sequences: one thread each; everything else is queued for the wave-per-sequence kernels, in two lists by length
         ShortArgs sa; memset(&sa, 0, sizeof(sa));
         sa.s = ea.s; sa.slotOff = ea.slotOff; sa.arr = ea.arr; sa.map = ea.map; sa.k = k; sa.xCode = ea.xCode; sa.kps = ea.kps; sa.ignoreMulti = ea.ignoreMulti;
@@ -2855,8 +2466,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         const uint32_t wide = std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU);
         // tiers 0 and 1 both queue into dOvIds
         if (twoLists) {
-            if (tuneInt("TIER0_WPE", 6) == 5) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 5>), dim3(wide), dim3(64), 0, st, ea);
-            else if (tuneInt("TIER0_WPE", 6) == 7) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 7>), dim3(wide), dim3(64), 0, st, ea);
+            if (tuneInt("TIER0_WPE", 5) == 6) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 6>), dim3(wide), dim3(64), 0, st, ea);
             else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256>), dim3(wide), dim3(64), 0, st, ea);
             ExtractArgs e1 = ea; e1.waveList = dLongList.as<uint32_t>(); e1.waveCount = dLongCount.as<uint32_t>();
             hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, e1);
@@ -2908,16 +2518,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         int keyBitsL = 0;
         if (NUCL) keyBitsL = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBitsL < 63 && (long double) (1ULL << keyBitsL) < v) keyBitsL++; }
         LinesOut lo;
-        StaticStoreView sv; memset(&sv, 0, sizeof(sv));
-        if (kc) {
-            sv.recs = kc->recs.p; sv.list = kc->list.as<uint32_t>(); sv.tags = kc->tags.as<uint32_t>(); sv.fineBeg = kc->fineBeg.as<uint32_t>(); sv.fineCnt = kc->fineCnt.as<uint32_t>();
-            sv.totLines = kc->tot2.as<uint64_t>(); sv.capLines = kc->capLines; sv.vhist = kc->vhist.as<uint32_t>(); sv.counters = kc->counters.as<unsigned long long>();
-            sv.aliveBits = kc->aliveBits.as<uint32_t>();
-            PH_CHECK(hipMemsetAsync(kc->counters.as<unsigned long long>() + 3, 0, 8, st));   // [3] an arena was too small ([2], the alive static records, stays)
-        }
-        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, kc ? &sv : nullptr);
+        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo);
         if (rcL) return rcL;
-        if (lo.cacheOverflow) { if (cacheOverflow) *cacheOverflow = true; return PLASSHIP_OK; }
         std::unique_ptr<plasship_cands> holderL; uint64_t NcL = 0; float msReduceL = 0;
         rcL = reduceToCandidates<NUCL, LONG>(ctx, db, lo.triples, lo.nTriples, lo.stalePos, lo.staleT, holderL, NcL, msReduceL, true);
         if (rcL) return rcL;
@@ -3233,32 +2835,5 @@ extern "C" int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, c
     PH_ENTER(ctx);
     const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX);     // kmermatcher.cpp:797-802
     if (nucl) return commFinish(ctx, lng ? kmermatchImpl<true, true>(ctx, db, par, out, stats) : kmermatchImpl<true, false>(ctx, db, par, out, stats));
-    // ---- the record cache (section 8): single GPU, protein, 16-byte records ----
-    static const bool cacheOn = [] { const char *e = getenv("PLASSHIP_KMER_CACHE"); return e ? atoi(e) != 0 : true; }();
-    static const bool legacy = getenv("PLASSHIP_LEGACY_PARTITION") != nullptr;
-    if (cacheOn && !legacy && !lng && !commOf(ctx) && par->kmer_size <= 16 && db->n > 0) {
-        if (!ctx->kcache) ctx->kcache = new KmerCache();
-        KmerCache &kc = *ctx->kcache;
-        const bool same = kc.valid && kc.N == (uint32_t) db->n && kc.k == par->kmer_size && kc.alph == par->alphabet_size && kc.kps == par->kmers_per_seq &&
-                          kc.scale == par->kmers_per_seq_scale && kc.ignoreMulti == par->ignore_multi_kmer;
-        const bool hit = same && kc.dbUid == db->uid, child = same && !hit && db->parentUid == kc.dbUid && db->d_changed.p != nullptr;
-        hipStream_t st = ctx->stream;
-        if (!hit && !child) {
-            const unsigned char *map = aa2numTable(false, par->alphabet_size);
-            DevBuf dMap; if (dMap.alloc(256) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-            PH_CHECK(hipMemcpyAsync(dMap.p, map, 256, hipMemcpyHostToDevice, st));
-            int keyBits = 0; { long double v = 1; for (int i = 0; i < par->kmer_size; i++) v *= (long double) (par->alphabet_size - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
-            const int rc = buildStaticStore(ctx, db, par, kc, dMap.as<unsigned char>(), map[(int) 'X'], keyBits);
-            if (rc) { kc.clear(); return rc; }
-        } else if (child) {
-            hipLaunchKernelGGL(markChangedKernel, dim3(gridFor(db->n, 256, 4096)), dim3(256), 0, st, db->d_changed.as<uint8_t>(), (uint32_t) db->n, kc.state.as<uint8_t>());
-            kc.dbUid = db->uid;
-        }
-        bool overflow = false;
-        const int rc = kmermatchImpl<false, false>(ctx, db, par, out, stats, &kc, &overflow);
-        if (rc) { kc.clear(); return rc; }                    // (a failed call may have removed records of changed sequences already: the store is rebuilt next time)
-        if (!overflow) return PLASSHIP_OK;
-        kc.clear();                                           // (no path sets `overflow` today: kept as the way out for a store that cannot serve a call)
-    } else if (ctx->kcache) ctx->kcache->clear();
     return commFinish(ctx, lng ? kmermatchImpl<false, true>(ctx, db, par, out, stats) : kmermatchImpl<false, false>(ctx, db, par, out, stats));
 }

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import (AA_AS, AA_KM, AA_RS, GD_AS, GD_KM, GD_P2N, GD_RS, NUCL_AS, NUCL_KM, NUCL_RS, aa_iter_flags, assert_same_db, read_db, run_oracle,
-                      sweep_positional, sweep_variants, ROOT)
+                      sweep_positional, sweep_variants)
 
 pytestmark = pytest.mark.gpu
 
@@ -602,48 +602,3 @@ def test_cli_unsupported_fails_loudly(golden, tmp_path, mod, extra):
     assert p.returncode != 0 and ("not supported" in p.stdout or "only" in p.stdout), p.stdout[-800:]
     assert not os.path.exists(outs[0][1] + ".index")
 
-
-
-def _cache_chain(tmp_path, tag, env, iters=6):
-    """six protein iterations on the 40 k-pair synthetic set in a child process (the cache switch is read once per process); writes
-    the candidate DB and the output DB of every iteration"""
-    import subprocess, sys
-    code = r'''
-import sys
-sys.path.insert(0, %r)
-import plass_amd
-from plass_amd import synth
-ctx = plass_amd.Context(0)
-db = ctx.upload_seqdb(*synth.protein_fragment_db(40000, seed=5), 0)
-hs = 67
-for it in range(%d):
-    hs += it %% 2
-    c, k = ctx.kmermatcher(db, plass_amd.KmermatchParams(hash_shift=hs, include_only_extendable=(it > 0)))
-    c.write(%r + "/%s_pref_%%d" %% it)
-    a, _ = ctx.rescorediagonal(db, db, c, plass_amd.RescoreParams(min_seq_id=0.9))
-    if it == 2:                      # the same DB twice: a cache hit without changes
-        c2, k2 = ctx.kmermatcher(db, plass_amd.KmermatchParams(hash_shift=hs, include_only_extendable=True))
-        assert (k2.n_kmer_records, k2.n_grouped, k2.n_candidates) == (k.n_kmer_records, k.n_grouped, k.n_candidates)
-    db, _ = ctx.assembleresults(db, a, plass_amd.AssembleParams(min_seq_id=0.9))
-    db.write(%r + "/%s_seq_%%d" %% (it + 1))
-    print("IT", it, k.n_kmer_records, k.n_grouped, k.n_candidates)
-print("CHAIN_OK")
-''' % (ROOT, iters, str(tmp_path), tag, str(tmp_path), tag)
-    p = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900, env=dict(os.environ, **env))
-    assert p.returncode == 0 and "CHAIN_OK" in p.stdout, p.stdout[-3000:]
-    return [l.split()[2:] for l in p.stdout.splitlines() if l.startswith("IT ")]
-
-
-def test_record_cache_is_invisible(tmp_path):
-    """the record cache of plasship_kmermatch (static store of the unchanged short sequences; the records of a sequence that changes
-    are removed through the location map: kmermatch.hip section 8) against the same chain without it: identical N_k / N_m / N_c,
-    candidate DBs and output DBs in all six iterations — and once more with arenas too small for iteration 0, which must run the group
-    kernel again with full arenas"""
-    ref = _cache_chain(tmp_path, "off", {"PLASSHIP_KMER_CACHE": "0"})
-    for tag, env in (("on", {"PLASSHIP_KMER_CACHE": "1"}),
-                     ("arena", {"PLASSHIP_KMER_CACHE": "1", "PLASSHIP_TUNE_ARENA_QUARTERS": "1"})):     # half-size arenas everywhere: iteration 0 overflows them and runs again with full ones
-        got = _cache_chain(tmp_path, tag, env)
-        assert got == ref, (tag, got, ref)
-        for it in range(6):
-            assert_same_db(tmp_path / f"off_pref_{it}", tmp_path / f"{tag}_pref_{it}", f"record cache {tag}: candidates of iteration {it}")
-            assert_same_db(tmp_path / f"off_seq_{it + 1}", tmp_path / f"{tag}_seq_{it + 1}", f"record cache {tag}: output DB of iteration {it}")

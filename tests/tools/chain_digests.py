@@ -20,6 +20,10 @@ def main():
     cfg, pairs, iters, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     if mode == "legacy":
         os.environ["PLASSHIP_LEGACY_PARTITION"] = "1"
+    if mode == "sharded1":
+        # ONE rank holds the send and receive buffers eight ranks would share (three record arrays of 60 GB at 50 M reads): it gets a
+        # larger share of the HBM than the 88 % default (nothing else runs in this process)
+        os.environ.setdefault("PLASSHIP_POOL_FRACTION", "0.96")
     import bench
     import plass_amd
     ctx = plass_amd.Context(0)
