@@ -46,14 +46,19 @@ __global__ __launch_bounds__(256) void aln2nuclKernel(A2NArgs a) {
         for (int p = 0; p < n3; p += 8) {
             uint64_t qw, tw; __builtin_memcpy(&qw, q + p, 8); __builtin_memcpy(&tw, t + p, 8);     // buffers are padded past their ends
             const int m = min(8, n3 - p);
+            // columns behind the end are blanked (byte 0 in both words) and their lookups of entry [0][0] taken off again: eight
+            // unconditional lookups per step that go out together.  ([0][0] itself is a legitimate entry here: like the reference,
+            // the walk runs into the terminator bytes when a protein twin is longer than its ORF / 3.)
+            const uint64_t mask = m >= 8 ? ~0ULL : ((1ULL << (8 * m)) - 1ULL);
+            const uint64_t lo7 = 0x7F7F7F7F7F7F7F7FULL, x = qw ^ tw;
+            ids += __popcll(~(((x & lo7) + lo7) | x | lo7) & mask);                                 // equal bytes among the first m
+            qw &= mask; tw &= mask;
 #pragma unroll
             for (int j = 0; j < 8; j++) {
-                if (j < m) {
-                    const unsigned x = (unsigned) (qw >> (8 * j)) & 0xFFu, y = (unsigned) (tw >> (8 * j)) & 0xFFu;
-                    ids += (x == y) ? 1 : 0;
-                    score += (int) smat[x * 123 + y];
-                }
+                const unsigned a = (unsigned) (qw >> (8 * j)) & 0xFFu, b = (unsigned) (tw >> (8 * j)) & 0xFFu;
+                score += (int) smat[a * 123 + b];
             }
+            score -= (8 - m) * (int) smat[0];
         }
         r.rawScore = score;
         r.bitScore = (int) (fma(a.lambda, (double) score, -a.logK) / a.ln2);      // implicit double -> int in the reference: truncation

@@ -88,6 +88,24 @@ template <int G> __device__ __forceinline__ void copyBytesG(char *dst, const cha
         else for (unsigned j = i; j < n; j++) dst[j] = src[j];
     }
 }
+// The score table in LDS.  Entry [0][0] is forced to 0: the scoring loops below BLANK the columns outside [first, last] (byte 0
+// in both words) instead of predicating them, so that the lookups of a step are unconditional — the compiler issues them together
+// and waits once (with one predicated block per column every `ds_read` had its own wait: profiles/r03_pmc_sq_per_kernel.txt).
+// No residue is byte 0.
+__device__ __forceinline__ void stageScoreTable(signed char *smat, const signed char *__restrict__ mat, int nThreads) {
+    for (int i = threadIdx.x; i < 123 * 123; i += nThreads) smat[i] = i ? mat[i] : (signed char) 0;
+}
+// 0xFF in every byte j of the result with lo <= j < hi
+__device__ __forceinline__ uint64_t byteRangeMask(int lo, int hi) {
+    const uint64_t belowHi = hi >= 8 ? ~0ULL : (hi <= 0 ? 0ULL : ((1ULL << (8 * hi)) - 1ULL));
+    const uint64_t belowLo = lo >= 8 ? ~0ULL : (lo <= 0 ? 0ULL : ((1ULL << (8 * lo)) - 1ULL));
+    return belowHi & ~belowLo;
+}
+// number of zero bytes of x among the bytes selected by mask (exact zero-byte test)
+__device__ __forceinline__ int zeroBytes(uint64_t x, uint64_t mask) {
+    const uint64_t lo7 = 0x7F7F7F7F7F7F7F7FULL;
+    return __popcll(~(((x & lo7) + lo7) | x | lo7) & mask);
+}
 // computeGlobalSubstitutionStartEndDistance (DistanceCalculator.h:204-220) over an ungapped overlap of `len` columns:
 // first/last column ('*' trimming), score sum over [first, last], identities over [first, last).  The boundary bytes
 // and the first 8-residue words are requested together (one memory round trip for overlaps up to 8*G residues).
@@ -102,14 +120,14 @@ template <int G> __device__ __forceinline__ void scoreColumnsG(const char *q, co
     if (last > 0 && (qe == '*' || te == '*')) last--;
     for (unsigned p = p0; p < len; p += 8u * G) {
         if (p != p0) { qw = loadU64Unaligned(q + p); tw = loadU64Unaligned(t + p); }
+        const int lo = (int) first - (int) p, hi = (int) last - (int) p;       // columns [lo, hi] of this word are scored
+        const uint64_t m = byteRangeMask(lo, hi + 1);
+        ids += zeroBytes(qw ^ tw, byteRangeMask(lo, hi));                       // [qStart, qEnd): the last aligned column is not counted
+        const uint64_t qv = qw & m, tv = tw & m;
 #pragma unroll
         for (unsigned j = 0; j < 8; j++) {
-            const unsigned c = p + j;
-            if (c >= first && c <= last) {
-                const unsigned a = (unsigned) (qw >> (8 * j)) & 0xFFu, b = (unsigned) (tw >> (8 * j)) & 0xFFu;
-                s += (int) smat[a * 123 + b];
-                if (c < last) ids += (a == b) ? 1 : 0;          // [qStart, qEnd): the last aligned column is not counted
-            }
+            const unsigned a = (unsigned) (qv >> (8 * j)) & 0xFFu, b = (unsigned) (tv >> (8 * j)) & 0xFFu;
+            s += (int) smat[a * 123 + b];
         }
     }
 }
@@ -127,12 +145,15 @@ __device__ __forceinline__ void scoreColumnsSerial(const char *q, const char *t,
     for (unsigned p = 0; p < len; p += 32) {
         if (p) { __builtin_memcpy(qw, q + p, 32); __builtin_memcpy(tw, t + p, 32); }
 #pragma unroll
-        for (unsigned j = 0; j < 32; j++) {
-            const unsigned c = p + j;
-            if (c >= first && c <= last) {
-                const unsigned a = (unsigned) (qw[j >> 3] >> (8 * (j & 7))) & 0xFFu, b = (unsigned) (tw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
+        for (unsigned k = 0; k < 4; k++) {
+            const int lo = (int) first - (int) (p + 8 * k), hi = (int) last - (int) (p + 8 * k);
+            const uint64_t m = byteRangeMask(lo, hi + 1);
+            ids += zeroBytes(qw[k] ^ tw[k], byteRangeMask(lo, hi));
+            const uint64_t qv = qw[k] & m, tv = tw[k] & m;
+#pragma unroll
+            for (unsigned j = 0; j < 8; j++) {
+                const unsigned a = (unsigned) (qv >> (8 * j)) & 0xFFu, b = (unsigned) (tv >> (8 * j)) & 0xFFu;
                 s += (int) smat[a * 123 + b];
-                if (c < last) ids += (a == b) ? 1 : 0;
             }
         }
     }
@@ -166,7 +187,7 @@ __device__ __forceinline__ void waveMemSync() {   // make this wave's global sto
 // wavefront works on its own queries and orders its own memory operations with fences — there is no workgroup barrier in the loop.
 __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
-    for (int i = threadIdx.x; i < 123 * 123; i += 256) smat[i] = a.mat[i];
+    stageScoreTable(smat, a.mat, 256);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
@@ -178,8 +199,8 @@ __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
         const uint64_t aoff = a.arenaOff[id];
         if (a.arenaOff[id + 1] == aoff) continue;          // no non-self hit: can never be extended
         Item *it = a.items + h0;
-        const char *orig = a.s.data + a.s.off[id];
-        unsigned querySeqLen = a.s.len[id];
+        const char *orig = a.s.data + seqOff(a.s, id);
+        unsigned querySeqLen = seqLen(a.s, id);
         nAln += h; nQRes += querySeqLen;
         // ---- queue fill (assembleresult.cpp:161-189) ----
         for (uint32_t i = lane; i < h; i += 64) {
@@ -223,7 +244,7 @@ __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
                 const bool rightStart = x.dbStart == 0 && (x.dbEnd != (int) x.dbLen - 1);
                 const bool leftStart = x.qStart == 0 && (x.qEnd != (int) x.qLen - 1);
                 if (!((rightStart || leftStart) && notBoth) || x.target == id) continue;
-                const unsigned tLen = a.s.len[x.target];
+                const unsigned tLen = seqLen(a.s, x.target);
                 if (x.dbStart == 0) {
                     const unsigned fragR = tLen - ((unsigned) x.dbEnd + 1);
                     if (fragR > 0 && (unsigned) x.qEnd == (querySeqLen - 1) && (key > bestR || (key == bestR && x.target < it[idxR].target))) { bestR = key; idxR = i; }
@@ -246,8 +267,8 @@ __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
             waveMemSync();
             auto extendRight = [&]() {
                 const Item x = it[idxR];
-                const char *tSeq = a.s.data + a.s.off[x.target];
-                const unsigned tLen = a.s.len[x.target], dbEnd = (unsigned) x.dbEnd, fragLen = tLen - (dbEnd + 1);
+                const char *tSeq = a.s.data + seqOff(a.s, x.target);
+                const unsigned tLen = seqLen(a.s, x.target), dbEnd = (unsigned) x.dbEnd, fragLen = tLen - (dbEnd + 1);
                 copyBytesG<64>(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen, lane);
                 curLen += fragLen; rightOff += fragLen;
                 if (lane == 0) atomicOr(&a.flags[x.target], 0x80u);
@@ -258,7 +279,7 @@ __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
                 const unsigned fragLen = (unsigned) x.dbStart;
                 if (curLen + fragLen >= a.maxSeqLen) brokeOut = true;
                 else {
-                    const char *tSeq = a.s.data + a.s.off[x.target];
+                    const char *tSeq = a.s.data + seqOff(a.s, x.target);
                     curStart -= fragLen;
                     copyBytesG<64>(buf + curStart, tSeq, fragLen, lane);
                     curLen += fragLen; leftOff += fragLen;
@@ -282,7 +303,7 @@ __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
                 const bool rightStart = x.dbStart == 0 && (x.dbEnd != (int) x.dbLen - 1);
                 const bool leftStart = x.qStart == 0 && (x.qEnd != (int) x.qLen - 1);
                 if (!used && (rightStart || leftStart) && notBoth && x.target != id) {
-                    const unsigned tLen = a.s.len[x.target];
+                    const unsigned tLen = seqLen(a.s, x.target);
                     if (x.dbStart == 0) { if ((tLen - ((unsigned) x.dbEnd + 1)) > rightOff && (unsigned) x.qEnd == (querySeqLen - 1) && rightOff > 0) st = 1; }
                     else if (x.qStart == 0) { if (x.dbStart > (int) leftOff && (unsigned) x.dbEnd == (tLen - 1) && leftOff > 0) st = 1; }
                 }
@@ -302,8 +323,8 @@ __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
             for (uint32_t i = lane; i < h; i += 64) {
                 Item x = it[i];
                 if (x.state != 1) continue;
-                const char *tSeq = a.s.data + a.s.off[x.target];
-                const unsigned tLen = a.s.len[x.target];
+                const char *tSeq = a.s.data + seqOff(a.s, x.target);
+                const unsigned tLen = seqLen(a.s, x.target);
                 const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
                 const unsigned dist = (unsigned) abs(diag);
                 unsigned qo = 0, to = 0, len = 0; bool hit = true;
@@ -498,7 +519,7 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
     __shared__ uint32_t sPop;
     __shared__ int sAbort;
     __shared__ uint32_t sPushed;
-    for (int i = threadIdx.x; i < 123 * 123; i += 64) smat[i] = a.mat[i];
+    stageScoreTable(smat, a.mat, 64);
     __syncthreads();
     const int lane = threadIdx.x;
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
@@ -519,8 +540,8 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
         cmp.abort = false;
         if (lane == 0) sAbort = 0;
         unsigned long long qResc = 0, qRescRes = 0;
-        const char *orig = a.s.data + a.s.off[id];
-        unsigned querySeqLen = a.s.len[id];
+        const char *orig = a.s.data + seqOff(a.s, id);
+        unsigned querySeqLen = seqLen(a.s, id);
         // ---- queue fill (nuclassembleresult.cpp:196-224); pad = useReverse of the hit's target ----
         for (uint32_t i = lane; i < h; i += 64) {
             const AlnRec r = a.recs[h0 + i];
@@ -585,8 +606,8 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
                 const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
                 const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
                 if (!((rightStart || leftStart) && notBoth && best.target != id)) continue;
-                const char *tSeq = a.s.data + a.s.off[best.target];
-                const unsigned tLen = a.s.len[best.target];
+                const char *tSeq = a.s.data + seqOff(a.s, best.target);
+                const unsigned tLen = seqLen(a.s, best.target);
                 const bool rev = best.pad != 0;
                 const char *aaT = nullptr; unsigned aaTLen = 0;
                 if (GUIDED) { aaT = a.aa.data + a.aa.off[best.target]; aaTLen = a.aa.len[best.target]; }
@@ -635,8 +656,8 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
             for (uint32_t d = 0; d < nDef; d++) {
                 const uint32_t found = def[d];
                 Item x = it[found];
-                const char *tSeq = a.s.data + a.s.off[x.target];
-                const unsigned tLen = a.s.len[x.target];
+                const char *tSeq = a.s.data + seqOff(a.s, x.target);
+                const unsigned tLen = seqLen(a.s, x.target);
                 const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
                 const Rescored rs = rescoreOnDiagonalNucl(qs, querySeqLen, tSeq, tLen, diag, smat, x.pad != 0);
                 qResc++; qRescRes += rs.diagonalLen;
@@ -661,7 +682,7 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
         if (aborted) {                                       // nothing of this query has been published
             if (lane == 0) a.redoList[atomicAdd(a.redoCount, 1u)] = id;
         } else {
-            nAln += h; nQRes += a.s.len[id]; nResc += qResc; nRescRes += qRescRes;
+            nAln += h; nQRes += seqLen(a.s, id); nResc += qResc; nRescRes += qRescRes;
             for (uint32_t i = lane; i < nUsed; i += 64) atomicOr(&a.flags[used[i]], 0x80u);
             if (couldExtend) {
                 if (lane == 0) {
@@ -696,7 +717,7 @@ constexpr int NT_BLOCK = 256;
 template <bool GUIDED>
 __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs a) {    // 4 blocks per CU: at most 128 VGPRs
     __shared__ signed char smat[123 * 123 + 7];
-    for (int i = threadIdx.x; i < 123 * 123; i += NT_BLOCK) smat[i] = a.mat[i];
+    stageScoreTable(smat, a.mat, NT_BLOCK);
     __syncthreads();
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
     NuclCmp cmp; cmp.a = &a; cmp.abort = false;
@@ -710,8 +731,8 @@ __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs 
         uint32_t nUsed = 0;
         cmp.abort = false;
         unsigned long long qResc = 0, qRescRes = 0;
-        const char *orig = a.s.data + a.s.off[id];
-        unsigned querySeqLen = a.s.len[id];
+        const char *orig = a.s.data + seqOff(a.s, id);
+        unsigned querySeqLen = seqLen(a.s, id);
         uint32_t nHeap = 0;
         for (uint32_t i = 0; i < h && !cmp.abort; i++) {                 // queue fill
             const AlnRec r = a.recs[h0 + i];
@@ -760,8 +781,8 @@ __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs 
                 const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
                 const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
                 if (!((rightStart || leftStart) && notBoth && best.target != id)) continue;
-                const char *tSeq = a.s.data + a.s.off[best.target];
-                const unsigned tLen = a.s.len[best.target];
+                const char *tSeq = a.s.data + seqOff(a.s, best.target);
+                const unsigned tLen = seqLen(a.s, best.target);
                 const bool rev = best.pad != 0;
                 const char *aaT = nullptr; unsigned aaTLen = 0;
                 if (GUIDED) { aaT = a.aa.data + a.aa.off[best.target]; aaTLen = a.aa.len[best.target]; }
@@ -805,8 +826,8 @@ __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs 
             for (uint32_t d = 0; d < nDef && !cmp.abort; d++) {                // re-score the deferred hits in deferral order
                 const uint32_t found = def[d];
                 Item x = it[found];
-                const char *tSeq = a.s.data + a.s.off[x.target];
-                const unsigned tLen = a.s.len[x.target];
+                const char *tSeq = a.s.data + seqOff(a.s, x.target);
+                const unsigned tLen = seqLen(a.s, x.target);
                 const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
                 const unsigned dist = (unsigned) abs(diag);
                 unsigned qo = 0, to = 0, len = 0; bool hit = true;
@@ -846,7 +867,7 @@ __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs 
         }
         if (cmp.abort) a.redoList[atomicAdd(a.redoCount, 1u)] = id;          // nothing of this query has been published
         else {
-            nAln += h; nQRes += a.s.len[id]; nResc += qResc; nRescRes += qRescRes;
+            nAln += h; nQRes += seqLen(a.s, id); nResc += qResc; nRescRes += qRescRes;
             for (uint32_t i = 0; i < nUsed; i++) atomicOr(&a.flags[used[i]], 0x80u);
             if (couldExtend) {
                 atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart;
@@ -913,7 +934,7 @@ __device__ __forceinline__ Rescored rescoreOnDiagonalG(const char *q, unsigned q
 template <int G, int WPE>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void assembleGroupKernel(AsmArgs a) {
     __shared__ signed char smat[123 * 123 + 7];
-    for (int i = threadIdx.x; i < 123 * 123; i += 256) smat[i] = a.mat[i];
+    stageScoreTable(smat, a.mat, 256);
     __syncthreads();
     const int gl = threadIdx.x & (G - 1);                         // lane within the group
     const uint32_t groupsTotal = gridDim.x * (256 / G);
@@ -924,8 +945,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
         const uint32_t h = (uint32_t) (h1 - h0);
         const uint64_t aoff = a.arenaOff[id];
-        const char *orig = a.s.data + a.s.off[id];
-        unsigned querySeqLen = a.s.len[id];
+        const char *orig = a.s.data + seqOff(a.s, id);
+        unsigned querySeqLen = seqLen(a.s, id);
         if (gl == 0) { nAln += h; nQRes += querySeqLen; }
         // ---- queue fill (assembleresult.cpp:161-189): lane i owns alignment i ----
         uint32_t xTarget = 0xFFFFFFFFu, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2, xTLen = 0; uint64_t xTOff = 0;
@@ -942,7 +963,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             // the self alignment is popped and discarded without any effect (selectFragmentToExtend: isNotIdentity):
             // it never enters the register queue
             xState = (xTarget == id) ? 2u : 0u;
-            xTOff = a.s.off[xTarget]; xTLen = a.s.len[xTarget];      // fetched up front: one memory round trip less per pop
+            xTOff = seqOff(a.s, xTarget); xTLen = seqLen(a.s, xTarget);      // fetched up front: one memory round trip less per pop
         }
         // tie-break of CompareResultByScore (smaller key wins) as a rank among the group's targets
         const uint32_t tRank = groupRank<G>(xTarget);
@@ -1140,27 +1161,54 @@ __global__ void outLenKernel(SeqView s, const uint32_t *__restrict__ flags, cons
     }
 }
 
-template <int G>
+template <int G, int U>
 __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen,
                                                       const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
                                                       const uint64_t *__restrict__ outOff, const uint32_t *__restrict__ keep,
                                                       const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
                                                       char *__restrict__ outData, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey) {
     // G lanes per sequence, 8 bytes per lane and step: 8 lanes take a read fragment (~46 residues) in one step with most lanes busy,
-    // eight sequences per wavefront; contigs take a few steps of contiguous 64-byte pieces
+    // eight sequences per wavefront; contigs take a few steps of contiguous 64-byte pieces.  A sequence is a chain of dependent
+    // round trips (what to copy -> the bytes -> the store) and the kernel is bound by the number of chains in flight (round 3: the
+    // wavefronts were parked on memory 89 % of their cycles at 2 TB/s), so a group works on U sequences at a time: the U sets of
+    // metadata are requested together, then the U first pieces.
     const int gl = threadIdx.x & (G - 1);
     constexpr int groupsPerBlock = 256 / G;
-    for (uint32_t id = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id < s.n; id += gridDim.x * groupsPerBlock) {
-        if (!keep[id]) continue;
-        const uint64_t o = outOff[id];
-        const bool ext = (flags[id] & 0x20u) != 0;
-        const uint32_t L = ext ? newLen[id] : s.len[id];
-        const char *src = ext ? (arena + newStart[id]) : (s.data + s.off[id]);
-        copyBytesG<G>(outData + o, src, L, gl);
-        if (gl == 0) {
-            outData[o + L] = '\n'; outData[o + L + 1] = '\0';
-            const uint64_t j = keepPos[id];
-            outOffArr[j] = o; outLen[j] = L; outKey[j] = inKey[id];
+    const uint32_t stride = gridDim.x * groupsPerBlock;
+    for (uint32_t id0 = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id0 < s.n; id0 += stride * U) {
+        uint32_t L[U]; const char *src[U]; uint64_t o[U]; bool k[U]; uint64_t w[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const uint32_t id = id0 + (uint32_t) u * stride;
+            k[u] = id < s.n && keep[id] != 0;
+            L[u] = 0; src[u] = s.data; o[u] = 0;
+            if (k[u]) {
+                const uint32_t f = flags[id]; const uint32_t l0 = s.len[id]; const uint64_t o0 = s.off[id];
+                o[u] = outOff[id];
+                const bool ext = (f & 0x20u) != 0;
+                L[u] = ext ? newLen[id] : l0;
+                src[u] = ext ? (arena + newStart[id]) : (s.data + o0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) w[u] = (k[u] && 8u * (unsigned) gl < L[u]) ? loadU64Unaligned(src[u] + 8 * gl) : 0ULL;     // buffers are padded past their ends
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (!k[u]) continue;
+            const uint32_t id = id0 + (uint32_t) u * stride;
+            const unsigned i = 8u * (unsigned) gl;
+            char *dst = outData + o[u];
+            if (i + 8 <= L[u]) storeU64Unaligned(dst + i, w[u]);
+            else for (unsigned j = i; j < L[u]; j++) dst[j] = (char) (w[u] >> (8 * (j - i)));
+            for (unsigned p = i + 8u * G; p < L[u]; p += 8u * G) {                       // the rest of a contig
+                if (p + 8 <= L[u]) storeU64Unaligned(dst + p, loadU64Unaligned(src[u] + p));
+                else for (unsigned j = p; j < L[u]; j++) dst[j] = src[u][j];
+            }
+            if (gl == 0) {
+                dst[L[u]] = '\n'; dst[L[u] + 1] = '\0';
+                const uint64_t j = keepPos[id];
+                outOffArr[j] = o[u]; outLen[j] = L[u]; outKey[j] = inKey[id];
+            }
         }
     }
 }
@@ -1279,15 +1327,15 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
         setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
-    static const int woG = tuneInt("WRITEOUT_G", 8);
+    static const int woU = tuneInt("WRITEOUT_U", 1);        // sequences a lane group has in flight; 2 and 4 changed nothing (profiles/r03_ab_knobs.txt): the kernel is not bound by its chains of round trips
     if (N) {
         const unsigned woGrid = std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16));
-        if (woG == 8) hipLaunchKernelGGL((writeOutKernel<8>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
-                              dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
-                              o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
-        else hipLaunchKernelGGL((writeOutKernel<16>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
-                              dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
-                              o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+        auto launch = [&](auto kern) {
+            hipLaunchKernelGGL(kern, dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
+                               dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
+                               o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+        };
+        if (woU == 1) launch(writeOutKernel<8, 1>); else if (woU == 2) launch(writeOutKernel<8, 2>); else launch(writeOutKernel<8, 4>);
     }
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
@@ -1394,6 +1442,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     PH_CHECK(hipMemsetAsync(dNewLen.p, 0, ((size_t) N + 1) * 4, st));
     PH_CHECK(hipMemsetAsync(dStats.p, 0, 128, st));
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(nucl), 123 * 123, hipMemcpyHostToDevice, st));
+    { const int rcOL = ensureOffLen(ctx, db); if (rcOL) return rcOL; }          // the extension kernels look up random targets
     const SeqView sv = db->view();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
     // work lists by queue size: [0] <= 16 alignments, [1] <= 32, [2] <= 64, [3] more (filled by arenaSizeKernel)

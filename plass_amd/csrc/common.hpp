@@ -14,6 +14,10 @@ namespace plasship {
 void setError(const std::string &msg);
 // every wait of the host for the stream goes through here and is counted (plasship_host_syncs(): bench.py reports waits per iteration)
 hipError_t streamSync(hipStream_t st);
+}
+struct plasship_seqdb; struct plasship_ctx;
+namespace plasship {
+int ensureOffLen(plasship_ctx *ctx, const plasship_seqdb *db);     // core.hip: builds plasship_seqdb::d_offLen once (stream-ordered)
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line);
 
 #define PH_CHECK(call)                                                                   \
@@ -76,9 +80,16 @@ struct SeqView {
     const char *data;          // entries "SEQ\n\0"
     const uint64_t *off;       // [n] byte offset of entry i (id = rank in key order)
     const uint32_t *len;       // [n] sequence length (entry length - 2)
+    const uint64_t *offLen;    // [n] off << 24 | len in one word, or nullptr (ensureOffLen): ONE line instead of two for a random entry
     uint32_t n;
     int nucl;
 };
+
+#ifdef __HIPCC__
+// offset / length of a RANDOM entry from the packed word (requires ensureOffLen on the DB)
+__device__ __forceinline__ uint64_t seqOff(const SeqView &s, uint32_t id) { return s.offLen[id] >> 24; }
+__device__ __forceinline__ uint32_t seqLen(const SeqView &s, uint32_t id) { return (uint32_t) s.offLen[id] & 0xFFFFFFu; }
+#endif
 
 // one candidate pair (query id implied by CSR)
 struct __attribute__((aligned(8))) CandHit { uint32_t target; int32_t prefScore; uint32_t diag16; uint32_t query; };
@@ -130,12 +141,15 @@ struct plasship_seqdb {
     // rank of every entry in DATA FILE order (empty: the file lay in key order, rank == id).  Only DBs read from files written by
     // several threads have one; concatdbs renumbers its second DB by it (DBConcat.cpp:46-47,113-118 opens it LINEAR_ACCCESS).
     plasship::DevBuf d_fileRank;
+    // offset and length of every entry packed into one word (plasship::ensureOffLen): the kernels that look up RANDOM entries
+    // (the targets of candidate pairs and alignments) fetch one line per entry instead of one of d_off and one of d_len
+    mutable plasship::DevBuf d_offLen;
     // host mirror of the index (lazily filled for device-produced DBs)
     bool hostIndexValid = false;
     std::vector<uint32_t> h_key, h_elen;
     std::vector<uint64_t> h_off;
     plasship::SeqView view() const {
-        plasship::SeqView v; v.data = d_data.as<char>(); v.off = d_off.as<uint64_t>(); v.len = d_len.as<uint32_t>();
+        plasship::SeqView v; v.data = d_data.as<char>(); v.off = d_off.as<uint64_t>(); v.len = d_len.as<uint32_t>(); v.offLen = d_offLen.as<uint64_t>();
         v.n = (uint32_t) n; v.nucl = (dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES); return v;
     }
 };

@@ -498,6 +498,18 @@ __global__ __launch_bounds__(256) void digestKernel(const char *__restrict__ dat
     for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o, 64); bytes += __shfl_xor(bytes, o, 64); }
     if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], sum); atomicAdd(&out[1], bytes); }
 }
+__global__ void packOffLenKernel(const uint64_t *__restrict__ off, const uint32_t *__restrict__ len, uint64_t n, uint64_t *__restrict__ out) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) out[i] = (off[i] << 24) | (uint64_t) (len[i] & 0xFFFFFFu);
+}
+// plasship_seqdb::d_offLen, built on the first call that looks up random entries of the DB (sequences are shorter than 2^20, a DB
+// smaller than 2^40 bytes).  Stream-ordered: the caller's kernels follow on ctx->stream.
+int ensureOffLen(plasship_ctx *ctx, const plasship_seqdb *db) {
+    if (db->d_offLen.p || db->n == 0) return PLASSHIP_OK;
+    if (db->d_offLen.alloc(db->n * 8) != hipSuccess) { setError("out of device memory for the packed offsets of a sequence DB"); return PLASSHIP_ERR_DEVICE; }
+    hipLaunchKernelGGL(packOffLenKernel, dim3((unsigned) std::min<uint64_t>((db->n + 255) / 256, (uint64_t) ctx->numCU * 16)), dim3(256), 0, ctx->stream,
+                       db->d_off.as<uint64_t>(), db->d_len.as<uint32_t>(), (uint64_t) db->n, db->d_offLen.as<uint64_t>());
+    return PLASSHIP_OK;
+}
 }  // namespace plasship
 extern "C" int plasship_seqdb_digest(plasship_ctx *ctx, const plasship_seqdb *db, uint64_t *digest, uint64_t *entry_bytes) {
     if (!ctx || !db || !digest) { setError("plasship_seqdb_digest: bad argument"); return PLASSHIP_ERR_ARG; }

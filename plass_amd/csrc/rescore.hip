@@ -43,6 +43,7 @@ struct RescoreArgs {
     double lambda, logK, ln2;
     unsigned long long *stats;   // [0] accepted, [1] overlap residues
     unsigned long long *longList, *longCount;   // hit indices queued for the 16-lane kernel
+    uint32_t shortMax;           // min(qLen, tLen) up to which the thread-per-pair kernel scores a pair itself
 };
 
 __device__ __forceinline__ bool canBeCoveredDev(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -108,57 +109,86 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
     if (len == 0) { r.first = 0; r.last = -1; return r; }   // empty sequence: reference reads out of bounds; unsupported
     // REV: the aligned query is the reverse complement of the stored one: qrev[i] = comp(q[qLen-1-i])
     auto Q = [&](unsigned i) -> char { return REV ? (char) comp[(unsigned char) q[qLen - 1 - (qo + i)]] : q[qo + i]; };
-    const char q0 = Q(0), t0 = t[to], qe = Q(len - 1), te = t[to + len - 1];
-    const unsigned first = (q0 == '*' || t0 == '*') ? 1u : 0u;
-    unsigned last = len - 1;
-    if (last > 0 && (qe == '*' || te == '*')) last--;
+    unsigned first, last;
     int s = 0, ids = 0;
+    // Columns outside [first, last] are BLANKED (byte 0 in both sequences' words; entry [0][0] of the LDS score table and entry 0
+    // of the complement table are 0), so that the lookups of a step are unconditional: the compiler issues them together and waits
+    // once.  (Round 3: with one predicated block per column every `ds_read` was followed by its own wait.)
     if (G == 1) {
-        // one thread per pair: 16 residues of both sequences per round trip (unaligned 16-byte loads; buffers are padded).
-        // The loop is bound by the number of memory requests, not by bytes: every lane streams its own two sequences.
-        // REV: the aligned query is the reverse complement of the stored one — the 16 stored bytes that end at the mirrored
-        // position are loaded and walked backwards (never reading before the start of the buffer).
-        // (forward strand: the next 16 residues of both sequences are requested before the current ones are scored — the walk is a
-        // chain of dependent round trips per lane, and the score lookups of one step hide most of the next step's latency)
-        uint64_t qn[2] = {0, 0}, tn[2] = {0, 0};
-        if (!REV && first <= last) { __builtin_memcpy(tn, t + to + first, 16); __builtin_memcpy(qn, q + qo + first, 16); }
-        for (unsigned p = first; p <= last; p += 16u) {
-            uint64_t qw[2], tw[2];
-            if (!REV) { tw[0] = tn[0]; tw[1] = tn[1]; qw[0] = qn[0]; qw[1] = qn[1]; if (p + 16u <= last) { __builtin_memcpy(tn, t + to + p + 16, 16); __builtin_memcpy(qn, q + qo + p + 16, 16); } }
-            else __builtin_memcpy(tw, t + to + p, 16);
-            const unsigned n = min(16u, last - p + 1);
-            bool wide = true;
-            if (REV) {
+        // one thread per pair: 16 residues of both sequences per round trip (unaligned 16-byte loads; buffers are padded), the next
+        // 16 requested before the current ones are scored.  A pair is a chain of dependent round trips per lane and the kernel is
+        // bound by their number: the first 16 columns are requested together with the bytes of the last column, before `first` and
+        // `last` are known (column 0 is blanked afterwards when it holds a '*').
+        // REV: the aligned query is the reverse complement of the stored one — the 16 stored bytes that end at the mirrored position
+        // are loaded and byte-reversed (near the start of the sequence byte by byte, never reading before the buffer); the
+        // complement is looked up per column.
+        auto fetchQ = [&](unsigned p, uint32_t *w) {
+            if (!REV) __builtin_memcpy(w, q + qo + p, 16);
+            else {
                 const unsigned rem = qLen - (qo + p);            // stored residues left of (and including) the mirrored position
-                wide = rem >= 16;
-                if (wide) __builtin_memcpy(qw, q + (qLen - 1 - (qo + p)) - 15, 16);
+                if (rem >= 16) {
+                    uint32_t v[4]; __builtin_memcpy(v, q + (qLen - 1 - (qo + p)) - 15, 16);
+                    w[0] = __builtin_bswap32(v[3]); w[1] = __builtin_bswap32(v[2]); w[2] = __builtin_bswap32(v[1]); w[3] = __builtin_bswap32(v[0]);
+                } else {
+                    uint64_t lo = 0, hi = 0;
+                    for (unsigned j = rem; j-- > 0;) { hi = (hi << 8) | (lo >> 56); lo = (lo << 8) | (uint64_t) (unsigned char) q[qLen - 1 - (qo + p + j)]; }
+                    w[0] = (uint32_t) lo; w[1] = (uint32_t) (lo >> 32); w[2] = (uint32_t) hi; w[3] = (uint32_t) (hi >> 32);
+                }
+            }
+        };
+        uint32_t qn[4], tn[4];
+        __builtin_memcpy(tn, t + to, 16); fetchQ(0, qn);
+        const char te = t[to + len - 1];
+        const char qeStored = REV ? q[qLen - 1 - (qo + len - 1)] : q[qo + len - 1];
+        const char qe = REV ? (char) comp[(unsigned char) qeStored] : qeStored;
+        const char t0 = (char) (tn[0] & 0xFFu);
+        const char q0 = REV ? (char) comp[qn[0] & 0xFFu] : (char) (qn[0] & 0xFFu);
+        first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+        last = len - 1;
+        if (last > 0 && (qe == '*' || te == '*')) last--;
+        for (unsigned p = 0; p <= last; p += 16u) {
+            uint32_t qw[4], tw[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { qw[k] = qn[k]; tw[k] = tn[k]; }
+            if (p + 16u <= last) { __builtin_memcpy(tn, t + to + p + 16, 16); fetchQ(p + 16, qn); }
+            const unsigned n = min(16u, last - p + 1);
+            const unsigned skip = p ? 0u : first;                // column 0 of the overlap is not scored when it holds a '*'
+            const unsigned blanks = (16u - n) + skip;
+            if (blanks) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int nb = (int) n - 4 * k;
+                    uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
+                    if (k == 0 && skip) m &= 0xFFFFFF00u;
+                    qw[k] &= m; tw[k] &= m;
+                }
             }
             if (!REV) {
                 // identities of the 16 columns at once: bytes equal up to the case bit are zero bytes of (q ^ t) & 0xDF..; exact
-                // zero-byte test, columns beyond n masked off (4 instructions per residue less than comparing byte by byte)
-                const uint64_t lo7 = 0x7F7F7F7F7F7F7F7FULL;
-                const uint64_t x0 = (qw[0] ^ tw[0]) & 0xDFDFDFDFDFDFDFDFULL, x1 = (qw[1] ^ tw[1]) & 0xDFDFDFDFDFDFDFDFULL;
-                uint64_t z0 = ~(((x0 & lo7) + lo7) | x0 | lo7), z1 = ~(((x1 & lo7) + lo7) | x1 | lo7);     // 0x80 in every zero byte
-                if (n < 8) { z0 &= (1ULL << (8 * n)) - 1ULL; z1 = 0; } else if (n < 16) z1 &= (1ULL << (8 * (n - 8))) - 1ULL;
-                ids += __popcll(z0) + __popcll(z1);
+                // zero-byte test; the blanked columns count as equal and are taken off again
+                int z = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t x = (qw[k] ^ tw[k]) & 0xDFDFDFDFu;
+                    z += __popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu));
+                }
+                ids += z - (int) blanks;
             }
 #pragma unroll
             for (unsigned j = 0; j < 16; j++) {
-                if (j < n) {
-                    unsigned a;
-                    if (!REV) a = (unsigned) (qw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
-                    else {
-                        const unsigned jj = 15u - j;                 // byte of the loaded block that holds stored position mirror - j
-                        const char c = wide ? (char) (qw[jj >> 3] >> (8 * (jj & 7))) : q[qLen - 1 - (qo + p + j)];
-                        a = (unsigned) comp[(unsigned char) c];
-                    }
-                    const unsigned b = (unsigned) (tw[j >> 3] >> (8 * (j & 7))) & 0xFFu;
-                    s += (int) smat[a * 123 + b];
-                    if (REV) ids += ((a & ~0x20u) == (b & ~0x20u)) ? 1 : 0;
-                }
+                unsigned a = (qw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                if (REV) a = (unsigned) comp[a];
+                const unsigned b = (tw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+                s += (int) smat[(a << 7) | b];
+                if (REV) ids += ((a & ~0x20u) == (b & ~0x20u)) ? 1 : 0;
             }
+            if (REV) ids -= (int) blanks;
         }
-    } else
+    } else {
+    const char q0 = Q(0), t0 = t[to], qe = Q(len - 1), te = t[to + len - 1];
+    first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+    last = len - 1;
+    if (last > 0 && (qe == '*' || te == '*')) last--;
     for (unsigned p = first + 8u * (unsigned) sl; p <= last; p += 8u * G) {
         // 8 consecutive residues of both sequences (unaligned 8-byte loads; the DB buffer is padded past its end)
         uint64_t tw; __builtin_memcpy(&tw, t + to + p, 8);
@@ -170,42 +200,65 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
         }
         else __builtin_memcpy(&qw, q + qo + p, 8);
         const unsigned n = min(8u, last - p + 1);
+        if (n < 8u) { const uint64_t m = (1ULL << (8 * n)) - 1ULL; qw &= m; tw &= m; }
 #pragma unroll
         for (unsigned j = 0; j < 8; j++) {
-            if (j < n) {
-                char a = (char) (qw >> (8 * j)), b = (char) (tw >> (8 * j));
-                if (REV) a = (char) comp[(unsigned char) a];
-                s += (int) smat[(int) a * 123 + (int) b];
-                ids += ((a & ~0x20) == (b & ~0x20)) ? 1 : 0;
-            }
+            unsigned a = (unsigned) (qw >> (8 * j)) & 0xFFu;
+            const unsigned b = (unsigned) (tw >> (8 * j)) & 0xFFu;
+            if (REV) a = (unsigned) comp[a];
+            s += (int) smat[(a << 7) | b];
+            ids += ((a & ~0x20u) == (b & ~0x20u)) ? 1 : 0;
         }
+        ids -= (int) (8u - n);
+    }
     }
     if (G > 1) { s = groupReduceSumG<G>(s); ids = groupReduceSumG<G>(ids); }
     r.score = (unsigned) max(s, 0); r.first = (int) first; r.last = (int) last; r.idCnt = ids;
     return r;
 }
 
-template <int G>
-__global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
-    __shared__ signed char smat[123 * 123 + 7];
+// ALL: every candidate pair is this kernel's (G > 1: no list of long overlaps)
+template <int G, int WPE, bool ALL = (G == 1)>
+__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rescoreKernel(RescoreArgs a) {
+    __shared__ signed char smat[123 * 128];              // row stride 128: the index of a column is (a << 7) | b
     __shared__ unsigned char sComp[256];                 // reverse-strand hits: complement of a stored letter (getRevFragment's mapping)
-    for (int i = threadIdx.x; i < 123 * 123; i += RS_BLOCK) smat[i] = a.mat[i];
-    for (int i = threadIdx.x; i < 256; i += RS_BLOCK) sComp[i] = (unsigned char) nuclRevCompChar((char) i);
+    for (int i = threadIdx.x; i < 123 * 128; i += RS_BLOCK) smat[i] = (i & 127) < 123 ? a.mat[(i >> 7) * 123 + (i & 127)] : (signed char) 0;
+    for (int i = threadIdx.x; i < 256; i += RS_BLOCK) sComp[i] = i ? (unsigned char) nuclRevCompChar((char) i) : (unsigned char) 0;
+    __syncthreads();
+    if (threadIdx.x == 0) smat[0] = 0;      // blanked columns (scoreDiagonal) look up [0][0]; no residue is byte 0
     __syncthreads();
     const int groupsPerBlock = RS_BLOCK / G;
     const int sl = threadIdx.x & (G - 1);
     const uint64_t stride = (uint64_t) gridDim.x * groupsPerBlock;
     unsigned long long accLocal = 0, ovLocal = 0;
-    const uint64_t nWork = (G == 1) ? a.nHits : (uint64_t) *a.longCount;
-    for (uint64_t w = (uint64_t) blockIdx.x * groupsPerBlock + (threadIdx.x / G); w < nWork; w += stride) {
-        const uint64_t h = (G == 1) ? w : a.longList[w];
-        const CandHit hit = a.hits[h];
+    const uint64_t nWork = ALL ? a.nHits : (uint64_t) *a.longCount;
+    // G == 1: the candidate of the next round and its sequences' offsets / lengths are requested while the current pair is scored
+    // (a pair is a chain of dependent round trips: candidate -> offsets and lengths -> residues; two of them leave the chain)
+    struct Meta { uint64_t qOff, tOff; uint32_t qLen, tLen; };
+    // (offset, length) of an entry come from ONE packed word: a random target costs one line of metadata instead of two
+    auto loadMeta = [&](const CandHit &c) { Meta m; const uint64_t qv = a.q.offLen[c.query], tv = a.t.offLen[c.target]; m.qOff = qv >> 24; m.qLen = (uint32_t) qv & 0xFFFFFFu; m.tOff = tv >> 24; m.tLen = (uint32_t) tv & 0xFFFFFFu; return m; };
+    uint64_t w = (uint64_t) blockIdx.x * groupsPerBlock + (threadIdx.x / G);
+    CandHit hitNext; Meta metaNext; CandHit hitAfter;
+    memset(&hitNext, 0, sizeof(hitNext)); memset(&hitAfter, 0, sizeof(hitAfter)); memset(&metaNext, 0, sizeof(metaNext));
+    if (G == 1) {
+        if (w < nWork) { hitNext = a.hits[w]; metaNext = loadMeta(hitNext); }
+        if (w + stride < nWork) hitAfter = a.hits[w + stride];
+    }
+    for (; w < nWork; w += stride) {
+        const uint64_t h = ALL ? w : a.longList[w];
+        CandHit hit; Meta me;
+        if (G == 1) {
+            hit = hitNext; me = metaNext;
+            hitNext = hitAfter;
+            if (w + stride < nWork) metaNext = loadMeta(hitNext);
+            if (w + 2 * stride < nWork) hitAfter = a.hits[w + 2 * stride];
+        } else { hit = a.hits[h]; me = loadMeta(hit); }
         const uint32_t qid = hit.query, tid = hit.target;
-        const char *q = a.q.data + a.q.off[qid];
-        const unsigned qLen = a.q.len[qid];
-        const char *t = a.t.data + a.t.off[tid];
-        const unsigned tLen = a.t.len[tid];
-        if (G == 1 && min(qLen, tLen) > RS_SHORT_MAX) {       // long overlap: 16 lanes will score it
+        const char *q = a.q.data + me.qOff;
+        const unsigned qLen = me.qLen;
+        const char *t = a.t.data + me.tOff;
+        const unsigned tLen = me.tLen;
+        if (G == 1 && min(qLen, tLen) > a.shortMax) {       // long overlap: 16 lanes will score it
             const unsigned long long o = atomicAdd(a.longCount, 1ULL); a.longList[o] = h;
             continue;
         }
@@ -215,18 +268,17 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
         rec.query = qid; rec.target = tid;
         bool accepted = false;
         if (canBeCoveredDev(a.covThr, a.covMode, (float) qLen, (float) tLen)) {
-            // computeUngappedAlignment: best over all wraps; default LocalAlignment if none scores > 0
+            // computeUngappedAlignment: best over all wraps (first the negative ones, then the positive ones; strictly better wins);
+            // default LocalAlignment if none scores > 0.  A wrap whose diagonal misses the sequences scores 0 and is skipped.
             int bStart = -1, bEnd = -1, bDiag = 0, bIds = 0; unsigned bScore = 0, bDiagLen = 0, bDist = 0;
             const unsigned d16 = hit.diag16 & 0xFFFFu;
-            for (unsigned d = 1; d <= 1 + tLen / 32768; d++) {
-                const int real = (int) (d16 - d * 65536u);
+            const unsigned nNeg = 1 + tLen / 32768, nPos = 1 + qLen / 65536;
+            for (unsigned c = 0; c < nNeg + nPos; c++) {
+                const int real = c < nNeg ? (int) (d16 - (c + 1) * 65536u) : (int) ((c - nNeg) * 65536u + d16);
+                const unsigned dist = (unsigned) abs(real);
+                if (!(real >= 0 ? dist < qLen : dist < tLen)) continue;
                 DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sComp, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sComp, sl);
-                if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
-            }
-            for (unsigned d = 0; d <= qLen / 65536; d++) {
-                const int real = (int) (d * 65536u + d16);
-                DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sComp, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sComp, sl);
-                if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = (unsigned) abs(real); bIds = s.idCnt; }
+                if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = dist; bIds = s.idCnt; }
             }
             if (sl == 0) ovLocal += bDiagLen;
             // ---- group-uniform finish (rescorediagonal.cpp:251-314) ----
@@ -276,10 +328,16 @@ __global__ __launch_bounds__(RS_BLOCK) void rescoreKernel(RescoreArgs a) {
     }
 }
 
-__global__ void compactAlnKernel(const AlnRec *__restrict__ in, const uint32_t *__restrict__ accept,
-                                 const uint64_t *__restrict__ pos, AlnRec *__restrict__ out, uint64_t n) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
-        if (accept[i]) out[pos[i]] = in[i];
+// four lanes per 64-byte record, 16 bytes each: both sides coalesced (one lane per record made every load and store instruction
+// touch 64 different lines: 8.8 ms for 226 M records, the wavefronts stalled on the memory pipe 80 % of their cycles)
+__global__ void compactAlnKernel(const uint4 *__restrict__ in, const uint32_t *__restrict__ accept,
+                                 const uint64_t *__restrict__ pos, uint4 *__restrict__ out, uint64_t n) {
+    static_assert(sizeof(AlnRec) == 64, "four 16-byte pieces per record");
+    const uint64_t total = n * 4;
+    for (uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t i = t >> 2;
+        if (accept[i]) out[pos[i] * 4 + (t & 3)] = in[t];
+    }
 }
 __global__ void gatherOffsetsKernel(const uint64_t *__restrict__ candQoff, const uint64_t *__restrict__ pos,
                                     uint64_t *__restrict__ alnQoff, uint64_t nQ) {
@@ -336,6 +394,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     if (dAll.alloc(std::max<uint64_t>(nHits, 1) * sizeof(AlnRec)) != hipSuccess || dAccept.alloc(std::max<uint64_t>(nHits, 1) * 4) != hipSuccess ||
         dPos.alloc((nHits + 1) * 8) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
 
+    { int rcOL = ensureOffLen(ctx, qdb); if (!rcOL) rcOL = ensureOffLen(ctx, tdb); if (rcOL) return rcOL; }
     RescoreArgs a;
     a.q = qdb->view(); a.t = tdb->view(); a.qoff = c->d_qoff.as<uint64_t>(); a.hits = c->d_hits.as<CandHit>(); a.nHits = nHits;
     a.out = dAll.as<AlnRec>(); a.accept = dAccept.as<uint32_t>(); a.minScore = dMinScore.as<uint32_t>(); a.minScoreLen = tabLen;
@@ -346,10 +405,19 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     if (dLongList.alloc(std::max<uint64_t>(nHits, 1) * 8) != hipSuccess || dLongCount.alloc(8) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 8, ctx->stream));
     a.longList = dLongList.as<unsigned long long>(); a.longCount = dLongCount.as<unsigned long long>();
+    a.shortMax = (uint32_t) tuneInt("RESCORE_SHORT", (int) RS_SHORT_MAX);
     const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * (uint64_t) tuneInt("RESCORE", nHits > 50000000ull ? 32 : 12));   // large lists: smaller shares per workgroup even out the tail (37.8 -> 35.9 ms at 250 M pairs)
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-    hipLaunchKernelGGL(rescoreKernel<1>, dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-    hipLaunchKernelGGL(rescoreKernel<16>, dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
+    static const int wpe = tuneInt("RESCORE_WPE", 5);       // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight)
+    static const int rsG = tuneInt("RESCORE_G", 1);         // lanes per pair of the main kernel (1: thread per pair + a 16-lane kernel for the long overlaps)
+    if (rsG == 8) hipLaunchKernelGGL((rescoreKernel<8, 6, true>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    else if (rsG == 16) hipLaunchKernelGGL((rescoreKernel<16, 6, true>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    else {
+        if (wpe == 4) hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+        else if (wpe == 6) hipLaunchKernelGGL((rescoreKernel<1, 6>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+        else hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
+    }
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), nHits, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
     // the accepted alignments are compacted into a buffer sized for ALL pairs (nearly all candidates of an assembly iteration are
@@ -363,8 +431,8 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     if (al->d_qoff.alloc((qdb->n + 1) * 8) != hipSuccess || al->d_recs.alloc(std::max<uint64_t>(nHits, 1) * sizeof(AlnRec)) != hipSuccess) {
         setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    if (nHits) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((nHits + 255) / 256, 65535)), dim3(256), 0, ctx->stream,
-                                  dAll.as<AlnRec>(), dAccept.as<uint32_t>(), dPos.as<uint64_t>(), al->d_recs.as<AlnRec>(), nHits);
+    if (nHits) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((4 * nHits + 255) / 256, (uint64_t) ctx->numCU * 64)), dim3(256), 0, ctx->stream,
+                                  dAll.as<uint4>(), dAccept.as<uint32_t>(), dPos.as<uint64_t>(), al->d_recs.as<uint4>(), nHits);
     hipLaunchKernelGGL(gatherOffsetsKernel, dim3((unsigned) std::min<uint64_t>((qdb->n + 256) / 256, 65535)), dim3(256), 0, ctx->stream,
                        c->d_qoff.as<uint64_t>(), dPos.as<uint64_t>(), al->d_qoff.as<uint64_t>(), (uint64_t) qdb->n);
     unsigned long long hs[2] = {0, 0};
