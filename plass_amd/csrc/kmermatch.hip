@@ -671,6 +671,7 @@ struct ShortArgs {
     SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map;
     int k, xCode, kps, ignoreMulti; float scale; uint64_t seed;
     uint64_t base, top, inv; int tz;     // alphabet base; base^(k-1); exact division by base = (x >> tz) * inv
+    uint32_t topLo, topHi, baseH;    // extractShortFastKernel: base^(H-1), base^(K-H-1), base^H for the two halves of the k-mer index (H = K / 2)
     uint32_t *waveList, *waveCount;      // sequences for the wave kernels ...
     uint32_t *longList, *longCount; uint32_t longWindows;   // ... those with more than longWindows windows go to this list instead (nullptr: one list)
     uint32_t *hugeList, *hugeCount; uint32_t hugeWindows;   //     and those with more than hugeWindows to this one (nullptr: no such list)
@@ -763,6 +764,144 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
         // the queued sequences, one atomic per wavefront and list (the wave kernels' tiers are fed from these lists directly: a
         // queue filled one sequence at a time — one atomic on one counter per sequence — costs more than the tier it feeds)
         const uint32_t nw = (toWave && active && a.s.len[id] >= (uint32_t) k) ? a.s.len[id] - (uint32_t) k + 1 : 0u;
+        const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
+        const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
+        auto append = [&](bool mine, uint32_t *list, uint32_t *count) {
+            const unsigned long long m = __ballot(mine);
+            if (!m) return;
+            uint32_t basePos = 0;
+            if (lane == 0) basePos = atomicAdd(count, (uint32_t) __popcll(m));
+            basePos = __shfl(basePos, 0, 64);
+            if (mine) list[basePos + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL))] = id;
+        };
+        append(toWave && !isLong && !isHuge, a.waveList, a.waveCount);
+        if (a.longList) append(isLong, a.longList, a.longCount);
+        if (a.hugeList) append(isHuge, a.hugeList, a.hugeCount);
+    }
+    stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
+    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
+}
+
+// The same, restated for the instruction mix (round 3).  The PMC pass over the kernel above (profiles/r03_pmc) showed it bound by
+// SCALAR issue — 1.3 M scalar against 0.67 M vector instructions per wavefront: per residue a chain of divergent branches (first
+// window or not, word boundary, X, the four-way switch of the pending stores, the probe loop), each paid in exec-mask bookkeeping —
+// and a third of its vector time in 64-bit multiplications (the rolling index and the repeat tag: twelve quarter-rate instructions
+// per residue).  Here
+//  * the lanes of a wavefront walk their sequences in lockstep, four residues (one 32-bit load) per iteration of a wave-uniform loop;
+//    the first window needs no code of its own: the index starts from K virtual letters of code 0 and is rolled forward;
+//  * the k-mer index base^0 d_0 + ... + base^(K-1) d_(K-1) is kept as TWO 32-bit halves (low H digits, high K - H digits): a roll
+//    is (x - d) >> tz times the 32-bit inverse of the odd part of the base plus digit * power — one quarter-rate multiplication per
+//    half, the digit products on the 24-bit multiplier — and the 64-bit index lo + hi * base^H is built only for a record that is written;
+//  * the digits that leave the halves come from a 16-byte register FIFO of the last letter codes at compile-time byte positions;
+//  * the repeat tag is any 16-bit function of the k-mer (see above): two 24-bit products of the halves.
+// Records, lists and statistics are those of the kernel above (which stays for k != 14 and for alphabets whose half-index does not
+// fit 32 bits).
+// the 24-bit multiplier (full rate; the compiler prefers the quarter-rate 32-bit one when it can prove the results equal)
+__device__ __forceinline__ uint32_t mulU24(uint32_t a, uint32_t b) { uint32_t r; asm("v_mul_u32_u24_e32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t waveMaxU32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t) __shfl_xor((int) v, o, 64));
+    return v;
+}
+template <bool LONG, int K, bool MUL24>
+__global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
+    constexpr int H = K / 2;
+    static_assert(K <= 16 && 16 - K + H + 3 <= 15, "the digits that leave the halves are read from the 16-byte FIFO before this iteration's codes enter it");
+    __shared__ unsigned char sMap[256];
+    __shared__ __attribute__((aligned(16))) unsigned short sSet[64 * 64];    // per-lane open-addressing set of tags, as above
+    typedef Rec<LONG> R;
+    R *arr = reinterpret_cast<R *>(a.arr);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
+    __syncthreads();
+    unsigned short *mySet = sSet + lane * 64;
+    const uint32_t inv32 = (uint32_t) a.inv, tz = (uint32_t) a.tz, topLo = a.topLo, topHi = a.topHi, xCode = (uint32_t) a.xCode;
+    const uint32_t baseH = a.baseH;
+    const bool multi = a.ignoreMulti != 0;
+    auto digitMul = [&](uint32_t d, uint32_t pw) -> uint32_t { return MUL24 ? __umul24(d, pw) : d * pw; };
+    unsigned long long stRes = 0, stRec = 0;
+    for (uint32_t b0 = a.idLo + blockIdx.x * 64; b0 < a.idHi; b0 += gridDim.x * 64) {
+        const uint32_t id = b0 + lane;
+        const bool active = id < a.idHi;
+        bool toWave = false;
+        uint32_t L = 0;
+        if (active) {
+            L = a.s.len[id];
+            const uint32_t nWin = (L >= (uint32_t) K) ? (L - K + 1) : 0;
+            const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));
+            // (more than 48 windows would overfill the 64-slot tag set: the kernel above hands such a sequence over at its 49th
+            // record, here it goes at once — the wave kernel's records are the same either way)
+            if (L > SHORT_MAXL || (size_t) nWin > consideredRaw || (multi && nWin > 48)) toWave = true;
+        }
+        const bool work = active && !toWave;
+        const uint32_t Lmax = (uint32_t) __builtin_amdgcn_readfirstlane((int) waveMaxU32(work ? L : 0u));
+        if (Lmax) {
+            const char *base = a.s.data;
+            uint64_t slot = 0; uint32_t bound = 0;
+            if (work) {
+                base += a.s.off[id];
+                slot = a.slotOff[id] - a.slotBias; bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
+                if (multi) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 8; i++) q[i] = z; }
+            }
+            const uint32_t Lw = work ? L : 0u;                 // a lane without work has no residue inside
+            uint32_t lo = 0, hi = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, nOut = 0;
+            uint64_t seqHash = 0;
+            int lastX = -1;
+            for (uint32_t i = 0; i < Lmax; i += 4) {
+                uint32_t word = 0;
+                if (i < Lw) __builtin_memcpy(&word, base + i, 4);                           // the buffer is padded past its end
+                const uint32_t cw = (uint32_t) sMap[word & 0xFFu] | ((uint32_t) sMap[(word >> 8) & 0xFFu] << 8) |
+                                    ((uint32_t) sMap[(word >> 16) & 0xFFu] << 16) | ((uint32_t) sMap[word >> 24] << 24);
+                const uint32_t f[4] = {f0, f1, f2, f3};
+                // identity hash (Util::hash: h = h * 31 + code), the up to four residues of this step at once: h * 31^m + their Horner sum
+                uint32_t part = 0, mult = 1;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const bool in = i + (uint32_t) j < Lw;
+                    const uint32_t c = (cw >> (8 * j)) & 0xFFu;
+                    part = in ? __umul24(part, 31u) + c : part;
+                    mult = in ? __umul24(mult, 31u) : mult;
+                }
+                seqHash = seqHash * (uint64_t) mult + (uint64_t) part;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t ii = i + (uint32_t) j;
+                    const bool in = ii < Lw;
+                    const uint32_t c = (cw >> (8 * j)) & 0xFFu;
+                    lastX = (in && c == xCode) ? (int) ii : lastX;
+                    constexpr int B0 = 16 - K, BH = 16 - K + H;
+                    const uint32_t d0 = (f[(B0 + j) >> 2] >> (8 * ((B0 + j) & 3))) & 0xFFu;    // the digits of window ii - K that leave the halves
+                    const uint32_t dh = (f[(BH + j) >> 2] >> (8 * ((BH + j) & 3))) & 0xFFu;
+                    lo = ((lo - d0) >> tz) * inv32 + digitMul(dh, topLo);
+                    hi = ((hi - dh) >> tz) * inv32 + digitMul(c, topHi);
+                    const int p = (int) ii + 1 - K;
+                    if (in && !toWave && p >= 0 && lastX < p) {
+                        if (multi) {
+                            const uint32_t t = mulU24(lo, 0x9E3779u) ^ mulU24(hi, 0x85EBCBu) ^ (lo >> 9) ^ (hi >> 7);
+                            const unsigned short tag = (unsigned short) max((t >> 8) & 0xFFFFu, 1u);      // 0 marks an empty slot
+                            uint32_t sl = (t >> 3) & 63u;
+                            unsigned short v = mySet[sl];
+                            while (v != 0 && v != tag) { sl = (sl + 1) & 63u; v = mySet[sl]; }     // one exit condition: the first probe almost always ends it
+                            if (v == tag) toWave = true; else mySet[sl] = tag;
+                        }
+                        R r; r.kmer = (uint64_t) lo + (uint64_t) hi * (uint64_t) baseH; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) p;
+                        if constexpr (LONG) r.pad = 0;
+                        arr[slot + 1 + nOut] = r;
+                        nOut++;
+                    }
+                }
+                f0 = f1; f1 = f2; f2 = f3; f3 = cw;
+            }
+            if (work && !toWave) {
+                R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
+                if constexpr (LONG) r.pad = 0;
+                arr[slot] = r;
+                R sen; memset(&sen, 0xFF, sizeof(R));
+                for (uint32_t i = 1 + nOut; i < bound; i++) arr[slot + i] = sen;
+                stRes += L; stRec += 1 + nOut;
+            }
+        }
+        const uint32_t nw = (toWave && active && L >= (uint32_t) K) ? L - (uint32_t) K + 1 : 0u;
         const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
         const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
         auto append = [&](bool mine, uint32_t *list, uint32_t *count) {
@@ -1515,15 +1654,21 @@ __global__ __launch_bounds__(256) void rxListKernel(const RxSeg *__restrict__ se
 // 6. best diagonal per (rep, target) run (writeKmerMatcherResult, kmermatcher.cpp:835-923) over weighted triples
 // =====================================================================================================
 template <bool NUCL>
-__global__ void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, uint64_t nScan, CandHit *__restrict__ tmpHits, uint32_t *__restrict__ emit,
+__global__ __launch_bounds__(256) void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, uint64_t nScan, CandHit *__restrict__ tmpHits, uint32_t *__restrict__ emitW,
                                  uint32_t *__restrict__ perRep) {
     // h[n .. nScan): what follows this rank's triples in the global (rep, target, diagonal) order as far as the last run's scan
     // can reach (sharded run: the head of the next ranks' triples and the stale records; nScan == n otherwise)
+    // A wavefront takes 64 consecutive triples; the candidates it emits are packed to the front of ITS 64 slots of tmpHits (one
+    // coalesced store per wavefront instead of 16-byte stores scattered over the slots of the run heads) and counted once per
+    // wavefront (emitW[i / 64]); the triples are in id order, so the candidates of one representative are counted with one atomic per
+    // wavefront.  (Round 3: the kernel's memory pipe was busy all the time with partial-line writes: profiles/r03_pmc.)
+    const int lane = threadIdx.x & 63;
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
         const Triple r = h[i];
         bool head = (i == 0);
         if (!head) { const Triple q = h[i - 1]; head = (q.rep != r.rep) || (q.target != r.target); }
         uint32_t e = 0;
+        CandHit c; c.target = 0; c.prefScore = 0; c.diag16 = 0; c.query = 0;
         if (head) {
             const uint32_t targetId = r.target;
             int32_t diagonal = r.diag, prevDiagonal = r.diag;
@@ -1536,21 +1681,34 @@ __global__ void reduceRunsKernel(const Triple *__restrict__ h, uint64_t n, uint6
             for (uint64_t j = i; j < nScan; j++) {
                 const Triple x = h[j];
                 if (x.target != targetId) break;
-                const uint64_t c = x.cnt & 0x7FFFFFFFu;
-                if (prevDiagonal == x.diag) diagonalCnt += c; else diagonalCnt = c;
+                const uint64_t cc = x.cnt & 0x7FFFFFFFu;
+                if (prevDiagonal == x.diag) diagonalCnt += cc; else diagonalCnt = cc;
                 // every record of the run is checked against the running maximum; the count only grows inside a
                 // run, so the state after the run is what the record-by-record walk leaves behind
                 if (diagonalCnt >= maxDiagonal) { diagonal = x.diag; maxDiagonal = diagonalCnt; if (NUCL) bestRev = ((x.cnt & 0x80000000u) == 0); }
-                prevDiagonal = x.diag; topScore += c;
+                prevDiagonal = x.diag; topScore += cc;
             }
             if (targetId != r.rep) {
-                CandHit c; c.target = targetId; c.prefScore = bestRev ? -(int) topScore : (int) topScore;
+                c.target = targetId; c.prefScore = bestRev ? -(int) topScore : (int) topScore;
                 c.diag16 = (uint32_t) (uint16_t) diagonal; c.query = r.rep;
-                tmpHits[i] = c; e = 1;
-                atomicAdd(&perRep[r.rep], 1u);
+                e = 1;
             }
         }
-        emit[i] = e;
+        // (the lanes of a wavefront leave the loop together except in its last round, where the active ones are the low lanes)
+        const unsigned long long act = __ballot(1), em = __ballot(e != 0);
+        const uint64_t i0 = i - (uint64_t) lane;
+        if (e) tmpHits[i0 + (uint64_t) __popcll(em & ((1ULL << lane) - 1ULL))] = c;
+        if (lane == 0) emitW[i0 >> 6] = (uint32_t) __popcll(em);
+        const uint32_t prevRep = (uint32_t) __shfl_up((int) r.rep, 1, 64);
+        const bool segHead = lane == 0 || prevRep != r.rep;
+        const unsigned long long hm = __ballot(segHead);
+        if (segHead) {
+            const unsigned long long above = lane == 63 ? 0ULL : (hm & ~((2ULL << lane) - 1ULL));
+            const int end = above ? __ffsll((long long) above) - 1 : 64;
+            const unsigned long long seg = (end == 64 ? ~0ULL : ((1ULL << end) - 1ULL)) & ~((1ULL << lane) - 1ULL) & act;
+            const uint32_t cnt = (uint32_t) __popcll(em & seg);
+            if (cnt) atomicAdd(&perRep[r.rep], cnt);
+        }
     }
 }
 
@@ -1611,10 +1769,13 @@ __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const u
 __global__ void fillU32Kernel(uint32_t *p, uint32_t v, uint64_t n) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) p[i] = v;
 }
-__global__ void placeHitsKernel(const CandHit *__restrict__ tmpHits, const uint32_t *__restrict__ emit, const uint64_t *__restrict__ epos,
+__global__ void placeHitsKernel(const CandHit *__restrict__ tmpHits, const uint64_t *__restrict__ eposW,
                                 uint64_t n, uint32_t qLo, CandHit *__restrict__ hits) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x)
-        if (emit[i]) { const CandHit c = tmpHits[i]; hits[epos[i] + (uint64_t) (c.query - qLo) + 1] = c; }      // self lines of queries qLo..query come first
+    // the candidates of the 64 triples [64 w, 64 w + 64) sit packed at the front of those slots of tmpHits (reduceRunsKernel)
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+        const uint64_t w = i >> 6, l = i & 63, e0 = eposW[w];
+        if (l < eposW[w + 1] - e0) { const CandHit c = tmpHits[i]; hits[e0 + l + (uint64_t) (c.query - qLo) + 1] = c; }      // self lines of queries qLo..query come first
+    }
 }
 // queries [qLo, qHi) have a self line (all of them; sharded run: the ones this rank owns)
 __global__ void placeSelfKernel(const uint64_t *__restrict__ qoff, uint32_t qLo, uint32_t qHi, CandHit *__restrict__ hits) {
@@ -2221,8 +2382,8 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
     // ---- per-(rep,target) reduction + CSR ----
     if (!lazyClock) tm.start(0);                             // (lazyClock: the caller recorded ev[13] and reads ev[13] .. ev[14] when the call is over)
     DevBuf dTmpHits, dEmit, dEpos, dPerRep, dQoff;
-    if (dTmpHits.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc(std::max<uint64_t>(nTriples, 1) * 4) != hipSuccess ||
-        dEpos.alloc((nTriples + 1) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (dTmpHits.alloc(std::max<uint64_t>(nTriples, 1) * sizeof(CandHit)) != hipSuccess || dEmit.alloc((nTriples / 64 + 2) * 4) != hipSuccess ||
+        dEpos.alloc((nTriples / 64 + 3) * 8) != hipSuccess || dPerRep.alloc(((size_t) N + 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     DevBuf dScanTmp2; const size_t scanTmp2Bytes = exclusiveScanTmpBytes(std::max<uint64_t>(nTriples, N) + 2);
     if (dScanTmp2.alloc(scanTmp2Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     uint64_t nHalo = 0;
@@ -2283,20 +2444,21 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
     } else
     hipLaunchKernelGGL(fillU32Kernel, dim3(gridFor((uint64_t) N + 1, 256, 4096)), dim3(256), 0, st, dPerRep.as<uint32_t>(), 1u, (uint64_t) N);
     if (nTriples) hipLaunchKernelGGL((reduceRunsKernel<NUCL>), dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, (const Triple *) cur, nTriples, nTriples + nHalo, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dPerRep.as<uint32_t>());
-    if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    const uint64_t nWaves = (nTriples + 63) / 64;              // candidates are counted per 64 triples (reduceRunsKernel)
+    if (exclusiveScanU32(st, dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nWaves, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     holder.reset(new plasship_cands());                              // released to the caller on success only
     plasship_cands *c = holder.get();
     c->reverseCapable = NUCL; c->nQueries = N;
     if (c->d_qoff.alloc(((size_t) N + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (exclusiveScanU32(st, dPerRep.as<uint32_t>(), c->d_qoff.as<uint64_t>(), N, dScanTmp2.p, scanTmp2Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     Nc = 0;
-    PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nTriples, 8, hipMemcpyDeviceToHost, st));
+    PH_CHECK(hipMemcpyAsync(&Nc, dEpos.as<uint64_t>() + nWaves, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
     const uint32_t qLo = cm ? (uint32_t) repBase : 0u, qHi = cm ? (uint32_t) (repBase + ownedN) : N;      // queries with a self line
     c->nHits = Nc + (qHi - qLo); c->nNonSelf = Nc;
     if (c->d_hits.alloc(std::max<uint64_t>(c->nHits, 1) * sizeof(CandHit)) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (qHi > qLo) hipLaunchKernelGGL(placeSelfKernel, dim3(gridFor(qHi - qLo, 256, 4096)), dim3(256), 0, st, c->d_qoff.as<uint64_t>(), qLo, qHi, c->d_hits.as<CandHit>());
-    if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEmit.as<uint32_t>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
+    if (nTriples) hipLaunchKernelGGL(placeHitsKernel, dim3(gridFor(nTriples, 256, 65535)), dim3(256), 0, st, dTmpHits.as<CandHit>(), dEpos.as<uint64_t>(), nTriples, qLo, c->d_hits.as<CandHit>());
     if (lazyClock) PH_CHECK(hipEventRecord(ctx->ev[14], st)); else msReduce = tm.stop(1);
     PH_TRACE(st, "kmermatch: reduce");
     PH_CHECK(plasship::streamSync(st));
@@ -2443,7 +2605,16 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             sa.hugeList = dOvIds.as<uint32_t>(); sa.hugeCount = dOvCnt.as<uint32_t>(); sa.hugeWindows = 64 * 16;
         }
         sa.idLo = sLo; sa.idHi = sHi; sa.slotBias = slotBias;
-        hipLaunchKernelGGL((extractShortKernel<LONG>), dim3(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", nMine > 20000000u ? 36 : 18))), dim3(64), 0, st, sa);   // 18 wavefronts fit a CU; on large sets twice that evens out the tail (50 M reads: 35.7 -> 34.4 ms)
+        // the fast restatement needs k = 14 and the half-indices (7 digits of the base, each at most the X code = base) in 32 bits
+        constexpr int KF = 14, HF = KF / 2;
+        bool fast = k == KF && tuneInt("SHORT_FAST", 1) == 1;      // PLASSHIP_TUNE_SHORT_FAST=2: the kernel above
+        uint64_t pwH = 1; for (int i = 0; i < HF; i++) pwH *= sa.base;
+        if (pwH * 2 >= (1ull << 32)) fast = false;
+        sa.topLo = (uint32_t) (pwH / sa.base); sa.topHi = (uint32_t) ea.powers[KF - HF - 1]; sa.baseH = (uint32_t) pwH;
+        const dim3 shortGrid(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", nMine > 20000000u ? 36 : 18)));
+        if (fast && sa.base < (1u << 8) && sa.topLo < (1u << 24) && sa.topHi < (1u << 24)) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, true>), shortGrid, dim3(64), 0, st, sa);
+        else if (fast) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, false>), shortGrid, dim3(64), 0, st, sa);
+        else hipLaunchKernelGGL((extractShortKernel<LONG>), shortGrid, dim3(64), 0, st, sa);   // 18 wavefronts fit a CU; on large sets twice that evens out the tail (50 M reads: 35.7 -> 34.4 ms)
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
