@@ -1602,18 +1602,16 @@ __global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__rest
 // pos[rep - repBase] (cnt is zeroed beforehand).  One wavefront per bucket; a representative's triples are counted 64 at a time
 // (a long contig is the representative of 10^5..10^6 triples: neither a serial walk per run nor one atomic per triple would do).
 __global__ __launch_bounds__(256) void repRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
-                                                     uint32_t repBase, uint32_t *__restrict__ cnt, uint64_t *__restrict__ pos) {
+                                                     uint32_t repBase, uint32_t *__restrict__ cnt) {
     for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
         const uint64_t s0 = (uint64_t) lineBeg[b] * RPL; const uint32_t n = unique[b];
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             const uint32_t i = i0 + laneId();
             const bool valid = i < n;
             const uint32_t rep = valid ? in[s0 + i].rep : 0xFFFFFFFFu;
-            const bool runHead = valid && (i == 0 || in[s0 + i - 1].rep != rep);          // first triple of the representative
             const uint32_t prevLane = __shfl_up(rep, 1, 64);
             const bool segHead = valid && (laneId() == 0 || prevLane != rep);            // first of its triples within these 64
             const unsigned long long heads = __ballot(segHead), vmask = __ballot(valid);
-            if (runHead) pos[rep - repBase] = s0 + i;
             if (segHead) {
                 const unsigned long long later = heads & ~((2ULL << laneId()) - 1ULL);   // heads behind this lane
                 const int end = later ? __ffsll((long long) later) - 1 : (int) __popcll(vmask);
@@ -1622,15 +1620,32 @@ __global__ __launch_bounds__(256) void repRunsKernel(const Triple *__restrict__ 
         }
     }
 }
-// every triple to its place in representative order: start[rep - repBase] + its offset within the representative's run
+// every triple to its place in representative order: start[rep - repBase] + its offset within the representative's run.  The
+// offset comes from the run heads among the 64 triples a wavefront holds (a run that began earlier is carried along as a
+// wave-uniform pair), so the only random access per representative is its start (round 3: an array of run positions, written by
+// the kernel above and read here, was a second random line per representative in both kernels).
 __global__ __launch_bounds__(256) void placeRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
-                                                       uint32_t repBase, const uint64_t *__restrict__ pos, const uint64_t *__restrict__ start, Triple *__restrict__ out) {
+                                                       uint32_t repBase, const uint64_t *__restrict__ start, Triple *__restrict__ out) {
+    const int lane = laneId();
     for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
         const uint64_t s0 = (uint64_t) lineBeg[b] * RPL; const uint32_t n = unique[b];
-        for (uint32_t i = laneId(); i < n; i += 64) {
-            const Triple t = in[s0 + i];
-            const uint32_t rel = t.rep - repBase;
-            out[start[rel] + (s0 + i - pos[rel])] = t;
+        uint32_t carryRep = 0xFFFFFFFFu, carryHead = 0;           // the run that reaches into these 64 from the left: its representative, the bucket index of its first triple
+        for (uint32_t i0 = 0; i0 < n; i0 += 64) {
+            const uint32_t i = i0 + (uint32_t) lane;
+            const bool valid = i < n;
+            Triple t; t.rep = 0xFFFFFFFFu; t.target = 0; t.diag = 0; t.cnt = 0;
+            if (valid) t = in[s0 + i];
+            const uint32_t rep = t.rep;
+            const uint32_t prevLane = __shfl_up(rep, 1, 64);
+            const bool segHead = valid && (lane == 0 || prevLane != rep);
+            const unsigned long long heads = __ballot(segHead), vmask = __ballot(valid);
+            const unsigned long long below = heads & ((lane == 63) ? ~0ULL : ((2ULL << lane) - 1ULL));       // heads at or before this lane (lane 0 is one)
+            const int headLane = 63 - __clzll((long long) below);
+            const uint32_t rep0 = (uint32_t) __shfl((int) rep, 0, 64);
+            const uint32_t runHead = (headLane == 0 && rep0 == carryRep) ? carryHead : i0 + (uint32_t) headLane;
+            if (valid) out[start[rep - repBase] + (uint64_t) (i - runHead)] = t;
+            const int lastLane = (int) __popcll(vmask) - 1;
+            carryRep = (uint32_t) __shfl((int) rep, lastLane, 64); carryHead = (uint32_t) __shfl((int) runHead, lastLane, 64);
         }
     }
 }
@@ -2060,15 +2075,15 @@ static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std
     // every bucket now holds its representatives' triples, each representative's contiguous and in (target, diagonal) order, but
     // the buckets are ranges of the bit-reversed id: count the triples per representative, prefix-sum over the ids, and move every
     // triple to its place in id order — the (rep, target, diagonal)-sorted array the run reduction walks
-    DevBuf dRepCnt, dRepPos, dRepStartLocal, dScanTmp4;
+    DevBuf dRepCnt, dRepStartLocal, dScanTmp4;
     DevBuf &dRepStart = dRepStartOut ? *dRepStartOut : dRepStartLocal;
     const size_t scanTmp4Bytes = exclusiveScanTmpBytes((size_t) nReps + 2);
-    if (dRepCnt.alloc(((size_t) nReps + 1) * 4) != hipSuccess || dRepPos.alloc(((size_t) nReps + 1) * 8) != hipSuccess || dRepStart.alloc(((size_t) nReps + 2) * 8) != hipSuccess ||
+    if (dRepCnt.alloc(((size_t) nReps + 1) * 4) != hipSuccess || dRepStart.alloc(((size_t) nReps + 2) * 8) != hipSuccess ||
         dScanTmp4.alloc(scanTmp4Bytes) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dRepCnt.p, 0, ((size_t) nReps + 1) * 4, st));
     const unsigned runGrid = std::min<uint32_t>((nSort + 3) / 4, (uint32_t) numCU * 8);
     hipLaunchKernelGGL(repRunsKernel, dim3(runGrid), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(),
-                       (const uint32_t *) dUnique.as<uint32_t>(), nSort, repBase, dRepCnt.as<uint32_t>(), dRepPos.as<uint64_t>());
+                       (const uint32_t *) dUnique.as<uint32_t>(), nSort, repBase, dRepCnt.as<uint32_t>());
     if (exclusiveScanU32(st, dRepCnt.as<uint32_t>(), dRepStart.as<uint64_t>(), nReps, dScanTmp4.p, scanTmp4Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     nTriples = 0;
     PH_COPY_SYNC(st, &nTriples, dRepStart.as<uint64_t>() + nReps, 8, hipMemcpyDeviceToHost);
@@ -2076,7 +2091,7 @@ static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std
     dR1.release(); dR2.release();
     if (dOut.alloc((std::max<uint64_t>(nTriples, 1) + slackTriples) * sizeof(Triple)) != hipSuccess) { setError("kmermatch: out of device memory for the sorted triples"); return PLASSHIP_ERR_DEVICE; }
     if (nTriples) hipLaunchKernelGGL(placeRunsKernel, dim3(runGrid), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort,
-                                     repBase, (const uint64_t *) dRepPos.as<uint64_t>(), (const uint64_t *) dRepStart.as<uint64_t>(), (Triple *) dOut.p);
+                                     repBase, (const uint64_t *) dRepStart.as<uint64_t>(), (Triple *) dOut.p);
     PH_CHECK(hipGetLastError());
     return PLASSHIP_OK;
 }

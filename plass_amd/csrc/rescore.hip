@@ -258,9 +258,17 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
         const unsigned qLen = me.qLen;
         const char *t = a.t.data + me.tOff;
         const unsigned tLen = me.tLen;
-        if (G == 1 && min(qLen, tLen) > a.shortMax) {       // long overlap: 16 lanes will score it
-            const unsigned long long o = atomicAdd(a.longCount, 1ULL); a.longList[o] = h;
-            continue;
+        if (G == 1) {                                         // long overlap: 16 lanes will score it (one atomic per wavefront, not per pair)
+            const bool toLong = min(qLen, tLen) > a.shortMax;
+            const unsigned long long m = __ballot(toLong);
+            if (m) {
+                const int leader = __ffsll((long long) m) - 1;
+                unsigned long long basePos = 0;
+                if (laneId() == leader) basePos = atomicAdd(a.longCount, (unsigned long long) __popcll(m));
+                basePos = __shfl(basePos, leader, 64);
+                if (toLong) a.longList[basePos + (unsigned long long) __popcll(m & ((1ULL << laneId()) - 1ULL))] = h;
+            }
+            if (toLong) continue;
         }
         const bool isReverse = a.reverseCapable && hit.prefScore < 0;
         const bool isIdentity = (qid == tid) && (a.includeIdentity || a.sameDB);
@@ -409,15 +417,12 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * (uint64_t) tuneInt("RESCORE", nHits > 50000000ull ? 32 : 12));   // large lists: smaller shares per workgroup even out the tail (37.8 -> 35.9 ms at 250 M pairs)
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
     static const int wpe = tuneInt("RESCORE_WPE", 5);       // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight)
-    static const int rsG = tuneInt("RESCORE_G", 1);         // lanes per pair of the main kernel (1: thread per pair + a 16-lane kernel for the long overlaps)
-    if (rsG == 8) hipLaunchKernelGGL((rescoreKernel<8, 6, true>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-    else if (rsG == 16) hipLaunchKernelGGL((rescoreKernel<16, 6, true>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-    else {
-        if (wpe == 4) hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-        else if (wpe == 6) hipLaunchKernelGGL((rescoreKernel<1, 6>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-        else hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-        hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
-    }
+    // (16 or 8 lanes per pair for EVERY pair, and a second thread-per-pair pass for the overlaps of 128-512 columns, were both
+    // slower — 76 / 53 ms and 83 ms against 45 ms per iteration at 50 M reads: profiles/r03_ab_knobs.txt)
+    if (wpe == 4) hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    else if (wpe == 6) hipLaunchKernelGGL((rescoreKernel<1, 6>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), nHits, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
     // the accepted alignments are compacted into a buffer sized for ALL pairs (nearly all candidates of an assembly iteration are
