@@ -82,10 +82,19 @@ __device__ __forceinline__ float seqIdThroughText(float f) {
 // arena buffers are padded past their ends, bytes beyond the range are masked off.
 __device__ __forceinline__ uint64_t loadU64Unaligned(const char *p) { uint64_t w; __builtin_memcpy(&w, p, 8); return w; }
 __device__ __forceinline__ void storeU64Unaligned(char *p, uint64_t w) { __builtin_memcpy(p, &w, 8); }
+// the last, partial word of a copy: the source word is read whole (the buffers are padded), the destination gets its 1-7 bytes as one
+// 4-, 2- and 1-byte store each — never a byte beyond n (the next sequence of the arena / the output DB belongs to another group).
+// (Byte by byte the tail was up to seven loads and seven stores of the whole wavefront per copy: round 3, profiles/r03_pmc.)
+__device__ __forceinline__ void storeTail(char *d, uint64_t v, unsigned r) {
+    if (r & 4u) { const uint32_t x = (uint32_t) v; __builtin_memcpy(d, &x, 4); d += 4; v >>= 32; }
+    if (r & 2u) { const uint16_t x = (uint16_t) v; __builtin_memcpy(d, &x, 2); d += 2; v >>= 16; }
+    if (r & 1u) *d = (char) v;
+}
 template <int G> __device__ __forceinline__ void copyBytesG(char *dst, const char *src, unsigned n, int gl) {
     for (unsigned i = 8u * (unsigned) gl; i < n; i += 8u * G) {
-        if (i + 8 <= n) storeU64Unaligned(dst + i, loadU64Unaligned(src + i));
-        else for (unsigned j = i; j < n; j++) dst[j] = src[j];
+        const uint64_t w = loadU64Unaligned(src + i);
+        if (i + 8 <= n) storeU64Unaligned(dst + i, w);
+        else storeTail(dst + i, w, n - i);
     }
 }
 // The score table in LDS.  Entry [0][0] is forced to 0: the scoring loops below BLANK the columns outside [first, last] (byte 0
@@ -1199,10 +1208,11 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
             const unsigned i = 8u * (unsigned) gl;
             char *dst = outData + o[u];
             if (i + 8 <= L[u]) storeU64Unaligned(dst + i, w[u]);
-            else for (unsigned j = i; j < L[u]; j++) dst[j] = (char) (w[u] >> (8 * (j - i)));
+            else if (i < L[u]) storeTail(dst + i, w[u], L[u] - i);
             for (unsigned p = i + 8u * G; p < L[u]; p += 8u * G) {                       // the rest of a contig
-                if (p + 8 <= L[u]) storeU64Unaligned(dst + p, loadU64Unaligned(src[u] + p));
-                else for (unsigned j = p; j < L[u]; j++) dst[j] = src[u][j];
+                const uint64_t x = loadU64Unaligned(src[u] + p);
+                if (p + 8 <= L[u]) storeU64Unaligned(dst + p, x);
+                else storeTail(dst + p, x, L[u] - p);
             }
             if (gl == 0) {
                 dst[L[u]] = '\n'; dst[L[u] + 1] = '\0';
@@ -1547,7 +1557,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     } else {
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     // wavefronts per SIMD of the register-queue kernels (PLASSHIP_TUNE_ASM16 / ASM64): the grid is what the CUs hold at once
-    const int w16 = tuneInt("ASM16", 6), w64 = tuneInt("ASM64", 4);
+    const int w16 = tuneInt("ASM16", 5), w64 = tuneInt("ASM64", 4);      // round 3 (after the copy tails went word-wise): 16.6 ms at 5 wavefronts, 17.0 at 6, 18.0 at 4
     const dim3 g16(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) w16)), g64(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) w64));
     if (a.nSmall) {
         if (w16 == 6) hipLaunchKernelGGL((assembleGroupKernel<16, 6>), g16, dim3(256), 0, st, a);
