@@ -159,7 +159,7 @@ def source_sha():
 
 
 # rocprofv3 names of the kernels behind a row of the stage table (all instantiations of a template are one row)
-KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShortKernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
+KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShort(Fast)?Kernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
                   "partitionKernel(k-mer records)": "linePartKernel<.*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel"}
 
 

@@ -1112,33 +1112,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     }
 }
 
-// arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
-// ... and the tier of each query that passed the pre-screen, by queue size (<= 16, <= 32, <= 64, more), as flags packed
-// for two 64-bit prefix sums (tierA: tier 0 | tier 1 << 32, tierB: tier 2 | tier 3 << 32); listKernel turns the scanned
-// positions into the work lists of the extension kernels (id order, no atomics)
-__global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const AlnRec *__restrict__ recs, uint32_t *__restrict__ leftCap,
-                                uint64_t *__restrict__ bytes, uint64_t maxSeqLen, int noPrescreen,
-                                uint64_t *__restrict__ tierA, uint64_t *__restrict__ tierB,
-                                const uint32_t *__restrict__ aaLen, uint32_t *__restrict__ aaLeftCap, uint64_t *__restrict__ aaBytes) {
-    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
-        int tier = -1;
-        uint64_t sum = 0, sumAa = 0;
-        bool can = noPrescreen != 0;       // nucleotide hits are mirrored first; the loop decides
-        for (uint64_t i = qoff[id]; i < qoff[id + 1]; i++) {
-            const AlnRec r = recs[i];
-            if (r.target == id) continue;
-            sum += (uint64_t) r.dbLen;
-            sumAa += (uint64_t) r.dbLen / 3 + 2;               // guided: a twin fragment is at most dbLen/3 + 1 residues
+// Pass 1, one thread per ALIGNMENT (a wavefront reads 64 records = 4 KB in a row; one thread per query walking its records was 64
+// lines per load instruction: 9 ms for 226 M records): the alignments of a query are contiguous, so the lanes of a wavefront form
+// segments by query — segmented sums of the target lengths, one atomic per query and wavefront.
+__global__ __launch_bounds__(256) void arenaSumKernel(const AlnRec *__restrict__ recs, uint64_t nAln, uint64_t maxSeqLen, unsigned long long *__restrict__ qSum,
+                                                      unsigned long long *__restrict__ qSumAa, uint32_t *__restrict__ qCan) {
+    const int lane = laneId();
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nAln; i += (uint64_t) gridDim.x * blockDim.x) {
+        const AlnRec r = recs[i];
+        const uint32_t id = r.query;
+        uint32_t add = 0, addAa = 0; bool can = false;
+        if (r.target != id) {
+            add = (uint32_t) r.dbLen; addAa = (uint32_t) r.dbLen / 3 + 2;               // guided: a twin fragment is at most dbLen/3 + 1 residues
             // exact pre-screen: the first extension of a query is decided by coordinates the alignment already
             // carries (selectFragmentToExtend + the two geometry tests, assembleresult.cpp:40-57,211-263); if no
             // alignment can start an extension the greedy loop drains its queue without changing anything.
             const bool notBoth = !(r.dbStart == 0 && r.qStart == 0);
             const bool rightStart = r.dbStart == 0 && (r.dbEnd != r.dbLen - 1);
             const bool leftStart = r.qStart == 0 && (r.qEnd != r.qLen - 1);
-            if (!((rightStart || leftStart) && notBoth)) continue;
-            if (r.dbStart == 0) can |= (r.qEnd == r.qLen - 1) && (r.dbLen - (r.dbEnd + 1) > 0);
-            else if (r.qStart == 0) can |= (r.dbEnd == r.dbLen - 1) && (r.dbStart > 0) && ((uint64_t) r.qLen + (uint64_t) r.dbStart < maxSeqLen);
+            if ((rightStart || leftStart) && notBoth) {
+                if (r.dbStart == 0) can = (r.qEnd == r.qLen - 1) && (r.dbLen - (r.dbEnd + 1) > 0);
+                else if (r.qStart == 0) can = (r.dbEnd == r.dbLen - 1) && (r.dbStart > 0) && ((uint64_t) r.qLen + (uint64_t) r.dbStart < maxSeqLen);
+            }
         }
+        // (the lanes of a wavefront leave the loop together except in its last round, where the active ones are the low lanes)
+        const unsigned long long act = __ballot(1);
+        const uint32_t prevId = (uint32_t) __shfl_up((int) id, 1, 64);
+        const bool head = lane == 0 || prevId != id;
+        const unsigned long long heads = __ballot(head), cans = __ballot(can);
+        const int segStart = 63 - __clzll((long long) (heads & (lane == 63 ? ~0ULL : ((2ULL << lane) - 1ULL))));
+        const unsigned long long later = lane == 63 ? 0ULL : (heads & ~((2ULL << lane) - 1ULL));
+        const int segEnd = (later ? __ffsll((long long) later) - 1 : (int) __popcll(act)) - 1;            // last lane of my segment
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t t = (uint32_t) __shfl_up((int) add, d, 64), ta = (uint32_t) __shfl_up((int) addAa, d, 64);
+            if (lane - d >= segStart) { add += t; addAa += ta; }
+        }
+        if (lane == segEnd) {
+            const unsigned long long seg = (segEnd == 63 ? ~0ULL : ((2ULL << segEnd) - 1ULL)) & ~((1ULL << segStart) - 1ULL);
+            if (add) atomicAdd(&qSum[id], (unsigned long long) add);
+            if (qSumAa && addAa) atomicAdd(&qSumAa[id], (unsigned long long) addAa);
+            if (cans & seg) atomicOr(&qCan[id], 1u);
+        }
+    }
+}
+// arena sizing: query + all targets on either side (a hit is attached at most once, to one side)
+// ... and the tier of each query that passed the pre-screen, by queue size (<= 16, <= 32, <= 64, more), as flags packed
+// for two 64-bit prefix sums (tierA: tier 0 | tier 1 << 32, tierB: tier 2 | tier 3 << 32); listKernel turns the scanned
+// positions into the work lists of the extension kernels (id order, no atomics)
+__global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const unsigned long long *__restrict__ qSum, const unsigned long long *__restrict__ qSumAa,
+                                const uint32_t *__restrict__ qCan, uint32_t *__restrict__ leftCap,
+                                uint64_t *__restrict__ bytes, int noPrescreen,
+                                uint64_t *__restrict__ tierA, uint64_t *__restrict__ tierB,
+                                const uint32_t *__restrict__ aaLen, uint32_t *__restrict__ aaLeftCap, uint64_t *__restrict__ aaBytes) {
+    for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
+        int tier = -1;
+        const uint64_t sum = qSum[id], sumAa = aaBytes ? qSumAa[id] : 0;
+        const bool can = noPrescreen != 0 || qCan[id] != 0;       // nucleotide hits are mirrored first: no pre-screen there
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
         bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 40) : 0;      // slack: the re-scoring loops read up to 32 bytes past the query
         if (aaBytes) { aaLeftCap[id] = (uint32_t) std::min<uint64_t>(sumAa, 0xFFFFFFFFull); aaBytes[id] = (sum && can) ? (2 * sumAa + aaLen[id] + 8) : 0; }
@@ -1463,7 +1493,15 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     if (dBigList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMidList.alloc(((size_t) N + 1) * 4) != hipSuccess || dMid32List.alloc(((size_t) N + 1) * 4) != hipSuccess ||
         dSmallList.alloc(((size_t) N + 1) * 4) != hipSuccess || dTierA.alloc(((size_t) N + 1) * 8) != hipSuccess || dTierB.alloc(((size_t) N + 1) * 8) != hipSuccess ||
         dPosA.alloc(((size_t) N + 2) * 8) != hipSuccess || dPosB.alloc(((size_t) N + 2) * 8) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), al->d_recs.as<AlnRec>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), (uint64_t) par->max_seq_len, nucl ? 1 : 0,
+    DevBuf dQSum, dQSumAa, dQCan;
+    if (dQSum.alloc(((size_t) N + 1) * 8) != hipSuccess || dQCan.alloc(((size_t) N + 1) * 4) != hipSuccess || (guided && dQSumAa.alloc(((size_t) N + 1) * 8) != hipSuccess)) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dQSum.p, 0, ((size_t) N + 1) * 8, st));
+    PH_CHECK(hipMemsetAsync(dQCan.p, 0, ((size_t) N + 1) * 4, st));
+    if (guided) PH_CHECK(hipMemsetAsync(dQSumAa.p, 0, ((size_t) N + 1) * 8, st));
+    if (al->nLines) hipLaunchKernelGGL(arenaSumKernel, dim3((unsigned) std::min<uint64_t>((al->nLines + 255) / 256, (uint64_t) ctx->numCU * 32)), dim3(256), 0, st, al->d_recs.as<AlnRec>(), (uint64_t) al->nLines,
+                                       (uint64_t) par->max_seq_len, dQSum.as<unsigned long long>(), guided ? dQSumAa.as<unsigned long long>() : (unsigned long long *) nullptr, dQCan.as<uint32_t>());
+    if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), (const unsigned long long *) dQSum.as<unsigned long long>(),
+                              (const unsigned long long *) dQSumAa.as<unsigned long long>(), (const uint32_t *) dQCan.as<uint32_t>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), nucl ? 1 : 0,
                               dTierA.as<uint64_t>(), dTierB.as<uint64_t>(),
                               guided ? aaDb->d_len.as<uint32_t>() : (const uint32_t *) nullptr, dAaLeftCap.as<uint32_t>(), guided ? dAaBytes.as<uint64_t>() : (uint64_t *) nullptr);
     if (guided && exclusiveScanU64(st, dAaBytes.as<uint64_t>(), dAaArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
