@@ -29,21 +29,6 @@ def init(backend, rank, world, device=None, timeout_s=None):
     return dist
 
 
-def partition_plan(world, n_buckets=4096):
-    """rank r owns the independent read partition seeded 1+r; k-mer hash bucket b (0..n_buckets-1, the top bits the
-    hash-partition kernel already uses) is owned by rank b % world — the layout of exchange 1 in SURVEY.md §8e."""
-    owner = [b % world for b in range(n_buckets)]
-    return {"seeds": [1 + r for r in range(world)], "bucket_owner": owner}
-
-
-def split_counts(bucket_counts, bucket_owner, world):
-    """per-destination record counts for an all-to-all of bucketed records (send side)"""
-    out = [0] * world
-    for c, o in zip(bucket_counts, bucket_owner):
-        out[o] += int(c)
-    return out
-
-
 def reduce_step(dist, elapsed_s, overlaps, device="cpu"):
     """max over ranks of the step time, sum over ranks of the overlap count (what bench.py reports)"""
     import torch
@@ -54,20 +39,3 @@ def reduce_step(dist, elapsed_s, overlaps, device="cpu"):
     c = torch.tensor([overlaps], dtype=torch.int64, device=device)
     dist.all_reduce(c, op=dist.ReduceOp.SUM)
     return float(t.item()), int(c.item())
-
-
-def exchange_counts(dist, send_counts, device="cpu"):
-    """all-to-all of the per-destination counts: returns what every source will send to this rank"""
-    import torch
-    s = torch.tensor(send_counts, dtype=torch.int64, device=device)
-    r = torch.empty_like(s)
-    dist.all_to_all_single(r, s)
-    return [int(x) for x in r.tolist()]
-
-
-def exchange_records(dist, records, send_counts, recv_counts):
-    """all-to-all(v) of fixed-size records (rows of a 2-D uint8/uint64 tensor), grouped by destination rank"""
-    import torch
-    out = torch.empty((sum(recv_counts),) + tuple(records.shape[1:]), dtype=records.dtype, device=records.device)
-    dist.all_to_all_single(out, records, output_split_sizes=list(recv_counts), input_split_sizes=list(send_counts))
-    return out

@@ -1,5 +1,5 @@
-"""world_size-2 gloo test (CPU) of the multi-rank plumbing bench.py uses: rank partition plan, max/sum step
-reduction, and the count + record all-to-all that the k-mer-bucket exchange is built on."""
+"""world_size-2 gloo tests (CPU) of the multi-rank plumbing: the step reduction bench.py reports with (max of the times, sum of the
+overlaps) and the communicator callbacks of the sharded run (plass_amd/shard.py: TorchComm) against the in-process reference."""
 import os
 import socket
 import sys
@@ -22,28 +22,11 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    import torch
     from plass_amd import dist as pd
     d = pd.init("gloo", rank, world)
-    plan = pd.partition_plan(world, n_buckets=64)
     # step reduction: time = max, overlaps = sum
     t, c = pd.reduce_step(d, 0.010 * (rank + 1), 1000 + rank)
-    # bucketed exchange: every rank holds records tagged (src, bucket, i); after the all-to-all a rank holds exactly the
-    # records of the buckets it owns, from every source
-    rng = np.random.default_rng(100 + rank)
-    counts = rng.integers(0, 50, size=64)
-    recs = []
-    for dst in range(world):
-        for b in range(64):
-            if plan["bucket_owner"][b] == dst:
-                for i in range(int(counts[b])):
-                    recs.append((rank, b, i))
-    recs = torch.tensor(recs, dtype=torch.int64).reshape(-1, 3)
-    send = pd.split_counts(counts, plan["bucket_owner"], world)
-    recv = pd.exchange_counts(d, send)
-    got = pd.exchange_records(d, recs, send, recv)
-    ok = bool((torch.tensor([plan["bucket_owner"][int(b)] for b in got[:, 1]]) == rank).all()) if len(got) else True
-    q.put((rank, t, c, plan["seeds"][rank], send, recv, int(got.shape[0]), ok, [int(x) for x in counts]))
+    q.put((rank, t, c))
     d.barrier()
     d.destroy_process_group()
 
@@ -60,12 +43,8 @@ def test_two_rank_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, t0, c0, s0, send0, recv0, n0, ok0, cnt0), (r1, t1, c1, s1, send1, recv1, n1, ok1, cnt1) = res
+    (r0, t0, c0), (r1, t1, c1) = res
     assert t0 == t1 == pytest.approx(0.020) and c0 == c1 == 2001          # max time, summed overlaps on every rank
-    assert (s0, s1) == (1, 2)                                             # independent partitions, distinct seeds
-    assert recv0 == [send0[0], send1[0]] and recv1 == [send0[1], send1[1]]
-    assert n0 == sum(recv0) and n1 == sum(recv1) and ok0 and ok1
-    assert n0 + n1 == sum(cnt0) + sum(cnt1)                               # nothing lost, nothing duplicated
 
 
 def _comm_worker(rank, world, port, q):
