@@ -1367,15 +1367,12 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
         setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
-    static const int woU = tuneInt("WRITEOUT_U", 1);        // sequences a lane group has in flight; 2 and 4 changed nothing (profiles/r03_ab_knobs.txt): the kernel is not bound by its chains of round trips
     if (N) {
+        // (2 and 4 sequences in flight per lane group changed nothing — profiles/r03_ab_knobs.txt: the kernel is not bound by its chains of round trips)
         const unsigned woGrid = std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16));
-        auto launch = [&](auto kern) {
-            hipLaunchKernelGGL(kern, dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
-                               dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
-                               o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
-        };
-        if (woU == 1) launch(writeOutKernel<8, 1>); else if (woU == 2) launch(writeOutKernel<8, 2>); else launch(writeOutKernel<8, 4>);
+        hipLaunchKernelGGL((writeOutKernel<8, 1>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
+                           dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
+                           o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
     }
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));

@@ -505,6 +505,7 @@ __global__ void packOffLenKernel(const uint64_t *__restrict__ off, const uint32_
 // smaller than 2^40 bytes).  Stream-ordered: the caller's kernels follow on ctx->stream.
 int ensureOffLen(plasship_ctx *ctx, const plasship_seqdb *db) {
     if (db->d_offLen.p || db->n == 0) return PLASSHIP_OK;
+    if (db->maxEntryLen >= (1u << 24) || db->dataBytes >= (1ull << 40)) { setError("a sequence DB with an entry of 2^24 bytes or more, or of 2^40 bytes or more in total, is not supported"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (db->d_offLen.alloc(db->n * 8) != hipSuccess) { setError("out of device memory for the packed offsets of a sequence DB"); return PLASSHIP_ERR_DEVICE; }
     hipLaunchKernelGGL(packOffLenKernel, dim3((unsigned) std::min<uint64_t>((db->n + 255) / 256, (uint64_t) ctx->numCU * 16)), dim3(256), 0, ctx->stream,
                        db->d_off.as<uint64_t>(), db->d_len.as<uint32_t>(), (uint64_t) db->n, db->d_offLen.as<uint64_t>());

@@ -2154,31 +2154,48 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_COPY_SYNC(st, hStart1.data(), dStart1.p, ((size_t) geo.nb1 + 1) * 4, hipMemcpyDeviceToHost);
         PH_CHECK(hipGetLastError());
         const uint64_t myLines = hStart1[geo.nb1];
-        // lines in list order = by bucket = by destination, packed into a send buffer of exactly their size (the slot array is
-        // consumed: it goes first, the receive buffer will need the room)
+        // lines in list order = by bucket = by destination.  The lines of the OTHER ranks' buckets are packed into a send buffer of
+        // exactly their size (the slot array is consumed: it goes first, the receive buffer will need the room); the lines of this
+        // rank's own buckets never pass through it: they are gathered straight into the receive buffer, behind what the others sent
+        // (one pass over them instead of a gather and a device-to-device copy — all of the data in a 1-rank group, 1/W of it otherwise).
+        const uint64_t selfBeg = hStart1[ownedBegin(geo.nb1, rk, W)], selfEnd = hStart1[ownedBegin(geo.nb1, rk + 1, W)];
+        const uint64_t selfLines = selfEnd - selfBeg, sendLines = myLines - selfLines;
+        const uint32_t chunksPerLine = (uint32_t) (RPL * sizeof(R) / 16);
+        auto gather = [&](uint64_t listFrom, uint64_t n, void *dst) {
+            if (n) hipLaunchKernelGGL(gatherLinesKernel, dim3(gridFor(n * chunksPerLine, 256, (unsigned) numCU * 16)), dim3(256), 0, st, (const uint4 *) dB.p, (const uint32_t *) dList1.as<uint32_t>() + listFrom,
+                                      n, chunksPerLine, (uint4 *) dst);
+        };
         dA.release();
-        if (dA.alloc(std::max<uint64_t>(myLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the send buffer"); return PLASSHIP_ERR_DEVICE; }
-        if (myLines) hipLaunchKernelGGL(gatherLinesKernel, dim3(gridFor(myLines * (RPL * sizeof(R) / 16), 256, (unsigned) numCU * 16)), dim3(256), 0, st, (const uint4 *) dB.p, (const uint32_t *) dList1.as<uint32_t>(),
-                                        myLines, (uint32_t) (RPL * sizeof(R) / 16), (uint4 *) dA.p);
-        dB.release(); dTag1.release(); dList1.release();    // (stream order: the gather has read them before anything reuses the memory)
+        if (dA.alloc(std::max<uint64_t>(sendLines, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the send buffer"); return PLASSHIP_ERR_DEVICE; }
+        gather(0, selfBeg, dA.p);
+        gather(selfEnd, myLines - selfEnd, (char *) dA.p + selfBeg * RPL * sizeof(R));
+        dTag1.release();
         // per-bucket line counts of every rank + the records this rank extracted
         std::vector<uint64_t> mine((size_t) geo.nb1 + 1), all(((size_t) geo.nb1 + 1) * (size_t) W);
         for (uint32_t j = 0; j < geo.nb1; j++) mine[j] = hStart1[j + 1] - hStart1[j];
         { unsigned long long ks[4] = {0, 0, 0, 0}; PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost); mine[geo.nb1] = ks[1] + ks[3]; }
         rc = commAllgatherHost(ctx, mine.data(), all.data(), mine.size() * 8); if (rc) return rc;
         std::vector<uint64_t> sendCount(W);
-        for (int r = 0; r < W; r++) { sendCount[r] = hStart1[ownedBegin(geo.nb1, r + 1, W)] - hStart1[ownedBegin(geo.nb1, r, W)]; NkAll += all[(size_t) r * mine.size() + geo.nb1]; }
-        uint64_t gotLines = 0;
-        // (room behind the received lines: the group kernel's arenas are addressed by level-2 line numbers, up to nbL * nb2 beyond)
-        rc = commAlltoallvRecords(ctx, dA.p, sendCount.data(), RPL * sizeof(R), dRx, &gotLines, (uint64_t) nbL * geo.nb2 + 1); if (rc) return rc;
-        res.exchangedRecordBytes = (myLines - sendCount[rk]) * RPL * sizeof(R);
+        for (int r = 0; r < W; r++) { sendCount[r] = (r == rk) ? 0 : hStart1[ownedBegin(geo.nb1, r + 1, W)] - hStart1[ownedBegin(geo.nb1, r, W)]; NkAll += all[(size_t) r * mine.size() + geo.nb1]; }
+        uint64_t gotOthers = 0;
+        // (room behind the received lines: this rank's own lines, and the group kernel's arenas, which are addressed by level-2 line
+        // numbers, up to nbL * nb2 beyond)
+        rc = commAlltoallvRecords(ctx, dA.p, sendCount.data(), RPL * sizeof(R), dRx, &gotOthers, selfLines + (uint64_t) nbL * geo.nb2 + 1); if (rc) return rc;
+        res.exchangedRecordBytes = sendLines * RPL * sizeof(R);
         PH_TRACE(st, "kmermatch: exchange 1 (level-1 lines)");
         dA.release();
+        gather(selfBeg, selfLines, (char *) dRx.p + gotOthers * RPL * sizeof(R));
+        dB.release(); dList1.release();    // (stream order: the gathers have read them before anything reuses the memory)
+        const uint64_t gotLines = gotOthers + selfLines;
         if (gotLines >= 0xFFFFFFFFull) { rc = PLASSHIP_ERR_UNSUPPORTED; setError("kmermatch: more than 2^32 lines on one rank"); }
         rc = commAgreeOk(ctx, rc == 0, "kmermatch: more than 2^32 lines on one rank"); if (rc) return rc;
         // what arrived: from every source s the lines of my buckets bLo .. bHi-1, bucket after bucket.  List: bucket-major, source-minor.
         std::vector<RxSeg> segs((size_t) nbL * W); std::vector<uint32_t> rxStart((size_t) nbL + 1);
-        std::vector<uint64_t> srcBase(W); { uint64_t o = 0; for (int s = 0; s < W; s++) { srcBase[s] = o; for (uint32_t j = bLo; j < bHi; j++) o += all[(size_t) s * mine.size() + j]; } if (o != gotLines) { setError("kmermatch: internal error, exchanged line counts do not add up"); return PLASSHIP_ERR_DEVICE; } }
+        // (in the receive buffer: the other ranks' lines in rank order, then this rank's own)
+        std::vector<uint64_t> srcBase(W); { uint64_t o = 0; auto linesFrom = [&](int s) { uint64_t c = 0; for (uint32_t j = bLo; j < bHi; j++) c += all[(size_t) s * mine.size() + j]; return c; };
+          for (int s = 0; s < W; s++) if (s != rk) { srcBase[s] = o; o += linesFrom(s); }
+          if (o != gotOthers || linesFrom(rk) != selfLines) { setError("kmermatch: internal error, exchanged line counts do not add up"); return PLASSHIP_ERR_DEVICE; }
+          srcBase[rk] = o; }
         { uint64_t d = 0; std::vector<uint64_t> run(srcBase);
           for (uint32_t j = 0; j < nbL; j++) { rxStart[j] = (uint32_t) d; for (int s = 0; s < W; s++) { const uint64_t c = all[(size_t) s * mine.size() + bLo + j]; segs[(size_t) j * W + s] = RxSeg{run[s], (uint32_t) c, (uint32_t) d}; run[s] += c; d += c; } }
           rxStart[nbL] = (uint32_t) d; }

@@ -217,8 +217,7 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
     return r;
 }
 
-// ALL: every candidate pair is this kernel's (G > 1: no list of long overlaps)
-template <int G, int WPE, bool ALL = (G == 1)>
+template <int G, int WPE>
 __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rescoreKernel(RescoreArgs a) {
     __shared__ signed char smat[123 * 128];              // row stride 128: the index of a column is (a << 7) | b
     __shared__ unsigned char sComp[256];                 // reverse-strand hits: complement of a stored letter (getRevFragment's mapping)
@@ -231,7 +230,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
     const int sl = threadIdx.x & (G - 1);
     const uint64_t stride = (uint64_t) gridDim.x * groupsPerBlock;
     unsigned long long accLocal = 0, ovLocal = 0;
-    const uint64_t nWork = ALL ? a.nHits : (uint64_t) *a.longCount;
+    const uint64_t nWork = (G == 1) ? a.nHits : (uint64_t) *a.longCount;
     // G == 1: the candidate of the next round and its sequences' offsets / lengths are requested while the current pair is scored
     // (a pair is a chain of dependent round trips: candidate -> offsets and lengths -> residues; two of them leave the chain)
     struct Meta { uint64_t qOff, tOff; uint32_t qLen, tLen; };
@@ -245,7 +244,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
         if (w + stride < nWork) hitAfter = a.hits[w + stride];
     }
     for (; w < nWork; w += stride) {
-        const uint64_t h = ALL ? w : a.longList[w];
+        const uint64_t h = (G == 1) ? w : a.longList[w];
         CandHit hit; Meta me;
         if (G == 1) {
             hit = hitNext; me = metaNext;
