@@ -169,3 +169,34 @@ def test_rccl_stub_exports_what_the_native_communicator_resolves():
     lib = ctypes.CDLL(stub)
     for name in sorted(wanted):
         assert hasattr(lib, name), "the stub lacks " + name
+
+
+def test_stored_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.py reads `roofline.traffic` from profiles/r03_pmc_traffic.json (two rocprofv3 --pmc passes of the driver's command) and
+    must refuse the file when the product sources differ from the ones recorded in it (a stored figure must not go
+    stale silently)."""
+    import json
+    import bench
+    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    rows = json.load(open(f))
+    assert rows["steps"] > 0 and rows["kernels"] and "--steps 20 --warmup 5" in rows["source"]
+    # the committed file belongs to the committed sources ...
+    assert rows["source_sha"] == bench.source_sha(), "profiles/r03_pmc_traffic.json was not regenerated after the last change of plass_amd/csrc or include/"
+    traffic, note = bench.stored_traffic("extractKernel", 1.0)
+    assert traffic and traffic > 1e9 and "rocprofv3" in note
+    # ... all instantiations of the kernel template are summed (rocprofv3 lists them as separate symbols)
+    per = [r["hbm_bytes_per_launch"] * r["launches"] / rows["steps"] for k, r in rows["kernels"].items() if "extractKernel<" in k]
+    assert len(per) >= 3 and traffic == pytest.approx(sum(per))
+    # ... and any other source hash is refused
+    monkeypatch.setattr(bench, "source_sha", lambda: "0" * 16)
+    traffic, note = bench.stored_traffic("extractKernel", 1.0)
+    assert traffic is None and "other sources" in note
+
+
+def test_committed_headline_digests_are_complete():
+    """tests/golden/c3_chain_digests.json: one digest per output DB of the 12 iterations of the 50 M-read chain (what bench.py's
+    `verify` compares a run with), labelled as self-generated (three implementations agreeing: tests/test_gpu_large.py)"""
+    import json
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_chain_digests.json")))
+    digs = g.get("seq_digests") or g.get("digests")
+    assert digs and len(digs) == 12 and len(set(digs)) == 12 and all(len(d) == 16 for d in digs)
