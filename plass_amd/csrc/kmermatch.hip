@@ -847,9 +847,14 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
             uint32_t lo = 0, hi = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, nOut = 0;
             uint64_t seqHash = 0;
             int lastX = -1;
+            uint32_t wordNext = 0;
+            if (Lw) __builtin_memcpy(&wordNext, base, 4);                                   // the buffer is padded past its end
             for (uint32_t i = 0; i < Lmax; i += 4) {
-                uint32_t word = 0;
-                if (i < Lw) __builtin_memcpy(&word, base + i, 4);                           // the buffer is padded past its end
+                // the four residues of the NEXT step are requested before this step's are used: the load is the head of the step's
+                // chain of dependent round trips (residues -> letter codes in LDS -> tag set in LDS -> store)
+                const uint32_t word = wordNext;
+                wordNext = 0;
+                if (i + 4 < Lw) __builtin_memcpy(&wordNext, base + i + 4, 4);
                 const uint32_t cw = (uint32_t) sMap[word & 0xFFu] | ((uint32_t) sMap[(word >> 8) & 0xFFu] << 8) |
                                     ((uint32_t) sMap[(word >> 16) & 0xFFu] << 16) | ((uint32_t) sMap[word >> 24] << 24);
                 const uint32_t f[4] = {f0, f1, f2, f3};
