@@ -146,6 +146,10 @@ typedef struct plasship_kmermatch_stats {
     uint64_t short_residues, short_records, wave_residues, wave_records;
     float ms_part_scatter;      /* the partScatterKernel launches of the hash partition (sort #1), summed            */
     int32_t n_part_scatter;     /* how many (1 or 2 levels)                                                          */
+    uint32_t n_scratch_sequences; /* sequences whose candidate k-mers did not fit LDS (HBM-scratch launch of the extraction)  */
+    uint32_t n_restarts;        /* 1: the call started over because the extraction's overflow count, checked late, was not 0 */
+    uint32_t n_cached_sequences; /* sequences whose selected windows came from the previous call's cache (same hash seed, bytes unchanged) */
+    uint32_t reserved0;
 } plasship_kmermatch_stats;
 
 int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par,

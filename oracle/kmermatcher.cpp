@@ -52,17 +52,30 @@ static bool cmpKmerLenIdPos(const KPos<T> &a, const KPos<T> &b) {       // kmerm
     if (a.seqLen != b.seqLen) return a.seqLen > b.seqLen;
     if (a.id != b.id) return a.id < b.id;
     if (a.pos != b.pos) return a.pos < b.pos;
-    // reference comparator ties here (only possible for NUCL records that differ in the strand
-    // bit); ips4o's order is unspecified => canonical tie-break: reverse-strand (bit63 = 0) first.
+    // reference comparator ties here (only possible for NUCL records of ONE sequence that differ in nothing but the strand bit:
+    // an inverted repeat whose two copies mirror each other's position); ips4o's order is unspecified => reverse strand (bit63 = 0) first.
     return a.kmer < b.kmer;
 }
+// Sort #2 (kmermatcher.h:98-130, compareRepSequenceAndIdAndDiag[Reverse]) compares (rep | bit 63, target id, diagonal) and nothing else:
+// nucleotide records of one (rep, target, diagonal) triple that differ in the strand bit of the rep field TIE, and the strand
+// writeKmerMatcherResult reports for the pair (kmermatcher.cpp:866-893) is that of the LAST record of the best diagonal's run.  ips4o
+// leaves the members of such a small tied group in the order it found them — the order assignGroup wrote them, i.e. sort-#1 order =
+// ascending k-mer — so the reference's effective rule is "the strand of the triple's member with the LARGEST k-mer" (measured:
+// tests/golden/make_strand_ties.sh — the unmodified reference at --threads 1 and 8 against this file).  Restated as a total order:
+// ties of sort #2 are resolved by the k-mer of the record the grouped record was made from (`ord`), then by the strand bit (forward
+// last) — the latter only decides between two records of one k-mer run that name the same target on the same diagonal with opposite
+// strands (one sequence holding the k-mer and its reverse complement at mirrored positions), where the reference's order follows the
+// positions; the GPU path carries exactly (k-mer, strand), so oracle and product agree everywhere.
+template <typename T> struct Grouped { KPos<T> r; uint64_t ord; };
 template <typename T, bool NUCL>
-static bool cmpRepIdDiag(const KPos<T> &a, const KPos<T> &b) {          // kmermatcher.h:98-130
+static bool cmpRepIdDiag(const Grouped<T> &x, const Grouped<T> &y) {
+    const KPos<T> &a = x.r, &b = y.r;
     uint64_t ak = NUCL ? (a.kmer | BIT63) : a.kmer, bk = NUCL ? (b.kmer | BIT63) : b.kmer;
     if (ak != bk) return ak < bk;
     if (a.id != b.id) return a.id < b.id;
     if (a.pos != b.pos) return a.pos < b.pos;
-    return a.kmer < b.kmer;   // canonical tie-break, see above
+    if (x.ord != y.ord) return x.ord < y.ord;       // protein records never get here with different fields: equal triples are equal records
+    return a.kmer < b.kmer;
 }
 
 static bool canBeCovered(float covThr, int covMode, float q, float t) {  // Util.cpp:533-550
@@ -255,6 +268,7 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
 
     // ---- K5: assignGroup (:450-559), exact in-place emulation -----------------------------------
     size_t writePos = 0;
+    std::vector<uint64_t> ordOf;                    // NUCL: k-mer (| bit 63) of the sort-#1 record each grouped record was made from
     {
         KPos<T> *h = arr.data();
         const size_t splitKmerCount = totalKmersPerSplit;
@@ -297,6 +311,7 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
                         bool canBeExtended = diagonal < 0 || (diagonal > (queryLen - h[i].seqLen));
                         bool cov = canBeCovered(par.covThr, par.covMode, (float) queryLen, (float) h[i].seqLen);
                         if ((!par.includeOnlyExtendable && cov) || (canBeExtended && par.includeOnlyExtendable)) {
+                            if (NUCL) ordOf.push_back(kmer);
                             h[writePos].kmer = rId; h[writePos].pos = (T) diagonal;
                             h[writePos].seqLen = h[i].seqLen; h[writePos].id = h[i].id;
                             writePos++;
@@ -321,7 +336,27 @@ static DB kmermatcherT(const DB &seqDb, const Params &par, KmerStats *stats) {
     if (stats) stats->nGrouped = writePos;
 
     // ---- K6: sort #2 (:427-431) ------------------------------------------------------------------
-    sortRecords(arr.begin(), arr.begin() + (ptrdiff_t) writePos, cmpRepIdDiag<T, NUCL>, nThr);
+    {
+        std::vector<Grouped<T>> g(writePos);
+        for (size_t i = 0; i < writePos; i++) { g[i].r = arr[i]; g[i].ord = (NUCL && !par.debugOldStrandTies) ? ordOf[i] : 0; }
+        ordOf = std::vector<uint64_t>();
+        sortRecords(g.begin(), g.end(), cmpRepIdDiag<T, NUCL>, nThr);
+        for (size_t i = 0; i < writePos; i++) arr[i] = g[i].r;
+        if (NUCL && stats) {     // how often the tie-break above decides anything
+            size_t triples = 0, pairs = 0;
+            for (size_t i = 0; i < writePos;) {
+                size_t j = i; bool pairMixed = false;
+                while (j < writePos && (arr[j].kmer | BIT63) == (arr[i].kmer | BIT63) && arr[j].id == arr[i].id) {
+                    size_t e = j; bool fwd = false, rev = false;
+                    while (e < writePos && (arr[e].kmer | BIT63) == (arr[j].kmer | BIT63) && arr[e].id == arr[j].id && arr[e].pos == arr[j].pos) { ((arr[e].kmer & BIT63) ? fwd : rev) = true; e++; }
+                    if (fwd && rev) { triples++; pairMixed = true; }
+                    j = e;
+                }
+                pairs += pairMixed; i = j;
+            }
+            stats->nStrandTieTriples = triples; stats->nStrandTiePairs = pairs;
+        }
+    }
 
     // ---- K7/K8: writeKmerMatcherResult, threads = 1 (:809-924) -------------------------------------
     DB out; out.dbtype = NUCL ? DBTYPE_PREFILTER_REV_RES : DBTYPE_PREFILTER_RES;

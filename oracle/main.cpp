@@ -85,6 +85,7 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
             else if (a == "--add-orf-stop") orfPar.addOrfStop = atoi(v.c_str()) != 0;
             else if (a == "--threads") par.threads = std::max(1, atoi(v.c_str()));
             else if (a == "--oracle-no-stale-scan") par.debugNoStaleScan = atoi(v.c_str()) != 0;
+            else if (a == "--oracle-old-strand-ties") par.debugOldStrandTies = atoi(v.c_str()) != 0;
             else if (a == "--gap-open") { if (multiParam(v, "nucl", t)) par.gapOpenNucl = atoi(t.c_str()); }
             else if (a == "--gap-extend") { if (multiParam(v, "nucl", t)) par.gapExtendNucl = atoi(t.c_str()); }
             else { /* accepted and ignored: --sub-mat --threads -v --compressed --mask … */ }
@@ -170,6 +171,7 @@ int main(int argc, char **argv) {
         double t0 = now(); KmerStats st;
         DB pref = kmermatcher(seq, par, &st);
         double t1 = now();
+        if (st.nStrandTieTriples) fprintf(stderr, "oracle kmermatcher: %zu (rep, target, diagonal) triples in %zu pairs hold both strands (sort-#2 ties)\n", st.nStrandTieTriples, st.nStrandTiePairs);
         fprintf(stderr, "oracle kmermatcher: %zu seqs, N_k=%zu N_m=%zu N_c=%zu, %.3f s\n", seq.size(), st.nKmerRecords, st.nGrouped, st.nCandidates, t1 - t0);
         if (!writeDB(pos[1], pref, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else if (mod == "rescorediagonal") {

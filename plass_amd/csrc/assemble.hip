@@ -1205,7 +1205,8 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
                                                       const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
                                                       const uint64_t *__restrict__ outOff, const uint32_t *__restrict__ keep,
                                                       const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
-                                                      char *__restrict__ outData, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey) {
+                                                      char *__restrict__ outData, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey,
+                                                      unsigned char *__restrict__ changedOut) {
     // G lanes per sequence, 8 bytes per lane and step: 8 lanes take a read fragment (~46 residues) in one step with most lanes busy,
     // eight sequences per wavefront; contigs take a few steps of contiguous 64-byte pieces.  A sequence is a chain of dependent
     // round trips (what to copy -> the bytes -> the store) and the kernel is bound by the number of chains in flight (round 3: the
@@ -1248,6 +1249,7 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
                 dst[L[u]] = '\n'; dst[L[u] + 1] = '\0';
                 const uint64_t j = keepPos[id];
                 outOffArr[j] = o[u]; outLen[j] = L[u]; outKey[j] = inKey[id];
+                if (changedOut) changedOut[j] = (flags[id] & 0x20u) ? 1 : 0;       // (only when nothing is dropped: j == id)
             }
         }
     }
@@ -1367,12 +1369,17 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
         setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
+    // lineage for kmermatcher's selected-window cache: same ids as `db`, the extended / cut entries marked
+    if (outN == N && N) {
+        if (o->d_changed.alloc((size_t) N) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        o->parentGen = db->gen;
+    }
     if (N) {
         // (2 and 4 sequences in flight per lane group changed nothing — profiles/r03_ab_knobs.txt: the kernel is not bound by its chains of round trips)
         const unsigned woGrid = std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16));
         hipLaunchKernelGGL((writeOutKernel<8, 1>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
                            dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
-                           o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
+                           o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
     }
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));

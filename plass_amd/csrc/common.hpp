@@ -130,10 +130,23 @@ struct plasship_ctx {
     bool hasComm = false;
     plasship_comm comm = {};
     int debugFailCollective = -1;       // plasship_ctx_debug_fail_collective: countdown to an injected rank-local failure
+    // kmermatcher's selected-window cache (kmermatch.hip section 2c): per sequence one 128-byte line {identity-record hash, the positions
+    // of the <= 60 selected k-mers} of the LAST plasship_kmermatch call on this context; the next call re-uses the line of every
+    // sequence its DB inherited unchanged from that call's DB when the selection parameters (hash seed included) are the same
+    struct KmCache {
+        plasship::DevBuf lines; uint64_t n = 0, gen = 0; bool valid = false;
+        int k = 0, alph = 0, kps = 0, ignoreMulti = 0, hashShift = 0;
+    } kmCache;
 };
 
+namespace plasship { uint64_t newDbGeneration(); }      // core.hip: a process-wide counter; every sequence DB handle gets its own number
 struct plasship_seqdb {
     int dbtype = 0;
+    // Lineage (kmermatch.hip, the selected-window cache): `gen` names this handle; a DB that buildOutputDB derived from another one
+    // WITHOUT dropping entries (same ids, same keys) names it in `parentGen` and marks in d_changed (one byte per id) the entries whose
+    // bytes differ from the parent's.  0 = no such parent (read from disk, generated, concatenated, entries dropped).
+    uint64_t gen = plasship::newDbGeneration(), parentGen = 0;
+    plasship::DevBuf d_changed;
     size_t n = 0;
     uint64_t dataBytes = 0, residues = 0;
     uint32_t maxEntryLen = 0;

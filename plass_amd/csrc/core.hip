@@ -221,6 +221,8 @@ extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
     return PLASSHIP_OK;
 }
 
+uint64_t plasship::newDbGeneration() { static std::atomic<uint64_t> g(0); return ++g; }
+
 extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);

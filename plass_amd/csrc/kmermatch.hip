@@ -72,6 +72,7 @@ __global__ void boundsKernel(const uint32_t *__restrict__ len, uint32_t n, int k
 // 2. extraction + selection, one wavefront (= one 64-thread block) per sequence
 // =====================================================================================================
 struct Cand { uint64_t kmer; uint32_t pos; uint32_t score; };   // score: low 16 bits hash, bit 31 = skipped
+constexpr uint32_t KMC_LINE = 128, KMC_POS = 60;                // selected-window cache (section 2c): bytes per sequence, positions per line
 
 struct ExtractArgs {
     SeqView s;
@@ -91,6 +92,9 @@ struct ExtractArgs {
     uint64_t slotBias;              // subtracted from every slot offset (re-extraction of one sequence into a scratch array;
                                     // sharded run: first slot of this rank's id range)
     uint32_t idLo, idHi;            // regular launch without a wave list: ids [idLo, idHi) (sharded run: this rank's share)
+    unsigned char *cacheLines;      // selected-window cache (section 2c): line id * 128 is rewritten for every sequence a wave kernel handles; nullptr = no cache
+    int fillOnOverflow;             // last tier: a sequence handed to the HBM-scratch launch leaves its slots as sentinels (the host may learn of
+                                    // the hand-over only after the partition has read the array: kmermatchImpl, `overflowPossible`)
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -316,8 +320,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
         const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));   // kmermatcher.cpp:223
         const bool allCand = (size_t) nWin <= consideredRaw;
+        auto fillSentinels = [&]() { if (a.fillOnOverflow) for (uint32_t i = lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; } };
         if (!FALLBACK && std::min((size_t) nWin, consideredRaw) > (size_t) cap) {       // cannot fit this instantiation's LDS: next tier
             if (lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
+            fillSentinels();
             continue;
         }
 
@@ -537,6 +543,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         }      // three-pass path
         if (overflow) {
             if (!FALLBACK && lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
+            if (!FALLBACK) fillSentinels();
             __syncthreads();
             continue;
         }
@@ -583,6 +590,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 arr[slot] = r;
             }
             for (uint32_t i = 1 + C + lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; }
+            if (!LONG && a.cacheLines) {       // the selected windows (C <= 59 here: no surplus) and the identity hash, for the next call with this seed
+                unsigned short *ln = reinterpret_cast<unsigned short *>(a.cacheLines + (size_t) id * KMC_LINE);
+                if ((uint32_t) lane < KMC_POS) ln[4 + lane] = ((uint32_t) lane < C) ? (unsigned short) cand[lane].pos : (unsigned short) 0xFFFFu;
+                if (lane == 0) *reinterpret_cast<unsigned long long *>(ln) = xxh64U64(seqHash, a.seed);
+            }
             stRes += L; stRec += 1 + C;
             __syncthreads();
             continue;
@@ -621,6 +633,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         }
         // ---- selection walk (kmermatcher.cpp:274-347) as prefix counts over the sorted candidates ----
         uint32_t binCarry = 0, selCarry = 0;
+        unsigned short *cacheLn = (!LONG && a.cacheLines) ? reinterpret_cast<unsigned short *>(a.cacheLines + (size_t) id * KMC_LINE) : nullptr;
         for (uint32_t c0 = 0; c0 < C; c0 += 64) {
             const uint32_t i = c0 + lane;
             Cand cd; cd.kmer = 0; cd.pos = 0; cd.score = 0x80000000u;
@@ -637,10 +650,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 R r; r.kmer = cd.kmer; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) cd.pos;
                 if constexpr (LONG) r.pad = 0;
                 arr[slot + 1 + selRank] = r;
+                if (cacheLn && selRank < KMC_POS) cacheLn[4 + selRank] = (unsigned short) cd.pos;
             }
             binCarry += (uint32_t) __popcll(mb); selCarry += (uint32_t) __popcll(ms);
         }
         const uint32_t numSel = (uint32_t) min((size_t) selCarry, considered);
+        if (cacheLn) {
+            if ((uint32_t) lane < KMC_POS && (uint32_t) lane >= numSel) cacheLn[4 + lane] = (unsigned short) 0xFFFFu;
+            if (lane == 0) *reinterpret_cast<unsigned long long *>(cacheLn) = xxh64U64(seqHash, a.seed);
+        }
         if (lane == 0) {   // identity record (kmermatcher.cpp:241-249)
             R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
             if constexpr (LONG) r.pad = 0;
@@ -677,6 +695,8 @@ struct ShortArgs {
     uint32_t *hugeList, *hugeCount; uint32_t hugeWindows;   //     and those with more than hugeWindows to this one (nullptr: no such list)
     unsigned long long *kstats;          // [0] residues, [1] records handled by this kernel
     uint32_t idLo, idHi; uint64_t slotBias;   // ids [idLo, idHi) (sharded run: this rank's share), records at arr[slotOff[id] - slotBias]
+    const unsigned char *changed; uint32_t *cachedList, *cachedCount;   // selected-window cache (section 2c): a sequence that is too long for this
+                                              // kernel and whose bytes are those of the last call's DB goes to this list, not to the wave kernels'
 };
 
 template <bool LONG>
@@ -695,12 +715,12 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
     for (uint32_t b0 = a.idLo + blockIdx.x * 64; b0 < a.idHi; b0 += gridDim.x * 64) {
         const uint32_t id = b0 + lane;
         const bool active = id < a.idHi;
-        bool toWave = false;
+        bool toWave = false, lenWave = false;
         if (active) {
             const uint32_t L = a.s.len[id];
             const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
             const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));
-            if (L > SHORT_MAXL || (size_t) nWin > consideredRaw) toWave = true;
+            if (L > SHORT_MAXL || (size_t) nWin > consideredRaw) toWave = lenWave = true;
             else {
                 const char *base = a.s.data + a.s.off[id];
                 const uint64_t slot = a.slotOff[id] - a.slotBias;
@@ -763,6 +783,9 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
         }
         // the queued sequences, one atomic per wavefront and list (the wave kernels' tiers are fed from these lists directly: a
         // queue filled one sequence at a time — one atomic on one counter per sequence — costs more than the tier it feeds)
+        // (too long for this kernel by its LENGTH and unchanged since the last call: the cached kernel takes it, section 2c)
+        const bool isCached = lenWave && a.cachedList && a.changed[id] == 0;
+        if (isCached) toWave = false;
         const uint32_t nw = (toWave && active && a.s.len[id] >= (uint32_t) k) ? a.s.len[id] - (uint32_t) k + 1 : 0u;
         const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
         const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
@@ -777,6 +800,7 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
         append(toWave && !isLong && !isHuge, a.waveList, a.waveCount);
         if (a.longList) append(isLong, a.longList, a.longCount);
         if (a.hugeList) append(isHuge, a.hugeList, a.hugeCount);
+        if (a.cachedList) append(isCached, a.cachedList, a.cachedCount);
     }
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
@@ -823,7 +847,7 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
     for (uint32_t b0 = a.idLo + blockIdx.x * 64; b0 < a.idHi; b0 += gridDim.x * 64) {
         const uint32_t id = b0 + lane;
         const bool active = id < a.idHi;
-        bool toWave = false;
+        bool toWave = false, lenWave = false;
         uint32_t L = 0;
         if (active) {
             L = a.s.len[id];
@@ -831,7 +855,7 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
             const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));
             // (more than 48 windows would overfill the 64-slot tag set: the kernel above hands such a sequence over at its 49th
             // record, here it goes at once — the wave kernel's records are the same either way)
-            if (L > SHORT_MAXL || (size_t) nWin > consideredRaw || (multi && nWin > 48)) toWave = true;
+            if (L > SHORT_MAXL || (size_t) nWin > consideredRaw || (multi && nWin > 48)) toWave = lenWave = true;
         }
         const bool work = active && !toWave;
         const uint32_t Lmax = (uint32_t) __builtin_amdgcn_readfirstlane((int) waveMaxU32(work ? L : 0u));
@@ -906,6 +930,8 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
                 stRes += L; stRec += 1 + nOut;
             }
         }
+        const bool isCached = lenWave && a.cachedList && a.changed[id] == 0;      // (section 2c)
+        if (isCached) toWave = false;
         const uint32_t nw = (toWave && active && L >= (uint32_t) K) ? L - (uint32_t) K + 1 : 0u;
         const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
         const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
@@ -920,9 +946,63 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
         append(toWave && !isLong && !isHuge, a.waveList, a.waveCount);
         if (a.longList) append(isLong, a.longList, a.longCount);
         if (a.hugeList) append(isHuge, a.hugeList, a.hugeCount);
+        if (a.cachedList) append(isCached, a.cachedList, a.cachedCount);
     }
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
+}
+
+// =====================================================================================================
+// 2c. the selected-window cache.  Plass changes the hash seed every other iteration (Assembler.cpp:99-110: hashShift += i % 2), and
+//     an iteration extends 10-20 % of the sequences: in iterations 2, 4, 6, ... most sequences are byte for byte what they were when
+//     kmermatcher last hashed them with this very seed, so the windows it selects are the same.  The wave-per-sequence kernels
+//     therefore leave, per sequence, one 128-byte line {identity-record hash, positions of the <= 59 selected windows (0xFFFF = none)};
+//     the next call with the same selection parameters sends every sequence its DB inherited UNCHANGED (plasship_seqdb::parentGen /
+//     d_changed) here instead: the k-mers at the cached positions are rebuilt from the sequence's bytes and the records written — no
+//     window is hashed, nothing is selected.  Protein DBs with --kmer-per-seq <= 60 and no length scaling (the Plass workflow) only:
+//     that is where a line holds every selected window.  The record set is exactly what the full kernels write (tests: the chained
+//     iterations of every protein parity test pass through here; PLASSHIP_TUNE_KMCACHE=0 switches it off).
+// =====================================================================================================
+struct CachedArgs {
+    SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map; const unsigned char *lines;
+    const uint32_t *list, *count; int k, xCode; uint32_t base, base7; uint64_t slotBias; unsigned long long *kstats;
+};
+__global__ __launch_bounds__(64) void extractCachedKernel(CachedArgs a) {
+    __shared__ unsigned char sMap[256];
+    typedef Rec<false> R;
+    R *arr = reinterpret_cast<R *>(a.arr);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
+    __syncthreads();
+    const uint32_t nWork = *a.count;
+    unsigned long long stRes = 0, stRec = 0;
+    uint32_t idNext = blockIdx.x < nWork ? a.list[blockIdx.x] : 0u;
+    for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
+        const uint32_t id = idNext;
+        if (w + gridDim.x < nWork) idNext = a.list[w + gridDim.x];
+        const uint32_t L = a.s.len[id];
+        const char *base = a.s.data + a.s.off[id];
+        const uint64_t slot = a.slotOff[id] - a.slotBias;
+        const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
+        const unsigned short *ln = reinterpret_cast<const unsigned short *>(a.lines + (size_t) id * KMC_LINE);
+        const uint32_t pos = ((uint32_t) lane < KMC_POS) ? (uint32_t) ln[4 + lane] : 0xFFFFu;
+        const bool have = pos != 0xFFFFu;
+        const uint32_t n = (uint32_t) __popcll(__ballot(have));          // the positions fill the line from its front
+        if (have) {
+            // the 14 residues of the window (the entry is "SEQ\n\0": 16 bytes from pos <= L - 14 stay inside it), mapped to letter codes
+            uint64_t r0, r1; __builtin_memcpy(&r0, base + pos, 8); __builtin_memcpy(&r1, base + pos + 8, 8);
+            uint64_t w0 = 0, w1 = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) { w0 |= (uint64_t) sMap[(r0 >> (8 * b)) & 0xFF] << (8 * b); w1 |= (uint64_t) sMap[(r1 >> (8 * b)) & 0xFF] << (8 * b); }
+            uint64_t kmer; (void) kmerIndexCore(w0, w1, a.k, (unsigned) a.xCode, a.base, a.base7, kmer);
+            R r; r.kmer = kmer; r.id = id; r.len = (uint16_t) L; r.pos = (int16_t) pos;
+            arr[slot + 1 + (uint32_t) lane] = r;
+        }
+        if (lane == 63) { R r; r.kmer = *reinterpret_cast<const unsigned long long *>(ln); r.id = id; r.len = (uint16_t) L; r.pos = 0; arr[slot] = r; }     // identity record (kmermatcher.cpp:241-249)
+        for (uint32_t i = 1 + n + (uint32_t) lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; }
+        stRes += L; stRec += 1 + n;
+    }
+    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
 }
 
 __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
@@ -1071,6 +1151,25 @@ __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q
     }
 }
 
+// Nucleotide strand ties of sort #2 (kmermatcher.h:98-130 compares rep, target and diagonal only; kmermatcher.cpp:866-893 reports the
+// strand of the LAST record of the best diagonal's run): the reference's ips4o leaves the records of one (rep, target, diagonal) triple
+// in the order assignGroup wrote them — sort-#1 order, ascending k-mer — so the strand that counts is that of the member with the
+// LARGEST k-mer (tests/golden/make_strand_ties.py measures it against the unmodified reference).  A grouped nucleotide record
+// therefore carries the k-mer it was made from in its spare bits: bits 32..62 of the rep field (the rep id needs 32, bit 63 is the
+// strand) hold the k-mer's low 31 bits, the length field — which nothing reads after assignGroup — the rest (16 bits in the 16-byte
+// layout: k <= 23; plasship_kmermatch moves a longer k to the 24-byte layout).  The aggregation keeps, per triple, the strand of the
+// largest (k-mer, strand) word (aggSortKernel).
+template <bool LONG> __device__ __forceinline__ void embedOrd(Rec<LONG> &o, uint64_t memberKmerField) {
+    const uint64_t K = memberKmerField & ~BIT63;
+    o.kmer |= (K & 0x7FFFFFFFull) << 32;
+    o.len = (decltype(o.len)) (K >> 31);
+}
+// (k-mer << 1 | forward strand) of a grouped nucleotide record: what the members of a triple are ranked by
+template <bool LONG> __device__ __forceinline__ unsigned long long ordWordOf(const Rec<LONG> &r) {
+    const uint64_t K = ((r.kmer >> 32) & 0x7FFFFFFFull) | ((uint64_t) (LONG ? (uint32_t) r.len : (uint32_t) (uint16_t) r.len) << 31);
+    return (K << 1) | (r.kmer >> 63);
+}
+
 template <bool NUCL, bool LONG, bool LINES>
 __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
     __shared__ unsigned long long hKey[GR_HT];
@@ -1174,6 +1273,7 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
                                 const bool cov = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) mLen);
                                 keep = (!a.includeOnlyExtendable && cov) || (canBeExtended && a.includeOnlyExtendable);
                                 o.kmer = rId; o.id = r.id; o.len = r.len; o.pos = (decltype(o.pos)) diagonal;
+                                if (NUCL) embedOrd(o, r.kmer);
                                 if (keep) maxRT = max(maxRT, (unsigned long long) (((rId & ~BIT63) << 32) | (unsigned long long) r.id));
                             }
                         }
@@ -1319,6 +1419,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                         const bool cov = canBeCoveredK(a.covThr, a.covMode, (float) queryLen, (float) mLen);
                         keep = (!a.includeOnlyExtendable && cov) || (canBeExtended && a.includeOnlyExtendable);
                         o.kmer = rId; o.id = r.id; o.len = r.len; o.pos = (int16_t) diagonal;
+                        if (NUCL) embedOrd(o, r.kmer);
                         if (keep) maxRT = max(maxRT, (unsigned long long) (((rId & ~BIT63) << 32) | (unsigned long long) r.id));
                     }
                 }
@@ -1384,28 +1485,39 @@ constexpr uint32_t AGG_CAP = 1024;          // records per bucket handled in LDS
 constexpr uint32_t AGG_HT = 2048;           // hash slots
 constexpr uint32_t AGG_NEEDS_SCRATCH = 0xFFFFFFFFu;   // uniqueCount of a bucket pass 1 left to the chunked pass
 template <bool LONG> struct DiagPack { static constexpr int BITS = LONG ? 22 : 16; static constexpr int64_t BIAS = LONG ? (1 << 21) : 32768; };
-struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag; uint32_t cnt; };   // cnt bit 31: some record of the run is forward-strand
+struct __attribute__((aligned(16))) Triple { uint32_t rep, target; int32_t diag; uint32_t cnt; };   // cnt bit 31 (nucleotides): the run's member with the largest k-mer is forward-strand
+// sharded nucleotide run, exchange 2: a triple some rank aggregated from ITS k-mer buckets, with the (k-mer << 1 | strand) word of its
+// top-ranked member — the owner merges the ranks' partial triples and needs it to name the strand of the whole triple.  Laid out
+// like Rec<true> (24 bytes: the line store moves it as such; the first 8 bytes are rep | target << 32 like a Triple's).
+struct __attribute__((aligned(8))) TripleX { uint32_t rep, target; int32_t diag; uint32_t cnt; uint64_t ord; };
+static_assert(sizeof(TripleX) == sizeof(Rec<true>) && sizeof(Triple) == sizeof(Rec<false>), "triples travel through the line store as records");
 
 // LINES: bucket b = the lines list[lineBeg[b] .. + lineCnt[b]) of `arr` (linepart.hpp); its triples go to outTriples[lineBeg[b] * RPL ...]
 struct AggLines { const uint32_t *list, *lineBeg, *lineCnt; };
 __device__ __forceinline__ bool isSentinel(const Triple &t) { return t.rep == 0xFFFFFFFFu && t.target == 0xFFFFFFFFu; }   // a padding slot of a line of triples
-// TRIPLES (sharded run, owner side): the input elements are weighted triples other ranks aggregated from THEIR k-mer buckets (16 bytes,
-// lines of RPL like the 16-byte records); equal (rep, target, diagonal) triples of several ranks merge here, counts add, strand flags OR.
+__device__ __forceinline__ bool isSentinel(const TripleX &t) { return t.rep == 0xFFFFFFFFu && t.target == 0xFFFFFFFFu; }
+// TRIPLES (sharded run, owner side): the input elements are weighted triples other ranks aggregated from THEIR k-mer buckets (Triple;
+// TripleX for nucleotides); equal (rep, target, diagonal) triples of several ranks merge here: counts add, the larger (k-mer, strand) word wins.
+// ORDOUT (sharded nucleotide run, every rank's own rep sort): the output elements are TripleX.
 // A representative is keyed by (rep - repBase) [bit-reversed over scrambleBits when != 0] relative to its bucket's first key.
-template <bool NUCL, bool LONG, bool LINES, bool TRIPLES = false>
+template <bool NUCL, bool LONG, bool LINES, bool TRIPLES = false, bool ORDOUT = false>
 __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void *outTriples, const uint64_t *__restrict__ bucketStart, uint32_t nBuckets,
                                                           unsigned long long *bigScratch, const uint64_t *__restrict__ bigOff,
                                                           uint32_t *__restrict__ uniqueCount, int localBits, int idBits, uint64_t repBase, AggLines ln, int scrambleBits) {
-    typedef typename std::conditional<TRIPLES, Triple, Rec<LONG>>::type R;
+    static_assert(!ORDOUT || NUCL, "only nucleotide triples carry a strand");
+    typedef typename std::conditional<TRIPLES, typename std::conditional<NUCL, TripleX, Triple>::type, Rec<LONG>>::type R;
+    typedef typename std::conditional<ORDOUT, TripleX, Triple>::type O;
     __shared__ unsigned long long hKey[AGG_HT];
     __shared__ uint32_t hVal[AGG_HT];
+    __shared__ unsigned long long hOrd[NUCL ? AGG_HT : 1];       // (k-mer << 1 | forward) of the slot's top-ranked member
     __shared__ unsigned long long lKey[AGG_CAP];
     __shared__ uint32_t lVal[AGG_CAP];
+    __shared__ unsigned long long lOrd[NUCL ? AGG_CAP : 1];
     __shared__ uint32_t sCount;
     __shared__ uint32_t sDistinct, sOver;
     __shared__ uint32_t sWave[LS_BLOCK / 64];
     const R *g = reinterpret_cast<const R *>(arr);
-    Triple *out = reinterpret_cast<Triple *>(outTriples);
+    O *out = reinterpret_cast<O *>(outTriples);
     constexpr int DB = DiagPack<LONG>::BITS;
     for (uint32_t b = blockIdx.x; b < nBuckets; b += gridDim.x) {
         // cnt record positions; LINES: positions in the bucket's line list, padding sentinels are skipped when read
@@ -1415,51 +1527,57 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
         auto recAt = [&](uint64_t i) -> R { if (LINES) return g[(uint64_t) ln.list[lb + (uint32_t) (i / RPL)] * RPL + (i % RPL)]; return g[s0 + i]; };
         if (cnt == 0) { if (threadIdx.x == 0) uniqueCount[b] = 0; continue; }
         const uint64_t bucketBase = (uint64_t) b << localBits;             // first (relative, possibly bit-reversed) rep key of the bucket
-        auto decode = [&](unsigned long long key, uint32_t val) {
-            Triple t;
+        auto decode = [&](unsigned long long key, uint32_t val, unsigned long long ord) {
+            O t;
             t.diag = (int32_t) ((int64_t) (key & ((1ULL << DB) - 1)) - DiagPack<LONG>::BIAS);
             const uint64_t k2 = key >> DB;
             t.target = (uint32_t) (k2 & ((1ULL << idBits) - 1));
             const uint64_t rp = (k2 >> idBits) + bucketBase;
             t.rep = (uint32_t) ((scrambleBits ? scrambleRep(rp, scrambleBits) : rp) + repBase);       // an involution: back to the id
             t.cnt = val;
+            if constexpr (ORDOUT) t.ord = ord;
             return t;
         };
-        auto packRec = [&](const R &r, uint32_t &val) {
-            uint64_t rep, target; int64_t diag;
-            if constexpr (TRIPLES) { rep = r.rep; target = r.target; diag = r.diag; val = r.cnt; }
-            else { rep = r.kmer & ~BIT63; target = r.id; diag = r.pos; val = 1u | ((NUCL && (r.kmer & BIT63)) ? 0x80000000u : 0u); }
+        // packed sort key, count and (nucleotides) rank word of one input element
+        auto packRec = [&](const R &r, uint32_t &val, unsigned long long &ord) {
+            uint64_t rep, target; int64_t diag; ord = 0;
+            if constexpr (TRIPLES) { rep = r.rep; target = r.target; diag = r.diag; val = r.cnt & 0x7FFFFFFFu; if constexpr (NUCL) ord = r.ord; }
+            else { rep = (uint32_t) r.kmer; target = r.id; diag = r.pos; val = 1u; if constexpr (NUCL) ord = ordWordOf(r); }     // (nucleotides: bits 32..62 of the rep field hold k-mer bits, embedOrd)
             rep -= repBase;                                                    // repBase: first rep of this rank's range (sharded run, owner side), else 0
             if (scrambleBits) rep = scrambleRep(rep, scrambleBits);            // buckets are ranges of the bit-reversed id (linepart.hpp)
             return (unsigned long long) (((((rep - bucketBase) << idBits) | target) << DB) | (uint64_t) (diag + DiagPack<LONG>::BIAS));
         };
         auto clearTable = [&]() {
-            for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) { hKey[i] = ~0ULL; hVal[i] = 0; }
+            for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) { hKey[i] = ~0ULL; hVal[i] = 0; if (NUCL) hOrd[i] = 0; }
             if (threadIdx.x == 0) sCount = 0;
             __syncthreads();
         };
-        auto insert = [&](unsigned long long key, uint32_t val) {      // count adds, strand flag ORs
+        auto insert = [&](unsigned long long key, uint32_t val, unsigned long long ord) {      // counts add, the larger rank word wins
             uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 40) & (AGG_HT - 1);
             for (;;) {
                 const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, key);
                 if (prev == ~0ULL || prev == key) break;
                 slot = (slot + 1) & (AGG_HT - 1);
             }
-            atomicAdd(&hVal[slot], val & 0x7FFFFFFFu);
-            if (val & 0x80000000u) atomicOr(&hVal[slot], 0x80000000u);
+            atomicAdd(&hVal[slot], val);
+            if (NUCL) atomicMax(&hOrd[slot], ord);
         };
-        // table -> lKey/lVal (unordered); returns the number of distinct keys (block-uniform)
+        // table -> lKey/lVal/lOrd (unordered); returns the number of distinct keys (block-uniform).  lVal: count | strand of the top-ranked member << 31
         auto extract = [&]() {
             for (uint32_t i = threadIdx.x; i < AGG_HT; i += LS_BLOCK) {
                 const unsigned long long k = hKey[i];
-                if (k != ~0ULL) { const uint32_t o = atomicAdd(&sCount, 1u); lKey[o] = k; lVal[o] = hVal[i]; }
+                if (k != ~0ULL) {
+                    const uint32_t o = atomicAdd(&sCount, 1u); lKey[o] = k;
+                    if (NUCL) { const unsigned long long od = hOrd[i]; lOrd[o] = od; lVal[o] = hVal[i] | ((uint32_t) (od & 1ULL) << 31); }
+                    else lVal[o] = hVal[i];
+                }
             }
             __syncthreads();
             return sCount;
         };
         auto sortListAndWrite = [&](uint32_t U) {
             uint32_t P = 1; while (P < U) P <<= 1;
-            for (uint32_t i = U + threadIdx.x; i < P; i += LS_BLOCK) { lKey[i] = ~0ULL; lVal[i] = 0; }
+            for (uint32_t i = U + threadIdx.x; i < P; i += LS_BLOCK) { lKey[i] = ~0ULL; lVal[i] = 0; if (ORDOUT) lOrd[i] = 0; }
             __syncthreads();
             for (uint32_t kk = 2; kk <= P; kk <<= 1) {
                 for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
@@ -1468,12 +1586,15 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
                         const uint32_t l = i | j;
                         const unsigned long long x = lKey[i], y = lKey[l];
                         const bool up = (i & kk) == 0;
-                        if ((x > y) == up) { lKey[i] = y; lKey[l] = x; const uint32_t vx = lVal[i]; lVal[i] = lVal[l]; lVal[l] = vx; }
+                        if ((x > y) == up) {
+                            lKey[i] = y; lKey[l] = x; const uint32_t vx = lVal[i]; lVal[i] = lVal[l]; lVal[l] = vx;
+                            if (ORDOUT) { const unsigned long long ox = lOrd[i]; lOrd[i] = lOrd[l]; lOrd[l] = ox; }
+                        }
                     }
                     __syncthreads();
                 }
             }
-            for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) out[s0 + i] = decode(lKey[i], lVal[i]);
+            for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) out[s0 + i] = decode(lKey[i], lVal[i], ORDOUT ? lOrd[i] : 0ull);
             if (threadIdx.x == 0) uniqueCount[b] = U;
             __syncthreads();
         };
@@ -1490,7 +1611,7 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
             __syncthreads();
             for (uint64_t i = threadIdx.x; i < cnt && !*(volatile uint32_t *) &sOver; i += LS_BLOCK) {
                 const R r = recAt(i); if (LINES && isSentinel(r)) continue;
-                uint32_t v; const unsigned long long key = packRec(r, v);
+                uint32_t v; unsigned long long od; const unsigned long long key = packRec(r, v, od);
                 uint32_t slot = (uint32_t) ((key * 0x9E3779B97F4A7C15ULL) >> 40) & (AGG_HT - 1);
                 bool placed = false;
                 for (uint32_t probe = 0; probe < AGG_HT; probe++) {
@@ -1500,8 +1621,8 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
                     slot = (slot + 1) & (AGG_HT - 1);
                 }
                 if (!placed) { atomicExch(&sOver, 1u); break; }
-                atomicAdd(&hVal[slot], v & 0x7FFFFFFFu);
-                if (v & 0x80000000u) atomicOr(&hVal[slot], 0x80000000u);
+                atomicAdd(&hVal[slot], v);
+                if (NUCL) atomicMax(&hOrd[slot], od);
             }
             __syncthreads();
             if (!sOver) { sortListAndWrite(extract()); done = true; }
@@ -1510,19 +1631,19 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
         if (done) continue;
         if (!bigScratch) { if (threadIdx.x == 0) uniqueCount[b] = AGG_NEEDS_SCRATCH; continue; }
         {
-            // oversized bucket (hot representatives): aggregate chunk by chunk in LDS, spill the partial (key,count)
-            // pairs to HBM scratch, then merge the partials — in LDS again when they fit, else by sorting them in HBM
-            unsigned long long *pk = bigScratch + bigOff[b];           // [2*P]: keys then values
+            // oversized bucket (hot representatives): aggregate chunk by chunk in LDS, spill the partial (key, count[, rank word])
+            // entries to HBM scratch, then merge the partials — in LDS again when they fit, else by sorting them in HBM
+            unsigned long long *pk = bigScratch + bigOff[b];           // [2 * P0 (protein) or 3 * P0 (nucleotides)]: keys, values, rank words
             uint64_t P0 = 1; while (P0 < cnt) P0 <<= 1;
-            unsigned long long *pv = pk + P0;
+            unsigned long long *pv = pk + P0, *po = pv + P0;
             uint64_t nPart = 0;
             for (uint64_t c0 = 0; c0 < cnt; c0 += AGG_CAP) {
                 const uint64_t c1 = min(cnt, c0 + (uint64_t) AGG_CAP);
                 clearTable();
-                for (uint64_t i = c0 + threadIdx.x; i < c1; i += LS_BLOCK) { const R r = recAt(i); if (LINES && isSentinel(r)) continue; uint32_t v; const unsigned long long key = packRec(r, v); insert(key, v); }
+                for (uint64_t i = c0 + threadIdx.x; i < c1; i += LS_BLOCK) { const R r = recAt(i); if (LINES && isSentinel(r)) continue; uint32_t v; unsigned long long od; const unsigned long long key = packRec(r, v, od); insert(key, v, od); }
                 __syncthreads();
                 const uint32_t U = extract();
-                for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) { pk[nPart + i] = lKey[i]; pv[nPart + i] = lVal[i]; }
+                for (uint32_t i = threadIdx.x; i < U; i += LS_BLOCK) { pk[nPart + i] = lKey[i]; pv[nPart + i] = lVal[i] & 0x7FFFFFFFu; if (NUCL) po[nPart + i] = lOrd[i]; }
                 nPart += U;
                 __syncthreads();
             }
@@ -1530,7 +1651,7 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
             bool fits = true;
             if (nPart <= (uint64_t) AGG_HT) {
                 clearTable();
-                for (uint64_t i = threadIdx.x; i < nPart; i += LS_BLOCK) insert(pk[i], (uint32_t) pv[i]);
+                for (uint64_t i = threadIdx.x; i < nPart; i += LS_BLOCK) insert(pk[i], (uint32_t) pv[i], NUCL ? po[i] : 0ull);
                 __syncthreads();
                 // count distinct keys before extracting (the list holds AGG_CAP entries)
                 uint32_t mine = 0;
@@ -1546,9 +1667,9 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
                 if (fits) sortListAndWrite(extract());
             } else fits = false;
             if (!fits) {
-                // sort the partial pairs by key in HBM scratch, then merge runs of equal keys
+                // sort the partial entries by key in HBM scratch, then merge runs of equal keys
                 uint64_t P = 1; while (P < nPart) P <<= 1;
-                for (uint64_t i = nPart + threadIdx.x; i < P; i += LS_BLOCK) { pk[i] = ~0ULL; pv[i] = 0; }
+                for (uint64_t i = nPart + threadIdx.x; i < P; i += LS_BLOCK) { pk[i] = ~0ULL; pv[i] = 0; if (NUCL) po[i] = 0; }
                 __syncthreads();
                 for (uint64_t kk = 2; kk <= P; kk <<= 1) {
                     for (uint64_t j = kk >> 1; j > 0; j >>= 1) {
@@ -1557,7 +1678,10 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
                             const uint64_t l = i | j;
                             const unsigned long long x = pk[i], y = pk[l];
                             const bool up = (i & kk) == 0;
-                            if ((x > y) == up) { pk[i] = y; pk[l] = x; const unsigned long long vx = pv[i]; pv[i] = pv[l]; pv[l] = vx; }
+                            if ((x > y) == up) {
+                                pk[i] = y; pk[l] = x; const unsigned long long vx = pv[i]; pv[i] = pv[l]; pv[l] = vx;
+                                if (NUCL) { const unsigned long long ox = po[i]; po[i] = po[l]; po[l] = ox; }
+                            }
                         }
                         __syncthreads();
                     }
@@ -1565,14 +1689,14 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
                 uint32_t written = 0;
                 for (uint64_t i0 = 0; i0 < nPart; i0 += LS_BLOCK) {
                     const uint64_t i = i0 + threadIdx.x;
-                    bool head = false; Triple t; t.rep = t.target = t.cnt = 0; t.diag = 0;
+                    bool head = false; O t; t.rep = t.target = t.cnt = 0; t.diag = 0;
                     if (i < nPart) {
                         const unsigned long long k = pk[i];
                         head = (i == 0) || (pk[i - 1] != k);
                         if (head) {
-                            uint32_t c = 0, fwd = 0;
-                            for (uint64_t j = i; j < nPart && pk[j] == k; j++) { c += (uint32_t) pv[j] & 0x7FFFFFFFu; fwd |= (uint32_t) pv[j] & 0x80000000u; }
-                            t = decode(k, c | fwd);
+                            uint32_t c = 0; unsigned long long om = 0;
+                            for (uint64_t j = i; j < nPart && pk[j] == k; j++) { c += (uint32_t) pv[j]; if (NUCL) om = max(om, po[j]); }
+                            t = decode(k, c | ((uint32_t) (om & 1ULL) << 31), om);
                         }
                     }
                     const unsigned long long mk = __ballot(head);
@@ -1606,7 +1730,8 @@ __global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__rest
 // representative occurs in exactly one bucket: the number of its triples and the position of the first go to cnt[rep - repBase] /
 // pos[rep - repBase] (cnt is zeroed beforehand).  One wavefront per bucket; a representative's triples are counted 64 at a time
 // (a long contig is the representative of 10^5..10^6 triples: neither a serial walk per run nor one atomic per triple would do).
-__global__ __launch_bounds__(256) void repRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
+template <class T>
+__global__ __launch_bounds__(256) void repRunsKernel(const T *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
                                                      uint32_t repBase, uint32_t *__restrict__ cnt) {
     for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
         const uint64_t s0 = (uint64_t) lineBeg[b] * RPL; const uint32_t n = unique[b];
@@ -1629,8 +1754,9 @@ __global__ __launch_bounds__(256) void repRunsKernel(const Triple *__restrict__ 
 // offset comes from the run heads among the 64 triples a wavefront holds (a run that began earlier is carried along as a
 // wave-uniform pair), so the only random access per representative is its start (round 3: an array of run positions, written by
 // the kernel above and read here, was a second random line per representative in both kernels).
-__global__ __launch_bounds__(256) void placeRunsKernel(const Triple *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
-                                                       uint32_t repBase, const uint64_t *__restrict__ start, Triple *__restrict__ out) {
+template <class T>
+__global__ __launch_bounds__(256) void placeRunsKernel(const T *__restrict__ in, const uint32_t *__restrict__ lineBeg, const uint32_t *__restrict__ unique, uint32_t nBuckets,
+                                                       uint32_t repBase, const uint64_t *__restrict__ start, T *__restrict__ out) {
     const int lane = laneId();
     for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
         const uint64_t s0 = (uint64_t) lineBeg[b] * RPL; const uint32_t n = unique[b];
@@ -1638,7 +1764,7 @@ __global__ __launch_bounds__(256) void placeRunsKernel(const Triple *__restrict_
         for (uint32_t i0 = 0; i0 < n; i0 += 64) {
             const uint32_t i = i0 + (uint32_t) lane;
             const bool valid = i < n;
-            Triple t; t.rep = 0xFFFFFFFFu; t.target = 0; t.diag = 0; t.cnt = 0;
+            T t; t.rep = 0xFFFFFFFFu; t.target = 0; t.diag = 0; t.cnt = 0;
             if (valid) t = in[s0 + i];
             const uint32_t rep = t.rep;
             const uint32_t prevLane = __shfl_up(rep, 1, 64);
@@ -1745,7 +1871,7 @@ template <bool NUCL, bool LONG> __host__ __device__ __forceinline__ bool recLess
     if (a.len != b.len) return a.len > b.len;
     if (a.id != b.id) return a.id < b.id;
     if (a.pos != b.pos) return a.pos < b.pos;
-    return a.kmer < b.kmer;      // canonical strand tie-break (reverse first)
+    return a.kmer < b.kmer;      // records of one sequence that differ in the strand only: reverse first (as oracle/kmermatcher.cpp)
 }
 template <bool NUCL, bool LONG>
 __global__ __launch_bounds__(256) void rankKernel(const void *recs, uint64_t n, const void *tkeys, uint32_t m, unsigned long long *diff) {
@@ -1916,12 +2042,12 @@ __global__ void arenaStartKernel(const uint32_t *__restrict__ lineBeg, uint32_t 
     for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < gGrid; j += gridDim.x * blockDim.x)
         arenaStart[j] = (uint64_t) lineBeg[std::min(j * bpb, nBuckets - 1)] * RPL;
 }
-// scratch need of the aggregation kernel per bucket (buckets beyond its LDS capacity): 2 * pow2ceil(records) 8-byte words
-__global__ void bigNeedKernel(const uint32_t *__restrict__ lineCnt, const uint32_t *__restrict__ unique, uint32_t nBuckets, uint64_t *__restrict__ need) {
+// scratch need of the aggregation kernel per bucket (buckets beyond its LDS capacity): 2 (nucleotides: 3) * pow2ceil(records) 8-byte words
+__global__ void bigNeedKernel(const uint32_t *__restrict__ lineCnt, const uint32_t *__restrict__ unique, uint32_t nBuckets, uint64_t *__restrict__ need, uint32_t wordsPerEntry) {
     for (uint32_t b = blockIdx.x * blockDim.x + threadIdx.x; b < nBuckets; b += gridDim.x * blockDim.x) {
         const uint64_t c = (uint64_t) lineCnt[b] * RPL;
         uint64_t v = 0;
-        if (unique[b] == AGG_NEEDS_SCRATCH) { uint64_t P = 1; while (P < c) P <<= 1; v = 2 * P; }      // only what pass 1 left over
+        if (unique[b] == AGG_NEEDS_SCRATCH) { uint64_t P = 1; while (P < c) P <<= 1; v = wordsPerEntry * P; }      // only what pass 1 left over (keys, counts[, rank words])
         need[b] = v;
     }
 }
@@ -1967,6 +2093,7 @@ static int buildLineLists(plasship_ctx *ctx, const uint32_t *dTags, uint64_t cap
     return PLASSHIP_OK;
 }
 
+constexpr int KM_RETRY_EARLY_OVERFLOW_CHECK = -1000;     // internal: kmermatchImpl is to be called again, waiting for the extraction's overflow count
 // What the line path hands to the run reduction
 struct LinesOut { void *triples = nullptr; uint64_t nTriples = 0, Nk = 0, Nm = 0; std::vector<int64_t> stalePos; uint32_t staleT = 0; float msSort1 = 0, msGroup = 0, msSort2 = 0, msPart = 0; int nPart = 1;
                   uint64_t exchangedRecordBytes = 0, exchangedTripleBytes = 0; };
@@ -1977,11 +2104,12 @@ constexpr uint64_t HALO_SLACK = 1u << 16;
 // the bit-reversed (rep - repBase), aggregation + sort per bucket, then every representative's triples to their place in
 // representative order.  TRIPLES: `in` holds weighted triples (owner side of a sharded run), else grouped records.
 // out: `dOut` = nTriples triples in (rep, target, diagonal) order (+ slackTriples of room behind them); dRepStart[nReps + 1] (optional)
-template <bool NUCL, bool LONG, bool TRIPLES>
+template <bool NUCL, bool LONG, bool TRIPLES, bool ORDOUT = false>
 static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std::pair<uint64_t, uint64_t>> &segs, uint64_t nIn, uint32_t nReps, uint32_t repBase, uint32_t nTargets,
                         uint64_t slackTriples, const std::function<void()> &inputConsumed, DevBuf &dOut, uint64_t &nTriples, DevBuf *dRepStartOut) {
-    constexpr bool PL = TRIPLES ? false : LONG;                // record layout the partition kernels move: triples are 16 bytes like Rec<false>
+    constexpr bool PL = TRIPLES ? NUCL : LONG;                 // record layout the partition kernels move: triples are 16 bytes like Rec<false>, nucleotide triples (TripleX) 24 like Rec<true>
     typedef Rec<PL> R;
+    typedef typename std::conditional<ORDOUT, TripleX, Triple>::type OutT;      // ORDOUT (sharded nucleotide run, before exchange 2): triples with their rank word
     hipStream_t st = ctx->stream;
     const int numCU = ctx->numCU;
     const int maxBits = PL ? 9 : 10;
@@ -2059,22 +2187,22 @@ static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std
     DevBuf dBigNeed, dBigOff, dBigScratch, dUnique, dScanTmp3, dSparse;
     const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSort + 2);
     if (dBigNeed.alloc(((size_t) nSort + 1) * 8) != hipSuccess || dBigOff.alloc(((size_t) nSort + 2) * 8) != hipSuccess || dUnique.alloc(((size_t) nSort + 1) * 4) != hipSuccess ||
-        dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess || dSparse.alloc(sortCap * RPL * sizeof(Triple)) != hipSuccess) {
+        dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess || dSparse.alloc(sortCap * RPL * sizeof(OutT)) != hipSuccess) {
         setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE;
     }
     // pass 1: every bucket aggregated in LDS (no scratch); pass 2: the few buckets with more distinct triples than LDS holds
     const AggLines aggLn{sortList, dSortBeg.as<uint32_t>(), dSortCnt.as<uint32_t>()};
     const unsigned aggGrid = std::min<uint32_t>(nSort, (uint32_t) numCU * (uint32_t) tuneInt("AGGSORT", 16));
-    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true, TRIPLES>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
+    hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true, TRIPLES, ORDOUT>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
                        (unsigned long long *) nullptr, (const uint64_t *) nullptr, dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) repBase, aggLn, repBits);
-    hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>());
+    hipLaunchKernelGGL(bigNeedKernel, dim3(gridFor(nSort, 256, 1024)), dim3(256), 0, st, (const uint32_t *) dSortCnt.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort, dBigNeed.as<uint64_t>(), NUCL ? 3u : 2u);
     if (exclusiveScanU64(st, dBigNeed.as<uint64_t>(), dBigOff.as<uint64_t>(), nSort, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t bigTot = 0;
     PH_COPY_SYNC(st, &bigTot, dBigOff.as<uint64_t>() + nSort, 8, hipMemcpyDeviceToHost);
     PH_CHECK(hipGetLastError());
     if (bigTot) {
         if (dBigScratch.alloc(bigTot * 8) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true, TRIPLES>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
+        hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, true, TRIPLES, ORDOUT>), dim3(aggGrid), dim3(LS_BLOCK), 0, st, sortRecs, dSparse.p, (const uint64_t *) nullptr, nSort,
                            dBigScratch.as<unsigned long long>(), (const uint64_t *) dBigOff.as<uint64_t>(), dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) repBase, aggLn, repBits);
     }
     // every bucket now holds its representatives' triples, each representative's contiguous and in (target, diagonal) order, but
@@ -2087,16 +2215,16 @@ static int repSortLines(plasship_ctx *ctx, const void *in, const std::vector<std
         dScanTmp4.alloc(scanTmp4Bytes) != hipSuccess) { setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dRepCnt.p, 0, ((size_t) nReps + 1) * 4, st));
     const unsigned runGrid = std::min<uint32_t>((nSort + 3) / 4, (uint32_t) numCU * 8);
-    hipLaunchKernelGGL(repRunsKernel, dim3(runGrid), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(),
+    hipLaunchKernelGGL(repRunsKernel<OutT>, dim3(runGrid), dim3(256), 0, st, (const OutT *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(),
                        (const uint32_t *) dUnique.as<uint32_t>(), nSort, repBase, dRepCnt.as<uint32_t>());
     if (exclusiveScanU32(st, dRepCnt.as<uint32_t>(), dRepStart.as<uint64_t>(), nReps, dScanTmp4.p, scanTmp4Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     nTriples = 0;
     PH_COPY_SYNC(st, &nTriples, dRepStart.as<uint64_t>() + nReps, 8, hipMemcpyDeviceToHost);
     PH_CHECK(hipGetLastError());
     dR1.release(); dR2.release();
-    if (dOut.alloc((std::max<uint64_t>(nTriples, 1) + slackTriples) * sizeof(Triple)) != hipSuccess) { setError("kmermatch: out of device memory for the sorted triples"); return PLASSHIP_ERR_DEVICE; }
-    if (nTriples) hipLaunchKernelGGL(placeRunsKernel, dim3(runGrid), dim3(256), 0, st, (const Triple *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort,
-                                     repBase, (const uint64_t *) dRepStart.as<uint64_t>(), (Triple *) dOut.p);
+    if (dOut.alloc((std::max<uint64_t>(nTriples, 1) + slackTriples) * sizeof(OutT)) != hipSuccess) { setError("kmermatch: out of device memory for the sorted triples"); return PLASSHIP_ERR_DEVICE; }
+    if (nTriples) hipLaunchKernelGGL(placeRunsKernel<OutT>, dim3(runGrid), dim3(256), 0, st, (const OutT *) dSparse.p, (const uint32_t *) dSortBeg.as<uint32_t>(), (const uint32_t *) dUnique.as<uint32_t>(), nSort,
+                                     repBase, (const uint64_t *) dRepStart.as<uint64_t>(), (OutT *) dOut.p);
     PH_CHECK(hipGetLastError());
     return PLASSHIP_OK;
 }
@@ -2113,7 +2241,8 @@ static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; ds
 // triples of all ranks with the same kernels (aggSortKernel<TRIPLES>).
 template <bool NUCL, bool LONG>
 static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, const LineGeo &geo, uint64_t total,
-                          DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res) {
+                          DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res,
+                          const uint32_t *dLateOverflow) {
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
@@ -2281,8 +2410,11 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(hArena.data(), dArenaStart.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(ks, dKStats.p, 32, hipMemcpyDeviceToHost, st));
+    uint32_t lateOverflow = 0;
+    if (dLateOverflow) PH_CHECK(hipMemcpyAsync(&lateOverflow, dLateOverflow, 4, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
+    if (lateOverflow) return KM_RETRY_EARLY_OVERFLOW_CHECK;          // (never in a sharded run: its ranks wait for the count right after the extraction)
     uint64_t NmLocal = 0;
     for (uint32_t j = 0; j < gGrid; j++) NmLocal += hOutCnt[j];
     uint64_t Nm = NmLocal;
@@ -2326,7 +2458,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_CHECK(hipMemcpyAsync(dTCap.p, &cap, 4, hipMemcpyHostToDevice, st));
         PH_CHECK(hipMemsetAsync(dDiff.p, 0, ((size_t) tb + 1) * 8, st));
         // re-extract the records of T into a scratch array with the very kernel that produced them
-        ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
+        ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0]; ta.cacheLines = nullptr;
         ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(1), dim3(64), 0, st, ta);
         std::vector<R> trec(tb);
@@ -2374,7 +2506,9 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     for (uint32_t j = 0; j < gGrid; j++) arenas[j] = std::make_pair(hArena[j] / RPL, hOutCnt[j]);
     DevBuf dTriples, dRepStart; uint64_t nTriples = 0;
     auto arenasConsumed = [&]() { if (cm) { if (geo.nb2) dRx.release(); else dArena.release(); } else (arenaBuf == dA.p ? dA : dB).release(); };
-    rc = repSortLines<NUCL, LONG, false>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, cm ? &dRepStart : nullptr);
+    // (sharded nucleotide run: the triples leave for their owners with the rank word of their top member, see TripleX)
+    if (NUCL && cm) rc = repSortLines<NUCL, LONG, false, NUCL>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, &dRepStart);
+    else rc = repSortLines<NUCL, LONG, false>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, cm ? &dRepStart : nullptr);
     if (rc) return rc;
     if (cm) {
         // ---- exchange 2: every representative's aggregated triples to the representative's owner (contiguous id ranges: the triples
@@ -2385,8 +2519,9 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_COPY_SYNC(st, ob.data(), dOB.p, ((size_t) W + 1) * 8, hipMemcpyDeviceToHost);
         for (int r = 0; r < W; r++) sendCount[r] = ob[r + 1] - ob[r];
         DevBuf dRxT; uint64_t gotT = 0;
-        rc = commAlltoallvRecords(ctx, dTriples.p, sendCount.data(), sizeof(Triple), dRxT, &gotT, RPL); if (rc) return rc;
-        res.exchangedTripleBytes = (nTriples - sendCount[rk]) * sizeof(Triple);
+        constexpr size_t xBytes = NUCL ? sizeof(TripleX) : sizeof(Triple);
+        rc = commAlltoallvRecords(ctx, dTriples.p, sendCount.data(), xBytes, dRxT, &gotT, RPL); if (rc) return rc;
+        res.exchangedTripleBytes = (nTriples - sendCount[rk]) * xBytes;
         PH_TRACE(st, "kmermatch: exchange 2 (aggregated triples)");
         dTriples.release(); dRepStart.release();
         const uint32_t repBase = (uint32_t) ownedBegin(N, rk, W), ownedN = (uint32_t) (ownedBegin(N, rk + 1, W) - repBase);
@@ -2547,7 +2682,7 @@ static int reduceToCandidates(plasship_ctx *ctx, const plasship_seqdb *db, void 
 
 template <bool NUCL, bool LONG>
 int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, plasship_cands **out,
-                  plasship_kmermatch_stats *stats) {
+                  plasship_kmermatch_stats *stats, bool overflowCheckEarly) {
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
@@ -2626,6 +2761,23 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 4, st));
     PH_CHECK(hipMemsetAsync(dKStats.p, 0, 32, st));
     ea.kstats = dKStats.as<unsigned long long>();
+    // ---- selected-window cache (section 2c): which sequences keep last call's selection, and where this call's selection is kept ----
+    plasship_ctx::KmCache &kc = ctx->kmCache;
+    const bool fastIndex = !NUCL && k <= 14 && ea.powers[1] <= 16;      // kmerIndexCore
+    const bool cacheEligible = !NUCL && !LONG && !cm && fastIndex && k <= 16 && par->kmers_per_seq >= 1 && par->kmers_per_seq <= (int) KMC_POS && par->kmers_per_seq_scale == 0.0f &&
+                               tuneInt("KMCACHE", 1) != 0;
+    const bool cacheReuse = cacheEligible && kc.valid && kc.n == N && kc.gen == db->parentGen && db->d_changed.p && kc.k == k && kc.alph == par->alphabet_size &&
+                            kc.kps == par->kmers_per_seq && kc.ignoreMulti == par->ignore_multi_kmer && kc.hashShift == par->hash_shift && !overflowCheckEarly;
+    kc.valid = false;                                         // (set again when this call has succeeded)
+    DevBuf dCachedList, dCachedCount;
+    if (cacheEligible && N) {
+        if (kc.lines.bytes < (size_t) N * KMC_LINE) { kc.lines.release(); if (kc.lines.alloc((size_t) N * KMC_LINE) != hipSuccess) { setError("kmermatch: out of device memory for the selected-window cache"); return PLASSHIP_ERR_DEVICE; } }
+        ea.cacheLines = kc.lines.as<unsigned char>();
+        if (cacheReuse) {
+            if (dCachedList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCachedCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            PH_CHECK(hipMemsetAsync(dCachedCount.p, 0, 4, st));
+        }
+    } else kc.lines.release();
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     bool twoLists = false;
     if (!NUCL && k <= 16 && nMine) {
@@ -2642,6 +2794,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             sa.hugeList = dOvIds.as<uint32_t>(); sa.hugeCount = dOvCnt.as<uint32_t>(); sa.hugeWindows = 64 * 16;
         }
         sa.idLo = sLo; sa.idHi = sHi; sa.slotBias = slotBias;
+        if (cacheReuse) { sa.changed = db->d_changed.as<unsigned char>(); sa.cachedList = dCachedList.as<uint32_t>(); sa.cachedCount = dCachedCount.as<uint32_t>(); }
         // the fast restatement needs k = 14 and the half-indices (7 digits of the base, each at most the X code = base) in 32 bits
         constexpr int KF = 14, HF = KF / 2;
         bool fast = k == KF && tuneInt("SHORT_FAST", 1) == 1;      // PLASSHIP_TUNE_SHORT_FAST=2: the kernel above
@@ -2653,6 +2806,13 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         else if (fast) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, false>), shortGrid, dim3(64), 0, st, sa);
         else hipLaunchKernelGGL((extractShortKernel<LONG>), shortGrid, dim3(64), 0, st, sa);   // 18 wavefronts fit a CU; on large sets twice that evens out the tail (50 M reads: 35.7 -> 34.4 ms)
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
+        if (cacheReuse) {
+            CachedArgs ca; memset(&ca, 0, sizeof(ca));
+            ca.s = ea.s; ca.slotOff = ea.slotOff; ca.arr = ea.arr; ca.map = ea.map; ca.lines = kc.lines.as<unsigned char>();
+            ca.list = dCachedList.as<uint32_t>(); ca.count = dCachedCount.as<uint32_t>(); ca.k = k; ca.xCode = ea.xCode;
+            ca.base = (uint32_t) ea.powers[1]; ca.base7 = (uint32_t) ea.powers[7]; ca.slotBias = slotBias; ca.kstats = dKStats.as<unsigned long long>();
+            hipLaunchKernelGGL(extractCachedKernel, dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("CACHED", 32))), dim3(64), 0, st, ca);
+        }
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
@@ -2684,16 +2844,20 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 16u))), dim3(64), 0, st, e2);
         PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));            // tier 2 has consumed the first queue: it becomes tier 3's output queue
         ExtractArgs e3 = ea; e3.waveList = dOv2Ids.as<uint32_t>(); e3.waveCount = dOv2Cnt.as<uint32_t>();
-        e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>();
+        e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>(); e3.fillOnOverflow = 1;
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 2u : 5u))), dim3(64), 0, st, e3);
     }
     // what the last stage could not hold either (candidate sets beyond LDS)
     DevBuf &dLastIds = *lastIds, &dLastCnt = *lastCnt;
     PH_CHECK(hipEventRecord(ctx->ev[5], st));
     uint32_t nOv = 0;
-    // protein DBs: a candidate set never exceeds the tiers' 128 entries (59 considered k-mers), and the last tier keeps up to 8160
-    // residues in LDS — nothing can be left over then, and nobody has to wait to learn that
-    const bool overflowPossible = NUCL || db->maxEntryLen > 8160u || par->kmers_per_seq > 120 || par->kmers_per_seq_scale != 0.0f;
+    // protein DBs: a candidate set hardly ever exceeds the tiers' 128 entries (59 considered k-mers), and the last tier keeps up to
+    // 8160 residues in LDS.  "Hardly ever": every window whose score is <= the threshold score is a candidate, and equal k-mers
+    // share a score — a homopolymer or tandem repeat of >= ~85 residues whose k-mer lies at or below the threshold overfills the set
+    // (ADVICE r3).  So the count of the last tier's hand-overs is not waited for here when an overflow is UNLIKELY; it travels with
+    // the group stage's counts (kmermatchLines), the last tier has left such a sequence's slots as sentinels, and if the count turns
+    // out non-zero the call starts over with the wait in place (`overflowCheckEarly`).
+    const bool overflowPossible = overflowCheckEarly || !useLines || cm != nullptr || NUCL || db->maxEntryLen > 8160u || par->kmers_per_seq > 120 || par->kmers_per_seq_scale != 0.0f;
     if (nMine && overflowPossible) {
         PH_CHECK(hipMemcpyAsync(&nOv, dLastCnt.p, 4, hipMemcpyDeviceToHost, st));
         PH_CHECK(plasship::streamSync(st));
@@ -2726,8 +2890,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         int keyBitsL = 0;
         if (NUCL) keyBitsL = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBitsL < 63 && (long double) (1ULL << keyBitsL) < v) keyBitsL++; }
         LinesOut lo;
-        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo);
-        if (rcL) return rcL;
+        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, (nMine && !overflowPossible) ? dLastCnt.as<uint32_t>() : nullptr);
+        if (rcL) return rcL;                                  // (KM_RETRY_EARLY_OVERFLOW_CHECK: the caller starts over)
         std::unique_ptr<plasship_cands> holderL; uint64_t NcL = 0; float msReduceL = 0;
         rcL = reduceToCandidates<NUCL, LONG>(ctx, db, lo.triples, lo.nTriples, lo.stalePos, lo.staleT, holderL, NcL, msReduceL, true);
         if (rcL) return rcL;
@@ -2740,11 +2904,17 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
             stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;
             stats->ms_part_scatter = lo.msPart; stats->n_part_scatter = lo.nPart;
-            unsigned long long ks[4] = {0, 0, 0, 0};
+            unsigned long long ks[4] = {0, 0, 0, 0}; uint32_t nCachedSeqs = 0;
+            if (cacheReuse) PH_CHECK(hipMemcpyAsync(&nCachedSeqs, dCachedCount.p, 4, hipMemcpyDeviceToHost, st));
             PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost);
+            stats->n_cached_sequences = nCachedSeqs;
             stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
             stats->residues = db->residues;
             stats->ms_extract = msExtract; stats->ms_sort1 = lo.msSort1; stats->ms_group = lo.msGroup; stats->ms_sort2 = lo.msSort2; stats->ms_reduce = msReduceL;
+            stats->n_scratch_sequences = nOv; stats->n_restarts = overflowCheckEarly ? 1u : 0u;
+        }
+        if (cacheEligible && N) {     // the lines now describe THIS DB (the wave kernels rewrote what changed, the rest was kept)
+            kc.valid = true; kc.n = N; kc.gen = db->gen; kc.k = k; kc.alph = par->alphabet_size; kc.kps = par->kmers_per_seq; kc.ignoreMulti = par->ignore_multi_kmer; kc.hashShift = par->hash_shift;
         }
         *out = holderL.release();
         return PLASSHIP_OK;
@@ -2987,7 +3157,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         std::vector<uint64_t> bigOff(nSortBuckets, 0); uint64_t bigTot = 0;
         for (uint32_t b = 0; b < nSortBuckets; b++) {
             const uint64_t c = hSortStart[b + 1] - hSortStart[b];
-            if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; bigOff[b] = bigTot; bigTot += 2 * P; }
+            if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; bigOff[b] = bigTot; bigTot += (NUCL ? 3 : 2) * P; }
         }
         if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess ||
             dUnique.alloc(((size_t) nSortBuckets + 1) * 4) != hipSuccess || dTripleStart.alloc(((size_t) nSortBuckets + 2) * 8) != hipSuccess) {
@@ -3027,6 +3197,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
         stats->residues = db->residues;
         stats->ms_extract = msExtract; stats->ms_sort1 = msSort1; stats->ms_group = msGroup; stats->ms_sort2 = msSort2; stats->ms_reduce = msReduce;
+        stats->n_scratch_sequences = nOv; stats->n_restarts = 0; stats->n_cached_sequences = 0;
     }
     *out = holder.release();
     return PLASSHIP_OK;
@@ -3041,7 +3212,15 @@ extern "C" int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, c
     if (!nucl && par->alphabet_size != 13 && par->alphabet_size != 21) { setError("plasship_kmermatch: --alph-size must be 13 or 21"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (db->maxEntryLen >= (1u << 20)) { setError("plasship_kmermatch: sequences of 2^20 residues or more are not supported"); return PLASSHIP_ERR_UNSUPPORTED; }
     PH_ENTER(ctx);
-    const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX);     // kmermatcher.cpp:797-802
-    if (nucl) return commFinish(ctx, lng ? kmermatchImpl<true, true>(ctx, db, par, out, stats) : kmermatchImpl<true, false>(ctx, db, par, out, stats));
-    return commFinish(ctx, lng ? kmermatchImpl<false, true>(ctx, db, par, out, stats) : kmermatchImpl<false, false>(ctx, db, par, out, stats));
+    // kmermatcher.cpp:797-802: KmerPosition<short> unless a sequence is too long for it.  (Nucleotide k > 23: the 16-byte grouped
+    // record has no room for the k-mer the strand rule needs — embedOrd — so such a run takes the 24-byte layout, whose arithmetic
+    // is the same on sequences that short.)
+    const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX) || (nucl && par->kmer_size > 23);
+    int rc = KM_RETRY_EARLY_OVERFLOW_CHECK;
+    for (int attempt = 0; attempt < 2 && rc == KM_RETRY_EARLY_OVERFLOW_CHECK; attempt++) {
+        const bool early = attempt > 0;
+        if (nucl) rc = lng ? kmermatchImpl<true, true>(ctx, db, par, out, stats, early) : kmermatchImpl<true, false>(ctx, db, par, out, stats, early);
+        else rc = lng ? kmermatchImpl<false, true>(ctx, db, par, out, stats, early) : kmermatchImpl<false, false>(ctx, db, par, out, stats, early);
+    }
+    return commFinish(ctx, rc);
 }

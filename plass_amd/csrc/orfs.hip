@@ -33,7 +33,11 @@ struct OrfInfo { uint32_t key, readKey, fromPos, toPos, flags; };      // flags:
 struct plasship_orfhdr {
     size_t n = 0;
     size_t nUnparsable = 0;             // entries that are not "<id>\t<from>[+-]<len>[\t<flags>]" (flags bit 2)
-    plasship::DevBuf d_info;            // OrfInfo[n]
+    plasship::DevBuf d_info;            // OrfInfo[n], in key order
+    // rank of every entry in DATA FILE order (empty: the file lay in key order) — like plasship_seqdb::d_fileRank: concatdbs numbers
+    // its second DB by it (DBConcat.cpp:46-47,113-118), and extractorfs writes ORFs and headers in the same thread order, so the
+    // header DB of a concatenation must be renumbered exactly like its sequence DB or the keys no longer correspond
+    plasship::DevBuf d_fileRank;
 };
 
 namespace plasship {
@@ -313,9 +317,11 @@ __global__ __launch_bounds__(256) void concatRankCopyKernel(const char *__restri
         if (gl == 0) { off[nA + r] = d; key[nA + r] = keyBase + r; }
     }
 }
-__global__ void concatInfoKernel(const OrfInfo *__restrict__ a, uint32_t nA, const OrfInfo *__restrict__ b, uint32_t nB, uint32_t keyBase, OrfInfo *__restrict__ out) {
+// rank != nullptr: entry j of B (key order) lay at place rank[j] of B's data file and is numbered by that
+__global__ void concatInfoKernel(const OrfInfo *__restrict__ a, uint32_t nA, const OrfInfo *__restrict__ b, uint32_t nB, const uint32_t *__restrict__ rank, uint32_t keyBase, OrfInfo *__restrict__ out) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nA + nB; i += gridDim.x * blockDim.x) {
-        if (i < nA) out[i] = a[i]; else { OrfInfo o = b[i - nA]; o.key = keyBase + (i - nA); out[i] = o; }
+        if (i < nA) out[i] = a[i];
+        else { const uint32_t j = i - nA, r = rank ? rank[j] : j; OrfInfo o = b[j]; o.key = keyBase + r; out[nA + r] = o; }
     }
 }
 __global__ void maxLenKernel(const uint32_t *__restrict__ v, uint32_t n, uint32_t *__restrict__ out) {
@@ -529,7 +535,7 @@ extern "C" int plasship_orfhdr_concat(plasship_ctx *ctx, const plasship_orfhdr *
     const uint64_t nn = (uint64_t) a->n + b->n;
     std::unique_ptr<plasship_orfhdr> o(new plasship_orfhdr());
     if (o->d_info.alloc((nn + 1) * sizeof(OrfInfo)) != hipSuccess) { setError("plasship_orfhdr_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (nn) hipLaunchKernelGGL(concatInfoKernel, dim3(gridOf(nn, ctx->numCU)), dim3(256), 0, st, a->d_info.as<OrfInfo>(), (uint32_t) a->n, b->d_info.as<OrfInfo>(), (uint32_t) b->n, maxKeyA + 1, o->d_info.as<OrfInfo>());
+    if (nn) hipLaunchKernelGGL(concatInfoKernel, dim3(gridOf(nn, ctx->numCU)), dim3(256), 0, st, a->d_info.as<OrfInfo>(), (uint32_t) a->n, b->d_info.as<OrfInfo>(), (uint32_t) b->n, (const uint32_t *) b->d_fileRank.as<uint32_t>(), maxKeyA + 1, o->d_info.as<OrfInfo>());
     o->n = (size_t) nn; o->nUnparsable = a->nUnparsable + b->nUnparsable;
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
@@ -606,6 +612,18 @@ extern "C" int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plas
     std::unique_ptr<plasship_orfhdr> o(new plasship_orfhdr());
     if (o->d_info.alloc((n + 1) * sizeof(OrfInfo)) != hipSuccess) { setError("plasship_orfhdr_read: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     { const int rc = stagedCopyToDevice(ctx, o->d_info.p, info.data(), n * sizeof(OrfInfo)); if (rc) return rc; }
+    {   // file order != key order (a DB several writer threads left behind): every entry's rank in the data file (as plasship_seqdb_upload does)
+        bool fileSorted = true;
+        for (size_t i = 1; i < n && fileSorted; i++) fileSorted = h.off[perm[i - 1]] <= h.off[perm[i]];
+        if (!fileSorted) {
+            std::vector<uint32_t> byOff(n), rank(n);
+            for (size_t i = 0; i < n; i++) byOff[i] = (uint32_t) i;
+            std::stable_sort(byOff.begin(), byOff.end(), [&](uint32_t x, uint32_t y) { return h.off[perm[x]] < h.off[perm[y]]; });
+            for (size_t r = 0; r < n; r++) rank[byOff[r]] = (uint32_t) r;
+            if (o->d_fileRank.alloc(n * 4) != hipSuccess) { setError("plasship_orfhdr_read: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            const int rc = stagedCopyToDevice(ctx, o->d_fileRank.p, rank.data(), n * 4); if (rc) return rc;
+        }
+    }
     o->n = n; o->nUnparsable = nBad;
     *out = o.release();
     return PLASSHIP_OK;

@@ -154,6 +154,31 @@ def nucleotide_read_db(n_pairs, genome_len=None, seed=1, coverage=20.0):
     return pack_db([_BASES[r] for r in reads])
 
 
+def plant_inverted_repeats(rng, genome, n):
+    """writes n inverted repeats (arm 40-150 nt + loop 0-60 nt + reverse complement of the arm) over the genome: loci where reads share
+    k-mers on BOTH strands — the (rep, target, diagonal) strand ties of kmermatcher's sort #2 (tests/golden/make_strand_ties.py)"""
+    for _ in range(n):
+        arm, loop = int(rng.integers(40, 151)), int(rng.integers(0, 61))
+        p0 = int(rng.integers(1000, genome.size - 1000))
+        genome[p0 + arm + loop:p0 + 2 * arm + loop] = (3 - genome[p0:p0 + arm])[::-1]
+    return genome
+
+
+def nucleotide_hairpin_reads(n_pairs, n_hairpins, seed=1, coverage=60.0):
+    """read codes [2 * n_pairs, 150] of ONE gene-dense genome with planted inverted repeats; returns (reads, genome length)"""
+    rng = np.random.default_rng(seed)
+    genome = plant_inverted_repeats(rng, make_genome(rng, max(20000, int(300 * n_pairs / coverage))), n_hairpins)
+    return make_reads(rng, genome, n_pairs), int(genome.size)
+
+
+def fixed_length_db(reads):
+    """(data, off, elen, key) of equally long reads (codes A0 C1 G2 T3) without a Python loop"""
+    n, L = reads.shape
+    ent = np.empty((n, L + 2), dtype=np.uint8)
+    ent[:, :L] = _BASES[reads]; ent[:, L] = 10; ent[:, L + 1] = 0
+    return ent.tobytes(), np.arange(n, dtype=np.uint64) * (L + 2), np.full(n, L + 2, dtype=np.uint32), np.arange(n, dtype=np.uint32)
+
+
 def orf_twin_dbs(n_pairs, genome_len=None, seed=1, coverage=20.0, min_codons=45):
     """PenguiN's guided stage works on nucleotide ORFs and their translations under the same keys (extractorfs +
     translatenucs --add-orf-stop).  Returns (nucl_db, aa_db), each (data, off, elen, key): for every read and frame the

@@ -13,8 +13,30 @@ $PLASS extractorfs $W/w/reads $W/w/B $START --threads 8 -v 0
 $PLASS translatenucs $W/w/A $W/w/aaA --add-orf-stop 1 --threads 8 -v 0
 $PLASS translatenucs $W/w/B $W/w/aaB --add-orf-stop 1 --threads 8 -v 0
 $PLASS concatdbs $W/w/aaA $W/w/aaB $W/w/aaC -v 0 --threads 1
-for f in aaA aaB aaC; do cp $W/w/$f $W/w/$f.index $W/w/$f.dbtype $W/concat/; done
-for f in aaA aaB; do awk -v f=$f 'NR>1 && $2<prev {c++} {prev=$2} END {print f": offset inversions in key order:", c+0, "of", NR}' $W/concat/$f.index; done
-printf 'aaA, aaB = plass translatenucs --add-orf-stop 1 --threads 8 of the two extractorfs passes on examples/reads_1.fastq.gz (raw files, thread order)\naaC = plass concatdbs aaA aaB\n' > $W/concat/MANIFEST
+# round 4: the header DBs of the same two passes — extractorfs writes ORFs and headers in the same thread order, the
+# workflow concatenates both (data/assemble.sh:72-77), and the keys of the two concatenations must keep corresponding
+$PLASS concatdbs $W/w/A_h $W/w/B_h $W/w/C_h -v 0 --threads 1
+$PLASS concatdbs $W/w/A $W/w/B $W/w/C -v 0 --threads 1
+# a header DB whose DATA FILE is not in key order (what a multi-threaded writer without renumbering leaves; extractorfs itself renumbers):
+# B_h's entries laid out in a seeded random order, index offsets to match — and the reference's concatenation with it as second DB
+python3 - $W/w/B_h $W/w/Bs_h <<'PY'
+import random, sys
+src, dst = sys.argv[1], sys.argv[2]
+data = open(src, 'rb').read()
+ent = [tuple(int(x) for x in l.split()[:3]) for l in open(src + '.index', 'rb')]
+order = list(range(len(ent))); random.Random(7).shuffle(order)
+off = {}; pos = 0
+with open(dst, 'wb') as f:
+    for i in order:
+        k, o, l = ent[i]; f.write(data[o:o + l]); off[k] = (pos, l); pos += l
+with open(dst + '.index', 'wb') as f:
+    for k, _, _ in ent:
+        f.write(b'%d\t%d\t%d\n' % (k, off[k][0], off[k][1]))
+open(dst + '.dbtype', 'wb').write(open(src + '.dbtype', 'rb').read())
+PY
+$PLASS concatdbs $W/w/A_h $W/w/Bs_h $W/w/Cs_h -v 0 --threads 1
+for f in aaA aaB aaC A_h B_h C_h Bs_h Cs_h A B C; do cp $W/w/$f $W/w/$f.index $W/w/$f.dbtype $W/concat/; done
+for f in aaA aaB A_h B_h Bs_h; do awk -v f=$f 'NR>1 && $2<prev {c++} {prev=$2} END {print f": offset inversions in key order:", c+0, "of", NR}' $W/concat/$f.index; done
+printf 'aaA, aaB = plass translatenucs --add-orf-stop 1 --threads 8 of the two extractorfs passes on examples/reads_1.fastq.gz (raw files, thread order)\naaC = plass concatdbs aaA aaB\nA, B, A_h, B_h = the nucleotide ORFs and their header DBs as the two extractorfs passes (--threads 8) left them; C = concatdbs A B, C_h = concatdbs A_h B_h\nBs_h = B_h with its data file in a seeded random order (index offsets to match); Cs_h = plass concatdbs A_h Bs_h\n' > $W/concat/MANIFEST
 tar -C $W -czf $HERE/concat_noncanonical.tar.gz concat
 rm -rf $W

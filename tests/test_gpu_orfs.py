@@ -152,3 +152,27 @@ def test_concatdbs_numbers_b_in_file_order(ctx, golden, tmp_path):
     p = subprocess.run([hip, "concatdbs", f"{c}/aaA", f"{c}/aaB", str(tmp_path / "cli")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert p.returncode == 0, p.stdout
     assert_same_db(f"{c}/aaC", tmp_path / "cli", "plass-hip concatdbs on thread-ordered inputs")
+
+
+def test_concatdbs_header_db_follows_the_file_order_too(ctx, golden, tmp_path):
+    """the header DB of a concatenation is renumbered by the same rule as its sequence DB (rank in B's data file,
+    DBConcat.cpp:46-47,113-118) — plasship_orfhdr_read keeps the rank, plasship_orfhdr_concat applies it.  Reference-written header
+    DBs of two extractorfs passes (key order) and one with a shuffled data file, each against the reference's own concatdbs;
+    through the C-ABI and through the command line."""
+    import subprocess
+    c = os.path.join(golden, "concat")
+    hip = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plass_amd", "plass-hip")
+    for bname, cname in (("B_h", "C_h"), ("Bs_h", "Cs_h")):
+        a = ctx.read_orfhdr(f"{c}/A_h"); b = ctx.read_orfhdr(f"{c}/{bname}")
+        out = ctx.concatdbs(a, b)
+        out.write(tmp_path / ("o_" + cname))
+        assert_same_db(f"{c}/{cname}", tmp_path / ("o_" + cname), f"header concatdbs {bname}")
+        p = subprocess.run([hip, "concatdbs", f"{c}/A_h", f"{c}/{bname}", str(tmp_path / ("cli_" + cname))], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert p.returncode == 0, p.stdout
+        assert_same_db(f"{c}/{cname}", tmp_path / ("cli_" + cname), f"plass-hip concatdbs {bname}")
+    from conftest import read_db
+    assert read_db(f"{c}/C_h")[1] != read_db(f"{c}/Cs_h")[1]            # the order of the file matters
+    # the nucleotide ORFs of the same passes
+    a = ctx.read_seqdb(f"{c}/A"); b = ctx.read_seqdb(f"{c}/B")
+    out = ctx.concatdbs(a, b); out.write(tmp_path / "n")
+    assert_same_db(f"{c}/C", tmp_path / "n", "concatdbs of the nucleotide ORF DBs")

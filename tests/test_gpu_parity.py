@@ -86,6 +86,21 @@ def test_golden_nucl_kmermatcher_rescore(ctx, golden, tmp_path, it):
     assert_same_db(f"{s}/aln_{it}", tmp_path / "aln", "nucl rescorediagonal")
 
 
+def test_golden_nucleotide_strand_ties(ctx, golden, tmp_path):
+    """a (rep, target, diagonal) triple with records of both strands: the pair's strand is that of the member with the largest k-mer
+    (the reference's effective order, kmermatcher.h:98-130 / kmermatcher.cpp:866-893; tests/golden/make_strand_ties.py) — the
+    reference's pref and aln DBs"""
+    import plass_amd
+    s = os.path.join(golden, "strand_ties")
+    db = ctx.read_seqdb(f"{s}/seq_0")
+    cands, _ = ctx.kmermatcher(db, km_params(0, nucl=True))
+    cands.write(tmp_path / "pref")
+    assert_same_db(f"{s}/pref_0", tmp_path / "pref", "strand ties kmermatcher")
+    alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+    alns.write(tmp_path / "aln")
+    assert_same_db(f"{s}/aln_0", tmp_path / "aln", "strand ties rescorediagonal")
+
+
 def nucl_as_params():
     import plass_amd
     return plass_amd.AssembleParams(min_seq_id=0.99, max_seq_len=200000)
@@ -201,6 +216,33 @@ def gd_km_params():
 def gd_rs_params():
     import plass_amd
     return plass_amd.RescoreParams(min_seq_id=0.97, cov_mode=1, a=True)
+
+
+def test_synthetic_hairpin_genome_strand_ties_vs_oracle(ctx, oracle_bin, tmp_path):
+    """20 k read pairs of a genome with 40 planted inverted repeats at 30x: dozens of (rep, target, diagonal) triples hold records of
+    both strands, in hub queries with many targets, over two iterations (contig-contig ties in the second) — every DB against the oracle,
+    and the oracle must have met ties (its log says so)"""
+    import plass_amd
+    from plass_amd import synth
+    reads, _ = synth.nucleotide_hairpin_reads(20000, 40, seed=23, coverage=30.0)
+    data, off, elen, key = synth.fixed_length_db(reads)
+    synth.write_db(str(tmp_path / "o_seq_0"), data, off, elen, key, 1)
+    db = ctx.upload_seqdb(data, off, elen, key, 1)
+    ties = 0
+    for it in range(2):
+        log = run_oracle(oracle_bin, ["kmermatcher", tmp_path / f"o_seq_{it}", tmp_path / f"o_pref_{it}"] + NUCL_KM)
+        ties += sum(int(l.split(": ", 1)[1].split()[0]) for l in log.splitlines() if "hold both strands" in l)
+        run_oracle(oracle_bin, ["rescorediagonal", tmp_path / f"o_seq_{it}", tmp_path / f"o_seq_{it}", tmp_path / f"o_pref_{it}", tmp_path / f"o_aln_{it}"] + NUCL_RS)
+        run_oracle(oracle_bin, ["nuclassembleresults", tmp_path / f"o_seq_{it}", tmp_path / f"o_aln_{it}", tmp_path / f"o_seq_{it + 1}"] + NUCL_AS)
+        cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+        cands.write(tmp_path / "g_pref")
+        assert_same_db(tmp_path / f"o_pref_{it}", tmp_path / "g_pref", f"hairpin kmermatcher it{it}")
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+        db2, _ = ctx.assembleresults(db, alns, nucl_as_params())
+        db2.write(tmp_path / "g_seq")
+        assert_same_db(tmp_path / f"o_seq_{it + 1}", tmp_path / "g_seq", f"hairpin nuclassembleresults it{it}")
+        db = db2
+    assert ties >= 10, "the read set holds no strand ties: the test does not reach the rule it is for"
 
 
 def test_golden_guided_modules(ctx, golden, tmp_path):
@@ -526,6 +568,38 @@ def test_adversarial_inputs_vs_oracle(ctx, oracle_bin, tmp_path):
         out, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9))
         out.write(tmp_path / f"g_seq{it}")
         assert_same_db(tmp_path / f"o_seq{it}", tmp_path / f"g_seq{it}", "adversarial assembleresults")
+
+
+def test_protein_repeats_overflow_the_candidate_set(ctx, oracle_bin, tmp_path):
+    """every window whose score is <= the threshold score is a candidate and equal k-mers share a score, so a
+    homopolymer or tandem repeat of >= ~85 residues overfills the 128-entry candidate set of the protein tiers whenever its k-mer
+    lies at or below the threshold.  The extraction's overflow count is checked late on protein DBs (no extra wait); such a
+    sequence must then restart the call with the HBM-scratch launch, not leave its slots unwritten.  20 homopolymers, tandem
+    repeats of period 2..7, four hash seeds — against the oracle, and the path must have been taken."""
+    rng = np.random.default_rng(11)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    rnd = lambda n: "".join(rng.choice(list(aa), size=n))
+    seqs = []
+    for ch in aa:
+        seqs.append(rnd(110) + ch * 200 + rnd(110))
+    for unit in ("GP", "GPP", "QAQS", "KDELK", "STSTPA", "GAGAGSG"):
+        seqs.append(rnd(90) + unit * (420 // len(unit)) + rnd(90))
+    base = seqs[3]
+    for i in range(60):                                      # reads over the flanks, so that the repeats' neighbours have candidates
+        p = int(rng.integers(0, len(base) - 80)); seqs.append(base[p:p + int(rng.integers(50, 80))])
+    _write_fasta_like_db(tmp_path / "seq", seqs, 0)
+    db = ctx.read_seqdb(tmp_path / "seq")
+    scratch = restarts = 0
+    for hs in (67, 68, 69, 70):
+        for ext in (0, 1):
+            run_oracle(oracle_bin, ["kmermatcher", tmp_path / "seq", tmp_path / "o_pref"] + AA_KM + ["--hash-shift", str(hs), "--include-only-extendable", str(ext)])
+            par = km_params(0); par.hash_shift = hs; par.include_only_extendable = bool(ext)
+            cands, st = ctx.kmermatcher(db, par)
+            cands.write(tmp_path / "g_pref")
+            assert_same_db(tmp_path / "o_pref", tmp_path / "g_pref", f"repeats, hash shift {hs}, extendable {ext}")
+            scratch += st.n_scratch_sequences; restarts += st.n_restarts
+            cands.free()
+    assert scratch > 0 and restarts > 0, "no sequence overflowed the candidate set: the test does not reach the path it is for"
 
 
 def test_empty_and_singleton_db(ctx, oracle_bin, tmp_path):

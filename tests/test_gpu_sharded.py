@@ -126,6 +126,32 @@ def test_sharded_golden_nucl_chained(ctxs, golden, tmp_path):
             assert_same_db(f"{s}/seq_{it + 1}", tmp_path / f"r{r}_seq_{it + 1}", f"nucl rank {r}, iteration {it}")
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_nucleotide_strand_ties(ctxs, golden, tmp_path, world):
+    """the strand of a mixed-strand triple when its records were grouped on DIFFERENT ranks: the triples travel with the rank word of
+    their top member (TripleX, kmermatch.hip) and the owner keeps the larger one — the reference's pref DB from every rank's share"""
+    s = os.path.join(golden, "strand_ties")
+    ref = ctxs[3]
+    expect = _cands_rows(ref.kmermatcher(ref.read_seqdb(f"{s}/seq_0"), km_params(0, nucl=True))[0])
+    ref.kmermatcher(ref.read_seqdb(f"{s}/seq_0"), km_params(0, nucl=True))[0].write(tmp_path / "single")
+    assert_same_db(f"{s}/pref_0", tmp_path / "single", "strand ties, single context")
+    res = _run(ctxs, world, lambda rank, ctx: _cands_rows(ctx.kmermatcher(ctx.read_seqdb(f"{s}/seq_0"), km_params(0, nucl=True))[0]))
+    _check_union(res, expect, f"strand ties, {world} ranks")
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_hairpin_genome_strand_ties(ctxs, tmp_path, world):
+    """many mixed-strand triples (a genome with planted inverted repeats) whose records are grouped on different ranks: the union of
+    the ranks' candidate lists equals the single-context list (which test_gpu_parity pins on the oracle)"""
+    from plass_amd import synth
+    reads, _ = synth.nucleotide_hairpin_reads(20000, 40, seed=23, coverage=30.0)
+    data, off, elen, key = synth.fixed_length_db(reads)
+    ref = ctxs[3]
+    expect = _cands_rows(ref.kmermatcher(ref.upload_seqdb(data, off, elen, key, 1), km_params(0, nucl=True))[0])
+    res = _run(ctxs, world, lambda rank, ctx: _cands_rows(ctx.kmermatcher(ctx.upload_seqdb(data, off, elen, key, 1), km_params(0, nucl=True))[0]))
+    _check_union(res, expect, f"hairpin strand ties, {world} ranks")
+
+
 def test_sharded_golden_long_nucl(ctxs, golden, tmp_path):
     """24-byte records (KmerPosition<int>), contigs of tens of kb, 3 ranks"""
     import plass_amd

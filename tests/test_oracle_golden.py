@@ -41,6 +41,21 @@ def test_oracle_nucl_iteration(oracle_bin, golden, tmp_path, it):
     assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "nuclassembleresults")
 
 
+def test_oracle_nucleotide_strand_ties(oracle_bin, golden, tmp_path):
+    """sort #2 compares (rep, target, diagonal) only (kmermatcher.h:98-130) and the strand of a candidate pair is that of the LAST
+    record of the best diagonal's run (kmermatcher.cpp:866-893): a DB on which a (rep, target, diagonal) triple holds records of both
+    strands, and what the unmodified reference wrote for it (identical at 1 and 8 threads; tests/golden/make_strand_ties.py).  Rounds
+    1-3's rule (reverse strand first) gets this pref entry wrong; `--oracle-old-strand-ties 1` still shows it."""
+    s = os.path.join(golden, "strand_ties")
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/seq_0", tmp_path / "pref"] + NUCL_KM)
+    assert_same_db(f"{s}/pref_0", tmp_path / "pref", "strand ties kmermatcher")
+    run_oracle(oracle_bin, ["rescorediagonal", f"{s}/seq_0", f"{s}/seq_0", f"{s}/pref_0", tmp_path / "aln"] + NUCL_RS)
+    assert_same_db(f"{s}/aln_0", tmp_path / "aln", "strand ties rescorediagonal")
+    run_oracle(oracle_bin, ["kmermatcher", f"{s}/seq_0", tmp_path / "pref_old"] + NUCL_KM + ["--oracle-old-strand-ties", "1"])
+    from conftest import read_db
+    assert read_db(tmp_path / "pref_old")[1] != read_db(f"{s}/pref_0")[1]
+
+
 @pytest.mark.parametrize("it", [0, 1])
 def test_oracle_long_nucleotide_contigs(oracle_bin, golden, tmp_path, it):
     """contigs of 17-36 kb that grow to 70 kb: KmerPosition<int> records and the +-65 536 diagonal wrap-around of the 16-bit
@@ -234,3 +249,10 @@ def test_oracle_concatdbs_follows_the_data_file_order(oracle_bin, golden, tmp_pa
     assert any(a[1] > b[1] for a, b in zip(idx, idx[1:])), "the fixture must hold a DB whose file order is not its key order"
     run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "aaA"), os.path.join(c, "aaB"), tmp_path / "out"])
     assert_same_db(os.path.join(c, "aaC"), tmp_path / "out", "concatdbs on thread-ordered inputs")
+    # the header DBs of the same passes (key order as extractorfs leaves them), and one whose data file is shuffled
+    run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "A_h"), os.path.join(c, "B_h"), tmp_path / "h"])
+    assert_same_db(os.path.join(c, "C_h"), tmp_path / "h", "concatdbs of the header DBs")
+    run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "A_h"), os.path.join(c, "Bs_h"), tmp_path / "hs"])
+    assert_same_db(os.path.join(c, "Cs_h"), tmp_path / "hs", "concatdbs of a header DB in shuffled file order")
+    run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "A"), os.path.join(c, "B"), tmp_path / "n"])
+    assert_same_db(os.path.join(c, "C"), tmp_path / "n", "concatdbs of the nucleotide ORF DBs")
