@@ -339,8 +339,9 @@ def main():
                 i = db.info(); print("step %d iteration %d: %d sequences, %d residues, longest entry %d" % (s, it, i["n"], i["residues"], i["max_entry_len"]), file=sys.stderr, flush=True)
             out, kst, rst, ast, wall = one_iteration(ctx, db, it)
             if VERBOSE and rank == 0:
-                print("   N_k=%d N_m=%d N_c=%d | scored=%d accepted=%d | aln=%d extended=%d rescored=%d | wall ms %s" % (
-                    kst.n_kmer_records, kst.n_grouped, kst.n_candidates, rst.n_scored, rst.n_accepted, ast.n_alignments, ast.n_extended, ast.n_rescored,
+                print("   N_k=%d N_m=%d N_c=%d cached=%d extract %.1f (short %.1f wave %.1f) | scored=%d accepted=%d | aln=%d extended=%d rescored=%d | wall ms %s" % (
+                    kst.n_kmer_records, kst.n_grouped, kst.n_candidates, kst.n_cached_sequences, kst.ms_extract, kst.ms_extract_short_kernel, kst.ms_extract_wave_kernel,
+                    rst.n_scored, rst.n_accepted, ast.n_alignments, ast.n_extended, ast.n_rescored,
                     ["%.1f" % x for x in wall[:3]]), file=sys.stderr, flush=True)
             if record:
                 ctx.sync()

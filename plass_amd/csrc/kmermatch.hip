@@ -74,6 +74,7 @@ __global__ void boundsKernel(const uint32_t *__restrict__ len, uint32_t n, int k
 struct Cand { uint64_t kmer; uint32_t pos; uint32_t score; };   // score: low 16 bits hash, bit 31 = skipped
 constexpr uint32_t KMC_LINE = 128, KMC_POS = 60;                // selected-window cache (section 2c): bytes per sequence, positions per line
 
+#define FALLBACK_NOSTATS(a) ((a).kstats == nullptr)       // the scratch launch that re-extracts one sequence for the stale-record check: no statistics, no cache
 struct ExtractArgs {
     SeqView s;
     const uint64_t *slotOff;        // [n+1]
@@ -92,9 +93,10 @@ struct ExtractArgs {
     uint64_t slotBias;              // subtracted from every slot offset (re-extraction of one sequence into a scratch array;
                                     // sharded run: first slot of this rank's id range)
     uint32_t idLo, idHi;            // regular launch without a wave list: ids [idLo, idHi) (sharded run: this rank's share)
-    unsigned char *cacheLines;      // selected-window cache (section 2c): line id * 128 is rewritten for every sequence a wave kernel handles; nullptr = no cache
-    int fillOnOverflow;             // last tier: a sequence handed to the HBM-scratch launch leaves its slots as sentinels (the host may learn of
-                                    // the hand-over only after the partition has read the array: kmermatchImpl, `overflowPossible`)
+    // One more input travels OUTSIDE this struct — the tuned tiers are at the edge of their register budgets (round 4: a block of code
+    // that filled an overflowing sequence's slots with sentinels cost the 4-scores tier 40 bytes of scratch per lane and 8-13 ms per
+    // iteration; that fill is a kernel of its own now, fillOverflowSlotsKernel):
+    //   kstats[4] = address of the selected-window cache lines (section 2c; 0 = no cache), fetched per sequence where it is used.
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     __shared__ __attribute__((aligned(16))) unsigned char sCodeAll[FALLBACK ? 1 : CODES];          // codes of a resident sequence
     __shared__ unsigned long long sPow64[(REGS > 0 && !FALLBACK) ? REGS + 2 : 1];                  // 31^(64 q) (identity hash of the register front end)
     __shared__ unsigned long long sValid[RESL / 64 + 2];             // per-tile validity masks
+    __shared__ unsigned short sKmcPos[64];                           // positions of the ordered path's selection, for the cache line (section 2c)
     typedef Rec<LONG> R;
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
@@ -320,10 +323,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         const uint32_t nWin = (L >= (uint32_t) k) ? (L - k + 1) : 0;
         const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));   // kmermatcher.cpp:223
         const bool allCand = (size_t) nWin <= consideredRaw;
-        auto fillSentinels = [&]() { if (a.fillOnOverflow) for (uint32_t i = lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; } };
         if (!FALLBACK && std::min((size_t) nWin, consideredRaw) > (size_t) cap) {       // cannot fit this instantiation's LDS: next tier
             if (lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
-            fillSentinels();
             continue;
         }
 
@@ -543,7 +544,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         }      // three-pass path
         if (overflow) {
             if (!FALLBACK && lane == 0) { const uint32_t o = atomicAdd(a.overflowCount, 1u); a.overflowIds[o] = id; }
-            if (!FALLBACK) fillSentinels();
             __syncthreads();
             continue;
         }
@@ -578,6 +578,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
             }
         }
         if (!needOrder) {
+            // (selected-window cache, section 2c: the positions — C <= 59 here, no surplus — and the identity hash go to the sequence's line
+            //  from the registers that hold them for the records; a separate block cost the tuned tiers 40 bytes of scratch per lane)
             for (uint32_t i = lane; i < C; i += 64) {
                 const Cand cd = cand[i];
                 R r; r.kmer = cd.kmer; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) cd.pos;
@@ -590,10 +592,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 arr[slot] = r;
             }
             for (uint32_t i = 1 + C + lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; }
-            if (!LONG && a.cacheLines) {       // the selected windows (C <= 59 here: no surplus) and the identity hash, for the next call with this seed
-                unsigned short *ln = reinterpret_cast<unsigned short *>(a.cacheLines + (size_t) id * KMC_LINE);
-                if ((uint32_t) lane < KMC_POS) ln[4 + lane] = ((uint32_t) lane < C) ? (unsigned short) cand[lane].pos : (unsigned short) 0xFFFFu;
-                if (lane == 0) *reinterpret_cast<unsigned long long *>(ln) = xxh64U64(seqHash, a.seed);
+            if (!LONG && !FALLBACK_NOSTATS(a)) {
+                unsigned char *cl = reinterpret_cast<unsigned char *>(a.kstats[4]);
+                if (cl) {
+                    unsigned short *ln = reinterpret_cast<unsigned short *>(cl + (size_t) id * KMC_LINE);
+                    if ((uint32_t) lane < KMC_POS) ln[4 + lane] = ((uint32_t) lane < C) ? (unsigned short) cand[lane].pos : (unsigned short) 0xFFFFu;
+                    if (lane == 0) *reinterpret_cast<unsigned long long *>(ln) = xxh64U64(seqHash, a.seed);
+                }
             }
             stRes += L; stRec += 1 + C;
             __syncthreads();
@@ -633,7 +638,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         }
         // ---- selection walk (kmermatcher.cpp:274-347) as prefix counts over the sorted candidates ----
         uint32_t binCarry = 0, selCarry = 0;
-        unsigned short *cacheLn = (!LONG && a.cacheLines) ? reinterpret_cast<unsigned short *>(a.cacheLines + (size_t) id * KMC_LINE) : nullptr;
         for (uint32_t c0 = 0; c0 < C; c0 += 64) {
             const uint32_t i = c0 + lane;
             Cand cd; cd.kmer = 0; cd.pos = 0; cd.score = 0x80000000u;
@@ -650,14 +654,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 R r; r.kmer = cd.kmer; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) cd.pos;
                 if constexpr (LONG) r.pad = 0;
                 arr[slot + 1 + selRank] = r;
-                if (cacheLn && selRank < KMC_POS) cacheLn[4 + selRank] = (unsigned short) cd.pos;
+                if (selRank < 64u) sKmcPos[selRank] = (unsigned short) cd.pos;       // (for the selected-window cache line below)
             }
             binCarry += (uint32_t) __popcll(mb); selCarry += (uint32_t) __popcll(ms);
         }
         const uint32_t numSel = (uint32_t) min((size_t) selCarry, considered);
-        if (cacheLn) {
-            if ((uint32_t) lane < KMC_POS && (uint32_t) lane >= numSel) cacheLn[4 + lane] = (unsigned short) 0xFFFFu;
-            if (lane == 0) *reinterpret_cast<unsigned long long *>(cacheLn) = xxh64U64(seqHash, a.seed);
+        if (!LONG && !FALLBACK_NOSTATS(a)) {
+            unsigned char *cl = reinterpret_cast<unsigned char *>(a.kstats[4]);
+            if (cl) {
+                __syncthreads();
+                unsigned short *ln = reinterpret_cast<unsigned short *>(cl + (size_t) id * KMC_LINE);
+                if ((uint32_t) lane < KMC_POS) ln[4 + lane] = ((uint32_t) lane < numSel) ? sKmcPos[lane] : (unsigned short) 0xFFFFu;
+                if (lane == 0) *reinterpret_cast<unsigned long long *>(ln) = xxh64U64(seqHash, a.seed);
+            }
         }
         if (lane == 0) {   // identity record (kmermatcher.cpp:241-249)
             R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
@@ -961,7 +970,7 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
 //     d_changed) here instead: the k-mers at the cached positions are rebuilt from the sequence's bytes and the records written — no
 //     window is hashed, nothing is selected.  Protein DBs with --kmer-per-seq <= 60 and no length scaling (the Plass workflow) only:
 //     that is where a line holds every selected window.  The record set is exactly what the full kernels write (tests: the chained
-//     iterations of every protein parity test pass through here; PLASSHIP_TUNE_KMCACHE=0 switches it off).
+//     iterations of every protein parity test pass through here; PLASSHIP_TUNE_KMCACHE=2 switches it off).
 // =====================================================================================================
 struct CachedArgs {
     SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map; const unsigned char *lines;
@@ -976,33 +985,58 @@ __global__ __launch_bounds__(64) void extractCachedKernel(CachedArgs a) {
     __syncthreads();
     const uint32_t nWork = *a.count;
     unsigned long long stRes = 0, stRec = 0;
-    uint32_t idNext = blockIdx.x < nWork ? a.list[blockIdx.x] : 0u;
-    for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
-        const uint32_t id = idNext;
-        if (w + gridDim.x < nWork) idNext = a.list[w + gridDim.x];
-        const uint32_t L = a.s.len[id];
-        const char *base = a.s.data + a.s.off[id];
-        const uint64_t slot = a.slotOff[id] - a.slotBias;
-        const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
+    // A sequence is a chain of dependent round trips (list entry -> index entry and cache line -> the windows' bytes -> the records):
+    // the list entry of sequence w + 2 * grid, and index entry, slot range and cache line of sequence w + grid, are in flight while
+    // sequence w is written, so one round trip per sequence — its bytes — is left on the critical path.
+    struct Meta { uint32_t id, L, pos; uint64_t off, slot, slot1; unsigned long long idh; };
+    auto loadMeta = [&](uint32_t id) {
+        Meta m; m.id = id; m.L = a.s.len[id]; m.off = a.s.off[id]; m.slot = a.slotOff[id] - a.slotBias; m.slot1 = a.slotOff[id + 1] - a.slotBias;
         const unsigned short *ln = reinterpret_cast<const unsigned short *>(a.lines + (size_t) id * KMC_LINE);
-        const uint32_t pos = ((uint32_t) lane < KMC_POS) ? (uint32_t) ln[4 + lane] : 0xFFFFu;
-        const bool have = pos != 0xFFFFu;
+        m.pos = ((uint32_t) lane < KMC_POS) ? (uint32_t) ln[4 + lane] : 0xFFFFu;
+        m.idh = *reinterpret_cast<const unsigned long long *>(ln);
+        return m;
+    };
+    Meta nxt; nxt.id = 0; nxt.L = 0; nxt.pos = 0xFFFFu; nxt.off = 0; nxt.slot = 0; nxt.slot1 = 0; nxt.idh = 0;
+    uint32_t id2 = 0;
+    if (blockIdx.x < nWork) nxt = loadMeta(a.list[blockIdx.x]);
+    if (blockIdx.x + gridDim.x < nWork) id2 = a.list[blockIdx.x + gridDim.x];
+    for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
+        const Meta cur = nxt;
+        if (w + gridDim.x < nWork) nxt = loadMeta(id2);
+        if (w + 2 * gridDim.x < nWork) id2 = a.list[w + 2 * gridDim.x];
+        const char *base = a.s.data + cur.off;
+        const uint32_t bound = (uint32_t) (cur.slot1 - cur.slot);
+        const bool have = cur.pos != 0xFFFFu;
         const uint32_t n = (uint32_t) __popcll(__ballot(have));          // the positions fill the line from its front
         if (have) {
             // the 14 residues of the window (the entry is "SEQ\n\0": 16 bytes from pos <= L - 14 stay inside it), mapped to letter codes
-            uint64_t r0, r1; __builtin_memcpy(&r0, base + pos, 8); __builtin_memcpy(&r1, base + pos + 8, 8);
+            uint64_t r0, r1; __builtin_memcpy(&r0, base + cur.pos, 8); __builtin_memcpy(&r1, base + cur.pos + 8, 8);
             uint64_t w0 = 0, w1 = 0;
 #pragma unroll
             for (int b = 0; b < 8; b++) { w0 |= (uint64_t) sMap[(r0 >> (8 * b)) & 0xFF] << (8 * b); w1 |= (uint64_t) sMap[(r1 >> (8 * b)) & 0xFF] << (8 * b); }
             uint64_t kmer; (void) kmerIndexCore(w0, w1, a.k, (unsigned) a.xCode, a.base, a.base7, kmer);
-            R r; r.kmer = kmer; r.id = id; r.len = (uint16_t) L; r.pos = (int16_t) pos;
-            arr[slot + 1 + (uint32_t) lane] = r;
+            R r; r.kmer = kmer; r.id = cur.id; r.len = (uint16_t) cur.L; r.pos = (int16_t) cur.pos;
+            arr[cur.slot + 1 + (uint32_t) lane] = r;
         }
-        if (lane == 63) { R r; r.kmer = *reinterpret_cast<const unsigned long long *>(ln); r.id = id; r.len = (uint16_t) L; r.pos = 0; arr[slot] = r; }     // identity record (kmermatcher.cpp:241-249)
-        for (uint32_t i = 1 + n + (uint32_t) lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; }
-        stRes += L; stRec += 1 + n;
+        if (lane == 63) { R r; r.kmer = cur.idh; r.id = cur.id; r.len = (uint16_t) cur.L; r.pos = 0; arr[cur.slot] = r; }     // identity record (kmermatcher.cpp:241-249)
+        for (uint32_t i = 1 + n + (uint32_t) lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[cur.slot + i] = r; }
+        stRes += cur.L; stRec += 1 + n;
     }
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
+}
+
+// the sequences the last tier handed to the HBM-scratch launch: their slots become sentinels.  (Protein runs learn of such a hand-over
+// only with the group stage's counts — kmermatchImpl, `overflowPossible` — and start over then; until that point the partition and
+// the group kernel read defined bytes.)  One wavefront per queued sequence; the queue is almost always empty.
+template <bool LONG>
+__global__ __launch_bounds__(64) void fillOverflowSlotsKernel(const uint32_t *__restrict__ ids, const uint32_t *__restrict__ count, const uint64_t *__restrict__ slotOff, uint64_t slotBias, void *arrV) {
+    Rec<LONG> *arr = reinterpret_cast<Rec<LONG> *>(arrV);
+    const uint32_t n = *count;
+    for (uint32_t w = blockIdx.x; w < n; w += gridDim.x) {
+        const uint32_t id = ids[w];
+        const uint64_t s0 = slotOff[id] - slotBias, s1 = slotOff[id + 1] - slotBias;
+        for (uint64_t i = s0 + threadIdx.x; i < s1; i += 64) { Rec<LONG> r; memset(&r, 0xFF, sizeof(r)); arr[i] = r; }
+    }
 }
 
 __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t *__restrict__ idx, uint32_t n, uint32_t *__restrict__ dst) {
@@ -2458,7 +2492,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_CHECK(hipMemcpyAsync(dTCap.p, &cap, 4, hipMemcpyHostToDevice, st));
         PH_CHECK(hipMemsetAsync(dDiff.p, 0, ((size_t) tb + 1) * 8, st));
         // re-extract the records of T into a scratch array with the very kernel that produced them
-        ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0]; ta.cacheLines = nullptr;
+        ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
         ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(1), dim3(64), 0, st, ta);
         std::vector<R> trec(tb);
@@ -2756,28 +2790,30 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     static const bool tier0 = [] { const char *e = getenv("PLASSHIP_TIER0"); return e ? atoi(e) != 0 : true; }();
     constexpr uint32_t TIER0_WINDOWS = 256;                  // 4 scores per lane (an 8-scores tier at 5 wavefronts per SIMD gained 0.3 %: not kept)
     if (dWaveList.alloc(((size_t) N + 1) * 4) != hipSuccess || dWaveCount.alloc(4) != hipSuccess || dLongList.alloc(((size_t) N + 1) * 4) != hipSuccess || dLongCount.alloc(4) != hipSuccess ||
-        dKStats.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        dKStats.alloc(64) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dWaveCount.p, 0, 4, st));
     PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 4, st));
-    PH_CHECK(hipMemsetAsync(dKStats.p, 0, 32, st));
+    PH_CHECK(hipMemsetAsync(dKStats.p, 0, 64, st));
     ea.kstats = dKStats.as<unsigned long long>();
     // ---- selected-window cache (section 2c): which sequences keep last call's selection, and where this call's selection is kept ----
     plasship_ctx::KmCache &kc = ctx->kmCache;
     const bool fastIndex = !NUCL && k <= 14 && ea.powers[1] <= 16;      // kmerIndexCore
     const bool cacheEligible = !NUCL && !LONG && !cm && fastIndex && k <= 16 && par->kmers_per_seq >= 1 && par->kmers_per_seq <= (int) KMC_POS && par->kmers_per_seq_scale == 0.0f &&
-                               tuneInt("KMCACHE", 1) != 0;
+                               tuneInt("KMCACHE", 1) == 1;      // PLASSHIP_TUNE_KMCACHE=2 switches the cache off
     const bool cacheReuse = cacheEligible && kc.valid && kc.n == N && kc.gen == db->parentGen && db->d_changed.p && kc.k == k && kc.alph == par->alphabet_size &&
                             kc.kps == par->kmers_per_seq && kc.ignoreMulti == par->ignore_multi_kmer && kc.hashShift == par->hash_shift && !overflowCheckEarly;
     kc.valid = false;                                         // (set again when this call has succeeded)
     DevBuf dCachedList, dCachedCount;
+    unsigned long long cacheLinesPtr = 0;                    // -> kstats[4] (see ExtractArgs)
     if (cacheEligible && N) {
         if (kc.lines.bytes < (size_t) N * KMC_LINE) { kc.lines.release(); if (kc.lines.alloc((size_t) N * KMC_LINE) != hipSuccess) { setError("kmermatch: out of device memory for the selected-window cache"); return PLASSHIP_ERR_DEVICE; } }
-        ea.cacheLines = kc.lines.as<unsigned char>();
+        cacheLinesPtr = (unsigned long long) (uintptr_t) kc.lines.p;
         if (cacheReuse) {
             if (dCachedList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCachedCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
             PH_CHECK(hipMemsetAsync(dCachedCount.p, 0, 4, st));
         }
     } else kc.lines.release();
+    PH_CHECK(hipMemcpyAsync(dKStats.as<unsigned long long>() + 4, &cacheLinesPtr, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     bool twoLists = false;
     if (!NUCL && k <= 16 && nMine) {
@@ -2844,7 +2880,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 16u))), dim3(64), 0, st, e2);
         PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));            // tier 2 has consumed the first queue: it becomes tier 3's output queue
         ExtractArgs e3 = ea; e3.waveList = dOv2Ids.as<uint32_t>(); e3.waveCount = dOv2Cnt.as<uint32_t>();
-        e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>(); e3.fillOnOverflow = 1;
+        e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>();
         hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 2u : 5u))), dim3(64), 0, st, e3);
     }
     // what the last stage could not hold either (candidate sets beyond LDS)
@@ -2861,7 +2897,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (nMine && overflowPossible) {
         PH_CHECK(hipMemcpyAsync(&nOv, dLastCnt.p, 4, hipMemcpyDeviceToHost, st));
         PH_CHECK(plasship::streamSync(st));
-    }
+    } else if (nMine) hipLaunchKernelGGL((fillOverflowSlotsKernel<LONG>), dim3(64), dim3(64), 0, st, (const uint32_t *) dLastIds.as<uint32_t>(), (const uint32_t *) dLastCnt.as<uint32_t>(),
+                                         (const uint64_t *) dSlotOff.as<uint64_t>(), slotBias, dA.p);
     PH_CHECK(hipGetLastError());
     if (nOv) {   // sequences whose candidate set did not fit LDS: same kernel, candidates in HBM scratch
         std::vector<uint32_t> ids(nOv), lens(nOv);

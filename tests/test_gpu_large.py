@@ -73,6 +73,61 @@ def test_large_chain_against_oracle_checksums(tmp_path):
         ctx.close()
 
 
+@pytest.mark.timeout(1500)
+def test_offsets_beyond_4gib_against_oracle_checksums(tmp_path):
+    """A DB whose data exceeds 2^32 bytes, every live sequence ABOVE that mark (missing #3): 560 000 filler sequences of
+    8 000 random residues (4.48 GB; nothing overlaps them, each contributes its 59 lowest-hash k-mers and is carried through), then the
+    protein fragments of 1 M reads of the configs[2] community — concatdbs filler fragments — and three iterations of the chain, every DB
+    against the digests the CPU oracle computed for the same DB (tests/golden/big_offsets.json, made by tests/golden/make_big_offsets.py).
+    All lengths stay below 32 767: the 16-byte records, the thread- and wave-per-sequence extraction tiers, rescoreKernel, the extension
+    kernels and writeOutKernel of the HEADLINE configuration run here with byte offsets of 4.48 - 4.7 GB."""
+    import sys
+    import bench
+    import plass_amd
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import make_big_offsets as mk
+    gold = json.load(open(os.path.join(HERE, "golden", "big_offsets.json")))
+    assert (gold["filler"]["n"], gold["filler"]["length"], gold["filler"]["seed"]) == (mk.FILLERS, mk.FILLER_LEN, mk.FILLER_SEED)
+    sp = bench.synth_params(gold["config"], gold["pairs"])
+    for k, v in gold["synth"].items():
+        assert getattr(sp, k) == pytest.approx(v), k
+    ctx = plass_amd.Context(0)
+    try:
+        fb = mk.write_filler_db(str(tmp_path / "filler"))
+        assert fb == gold["filler"]["bytes"] and fb > (1 << 32)
+        filler = ctx.read_seqdb(tmp_path / "filler")
+        assert filler.digest() == (gold["filler_db"]["digest"], gold["filler_db"]["bytes"]), "the filler sequences differ from the generator's in the build container"
+        for sfx in ("", ".index", ".dbtype"):
+            os.remove(str(tmp_path / "filler") + sfx)
+        reads, _ = ctx.synth_read_pairs(sp)
+        live = ctx.plass_fragments(reads)
+        reads.free()
+        assert live.digest() == (gold["live"]["digest"], gold["live"]["bytes"])
+        db = ctx.concatdbs(filler, live)
+        filler.free(); live.free()
+        assert db.digest() == (gold["db"]["digest"], gold["db"]["bytes"]) and db.info()["max_entry_len"] < 32767
+        for it, want in enumerate(gold["iterations"]):
+            par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=bench.hash_shift(it),
+                                            include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
+            cands, kst = ctx.kmermatcher(db, par)
+            cands.write(tmp_path / "pref")
+            check(tmp_path / "pref", want["pref"], "kmermatcher, iteration %d" % it)
+            alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5))
+            cands.free()
+            alns.write(tmp_path / "aln")
+            check(tmp_path / "aln", want["aln"], "rescorediagonal, iteration %d" % it)
+            out, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
+            alns.free(); db.free()
+            assert ast.n_extended > 10000                    # live sequences (all above 2^32) were extended and written
+            assert out.digest() == (want["seq"]["digest"], want["seq"]["bytes"]), "device digest of seq_%d" % (it + 1)
+            db = out
+        db.write(tmp_path / "seq")                           # the DB writer on > 4 GiB of entries, once
+        check(tmp_path / "seq", gold["iterations"][-1]["seq"], "assembleresults, last iteration (DB files)")
+        db.free()
+    finally:
+        ctx.close()
+
+
 def test_split_data_files_and_text_round_trips(tmp_path, golden):
     """host boundary on the GPU box: a sequence DB whose data is split over NAME.0..NAME.2 (the reference's unmerged writer files) loads
     like the merged one; prefilter / alignment DBs written by the threaded writers parse back to the same lists (write -> read -> write
