@@ -116,7 +116,7 @@ def one_iteration(ctx, db, it):
     return out, kst, rst, ast, ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s1 - s0, s2 - s1, s3 - s2)
 
 
-def stage_table(kst, rst, ast):
+def stage_table(kst, rst, ast, nucl_queue=False):
     """per kernel / stage: (HIP-event ms, algorithmic bytes per SURVEY.md section 8d, is_single_kernel, launches).
     The hash partition (the reference's sort #1, ideal traffic 2*s*N_k = one read + one write of the records) runs as several
     partition-kernel launches: the kernel is listed on its own with the stage's ideal bytes split over its launches, so every
@@ -137,8 +137,13 @@ def stage_table(kst, rst, ast):
     # round trips in between count): the number the north star's "achieved HBM bandwidth in kmermatcher" refers to
     t["kmermatcher_stage"] = (kst.ms_extract + kst.ms_sort1 + kst.ms_group + kst.ms_sort2 + kst.ms_reduce,
                               kst.residues + 4 * s * Nk + 4 * s * Nm + 12 * Nc, False, 1)
-    for i, (name, single) in enumerate((("assembleGroupKernel<16>", True), ("assembleGroupKernel<32>+<64>", False), ("assembleBigKernel", True))):
-        t[name] = (ast.ms_tier_kernel[i], 32 * ast.tier_alignments[i] + 2 * ast.tier_query_residues[i] + 2 * ast.tier_rescored_residues[i], single, 1)
+    if nucl_queue:
+        # nuclassembleresults / guidedassembleresults: the heap-replay queue kernels (one thread per query up to 256 hits, one wavefront
+        # per query beyond, re-runs of the queries that met an unknown comparator tuple) are timed as ONE interval (assemble.hip)
+        t["assembleNuclKernel(+assembleNuclThreadKernel, all passes)"] = (ast.ms_tier_kernel[0], 32 * ast.tier_alignments[0] + 2 * ast.tier_query_residues[0] + 2 * ast.tier_rescored_residues[0], True, 1)
+    else:
+        for i, (name, single) in enumerate((("assembleGroupKernel<16>", True), ("assembleGroupKernel<32>+<64>", False), ("assembleBigKernel", True))):
+            t[name] = (ast.ms_tier_kernel[i], 32 * ast.tier_alignments[i] + 2 * ast.tier_query_residues[i] + 2 * ast.tier_rescored_residues[i], single, 1)
     # the other two modules as whole stages, against SURVEY.md section 8d's B_R = (12 + 2 ov + 32) N_c and B_A = 32 N_aln + 2 R + 2 ov N_resc
     # (every kernel of the module: work lists, compaction, the extension tiers, writing the next DB)
     t["rescore_stage"] = (rst.ms_kernel, 12 * rst.n_scored + 2 * rst.overlap_residues + 32 * rst.n_scored, False, 1)
@@ -160,21 +165,26 @@ def source_sha():
 
 # rocprofv3 names of the kernels behind a row of the stage table (all instantiations of a template are one row)
 KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShort(Fast)?Kernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
-                  "partitionKernel(k-mer records)": "linePartKernel<.*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel"}
+                  "partitionKernel(k-mer records)": "linePartKernel<.*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel",
+                  "assembleNuclKernel(+assembleNuclThreadKernel, all passes)": "assembleNucl(Thread)?Kernel<"}
+PMC_FILES = {"c3": "r03_pmc_traffic.json", "c5": "r04_pmc_traffic_c5.json"}      # (c3: replaced by the round-4 pass when it has run)
 
 
-def stored_traffic(kernel, launches_per_step):
+def stored_traffic(kernel, launches_per_step, cfg="c3"):
     """(HBM bytes per launch of `kernel` — all its instantiations together — from the stored PMC passes of the driver's command, note).
-    profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes, FETCH_SIZE doubled as
+    profiles/r04_pmc_traffic[_c5].json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950; the file records the hash of the sources it was measured on and is refused for any
     other code.  A stored figure, not measured in this run: PMC collection serialises the kernels."""
-    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    name = PMC_FILES.get(cfg)
+    if name is None:
+        return None, "no PMC pass is stored for --config %s" % cfg
+    f = os.path.join(ROOT, "profiles", name)
     try:
         rows = json.load(open(f))
     except (OSError, ValueError):
-        return None, "no stored PMC profile (profiles/r03_pmc_traffic.json)"
+        return None, "no stored PMC profile (profiles/%s)" % name
     if rows.get("source_sha") != source_sha():
-        return None, "profiles/r03_pmc_traffic.json was taken from other sources (%s, this build %s): not quoted" % (rows.get("source_sha"), source_sha())
+        return None, "profiles/%s was taken from other sources (%s, this build %s): not quoted" % (name, rows.get("source_sha"), source_sha())
     pat = KERNEL_SYMBOLS.get(kernel, re.escape(re.sub(r"[<(].*", "", kernel)) + "[<(]")
     tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for name, r in rows.get("kernels", {}).items() if re.search(pat, name))
     steps = rows.get("steps", 0)
@@ -339,9 +349,9 @@ def main():
                 i = db.info(); print("step %d iteration %d: %d sequences, %d residues, longest entry %d" % (s, it, i["n"], i["residues"], i["max_entry_len"]), file=sys.stderr, flush=True)
             out, kst, rst, ast, wall = one_iteration(ctx, db, it)
             if VERBOSE and rank == 0:
-                print("   N_k=%d N_m=%d N_c=%d cached=%d extract %.1f (short %.1f wave %.1f) | scored=%d accepted=%d | aln=%d extended=%d rescored=%d | wall ms %s" % (
+                print("   N_k=%d N_m=%d N_c=%d cached=%d extract %.1f (short %.1f wave %.1f) | scored=%d accepted=%d | aln=%d extended=%d rescored=%d db +%.2f GB / copy %.2f GB asm %.1f | wall ms %s" % (
                     kst.n_kmer_records, kst.n_grouped, kst.n_candidates, kst.n_cached_sequences, kst.ms_extract, kst.ms_extract_short_kernel, kst.ms_extract_wave_kernel,
-                    rst.n_scored, rst.n_accepted, ast.n_alignments, ast.n_extended, ast.n_rescored,
+                    rst.n_scored, rst.n_accepted, ast.n_alignments, ast.n_extended, ast.n_rescored, ast.db_appended_bytes / 1e9, ast.db_copied_bytes / 1e9, ast.ms_kernel,
                     ["%.1f" % x for x in wall[:3]]), file=sys.stderr, flush=True)
             if record:
                 ctx.sync()
@@ -384,7 +394,7 @@ def main():
             bytes_avg = tot[dom][1] / max(tot[dom][3], 1)
             achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
             km = tot["kmermatcher_stage"]
-            traffic, traffic_note = stored_traffic(dom, tot[dom][3] / len(stats))
+            traffic, traffic_note = stored_traffic(dom, tot[dom][3] / len(stats), args.config)
             stage = lambda key: {"algorithmic_bytes_per_step": tot[key][1] / len(stats), "ms_per_step": tot[key][0] / len(stats),
                                  "frac": (tot[key][1] / (tot[key][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot[key][0] > 0 else 0.0}
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -575,7 +585,7 @@ def main_c5(args):
     st = {"reads": reads, "nu0": nu0, "aa0": aa0}
     ri, ni = reads.info(), nu0.info()
 
-    def run(n, record):
+    def run(n, record, digests=None):
         rows, total = [], 0
         for s_ in range(n):
             it = s_ % chain
@@ -584,6 +594,8 @@ def main_c5(args):
             if record:
                 ctx.sync()
                 rows.append((it, (time.perf_counter() - ts) * 1e3, kst, rst, ast, extra, kind)); total += kst.n_candidates
+            if digests is not None:                          # what the step left behind: the extended ORFs and their twins, or the non-circular contigs
+                digests.append("+".join(x.digest()[0] for x in ((st["nu"], st["aa"]) if kind == "guided" else (st["db"],))))
         return rows, total
 
     run(warmup, False)
@@ -592,15 +604,31 @@ def main_c5(args):
     rows, overlaps = run(steps, True)
     ctx.sync(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    # ---- untimed verification: one more traversal, digest of every step's output DB(s) against the committed digests of this workload
+    # (tests/golden/c5_chain_digests.json — the GPU path's own output, a regression pin; the same chains are checked against the CPU
+    # oracle at 5 M reads by tests/test_gpu_large_nucl.py) ----
+    verify = None
+    if not args.no_verify:
+        digests = []
+        run(chain, False, digests)
+        verify = {"step_digests": digests, "reference": None, "match": None}
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "c5_chain_digests.json")))
+        except (OSError, ValueError):
+            gold = None
+        if gold and gold.get("pairs") == sp.n_pairs:
+            verify["reference"] = "tests/golden/c5_chain_digests.json"
+            verify["match"] = digests == gold["digests"][:len(digests)]
     tot = {}
     for (_, _, k, r, a, extra, kind) in rows:
-        tab = stage_table(k, r, a)
+        tab = stage_table(k, r, a, nucl_queue=True)
         tab["proteinaln2nucl / cyclecheck"] = (extra, 0, False, 1)
         for key, (ms, b, single, launches) in tab.items():
             v = tot.setdefault(key, [0.0, 0, single, 0]); v[0] += ms; v[1] += b; v[3] += launches
     dom = max((k for k in tot if tot[k][2]), key=lambda k: tot[k][0])
     ms_avg = tot[dom][0] / max(tot[dom][3], 1); bytes_avg = tot[dom][1] / max(tot[dom][3], 1)
     achieved = bytes_avg / (ms_avg * 1e-3) / 1e9 if ms_avg > 0 else 0.0
+    traffic, traffic_note = stored_traffic(dom, tot[dom][3] / len(rows), "c5")
     stage = lambda key: {"algorithmic_bytes_per_step": tot[key][1] / len(rows), "ms_per_step": tot[key][0] / len(rows),
                          "frac": (tot[key][1] / (tot[key][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot[key][0] > 0 else 0.0}
     line = {"metric": "read-overlaps/s per assembly iteration", "value": overlaps / elapsed if elapsed > 0 else 0.0, "unit": "overlaps/s", "n_gpus": 1, "steps": steps, "warmup": warmup,
@@ -617,8 +645,8 @@ def main_c5(args):
                             "partition_ms": round(k.ms_sort1, 3), "group_ms": round(k.ms_group, 3), "repsort_ms": round(k.ms_sort2, 3), "reduce_ms": round(k.ms_reduce, 3),
                             "rescore_ms": round(r.ms_kernel, 3), "assemble_ms": round(a.ms_kernel, 3), "aln2nucl_or_cyclecheck_ms": round(extra, 3)}
                            for i, (it, ms, k, r, a, extra, kind) in enumerate(rows)],
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "traffic_note": "no PMC pass stored for --config c5", "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_note": traffic_note, "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg,
                          "stage_ms_per_step": {k: round(v[0] / len(rows), 4) for k, v in tot.items()},
                          "kmermatcher_stage": stage("kmermatcher_stage"), "rescore_stage": stage("rescore_stage"), "assemble_stage": stage("assemble_stage")}}
     for key in ("nu", "aa", "db"):
@@ -627,6 +655,7 @@ def main_c5(args):
             x.free()
     nu0.free(); aa0.free(); reads.free()
     ctx.close()
+    line["verify"] = verify
     line["cpu_baseline"] = None if args.no_cpu_baseline else cpu_baseline_c5(args.cpu_sample_pairs)
     import ctypes
     sys.stderr.flush(); ctypes.CDLL(None).fflush(None)

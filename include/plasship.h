@@ -234,6 +234,9 @@ typedef struct plasship_assemble_stats {
     /* per kernel tier: [0] 16 lanes per query (<= 16 alignments), [1] one wave per query (17..64), [2] HBM queue (> 64) */
     float ms_tier_kernel[3];
     uint64_t tier_alignments[3], tier_query_residues[3], tier_rescored_residues[3];
+    /* how the output DB was made: bytes appended to the heap it shares with the input DB (the rewritten entries only), or bytes of a
+     * full copy (no shared heap yet, or no room left in it) — one of the two is 0 */
+    uint64_t db_appended_bytes, db_copied_bytes;
 } plasship_assemble_stats;
 
 int plasship_assemble(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_alns *a,

@@ -49,7 +49,7 @@ class AssembleStats(C.Structure):
     _fields_ = [("n_extended", C.c_uint64), ("n_rescored", C.c_uint64), ("out_residues", C.c_uint64), ("ms_kernel", C.c_float),
                 ("ms_assemble_kernel", C.c_float), ("n_alignments", C.c_uint64), ("rescored_residues", C.c_uint64),
                 ("ms_tier_kernel", C.c_float * 3), ("tier_alignments", C.c_uint64 * 3), ("tier_query_residues", C.c_uint64 * 3),
-                ("tier_rescored_residues", C.c_uint64 * 3)]
+                ("tier_rescored_residues", C.c_uint64 * 3), ("db_appended_bytes", C.c_uint64), ("db_copied_bytes", C.c_uint64)]
 
 
 class _Aln2NuclParams(C.Structure):

@@ -1190,13 +1190,49 @@ __global__ void listKernel(uint32_t n, const uint64_t *__restrict__ tierA, const
 }
 
 __global__ void outLenKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen, int keepTarget,
-                             uint64_t *__restrict__ outBytes, uint32_t *__restrict__ keep) {
+                             uint64_t *__restrict__ outBytes, uint32_t *__restrict__ keep, uint64_t *__restrict__ appBytes) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
         const uint32_t f = flags[id];
-        uint64_t b = 0; uint32_t k = 0;
-        if (f & 0x20u) { b = (uint64_t) newLen[id] + 2; k = 1; }
+        uint64_t b = 0, ap = 0; uint32_t k = 0;
+        if (f & 0x20u) { b = (uint64_t) newLen[id] + 2; k = 1; ap = b; }
         else if (keepTarget || !(f & 0x80u)) { b = (uint64_t) s.len[id] + 2; k = 1; }
         outBytes[id] = b; keep[id] = k;
+        if (appBytes) appBytes[id] = ap;                      // what the entry adds to a shared heap: only rewritten entries have new bytes
+    }
+}
+
+// The output DB as an INDEX over the heap the input DB lives in (SeqHeap, common.hpp): an entry that is carried over keeps its bytes
+// where they are, a rewritten one (flag 0x20: extended, cut, chopped) is copied from the arena to heapBase + appOff[id] behind
+// everything the heap held.  G lanes per entry; what moves per iteration is the rewritten 10-20 % of the sequences instead of
+// 2 x all residues (writeOutKernel below: 15 ms per iteration at 50 M reads, the same again on every rank of a sharded run).
+template <int G>
+__global__ __launch_bounds__(256) void appendOutKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen,
+                                                       const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
+                                                       const uint64_t *__restrict__ appOff, uint64_t heapBase, const uint32_t *__restrict__ keep,
+                                                       const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
+                                                       char *__restrict__ heap, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey,
+                                                       unsigned char *__restrict__ changedOut) {
+    const int gl = threadIdx.x & (G - 1);
+    constexpr int groupsPerBlock = 256 / G;
+    for (uint32_t id = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id < s.n; id += gridDim.x * groupsPerBlock) {
+        if (!keep[id]) continue;
+        const uint32_t f = flags[id];
+        const bool ext = (f & 0x20u) != 0;
+        uint64_t o; uint32_t L;
+        if (ext) {
+            L = newLen[id]; o = heapBase + appOff[id];
+            const char *src = arena + newStart[id]; char *dst = heap + o;
+            for (unsigned p = 8u * (unsigned) gl; p < L; p += 8u * G) {
+                const uint64_t x = loadU64Unaligned(src + p);                            // buffers are padded past their ends
+                if (p + 8 <= L) storeU64Unaligned(dst + p, x); else storeTail(dst + p, x, L - p);
+            }
+            if (gl == 0) { dst[L] = '\n'; dst[L + 1] = '\0'; }
+        } else { L = s.len[id]; o = s.off[id]; }
+        if (gl == 0) {
+            const uint64_t j = keepPos[id];
+            outOffArr[j] = o; outLen[j] = L; outKey[j] = inKey[id];
+            if (changedOut) changedOut[j] = ext ? 1 : 0;
+        }
     }
 }
 
@@ -1343,43 +1379,81 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
     return PLASSHIP_OK;
 }
 
-// builds one output DB (extended entries from the arena + carried-over entries of `db`), entries in key order
-int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
-                            const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                            const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent) {
+// builds one output DB (extended entries from the arena + carried-over entries of `db`), entries in key order.
+// mode 0: the DB shares `db`'s heap when it has one with room (appendOutKernel: only the rewritten entries move); else its entries are
+//         written back to back into a NEW heap with room for the iterations to come (PLASSHIP_TUNE_DBHEAP_X times the data, default 3;
+//         PLASSHIP_TUNE_DBHEAP=2: no heaps, every DB in an exact buffer of its own as in rounds 1-3)
+// mode 1: a packed copy in an exact buffer (packedCopyOf)
+static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
+                             const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
+                             const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent, int mode) {
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();
-    DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen;
+    const bool useHeaps = mode == 0 && tuneInt("DBHEAP", 1) == 1;
+    const bool mayAppend = useHeaps && db->heap != nullptr;
+    DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen, dAppBytes, dAppOff;
     if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
-        dKeepPos.alloc(((size_t) N + 2) * 8) != hipSuccess || dMaxLen.alloc(4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (N) hipLaunchKernelGGL(outLenKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, dFlags, dNewLen, keepTarget, dOutBytes.as<uint64_t>(), dKeep.as<uint32_t>());
+        dKeepPos.alloc(((size_t) N + 2) * 8) != hipSuccess || dMaxLen.alloc(4) != hipSuccess ||
+        (mayAppend && (dAppBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dAppOff.alloc(((size_t) N + 2) * 8) != hipSuccess))) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (N) hipLaunchKernelGGL(outLenKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, dFlags, dNewLen, keepTarget, dOutBytes.as<uint64_t>(), dKeep.as<uint32_t>(),
+                              mayAppend ? dAppBytes.as<uint64_t>() : (uint64_t *) nullptr);
     if (exclusiveScanU64(st, dOutBytes.as<uint64_t>(), dOutOff.as<uint64_t>(), N, dTmp, tmpBytes) ||
-        exclusiveScanU32(st, dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), N, dTmp, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t outBytes = 0, outN = 0;
+        exclusiveScanU32(st, dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), N, dTmp, tmpBytes) ||
+        (mayAppend && exclusiveScanU64(st, dAppBytes.as<uint64_t>(), dAppOff.as<uint64_t>(), N, dTmp, tmpBytes))) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
+    uint64_t outBytes = 0, outN = 0, appTotal = 0;
     PH_CHECK(hipMemcpyAsync(&outBytes, dOutOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(hipMemcpyAsync(&outN, dKeepPos.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    if (mayAppend) PH_CHECK(hipMemcpyAsync(&appTotal, dAppOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     std::unique_ptr<plasship_seqdb> holder(new plasship_seqdb());   // released to the caller on success only
     plasship_seqdb *o = holder.get();
     o->dbtype = db->dbtype; o->n = (size_t) outN; o->dataBytes = outBytes; o->residues = outBytes - 2 * outN; o->hostIndexValid = false;
-    if (o->d_data.alloc(outBytes + 64) != hipSuccess || o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
-        size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
-        setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
+    if (o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
+        setError("plasship_assemble: out of device memory for the output DB's index"); return PLASSHIP_ERR_DEVICE;
     }
-    PH_CHECK(hipMemsetAsync((char *) o->d_data.p + outBytes, 0, 64, st));
     // lineage for kmermatcher's selected-window cache: same ids as `db`, the extended / cut entries marked
-    if (outN == N && N) {
+    if (outN == N && N && mode == 0) {
         if (o->d_changed.alloc((size_t) N) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         o->parentGen = db->gen;
     }
-    if (N) {
-        // (2 and 4 sequences in flight per lane group changed nothing — profiles/r03_ab_knobs.txt: the kernel is not bound by its chains of round trips)
-        const unsigned woGrid = std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16));
-        hipLaunchKernelGGL((writeOutKernel<8, 1>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
-                           dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
-                           o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
+    // room in the shared heap?  (the reservation is atomic: two DBs derived from one parent get disjoint ranges; a reservation that
+    // does not fit is simply left unused — the heap is about to be replaced anyway)
+    bool append = false; uint64_t heapBase = 0;
+    if (mayAppend) {
+        heapBase = db->heap->used.fetch_add(appTotal);
+        append = heapBase + appTotal + 64 <= db->heap->buf.bytes;
+    }
+    if (append) {
+        o->heap = db->heap; o->contiguous = false;
+        if (N) hipLaunchKernelGGL((appendOutKernel<8>), dim3(std::min<uint32_t>((N + 31) / 32, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16))), dim3(256), 0, st, sv, dFlags, dNewLen, dNewStart, dArena,
+                                  (const uint64_t *) dAppOff.as<uint64_t>(), heapBase, (const uint32_t *) dKeep.as<uint32_t>(), (const uint64_t *) dKeepPos.as<uint64_t>(), (const uint32_t *) db->d_key.as<uint32_t>(),
+                                  db->heap->buf.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
+    } else {
+        char *dst = nullptr;
+        if (useHeaps) {
+            o->heap = std::make_shared<SeqHeap>();
+            const uint64_t cap = outBytes * (uint64_t) std::max(2, tuneInt("DBHEAP_X", 3)) + 4096;
+            if (o->heap->buf.alloc(cap) == hipSuccess) { o->heap->used = outBytes; dst = o->heap->buf.as<char>(); }
+            else o->heap.reset();                             // no room for the slack: an exact buffer will do
+        }
+        if (!dst) {
+            if (o->d_data.alloc(outBytes + 64) != hipSuccess) {
+                size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
+                setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
+            }
+            dst = o->d_data.as<char>();
+        }
+        o->contiguous = true;
+        PH_CHECK(hipMemsetAsync(dst + outBytes, 0, 64, st));
+        if (N) {
+            // (2 and 4 sequences in flight per lane group changed nothing — profiles/r03_ab_knobs.txt: the kernel is not bound by its chains of round trips)
+            const unsigned woGrid = std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16));
+            hipLaunchKernelGGL((writeOutKernel<8, 1>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
+                               dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
+                               dst, o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
+        }
     }
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dMaxLen.p, 0, 4, st));
@@ -1391,7 +1465,25 @@ int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const u
     PH_CHECK(plasship::streamSync(st));
     PH_CHECK(hipGetLastError());
     o->maxEntryLen = maxLen + 2;
+    o->buildAppendedBytes = append ? appTotal : 0; o->buildCopiedBytes = append ? 0 : outBytes;
     *out = holder.release();
+    return PLASSHIP_OK;
+}
+int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
+                            const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
+                            const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent) {
+    return buildOutputDBImpl(ctx, db, dFlags, dNewLen, dNewStart, dArena, keepTarget, dTmp, tmpBytes, out, dExtra, hExtra, extraBytes, doneEvent, 0);
+}
+int plasship::packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::unique_ptr<plasship_seqdb> &out) {
+    const uint32_t N = (uint32_t) db->n;
+    DevBuf dFlags, dTmp; const size_t tmpBytes = exclusiveScanTmpBytes((size_t) N + 2);
+    if (dFlags.alloc(((size_t) N + 1) * 4) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship: out of device memory while packing a sequence DB"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dFlags.p, 0, ((size_t) N + 1) * 4, ctx->stream));
+    plasship_seqdb *o = nullptr;
+    const int rc = buildOutputDBImpl(ctx, db, dFlags.as<uint32_t>(), nullptr, nullptr, nullptr, 1, dTmp.p, tmpBytes, &o, nullptr, nullptr, 0, nullptr, 1);
+    if (rc) return rc;
+    o->maxEntryLen = db->maxEntryLen;
+    out.reset(o);
     return PLASSHIP_OK;
 }
 
@@ -1652,6 +1744,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         }
         stats->ms_assemble_kernel = sum;
         stats->n_alignments = nLines; stats->rescored_residues = hs[2];
+        stats->db_appended_bytes = o->buildAppendedBytes; stats->db_copied_bytes = o->buildCopiedBytes;
     }
     *out = holdO.release();
     if (guided) *outAa = holdAa.release();

@@ -4,7 +4,9 @@
 #include <cstdint>
 #include <cstddef>
 #include <cstdio>
+#include <atomic>
 #include <functional>
+#include <memory>
 #include <string>
 #include <vector>
 #include "../../include/plasship.h"
@@ -139,7 +141,14 @@ struct plasship_ctx {
     } kmCache;
 };
 
-namespace plasship { uint64_t newDbGeneration(); }      // core.hip: a process-wide counter; every sequence DB handle gets its own number
+namespace plasship {
+uint64_t newDbGeneration();
+// An append-only byte heap shared by a chain of sequence DBs (assemble.hip, buildOutputDB): an assembly iteration changes 10-20 % of
+// the sequences, so the DB it makes keeps the bytes of the unchanged entries where they are — its index points into the heap of the
+// DB it derives from — and only the extended entries are appended behind `used`.  Nothing is ever overwritten, so every DB of the
+// chain stays valid for as long as its handle lives; the buffer goes when the last of them does.
+struct SeqHeap { DevBuf buf; std::atomic<uint64_t> used{0}; };
+}      // core.hip: a process-wide counter; every sequence DB handle gets its own number
 struct plasship_seqdb {
     int dbtype = 0;
     // Lineage (kmermatch.hip, the selected-window cache): `gen` names this handle; a DB that buildOutputDB derived from another one
@@ -151,6 +160,12 @@ struct plasship_seqdb {
     uint64_t dataBytes = 0, residues = 0;
     uint32_t maxEntryLen = 0;
     plasship::DevBuf d_data, d_off, d_len, d_key;
+    // heap != nullptr: the entries' bytes are in heap->buf (d_data is empty) at d_off[i], NOT necessarily back to back or in key order;
+    // `contiguous` says whether they are (a freshly compacted heap is; then, like d_data, the bytes [0, dataBytes) are the data file)
+    std::shared_ptr<plasship::SeqHeap> heap;
+    bool contiguous = true;
+    uint64_t buildAppendedBytes = 0, buildCopiedBytes = 0;  // how buildOutputDB made this DB: bytes appended to the shared heap / bytes of a full copy
+    const char *dataPtr() const { return heap ? heap->buf.as<char>() : d_data.as<char>(); }
     // rank of every entry in DATA FILE order (empty: the file lay in key order, rank == id).  Only DBs read from files written by
     // several threads have one; concatdbs renumbers its second DB by it (DBConcat.cpp:46-47,113-118 opens it LINEAR_ACCCESS).
     plasship::DevBuf d_fileRank;
@@ -162,7 +177,7 @@ struct plasship_seqdb {
     std::vector<uint32_t> h_key, h_elen;
     std::vector<uint64_t> h_off;
     plasship::SeqView view() const {
-        plasship::SeqView v; v.data = d_data.as<char>(); v.off = d_off.as<uint64_t>(); v.len = d_len.as<uint32_t>(); v.offLen = d_offLen.as<uint64_t>();
+        plasship::SeqView v; v.data = dataPtr(); v.off = d_off.as<uint64_t>(); v.len = d_len.as<uint32_t>(); v.offLen = d_offLen.as<uint64_t>();
         v.n = (uint32_t) n; v.nucl = (dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES); return v;
     }
 };
@@ -214,6 +229,9 @@ int commAllgathervBytes(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes
 int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t sendBytes, DevBuf &recv, const std::vector<uint64_t> &recvBytes);
 // builds an output sequence DB in key order (assemble.hip): entries with flag 0x20 come from `dArena + dNewStart[id]` (dNewLen[id]
 // residues), the others are carried over from `db` (dropped when !keepTarget and flag 0x80 is set)
+// a copy of `db` with its entries back to back in key order in a buffer of its own (assemble.hip); callers that stream or copy the
+// data of a DB as one block (DB files, downloads, concatdbs) take it when !db->contiguous
+int packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::unique_ptr<plasship_seqdb> &out);
 int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                   const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
                   const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr);

@@ -435,11 +435,14 @@ extern "C" int plasship_seqdb_info(const plasship_seqdb *db, size_t *n, uint64_t
 extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *cdb, char *data, uint64_t *off,
                                        uint32_t *elen, uint32_t *key) {
     if (!ctx || !cdb) { setError("plasship_seqdb_download: bad argument"); return PLASSHIP_ERR_ARG; }
-    plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     PH_ENTER(ctx);
+    // (a DB that shares an append-only heap with its ancestors is packed into a buffer of its own first: what leaves is the data file)
+    std::unique_ptr<plasship_seqdb> packedTmp;
+    if (!cdb->contiguous) { const int rcP = packedCopyOf(ctx, cdb, packedTmp); if (rcP) return rcP; cdb = packedTmp.get(); }
+    plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
     PH_CHECK(plasship::streamSync(ctx->stream));
-    if (data && db->dataBytes) { rc = stagedCopyToHost(ctx, data, db->d_data.p, db->dataBytes); if (rc) return rc; }
+    if (data && db->dataBytes) { rc = stagedCopyToHost(ctx, data, db->dataPtr(), db->dataBytes); if (rc) return rc; }
     if (off) memcpy(off, db->h_off.data(), db->n * 8);
     if (elen) memcpy(elen, db->h_elen.data(), db->n * 4);
     if (key) memcpy(key, db->h_key.data(), db->n * 4);
@@ -448,8 +451,10 @@ extern "C" int plasship_seqdb_download(plasship_ctx *ctx, const plasship_seqdb *
 
 extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb, const char *db_path) {
     if (!ctx || !cdb || !db_path) { setError("plasship_seqdb_write: bad argument"); return PLASSHIP_ERR_ARG; }
-    plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     PH_ENTER(ctx);
+    std::unique_ptr<plasship_seqdb> packedTmp;              // (see plasship_seqdb_download)
+    if (!cdb->contiguous) { const int rcP = packedCopyOf(ctx, cdb, packedTmp); if (rcP) return rcP; cdb = packedTmp.get(); }
+    plasship_seqdb *db = const_cast<plasship_seqdb *>(cdb);
     int rc = ensureHostIndex(ctx, db); if (rc) return rc;
     PH_CHECK(plasship::streamSync(ctx->stream));
     // the device layout is the file layout (entries "SEQ\n\0" back to back in key order): the data file is the device buffer, streamed
@@ -461,14 +466,14 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
         for (size_t i = b; i < e; i++) if (db->h_off[i] + db->h_elen[i] != (i + 1 < db->n ? db->h_off[i + 1] : db->dataBytes)) { packed = false; return; }
     });
     if (packed) {
-        rc = stagedDownload(ctx, db->d_data.p, db->dataBytes, [&](const char *src, uint64_t, uint64_t nb) { w.data(src, (size_t) nb); return !w.failed; });
+        rc = stagedDownload(ctx, db->dataPtr(), db->dataBytes, [&](const char *src, uint64_t, uint64_t nb) { w.data(src, (size_t) nb); return !w.failed; });
         if (rc == PLASSHIP_ERR_IO) setError(std::string("error while writing ") + db_path);
         if (rc) return rc;
         w.index(db->h_key.data(), db->h_elen.data(), db->n);
     } else {                                                  // a DB with gaps between its entries (none of the producers here makes one)
         HostBytes data;
         if (!data.alloc(db->dataBytes)) { setError("plasship_seqdb_write: out of host memory"); return PLASSHIP_ERR_IO; }
-        rc = stagedCopyToHost(ctx, data.data(), db->d_data.p, db->dataBytes); if (rc) return rc;
+        rc = stagedCopyToHost(ctx, data.data(), db->dataPtr(), db->dataBytes); if (rc) return rc;
         for (size_t i = 0; i < db->n; i++) w.add(db->h_key[i], data.data() + db->h_off[i], db->h_elen[i] - 1);
     }
     if (!w.close(err)) { setError(err); return PLASSHIP_ERR_IO; }
@@ -521,7 +526,7 @@ extern "C" int plasship_seqdb_digest(plasship_ctx *ctx, const plasship_seqdb *db
     if (d.alloc(16) != hipSuccess) { setError("plasship_seqdb_digest: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(d.p, 0, 16, ctx->stream));
     if (db->n) hipLaunchKernelGGL(digestKernel, dim3((unsigned) std::min<size_t>((db->n + 255) / 256, (size_t) ctx->numCU * 64)), dim3(256), 0, ctx->stream,
-                                  db->d_data.as<char>(), db->d_off.as<uint64_t>(), db->d_len.as<uint32_t>(), db->d_key.as<uint32_t>(), (uint32_t) db->n, d.as<unsigned long long>());
+                                  db->dataPtr(), db->d_off.as<uint64_t>(), db->d_len.as<uint32_t>(), db->d_key.as<uint32_t>(), (uint32_t) db->n, d.as<unsigned long long>());
     PH_COPY_SYNC(ctx->stream, h, d.p, 16, hipMemcpyDeviceToHost);
     PH_CHECK(hipGetLastError());
     *digest = h[0]; if (entry_bytes) *entry_bytes = h[1];

@@ -499,12 +499,16 @@ extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a,
     uint32_t maxKeyA = 0; int rc = maxKeyOf(ctx, a->d_key.as<uint32_t>(), a->n, &maxKeyA); if (rc) return rc;
     const uint64_t nn = (uint64_t) a->n + b->n;
     if (nn >= 0xFFFFFFFFull || (uint64_t) maxKeyA + 1 + b->n > 0xFFFFFFFFull) { setError("plasship_seqdb_concat: too many sequences"); return PLASSHIP_ERR_UNSUPPORTED; }
+    // (concatenation copies the two data blocks as they are: a DB that lives in a shared heap is packed first)
+    std::unique_ptr<plasship_seqdb> packedA, packedB;
+    if (!a->contiguous) { const int rcP = packedCopyOf(ctx, a, packedA); if (rcP) return rcP; a = packedA.get(); }
+    if (!b->contiguous) { const int rcP = packedCopyOf(ctx, b, packedB); if (rcP) return rcP; b = packedB.get(); }
     const uint64_t dataBytes = a->dataBytes + b->dataBytes;
     std::unique_ptr<plasship_seqdb> o(new plasship_seqdb());
     if (o->d_data.alloc(dataBytes + 64) != hipSuccess || o->d_off.alloc((nn + 1) * 8) != hipSuccess || o->d_len.alloc((nn + 1) * 4) != hipSuccess ||
         o->d_key.alloc((nn + 1) * 4) != hipSuccess) { setError("plasship_seqdb_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (a->dataBytes) PH_CHECK(hipMemcpyAsync(o->d_data.p, a->d_data.p, a->dataBytes, hipMemcpyDeviceToDevice, st));
-    if (b->dataBytes && !b->d_fileRank.p) PH_CHECK(hipMemcpyAsync((char *) o->d_data.p + a->dataBytes, b->d_data.p, b->dataBytes, hipMemcpyDeviceToDevice, st));
+    if (a->dataBytes) PH_CHECK(hipMemcpyAsync(o->d_data.p, a->dataPtr(), a->dataBytes, hipMemcpyDeviceToDevice, st));
+    if (b->dataBytes && !b->d_fileRank.p) PH_CHECK(hipMemcpyAsync((char *) o->d_data.p + a->dataBytes, b->dataPtr(), b->dataBytes, hipMemcpyDeviceToDevice, st));
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + dataBytes, 0, 64, st));
     hipLaunchKernelGGL(concatIndexKernel, dim3(gridOf(nn + 1, ctx->numCU)), dim3(256), 0, st, a->d_off.as<uint64_t>(), a->d_len.as<uint32_t>(), a->d_key.as<uint32_t>(), (uint32_t) a->n,
                        b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), (uint32_t) b->n, a->dataBytes, maxKeyA + 1, o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>());
@@ -515,7 +519,7 @@ extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a,
         if (dBytes.alloc((b->n + 1) * 8) != hipSuccess || dNewOff.alloc((b->n + 2) * 8) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship_seqdb_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(concatRankLenKernel, dim3(gridOf(b->n, ctx->numCU)), dim3(256), 0, st, b->d_len.as<uint32_t>(), b->d_fileRank.as<uint32_t>(), (uint32_t) b->n, o->d_len.as<uint32_t>() + a->n, dBytes.as<uint64_t>());
         if (exclusiveScanU64(st, dBytes.as<uint64_t>(), dNewOff.as<uint64_t>(), b->n, dTmp.p, tmpBytes)) { setError("plasship_seqdb_concat: scan failed"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(concatRankCopyKernel, dim3(gridOf((b->n + 15) / 16, ctx->numCU)), dim3(256), 0, st, b->d_data.as<char>(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->d_fileRank.as<uint32_t>(), (uint32_t) b->n,
+        hipLaunchKernelGGL(concatRankCopyKernel, dim3(gridOf((b->n + 15) / 16, ctx->numCU)), dim3(256), 0, st, b->dataPtr(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), b->d_fileRank.as<uint32_t>(), (uint32_t) b->n,
                            dNewOff.as<uint64_t>(), a->dataBytes, (uint32_t) a->n, maxKeyA + 1, o->d_data.as<char>(), o->d_off.as<uint64_t>(), o->d_key.as<uint32_t>());
         PH_CHECK(plasship::streamSync(st));
     }

@@ -172,12 +172,12 @@ def test_rccl_stub_exports_what_the_native_communicator_resolves():
 
 
 def test_stored_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_path, monkeypatch):
-    """bench.py reads `roofline.traffic` from profiles/r03_pmc_traffic.json (two rocprofv3 --pmc passes of the driver's command) and
+    """bench.py reads `roofline.traffic` from profiles/<bench.PMC_FILES[config]> (two rocprofv3 --pmc passes of the driver's command) and
     must refuse the file when the product sources differ from the ones recorded in it (a stored figure must not go
     stale silently)."""
     import json
     import bench
-    f = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+    f = os.path.join(ROOT, "profiles", bench.PMC_FILES["c3"])
     rows = json.load(open(f))
     assert rows["steps"] > 0 and rows["kernels"] and "--steps 20 --warmup 5" in rows["source"]
     # for the sources the file was measured on the figure is quoted ...
