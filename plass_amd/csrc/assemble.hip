@@ -1381,7 +1381,7 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
 
 // builds one output DB (extended entries from the arena + carried-over entries of `db`), entries in key order.
 // mode 0: the DB shares `db`'s heap when it has one with room (appendOutKernel: only the rewritten entries move); else its entries are
-//         written back to back into a NEW heap with room for the iterations to come (PLASSHIP_TUNE_DBHEAP_X times the data, default 3;
+//         written back to back into a NEW heap with room for the iterations to come (as much again as the data, at most PLASSHIP_TUNE_DBHEAP_GB = 8 GB;
 //         PLASSHIP_TUNE_DBHEAP=2: no heaps, every DB in an exact buffer of its own as in rounds 1-3)
 // mode 1: a packed copy in an exact buffer (packedCopyOf)
 static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
@@ -1434,7 +1434,9 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
         char *dst = nullptr;
         if (useHeaps) {
             o->heap = std::make_shared<SeqHeap>();
-            const uint64_t cap = outBytes * (uint64_t) std::max(2, tuneInt("DBHEAP_X", 3)) + 4096;
+            // room for the entries the next iterations rewrite (25-35 % of the data per iteration at 50 M reads): as much again as the
+            // data, but no more than PLASSHIP_TUNE_DBHEAP_GB (default 8) — kmermatcher's record arrays need 170 of the 288 GB there
+            const uint64_t cap = outBytes + std::min<uint64_t>(outBytes, (uint64_t) tuneInt("DBHEAP_GB", 8) << 30) + 4096;
             if (o->heap->buf.alloc(cap) == hipSuccess) { o->heap->used = outBytes; dst = o->heap->buf.as<char>(); }
             else o->heap.reset();                             // no room for the slack: an exact buffer will do
         }

@@ -14,10 +14,10 @@
 //     reference's 65 536-bin threshold walk becomes a two-level 256-bin LDS radix select, the per
 //     sequence std::sort becomes an LDS bitonic sort of only the <= ~60 candidate k-mers.
 //   * sort #1 is NOT a sort: only grouping by equal k-mer and the identity of the run's first record
-//     matter (its order is destroyed by sort #2 anyway).  Records are hash-partitioned (1–2 scatter
-//     passes, unstable, LDS-privatised histograms) into buckets that fit an LDS hash table; the run
-//     head is an atomicMax/atomicMin over (seqLen desc, id, pos).  One read+write per level instead
-//     of the 8+ passes of an LSD radix sort over 16-byte records.
+//     matter (its order is destroyed by sort #2 anyway).  Records are hash-partitioned over the line
+//     store (linepart.hpp: 1–2 levels, unstable, no histogram pass) into buckets that fit an LDS hash
+//     table; the run head is one atomicMin over a packed (seqLen desc, id, pos, strand) word.  One
+//     read+write per level instead of the 8+ passes of an LSD radix sort over 16-byte records.
 //   * sort #2 must be a true sort (the reference scans across rep boundaries, Appendix A.3): records
 //     are range-partitioned by rep id (order preserving) and each bucket is bitonic-sorted in LDS.
 //   * per-(rep,target) reduction: one thread per run head walks its run.
@@ -1044,118 +1044,6 @@ __global__ void gatherU32Kernel(const uint32_t *__restrict__ src, const uint32_t
 }
 
 // =====================================================================================================
-// 3. segmented, unstable bucket partition (used for the hash grouping and for the rep-range sort)
-// =====================================================================================================
-// (Key kinds, kmerMix and the record layouts: linepart.hpp.)  This dense two-pass partition (histogram, then scatter) was round 1's
-// path; single-GPU and sharded runs take the line-store partition of linepart.hpp now.  It stays behind PLASSHIP_LEGACY_PARTITION=1
-// (single GPU) as an independent implementation for cross-checks at sizes no CPU oracle can follow (tests/test_gpu_large.py).
-constexpr int PT_BLOCK = 256;
-constexpr int PT_ITEMS = 16;
-constexpr int PT_TILE = PT_BLOCK * PT_ITEMS;
-
-struct PartArgs {
-    const void *in; void *out;
-    const uint64_t *segStart;       // [nSeg] first record of the segment in `in`
-    const uint64_t *segCount;       // [nSeg] valid records in the segment
-    uint32_t *count;                // [nSeg << bits]
-    unsigned long long *cursor;     // [nSeg << bits] running write positions (scatter)
-    int shift, bits, rangeBits, dropSentinels;
-    int sharedTable;                // all segments accumulate into one bucket table (segment id does not offset it)
-    uint32_t segMod;                // != 0: segment s uses table (s % segMod) — sharded run, level 2: the W source runs of a level-1 bucket share its table
-    unsigned long long *minKey;     // optional: global minimum of (kmer | BIT63) (NUCL first-run quirk)
-    // optional: histogram of the records by k-mer VALUE (VH_BINS monotone bins of the sort-#1 key): bounds the sort-#1 rank
-    // of any record without sorting, which is all the stale-record check (section 7) needs most of the time
-    uint32_t *valueHist; int valueShift;
-    uint64_t repBase;               // KEY_RANGE: subtracted from the rep id (sharded run: first rep this rank owns)
-};
-template <bool NUCL, int MODE> __device__ __forceinline__ uint32_t bucketOf(const PartArgs &a, uint64_t kmerField, uint32_t nb) {
-    if (MODE == KEY_HASH) return (uint32_t) (kmerMix<NUCL>(kmerField) >> a.shift) & (nb - 1);
-    if (MODE == KEY_RANGE) return (uint32_t) ((((kmerField & ~BIT63) - a.repBase) << (64 - a.rangeBits)) >> a.shift) & (nb - 1);   // left-aligned rep id: top bits = id range
-    return 0;
-}
-template <bool NUCL, bool LONG, int MODE>
-__global__ __launch_bounds__(PT_BLOCK) void partHistKernel(PartArgs a) {
-    __shared__ uint32_t sh[4096];
-    __shared__ uint32_t shv[VH_BINS];
-    typedef Rec<LONG> R;
-    const R *in = reinterpret_cast<const R *>(a.in);
-    const uint32_t seg = blockIdx.y;
-    const uint64_t s0 = a.segStart[seg], cnt = a.segCount[seg];
-    const uint64_t t0 = (uint64_t) blockIdx.x * PT_TILE;
-    if (t0 >= cnt) return;
-    const uint32_t nb = 1u << a.bits;
-    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) sh[i] = 0;
-    if (a.valueHist) for (uint32_t i = threadIdx.x; i < VH_BINS; i += PT_BLOCK) shv[i] = 0;
-    __syncthreads();
-    unsigned long long mn = ~0ULL;
-#pragma unroll 4
-    for (int it = 0; it < PT_ITEMS; it++) {
-        const uint64_t i = t0 + (uint64_t) it * PT_BLOCK + threadIdx.x;
-        if (i < cnt) {
-            const R r = in[s0 + i];
-            if (a.dropSentinels && isSentinel(r)) continue;
-            const uint32_t b = bucketOf<NUCL, MODE>(a, r.kmer, nb);
-            atomicAdd(&sh[b], 1u);
-            if (a.valueHist) atomicAdd(&shv[valueBin<NUCL>(r.kmer, a.valueShift)], 1u);
-            if (NUCL && a.minKey) mn = min(mn, (unsigned long long) (r.kmer | BIT63));
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) atomicAdd(&a.count[(a.sharedTable ? 0 : ((uint64_t) (a.segMod ? seg % a.segMod : seg) << a.bits)) + i], c); }
-    if (a.valueHist) for (uint32_t i = threadIdx.x; i < VH_BINS; i += PT_BLOCK) { const uint32_t c = shv[i]; if (c) atomicAdd(&a.valueHist[i], c); }
-    if (NUCL && a.minKey) {
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned long long) __shfl_xor(mn, o, 64));
-        if (laneId() == 0 && mn != ~0ULL) atomicMin(a.minKey, mn);
-    }
-}
-
-template <bool NUCL, bool LONG, int MODE>
-__global__ __launch_bounds__(PT_BLOCK) void partScatterKernel(PartArgs a) {
-    // bucket tables sized by the launch (dynamic LDS: 12 bytes per bucket): with the few hundred buckets of a level the
-    // kernel is limited by registers, not by LDS, and more tiles are in flight per CU
-    extern __shared__ unsigned long long ptDyn[];
-    typedef Rec<LONG> R;
-    const R *in = reinterpret_cast<const R *>(a.in);
-    R *out = reinterpret_cast<R *>(a.out);
-    const uint32_t seg = blockIdx.y;
-    const uint64_t s0 = a.segStart[seg], cnt = a.segCount[seg];
-    const uint64_t t0 = (uint64_t) blockIdx.x * PT_TILE;
-    if (t0 >= cnt) return;
-    const uint32_t nb = 1u << a.bits;
-    unsigned long long *sbase = ptDyn;                                   // [nb]
-    uint32_t *sh = reinterpret_cast<uint32_t *>(ptDyn + nb);             // [nb]
-    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) sh[i] = 0;
-    __syncthreads();
-    R recs[PT_ITEMS]; uint32_t br[PT_ITEMS];                             // bucket (12 bits) | rank inside the tile's bucket (<= 4096: 13 bits)
-#pragma unroll
-    for (int it = 0; it < PT_ITEMS; it++) {
-        const uint64_t i = t0 + (uint64_t) it * PT_BLOCK + threadIdx.x;
-        br[it] = 0xFFFFFFFFu;
-        if (i < cnt) {
-            recs[it] = in[s0 + i];
-            if (!(a.dropSentinels && isSentinel(recs[it]))) {
-                const uint32_t b = bucketOf<NUCL, MODE>(a, recs[it].kmer, nb);
-                br[it] = (b << 16) | atomicAdd(&sh[b], 1u);
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < nb; i += PT_BLOCK) { const uint32_t c = sh[i]; if (c) sbase[i] = atomicAdd(&a.cursor[(a.sharedTable ? 0 : ((uint64_t) (a.segMod ? seg % a.segMod : seg) << a.bits)) + i], (unsigned long long) c); }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < PT_ITEMS; it++)
-        if (br[it] != 0xFFFFFFFFu) out[sbase[br[it] >> 16] + (br[it] & 0xFFFFu)] = recs[it];
-}
-
-__global__ void copyU64Kernel(const uint64_t *__restrict__ src, unsigned long long *__restrict__ dst, uint64_t n) {
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) dst[i] = src[i];
-}
-__global__ void diffU64Kernel(const uint64_t *__restrict__ start, uint64_t *__restrict__ cnt, uint64_t n) {   // cnt[i] = start[i+1]-start[i]
-    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) cnt[i] = start[i + 1] - start[i];
-}
-
-// =====================================================================================================
 // 4. assignGroup over hash buckets with an LDS hash table (kmermatcher.cpp:450-559)
 // =====================================================================================================
 constexpr int GR_BLOCK = 256;
@@ -1751,15 +1639,6 @@ __global__ __launch_bounds__(LS_BLOCK) void aggSortKernel(const void *arr, void 
     }
 }
 
-__global__ __launch_bounds__(256) void compactTriplesKernel(const Triple *__restrict__ in, const uint64_t *__restrict__ bucketStart, const uint32_t *__restrict__ lineBeg,
-                                                            const uint64_t *__restrict__ tripleStart, uint32_t nBuckets, Triple *__restrict__ out) {
-    // one wave per bucket; lineBeg != nullptr: the bucket's triples start at lineBeg[b] * RPL (line-store input of aggSortKernel)
-    for (uint32_t b = blockIdx.x * 4 + (threadIdx.x >> 6); b < nBuckets; b += gridDim.x * 4) {
-        const uint64_t s0 = lineBeg ? (uint64_t) lineBeg[b] * RPL : bucketStart[b], d0 = tripleStart[b], n = tripleStart[b + 1] - d0;
-        for (uint64_t i = laneId(); i < n; i += 64) out[d0 + i] = in[s0 + i];
-    }
-}
-
 // line-store path: the triples of bucket b lie at in[lineBeg[b] * RPL ...] (unique[b] of them), grouped by representative.  Every
 // representative occurs in exactly one bucket: the number of its triples and the position of the first go to cnt[rep - repBase] /
 // pos[rep - repBase] (cnt is zeroed beforehand).  One wavefront per bucket; a representative's triples are counted 64 at a time
@@ -1907,24 +1786,7 @@ template <bool NUCL, bool LONG> __host__ __device__ __forceinline__ bool recLess
     if (a.pos != b.pos) return a.pos < b.pos;
     return a.kmer < b.kmer;      // records of one sequence that differ in the strand only: reverse first (as oracle/kmermatcher.cpp)
 }
-template <bool NUCL, bool LONG>
-__global__ __launch_bounds__(256) void rankKernel(const void *recs, uint64_t n, const void *tkeys, uint32_t m, unsigned long long *diff) {
-    typedef Rec<LONG> R;
-    const R *g = reinterpret_cast<const R *>(recs);
-    const R *tk = reinterpret_cast<const R *>(tkeys);
-    __shared__ uint32_t sDiff[1025];
-    const bool useLds = m <= 1024;
-    if (useLds) { for (uint32_t i = threadIdx.x; i <= m; i += 256) sDiff[i] = 0; __syncthreads(); }
-    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t) gridDim.x * 256) {
-        const R r = g[i];
-        uint32_t lo = 0, hi = m;                      // first j with r < tk[j]
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (recLess1<NUCL, LONG>(r, tk[mid])) hi = mid; else lo = mid + 1; }
-        if (useLds) atomicAdd(&sDiff[lo], 1u); else atomicAdd(&diff[lo], 1ULL);
-    }
-    if (useLds) { __syncthreads(); for (uint32_t i = threadIdx.x; i <= m; i += 256) { const uint32_t c = sDiff[i]; if (c) atomicAdd(&diff[i], (unsigned long long) c); } }
-}
-
-// the same over a line store: every written line (tag != TAG_NONE) of the hash-partitioned records, padding sentinels skipped
+// over the line store: every written line (tag != TAG_NONE) of the hash-partitioned records, padding sentinels skipped
 template <bool NUCL, bool LONG>
 __global__ __launch_bounds__(256) void rankLinesKernel(const void *recs, const uint32_t *__restrict__ tags, uint64_t nLines, const uint64_t *__restrict__ nLinesDev,
                                                        const void *tkeys, uint32_t m, unsigned long long *diff) {
@@ -2721,13 +2583,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const int k = par->kmer_size;
-    Timer tm{ctx, 0};
-    float msExtract = 0, msSort1 = 0, msGroup = 0, msSort2 = 0, msReduce = 0;
+    float msExtract = 0;
     // sharded run (plasship_ctx_set_comm): this rank extracts the sequences [sLo, sHi), owns the k-mer hash buckets that map to
     // it, and owns the representatives / queries [repBase, repBase + ownedN)
     const plasship_comm *cm = commOf(ctx);
     const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
-    const bool useLinesEarly = cm || getenv("PLASSHIP_LEGACY_PARTITION") == nullptr;      // == useLines below
 
     // ---- slot bounds + offsets ----
     DevBuf dBound, dSlotOff, dScanTmp;
@@ -2735,7 +2595,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (dBound.alloc(((size_t) N + 1) * 4) != hipSuccess || dSlotOff.alloc(((size_t) N + 2) * 8) != hipSuccess || dScanTmp.alloc(scanTmpBytes) != hipSuccess) {
         setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
-    if (useLinesEarly) PH_CHECK(hipEventRecord(ctx->ev[0], st)); else tm.start(0);
+    PH_CHECK(hipEventRecord(ctx->ev[0], st));
     if (N) hipLaunchKernelGGL(boundsKernel, dim3(gridFor(N, 256, 4096)), dim3(256), 0, st, db->d_len.as<uint32_t>(), N, k, par->kmers_per_seq, par->kmers_per_seq_scale, dBound.as<uint32_t>());
     if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t total = 0;
@@ -2755,15 +2615,12 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const uint32_t nMine = sHi - sLo;
 
     DevBuf dA, dB;   // ping-pong record arrays
-    // single GPU: the line-store partition (linepart.hpp; PLASSHIP_LEGACY_PARTITION=1 keeps the dense two-pass partition the
-    // sharded run uses).  Its record buffers hold whole lines plus one partial line per bucket and piece.
-    static const bool legacyPartition = getenv("PLASSHIP_LEGACY_PARTITION") != nullptr;
-    const bool useLines = cm || !legacyPartition;            // (the dense partition below is a single-GPU cross-check path)
+    // the line-store partition (linepart.hpp): its record buffers hold whole lines plus one partial line per bucket and piece
     if (cm && W > 1024) { setError("kmermatch: more than 1024 ranks"); return PLASSHIP_ERR_UNSUPPORTED; }
-    const LineGeo geo = useLines ? lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W) : LineGeo();
+    const LineGeo geo = lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W);
     // single GPU: both buffers serve level 1 and level 2 (and the group kernel's arenas); sharded run: the slot array / level-1 output,
     // and the packed send buffer of exchange 1 (at most cap1 lines)
-    const uint64_t recCap = useLines ? std::max<uint64_t>(total, (uint64_t) RPL * (cm ? geo.cap1 : std::max(geo.cap1, geo.cap2))) : std::max<uint64_t>(total, 1);
+    const uint64_t recCap = std::max<uint64_t>(total, (uint64_t) RPL * (cm ? geo.cap1 : std::max(geo.cap1, geo.cap2)));
     if (dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess) {
         setError("kmermatch: out of device memory for the k-mer record arrays (" + std::to_string(2 * recCap * sizeof(R)) + " bytes)"); return PLASSHIP_ERR_DEVICE;
     }
@@ -2893,7 +2750,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // (ADVICE r3).  So the count of the last tier's hand-overs is not waited for here when an overflow is UNLIKELY; it travels with
     // the group stage's counts (kmermatchLines), the last tier has left such a sequence's slots as sentinels, and if the count turns
     // out non-zero the call starts over with the wait in place (`overflowCheckEarly`).
-    const bool overflowPossible = overflowCheckEarly || !useLines || cm != nullptr || NUCL || db->maxEntryLen > 8160u || par->kmers_per_seq > 120 || par->kmers_per_seq_scale != 0.0f;
+    const bool overflowPossible = overflowCheckEarly || cm != nullptr || NUCL || db->maxEntryLen > 8160u || par->kmers_per_seq > 120 || par->kmers_per_seq_scale != 0.0f;
     if (nMine && overflowPossible) {
         PH_CHECK(hipMemcpyAsync(&nOv, dLastCnt.p, 4, hipMemcpyDeviceToHost, st));
         PH_CHECK(plasship::streamSync(st));
@@ -2919,11 +2776,10 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         PH_CHECK(plasship::streamSync(st));
         PH_CHECK(hipGetLastError());
     }
-    if (!useLinesEarly) msExtract = tm.stop(1);              // (line-store path: the next boundary event is recorded by kmermatchLines)
     PH_TRACE(st, "kmermatch: extraction");
     traceBadIds<LONG>(ctx, "kmermatch: extracted slots", dA.p, total, N);
 
-    if (useLines) {
+    {
         int keyBitsL = 0;
         if (NUCL) keyBitsL = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBitsL < 63 && (long double) (1ULL << keyBitsL) < v) keyBitsL++; }
         LinesOut lo;
@@ -2956,288 +2812,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         *out = holderL.release();
         return PLASSHIP_OK;
     }
-    // ---- the dense partition (PLASSHIP_LEGACY_PARTITION=1, single GPU only): round 1's histogram + scatter passes and the three-phase
-    //      group kernel, kept as an independent implementation the line-store path is cross-checked against (tests/test_gpu_large.py) ----
-    // ---- hash partition (replaces sort #1) ----
-    tm.start(0);
-    // value histogram for the stale-record check: bins of the k-mer value (real k-mers need keyBits bits)
-    DevBuf dVHist, dMinKey, dSeg0Start, dSeg0Cnt;
-    if (dVHist.alloc(VH_BINS * 4) != hipSuccess || dMinKey.alloc(8) != hipSuccess || dSeg0Start.alloc(8) != hipSuccess || dSeg0Cnt.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    PH_CHECK(hipMemsetAsync(dVHist.p, 0, VH_BINS * 4, st));
-    PH_CHECK(hipMemsetAsync(dMinKey.p, 0xFF, 8, st));
-    { uint64_t z = 0; PH_CHECK(hipMemcpyAsync(dSeg0Start.p, &z, 8, hipMemcpyHostToDevice, st)); PH_CHECK(hipMemcpyAsync(dSeg0Cnt.p, &total, 8, hipMemcpyHostToDevice, st)); }
-    int keyBits = 0;
-    if (NUCL) keyBits = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBits < 63 && (long double) (1ULL << keyBits) < v) keyBits++; }
-    const int valueShift = std::max(0, keyBits - 11);      // VH_BINS = 2^11 monotone bins
-    void *bufA = dA.p, *bufB = dB.p;        // level 1 reads bufA (partTotal slots), writes bufB
-    uint64_t partTotal = total;
-    const int totalBits = std::max(0, ceilLog2((partTotal + 1535) / 1536));   // ~1000-1500 records per final bucket: the group kernel
-                                                                                                    // pays a fixed number of block barriers per bucket
-    // coarse level first: few wide buckets => every tile writes long contiguous runs; the fine level then scatters inside a
-    // bucket that fits the L2 / Infinity Cache
-    const int b2w = (totalBits > 11) ? 11 : 0;
-    const int b1 = std::min(totalBits - b2w, 11), b2 = std::min(std::max(totalBits - b1, 0), 11);
-    const uint32_t nB1 = 1u << b1, nB = 1u << (b1 + b2);
-    const uint32_t nbL = nB1;
-    DevBuf dCnt1, dStart1, dCur1, dCnt2, dStart2, dCur2, dSegCnt1;
-    if (dCnt1.alloc((size_t) nB1 * 4) != hipSuccess || dStart1.alloc(((size_t) nB1 + 1) * 8) != hipSuccess || dCur1.alloc((size_t) nB1 * 8) != hipSuccess ||
-        dSegCnt1.alloc((size_t) nB1 * 8) != hipSuccess ||
-        dCnt2.alloc((size_t) nB * 4) != hipSuccess || dStart2.alloc(((size_t) nB + 1) * 8) != hipSuccess || dCur2.alloc((size_t) nB * 8) != hipSuccess) {
-        setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
-    }
-    PH_CHECK(hipMemsetAsync(dCnt1.p, 0, (size_t) nB1 * 4, st));
-    PartArgs pa; memset(&pa, 0, sizeof(pa));
-    pa.in = bufA; pa.out = bufB; pa.segStart = dSeg0Start.as<uint64_t>(); pa.segCount = dSeg0Cnt.as<uint64_t>(); pa.count = dCnt1.as<uint32_t>();
-    pa.cursor = dCur1.as<unsigned long long>(); pa.shift = 64 - b1; pa.bits = b1; pa.rangeBits = 0;
-    pa.dropSentinels = 1; pa.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
-    if (b1 == 0) pa.shift = 63;   // single bucket: (key >> 63) & 0 == 0
-    pa.valueHist = dVHist.as<uint32_t>(); pa.valueShift = valueShift;
-    const unsigned tiles0 = (unsigned) std::max<uint64_t>(1, (partTotal + PT_TILE - 1) / PT_TILE);
-    hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), 0, st, pa);
-    if (exclusiveScanU32(st, dCnt1.as<uint32_t>(), dStart1.as<uint64_t>(), nB1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dCur1.as<unsigned long long>(), (uint64_t) nB1);
-    pa.minKey = nullptr; pa.valueHist = nullptr;
-    PH_CHECK(hipEventRecord(ctx->ev[8], st));
-    hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles0, 1), dim3(PT_BLOCK), (size_t) 12 << pa.bits, st, pa);
-    PH_CHECK(hipEventRecord(ctx->ev[9], st));
-    int nScatter = 1;
-    std::vector<uint64_t> hStart1(nB1 + 1);
-    PH_CHECK(hipMemcpyAsync(hStart1.data(), dStart1.p, ((size_t) nB1 + 1) * 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(plasship::streamSync(st));
-    PH_CHECK(hipGetLastError());
-    uint64_t Nk = hStart1[nB1];                // records on this rank
-    void *cur = bufB, *other = bufA;
-    const uint64_t *dBucketStart = dStart1.as<uint64_t>();
-    // level 2 reads `l2Segs` segments; segment s accumulates into table (s % l2SegMod)
-    const uint64_t *l2SegStart = dStart1.as<uint64_t>(), *l2SegCount = dSegCnt1.as<uint64_t>();
-    uint32_t l2Segs = nB1, l2SegMod = 0;
-    uint64_t maxSeg = 0; for (uint32_t i = 0; i < nB1; i++) maxSeg = std::max(maxSeg, hStart1[i + 1] - hStart1[i]);
-    DevBuf dSegS, dSegC;
-    const uint64_t NkG = Nk;
-    const uint32_t nB2 = nbL << b2;            // level-2 tables (= final buckets of this rank)
-    if (b2 > 0) {
-        hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nB1, 256, 64)), dim3(256), 0, st, dStart1.as<uint64_t>(), dSegCnt1.as<uint64_t>(), (uint64_t) nB1);
-        PH_CHECK(hipMemsetAsync(dCnt2.p, 0, (size_t) nB2 * 4, st));
-        PartArgs p2; memset(&p2, 0, sizeof(p2));
-        p2.in = cur; p2.out = other; p2.segStart = l2SegStart; p2.segCount = l2SegCount; p2.count = dCnt2.as<uint32_t>();
-        p2.cursor = dCur2.as<unsigned long long>(); p2.shift = 64 - b1 - b2; p2.bits = b2; p2.dropSentinels = 0; p2.segMod = l2SegMod;
-        const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxSeg + PT_TILE - 1) / PT_TILE);
-        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, l2Segs), dim3(PT_BLOCK), 0, st, p2);
-        if (exclusiveScanU32(st, dCnt2.as<uint32_t>(), dStart2.as<uint64_t>(), nB2, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nB2, 256, 1024)), dim3(256), 0, st, dStart2.as<uint64_t>(), dCur2.as<unsigned long long>(), (uint64_t) nB2);
-        PH_CHECK(hipEventRecord(ctx->ev[10], st));
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_HASH>), dim3(tiles, l2Segs), dim3(PT_BLOCK), (size_t) 12 << p2.bits, st, p2);
-        PH_CHECK(hipEventRecord(ctx->ev[11], st));
-        nScatter = 2;
-        std::swap(cur, other);
-        dBucketStart = dStart2.as<uint64_t>();
-    }
-    msSort1 = tm.stop(1);
-    PH_TRACE(st, "kmermatch: hash partition");
-    traceBadIds<LONG>(ctx, "kmermatch: bucketed records", cur, Nk, N);
-
-    // ---- assignGroup ----
-    tm.start(0);
-    const uint32_t nBuckets = (b2 > 0) ? nB2 : nB1;
-    const uint32_t gBlocks = std::min<uint32_t>(nBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("GROUP", 6));
-    const uint32_t bpb = (nBuckets + gBlocks - 1) / gBlocks;
-    const uint32_t gGrid = (nBuckets + bpb - 1) / bpb;
-    DevBuf dOutCnt, dArenaStart, dMaxRT;
-    if (dOutCnt.alloc((size_t) gGrid * 8) != hipSuccess || dArenaStart.alloc((size_t) gGrid * 8) != hipSuccess || dMaxRT.alloc(8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    GroupArgs ga; memset(&ga, 0, sizeof(ga));
-    ga.in = cur; ga.out = other; ga.bucketStart = dBucketStart; ga.nBuckets = nBuckets; ga.bucketsPerBlock = bpb; ga.outCount = dOutCnt.as<uint64_t>();
-    PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
-    ga.maxRepTarget = dMaxRT.as<unsigned long long>();
-    ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
-    hipLaunchKernelGGL((groupKernel<NUCL, LONG, false>), dim3(gGrid), dim3(GR_BLOCK), 0, st, ga);
-    std::vector<uint64_t> hOutCnt(gGrid), hBStart(nBuckets + 1);
-    DevBuf dLastRun; unsigned long long hLastRun[4] = {0, 0, 0, 0}; std::vector<uint32_t> hVHist(VH_BINS);
-    if (dLastRun.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    hipLaunchKernelGGL(lastRunInfoKernel, dim3(1), dim3(1), 0, st, dMaxRT.as<unsigned long long>(), dSlotOff.as<uint64_t>(), db->d_len.as<uint32_t>(), N, dLastRun.as<unsigned long long>());
-    PH_CHECK(hipMemcpyAsync(hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipMemcpyAsync(hVHist.data(), dVHist.p, VH_BINS * 4, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipMemcpyAsync(hOutCnt.data(), dOutCnt.p, (size_t) gGrid * 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(hipMemcpyAsync(hBStart.data(), dBucketStart, ((size_t) nBuckets + 1) * 8, hipMemcpyDeviceToHost, st));
-    PH_CHECK(plasship::streamSync(st));
-    PH_CHECK(hipGetLastError());
-    std::vector<uint64_t> hArena(gGrid); uint64_t Nm = 0, maxArena = 0;
-    for (uint32_t j = 0; j < gGrid; j++) { hArena[j] = hBStart[(size_t) j * bpb]; Nm += hOutCnt[j]; maxArena = std::max(maxArena, hOutCnt[j]); }
-    PH_CHECK(hipMemcpyAsync(dArenaStart.p, hArena.data(), (size_t) gGrid * 8, hipMemcpyHostToDevice, st));
-    const uint64_t NmLocal = Nm;               // grouped records this rank produced
-    std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
-    std::swap(cur, other);   // cur = grouped records, scattered in arenas; other = the N_k hash-bucketed records (dense)
-    msGroup = tm.stop(1);
-    PH_TRACE(st, "kmermatch: group");
-
-    // ---- stale records behind the compaction point that continue the last run (see section 7 above) ----
-    std::vector<int64_t> stalePos;          // original k-mer positions of the sort-#1 records of rank N_m, N_m+1, … that belong to T
-    uint32_t staleT = 0;
-    if (Nm > 0 && Nm < NkG) {
-        const unsigned long long maxRT = hLastRun[0];
-        staleT = (uint32_t) (maxRT & 0xFFFFFFFFull);
-        const uint64_t so[2] = {hLastRun[1], hLastRun[2]}; const uint32_t tLen = (uint32_t) hLastRun[3];
-        const uint32_t tb = (uint32_t) (so[1] - so[0]);
-        DevBuf dTRec, dTId, dTScr, dTOff, dTCap, dDiff;
-        uint32_t cap = 64; while (cap < tLen + 1) cap <<= 1;
-        const uint64_t zero = 0;
-        if (dTRec.alloc((size_t) tb * sizeof(R)) != hipSuccess || dTId.alloc(4) != hipSuccess || dTScr.alloc((size_t) cap * sizeof(Cand)) != hipSuccess ||
-            dTOff.alloc(8) != hipSuccess || dTCap.alloc(4) != hipSuccess || dDiff.alloc(((size_t) tb + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        PH_CHECK(hipMemcpyAsync(dTId.p, &staleT, 4, hipMemcpyHostToDevice, st));
-        PH_CHECK(hipMemcpyAsync(dTOff.p, &zero, 8, hipMemcpyHostToDevice, st));
-        PH_CHECK(hipMemcpyAsync(dTCap.p, &cap, 4, hipMemcpyHostToDevice, st));
-        PH_CHECK(hipMemsetAsync(dDiff.p, 0, ((size_t) tb + 1) * 8, st));
-        // re-extract the records of T into a scratch array with the very kernel that produced them
-        ExtractArgs ta = ea; ta.waveList = nullptr; ta.waveCount = nullptr; ta.kstats = nullptr; ta.arr = dTRec.p; ta.slotBias = so[0];
-        ta.idList = dTId.as<uint32_t>(); ta.nIds = 1; ta.scratch = dTScr.as<Cand>(); ta.scratchOff = dTOff.as<uint64_t>(); ta.scratchCap = dTCap.as<uint32_t>();
-        if (traceOn()) fprintf(stderr, "[plasship] kmermatch: stale check T=%u slots [%llu, %llu) len %u Nm=%llu NkG=%llu\n", staleT, (unsigned long long) so[0], (unsigned long long) so[1], tLen, (unsigned long long) Nm, (unsigned long long) NkG);
-        hipLaunchKernelGGL((extractKernel<NUCL, LONG, 1, true>), dim3(1), dim3(64), 0, st, ta);
-        PH_TRACE(st, "kmermatch: re-extraction of the last run's target");
-        std::vector<R> trec(tb);
-        PH_CHECK(hipMemcpyAsync(trec.data(), dTRec.p, (size_t) tb * sizeof(R), hipMemcpyDeviceToHost, st));
-        PH_CHECK(plasship::streamSync(st));
-        trec.erase(std::remove_if(trec.begin(), trec.end(), [](const R &r) { return r.kmer == ~0ULL && r.id == 0xFFFFFFFFu; }), trec.end());
-        std::sort(trec.begin(), trec.end(), [](const R &x, const R &y) { return recLess1<NUCL, LONG>(x, y); });
-        const uint32_t m = (uint32_t) trec.size();
-        // cheap exact filter first: the value histogram bounds the sort-#1 rank of every record of T; the scan can only reach
-        // a record of T if rank N_m itself can be one of them
-        bool mayHit = false;
-        if (m) {
-            std::vector<uint64_t> cum(VH_BINS + 1, 0);
-            for (uint32_t b = 0; b < VH_BINS; b++) cum[b + 1] = cum[b] + hVHistG[b];
-            for (uint32_t j = 0; j < m && !mayHit; j++) { const uint32_t b = valueBin<NUCL>(trec[j].kmer, valueShift); mayHit = Nm >= cum[b] && Nm < cum[b + 1]; }
-        }
-        if (m && mayHit) {
-            PH_CHECK(hipMemcpyAsync(dTRec.p, trec.data(), (size_t) m * sizeof(R), hipMemcpyHostToDevice, st));
-            hipLaunchKernelGGL((rankKernel<NUCL, LONG>), dim3(gridFor(Nk, 256, (unsigned) ctx->numCU * 8)), dim3(256), 0, st, (const void *) other, Nk, (const void *) dTRec.p, m, dDiff.as<unsigned long long>());
-            PH_TRACE(st, "kmermatch: rank pass");
-            std::vector<unsigned long long> diff((size_t) m + 1);
-            PH_CHECK(hipMemcpyAsync(diff.data(), dDiff.p, ((size_t) m + 1) * 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(plasship::streamSync(st));
-            unsigned long long rank = 0, expect = Nm;
-            for (uint32_t j = 0; j < m; j++) {
-                rank += diff[j];                         // records strictly before trec[j] in sort-#1 order
-                if (rank == expect) { stalePos.push_back((int64_t) trec[j].pos); expect++; }
-                else if (rank > expect) break;
-            }
-        }
-    }
-
-    // ---- sort #2: range partition by rep id + local bitonic sort ----
-    tm.start(0);
-    const uint64_t *segStartP = dArenaStart.as<uint64_t>(), *segCountP = dOutCnt.as<uint64_t>();   // where the grouped records are
-    uint32_t nSeg = gGrid; uint64_t maxSeg1 = maxArena, NmHere = NmLocal;
-    if (traceOn()) fprintf(stderr, "[plasship] kmermatch: N=%u Nk=%llu NmLocal=%llu gGrid=%u maxArena=%llu stale=%zu\n", N, (unsigned long long) Nk, (unsigned long long) NmLocal, gGrid, (unsigned long long) maxArena, stalePos.size());
-    PH_TRACE(st, "kmermatch: stale-record check");
-    // rep ids are sorted relative to the first rep this rank owns (0 on a single GPU); targets are ids of the whole DB
-    const int idBits = std::max(1, ceilLog2((uint64_t) N));
-    // sharded run: from the LARGEST share of any rank (ceil(N / W)), so that the key layout — and the "too many sequences" exit
-    // below — is the same decision on every rank
-    const int repBits = idBits;
-    // ~512 records per sort bucket, at most 2^22 buckets (two partition levels of 11 bits): beyond 2 G grouped records the buckets
-    // grow instead (the aggregation kernel takes buckets of any size)
-    const int wantBits = std::min(22, std::max(0, ceilLog2((NmHere + 511) / 512)));
-    // packed sort key = [rep - bucketBase | target | diagonal | strand] must fit 63 bits
-    const int allowedLocal = 62 - idBits - DiagPack<LONG>::BITS;
-    const int sBits = std::max(std::min(wantBits, repBits), std::max(0, repBits - allowedLocal));
-    if (sBits > 22) { setError("kmermatch: too many sequences for the packed rep-sort key"); return PLASSHIP_ERR_UNSUPPORTED; }
-    const int s2w = (sBits > 11) ? 11 : 0;
-    const int s1 = std::min(sBits - s2w, 11), s2 = std::min(std::max(sBits - s1, 0), 11);
-    const uint32_t nS1 = 1u << s1, nS = 1u << (s1 + s2);
-    DevBuf dRC1, dRS1, dRCur1, dRSegCnt, dRC2, dRS2, dRCur2;
-    if (dRC1.alloc((size_t) nS1 * 4) != hipSuccess || dRS1.alloc(((size_t) nS1 + 1) * 8) != hipSuccess || dRCur1.alloc((size_t) nS1 * 8) != hipSuccess ||
-        dRSegCnt.alloc((size_t) nS1 * 8) != hipSuccess || dRC2.alloc((size_t) nS * 4) != hipSuccess || dRS2.alloc(((size_t) nS + 1) * 8) != hipSuccess ||
-        dRCur2.alloc((size_t) nS * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    const uint64_t *dSortStart = nullptr; uint32_t nSortBuckets = 0;
-    std::vector<uint64_t> hSortStart;
-    {
-        // level 1 reads the grouped records straight out of the group kernel's arenas (segments); all arenas
-        // accumulate into one bucket table.
-        PH_CHECK(hipMemsetAsync(dRC1.p, 0, (size_t) nS1 * 4, st));
-        PartArgs p1; memset(&p1, 0, sizeof(p1));
-        p1.in = cur; p1.out = other; p1.segStart = segStartP; p1.segCount = segCountP; p1.count = dRC1.as<uint32_t>();
-        p1.cursor = dRCur1.as<unsigned long long>(); p1.shift = 64 - s1; p1.bits = s1; p1.rangeBits = repBits; p1.dropSentinels = 0; p1.sharedTable = 1;
-        p1.repBase = 0;
-        if (s1 == 0) p1.shift = 63;
-        const unsigned tiles = (unsigned) std::max<uint64_t>(1, (maxSeg1 + PT_TILE - 1) / PT_TILE);
-        hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, nSeg), dim3(PT_BLOCK), 0, st, p1);
-        if (exclusiveScanU32(st, dRC1.as<uint32_t>(), dRS1.as<uint64_t>(), nS1, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-        hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nS1, 256, 64)), dim3(256), 0, st, dRS1.as<uint64_t>(), dRCur1.as<unsigned long long>(), (uint64_t) nS1);
-        hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles, nSeg), dim3(PT_BLOCK), (size_t) 12 << p1.bits, st, p1);
-        std::swap(cur, other);
-        std::vector<uint64_t> hS1(nS1 + 1);
-        PH_CHECK(hipMemcpyAsync(hS1.data(), dRS1.p, ((size_t) nS1 + 1) * 8, hipMemcpyDeviceToHost, st));
-        PH_CHECK(plasship::streamSync(st));
-        PH_CHECK(hipGetLastError());
-        dSortStart = dRS1.as<uint64_t>(); nSortBuckets = nS1; hSortStart = hS1;
-        if (s2 > 0) {
-            uint64_t maxSeg = 0; for (uint32_t i = 0; i < nS1; i++) maxSeg = std::max(maxSeg, hS1[i + 1] - hS1[i]);
-            hipLaunchKernelGGL(diffU64Kernel, dim3(gridFor(nS1, 256, 64)), dim3(256), 0, st, dRS1.as<uint64_t>(), dRSegCnt.as<uint64_t>(), (uint64_t) nS1);
-            PH_CHECK(hipMemsetAsync(dRC2.p, 0, (size_t) nS * 4, st));
-            PartArgs p2; memset(&p2, 0, sizeof(p2));
-            p2.in = cur; p2.out = other; p2.segStart = dRS1.as<uint64_t>(); p2.segCount = dRSegCnt.as<uint64_t>(); p2.count = dRC2.as<uint32_t>();
-            p2.cursor = dRCur2.as<unsigned long long>(); p2.shift = 64 - s1 - s2; p2.bits = s2; p2.rangeBits = repBits; p2.dropSentinels = 0; p2.repBase = 0;
-            const unsigned tiles2 = (unsigned) std::max<uint64_t>(1, (maxSeg + PT_TILE - 1) / PT_TILE);
-            hipLaunchKernelGGL((partHistKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), 0, st, p2);
-            if (exclusiveScanU32(st, dRC2.as<uint32_t>(), dRS2.as<uint64_t>(), nS, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-            hipLaunchKernelGGL(copyU64Kernel, dim3(gridFor(nS, 256, 1024)), dim3(256), 0, st, dRS2.as<uint64_t>(), dRCur2.as<unsigned long long>(), (uint64_t) nS);
-            hipLaunchKernelGGL((partScatterKernel<NUCL, LONG, KEY_RANGE>), dim3(tiles2, nS1), dim3(PT_BLOCK), (size_t) 12 << p2.bits, st, p2);
-            std::swap(cur, other);
-            hSortStart.resize((size_t) nS + 1);
-            PH_CHECK(hipMemcpyAsync(hSortStart.data(), dRS2.p, ((size_t) nS + 1) * 8, hipMemcpyDeviceToHost, st));
-            PH_CHECK(plasship::streamSync(st));
-            dSortStart = dRS2.as<uint64_t>(); nSortBuckets = nS;
-        }
-    }
-    // aggregate + sort each bucket; buckets beyond the LDS capacity sort in HBM scratch
-    DevBuf dBigOff, dBigScratch, dUnique, dTripleStart;
-    {
-        std::vector<uint64_t> bigOff(nSortBuckets, 0); uint64_t bigTot = 0;
-        for (uint32_t b = 0; b < nSortBuckets; b++) {
-            const uint64_t c = hSortStart[b + 1] - hSortStart[b];
-            if (c > (uint64_t) AGG_CAP) { uint64_t P = 1; while (P < c) P <<= 1; bigOff[b] = bigTot; bigTot += (NUCL ? 3 : 2) * P; }
-        }
-        if (dBigOff.alloc((size_t) nSortBuckets * 8) != hipSuccess || dBigScratch.alloc(std::max<uint64_t>(bigTot, 1) * 8) != hipSuccess ||
-            dUnique.alloc(((size_t) nSortBuckets + 1) * 4) != hipSuccess || dTripleStart.alloc(((size_t) nSortBuckets + 2) * 8) != hipSuccess) {
-            setError("kmermatch: out of device memory for the rep sort"); return PLASSHIP_ERR_DEVICE;
-        }
-        PH_CHECK(hipMemcpyAsync(dBigOff.p, bigOff.data(), (size_t) nSortBuckets * 8, hipMemcpyHostToDevice, st));
-    }
-    // pass 1 aggregates every bucket in LDS; pass 2 revisits the buckets it flagged (more distinct triples than LDS holds)
-    for (int pass = 0; pass < 2; pass++)
-        hipLaunchKernelGGL((aggSortKernel<NUCL, LONG, false>), dim3(std::min<uint32_t>(nSortBuckets, (uint32_t) ctx->numCU * (uint32_t) tuneInt("AGGSORT", 16))), dim3(LS_BLOCK), 0, st,
-                           (const void *) cur, other, dSortStart, nSortBuckets, pass ? dBigScratch.as<unsigned long long>() : (unsigned long long *) nullptr, (const uint64_t *) dBigOff.as<uint64_t>(),
-                           dUnique.as<uint32_t>(), repBits - sBits, idBits, (uint64_t) 0, AggLines{nullptr, nullptr, nullptr}, 0);
-    DevBuf dScanTmp3; const size_t scanTmp3Bytes = exclusiveScanTmpBytes((size_t) nSortBuckets + 2);
-    if (dScanTmp3.alloc(scanTmp3Bytes) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-    if (exclusiveScanU32(st, dUnique.as<uint32_t>(), dTripleStart.as<uint64_t>(), nSortBuckets, dScanTmp3.p, scanTmp3Bytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
-    uint64_t nTriples = 0;
-    PH_CHECK(hipMemcpyAsync(&nTriples, dTripleStart.as<uint64_t>() + nSortBuckets, 8, hipMemcpyDeviceToHost, st));
-    hipLaunchKernelGGL(compactTriplesKernel, dim3(std::min<uint32_t>((nSortBuckets + 3) / 4, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st,
-                       (const Triple *) other, dSortStart, (const uint32_t *) nullptr, dTripleStart.as<uint64_t>(), nSortBuckets, (Triple *) cur);
-    msSort2 = tm.stop(1);
-    PH_TRACE(st, "kmermatch: rep sort");
-    PH_CHECK(hipGetLastError());
-
-    std::unique_ptr<plasship_cands> holder; uint64_t Nc = 0;
-    { const int rcR = reduceToCandidates<NUCL, LONG>(ctx, db, cur, nTriples, stalePos, staleT, holder, Nc, msReduce); if (rcR) return rcR; }
-    if (stats) {
-        // sharded run: what THIS rank's kernels processed (records of its buckets, grouped records of its reps, candidates of its queries)
-        stats->n_kmer_records = Nk; stats->n_grouped = NmHere; stats->n_candidates = Nc; stats->record_bytes = LONG ? 20 : 16;
-        {
-            float ms = 0, ms2 = 0; (void) hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]); (void) hipEventElapsedTime(&ms2, ctx->ev[4], ctx->ev[5]);
-            stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;
-            float msS = 0, msS2 = 0; (void) hipEventElapsedTime(&msS, ctx->ev[8], ctx->ev[9]); if (nScatter == 2) (void) hipEventElapsedTime(&msS2, ctx->ev[10], ctx->ev[11]);
-            stats->ms_part_scatter = msS + msS2; stats->n_part_scatter = nScatter;
-            unsigned long long ks[4] = {0, 0, 0, 0};
-            PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost);
-            stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
-        }
-        stats->residues = db->residues;
-        stats->ms_extract = msExtract; stats->ms_sort1 = msSort1; stats->ms_group = msGroup; stats->ms_sort2 = msSort2; stats->ms_reduce = msReduce;
-        stats->n_scratch_sequences = nOv; stats->n_restarts = 0; stats->n_cached_sequences = 0;
-    }
-    *out = holder.release();
-    return PLASSHIP_OK;
 }
 }  // namespace
 

@@ -179,12 +179,13 @@ def _chain_digests(cfg, pairs, iters, mode):
 @pytest.mark.timeout(3000)
 def test_headline_size_three_implementations_agree():
     """BASELINE.json configs[2] at FULL size (25 M read pairs = 50 M reads -> 88 M protein fragments, 5.3 G k-mer record slots:
-    beyond 2^32, ten times what the CPU oracle can follow): all 12 iterations run three ways — the line-store path, the dense
-    histogram/scatter partition with the three-phase group kernel (PLASSHIP_LEGACY_PARTITION=1) and the sharded orchestration in a
-    1-rank group — must give identical counts and identical digests of seq_1..seq_12.  PLASS_TEST_HEADLINE_PAIRS scales it down."""
+    beyond 2^32, ten times what the CPU oracle can follow): all 12 iterations run three ways — the path as it ships (selected-window
+    cache, DBs as indices over a shared heap), the same with both switched off (every window hashed, every DB copied whole) and the
+    sharded orchestration in a 1-rank group — must give identical counts and identical digests of seq_1..seq_12.
+    PLASS_TEST_HEADLINE_PAIRS scales it down."""
     pairs = int(os.environ.get("PLASS_TEST_HEADLINE_PAIRS", "25000000"))
     iters = int(os.environ.get("PLASS_TEST_HEADLINE_ITERS", "12"))
-    runs = [_chain_digests("c3", pairs, iters, m) for m in ("lines", "legacy", "sharded1")]
+    runs = [_chain_digests("c3", pairs, iters, m) for m in ("lines", "plain", "sharded1")]
     if pairs >= 25000000:
         assert runs[0]["iterations"][0]["N_k"] > 2.9e9 and runs[0]["fragments"] > 80e6
     for r in runs[1:]:
@@ -192,7 +193,7 @@ def test_headline_size_three_implementations_agree():
         for it, (a, b) in enumerate(zip(runs[0]["iterations"], r["iterations"])):
             for k in ("N_c", "verified", "extended", "residues", "digest"):
                 assert a[k] == b[k], "iteration %d: %s of the %s path is %s, of the line-store path %s" % (it, k, r["mode"], b[k], a[k])
-            if r["mode"] == "legacy":
+            if r["mode"] == "plain":
                 assert (a["N_k"], a["N_m"]) == (b["N_k"], b["N_m"])
     committed = json.load(open(os.path.join(HERE, "golden", "c3_chain_digests.json")))
     if committed.get("pairs") == pairs:                      # the digests bench.py prints and checks for this workload
