@@ -372,7 +372,10 @@ int main(int argc, char **argv) {
         const bool prot = mod == "assemble-chain", nuc = mod == "nuclassemble-chain", gd = mod == "guidedassemble-chain";
         if (pos.size() != (gd ? 3u : 2u)) { fprintf(stdout, "%s: wrong number of databases\n", mod.c_str()); return EXIT_FAILURE; }
         if (f.numIterations < 1) { fprintf(stdout, "--num-iterations must be at least 1\n"); return EXIT_FAILURE; }
-        plasship_ctx *wctx = nullptr; std::thread writer; int writerRc = 0;
+        plasship_ctx *wctx = nullptr; std::thread writer; int writerRc = 0; std::string writerErr;
+        // every exit path below joins the writer first (a joinable std::thread that goes out of scope terminates the process, and an
+        // intermediate DB must not be left half written behind an ordinary error message: ADVICE r3)
+        struct JoinOnExit { std::thread &t; ~JoinOnExit() { if (t.joinable()) t.join(); } } joinOnExit{writer};
         if (!f.writeIntermediate.empty() && plasship_ctx_create(-1, &wctx)) return fail(mod.c_str());
         auto joinWriter = [&]() { if (writer.joinable()) writer.join(); return writerRc; };
         auto writeAsync = [&](const plasship_seqdb *d, const std::string &name) {
@@ -380,7 +383,7 @@ int main(int argc, char **argv) {
             joinWriter();
             const std::string path = f.writeIntermediate + "/" + name;
             writer = std::thread([&, d, path]() {
-                if (plasship_seqdb_write(wctx, d, path.c_str())) { writerRc = 1; return; }
+                if (plasship_seqdb_write(wctx, d, path.c_str())) { writerRc = 1; writerErr = plasship_last_error(); return; }      // (the error text is the writer THREAD's)
                 FILE *fd = fopen((path + ".done").c_str(), "w"); if (fd) fclose(fd); else writerRc = 1;     // data/assemble.sh:147 `touch assembly_$STEP.done`
             });
         };
@@ -446,7 +449,7 @@ int main(int argc, char **argv) {
             } else if (plasship_assemble(ctx, db, al, &ap, &next, &as)) return fail(mod.c_str());
             kernelMs += as.ms_kernel;
             plasship_alns_free(ctx, al); plasship_cands_free(ctx, c);
-            if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), plasship_last_error()); return EXIT_FAILURE; }   // the writer read `db`
+            if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), writerErr.c_str()); return EXIT_FAILURE; }   // the writer read `db`
             plasship_seqdb_free(ctx, db); if (gd) plasship_seqdb_free(ctx, aa);
             db = next; aa = nextAa;
             if (nuc) {     // data/nuclassemble.sh:19-61,132: circular contigs leave the loop, the rest goes on
@@ -459,7 +462,7 @@ int main(int argc, char **argv) {
             if (it + 1 < f.numIterations) writeAsync(db, (gd ? "assembly_nucl_" : "assembly_") + std::to_string(it));
         }
         const double tLoop = now();
-        if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), plasship_last_error()); return EXIT_FAILURE; }
+        if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), writerErr.c_str()); return EXIT_FAILURE; }
         if (plasship_seqdb_write(ctx, db, pos[1].c_str()) || (gd && plasship_seqdb_write(ctx, aa, pos[2].c_str()))) return fail(mod.c_str());
         const double tEnd = now();
         fprintf(stdout, "chain: %d iterations, %llu candidate overlaps | read %.3fs preprocessing %.3fs iterations %.3fs (kernels %.3fs) write %.3fs\n", f.numIterations, overlaps,

@@ -7,6 +7,7 @@
 #include <atomic>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/plasship.h"
@@ -156,6 +157,9 @@ struct plasship_seqdb {
     // bytes differ from the parent's.  0 = no such parent (read from disk, generated, concatenated, entries dropped).
     uint64_t gen = plasship::newDbGeneration(), parentGen = 0;
     plasship::DevBuf d_changed;
+    // d_ext (one word per id, with d_changed; may be empty): for an entry the assembler EXTENDED — new = a residues + the parent's
+    // entry + b residues — (a << 16) | length of the parent's entry; 0xFFFFFFFF otherwise (unchanged, cut, layouts >= 65536)
+    plasship::DevBuf d_ext;
     size_t n = 0;
     uint64_t dataBytes = 0, residues = 0;
     uint32_t maxEntryLen = 0;
@@ -172,6 +176,10 @@ struct plasship_seqdb {
     // offset and length of every entry packed into one word (plasship::ensureOffLen): the kernels that look up RANDOM entries
     // (the targets of candidate pairs and alignments) fetch one line per entry instead of one of d_off and one of d_len
     mutable plasship::DevBuf d_offLen;
+    // (built lazily on the stream of the first context that needs it; a second context on the same handle — the chain driver's writer
+    //  thread, ranks sharing a DB — takes the lock and waits for that kernel on its own stream: ensureOffLen, core.hip)
+    mutable std::mutex offLenMu; mutable hipEvent_t offLenEv = nullptr; mutable hipStream_t offLenStream = nullptr;
+    ~plasship_seqdb() { if (offLenEv) (void) hipEventDestroy(offLenEv); }
     // host mirror of the index (lazily filled for device-produced DBs)
     bool hostIndexValid = false;
     std::vector<uint32_t> h_key, h_elen;
@@ -232,9 +240,13 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
 // a copy of `db` with its entries back to back in key order in a buffer of its own (assemble.hip); callers that stream or copy the
 // data of a DB as one block (DB files, downloads, concatdbs) take it when !db->contiguous
 int packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::unique_ptr<plasship_seqdb> &out);
+// extOrigin (assembleresults only): where the ORIGINAL entry of id lies in the arena = arenaOff[id] + leftCap[id]; with it the output
+// DB records how far each extended entry grew to the left (plasship_seqdb::d_ext)
+struct ExtOrigin { const uint64_t *arenaOff; const uint32_t *leftCap; };
 int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                   const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                  const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr);
+                  const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr,
+                  const ExtOrigin *extOrigin = nullptr);
 // ---- host boundary (core.hip): bulk copies through the context's pinned double buffer, on the context stream ----
 // H2D of `total` bytes the caller produces chunk by chunk: produce(dst, byteOffset, bytes) fills a pinned chunk (consecutive chunks,
 // in order; it may use the host threads) while the previous chunk is in flight.  Returns after the last copy has completed.

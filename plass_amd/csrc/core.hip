@@ -329,26 +329,56 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
     PH_ENTER(ctx);
     // ids are ranks in key order (DBReader::getId); repack the data in id order so that device offsets
     // are monotone and neighbouring ids are neighbours in HBM.
+    // (every loop over the entries runs on all host threads: 88 M entries at 50 M reads, and the GPU waits for this — round 4)
     std::vector<uint32_t> perm(n);
-    std::iota(perm.begin(), perm.end(), 0u);
-    bool sorted = true;
-    for (size_t i = 1; i < n && sorted; i++) sorted = key[i - 1] <= key[i];
+    std::atomic<bool> sortedA(true);
+    parallelRanges(n, [&](int, size_t b, size_t e) {
+        bool ok = true;
+        for (size_t i = b; i < e; i++) { perm[i] = (uint32_t) i; if (i > 0 && key[i - 1] > key[i]) ok = false; }
+        if (!ok) sortedA = false;
+    });
+    const bool sorted = sortedA;
     if (!sorted) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
     std::unique_ptr<plasship_seqdb> holder(new plasship_seqdb());   // released to the caller on success only
     plasship_seqdb *db = holder.get();
     db->dbtype = dbtype; db->n = n;
     db->h_key.resize(n); db->h_elen.resize(n); db->h_off.resize(n);
+    std::vector<uint32_t> hlen(n);
     uint64_t total = 0; uint32_t maxE = 0;
-    for (size_t i = 0; i < n; i++) {
-        uint32_t s = perm[i];
-        if (off[s] + elen[s] > data_bytes) { setError("plasship_seqdb_upload: entry beyond data"); return PLASSHIP_ERR_ARG; }
-        if (elen[s] < 2) { setError("plasship_seqdb_upload: sequence entry shorter than \"\\n\\0\""); return PLASSHIP_ERR_ARG; }
-        db->h_key[i] = key[s]; db->h_elen[i] = elen[s]; db->h_off[i] = total;
-        total += elen[s]; maxE = std::max(maxE, elen[s]);
+    {   // offsets in id order = prefix sums of the entry lengths: per-range sums first, then every range fills its part
+        const int maxT = hostThreads();
+        std::vector<uint64_t> rangeSum((size_t) maxT + 1, 0), rangeBeg((size_t) maxT + 1, 0); std::vector<uint32_t> rangeMax((size_t) maxT + 1, 0);
+        std::vector<std::pair<size_t, size_t>> ranges((size_t) maxT + 1, std::make_pair((size_t) 0, (size_t) 0));
+        std::atomic<int> bad(0);
+        const int used = parallelRanges(n, [&](int t, size_t b, size_t e) {
+            uint64_t sum = 0; uint32_t mx = 0;
+            for (size_t i = b; i < e; i++) {
+                const uint32_t sI = perm[i];
+                if (off[sI] + elen[sI] > data_bytes) { bad = 1; return; }
+                if (elen[sI] < 2) { bad = 2; return; }
+                sum += elen[sI]; mx = std::max(mx, elen[sI]);
+            }
+            rangeSum[(size_t) t] = sum; rangeMax[(size_t) t] = mx; ranges[(size_t) t] = std::make_pair(b, e);
+        });
+        if (bad == 1) { setError("plasship_seqdb_upload: entry beyond data"); return PLASSHIP_ERR_ARG; }
+        if (bad == 2) { setError("plasship_seqdb_upload: sequence entry shorter than \"\\n\\0\""); return PLASSHIP_ERR_ARG; }
+        // (the ranges are contiguous and ascending in t: parallelRanges hands out [0, n) in order)
+        std::vector<int> order((size_t) used); for (int t = 0; t < used; t++) order[(size_t) t] = t;
+        std::sort(order.begin(), order.end(), [&](int x, int y) { return ranges[(size_t) x].first < ranges[(size_t) y].first; });
+        for (int q = 0; q < used; q++) { const int t = order[(size_t) q]; rangeBeg[(size_t) t] = total; total += rangeSum[(size_t) t]; maxE = std::max(maxE, rangeMax[(size_t) t]); }
+        std::vector<std::pair<size_t, size_t>> rs(ranges.begin(), ranges.begin() + used);
+        parallelRanges((size_t) used, [&](int, size_t qb, size_t qe) {
+            for (size_t q = qb; q < qe; q++) {
+                uint64_t o = rangeBeg[q];
+                for (size_t i = rs[q].first; i < rs[q].second; i++) {
+                    const uint32_t sI = perm[i];
+                    db->h_key[i] = key[sI]; db->h_elen[i] = elen[sI]; db->h_off[i] = o; hlen[i] = elen[sI] - 2;
+                    o += elen[sI];
+                }
+            }
+        }, nullptr, 1);
     }
     db->dataBytes = total; db->maxEntryLen = maxE; db->residues = total - 2 * (uint64_t) n; db->hostIndexValid = true;
-    std::vector<uint32_t> hlen(n);
-    for (size_t i = 0; i < n; i++) hlen[i] = db->h_elen[i] - 2;
     // pad the data buffer so 16-byte vector loads at the tail stay in bounds
     if (db->d_data.alloc(total + 64) != hipSuccess || db->d_off.alloc((n + 1) * 8) != hipSuccess ||
         db->d_len.alloc((n + 1) * 4) != hipSuccess || db->d_key.alloc((n + 1) * 4) != hipSuccess) {
@@ -511,11 +541,19 @@ __global__ void packOffLenKernel(const uint64_t *__restrict__ off, const uint32_
 // plasship_seqdb::d_offLen, built on the first call that looks up random entries of the DB (sequences are shorter than 2^20, a DB
 // smaller than 2^40 bytes).  Stream-ordered: the caller's kernels follow on ctx->stream.
 int ensureOffLen(plasship_ctx *ctx, const plasship_seqdb *db) {
-    if (db->d_offLen.p || db->n == 0) return PLASSHIP_OK;
+    if (db->n == 0) return PLASSHIP_OK;
+    std::lock_guard<std::mutex> g(db->offLenMu);
+    if (db->d_offLen.p) {       // built by another context: its kernel must have run before this stream reads the words
+        if (db->offLenStream != ctx->stream && db->offLenEv) PH_CHECK(hipStreamWaitEvent(ctx->stream, db->offLenEv, 0));
+        return PLASSHIP_OK;
+    }
     if (db->maxEntryLen >= (1u << 24) || db->dataBytes >= (1ull << 40)) { setError("a sequence DB with an entry of 2^24 bytes or more, or of 2^40 bytes or more in total, is not supported"); return PLASSHIP_ERR_UNSUPPORTED; }
     if (db->d_offLen.alloc(db->n * 8) != hipSuccess) { setError("out of device memory for the packed offsets of a sequence DB"); return PLASSHIP_ERR_DEVICE; }
     hipLaunchKernelGGL(packOffLenKernel, dim3((unsigned) std::min<uint64_t>((db->n + 255) / 256, (uint64_t) ctx->numCU * 16)), dim3(256), 0, ctx->stream,
                        db->d_off.as<uint64_t>(), db->d_len.as<uint32_t>(), (uint64_t) db->n, db->d_offLen.as<uint64_t>());
+    db->offLenStream = ctx->stream;
+    if (!db->offLenEv) PH_CHECK(hipEventCreateWithFlags(&db->offLenEv, hipEventDisableTiming));
+    PH_CHECK(hipEventRecord(db->offLenEv, ctx->stream));
     return PLASSHIP_OK;
 }
 }  // namespace plasship

@@ -103,6 +103,7 @@ bool readDBFiles(const std::string &path, HostDB &db, std::string &err) {
     const uint64_t dataSize = total;
     const int used = parallelRanges(nb, [&](int tix, size_t b, size_t e) {
         Part &pt = parts[(size_t) tix];
+        { const size_t guess = (e - b) / 16 + 16; pt.key.reserve(guess); pt.off.reserve(guess); pt.elen.reserve(guess); }      // an index line is >= 6, typically 15-25 bytes
         const char *p = base + b, *end = base + e, *fileEnd = base + nb;
         if (b > 0) { while (p < fileEnd && p[-1] != '\n') p++; }              // first line start at or after b
         while (p < end) {
@@ -120,12 +121,14 @@ bool readDBFiles(const std::string &path, HostDB &db, std::string &err) {
     size_t lines = 0;
     for (int t = 0; t < used; t++) { if (parts[(size_t) t].bad) { err = "index entry points past the data of " + path; return false; } lines += parts[(size_t) t].key.size(); }
     db.key.resize(lines); db.off.resize(lines); db.elen.resize(lines);
-    size_t at = 0;
-    for (int t = 0; t < used; t++) {
-        const Part &pt = parts[(size_t) t];
-        if (!pt.key.empty()) { memcpy(&db.key[at], pt.key.data(), pt.key.size() * 4); memcpy(&db.off[at], pt.off.data(), pt.off.size() * 8); memcpy(&db.elen[at], pt.elen.data(), pt.elen.size() * 4); }
-        at += pt.key.size();
-    }
+    std::vector<size_t> at((size_t) used + 1, 0);
+    for (int t = 0; t < used; t++) at[(size_t) t + 1] = at[(size_t) t] + parts[(size_t) t].key.size();
+    parallelRanges((size_t) used, [&](int, size_t tb, size_t te) {
+        for (size_t t = tb; t < te; t++) {
+            const Part &pt = parts[t];
+            if (!pt.key.empty()) { memcpy(&db.key[at[t]], pt.key.data(), pt.key.size() * 4); memcpy(&db.off[at[t]], pt.off.data(), pt.off.size() * 8); memcpy(&db.elen[at[t]], pt.elen.data(), pt.elen.size() * 4); }
+        }
+    }, nullptr, 1);
     return true;
 }
 

@@ -1,9 +1,8 @@
 """One-process-per-GPU plumbing for the hot path (torch.distributed; backend "nccl" = RCCL on ROCm, "gloo" in CPU tests).
 
 bench.py's control plane: process-group set-up, the barrier-bracketed step time (max over ranks) and the overlap count
-(sum over ranks).  The data path of a sharded run (one read set over the GPUs: DESIGN.md §6) is in plass_amd/shard.py;
-`partition_plan` / `exchange_records` serve the older `--mode partitions` run (independent read sets, no data-path
-collective) and the 2-rank gloo test of the count + record all-to-all.
+(sum over ranks).  The data path of a sharded run (one read set over the GPUs: DESIGN.md §6) is in the library
+(plass_amd/csrc/comm.hip, comm_rccl.hip) and, for the caller-supplied collectives, in plass_amd/shard.py.
 """
 import os
 
