@@ -167,7 +167,7 @@ def source_sha():
 KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShort(Fast)?Kernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
                   "partitionKernel(k-mer records)": "linePartKernel<.*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel",
                   "assembleNuclKernel(+assembleNuclThreadKernel, all passes)": "assembleNucl(Thread)?Kernel<"}
-PMC_FILES = {"c3": "r03_pmc_traffic.json", "c5": "r04_pmc_traffic_c5.json"}      # (c3: replaced by the round-4 pass when it has run)
+PMC_FILES = {"c3": "r04_pmc_traffic.json", "c5": "r04_pmc_traffic_c5.json"}
 
 
 def stored_traffic(kernel, launches_per_step, cfg="c3"):
@@ -349,8 +349,8 @@ def main():
                 i = db.info(); print("step %d iteration %d: %d sequences, %d residues, longest entry %d" % (s, it, i["n"], i["residues"], i["max_entry_len"]), file=sys.stderr, flush=True)
             out, kst, rst, ast, wall = one_iteration(ctx, db, it)
             if VERBOSE and rank == 0:
-                print("   N_k=%d N_m=%d N_c=%d cached=%d incr=%d extract %.1f (short %.1f wave %.1f) | scored=%d accepted=%d | aln=%d extended=%d rescored=%d db +%.2f GB / copy %.2f GB asm %.1f | wall ms %s" % (
-                    kst.n_kmer_records, kst.n_grouped, kst.n_candidates, kst.n_cached_sequences, kst.n_incremental_sequences, kst.ms_extract, kst.ms_extract_short_kernel, kst.ms_extract_wave_kernel,
+                print("   N_k=%d N_m=%d N_c=%d cached=%d extract %.1f (short %.1f wave %.1f) | scored=%d accepted=%d | aln=%d extended=%d rescored=%d db +%.2f GB / copy %.2f GB asm %.1f | wall ms %s" % (
+                    kst.n_kmer_records, kst.n_grouped, kst.n_candidates, kst.n_cached_sequences, kst.ms_extract, kst.ms_extract_short_kernel, kst.ms_extract_wave_kernel,
                     rst.n_scored, rst.n_accepted, ast.n_alignments, ast.n_extended, ast.n_rescored, ast.db_appended_bytes / 1e9, ast.db_copied_bytes / 1e9, ast.ms_kernel,
                     ["%.1f" % x for x in wall[:3]]), file=sys.stderr, flush=True)
             if record:

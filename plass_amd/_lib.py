@@ -28,7 +28,7 @@ class KmermatchStats(C.Structure):
                 ("residues", C.c_uint64), ("ms_extract_short_kernel", C.c_float), ("ms_extract_wave_kernel", C.c_float),
                 ("short_residues", C.c_uint64), ("short_records", C.c_uint64), ("wave_residues", C.c_uint64), ("wave_records", C.c_uint64),
                 ("ms_part_scatter", C.c_float), ("n_part_scatter", C.c_int32), ("n_scratch_sequences", C.c_uint32), ("n_restarts", C.c_uint32),
-                ("n_cached_sequences", C.c_uint32), ("n_incremental_sequences", C.c_uint32)]
+                ("n_cached_sequences", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 class _RescoreParams(C.Structure):

@@ -1205,20 +1205,13 @@ __global__ void outLenKernel(SeqView s, const uint32_t *__restrict__ flags, cons
 // where they are, a rewritten one (flag 0x20: extended, cut, chopped) is copied from the arena to heapBase + appOff[id] behind
 // everything the heap held.  G lanes per entry; what moves per iteration is the rewritten 10-20 % of the sequences instead of
 // 2 x all residues (writeOutKernel below: 15 ms per iteration at 50 M reads, the same again on every rank of a sharded run).
-// plasship_seqdb::d_ext of one entry: (residues added on the left << 16) | old length for an extended entry whose lengths fit 16 bits
-__device__ __forceinline__ uint32_t extWord(bool ext, const ExtOrigin &org, uint32_t id, const uint64_t *newStart, uint32_t oldLen, uint32_t newLen) {
-    if (!ext || !org.arenaOff) return 0xFFFFFFFFu;
-    const uint64_t left = org.arenaOff[id] + org.leftCap[id] - newStart[id];
-    if (left > 0xFFFFull || oldLen > 0xFFFFu || left + oldLen > newLen) return 0xFFFFFFFFu;
-    return (uint32_t) (left << 16) | oldLen;
-}
 template <int G>
 __global__ __launch_bounds__(256) void appendOutKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen,
                                                        const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
                                                        const uint64_t *__restrict__ appOff, uint64_t heapBase, const uint32_t *__restrict__ keep,
                                                        const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
                                                        char *__restrict__ heap, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey,
-                                                       unsigned char *__restrict__ changedOut, uint32_t *__restrict__ extOut, ExtOrigin org) {
+                                                       unsigned char *__restrict__ changedOut) {
     const int gl = threadIdx.x & (G - 1);
     constexpr int groupsPerBlock = 256 / G;
     for (uint32_t id = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id < s.n; id += gridDim.x * groupsPerBlock) {
@@ -1239,7 +1232,6 @@ __global__ __launch_bounds__(256) void appendOutKernel(SeqView s, const uint32_t
             const uint64_t j = keepPos[id];
             outOffArr[j] = o; outLen[j] = L; outKey[j] = inKey[id];
             if (changedOut) changedOut[j] = ext ? 1 : 0;
-            if (extOut) extOut[j] = extWord(ext, org, id, newStart, s.len[id], L);
         }
     }
 }
@@ -1250,7 +1242,7 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
                                                       const uint64_t *__restrict__ outOff, const uint32_t *__restrict__ keep,
                                                       const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
                                                       char *__restrict__ outData, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey,
-                                                      unsigned char *__restrict__ changedOut, uint32_t *__restrict__ extOut, ExtOrigin org) {
+                                                      unsigned char *__restrict__ changedOut) {
     // G lanes per sequence, 8 bytes per lane and step: 8 lanes take a read fragment (~46 residues) in one step with most lanes busy,
     // eight sequences per wavefront; contigs take a few steps of contiguous 64-byte pieces.  A sequence is a chain of dependent
     // round trips (what to copy -> the bytes -> the store) and the kernel is bound by the number of chains in flight (round 3: the
@@ -1294,7 +1286,6 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
                 const uint64_t j = keepPos[id];
                 outOffArr[j] = o[u]; outLen[j] = L[u]; outKey[j] = inKey[id];
                 if (changedOut) changedOut[j] = (flags[id] & 0x20u) ? 1 : 0;       // (only when nothing is dropped: j == id)
-                if (extOut) extOut[j] = extWord((flags[id] & 0x20u) != 0, org, id, newStart, s.len[id], L[u]);
             }
         }
     }
@@ -1395,7 +1386,7 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
 // mode 1: a packed copy in an exact buffer (packedCopyOf)
 static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                              const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                             const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent, int mode, const ExtOrigin *extOrigin) {
+                             const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent, int mode) {
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();
@@ -1419,15 +1410,14 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
     std::unique_ptr<plasship_seqdb> holder(new plasship_seqdb());   // released to the caller on success only
     plasship_seqdb *o = holder.get();
     o->dbtype = db->dbtype; o->n = (size_t) outN; o->dataBytes = outBytes; o->residues = outBytes - 2 * outN; o->hostIndexValid = false;
-    if (o->d_off.alloc((outN + 1) * 8) != hipSuccess || o->d_len.alloc((outN + 1) * 4) != hipSuccess || o->d_key.alloc((outN + 1) * 4) != hipSuccess) {
+    if (o->d_off.allocLong((outN + 1) * 8) != hipSuccess || o->d_len.allocLong((outN + 1) * 4) != hipSuccess || o->d_key.allocLong((outN + 1) * 4) != hipSuccess) {
         setError("plasship_assemble: out of device memory for the output DB's index"); return PLASSHIP_ERR_DEVICE;
     }
     // lineage for kmermatcher's selected-window cache: same ids as `db`, the extended / cut entries marked
     if (outN == N && N && mode == 0) {
-        if (o->d_changed.alloc((size_t) N) != hipSuccess || (extOrigin && o->d_ext.alloc((size_t) N * 4) != hipSuccess)) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        if (o->d_changed.allocLong((size_t) N) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         o->parentGen = db->gen;
     }
-    const ExtOrigin org = (extOrigin && o->d_ext.p) ? *extOrigin : ExtOrigin{nullptr, nullptr};
     // room in the shared heap?  (the reservation is atomic: two DBs derived from one parent get disjoint ranges; a reservation that
     // does not fit is simply left unused — the heap is about to be replaced anyway)
     bool append = false; uint64_t heapBase = 0;
@@ -1439,7 +1429,7 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
         o->heap = db->heap; o->contiguous = false;
         if (N) hipLaunchKernelGGL((appendOutKernel<8>), dim3(std::min<uint32_t>((N + 31) / 32, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16))), dim3(256), 0, st, sv, dFlags, dNewLen, dNewStart, dArena,
                                   (const uint64_t *) dAppOff.as<uint64_t>(), heapBase, (const uint32_t *) dKeep.as<uint32_t>(), (const uint64_t *) dKeepPos.as<uint64_t>(), (const uint32_t *) db->d_key.as<uint32_t>(),
-                                  db->heap->buf.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>(), o->d_ext.as<uint32_t>(), org);
+                                  db->heap->buf.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
     } else {
         char *dst = nullptr;
         if (useHeaps) {
@@ -1447,11 +1437,11 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
             // room for the entries the next iterations rewrite (25-35 % of the data per iteration at 50 M reads): as much again as the
             // data, but no more than PLASSHIP_TUNE_DBHEAP_GB (default 8) — kmermatcher's record arrays need 170 of the 288 GB there
             const uint64_t cap = outBytes + std::min<uint64_t>(outBytes, (uint64_t) tuneInt("DBHEAP_GB", 8) << 30) + 4096;
-            if (o->heap->buf.alloc(cap) == hipSuccess) { o->heap->used = outBytes; dst = o->heap->buf.as<char>(); }
+            if (o->heap->buf.allocLong(cap) == hipSuccess) { o->heap->used = outBytes; dst = o->heap->buf.as<char>(); }
             else o->heap.reset();                             // no room for the slack: an exact buffer will do
         }
         if (!dst) {
-            if (o->d_data.alloc(outBytes + 64) != hipSuccess) {
+            if (o->d_data.allocLong(outBytes + 64) != hipSuccess) {
                 size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
                 setError("plasship_assemble: out of device memory for the output DB (" + std::to_string(outBytes) + " bytes, " + std::to_string(outN) + " sequences; device free " + std::to_string(fr) + " of " + std::to_string(tt) + ")"); return PLASSHIP_ERR_DEVICE;
             }
@@ -1464,7 +1454,7 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
             const unsigned woGrid = std::min<uint32_t>((N + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16));
             hipLaunchKernelGGL((writeOutKernel<8, 1>), dim3(woGrid), dim3(256), 0, st, sv, dFlags, dNewLen,
                                dNewStart, dArena, dOutOff.as<uint64_t>(), dKeep.as<uint32_t>(), dKeepPos.as<uint64_t>(), db->d_key.as<uint32_t>(),
-                               dst, o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>(), o->d_ext.as<uint32_t>(), org);
+                               dst, o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
         }
     }
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + outN, &outBytes, 8, hipMemcpyHostToDevice, st));
@@ -1483,8 +1473,8 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
 }
 int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                             const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                            const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent, const ExtOrigin *extOrigin) {
-    return buildOutputDBImpl(ctx, db, dFlags, dNewLen, dNewStart, dArena, keepTarget, dTmp, tmpBytes, out, dExtra, hExtra, extraBytes, doneEvent, 0, extOrigin);
+                            const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent) {
+    return buildOutputDBImpl(ctx, db, dFlags, dNewLen, dNewStart, dArena, keepTarget, dTmp, tmpBytes, out, dExtra, hExtra, extraBytes, doneEvent, 0);
 }
 int plasship::packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::unique_ptr<plasship_seqdb> &out) {
     const uint32_t N = (uint32_t) db->n;
@@ -1492,7 +1482,7 @@ int plasship::packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::uni
     if (dFlags.alloc(((size_t) N + 1) * 4) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship: out of device memory while packing a sequence DB"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync(dFlags.p, 0, ((size_t) N + 1) * 4, ctx->stream));
     plasship_seqdb *o = nullptr;
-    const int rc = buildOutputDBImpl(ctx, db, dFlags.as<uint32_t>(), nullptr, nullptr, nullptr, 1, dTmp.p, tmpBytes, &o, nullptr, nullptr, 0, nullptr, 1, nullptr);
+    const int rc = buildOutputDBImpl(ctx, db, dFlags.as<uint32_t>(), nullptr, nullptr, nullptr, 1, dTmp.p, tmpBytes, &o, nullptr, nullptr, 0, nullptr, 1);
     if (rc) return rc;
     o->maxEntryLen = db->maxEntryLen;
     out.reset(o);
@@ -1735,12 +1725,8 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         if (rc != PLASSHIP_OK) return rc;
         arenaP = dGathered.as<char>(); aaArenaP = dGatheredAa.as<char>();
     }
-    // (protein DBs on one GPU: the output DB also records how far each extended entry grew to the left — kmermatcher's incremental
-    //  extraction of the next same-seed iteration, kmermatch.hip section 2d; the arena of a sharded run is the gathered one)
-    const ExtOrigin extOrg{dArenaOff.as<uint64_t>(), dLeftCap.as<uint32_t>()};
-    const bool recordExt = !nucl && !guided && !commOf(ctx);
     int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), arenaP, par->keep_target, dTmp.p, tmpBytes, &o,
-                              dStats.p, hs, 128, guided ? (hipEvent_t) nullptr : ctx->ev[1], recordExt ? &extOrg : nullptr);
+                              dStats.p, hs, 128, guided ? (hipEvent_t) nullptr : ctx->ev[1]);
     if (rcOut != PLASSHIP_OK) return rcOut;
     std::unique_ptr<plasship_seqdb> holdO(o), holdAa;              // released to the caller on success only
     if (guided) {

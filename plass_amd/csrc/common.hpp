@@ -56,7 +56,11 @@ bool traceOn();
 // Caching device allocator: hipMalloc/hipFree synchronise the device and cost 0.1–1 ms each, which would
 // dominate an assembly iteration on a 1 M-read set.  Freed blocks are kept (size classes with <= 12.5 % slack)
 // and handed out again; everything is returned to HIP when the last context is destroyed or on out-of-memory.
-hipError_t poolMalloc(void **p, size_t n);
+// longLived: a buffer that outlives the module call that makes it (sequence DBs and their heaps, the selected-window cache).  It is
+// placed at the TOP of the highest free range that holds it instead of at the front of the best-fitting one, so that the long-lived
+// buffers collect at one end of the arena and the 60 GB record arrays of kmermatcher keep finding contiguous room (round 4: with
+// heaps and cache lines scattered over the arena the 50 M-read chain ran out of memory with 80 GB free).
+hipError_t poolMalloc(void **p, size_t n, bool longLived = false);
 // every C-ABI entry that allocates calls this first (PH_ENTER): the stream the calling thread's allocations belong to
 void poolEnter(hipStream_t stream);
 #define PH_ENTER(ctx)                                                                    \
@@ -73,7 +77,8 @@ struct DevBuf {
     DevBuf() {}
     DevBuf(const DevBuf &) = delete; DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    hipError_t alloc(size_t n) { release(); bytes = n; if (n == 0) { p = nullptr; return hipSuccess; } return poolMalloc(&p, n); }
+    hipError_t alloc(size_t n, bool longLived = false) { release(); bytes = n; if (n == 0) { p = nullptr; return hipSuccess; } return poolMalloc(&p, n, longLived); }
+    hipError_t allocLong(size_t n) { return alloc(n, true); }
     void release() { if (p) { poolFree(p); p = nullptr; } bytes = 0; }
     template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
 };
@@ -157,9 +162,6 @@ struct plasship_seqdb {
     // bytes differ from the parent's.  0 = no such parent (read from disk, generated, concatenated, entries dropped).
     uint64_t gen = plasship::newDbGeneration(), parentGen = 0;
     plasship::DevBuf d_changed;
-    // d_ext (one word per id, with d_changed; may be empty): for an entry the assembler EXTENDED — new = a residues + the parent's
-    // entry + b residues — (a << 16) | length of the parent's entry; 0xFFFFFFFF otherwise (unchanged, cut, layouts >= 65536)
-    plasship::DevBuf d_ext;
     size_t n = 0;
     uint64_t dataBytes = 0, residues = 0;
     uint32_t maxEntryLen = 0;
@@ -240,13 +242,9 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
 // a copy of `db` with its entries back to back in key order in a buffer of its own (assemble.hip); callers that stream or copy the
 // data of a DB as one block (DB files, downloads, concatdbs) take it when !db->contiguous
 int packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::unique_ptr<plasship_seqdb> &out);
-// extOrigin (assembleresults only): where the ORIGINAL entry of id lies in the arena = arenaOff[id] + leftCap[id]; with it the output
-// DB records how far each extended entry grew to the left (plasship_seqdb::d_ext)
-struct ExtOrigin { const uint64_t *arenaOff; const uint32_t *leftCap; };
 int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                   const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                  const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr,
-                  const ExtOrigin *extOrigin = nullptr);
+                  const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr);
 // ---- host boundary (core.hip): bulk copies through the context's pinned double buffer, on the context stream ----
 // H2D of `total` bytes the caller produces chunk by chunk: produce(dst, byteOffset, bytes) fills a pinned chunk (consecutive chunks,
 // in order; it may use the host threads) while the previous chunk is in flight.  Returns after the last copy has completed.

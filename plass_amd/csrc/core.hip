@@ -41,17 +41,26 @@ int g_ctxCount = 0;
 size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
 
 // best fit over all free ranges of the device (a few hundred at most)
-bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor, bool *waitAll) {
-    int bs = -1; size_t bo = 0, bsz = ~(size_t) 0;
+bool takeRange(DevicePool &dp, int dev, size_t n, void **p, hipStream_t *waitFor, bool *waitAll, bool longLived) {
+    int bs = -1; size_t bo = 0, bsz = ~(size_t) 0; const char *bestEnd = nullptr;
     for (size_t i = 0; i < dp.slabs.size(); i++)
-        for (auto &kv : dp.slabs[i].free) if (kv.second.size >= n && kv.second.size < bsz) { bs = (int) i; bo = kv.first; bsz = kv.second.size; }
+        for (auto &kv : dp.slabs[i].free) {
+            if (kv.second.size < n) continue;
+            if (longLived) {        // the free range that ends highest in the largest slab (the big one of a large job)
+                const char *end = dp.slabs[i].base + kv.first + kv.second.size;
+                if (bs < 0 || dp.slabs[i].size > dp.slabs[bs].size || (dp.slabs[i].size == dp.slabs[bs].size && end > bestEnd)) { bs = (int) i; bo = kv.first; bsz = kv.second.size; bestEnd = end; }
+            } else if (kv.second.size < bsz) { bs = (int) i; bo = kv.first; bsz = kv.second.size; }
+        }
     if (bs < 0) return false;
     Slab &sl = dp.slabs[bs];
     const FreeRange fr = sl.free[bo];
     sl.free.erase(bo);
-    if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
+    size_t at = bo;
+    if (longLived) { at = bo + fr.size - n; if (fr.size > n) sl.free[bo] = FreeRange{fr.size - n, fr.stream, fr.mixed}; }
+    else if (fr.size > n) sl.free[bo + n] = FreeRange{fr.size - n, fr.stream, fr.mixed};
     sl.used += n;
-    *p = sl.base + bo;
+    *p = sl.base + at;
+    bo = at;
     g_poolLive[*p] = PoolLive{dev, bs, bo, n, tl_poolStream};
     *waitAll = fr.mixed; *waitFor = (!fr.mixed && fr.stream != tl_poolStream) ? fr.stream : nullptr;
     return true;
@@ -71,9 +80,9 @@ void trimLocked(int onlyDevice) {      // give completely free slabs back to HIP
 // debugging aid: PLASSHIP_POOL_POISON=<0..255> fills every block handed out with that byte, so that a kernel reading
 // memory it did not write fails the same way on every run (recycled blocks otherwise hold the previous call's data)
 static int poisonByte() { static const int v = [] { const char *e = getenv("PLASSHIP_POOL_POISON"); return e ? atoi(e) : -1; }(); return v; }
-static hipError_t poolMallocRaw(void **p, size_t n);
-hipError_t poolMalloc(void **p, size_t n) {
-    const hipError_t e = poolMallocRaw(p, n);
+static hipError_t poolMallocRaw(void **p, size_t n, bool longLived);
+hipError_t poolMalloc(void **p, size_t n, bool longLived) {
+    const hipError_t e = poolMallocRaw(p, n, longLived);
     if (e == hipSuccess && poisonByte() >= 0) { (void) hipDeviceSynchronize(); (void) hipMemset(*p, poisonByte(), n); (void) hipDeviceSynchronize(); }
     return e;
 }
@@ -86,7 +95,7 @@ static void poolForgetStream(hipStream_t stream) {
     if (tl_poolStream == stream) tl_poolStream = nullptr;
 }
 static double poolFraction() { static const double v = [] { const char *e = getenv("PLASSHIP_POOL_FRACTION"); const double x = e ? atof(e) : 0.0; return (x > 0.05 && x <= 0.98) ? x : 0.88; }(); return v; }
-static hipError_t poolMallocRaw(void **p, size_t n) {
+static hipError_t poolMallocRaw(void **p, size_t n, bool longLived) {
     n = std::max<size_t>((n + POOL_ALIGN - 1) / POOL_ALIGN * POOL_ALIGN, POOL_ALIGN);
     int dev = 0; (void) hipGetDevice(&dev);
     const size_t MB2 = (size_t) 2 << 20;
@@ -96,7 +105,7 @@ static hipError_t poolMallocRaw(void **p, size_t n) {
         {
             std::lock_guard<std::mutex> g(g_poolMu);
             DevicePool &dp = g_pools[dev];
-            hit = takeRange(dp, dev, n, p, &waitFor, &waitAll);
+            hit = takeRange(dp, dev, n, p, &waitFor, &waitAll, longLived);
             if (hit) g_poolHits++;
             else {
                 // a new slab: modest while the process is small, most of the remaining HBM once it is not
@@ -380,8 +389,8 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
     }
     db->dataBytes = total; db->maxEntryLen = maxE; db->residues = total - 2 * (uint64_t) n; db->hostIndexValid = true;
     // pad the data buffer so 16-byte vector loads at the tail stay in bounds
-    if (db->d_data.alloc(total + 64) != hipSuccess || db->d_off.alloc((n + 1) * 8) != hipSuccess ||
-        db->d_len.alloc((n + 1) * 4) != hipSuccess || db->d_key.alloc((n + 1) * 4) != hipSuccess) {
+    if (db->d_data.allocLong(total + 64) != hipSuccess || db->d_off.allocLong((n + 1) * 8) != hipSuccess ||
+        db->d_len.allocLong((n + 1) * 4) != hipSuccess || db->d_key.allocLong((n + 1) * 4) != hipSuccess) {
         setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
     PH_CHECK(hipMemsetAsync((char *) db->d_data.p + total, 0, 64, ctx->stream));     // the padding only; the entries are copied below
@@ -410,7 +419,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
             std::iota(byOff.begin(), byOff.end(), 0u);
             std::stable_sort(byOff.begin(), byOff.end(), [&](uint32_t x, uint32_t y) { return off[perm[x]] < off[perm[y]]; });
             for (size_t r = 0; r < n; r++) rank[byOff[r]] = (uint32_t) r;
-            if (db->d_fileRank.alloc(n * 4) != hipSuccess) { setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            if (db->d_fileRank.allocLong(n * 4) != hipSuccess) { setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE; }
             const int rc = stagedCopyToDevice(ctx, db->d_fileRank.p, rank.data(), n * 4); if (rc) return rc;
         }
     }
@@ -548,7 +557,7 @@ int ensureOffLen(plasship_ctx *ctx, const plasship_seqdb *db) {
         return PLASSHIP_OK;
     }
     if (db->maxEntryLen >= (1u << 24) || db->dataBytes >= (1ull << 40)) { setError("a sequence DB with an entry of 2^24 bytes or more, or of 2^40 bytes or more in total, is not supported"); return PLASSHIP_ERR_UNSUPPORTED; }
-    if (db->d_offLen.alloc(db->n * 8) != hipSuccess) { setError("out of device memory for the packed offsets of a sequence DB"); return PLASSHIP_ERR_DEVICE; }
+    if (db->d_offLen.allocLong(db->n * 8) != hipSuccess) { setError("out of device memory for the packed offsets of a sequence DB"); return PLASSHIP_ERR_DEVICE; }
     hipLaunchKernelGGL(packOffLenKernel, dim3((unsigned) std::min<uint64_t>((db->n + 255) / 256, (uint64_t) ctx->numCU * 16)), dim3(256), 0, ctx->stream,
                        db->d_off.as<uint64_t>(), db->d_len.as<uint32_t>(), (uint64_t) db->n, db->d_offLen.as<uint64_t>());
     db->offLenStream = ctx->stream;

@@ -74,7 +74,7 @@ __global__ void boundsKernel(const uint32_t *__restrict__ len, uint32_t n, int k
 struct Cand { uint64_t kmer; uint32_t pos; uint32_t score; };   // score: low 16 bits hash, bit 31 = skipped
 // selected-window cache (section 2c): one 128-byte line per sequence = {u64 identity hash BEFORE its XXH64 (Util::hash of the letter
 // codes: seed-independent), u16 position of up to 59 selected windows (0xFFFF = none), u16 flags}
-constexpr uint32_t KMC_LINE = 128, KMC_POS = 59, KMC_FLAGS = 63, KMC_CLEAN = 1;     // flags word at u16 index 63; CLEAN: see extractIncrKernel
+constexpr uint32_t KMC_LINE = 128, KMC_POS = 59, KMC_FLAGS = 63, KMC_CLEAN = 1;     // flags word at u16 index 63; CLEAN: every candidate was selected (unordered path)
 
 #define FALLBACK_NOSTATS(a) ((a).kstats == nullptr)       // the scratch launch that re-extracts one sequence for the stale-record check: no statistics, no cache
 struct ExtractArgs {
@@ -710,7 +710,6 @@ struct ShortArgs {
     uint32_t idLo, idHi; uint64_t slotBias;   // ids [idLo, idHi) (sharded run: this rank's share), records at arr[slotOff[id] - slotBias]
     const unsigned char *changed; uint32_t *cachedList, *cachedCount;   // selected-window cache (section 2c): a sequence that is too long for this
                                               // kernel and whose bytes are those of the last call's DB goes to this list, not to the wave kernels'
-    const uint32_t *ext; uint32_t *incrList, *incrCount;                // ... and one that the last iteration EXTENDED (plasship_seqdb::d_ext) to this one
 };
 
 template <bool LONG>
@@ -799,8 +798,7 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
         // queue filled one sequence at a time — one atomic on one counter per sequence — costs more than the tier it feeds)
         // (too long for this kernel by its LENGTH and unchanged since the last call: the cached kernel takes it, section 2c)
         const bool isCached = lenWave && a.cachedList && a.changed[id] == 0;
-        const bool isIncr = lenWave && a.incrList && !isCached && a.ext[id] != 0xFFFFFFFFu;
-        if (isCached || isIncr) toWave = false;
+        if (isCached) toWave = false;
         const uint32_t nw = (toWave && active && a.s.len[id] >= (uint32_t) k) ? a.s.len[id] - (uint32_t) k + 1 : 0u;
         const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
         const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
@@ -816,7 +814,6 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
         if (a.longList) append(isLong, a.longList, a.longCount);
         if (a.hugeList) append(isHuge, a.hugeList, a.hugeCount);
         if (a.cachedList) append(isCached, a.cachedList, a.cachedCount);
-        if (a.incrList) append(isIncr, a.incrList, a.incrCount);
     }
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
@@ -947,8 +944,7 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
             }
         }
         const bool isCached = lenWave && a.cachedList && a.changed[id] == 0;      // (section 2c)
-        const bool isIncr = lenWave && a.incrList && !isCached && a.ext[id] != 0xFFFFFFFFu;
-        if (isCached || isIncr) toWave = false;
+        if (isCached) toWave = false;
         const uint32_t nw = (toWave && active && L >= (uint32_t) K) ? L - (uint32_t) K + 1 : 0u;
         const bool isHuge = toWave && a.hugeList && nw > a.hugeWindows;
         const bool isLong = toWave && !isHuge && a.longList && nw > a.longWindows;
@@ -964,7 +960,6 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
         if (a.longList) append(isLong, a.longList, a.longCount);
         if (a.hugeList) append(isHuge, a.hugeList, a.hugeCount);
         if (a.cachedList) append(isCached, a.cachedList, a.cachedCount);
-        if (a.incrList) append(isIncr, a.incrList, a.incrCount);
     }
     stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
@@ -1032,160 +1027,6 @@ __global__ __launch_bounds__(64) void extractCachedKernel(CachedArgs a) {
         stRes += cur.L; stRec += 1 + n;
     }
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
-}
-
-// ---- 2d. EXTENDED sequences in a same-seed iteration.  The assembler extends a sequence by whole fragments at its ends: the new
-// sequence is  [a new residues] + the old sequence + [b new residues]  (plasship_seqdb::d_ext holds a and the old length).  The
-// windows that lie inside the old part score what they scored last time (same seed), so the new selection — the `considered`
-// lowest scores — can only hold windows that were selected before or windows that touch new residues: a window that was not among
-// the old lowest 59 has at least 59 old windows below it and cannot be among the new lowest 59.  That argument needs the old line
-// to hold ALL old windows up to the old threshold score, which it does when it is CLEAN (written by the unordered path: no surplus
-// in the threshold bin, no repeated k-mer, so every candidate was selected).  This kernel therefore hashes  <= 59 + a + b  windows
-// instead of all L - 13, runs the same threshold bisection over them (the counts of scores below any value up to the new threshold
-// are the same as over all windows) and writes records and the new line — unless the old line is not clean, the new candidates
-// have a surplus or a repeat (the ordered path is needed: the reference's walk, kmermatcher.cpp:274-347), or a + b is too large:
-// then the sequence goes to the wave kernels' lists like any other.  One wavefront per sequence, up to 256 windows in registers.
-struct IncrArgs {
-    SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map; unsigned char *lines; const uint32_t *ext;
-    const uint32_t *list, *count; int k, xCode, kps, ignoreMulti; uint32_t base, base7; uint64_t slotBias, seed; unsigned long long *kstats;
-    uint32_t *waveList, *waveCount, *longList, *longCount, *hugeList, *hugeCount; uint32_t longWindows, hugeWindows;
-    unsigned long long *incrStats;      // [0] sequences done here, [1] handed to the wave kernels
-};
-__device__ __forceinline__ uint64_t pow31(uint32_t e) { uint64_t r = 1, b = 31; while (e) { if (e & 1u) r *= b; b *= b; e >>= 1; } return r; }
-__global__ __launch_bounds__(64) void extractIncrKernel(IncrArgs a) {
-    __shared__ unsigned char sMap[256];
-    __shared__ unsigned long long sK[64];
-    typedef Rec<false> R;
-    R *arr = reinterpret_cast<R *>(a.arr);
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
-    __syncthreads();
-    const uint32_t nWork = *a.count;
-    unsigned long long stRes = 0, stRec = 0, nDone = 0, nLeft = 0;
-    const uint32_t K = (uint32_t) a.k;
-    for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
-        const uint32_t id = a.list[w];
-        const uint32_t L = a.s.len[id], e = a.ext[id];
-        const uint32_t aL = e >> 16, oldLen = e & 0xFFFFu;
-        const char *base = a.s.data + a.s.off[id];
-        unsigned short *ln = reinterpret_cast<unsigned short *>(a.lines + (size_t) id * KMC_LINE);
-        const uint32_t posOld = ((uint32_t) lane < KMC_POS) ? (uint32_t) ln[4 + lane] : 0xFFFFu;
-        const unsigned long long rawOld = *reinterpret_cast<const unsigned long long *>(ln);
-        const uint32_t lineFlags = ln[KMC_FLAGS];
-        const uint32_t nOld = (uint32_t) __popcll(__ballot(posOld != 0xFFFFu));
-        const uint32_t bR = (aL + oldLen <= L) ? L - aL - oldLen : 0u;
-        const uint32_t U = nOld + aL + bR;
-        bool ok = (lineFlags & KMC_CLEAN) && aL + oldLen <= L && oldLen >= K && U <= 256u && (aL + bR) > 0u;
-        uint32_t sc[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}, pp[4] = {0, 0, 0, 0};
-        uint64_t km[4] = {0, 0, 0, 0};
-        uint32_t n = 0;
-        if (ok) {
-            const uint32_t rs = aL + oldLen - K + 1;            // first window that touches the new residues on the right
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t u = (uint32_t) r * 64u + (uint32_t) lane;
-                if ((uint32_t) r * 64u < U) {                   // wave-uniform
-                    if (u < U) {
-                        uint32_t p;
-                        if (u < nOld) p = posOld + aL;          // (row 0: lane u holds position u of the old line)
-                        else { const uint32_t t = u - nOld; p = (t < aL) ? t : rs + (t - aL); }
-                        uint64_t r0, r1; __builtin_memcpy(&r0, base + p, 8); __builtin_memcpy(&r1, base + p + 8, 8);
-                        uint64_t w0 = 0, w1 = 0;
-#pragma unroll
-                        for (int b = 0; b < 8; b++) { w0 |= (uint64_t) sMap[(r0 >> (8 * b)) & 0xFF] << (8 * b); w1 |= (uint64_t) sMap[(r1 >> (8 * b)) & 0xFF] << (8 * b); }
-                        uint64_t kmer;
-                        const bool valid = kmerIndexCore(w0, w1, a.k, (unsigned) a.xCode, a.base, a.base7, kmer);
-                        pp[r] = p; km[r] = kmer;
-                        if (valid) sc[r] = (uint32_t) (xxh64U64(kmer, a.seed) & 0xFFFFu);
-                    }
-                    n += (uint32_t) __popcll(__ballot(sc[r] != 0xFFFFFFFFu));
-                }
-            }
-        }
-        const uint32_t considered = min((uint32_t) (a.kps - 1), n);
-        uint32_t sStar = 0xFFFFu; int tooMuch = 0;
-        if (ok && considered == 0) ok = false;
-        if (ok && n > considered) {        // the considered-th smallest score (kmermatcher.cpp:224-239) by bisection over the score bits
-            uint32_t t = 0;
-#pragma unroll 1
-            for (int bit = 15; bit >= 0; bit--) {
-                const uint32_t tr = t | (1u << bit);
-                uint32_t below = 0;
-#pragma unroll
-                for (int r = 0; r < 4; r++) below += (uint32_t) __popcll(__ballot(sc[r] < tr));
-                if (below < considered) t = tr;
-            }
-            sStar = t;
-            uint32_t upTo = 0;
-#pragma unroll
-            for (int r = 0; r < 4; r++) upTo += (uint32_t) __popcll(__ballot(sc[r] <= t));
-            tooMuch = (int) upTo - (int) considered;
-            if (tooMuch != 0) ok = false;                       // surplus in the threshold bin: the ordered walk decides
-        }
-        // candidates (= the selection when nothing needs an order): rank them, check for repeated k-mers
-        uint32_t C = 0, myRank[4] = {0, 0, 0, 0}; bool mine[4] = {false, false, false, false};
-        if (ok) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                mine[r] = sc[r] != 0xFFFFFFFFu && sc[r] <= sStar;
-                const unsigned long long m = __ballot(mine[r]);
-                myRank[r] = C + (uint32_t) __popcll(m & ((1ULL << lane) - 1ULL));
-                C += (uint32_t) __popcll(m);
-            }
-            if (C > KMC_POS) ok = false;
-        }
-        if (ok && a.ignoreMulti && C > 1) {
-            __syncthreads();
-#pragma unroll
-            for (int r = 0; r < 4; r++) if (mine[r]) sK[myRank[r]] = km[r];
-            __syncthreads();
-            bool dup = false;
-            const unsigned long long my = ((uint32_t) lane < C) ? sK[lane] : 0ull;
-            for (uint32_t j = 0; j < C; j++) { const unsigned long long x = sK[j]; dup |= ((uint32_t) lane < C && j != (uint32_t) lane && x == my); }
-            if (__ballot(dup)) ok = false;
-        }
-        if (!ok) {          // to the wave kernels, by window count (as the thread-per-sequence kernel files them)
-            if (lane == 0) {
-                const uint32_t nw = (L >= K) ? L - K + 1 : 0u;
-                uint32_t *list = a.waveList, *cnt = a.waveCount;
-                if (a.hugeList && nw > a.hugeWindows) { list = a.hugeList; cnt = a.hugeCount; }
-                else if (a.longList && nw > a.longWindows) { list = a.longList; cnt = a.longCount; }
-                list[atomicAdd(cnt, 1u)] = id;
-            }
-            nLeft++;
-            continue;
-        }
-        // ---- records, the new line, the identity record ----
-        const uint64_t slot = a.slotOff[id] - a.slotBias;
-        const uint32_t bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            if (mine[r]) {
-                R rec; rec.kmer = km[r]; rec.id = id; rec.len = (uint16_t) L; rec.pos = (int16_t) pp[r];
-                arr[slot + 1 + myRank[r]] = rec;
-                ln[4 + myRank[r]] = (unsigned short) pp[r];
-            }
-        }
-        if ((uint32_t) lane >= C && (uint32_t) lane < KMC_POS) ln[4 + lane] = (unsigned short) 0xFFFFu;
-        // identity hash (Util::hash: sum code[p] * 31^(L-1-p) mod 2^64) from the old one: (hLeft * 31^oldLen + old) * 31^b + hRight
-        uint64_t part = 0;
-        for (uint32_t t = (uint32_t) lane; t < aL + bR; t += 64) {
-            const bool left = t < aL;
-            const uint32_t p = left ? t : aL + oldLen + (t - aL);
-            const uint32_t ex = left ? (aL - 1 - t) + oldLen + bR : (bR - 1 - (t - aL));
-            part += (uint64_t) sMap[(unsigned char) base[p]] * pow31(ex);
-        }
-        part = waveReduceSumU64(part);
-        const uint64_t raw = rawOld * pow31(bR) + part;
-        if (lane == 0) {
-            *reinterpret_cast<unsigned long long *>(ln) = raw; ln[KMC_FLAGS] = (unsigned short) KMC_CLEAN;
-            R rec; rec.kmer = xxh64U64(raw, a.seed); rec.id = id; rec.len = (uint16_t) L; rec.pos = 0; arr[slot] = rec;
-        }
-        for (uint32_t i = 1 + C + (uint32_t) lane; i < bound; i += 64) { R rec; memset(&rec, 0xFF, sizeof(R)); arr[slot + i] = rec; }
-        stRes += L; stRec += 1 + C; nDone++;
-    }
-    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
-    if (lane == 0 && a.incrStats) { if (nDone) atomicAdd(&a.incrStats[0], nDone); if (nLeft) atomicAdd(&a.incrStats[1], nLeft); }
 }
 
 // the sequences the last tier handed to the HBM-scratch launch: their slots become sentinels.  (Protein runs learn of such a hand-over
@@ -2823,19 +2664,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const bool cacheReuse = cacheEligible && kc.valid && kc.n == N && kc.gen == db->parentGen && db->d_changed.p && kc.k == k && kc.alph == par->alphabet_size &&
                             kc.kps == par->kmers_per_seq && kc.ignoreMulti == par->ignore_multi_kmer && kc.hashShift == par->hash_shift && !overflowCheckEarly;
     kc.valid = false;                                         // (set again when this call has succeeded)
-    DevBuf dCachedList, dCachedCount, dIncrList, dIncrCount;
-    const bool incrReuse = cacheReuse && db->d_ext.p && tuneInt("KMINCR", 1) == 1;        // extended sequences too (section 2d); PLASSHIP_TUNE_KMINCR=2: off
+    DevBuf dCachedList, dCachedCount;
     unsigned long long cacheLinesPtr = 0;                    // -> kstats[4] (see ExtractArgs)
     if (cacheEligible && N) {
-        if (kc.lines.bytes < (size_t) N * KMC_LINE) { kc.lines.release(); if (kc.lines.alloc((size_t) N * KMC_LINE) != hipSuccess) { setError("kmermatch: out of device memory for the selected-window cache"); return PLASSHIP_ERR_DEVICE; } }
+        if (kc.lines.bytes < (size_t) N * KMC_LINE) { kc.lines.release(); if (kc.lines.allocLong((size_t) N * KMC_LINE) != hipSuccess) { setError("kmermatch: out of device memory for the selected-window cache"); return PLASSHIP_ERR_DEVICE; } }
         cacheLinesPtr = (unsigned long long) (uintptr_t) kc.lines.p;
         if (cacheReuse) {
             if (dCachedList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCachedCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
             PH_CHECK(hipMemsetAsync(dCachedCount.p, 0, 4, st));
-            if (incrReuse) {
-                if (dIncrList.alloc(((size_t) N + 1) * 4) != hipSuccess || dIncrCount.alloc(32) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-                PH_CHECK(hipMemsetAsync(dIncrCount.p, 0, 32, st));       // [0] list length, words 2..5: incrStats
-            }
         }
     } else kc.lines.release();
     PH_CHECK(hipMemcpyAsync(dKStats.as<unsigned long long>() + 4, &cacheLinesPtr, 8, hipMemcpyHostToDevice, st));
@@ -2856,7 +2692,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
         sa.idLo = sLo; sa.idHi = sHi; sa.slotBias = slotBias;
         if (cacheReuse) { sa.changed = db->d_changed.as<unsigned char>(); sa.cachedList = dCachedList.as<uint32_t>(); sa.cachedCount = dCachedCount.as<uint32_t>(); }
-        if (incrReuse) { sa.ext = db->d_ext.as<uint32_t>(); sa.incrList = dIncrList.as<uint32_t>(); sa.incrCount = dIncrCount.as<uint32_t>(); }
         // the fast restatement needs k = 14 and the half-indices (7 digits of the base, each at most the X code = base) in 32 bits
         constexpr int KF = 14, HF = KF / 2;
         bool fast = k == KF && tuneInt("SHORT_FAST", 1) == 1;      // PLASSHIP_TUNE_SHORT_FAST=2: the kernel above
@@ -2874,16 +2709,6 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             ca.list = dCachedList.as<uint32_t>(); ca.count = dCachedCount.as<uint32_t>(); ca.k = k; ca.xCode = ea.xCode;
             ca.base = (uint32_t) ea.powers[1]; ca.base7 = (uint32_t) ea.powers[7]; ca.slotBias = slotBias; ca.seed = ea.seed; ca.kstats = dKStats.as<unsigned long long>();
             hipLaunchKernelGGL(extractCachedKernel, dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("CACHED", 32))), dim3(64), 0, st, ca);
-        }
-        if (incrReuse) {      // before the wave kernels: what it cannot do goes to their lists
-            IncrArgs ia; memset(&ia, 0, sizeof(ia));
-            ia.s = ea.s; ia.slotOff = ea.slotOff; ia.arr = ea.arr; ia.map = ea.map; ia.lines = kc.lines.as<unsigned char>(); ia.ext = db->d_ext.as<uint32_t>();
-            ia.list = dIncrList.as<uint32_t>(); ia.count = dIncrCount.as<uint32_t>(); ia.k = k; ia.xCode = ea.xCode; ia.kps = ea.kps; ia.ignoreMulti = ea.ignoreMulti;
-            ia.base = (uint32_t) ea.powers[1]; ia.base7 = (uint32_t) ea.powers[7]; ia.slotBias = slotBias; ia.seed = ea.seed; ia.kstats = dKStats.as<unsigned long long>();
-            ia.waveList = sa.waveList; ia.waveCount = sa.waveCount; ia.longList = sa.longList; ia.longCount = sa.longCount; ia.hugeList = sa.hugeList; ia.hugeCount = sa.hugeCount;
-            ia.longWindows = sa.longWindows; ia.hugeWindows = sa.hugeWindows;
-            ia.incrStats = reinterpret_cast<unsigned long long *>(dIncrCount.as<uint32_t>() + 2);
-            hipLaunchKernelGGL(extractIncrKernel, dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("INCR", 32))), dim3(64), 0, st, ia);
         }
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
@@ -2978,10 +2803,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             stats->ms_part_scatter = lo.msPart; stats->n_part_scatter = lo.nPart;
             unsigned long long ks[4] = {0, 0, 0, 0}; uint32_t nCachedSeqs = 0;
             if (cacheReuse) PH_CHECK(hipMemcpyAsync(&nCachedSeqs, dCachedCount.p, 4, hipMemcpyDeviceToHost, st));
-            unsigned long long incrSt[2] = {0, 0};
-            if (incrReuse) PH_CHECK(hipMemcpyAsync(incrSt, dIncrCount.as<uint32_t>() + 2, 16, hipMemcpyDeviceToHost, st));
             PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost);
-            stats->n_cached_sequences = nCachedSeqs; stats->n_incremental_sequences = (uint32_t) incrSt[0];
+            stats->n_cached_sequences = nCachedSeqs; stats->reserved0 = 0;
             stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
             stats->residues = db->residues;
             stats->ms_extract = msExtract; stats->ms_sort1 = lo.msSort1; stats->ms_group = lo.msGroup; stats->ms_sort2 = lo.msSort2; stats->ms_reduce = msReduceL;

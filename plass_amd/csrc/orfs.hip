@@ -399,8 +399,8 @@ extern "C" int plasship_extract_orfs(plasship_ctx *ctx, const plasship_seqdb *re
     if (M >= 0xFFFFFFFFull) { setError("plasship_extract_orfs: too many ORFs"); return PLASSHIP_ERR_UNSUPPORTED; }
     std::unique_ptr<plasship_seqdb> o(new plasship_seqdb());
     std::unique_ptr<plasship_orfhdr> h(new plasship_orfhdr());
-    if (o->d_data.alloc(dataBytes + 64) != hipSuccess || o->d_off.alloc((M + 1) * 8) != hipSuccess || o->d_len.alloc((M + 1) * 4) != hipSuccess ||
-        o->d_key.alloc((M + 1) * 4) != hipSuccess || h->d_info.alloc((M + 1) * sizeof(OrfInfo)) != hipSuccess) { setError("plasship_extract_orfs: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (o->d_data.allocLong(dataBytes + 64) != hipSuccess || o->d_off.allocLong((M + 1) * 8) != hipSuccess || o->d_len.allocLong((M + 1) * 4) != hipSuccess ||
+        o->d_key.allocLong((M + 1) * 4) != hipSuccess || h->d_info.alloc((M + 1) * sizeof(OrfInfo)) != hipSuccess) { setError("plasship_extract_orfs: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + dataBytes, 0, 64, st));
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + M, &dataBytes, 8, hipMemcpyHostToDevice, st));
     a.orfBase = dOrfBase.as<uint64_t>(); a.byteBase = dByteBase.as<uint64_t>();
@@ -463,8 +463,8 @@ extern "C" int plasship_translate_nucs(plasship_ctx *ctx, const plasship_seqdb *
     PH_CHECK(hipGetLastError());
     const uint64_t M = tot[0], dataBytes = tot[1];
     std::unique_ptr<plasship_seqdb> o(new plasship_seqdb());
-    if (o->d_data.alloc(dataBytes + 64) != hipSuccess || o->d_off.alloc((M + 1) * 8) != hipSuccess || o->d_len.alloc((M + 1) * 4) != hipSuccess ||
-        o->d_key.alloc((M + 1) * 4) != hipSuccess) { setError("plasship_translate_nucs: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (o->d_data.allocLong(dataBytes + 64) != hipSuccess || o->d_off.allocLong((M + 1) * 8) != hipSuccess || o->d_len.allocLong((M + 1) * 4) != hipSuccess ||
+        o->d_key.allocLong((M + 1) * 4) != hipSuccess) { setError("plasship_translate_nucs: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + dataBytes, 0, 64, st));
     PH_CHECK(hipMemcpyAsync(o->d_off.as<uint64_t>() + M, &dataBytes, 8, hipMemcpyHostToDevice, st));
     a.byteBase = dByteBase.as<uint64_t>(); a.idxBase = dIdxBase.as<uint64_t>();
@@ -505,8 +505,8 @@ extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a,
     if (!b->contiguous) { const int rcP = packedCopyOf(ctx, b, packedB); if (rcP) return rcP; b = packedB.get(); }
     const uint64_t dataBytes = a->dataBytes + b->dataBytes;
     std::unique_ptr<plasship_seqdb> o(new plasship_seqdb());
-    if (o->d_data.alloc(dataBytes + 64) != hipSuccess || o->d_off.alloc((nn + 1) * 8) != hipSuccess || o->d_len.alloc((nn + 1) * 4) != hipSuccess ||
-        o->d_key.alloc((nn + 1) * 4) != hipSuccess) { setError("plasship_seqdb_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (o->d_data.allocLong(dataBytes + 64) != hipSuccess || o->d_off.allocLong((nn + 1) * 8) != hipSuccess || o->d_len.allocLong((nn + 1) * 4) != hipSuccess ||
+        o->d_key.allocLong((nn + 1) * 4) != hipSuccess) { setError("plasship_seqdb_concat: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     if (a->dataBytes) PH_CHECK(hipMemcpyAsync(o->d_data.p, a->dataPtr(), a->dataBytes, hipMemcpyDeviceToDevice, st));
     if (b->dataBytes && !b->d_fileRank.p) PH_CHECK(hipMemcpyAsync((char *) o->d_data.p + a->dataBytes, b->dataPtr(), b->dataBytes, hipMemcpyDeviceToDevice, st));
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + dataBytes, 0, 64, st));
@@ -624,7 +624,7 @@ extern "C" int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plas
             for (size_t i = 0; i < n; i++) byOff[i] = (uint32_t) i;
             std::stable_sort(byOff.begin(), byOff.end(), [&](uint32_t x, uint32_t y) { return h.off[perm[x]] < h.off[perm[y]]; });
             for (size_t r = 0; r < n; r++) rank[byOff[r]] = (uint32_t) r;
-            if (o->d_fileRank.alloc(n * 4) != hipSuccess) { setError("plasship_orfhdr_read: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            if (o->d_fileRank.allocLong(n * 4) != hipSuccess) { setError("plasship_orfhdr_read: out of device memory"); return PLASSHIP_ERR_DEVICE; }
             const int rc = stagedCopyToDevice(ctx, o->d_fileRank.p, rank.data(), n * 4); if (rc) return rc;
         }
     }

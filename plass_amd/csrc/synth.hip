@@ -50,8 +50,8 @@ extern "C" int plasship_synth_read_pairs(plasship_ctx *ctx, const plasship_synth
     const uint64_t nReads = 2 * par->n_pairs; const uint32_t entry = par->read_len + 2;
     std::unique_ptr<plasship_seqdb> o(new plasship_seqdb());
     const uint64_t dataBytes = nReads * entry;
-    if (o->d_data.alloc(dataBytes + 64) != hipSuccess || o->d_off.alloc((nReads + 1) * 8) != hipSuccess || o->d_len.alloc((nReads + 1) * 4) != hipSuccess ||
-        o->d_key.alloc((nReads + 1) * 4) != hipSuccess) { setError("plasship_synth_read_pairs: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    if (o->d_data.allocLong(dataBytes + 64) != hipSuccess || o->d_off.allocLong((nReads + 1) * 8) != hipSuccess || o->d_len.allocLong((nReads + 1) * 4) != hipSuccess ||
+        o->d_key.allocLong((nReads + 1) * 4) != hipSuccess) { setError("plasship_synth_read_pairs: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemsetAsync((char *) o->d_data.p + dataBytes, 0, 64, st));
     PH_CHECK(hipMemsetAsync(o->d_off.p, 0, 8, st));
     SynthReads sr; memset(&sr, 0, sizeof(sr));
