@@ -239,6 +239,10 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     for (auto &ev : ctx->ev) if (ev) (void) hipEventDestroy(ev);
     for (int i = 0; i < 2; i++) { if (ctx->stage[i]) (void) hipHostFree(ctx->stage[i]); if (ctx->stageEv[i]) (void) hipEventDestroy(ctx->stageEv[i]); }
     if (ctx->pinnedTable) (void) hipHostFree(ctx->pinnedTable);
+    // the context's own device buffers (comparator tables, the 11 GB of selected-window cache lines) go back to the arena BEFORE it is
+    // trimmed: a slab is returned to the driver only when nothing in it is live (round 4: the cache lines kept the 250 GB slab of a
+    // closed context alive, and the next process on the GPU — bench.py's fused-driver child, a test's subprocess — ran out of memory)
+    ctx->kmCache.lines.release(); ctx->d_cmpCache.release(); ctx->d_ambKeys.release(); ctx->d_ambVals.release();
     if (ctx->stream) { poolForgetStream(ctx->stream); (void) hipStreamDestroy(ctx->stream); }
     bool last; { std::lock_guard<std::mutex> g(g_poolMu); last = (--g_ctxCount <= 0); }
     if (last) {

@@ -21,7 +21,7 @@ int hostThreads() {
         if (const char *e = getenv("PLASSHIP_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return std::min(v, 256); }
         cpu_set_t cs; CPU_ZERO(&cs);
         int c = (sched_getaffinity(0, sizeof(cs), &cs) == 0) ? CPU_COUNT(&cs) : (int) std::thread::hardware_concurrency();
-        return std::max(1, std::min(c, 16));
+        return std::max(1, std::min(c, 32));
     }();
     return n;
 }
