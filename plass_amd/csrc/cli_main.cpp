@@ -458,7 +458,7 @@ int main(int argc, char **argv) {
                 if (cs.n_cyclic && plasship_seqdb_write(ctx, cyc, (pos[1] + "_cycle_" + std::to_string(it)).c_str())) return fail(mod.c_str());
                 plasship_seqdb_free(ctx, cyc); plasship_seqdb_free(ctx, db); db = rest;
             }
-            fprintf(stdout, "iteration %d: candidates %llu verified %llu extended %llu\n", it, (unsigned long long) ks.n_candidates, (unsigned long long) rs.n_accepted, (unsigned long long) as.n_extended);
+            fprintf(stdout, "iteration %d: candidates %llu verified %llu extended %llu (%.3f s since the DB was read)\n", it, (unsigned long long) ks.n_candidates, (unsigned long long) rs.n_accepted, (unsigned long long) as.n_extended, now() - tPrep);
             if (it + 1 < f.numIterations) writeAsync(db, (gd ? "assembly_nucl_" : "assembly_") + std::to_string(it));
         }
         const double tLoop = now();
