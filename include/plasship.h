@@ -49,6 +49,11 @@ const char *plasship_version(void);
 int plasship_ctx_create(int device_ordinal, plasship_ctx **out);
 void plasship_ctx_destroy(plasship_ctx *ctx);
 int plasship_ctx_sync(plasship_ctx *ctx);
+/* A caller that knows a large job is coming (the fused chain drivers: a multi-GB input DB) lets the library take its device arena —
+ * one hipMalloc of most of the free HBM, 3-4 s on an MI355X whose memory another process has just used — in a background thread
+ * while the caller reads and parses its input on the host.  Allocations wait for it; without the call the first large allocation
+ * takes the arena itself.  No reference counterpart (the reference has no device). */
+int plasship_ctx_reserve_async(plasship_ctx *ctx);
 /* raw hipStream_t of the context, so a caller can bracket work with its own events */
 void *plasship_ctx_stream(plasship_ctx *ctx);
 /* diagnostic: how often the host has waited for a stream since the library was loaded (all contexts of the process).  A module

@@ -111,6 +111,7 @@ SYMBOLS = [
     ("plasship_ctx_create", C.c_int, [C.c_int, C.POINTER(P)]),
     ("plasship_ctx_destroy", None, [P]),
     ("plasship_ctx_sync", C.c_int, [P]),
+    ("plasship_ctx_reserve_async", C.c_int, [P]),
     ("plasship_ctx_stream", P, [P]),
     ("plasship_host_syncs", C.c_ulonglong, []),
     ("plasship_ctx_debug_fail_collective", C.c_int, [P, C.c_int]),

@@ -19,6 +19,7 @@
 #include <set>
 #include <string>
 #include <thread>
+#include <sys/stat.h>
 #include <vector>
 
 static bool multiParam(const std::string &v, const char *which, std::string &out) {
@@ -387,6 +388,8 @@ int main(int argc, char **argv) {
                 FILE *fd = fopen((path + ".done").c_str(), "w"); if (fd) fclose(fd); else writerRc = 1;     // data/assemble.sh:147 `touch assembly_$STEP.done`
             });
         };
+        // a multi-GB input: the library takes its device arena (seconds of hipMalloc) while this thread reads and parses the DB files
+        { struct stat stIn; if (stat(pos[0].c_str(), &stIn) == 0 && stIn.st_size >= ((off_t) 1 << 30)) (void) plasship_ctx_reserve_async(ctx); }
         plasship_seqdb *in = nullptr;
         if (plasship_seqdb_read(ctx, pos[0].c_str(), &in)) return fail(mod.c_str());
         const double tRead = now();

@@ -5,6 +5,8 @@
 #include "host_util.hpp"
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <thread>
 #include <memory>
 #include <chrono>
 #include <cstdio>
@@ -38,6 +40,9 @@ struct PoolLive { int device; int slab; size_t off, size; hipStream_t stream; };
 std::unordered_map<void *, PoolLive> g_poolLive;
 thread_local hipStream_t tl_poolStream = nullptr;    // stream of the API call this thread is in (poolEnter)
 int g_ctxCount = 0;
+// plasship_ctx_reserve_async: the arena's big slab is being allocated by a background thread; an allocation that finds no range waits
+std::mutex g_reserveMu; std::condition_variable g_reserveCv; int g_reserving = 0;
+thread_local bool tl_isReserver = false;
 size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
 
 // best fit over all free ranges of the device (a few hundred at most)
@@ -121,6 +126,10 @@ static hipError_t poolMallocRaw(void **p, size_t n, bool longLived) {
             if (waitAll) (void) hipDeviceSynchronize();
             else if (waitFor) (void) plasship::streamSync(waitFor);          // the previous user's queued work must be through
             return hipSuccess;
+        }
+        if (!tl_isReserver) {                                    // the arena is on its way (plasship_ctx_reserve_async): wait for it, look again
+            std::unique_lock<std::mutex> lk(g_reserveMu);
+            if (g_reserving) { g_reserveCv.wait(lk, [] { return g_reserving == 0; }); continue; }
         }
         const auto t0 = std::chrono::steady_clock::now();
         void *base = nullptr;
@@ -230,6 +239,25 @@ extern "C" int plasship_ctx_create(int device_ordinal, plasship_ctx **out) {
     return PLASSHIP_OK;
 }
 
+extern "C" int plasship_ctx_reserve_async(plasship_ctx *ctx) {
+    if (!ctx) { setError("plasship_ctx_reserve_async: ctx is NULL"); return PLASSHIP_ERR_ARG; }
+    {
+        std::lock_guard<std::mutex> g(g_poolMu);
+        for (const auto &sl : g_pools[ctx->device].slabs) if (sl.base && sl.size >= ((size_t) 16 << 30)) return PLASSHIP_OK;      // there is one already
+    }
+    { std::lock_guard<std::mutex> lk(g_reserveMu); if (g_reserving) return PLASSHIP_OK; g_reserving = 1; }
+    const int dev = ctx->device;
+    std::thread([dev] {
+        (void) hipSetDevice(dev);
+        tl_isReserver = true;
+        void *p = nullptr;
+        if (poolMalloc(&p, (size_t) 4 << 30) == hipSuccess) poolFree(p);      // >= 4 GB: "a large job" -> one slab of most of the free HBM
+        { std::lock_guard<std::mutex> lk(g_reserveMu); g_reserving = 0; }
+        g_reserveCv.notify_all();
+    }).detach();
+    return PLASSHIP_OK;
+}
+
 uint64_t plasship::newDbGeneration() { static std::atomic<uint64_t> g(0); return ++g; }
 
 extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
@@ -242,6 +270,7 @@ extern "C" void plasship_ctx_destroy(plasship_ctx *ctx) {
     // the context's own device buffers (comparator tables, the 11 GB of selected-window cache lines) go back to the arena BEFORE it is
     // trimmed: a slab is returned to the driver only when nothing in it is live (round 4: the cache lines kept the 250 GB slab of a
     // closed context alive, and the next process on the GPU — bench.py's fused-driver child, a test's subprocess — ran out of memory)
+    { std::unique_lock<std::mutex> lk(g_reserveMu); g_reserveCv.wait(lk, [] { return g_reserving == 0; }); }      // (a reservation in flight must land first)
     ctx->kmCache.lines.release(); ctx->d_cmpCache.release(); ctx->d_ambKeys.release(); ctx->d_ambVals.release();
     if (ctx->stream) { poolForgetStream(ctx->stream); (void) hipStreamDestroy(ctx->stream); }
     bool last; { std::lock_guard<std::mutex> g(g_poolMu); last = (--g_ctxCount <= 0); }

@@ -140,7 +140,7 @@ DBFileWriter::~DBFileWriter() {
     for (const char *sfx : {"", ".index", ".dbtype"}) (void) remove((path + sfx + tmpSuffix).c_str());
 }
 bool DBFileWriter::open(const std::string &p, int type, std::string &err) {
-    path = p; dbtype = type; off = 0; failed = false;
+    path = p; dbtype = type; off = 0; dataPos = 0; failed = false;
     tmpSuffix = ".tmp." + std::to_string((long) getpid());
     fd = fopen((p + tmpSuffix).c_str(), "wb"); fi = fopen((p + ".index" + tmpSuffix).c_str(), "wb");
     open_ = true;
@@ -150,7 +150,25 @@ bool DBFileWriter::open(const std::string &p, int type, std::string &err) {
     return true;
 }
 void DBFileWriter::data(const char *bytes, size_t n) {
-    if (n && fwrite(bytes, 1, n, fd) != n) failed = true;
+    if (!n) return;
+    // a chunk of the data file (32 MB from the staging buffers): slices written with pwrite() on all host threads — one fwrite() copies
+    // into the page cache at ~4 GB/s, and the 12.7 GB final DB of a 50 M-read assembly spent 3 s there (round 4)
+    if (n < ((size_t) 4 << 20)) { if (fwrite(bytes, 1, n, fd) != n) failed = true; dataPos += n; return; }
+    if (fflush(fd) != 0) { failed = true; return; }
+    const int fdn = fileno(fd);
+    const uint64_t base = dataPos;
+    std::atomic<bool> ok(true);
+    const size_t SL = (size_t) 2 << 20;
+    const size_t nSl = (n + SL - 1) / SL;
+    parallelRanges(nSl, [&](int, size_t b, size_t e) {
+        for (size_t sl = b; sl < e && ok; sl++) {
+            size_t o = sl * SL; const size_t end = std::min(n, o + SL);
+            while (o < end) { const ssize_t w = pwrite(fdn, bytes + o, end - o, (off_t) (base + o)); if (w <= 0) { ok = false; break; } o += (size_t) w; }
+        }
+    }, nullptr, 2);
+    if (!ok) { failed = true; return; }
+    dataPos += n;
+    if (fseeko(fd, (off_t) dataPos, SEEK_SET) != 0) failed = true;
 }
 void DBFileWriter::index(const uint32_t *keys, const uint32_t *elen, size_t n) {
     if (!n) return;
@@ -180,6 +198,7 @@ void DBFileWriter::index(const uint32_t *keys, const uint32_t *elen, size_t n) {
 void DBFileWriter::add(uint32_t key, const char *bytes, size_t n) {
     if (n && fwrite(bytes, 1, n, fd) != n) failed = true;
     if (fputc('\0', fd) == EOF) failed = true;
+    dataPos += n + 1;
     char tmp[64]; char *q = fmtU32(key, tmp); *q++ = '\t'; q = fmtU64(off, q); *q++ = '\t'; q = fmtU64(n + 1, q); *q++ = '\n';
     ibuf.append(tmp, (size_t) (q - tmp));
     if (ibuf.size() > (1 << 22) - 128) { if (fwrite(ibuf.data(), 1, ibuf.size(), fi) != ibuf.size()) failed = true; ibuf.clear(); }

@@ -48,7 +48,7 @@ bool readDBFiles(const std::string &path, HostDB &db, std::string &err);
 //               all host threads
 //   small DBs:  add(key, bytes) per entry
 struct DBFileWriter {
-    FILE *fd = nullptr, *fi = nullptr; std::string path, tmpSuffix; uint64_t off = 0; int dbtype = 0; bool failed = false, open_ = false;
+    FILE *fd = nullptr, *fi = nullptr; std::string path, tmpSuffix; uint64_t off = 0, dataPos = 0; int dbtype = 0; bool failed = false, open_ = false;
     std::string ibuf;
     DBFileWriter() {}
     DBFileWriter(const DBFileWriter &) = delete; DBFileWriter &operator=(const DBFileWriter &) = delete;

@@ -44,7 +44,6 @@ struct RescoreArgs {
     unsigned long long *stats;   // [0] accepted, [1] overlap residues
     unsigned long long *longList, *longCount;   // hit indices queued for the 16-lane kernel
     uint32_t shortMax;           // min(qLen, tLen) up to which the thread-per-pair kernel scores a pair itself
-    int selfToLong;              // self hits go to the 16-lane kernel whatever their length
 };
 
 __device__ __forceinline__ bool canBeCoveredDev(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -259,9 +258,9 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
         const char *t = a.t.data + me.tOff;
         const unsigned tLen = me.tLen;
         if (G == 1) {                                         // long overlap: 16 lanes will score it (one atomic per wavefront, not per pair)
-            // ... and so will they every SELF hit (a third of the list: every query's first line): it runs over the whole sequence, so
-            // in a thread-per-pair wavefront it is the lane all others wait for — a 400-residue contig beside 40-column read overlaps
-            const bool toLong = min(qLen, tLen) > a.shortMax || (a.selfToLong && qid == tid);
+            // (round 4: sending every SELF hit — a third of the list, and the lane the others wait for — to the 16-lane kernel as well
+            //  doubled the stage, 45 -> 89 ms: its per-pair epilogue on 16 lanes costs more than the waiting; profiles/r04_ab_knobs.txt)
+            const bool toLong = min(qLen, tLen) > a.shortMax;
             const unsigned long long m = __ballot(toLong);
             if (m) {
                 const int leader = __ffsll((long long) m) - 1;
@@ -416,7 +415,6 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 8, ctx->stream));
     a.longList = dLongList.as<unsigned long long>(); a.longCount = dLongCount.as<unsigned long long>();
     a.shortMax = (uint32_t) tuneInt("RESCORE_SHORT", (int) RS_SHORT_MAX);
-    a.selfToLong = (qdb == tdb && tuneInt("RESCORE_SELF", 1) == 1) ? 1 : 0;      // PLASSHIP_TUNE_RESCORE_SELF=2: self hits stay with the thread-per-pair kernel
     const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * (uint64_t) tuneInt("RESCORE", nHits > 50000000ull ? 32 : 12));   // large lists: smaller shares per workgroup even out the tail (37.8 -> 35.9 ms at 250 M pairs)
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
     static const int wpe = tuneInt("RESCORE_WPE", 5);       // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight)

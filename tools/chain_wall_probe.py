@@ -10,7 +10,7 @@ ctx = plass_amd.Context(0)
 db, wl = bench.build_workload(ctx, "c3", pairs)
 td = tempfile.mkdtemp(prefix="plass_wall_probe_")
 db.write(os.path.join(td, "frag")); db.free(); ctx.close()
-for extra in ({}, {"PLASSHIP_TUNE_DBHEAP": "2"}, {"PLASSHIP_TUNE_KMCACHE": "2"}):
+for extra in ({}, {}):
     env = dict(g.child_env()); env["PLASSHIP_POOL_STATS"] = "1"; env.update(extra)
     t0 = time.perf_counter()
     p = subprocess.run([os.path.join(ROOT, "plass_amd", "plass-hip"), "assemble-chain", os.path.join(td, "frag"), os.path.join(td, "out"), "--num-iterations", "12"],
