@@ -260,6 +260,8 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
         if (G == 1) {                                         // long overlap: 16 lanes will score it (one atomic per wavefront, not per pair)
             // (round 4: sending every SELF hit — a third of the list, and the lane the others wait for — to the 16-lane kernel as well
             //  doubled the stage, 45 -> 89 ms: its per-pair epilogue on 16 lanes costs more than the waiting; profiles/r04_ab_knobs.txt)
+            // (nor do the self hits hold the other lanes up measurably: the self hits in a launch of their own and the rest in a second
+            //  one — every lane of a wavefront on pairs of one kind — took 47.3 ms against 44.9 ms for the one launch; same file)
             const bool toLong = min(qLen, tLen) > a.shortMax;
             const unsigned long long m = __ballot(toLong);
             if (m) {
