@@ -407,19 +407,38 @@ __device__ __forceinline__ uint32_t ambHash(uint32_t a1, uint32_t b1, uint32_t a
 // posterior class of one (alpha, beta) tuple the memo does not hold yet: 0 (p < 0.45), 1 (p > 0.55), 2 (between), or -1 when the
 // decision sits on a threshold and the host table lacks the tuple (the query is then re-run).  Kept out of line: it is rare
 // (the memo absorbs it) and its double-precision lgamma / exp / log would otherwise dictate the register budget of the callers.
+// lgamma of a positive integer: log((n - 1)!) from the exact product below 16, Stirling's series above (truncation < 2e-14)
+__device__ __forceinline__ double lgammaInt(unsigned n) {
+    if (n < 16) { double f = 1.0; for (unsigned i = 2; i < n; i++) f *= (double) i; return log(f); }
+    const double x = (double) n, r = 1.0 / x, r2 = r * r;
+    return (x - 0.5) * log(x) - x + 0.91893853320467274178 +
+           r * (1.0 / 12.0 - r2 * (1.0 / 360.0 - r2 * (1.0 / 1260.0 - r2 * (1.0 / 1680.0 - r2 * (1.0 / 1188.0)))));
+}
+// Round 4: the reference evaluates p = sum_{i < alpha2} exp(log_r_i + log_c) with four lgamma and, per term, one exp and five log in
+// double (nuclassembleresult.cpp:36-58).  Only the CLASS of p is used, and a p within AMB_EPS of a threshold is decided by the host's
+// libm anyway (below), so the device may take any route that is accurate to well below AMB_EPS: the terms are t_0 = exp(log_c),
+// t_{i+1} = t_i (alpha1 + i)(beta2 + i) / ((i + 1)(i + alpha1 + beta1 + beta2)) — one division per term instead of six
+// transcendentals (rescaled when they grow: the sequence rises, then falls) — and the arguments of lgamma are integers.  The contigs
+// of the late nucleotide iterations of configs[4] overlap in thousands of columns with dozens of mismatches: such tuples miss the
+// memo (CMP_LEN, CMP_MM), and the heap of a query with 200 hits asks for thousands of them — 707 -> see profiles/r04_ab_knobs.txt.
 __device__ __attribute__((noinline)) int nuclPosteriorClassDev(unsigned alpha1, unsigned beta1, unsigned alpha2, unsigned beta2, const AsmArgs *ap) {
-    const double log_c = (lgamma((double) (beta1 + beta2)) + lgamma((double) (alpha1 + beta1))) -
-                         (lgamma((double) (alpha1 + beta1 + beta2)) + lgamma((double) beta1));
-    double log_r = 0.0, p = 0.0;
-    for (size_t idx = 0; idx < alpha2; idx++) {
-        p += exp(log_r + log_c);
-        log_r = log((double) (alpha1 + idx)) + log((double) (beta2 + idx)) - (log((double) (idx + 1)) + log((double) (idx + alpha1 + beta1 + beta2))) + log_r;
+    const double log_c = (lgammaInt(beta1 + beta2) + lgammaInt(alpha1 + beta1)) - (lgammaInt(alpha1 + beta1 + beta2) + lgammaInt(beta1));
+    double t = 1.0, sum = 0.0, logScale = 0.0;
+    const double S = (double) alpha1 + (double) beta1 + (double) beta2;
+    for (unsigned idx = 0; idx < alpha2; idx++) {
+        sum += t;
+        const double i = (double) idx;
+        t *= (((double) alpha1 + i) * ((double) beta2 + i)) / ((i + 1.0) * (i + S));
+        if (t > 1e200) { t *= 1e-200; sum *= 1e-200; logScale += 460.51701859880913680; }      // 200 ln 10
     }
+    const double p = sum > 0.0 ? exp(log_c + logScale + log(sum)) : 0.0;
     int cls = (p < 0.45) ? 0 : ((p > 0.55) ? 1 : 2);
     // The reference's decision is glibc's rounding of p whenever p sits on a threshold (zero mismatches on both sides and
     // overlap lengths 9 : 11 give exactly 0.45).  Device and host libm agree to ~1e-15; inside a 1e-9 band the class is
     // taken from the host-evaluated table instead.
-    const double AMB_EPS = 1e-9;
+    // (log_c is a difference of numbers of the size of the overlap lengths times their logarithm: its rounding error, here and in
+    // the host's lgamma, grows with them — the band does too)
+    const double AMB_EPS = 1e-9 + 1e-13 * (S + (double) alpha2);
     if (fabs(p - 0.45) < AMB_EPS || fabs(p - 0.55) < AMB_EPS) {
         const AsmArgs &a = *ap;
         if (a.ambMask) {
@@ -593,7 +612,10 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
         }
         char *buf = a.arena + aoff;
         uint64_t curStart = a.leftCap[id];
-        for (uint32_t i = lane; i < querySeqLen; i += 64) buf[curStart + i] = orig[i];
+        // the query is copied into its arena slice when the first fragment is attached: most queries that pass the pre-screen still end
+        // without an extension (their extendable hit is not the one the comparator pops first, or it names a consumed side)
+        const unsigned origLen = querySeqLen;
+        bool copied = false;
         uint64_t curLen = querySeqLen;
         __syncthreads();
         bool couldExtend = false;
@@ -627,6 +649,7 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
                     if (rightOff > 0) { if (lane == 0) def[nDef] = bi; nDef++; continue; }
                     const unsigned fragLen = tLen - (dbEnd + 1);
                     if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    if (!copied) { copyBytesG<64>(buf + curStart, orig, origLen, lane); copied = true; }
                     for (unsigned i = lane; i < fragLen; i += 64)
                         buf[curStart + curLen + i] = rev ? nuclRevN(tSeq[fragLen - 1 - i]) : tSeq[dbEnd + 1 + i];
                     curLen += fragLen; rightOff += fragLen;
@@ -641,6 +664,7 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
                     if (leftOff > 0) { if (lane == 0) def[nDef] = bi; nDef++; continue; }
                     const unsigned fragLen = dbStart;
                     if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                    if (!copied) { copyBytesG<64>(buf + curStart, orig, origLen, lane); copied = true; }
                     curStart -= fragLen;
                     for (unsigned i = lane; i < fragLen; i += 64)
                         buf[curStart + i] = rev ? nuclRevN(tSeq[(tLen - dbStart) + (fragLen - 1 - i)]) : tSeq[i];
@@ -718,30 +742,95 @@ __device__ __forceinline__ void copyBytesSerial(char *dst, const char *src, unsi
     for (; i + 8 <= n; i += 8) storeU64Unaligned(dst + i, loadU64Unaligned(src + i));
     for (; i < n; i++) dst[i] = src[i];
 }
-__device__ __forceinline__ void copyRevCompSerial(char *dst, const char *src, unsigned n) {     // getNuclRevFragment
-    for (unsigned i = 0; i < n; i++) dst[i] = nuclRevN(src[n - 1 - i]);
+// Reverse-strand targets eight residues per load: the word that ENDS at the mirrored position, byte-swapped, every byte through the
+// complement table in LDS.
+// bytes src[hi - 7 .. hi] in reverse order (byte j of the result = src[hi - j]); for hi < 7 the bytes below src[0] are not touched
+// and the upper bytes of the result are unspecified
+__device__ __forceinline__ uint64_t loadRevWord(const char *src, unsigned hi) {
+    if (hi >= 7) return __builtin_bswap64(loadU64Unaligned(src + (hi - 7)));
+    return __builtin_bswap64(loadU64Unaligned(src)) >> (8u * (7u - hi));
 }
-// 256 threads share one score table: the kernel is latency bound, the number of queries in flight per CU is what counts
+__device__ __forceinline__ uint64_t compWord(uint64_t w, const unsigned char *sComp) {
+    uint64_t r = 0;
+#pragma unroll
+    for (unsigned j = 0; j < 8; j++) r |= (uint64_t) sComp[(unsigned) (w >> (8 * j)) & 0xFFu] << (8 * j);
+    return r;
+}
+// ---- cooperative halves of the kernel below: one job of ONE lane at a time, worked on by all 64 lanes (coalesced) ----
+template <typename T> __device__ __forceinline__ T bcast(T v, int srcLane) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "bcast");
+    if (sizeof(T) == 4) { int x; __builtin_memcpy(&x, &v, 4); x = __builtin_amdgcn_readlane(x, srcLane); T r; __builtin_memcpy(&r, &x, 4); return r; }
+    int x[2]; __builtin_memcpy(x, &v, 8); x[0] = __builtin_amdgcn_readlane(x[0], srcLane); x[1] = __builtin_amdgcn_readlane(x[1], srcLane);
+    T r; __builtin_memcpy(&r, x, 8); return r;
+}
+// dst[i] = nuclRevN(src[n - 1 - i]), 8 bytes per lane and step
+__device__ __forceinline__ void copyRevCompWave(char *dst, const char *src, unsigned n, const unsigned char *sComp, int lane) {
+    for (unsigned i = 8u * (unsigned) lane; i < n; i += 512u) {
+        const uint64_t w = compWord(loadRevWord(src, n - 1 - i), sComp);
+        if (i + 8 <= n) storeU64Unaligned(dst + i, w);
+        else storeTail(dst + i, w, n - i);
+    }
+}
+// scoreColumnsG<64> against the reverse complement of the target: column p is nuclRevN(tSeq[tHi - p]); partial sums per lane
+__device__ __forceinline__ void scoreColumnsRevWave(const char *q, const char *tSeq, unsigned tHi, unsigned len, const signed char *smat, const unsigned char *sComp, int lane,
+                                                    unsigned &first, unsigned &last, int &s, int &ids) {
+    const char q0 = q[0], qe = q[len - 1];
+    const char t0 = (char) sComp[(unsigned char) tSeq[tHi]], te = (char) sComp[(unsigned char) tSeq[tHi - (len - 1)]];
+    first = (q0 == '*' || t0 == '*') ? 1u : 0u;
+    last = len - 1;
+    if (last > 0 && (qe == '*' || te == '*')) last--;
+    for (unsigned p = 8u * (unsigned) lane; p < len; p += 512u) {
+        const uint64_t qw = loadU64Unaligned(q + p), tc = compWord(loadRevWord(tSeq, tHi - p), sComp);
+        const int lo = (int) first - (int) p, hi = (int) last - (int) p;
+        const uint64_t m = byteRangeMask(lo, hi + 1);
+        ids += zeroBytes(qw ^ tc, byteRangeMask(lo, hi));
+        const uint64_t qv = qw & m, tv = tc & m;
+#pragma unroll
+        for (unsigned j = 0; j < 8; j++) {
+            const unsigned a = (unsigned) (qv >> (8 * j)) & 0xFFu, b = (unsigned) (tv >> (8 * j)) & 0xFFu;
+            s += (int) smat[a * 123 + b];
+        }
+    }
+}
+
+// ---- nucleotide / guided variants, ONE LANE per queue, ONE WAVEFRONT per copy and per re-scored overlap (round 4).
+//      Rounds 2-3 ran the reference's loop statement by statement in one thread per query: what a wavefront per query wastes is 63
+//      lanes during every heap operation (a chain of dependent loads and, for overlaps the memo does not cover, a posterior class in
+//      double precision), so the heaps stay one per lane.  But a lane that copies a fragment or walks an overlap alone issues loads
+//      whose 64 addresses lie in 64 different lines, 2 048 such streams per CU evict each other from the L1, and the lanes of a
+//      wavefront wait for the one with the longest overlaps: in the late nucleotide iterations of configs[4] (contigs of 5-100 kb
+//      with up to 256 hits) the kernel spent 700 ms per call that way.  Now a round of the loop is three phases per wavefront:
+//      (1) every lane pops its own heap and only RECORDS what it attaches (at most the query itself, one fragment per side);
+//      (2) the recorded copies, then (3) the deferred hits' overlaps, are worked through one lane's job at a time by all 64 lanes,
+//      8 bytes per lane and step, partial scores reduced across the wavefront; the owner takes the result and pushes the hit back.
+//      Queue, deferral list and hit records live in the query's slice of the global scratch arrays like in assembleNuclKernel. ----
+// 256 threads share one score table: the number of queues in flight per CU is what counts in phase 1
 constexpr int NT_BLOCK = 256;
+struct CopyJob { char *dst; const char *src; unsigned n; unsigned rev; };
 template <bool GUIDED>
 __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs a) {    // 4 blocks per CU: at most 128 VGPRs
     __shared__ signed char smat[123 * 123 + 7];
+    __shared__ unsigned char sComp[256];                     // nuclRevN of every byte
     stageScoreTable(smat, a.mat, NT_BLOCK);
+    for (int i = threadIdx.x; i < 256; i += NT_BLOCK) sComp[i] = (unsigned char) nuclRevN((char) i);
     __syncthreads();
+    const int lane = laneId();
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
     NuclCmp cmp; cmp.a = &a; cmp.abort = false;
-    for (uint32_t w = blockIdx.x * NT_BLOCK + threadIdx.x; w < a.nQueryList; w += gridDim.x * NT_BLOCK) {
-        const uint32_t id = a.queryList[w];
-        const uint64_t h0 = a.qoff[id];
-        const uint32_t h = (uint32_t) (a.qoff[id + 1] - h0);
-        const uint64_t aoff = a.arenaOff[id];
+    for (uint32_t w0 = blockIdx.x * NT_BLOCK + (threadIdx.x & ~63u); w0 < a.nQueryList; w0 += gridDim.x * NT_BLOCK) {      // wavefront-uniform
+        const uint32_t w = w0 + (uint32_t) lane;
+        const bool valid = w < a.nQueryList;
+        const uint32_t id = valid ? a.queryList[w] : 0u;
+        const uint64_t h0 = valid ? a.qoff[id] : 0ull;
+        const uint32_t h = valid ? (uint32_t) (a.qoff[id + 1] - h0) : 0u;
+        const uint64_t aoff = valid ? a.arenaOff[id] : 0ull;
         Item *it = a.items + h0;
         uint32_t *hp = a.heap + 3 * h0, *def = hp + h, *used = def + h;
         uint32_t nUsed = 0;
         cmp.abort = false;
         unsigned long long qResc = 0, qRescRes = 0;
-        const char *orig = a.s.data + seqOff(a.s, id);
-        unsigned querySeqLen = seqLen(a.s, id);
+        const char *orig = a.s.data + (valid ? seqOff(a.s, id) : 0ull);
+        unsigned querySeqLen = valid ? seqLen(a.s, id) : 0u;
         uint32_t nHeap = 0;
         for (uint32_t i = 0; i < h && !cmp.abort; i++) {                 // queue fill
             const AlnRec r = a.recs[h0 + i];
@@ -767,121 +856,154 @@ __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs 
             if (x.state == 0) heapPush(hp, nHeap, i, it, cmp);
         }
         const char *aaQ = nullptr; char *aaBuf = nullptr; uint64_t aaStart = 0, aaLen = 0; bool exclL = false, exclR = false;
-        if (GUIDED) {
+        if (GUIDED && valid) {
             aaQ = a.aa.data + a.aa.off[id]; aaLen = a.aa.len[id];
             exclL = aaQ[0] == '*'; exclR = aaQ[aaLen - 1] == '*';
             aaBuf = a.aaArena + a.aaArenaOff[id]; aaStart = a.aaLeftCap[id];
-            copyBytesSerial(aaBuf + aaStart, aaQ, (unsigned) aaLen);
+            copyBytesSerial(aaBuf + aaStart, aaQ, (unsigned) aaLen);      // (the protein twins are a third of the length, their fragments a few residues)
         }
         char *buf = a.arena + aoff;
-        uint64_t curStart = a.leftCap[id];
-        copyBytesSerial(buf + curStart, orig, querySeqLen);
+        uint64_t curStart = valid ? a.leftCap[id] : 0ull;
+        // the query is copied into its arena slice when the first fragment is attached: many queries that pass the pre-screen still end
+        // without an extension (their extendable hit names a target that offers nothing new)
+        const unsigned origLen = querySeqLen;
+        bool copied = false;
         uint64_t curLen = querySeqLen;
         bool couldExtend = false;
-        while (nHeap > 0 && !cmp.abort) {
+        bool active = valid && nHeap > 0 && !cmp.abort;
+        while (__any(active)) {
+            // ---- phase 1, per lane: pop until the heap is empty; attachments are recorded, not made ----
             unsigned leftOff = 0, rightOff = 0;
             bool brokeOut = false;
             uint32_t nDef = 0;
-            while (nHeap > 0) {
-                const uint32_t bi = heapPop(hp, nHeap, it, cmp);
-                if (cmp.abort) break;
-                const Item best = it[bi];
-                const bool notBoth = !(best.dbStart == 0 && best.qStart == 0);
-                const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
-                const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
-                if (!((rightStart || leftStart) && notBoth && best.target != id)) continue;
-                const char *tSeq = a.s.data + seqOff(a.s, best.target);
-                const unsigned tLen = seqLen(a.s, best.target);
-                const bool rev = best.pad != 0;
-                const char *aaT = nullptr; unsigned aaTLen = 0;
-                if (GUIDED) { aaT = a.aa.data + a.aa.off[best.target]; aaTLen = a.aa.len[best.target]; }
-                if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff || (GUIDED && (exclR || aaT[0] == '*'))) continue; }
-                else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff || (GUIDED && (exclL || aaT[aaTLen - 1] == '*'))) continue; }
-                const unsigned dbStart = (unsigned) best.dbStart, dbEnd = (unsigned) best.dbEnd, qStart = (unsigned) best.qStart, qEnd = (unsigned) best.qEnd;
-                if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
-                    if (rightOff > 0) { def[nDef++] = bi; continue; }
-                    const unsigned fragLen = tLen - (dbEnd + 1);
-                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
-                    if (rev) copyRevCompSerial(buf + curStart + curLen, tSeq, fragLen);
-                    else copyBytesSerial(buf + curStart + curLen, tSeq + dbEnd + 1, fragLen);
-                    curLen += fragLen; rightOff += fragLen;
-                    if (GUIDED) {
-                        const unsigned aaFrag = (tLen / 3 - dbEnd / 3) - 1;
-                        if (aaStart + aaLen + aaFrag > a.aaArenaOff[id + 1] - a.aaArenaOff[id]) atomicAdd(&a.stats[12], 1ull);
-                        else { copyBytesSerial(aaBuf + aaStart + aaLen, aaT + dbEnd / 3 + 1, aaFrag); aaLen += aaFrag; }
+            CopyJob job[3];
+            job[0].n = 0; job[1].n = 0; job[2].n = 0;
+            if (active) {
+                while (nHeap > 0) {
+                    const uint32_t bi = heapPop(hp, nHeap, it, cmp);
+                    if (cmp.abort) break;
+                    const Item best = it[bi];
+                    const bool notBoth = !(best.dbStart == 0 && best.qStart == 0);
+                    const bool rightStart = best.dbStart == 0 && (best.dbEnd != (int) best.dbLen - 1);
+                    const bool leftStart = best.qStart == 0 && (best.qEnd != (int) best.qLen - 1);
+                    if (!((rightStart || leftStart) && notBoth && best.target != id)) continue;
+                    const char *tSeq = a.s.data + seqOff(a.s, best.target);
+                    const unsigned tLen = seqLen(a.s, best.target);
+                    const bool rev = best.pad != 0;
+                    const char *aaT = nullptr; unsigned aaTLen = 0;
+                    if (GUIDED) { aaT = a.aa.data + a.aa.off[best.target]; aaTLen = a.aa.len[best.target]; }
+                    if (best.dbStart == 0) { if ((tLen - ((unsigned) best.dbEnd + 1)) <= rightOff || (GUIDED && (exclR || aaT[0] == '*'))) continue; }
+                    else if (best.qStart == 0) { if (best.dbStart <= (int) leftOff || (GUIDED && (exclL || aaT[aaTLen - 1] == '*'))) continue; }
+                    const unsigned dbStart = (unsigned) best.dbStart, dbEnd = (unsigned) best.dbEnd, qStart = (unsigned) best.qStart, qEnd = (unsigned) best.qEnd;
+                    if (dbStart == 0 && qEnd == (querySeqLen - 1)) {            // right extension
+                        if (rightOff > 0) { def[nDef++] = bi; continue; }
+                        const unsigned fragLen = tLen - (dbEnd + 1);
+                        if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                        if (!copied) { job[0].dst = buf + curStart; job[0].src = orig; job[0].n = origLen; job[0].rev = 0; copied = true; }
+                        job[1].dst = buf + curStart + curLen; job[1].src = rev ? tSeq : tSeq + dbEnd + 1; job[1].n = fragLen; job[1].rev = rev ? 1u : 0u;
+                        curLen += fragLen; rightOff += fragLen;
+                        if (GUIDED) {
+                            const unsigned aaFrag = (tLen / 3 - dbEnd / 3) - 1;
+                            if (aaStart + aaLen + aaFrag > a.aaArenaOff[id + 1] - a.aaArenaOff[id]) atomicAdd(&a.stats[12], 1ull);
+                            else { copyBytesSerial(aaBuf + aaStart + aaLen, aaT + dbEnd / 3 + 1, aaFrag); aaLen += aaFrag; }
+                        }
+                        used[nUsed++] = best.target;
+                    } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
+                        if (leftOff > 0) { def[nDef++] = bi; continue; }
+                        const unsigned fragLen = dbStart;
+                        if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
+                        if (!copied) { job[0].dst = buf + curStart; job[0].src = orig; job[0].n = origLen; job[0].rev = 0; copied = true; }
+                        curStart -= fragLen;
+                        job[2].dst = buf + curStart; job[2].src = rev ? tSeq + (tLen - dbStart) : tSeq; job[2].n = fragLen; job[2].rev = rev ? 1u : 0u;
+                        curLen += fragLen; leftOff += fragLen;
+                        if (GUIDED) {
+                            const unsigned aaFrag = fragLen / 3 + ((aaT[0] == '*') ? 1u : 0u);
+                            if (aaFrag > aaStart) atomicAdd(&a.stats[12], 1ull);
+                            else { aaStart -= aaFrag; copyBytesSerial(aaBuf + aaStart, aaT, aaFrag); aaLen += aaFrag; }
+                        }
+                        used[nUsed++] = best.target;
                     }
-                    used[nUsed++] = best.target;
-                } else if (qStart == 0 && dbEnd == (tLen - 1)) {            // left extension
-                    if (leftOff > 0) { def[nDef++] = bi; continue; }
-                    const unsigned fragLen = dbStart;
-                    if (curLen + fragLen >= a.maxSeqLen) { brokeOut = true; break; }
-                    curStart -= fragLen;
-                    if (rev) copyRevCompSerial(buf + curStart, tSeq + (tLen - dbStart), fragLen);
-                    else copyBytesSerial(buf + curStart, tSeq, fragLen);
-                    curLen += fragLen; leftOff += fragLen;
-                    if (GUIDED) {
-                        const unsigned aaFrag = fragLen / 3 + ((aaT[0] == '*') ? 1u : 0u);
-                        if (aaFrag > aaStart) atomicAdd(&a.stats[12], 1ull);
-                        else { aaStart -= aaFrag; copyBytesSerial(aaBuf + aaStart, aaT, aaFrag); aaLen += aaFrag; }
-                    }
-                    used[nUsed++] = best.target;
+                }
+                if (cmp.abort) active = false;
+            }
+            // ---- phase 2, per wavefront: the recorded copies, one lane's job at a time ----
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                unsigned long long m = __ballot(job[k].n > 0);
+                while (m) {
+                    const int j = __ffsll((long long) m) - 1; m &= m - 1;
+                    char *dst = bcast(job[k].dst, j); const char *src = bcast(job[k].src, j);
+                    const unsigned n = bcast(job[k].n, j), rv = bcast(job[k].rev, j);
+                    if (rv) copyRevCompWave(dst, src, n, sComp, lane); else copyBytesG<64>(dst, src, n, lane);
                 }
             }
-            if (cmp.abort) break;
-            if (leftOff > 0 || rightOff > 0) couldExtend = true;
-            if (brokeOut && nHeap > 0) break;
+            waveMemSync();                                            // phase 3 reads what phase 2 wrote through other lanes
+            if (active) {
+                if (leftOff > 0 || rightOff > 0) couldExtend = true;
+                if (brokeOut && nHeap > 0) active = false;
+            }
+            // ---- phase 3: the deferred hits on the extended query, in deferral order; overlaps walked by the wavefront ----
             querySeqLen = (unsigned) curLen;
             const char *qs = buf + curStart;
-            for (uint32_t d = 0; d < nDef && !cmp.abort; d++) {                // re-score the deferred hits in deferral order
-                const uint32_t found = def[d];
-                Item x = it[found];
-                const char *tSeq = a.s.data + seqOff(a.s, x.target);
-                const unsigned tLen = seqLen(a.s, x.target);
-                const int diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
-                const unsigned dist = (unsigned) abs(diag);
-                unsigned qo = 0, to = 0, len = 0; bool hit = true;
-                if (diag >= 0 && dist < querySeqLen) { qo = dist; to = 0; len = min(tLen, querySeqLen - dist); }
-                else if (diag < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, querySeqLen); }
-                else hit = false;
-                int startPos = -1, endPos = -1, sc = 0, ids = 0;
-                if (hit && len > 0) {
-                    unsigned first, last;
-                    if (x.pad == 0) scoreColumnsSerial(qs + qo, tSeq + to, len, smat, first, last, sc, ids);
-                    else {                                                    // target walked as its reverse complement
-                        auto T = [&](unsigned i) -> char { return nuclRevN(tSeq[tLen - 1 - (to + i)]); };
-                        first = (qs[qo] == '*' || T(0) == '*') ? 1u : 0u;
-                        last = len - 1;
-                        if (last > 0 && (qs[qo + len - 1] == '*' || T(len - 1) == '*')) last--;
-                        for (unsigned p = first; p <= last; p++) {
-                            const char qa = qs[qo + p], tb = T(p);
-                            sc += (int) smat[(int) qa * 123 + (int) tb];
-                            if (p < last) ids += (qa == tb) ? 1 : 0;
-                        }
-                    }
-                    startPos = (int) first; endPos = (int) last;
+            const uint32_t myDef = active ? nDef : 0u;
+            uint32_t maxDef = myDef;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) maxDef = max(maxDef, (uint32_t) __shfl_xor((int) maxDef, o, 64));
+            for (uint32_t d = 0; d < maxDef; d++) {
+                const bool mine = d < myDef && !cmp.abort;
+                uint32_t found = 0; Item x; memset(&x, 0, sizeof(x));
+                const char *tSeq = nullptr; unsigned tLen = 0, qo = 0, to = 0, len = 0, dist = 0; int diag = 0; bool hit = false;
+                if (mine) {
+                    found = def[d];
+                    x = it[found];
+                    tSeq = a.s.data + seqOff(a.s, x.target);
+                    tLen = seqLen(a.s, x.target);
+                    diag = (int) ((unsigned) x.qStart + leftOff) - x.dbStart;
+                    dist = (unsigned) abs(diag);
+                    hit = true;
+                    if (diag >= 0 && dist < querySeqLen) { qo = dist; to = 0; len = min(tLen, querySeqLen - dist); }
+                    else if (diag < 0 && dist < tLen) { qo = 0; to = dist; len = min(tLen - dist, querySeqLen); }
+                    else hit = false;
                 }
-                const unsigned score = (unsigned) max(sc, 0);
-                qResc++; qRescRes += hit ? len : 0;
-                int qS, qE, dS, dE;
-                if (diag >= 0) { qS = startPos + (int) dist; qE = endPos + (int) dist; dS = startPos; dE = endPos; }
-                else { qS = startPos; qE = endPos; dS = startPos + (int) dist; dE = endPos + (int) dist; }
-                const float seqId = (float) ids / ((float) qE - (float) qS);
-                x.seqId = seqId; x.qLen = querySeqLen; x.dbLen = tLen; x.alnLength = hit ? len : 0u;
-                const float spc = (float) score / (float) ((double) x.alnLength + 0.5);
-                x.score = (int) (spc * 100);
-                x.qStart = qS; x.qEnd = qE; x.dbStart = dS; x.dbEnd = dE;
-                it[found] = x;
-                if (seqId >= a.seqIdThr) heapPush(hp, nHeap, found, it, cmp);
+                int startPos = -1, endPos = -1, sc = 0, ids = 0;
+                unsigned long long m = __ballot(mine && hit && len > 0);
+                while (m) {
+                    const int j = __ffsll((long long) m) - 1; m &= m - 1;
+                    const char *jq = bcast(qs + qo, j); const char *jt = bcast(tSeq, j);
+                    const unsigned jTo = bcast(to, j), jLen = bcast(len, j), jTLen = bcast(tLen, j), jRev = bcast((unsigned) x.pad, j);
+                    unsigned first = 0, last = 0; int s = 0, idn = 0;
+                    if (jRev) scoreColumnsRevWave(jq, jt, jTLen - 1 - jTo, jLen, smat, sComp, lane, first, last, s, idn);
+                    else scoreColumnsG<64>(jq, jt + jTo, jLen, smat, lane, first, last, s, idn);
+                    s = waveReduceSum(s); idn = waveReduceSum(idn);
+                    if (lane == j) { startPos = (int) first; endPos = (int) last; sc = s; ids = idn; }
+                }
+                if (mine) {
+                    const unsigned score = (unsigned) max(sc, 0);
+                    qResc++; qRescRes += hit ? len : 0;
+                    int qS, qE, dS, dE;
+                    if (diag >= 0) { qS = startPos + (int) dist; qE = endPos + (int) dist; dS = startPos; dE = endPos; }
+                    else { qS = startPos; qE = endPos; dS = startPos + (int) dist; dE = endPos + (int) dist; }
+                    const float seqId = (float) ids / ((float) qE - (float) qS);
+                    x.seqId = seqId; x.qLen = querySeqLen; x.dbLen = tLen; x.alnLength = hit ? len : 0u;
+                    const float spc = (float) score / (float) ((double) x.alnLength + 0.5);
+                    x.score = (int) (spc * 100);
+                    x.qStart = qS; x.qEnd = qE; x.dbStart = dS; x.dbEnd = dE;
+                    it[found] = x;
+                    if (seqId >= a.seqIdThr) heapPush(hp, nHeap, found, it, cmp);
+                }
             }
+            active = active && nHeap > 0 && !cmp.abort;
         }
-        if (cmp.abort) a.redoList[atomicAdd(a.redoCount, 1u)] = id;          // nothing of this query has been published
-        else {
-            nAln += h; nQRes += seqLen(a.s, id); nResc += qResc; nRescRes += qRescRes;
-            for (uint32_t i = 0; i < nUsed; i++) atomicOr(&a.flags[used[i]], 0x80u);
-            if (couldExtend) {
-                atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart;
-                if (GUIDED) { a.aaNewLen[id] = (uint32_t) aaLen; a.aaNewStart[id] = a.aaArenaOff[id] + aaStart; }
-                nExt++;
+        if (valid) {
+            if (cmp.abort) a.redoList[atomicAdd(a.redoCount, 1u)] = id;          // nothing of this query has been published
+            else {
+                nAln += h; nQRes += seqLen(a.s, id); nResc += qResc; nRescRes += qRescRes;
+                for (uint32_t i = 0; i < nUsed; i++) atomicOr(&a.flags[used[i]], 0x80u);
+                if (couldExtend) {
+                    atomicOr(&a.flags[id], 0x20u); a.newLen[id] = (uint32_t) curLen; a.newStart[id] = aoff + curStart;
+                    if (GUIDED) { a.aaNewLen[id] = (uint32_t) aaLen; a.aaNewStart[id] = a.aaArenaOff[id] + aaStart; }
+                    nExt++;
+                }
             }
         }
     }
@@ -1115,8 +1237,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 // Pass 1, one thread per ALIGNMENT (a wavefront reads 64 records = 4 KB in a row; one thread per query walking its records was 64
 // lines per load instruction: 9 ms for 226 M records): the alignments of a query are contiguous, so the lanes of a wavefront form
 // segments by query — segmented sums of the target lengths, one atomic per query and wavefront.
+// mirror: nuclassembleresults puts a reverse-strand hit (qStart > qEnd) on the query's strand before anything looks at its coordinates
+// (nuclassembleresult.cpp:207-216); the pre-screen tests the mirrored coordinates then.
 __global__ __launch_bounds__(256) void arenaSumKernel(const AlnRec *__restrict__ recs, uint64_t nAln, uint64_t maxSeqLen, unsigned long long *__restrict__ qSum,
-                                                      unsigned long long *__restrict__ qSumAa, uint32_t *__restrict__ qCan) {
+                                                      unsigned long long *__restrict__ qSumAa, uint32_t *__restrict__ qCan, int mirror) {
     const int lane = laneId();
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < nAln; i += (uint64_t) gridDim.x * blockDim.x) {
         const AlnRec r = recs[i];
@@ -1127,12 +1251,14 @@ __global__ __launch_bounds__(256) void arenaSumKernel(const AlnRec *__restrict__
             // exact pre-screen: the first extension of a query is decided by coordinates the alignment already
             // carries (selectFragmentToExtend + the two geometry tests, assembleresult.cpp:40-57,211-263); if no
             // alignment can start an extension the greedy loop drains its queue without changing anything.
-            const bool notBoth = !(r.dbStart == 0 && r.qStart == 0);
-            const bool rightStart = r.dbStart == 0 && (r.dbEnd != r.dbLen - 1);
-            const bool leftStart = r.qStart == 0 && (r.qEnd != r.qLen - 1);
+            int qS = r.qStart, qE = r.qEnd, dS = r.dbStart, dE = r.dbEnd;
+            if (mirror && qS > qE) { qS = r.qEnd; qE = r.qStart; dS = r.dbLen - r.dbEnd - 1; dE = r.dbLen - r.dbStart - 1; }
+            const bool notBoth = !(dS == 0 && qS == 0);
+            const bool rightStart = dS == 0 && (dE != r.dbLen - 1);
+            const bool leftStart = qS == 0 && (qE != r.qLen - 1);
             if ((rightStart || leftStart) && notBoth) {
-                if (r.dbStart == 0) can = (r.qEnd == r.qLen - 1) && (r.dbLen - (r.dbEnd + 1) > 0);
-                else if (r.qStart == 0) can = (r.dbEnd == r.dbLen - 1) && (r.dbStart > 0) && ((uint64_t) r.qLen + (uint64_t) r.dbStart < maxSeqLen);
+                if (dS == 0) can = (qE == r.qLen - 1) && (r.dbLen - (dE + 1) > 0);
+                else if (qS == 0) can = (dE == r.dbLen - 1) && (dS > 0) && ((uint64_t) r.qLen + (uint64_t) dS < maxSeqLen);
             }
         }
         // (the lanes of a wavefront leave the loop together except in its last round, where the active ones are the low lanes)
@@ -1162,17 +1288,21 @@ __global__ __launch_bounds__(256) void arenaSumKernel(const AlnRec *__restrict__
 // positions into the work lists of the extension kernels (id order, no atomics)
 __global__ void arenaSizeKernel(SeqView s, const uint64_t *__restrict__ qoff, const unsigned long long *__restrict__ qSum, const unsigned long long *__restrict__ qSumAa,
                                 const uint32_t *__restrict__ qCan, uint32_t *__restrict__ leftCap,
-                                uint64_t *__restrict__ bytes, int noPrescreen,
+                                uint64_t *__restrict__ bytes, int nuclTiers, uint64_t threadBytes,
                                 uint64_t *__restrict__ tierA, uint64_t *__restrict__ tierB,
                                 const uint32_t *__restrict__ aaLen, uint32_t *__restrict__ aaLeftCap, uint64_t *__restrict__ aaBytes) {
     for (uint32_t id = blockIdx.x * blockDim.x + threadIdx.x; id < s.n; id += gridDim.x * blockDim.x) {
         int tier = -1;
         const uint64_t sum = qSum[id], sumAa = aaBytes ? qSumAa[id] : 0;
-        const bool can = noPrescreen != 0 || qCan[id] != 0;       // nucleotide hits are mirrored first: no pre-screen there
+        const bool can = qCan[id] != 0;
         leftCap[id] = (uint32_t) std::min<uint64_t>(sum, 0xFFFFFFFFull);
-        bytes[id] = (sum && can) ? (2 * sum + s.len[id] + 40) : 0;      // slack: the re-scoring loops read up to 32 bytes past the query
+        const uint64_t slice = (sum && can) ? (2 * sum + s.len[id] + 40) : 0;
+        bytes[id] = slice;      // slack: the re-scoring loops read up to 32 bytes past the query
         if (aaBytes) { aaLeftCap[id] = (uint32_t) std::min<uint64_t>(sumAa, 0xFFFFFFFFull); aaBytes[id] = (sum && can) ? (2 * sumAa + aaLen[id] + 8) : 0; }
-        if (sum && can) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = noPrescreen ? (h <= 256 ? 0 : 1) : (h <= 16 ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3))); }   // nucleotide variants: thread-per-query list (one list: the long queues overlap with the many short ones), wave-per-query list
+        // nucleotide variants: thread-per-query list (up to 256 hits AND an arena slice — query + twice the targets — of at most threadBytes:
+        // a thread copies and re-scores byte ranges alone, and its wavefront waits for it; round 4: the contigs of the late iterations of
+        // configs[4], 10-100 kb with a few dozen hits, kept their wavefronts for hundreds of ms), wave-per-query list for the rest
+        if (sum && can) { const uint64_t h = qoff[id + 1] - qoff[id]; tier = nuclTiers ? ((h <= 256 && slice <= threadBytes) ? 0 : 1) : (h <= 16 ? 0 : (h <= 32 ? 1 : (h <= 64 ? 2 : 3))); }
         tierA[id] = (tier == 0) ? 1ull : ((tier == 1) ? (1ull << 32) : 0ull);
         tierB[id] = (tier == 2) ? 1ull : ((tier == 3) ? (1ull << 32) : 0ull);
     }
@@ -1186,6 +1316,46 @@ __global__ void listKernel(uint32_t n, const uint64_t *__restrict__ tierA, const
         else if (a) list1[(uint32_t) (posA[id] >> 32)] = id;
         else if (b & 0xFFFFFFFFull) list2[(uint32_t) posB[id]] = id;
         else if (b) list3[(uint32_t) (posB[id] >> 32)] = id;
+    }
+}
+
+// Thread-per-query list of the nucleotide variants in CLASSES of similar work (round 4): the lanes of a wavefront walk their queries in
+// lockstep, and the work of a query — re-scoring its deferred hits after every pair of extensions — spans three orders of magnitude
+// (a read with 4 hits: 500 residues; a contig with 160 hits: 290 000; profiles/r04_ab_knobs.txt).  The class is the binary order of
+// magnitude of the query's arena slice (query + twice its targets); the list is rewritten class by class, heaviest first, in whatever
+// order the atomics give inside a class (a query's result does not depend on when it runs).
+constexpr int NW_CLASSES = 16;
+__device__ __forceinline__ int nuclWorkClass(uint64_t slice) {
+    const int k = 63 - __clzll((long long) (slice | 1ull));
+    return NW_CLASSES - 1 - (min(max(k, 9), 9 + NW_CLASSES - 1) - 9);
+}
+__global__ __launch_bounds__(256) void nuclClassCountKernel(const uint32_t *__restrict__ list, uint32_t n, const uint64_t *__restrict__ bytes, uint32_t *__restrict__ counts) {
+    __shared__ uint32_t sCnt[NW_CLASSES];
+    if (threadIdx.x < NW_CLASSES) sCnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) atomicAdd(&sCnt[nuclWorkClass(bytes[list[i]])], 1u);
+    __syncthreads();
+    if (threadIdx.x < NW_CLASSES && sCnt[threadIdx.x]) atomicAdd(&counts[threadIdx.x], sCnt[threadIdx.x]);
+}
+// counts[0..15] class sizes, counts[16..31] fill counters (zeroed by the caller)
+__global__ __launch_bounds__(256) void nuclClassScatterKernel(const uint32_t *__restrict__ list, uint32_t n, const uint64_t *__restrict__ bytes, uint32_t *__restrict__ counts,
+                                                              uint32_t *__restrict__ out) {
+    __shared__ uint32_t sCnt[NW_CLASSES], sBase[NW_CLASSES];
+    for (uint32_t t0 = blockIdx.x * 256; t0 < n; t0 += gridDim.x * 256) {
+        if (threadIdx.x < NW_CLASSES) sCnt[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t i = t0 + threadIdx.x;
+        uint32_t id = 0, r = 0; int c = -1;
+        if (i < n) { id = list[i]; c = nuclWorkClass(bytes[id]); r = atomicAdd(&sCnt[c], 1u); }
+        __syncthreads();
+        if (threadIdx.x < NW_CLASSES) {
+            uint32_t before = 0;
+            for (int k = 0; k < (int) threadIdx.x; k++) before += counts[k];
+            sBase[threadIdx.x] = before + (sCnt[threadIdx.x] ? atomicAdd(&counts[NW_CLASSES + threadIdx.x], sCnt[threadIdx.x]) : 0u);
+        }
+        __syncthreads();
+        if (c >= 0) out[sBase[c] + r] = id;
+        __syncthreads();
     }
 }
 
@@ -1597,9 +1767,10 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     PH_CHECK(hipMemsetAsync(dQCan.p, 0, ((size_t) N + 1) * 4, st));
     if (guided) PH_CHECK(hipMemsetAsync(dQSumAa.p, 0, ((size_t) N + 1) * 8, st));
     if (al->nLines) hipLaunchKernelGGL(arenaSumKernel, dim3((unsigned) std::min<uint64_t>((al->nLines + 255) / 256, (uint64_t) ctx->numCU * 32)), dim3(256), 0, st, al->d_recs.as<AlnRec>(), (uint64_t) al->nLines,
-                                       (uint64_t) par->max_seq_len, dQSum.as<unsigned long long>(), guided ? dQSumAa.as<unsigned long long>() : (unsigned long long *) nullptr, dQCan.as<uint32_t>());
+                                       (uint64_t) par->max_seq_len, dQSum.as<unsigned long long>(), guided ? dQSumAa.as<unsigned long long>() : (unsigned long long *) nullptr, dQCan.as<uint32_t>(),
+                                       (nucl && !guided) ? 1 : 0);
     if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), (const unsigned long long *) dQSum.as<unsigned long long>(),
-                              (const unsigned long long *) dQSumAa.as<unsigned long long>(), (const uint32_t *) dQCan.as<uint32_t>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), nucl ? 1 : 0,
+                              (const unsigned long long *) dQSumAa.as<unsigned long long>(), (const uint32_t *) dQCan.as<uint32_t>(), dLeftCap.as<uint32_t>(), dBytes.as<uint64_t>(), nucl ? 1 : 0, (uint64_t) tuneInt("NUCL_THREAD_BYTES", 1 << 30),
                               dTierA.as<uint64_t>(), dTierB.as<uint64_t>(),
                               guided ? aaDb->d_len.as<uint32_t>() : (const uint32_t *) nullptr, dAaLeftCap.as<uint32_t>(), guided ? dAaBytes.as<uint64_t>() : (uint64_t *) nullptr);
     if (guided && exclusiveScanU64(st, dAaBytes.as<uint64_t>(), dAaArenaOff.as<uint64_t>(), N, dTmp.p, tmpBytes)) { setError("plasship_assemble: scan failed"); return PLASSHIP_ERR_DEVICE; }
@@ -1669,6 +1840,16 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
             if (pass == 0) {
                 if (cnts[0]) {
                     a.queryList = dSmallList.as<uint32_t>(); a.nQueryList = cnts[0];
+                    if (tuneInt("NUCL_CLASSES", 1) == 1) {                    // PLASSHIP_TUNE_NUCL_CLASSES=2: id order
+                        DevBuf dCls;
+                        if (dCls.alloc(2 * NW_CLASSES * 4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+                        PH_CHECK(hipMemsetAsync(dCls.p, 0, 2 * NW_CLASSES * 4, st));
+                        const unsigned g = std::min<uint32_t>((cnts[0] + 255) / 256, (uint32_t) ctx->numCU * 8);
+                        hipLaunchKernelGGL(nuclClassCountKernel, dim3(g), dim3(256), 0, st, (const uint32_t *) dSmallList.as<uint32_t>(), cnts[0], (const uint64_t *) dBytes.as<uint64_t>(), dCls.as<uint32_t>());
+                        hipLaunchKernelGGL(nuclClassScatterKernel, dim3(g), dim3(256), 0, st, (const uint32_t *) dSmallList.as<uint32_t>(), cnts[0], (const uint64_t *) dBytes.as<uint64_t>(), dCls.as<uint32_t>(),
+                                           dMidList.as<uint32_t>());          // (the 64-lane list is a protein tier: unused here)
+                        a.queryList = dMidList.as<uint32_t>();
+                    }
                     const uint32_t grid = std::min<uint32_t>((cnts[0] + NT_BLOCK - 1) / NT_BLOCK, (uint32_t) ctx->numCU * 8);
                     if (guided) hipLaunchKernelGGL(assembleNuclThreadKernel<true>, dim3(grid), dim3(NT_BLOCK), 0, st, a);
                     else hipLaunchKernelGGL(assembleNuclThreadKernel<false>, dim3(grid), dim3(NT_BLOCK), 0, st, a);
