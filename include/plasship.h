@@ -294,7 +294,7 @@ typedef struct plasship_cyclecheck_params {
 } plasship_cyclecheck_params;
 typedef struct plasship_cyclecheck_stats {
     uint64_t n_cyclic;
-    uint64_t n_wave_small, n_wave_large, n_block;   /* sequences per kernel tier (<= 380 nt, <= 3000 nt, longer)       */
+    uint64_t n_wave_small, n_wave_large, n_block;   /* sequences per kernel tier (<= 380 nt, <= 3068 nt, longer)       */
     float ms_kernel;
 } plasship_cyclecheck_stats;
 int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_cyclecheck_params *par, plasship_seqdb **out_cycle,

@@ -57,74 +57,122 @@ __device__ __forceinline__ bool bandPasses(const uint32_t *hits, uint32_t d, uin
     return (double) rate > 0.2;
 }
 
-// ---- one wavefront per sequence, everything in LDS -------------------------------------------------------------------
-template <int SLOTS, int MAXL>
-__global__ __launch_bounds__(64) void cycleWaveKernel(CycArgs a) {
+// ---- round 4: one table entry = (k-mer << 18 | position), the smallest position of a k-mer kept by a 64-bit atomicMin; two phases
+//      per sequence (front k-mers in the table, middle and back k-mers looked up; middle k-mers in the table, back k-mers looked up)
+//      instead of two minima per entry, so an entry is 8 bytes instead of 16 and a phase holds a third of the sequence instead of two:
+//      a 3 000-nt contig needs 16 KB of LDS instead of 64 KB + staging + histogram (rounds 1-3: 4-5 wavefronts per CU in the two larger
+//      wave tiers, 125 + 82 ms per call on the contigs of configs[4]'s last iteration).  The histogram of diagonals lives in HBM
+//      scratch and is only made when a first pass over both phases has seen a hit at all — a contig without an internal repeat of
+//      22 letters between its thirds, i.e. nearly every one, never touches it.  k-mers are rolled along contiguous ranges of
+//      positions (one letter per position instead of 22).  Contigs longer than the table holds take several passes per phase, each
+//      over the k-mers of one hash range: a workgroup with 64 KB of LDS handles any length below 2^18 (rounds 1-3: tables in HBM,
+//      global atomics, batches of 2 GB with a host wait each — 20 launches of 9 ms in that iteration).
+constexpr int CC_POS_BITS = 18;
+constexpr uint32_t CC_PACK_MAXL = (1u << CC_POS_BITS) - 1;
+struct CycTabArgs {
+    SeqView s;
+    const unsigned char *map;
+    const uint32_t *list; uint32_t nList;
+    uint32_t *split;
+    uint32_t *hist; uint64_t histStride;          // per workgroup: 2 * (longest sequence of the tier / 3) + 2 bins
+    uint32_t *fallList; uint32_t *fallCount;      // sequences whose table overflowed (never seen; the HBM kernel below takes them)
+};
+template <int THREADS, int SLOTS, int STAGE>      // STAGE: longest sequence whose letter codes are staged in LDS (0: read from HBM)
+__global__ __launch_bounds__(THREADS) void cycleTableKernel(CycTabArgs a) {
     __shared__ unsigned char sMap[256];
-    __shared__ unsigned char sNum[MAXL + CC_K + 8];
-    __shared__ unsigned long long sKey[SLOTS];
-    __shared__ uint32_t sMinF[SLOTS], sMinM[SLOTS];
-    __shared__ uint32_t sHits[2 * (MAXL / 3) + 2];
-    __shared__ uint32_t sAny;
-    const int lane = threadIdx.x;
-    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
+    __shared__ unsigned char sNum[STAGE ? STAGE + 8 : 8];
+    __shared__ unsigned long long sTab[SLOTS];
+    __shared__ uint32_t sHits, sFirst, sOver;
+    const uint32_t tid = threadIdx.x;
+    constexpr uint32_t mask = SLOTS - 1;
+    constexpr int slotShift = 64 - __builtin_ctz(SLOTS);
+    for (uint32_t i = tid; i < 256; i += THREADS) sMap[i] = a.map[i];
     __syncthreads();
+    uint32_t *hist = a.hist + (uint64_t) blockIdx.x * a.histStride;
     for (uint32_t w = blockIdx.x; w < a.nList; w += gridDim.x) {
         const uint32_t id = a.list[w];
         const uint32_t L = a.s.len[id];
         const char *seq = a.s.data + a.s.off[id];
         const uint32_t third = L / 3, nk = L - CC_K + 1, nBins = 2 * third + 1;
-        // table sized to the sequence (load <= 0.5 for its 2L/3 front + middle k-mers): clearing it is most of the work
-        // for a sequence without repeats
-        uint32_t slots = 256; while (slots * 3 < L * 4 + 64 && slots < (uint32_t) SLOTS) slots <<= 1;
-        const uint32_t mask = slots - 1;
-        for (uint32_t i = lane; i < L; i += 64) sNum[i] = sMap[(unsigned char) seq[i]];
-        for (uint32_t i = lane; i < slots; i += 64) { sKey[i] = CC_EMPTY; sMinF[i] = 0xFFFFFFFFu; sMinM[i] = 0xFFFFFFFFu; }
-        for (uint32_t i = lane; i < nBins; i += 64) sHits[i] = 0;
-        if (lane == 0) sAny = 0;
+        // positions by class (kmerClass): front [1, third + 1], middle [third + 2, 2 third + 1], back [2 third + 2, nk - 1]; position 0 is
+        // "back" too, but its diagonals are <= 0 and never counted
+        const uint32_t fLo = 1, fHi = min(third + 1, nk - 1), mLo = third + 2, mHi = min(2 * third + 1, nk - 1), bLo = 2 * third + 2, bHi = nk - 1;
+        const uint32_t passes = (third + 2 + SLOTS / 2 - 1) / (SLOTS / 2);          // load <= 0.5 per pass on average
+        if (STAGE) for (uint32_t i = tid; i < L; i += THREADS) sNum[i] = sMap[(unsigned char) seq[i]];
+        if (tid == 0) { sHits = 0; sFirst = 0xFFFFFFFFu; sOver = 0; }
         __syncthreads();
-        auto kmerAt = [&](uint32_t p) { unsigned long long v = 0; for (int i = CC_K - 1; i >= 0; i--) v = v * 4ULL + sNum[p + i]; return v; };
-        // phase 1: front and middle k-mers -> table (smallest position per k-mer and third)
-        for (uint32_t p = lane; p < nk; p += 64) {
-            const int c = kmerClass(p, third);
-            if (c == 2) continue;
-            const unsigned long long k = kmerAt(p);
-            uint32_t sl = hashSlot(k, mask);
-            for (;;) {
-                const unsigned long long prev = atomicCAS(&sKey[sl], CC_EMPTY, k);
-                if (prev == CC_EMPTY || prev == k) break;
+        auto code = [&](uint32_t i) -> unsigned long long { return STAGE ? (unsigned long long) sNum[i] : (unsigned long long) sMap[(unsigned char) seq[i]]; };
+        // every thread walks a contiguous part of [lo, hi] with a rolling index: idx' = (idx - code[p]) / 4 + code[p + k] * 4^(k-1)
+        auto walk = [&](uint32_t lo, uint32_t hi, uint32_t pass, auto &&visit) {
+            if (lo > hi) return;
+            const uint32_t n = hi - lo + 1, chunk = (n + THREADS - 1) / THREADS;
+            const uint32_t p0 = lo + tid * chunk, p1 = min(hi + 1, p0 + chunk);
+            if (p0 >= p1) return;
+            unsigned long long k = 0;
+            for (int i = CC_K - 1; i >= 0; i--) k = k * 4ULL + code(p0 + (uint32_t) i);
+            for (uint32_t p = p0; p < p1; p++) {
+                if (passes == 1 || (uint32_t) ((((k * 0xD6E8FEB86659FD93ULL) >> 40) * passes) >> 24) == pass) visit(p, k);
+                if (p + 1 < p1) k = ((k - code(p)) >> 2) + (code(p + CC_K) << (2 * (CC_K - 1)));
+            }
+        };
+        auto insert = [&](uint32_t p, unsigned long long k) {
+            const unsigned long long word = (k << CC_POS_BITS) | p;
+            uint32_t sl = (uint32_t) ((k * 0x9E3779B97F4A7C15ULL) >> slotShift);
+            for (uint32_t probes = 0; probes < (uint32_t) SLOTS; probes++) {
+                unsigned long long cur = sTab[sl];
+                if (cur == CC_EMPTY) { cur = atomicCAS(&sTab[sl], CC_EMPTY, word); if (cur == CC_EMPTY) return; }
+                if ((cur >> CC_POS_BITS) == k) { atomicMin(&sTab[sl], word); return; }
                 sl = (sl + 1) & mask;
             }
-            atomicMin(c == 0 ? &sMinF[sl] : &sMinM[sl], p);
-        }
-        __syncthreads();
-        // phase 2: middle k-mers against the first front occurrence, back k-mers against the first front and first middle one
-        for (uint32_t p = lane; p < nk; p += 64) {
-            const int c = kmerClass(p, third);
-            if (c == 0) continue;
-            const unsigned long long k = kmerAt(p);
-            uint32_t sl = hashSlot(k, mask);
-            for (;;) {
-                const unsigned long long kk = sKey[sl];
-                if (kk == k || kk == CC_EMPTY) { if (kk != k) sl = 0xFFFFFFFFu; break; }
-                sl = (sl + 1) & mask;
+            sOver = 1;
+        };
+        for (int round = 0; round < 2; round++) {                 // round 0: is there any hit?  round 1: the histogram
+            if (round == 1) {
+                for (uint32_t i = tid; i < nBins; i += THREADS) hist[i] = 0;
+                __threadfence();
+                __syncthreads();
             }
-            if (sl == 0xFFFFFFFFu) continue;
-            const uint32_t mf = sMinF[sl], mm = sMinM[sl];
-            if (mf != 0xFFFFFFFFu) { const int diag = (int) p - (int) mf; if (diag >= (int) third) { atomicAdd(&sHits[diag - (int) third], 1u); sAny = 1; } }
-            if (c == 2 && mm != 0xFFFFFFFFu) { const int diag = (int) p - (int) mm; if (diag >= (int) third) { atomicAdd(&sHits[diag - (int) third], 1u); sAny = 1; } }
-        }
-        __syncthreads();
-        uint32_t split = 0;
-        if (sAny) {
-            for (uint32_t base = 0; base < 2 * third; base += 64) {
-                const uint32_t d = base + lane;
-                const bool pass = d < 2 * third && sHits[d] != 0 && bandPasses(sHits, d, third, L);
-                const unsigned long long m = __ballot(pass);
-                if (m) { split = base + (uint32_t) __builtin_ctzll(m) + third; break; }
+            auto lookup = [&](uint32_t p, unsigned long long k) {
+                uint32_t sl = (uint32_t) ((k * 0x9E3779B97F4A7C15ULL) >> slotShift);
+                for (uint32_t probes = 0; probes < (uint32_t) SLOTS; probes++) {
+                    const unsigned long long cur = sTab[sl];
+                    if (cur == CC_EMPTY) return;
+                    if ((cur >> CC_POS_BITS) == k) {
+                        const int diag = (int) p - (int) (uint32_t) (cur & CC_PACK_MAXL);
+                        if (diag >= (int) third) { if (round == 0) sHits = 1; else atomicAdd(&hist[diag - (int) third], 1u); }
+                        return;
+                    }
+                    sl = (sl + 1) & mask;
+                }
+            };
+            for (int phase = 0; phase < 2; phase++) {
+                for (uint32_t pass = 0; pass < passes; pass++) {
+                    for (uint32_t i = tid; i < (uint32_t) SLOTS; i += THREADS) sTab[i] = CC_EMPTY;
+                    __syncthreads();
+                    if (phase == 0) walk(fLo, fHi, pass, insert); else walk(mLo, mHi, pass, insert);
+                    __syncthreads();
+                    if (phase == 0) walk(mLo, mHi, pass, lookup);
+                    walk(bLo, bHi, pass, lookup);
+                    __syncthreads();
+                }
             }
+            if (sOver || sHits == 0) break;
         }
-        if (lane == 0) a.split[id] = split;
+        if (sOver) {
+            if (tid == 0) a.fallList[atomicAdd(a.fallCount, 1u)] = id;
+        } else {
+            if (sHits) {
+                __threadfence();
+                __syncthreads();
+                for (uint32_t base = 0; base < 2 * third; base += THREADS) {
+                    const uint32_t d = base + tid;
+                    if (d < 2 * third && hist[d] != 0 && bandPasses(hist, d, third, L)) atomicMin(&sFirst, d);
+                    __syncthreads();
+                    if (sFirst != 0xFFFFFFFFu) break;
+                }
+            }
+            if (tid == 0) a.split[id] = (sFirst != 0xFFFFFFFFu) ? sFirst + third : 0u;
+        }
         __syncthreads();
     }
 }
@@ -206,10 +254,12 @@ __global__ __launch_bounds__(256) void cycleBlockKernel(CycArgs a) {
     }
 }
 
-// tier of every sequence: 0-3 wave kernel with a table of up to 256 / 512 / 2048 / 4096 slots in LDS (the LDS a wavefront
-// holds decides how many sequences a CU works on at a time: reads and merged read pairs get the small instantiations),
-// 4 workgroup kernel; sequences without a k-mer or at / above --max-seq-len are not circular
-constexpr uint32_t CC_L0 = 190, CC_LA = 380, CC_L1 = 1536, CC_L2 = 3000;
+// tier of every sequence: 0-2 one wavefront per sequence with a table of 256 / 1024 / 2048 entries in LDS (a phase inserts at most
+// L/3 + 2 k-mers, load <= 0.5; the LDS a wavefront holds decides how many sequences a CU works on at a time: reads and merged read
+// pairs get the small instantiation), 3 one workgroup of 256 threads with 8192 entries and as many passes as the length asks for,
+// 4 (2^18 letters and more: the position no longer fits beside the k-mer) the HBM kernel; sequences without a k-mer or at / above
+// --max-seq-len are not circular
+constexpr uint32_t CC_L0 = 380, CC_L1 = 1532, CC_L2 = 3068;
 constexpr int CC_TIERS = 5;
 __global__ void cycleTierKernel(SeqView s, uint64_t maxSeqLen, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, uint32_t *__restrict__ split) {
     for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < s.n; b0 += gridDim.x * blockDim.x) {
@@ -218,7 +268,7 @@ __global__ void cycleTierKernel(SeqView s, uint64_t maxSeqLen, uint32_t *__restr
         if (id < s.n) {
             const uint32_t L = s.len[id];
             split[id] = 0;
-            if (L >= (uint32_t) CC_K && (uint64_t) L < maxSeqLen) tier = L <= CC_L0 ? 0 : (L <= CC_LA ? 1 : (L <= CC_L1 ? 2 : (L <= CC_L2 ? 3 : 4)));
+            if (L >= (uint32_t) CC_K && (uint64_t) L < maxSeqLen) tier = L <= CC_L0 ? 0 : (L <= CC_L1 ? 1 : (L <= CC_L2 ? 2 : (L <= CC_PACK_MAXL ? 3 : 4)));
         }
         for (int t = 0; t < CC_TIERS; t++) {
             const unsigned long long m = __ballot(tier == t);
@@ -271,10 +321,32 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
     PH_COPY_SYNC(st, cnt, dCounts.p, 32, hipMemcpyDeviceToHost);
     CycArgs a; memset(&a, 0, sizeof(a));
     a.s = sv; a.map = dMap.as<unsigned char>(); a.split = dSplit.as<uint32_t>();
-    if (cnt[0]) { a.list = dLists.as<uint32_t>(); a.nList = cnt[0]; hipLaunchKernelGGL((cycleWaveKernel<256, CC_L0>), dim3(std::min<uint32_t>(cnt[0], (uint32_t) ctx->numCU * 32)), dim3(64), 0, st, a); }
-    if (cnt[1]) { a.list = dLists.as<uint32_t>() + N; a.nList = cnt[1]; hipLaunchKernelGGL((cycleWaveKernel<512, CC_LA>), dim3(std::min<uint32_t>(cnt[1], (uint32_t) ctx->numCU * 24)), dim3(64), 0, st, a); }
-    if (cnt[2]) { a.list = dLists.as<uint32_t>() + 2 * (size_t) N; a.nList = cnt[2]; hipLaunchKernelGGL((cycleWaveKernel<2048, CC_L1>), dim3(std::min<uint32_t>(cnt[2], (uint32_t) ctx->numCU * 8)), dim3(64), 0, st, a); }
-    if (cnt[3]) { a.list = dLists.as<uint32_t>() + 3 * (size_t) N; a.nList = cnt[3]; hipLaunchKernelGGL((cycleWaveKernel<4096, CC_L2>), dim3(std::min<uint32_t>(cnt[3], (uint32_t) ctx->numCU * 4)), dim3(64), 0, st, a); }
+    // tiers 0-3: tables in LDS; a sequence whose table overflowed (more distinct k-mers in a hash range than entries: not seen) joins tier 4
+    DevBuf dHist, dFall;
+    {
+        const uint32_t maxL = (uint32_t) std::min<uint64_t>(db->maxEntryLen, CC_PACK_MAXL);
+        const uint32_t grid[4] = {std::min<uint32_t>(cnt[0], (uint32_t) ctx->numCU * 32), std::min<uint32_t>(cnt[1], (uint32_t) ctx->numCU * 16),
+                                  std::min<uint32_t>(cnt[2], (uint32_t) ctx->numCU * 8), std::min<uint32_t>(cnt[3], (uint32_t) ctx->numCU * 2)};
+        const uint64_t stride[4] = {2 * (uint64_t) (CC_L0 / 3) + 2, 2 * (uint64_t) (CC_L1 / 3) + 2, 2 * (uint64_t) (CC_L2 / 3) + 2, 2 * (uint64_t) (maxL / 3) + 2};
+        uint64_t histWords = 0, histOff[4];
+        for (int t = 0; t < 4; t++) { histOff[t] = histWords; histWords += cnt[t] ? grid[t] * stride[t] : 0; }
+        if (dHist.alloc((histWords + 1) * 4) != hipSuccess || dFall.alloc(4) != hipSuccess) { setError("plasship_cyclecheck: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemsetAsync(dFall.p, 0, 4, st));
+        CycTabArgs ta; memset(&ta, 0, sizeof(ta));
+        ta.s = sv; ta.map = dMap.as<unsigned char>(); ta.split = dSplit.as<uint32_t>();
+        ta.fallList = dLists.as<uint32_t>() + 4 * (size_t) N + cnt[4]; ta.fallCount = dFall.as<uint32_t>();
+        for (int t = 0; t < 4; t++) {
+            if (!cnt[t]) continue;
+            ta.list = dLists.as<uint32_t>() + (size_t) t * N; ta.nList = cnt[t]; ta.hist = dHist.as<uint32_t>() + histOff[t]; ta.histStride = stride[t];
+            if (t == 0) hipLaunchKernelGGL((cycleTableKernel<64, 256, CC_L0>), dim3(grid[t]), dim3(64), 0, st, ta);
+            else if (t == 1) hipLaunchKernelGGL((cycleTableKernel<64, 1024, CC_L1>), dim3(grid[t]), dim3(64), 0, st, ta);
+            else if (t == 2) hipLaunchKernelGGL((cycleTableKernel<64, 2048, CC_L2>), dim3(grid[t]), dim3(64), 0, st, ta);
+            else hipLaunchKernelGGL((cycleTableKernel<256, 8192, 0>), dim3(grid[t]), dim3(256), 0, st, ta);
+        }
+        uint32_t nFall = 0;
+        PH_COPY_SYNC(st, &nFall, dFall.p, 4, hipMemcpyDeviceToHost);
+        cnt[4] += nFall;
+    }
     if (cnt[4]) {
         // long contigs: scratch tables in HBM, in batches of at most ~2 GB
         const uint32_t nLong = cnt[4];
@@ -328,7 +400,7 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
     }
     if (stats) {
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-        stats->ms_kernel = ms; stats->n_cyclic = oc->n; stats->n_wave_small = cnt[0] + cnt[1]; stats->n_wave_large = cnt[2] + cnt[3]; stats->n_block = cnt[4];
+        stats->ms_kernel = ms; stats->n_cyclic = oc->n; stats->n_wave_small = cnt[0]; stats->n_wave_large = cnt[1] + cnt[2]; stats->n_block = cnt[3] + cnt[4];
     }
     *out_cycle = holdC.release();
     if (out_rest) *out_rest = orest;

@@ -326,6 +326,13 @@ def test_cyclecheck_vs_oracle(ctx, oracle_bin, tmp_path):
             u = rnd(int(rng.integers(5, 200))); seqs.append((u * (n // len(u) + 1))[:n])
         else:
             seqs.append(g[:n // 2] + "N" * int(rng.integers(1, 50)) + g[:n // 2])
+    # round 4: contigs that need several passes over the LDS table (a phase of a 130 kb contig holds 43 k k-mers, the table 4 k per
+    # pass), and two beyond 2^18 letters (position and k-mer no longer share a 64-bit entry: the HBM-table kernel)
+    g = rnd(130000); seqs.append(g + g[:40000])
+    seqs.append(rnd(150000))
+    g = rnd(90000); seqs.append(g[:45000] + "N" * 7 + g[:45000] + g[45000:])
+    g = rnd(200000); seqs.append(g + g[:75000])
+    seqs.append(rnd(270000))
     data, off, elen, key = synth.nucleotide_read_db(3000, seed=9)
     synth.write_db(str(tmp_path / "reads"), data, off, elen, key, 1)
     _, er = read_db(tmp_path / "reads")
@@ -334,11 +341,12 @@ def test_cyclecheck_vs_oracle(ctx, oracle_bin, tmp_path):
     db = ctx.read_seqdb(tmp_path / "seq")
     n_cyc = 0
     for chop in (0, 1):
-        run_oracle(oracle_bin, ["cyclecheck", tmp_path / "seq", tmp_path / f"o{chop}", "--max-seq-len", "200000", "--chop-cycle", chop])
-        cyc, st = ctx.cyclecheck(db, max_seq_len=200000, chop_cycle=bool(chop))
+        run_oracle(oracle_bin, ["cyclecheck", tmp_path / "seq", tmp_path / f"o{chop}", "--max-seq-len", "300000", "--chop-cycle", chop])
+        cyc, st = ctx.cyclecheck(db, max_seq_len=300000, chop_cycle=bool(chop))
         cyc.write(tmp_path / f"g{chop}")
         assert_same_db(tmp_path / f"o{chop}", tmp_path / f"g{chop}", f"cyclecheck vs oracle, chop {chop}")
         n_cyc = st.n_cyclic
+        assert st.n_block >= 7 and st.n_wave_large > 20
     assert n_cyc > 20
 
 
