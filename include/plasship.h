@@ -296,6 +296,7 @@ typedef struct plasship_cyclecheck_stats {
     uint64_t n_cyclic;
     uint64_t n_wave_small, n_wave_large, n_block;   /* sequences per kernel tier (<= 380 nt, <= 3068 nt, longer)       */
     float ms_kernel;
+    uint64_t n_known;      /* entries not looked at: unchanged since the last call's "rest" DB, all of whose entries are linear */
 } plasship_cyclecheck_stats;
 int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_cyclecheck_params *par, plasship_seqdb **out_cycle,
                         plasship_seqdb **out_rest, plasship_cyclecheck_stats *stats);

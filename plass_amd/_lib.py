@@ -69,7 +69,7 @@ class _CyclecheckParams(C.Structure):
 
 
 class CyclecheckStats(C.Structure):
-    _fields_ = [("n_cyclic", C.c_uint64), ("n_wave_small", C.c_uint64), ("n_wave_large", C.c_uint64), ("n_block", C.c_uint64), ("ms_kernel", C.c_float)]
+    _fields_ = [("n_cyclic", C.c_uint64), ("n_wave_small", C.c_uint64), ("n_wave_large", C.c_uint64), ("n_block", C.c_uint64), ("ms_kernel", C.c_float), ("n_known", C.c_uint64)]
 
 
 class _OrfParams(C.Structure):

@@ -1455,7 +1455,7 @@ __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t 
                 dst[L[u]] = '\n'; dst[L[u] + 1] = '\0';
                 const uint64_t j = keepPos[id];
                 outOffArr[j] = o[u]; outLen[j] = L[u]; outKey[j] = inKey[id];
-                if (changedOut) changedOut[j] = (flags[id] & 0x20u) ? 1 : 0;       // (only when nothing is dropped: j == id)
+                if (changedOut) changedOut[j] = (flags[id] & 0x20u) ? 1 : 0;
             }
         }
     }
@@ -1583,10 +1583,12 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
     if (o->d_off.allocLong((outN + 1) * 8) != hipSuccess || o->d_len.allocLong((outN + 1) * 4) != hipSuccess || o->d_key.allocLong((outN + 1) * 4) != hipSuccess) {
         setError("plasship_assemble: out of device memory for the output DB's index"); return PLASSHIP_ERR_DEVICE;
     }
-    // lineage for kmermatcher's selected-window cache: same ids as `db`, the extended / cut entries marked
-    if (outN == N && N && mode == 0) {
-        if (o->d_changed.allocLong((size_t) N) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        o->parentGen = db->gen;
+    // lineage: the extended / cut entries marked (one byte per NEW id); same ids as `db` if nothing was dropped (kmermatcher's
+    // selected-window cache needs that), else only "an unmarked entry is an entry of `db`" (cyclecheck's known-linear entries)
+    if (outN && mode == 0) {
+        if (o->d_changed.allocLong((size_t) outN) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        o->ancestorGen = db->gen;
+        if (outN == N) o->parentGen = db->gen;
     }
     // room in the shared heap?  (the reservation is atomic: two DBs derived from one parent get disjoint ranges; a reservation that
     // does not fit is simply left unused — the heap is about to be replaced anyway)

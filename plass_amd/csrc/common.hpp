@@ -145,6 +145,9 @@ struct plasship_ctx {
         plasship::DevBuf lines; uint64_t n = 0, gen = 0; bool valid = false;
         int k = 0, alph = 0, kps = 0, ignoreMulti = 0, hashShift = 0;
     } kmCache;
+    // cyclecheck.hip: generation of the last "rest" DB plasship_cyclecheck made on this context (every entry of it is known not to be
+    // circular at that --max-seq-len); a later call on a DB that descends from it checks only the entries rewritten since
+    uint64_t cycKnownGen = 0, cycKnownMaxLen = 0;
 };
 
 namespace plasship {
@@ -160,7 +163,9 @@ struct plasship_seqdb {
     // Lineage (kmermatch.hip, the selected-window cache): `gen` names this handle; a DB that buildOutputDB derived from another one
     // WITHOUT dropping entries (same ids, same keys) names it in `parentGen` and marks in d_changed (one byte per id) the entries whose
     // bytes differ from the parent's.  0 = no such parent (read from disk, generated, concatenated, entries dropped).
-    uint64_t gen = plasship::newDbGeneration(), parentGen = 0;
+    // `ancestorGen` is the weaker statement that survives dropped entries (nuclassembleresults removes the consumed targets): every
+    // entry with d_changed == 0 is byte for byte an entry of the DB with that generation, under whatever id (cyclecheck.hip).
+    uint64_t gen = plasship::newDbGeneration(), parentGen = 0, ancestorGen = 0;
     plasship::DevBuf d_changed;
     size_t n = 0;
     uint64_t dataBytes = 0, residues = 0;

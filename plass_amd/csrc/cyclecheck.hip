@@ -261,23 +261,38 @@ __global__ __launch_bounds__(256) void cycleBlockKernel(CycArgs a) {
 // --max-seq-len are not circular
 constexpr uint32_t CC_L0 = 380, CC_L1 = 1532, CC_L2 = 3068;
 constexpr int CC_TIERS = 5;
-__global__ void cycleTierKernel(SeqView s, uint64_t maxSeqLen, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts, uint32_t *__restrict__ split) {
-    for (uint32_t b0 = blockIdx.x * blockDim.x; b0 < s.n; b0 += gridDim.x * blockDim.x) {
-        const uint32_t id = b0 + threadIdx.x;
-        int tier = -1;
-        if (id < s.n) {
-            const uint32_t L = s.len[id];
-            split[id] = 0;
-            if (L >= (uint32_t) CC_K && (uint64_t) L < maxSeqLen) tier = L <= CC_L0 ? 0 : (L <= CC_L1 ? 1 : (L <= CC_L2 ? 2 : (L <= CC_PACK_MAXL ? 3 : 4)));
+// `known` (nullable): one byte per id, 0 = the entry is byte for byte an entry of a DB whose entries are all known not to be circular
+// (the "rest" DB of the last call, plasship_ctx::cycKnownGen) — it is not looked at again.  A workgroup classifies 2 048 ids per round
+// and reserves its part of every list with one atomic per tier (rounds 1-3: one per wavefront and tier, 10 ms at 35 M sequences).
+constexpr int CC_TIER_PER = 8;
+__global__ __launch_bounds__(256) void cycleTierKernel(SeqView s, uint64_t maxSeqLen, const unsigned char *__restrict__ known, uint32_t *__restrict__ lists, uint32_t *__restrict__ counts,
+                                                       uint32_t *__restrict__ split) {
+    __shared__ uint32_t sCnt[CC_TIERS + 1], sBase[CC_TIERS + 1];
+    for (uint64_t b0 = (uint64_t) blockIdx.x * (256 * CC_TIER_PER); b0 < s.n; b0 += (uint64_t) gridDim.x * (256 * CC_TIER_PER)) {
+        if (threadIdx.x <= CC_TIERS) sCnt[threadIdx.x] = 0;
+        __syncthreads();
+        int tier[CC_TIER_PER]; uint32_t rank[CC_TIER_PER];
+#pragma unroll
+        for (int j = 0; j < CC_TIER_PER; j++) {
+            const uint64_t id = b0 + (uint64_t) j * 256 + threadIdx.x;
+            tier[j] = -1; rank[j] = 0;
+            if (id < s.n) {
+                const uint32_t L = s.len[id];
+                split[id] = 0;
+                if (L >= (uint32_t) CC_K && (uint64_t) L < maxSeqLen) {
+                    if (known && known[id] == 0) tier[j] = CC_TIERS;                      // counted, not listed
+                    else tier[j] = L <= CC_L0 ? 0 : (L <= CC_L1 ? 1 : (L <= CC_L2 ? 2 : (L <= CC_PACK_MAXL ? 3 : 4)));
+                    rank[j] = atomicAdd(&sCnt[tier[j]], 1u);
+                }
+            }
         }
-        for (int t = 0; t < CC_TIERS; t++) {
-            const unsigned long long m = __ballot(tier == t);
-            if (!m) continue;
-            uint32_t base = 0;
-            if (laneId() == 0) base = atomicAdd(&counts[t], (uint32_t) __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (tier == t) lists[(size_t) t * s.n + base + (uint32_t) __popcll(m & ((1ULL << laneId()) - 1ULL))] = id;
-        }
+        __syncthreads();
+        if (threadIdx.x <= CC_TIERS) sBase[threadIdx.x] = sCnt[threadIdx.x] ? atomicAdd(&counts[threadIdx.x], sCnt[threadIdx.x]) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < CC_TIER_PER; j++)
+            if (tier[j] >= 0 && tier[j] < CC_TIERS) lists[(size_t) tier[j] * s.n + sBase[tier[j]] + rank[j]] = (uint32_t) (b0 + (uint64_t) j * 256 + threadIdx.x);
+        __syncthreads();
     }
 }
 
@@ -316,7 +331,11 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
     PH_CHECK(hipMemcpyAsync(dMap.p, aa2numTable(true, 5), 256, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dCounts.p, 0, 32, st));
     const unsigned gridN = std::min<uint32_t>((N + 255) / 256 + 1, (uint32_t) ctx->numCU * 16);
-    if (N) hipLaunchKernelGGL(cycleTierKernel, dim3(gridN), dim3(256), 0, st, sv, (uint64_t) par->max_seq_len, dLists.as<uint32_t>(), dCounts.as<uint32_t>(), dSplit.as<uint32_t>());
+    // entries the last call on this context has already found linear (they sit unchanged in a descendant of its "rest" DB) are skipped;
+    // PLASSHIP_TUNE_CYCSKIP=2 checks everything
+    const bool skipKnown = db->ancestorGen != 0 && db->ancestorGen == ctx->cycKnownGen && ctx->cycKnownMaxLen == (uint64_t) par->max_seq_len && db->d_changed.p && tuneInt("CYCSKIP", 1) == 1;
+    if (N) hipLaunchKernelGGL(cycleTierKernel, dim3(std::min<uint32_t>((N + 2047) / 2048, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, sv, (uint64_t) par->max_seq_len,
+                              skipKnown ? db->d_changed.as<unsigned char>() : (const unsigned char *) nullptr, dLists.as<uint32_t>(), dCounts.as<uint32_t>(), dSplit.as<uint32_t>());
     uint32_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     PH_COPY_SYNC(st, cnt, dCounts.p, 32, hipMemcpyDeviceToHost);
     CycArgs a; memset(&a, 0, sizeof(a));
@@ -397,10 +416,11 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
         if (N) hipLaunchKernelGGL(cycleFlagsKernel, dim3(gridN), dim3(256), 0, st, sv, dSplit.as<uint32_t>(), 0, 1, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>());
         rc = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), sv.data, 0, dTmp.p, tmpBytes, &orest);
         if (rc != PLASSHIP_OK) return rc;
+        ctx->cycKnownGen = orest->gen; ctx->cycKnownMaxLen = (uint64_t) par->max_seq_len;      // every entry of it has split == 0
     }
     if (stats) {
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]);
-        stats->ms_kernel = ms; stats->n_cyclic = oc->n; stats->n_wave_small = cnt[0]; stats->n_wave_large = cnt[1] + cnt[2]; stats->n_block = cnt[3] + cnt[4];
+        stats->ms_kernel = ms; stats->n_cyclic = oc->n; stats->n_wave_small = cnt[0]; stats->n_wave_large = cnt[1] + cnt[2]; stats->n_block = cnt[3] + cnt[4]; stats->n_known = cnt[5];
     }
     *out_cycle = holdC.release();
     if (out_rest) *out_rest = orest;

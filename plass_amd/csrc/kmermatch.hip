@@ -2738,7 +2738,12 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         } else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, ea);
         ExtractArgs e2 = ea; e2.waveList = dOvIds.as<uint32_t>(); e2.waveCount = dOvCnt.as<uint32_t>();
         e2.overflowIds = dOv2Ids.as<uint32_t>(); e2.overflowCount = dOv2Cnt.as<uint32_t>();
-        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 16u))), dim3(64), 0, st, e2);
+        // (round 4: a nucleotide sequence of this tier has at most 3 072 windows, i.e. 60 + 0.1 L <= 370 selected k-mers at the workflow's
+        //  scaling: 512 candidates instead of 1 024 halve its LDS and let eight instead of four wavefronts work per CU; a candidate set
+        //  that does not fit is queued for the next tier like any other overflow)
+        constexpr int CAP48 = NUCL ? 512 : 128;
+        if (NUCL && tuneInt("NUCL_CAP48", 1) == 1) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP48, false, 48, 992, NUCL ? 2 : 0>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * 8u)), dim3(64), 0, st, e2);
+        else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 16u))), dim3(64), 0, st, e2);
         PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));            // tier 2 has consumed the first queue: it becomes tier 3's output queue
         ExtractArgs e3 = ea; e3.waveList = dOv2Ids.as<uint32_t>(); e3.waveCount = dOv2Cnt.as<uint32_t>();
         e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>();
