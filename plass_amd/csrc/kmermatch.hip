@@ -819,6 +819,37 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[0], stRes); atomicAdd(&a.kstats[1], stRec); }
 }
 
+// Nucleotide DBs (and protein k > 16) have no thread-per-sequence kernel in front of the wave kernels; this one only sorts the ids into the
+// tiers' lists by window count (round 4: until then the 16-scores tier walked every sequence itself, reads of 130 windows included).
+__global__ __launch_bounds__(256) void classifyWindowsKernel(const uint32_t *__restrict__ len, uint32_t idLo, uint32_t idHi, uint32_t k, uint32_t longWindows, uint32_t hugeWindows,
+                                                             uint32_t *__restrict__ waveList, uint32_t *__restrict__ waveCount, uint32_t *__restrict__ longList, uint32_t *__restrict__ longCount,
+                                                             uint32_t *__restrict__ hugeList, uint32_t *__restrict__ hugeCount) {
+    __shared__ uint32_t sCnt[3], sBase[3];
+    constexpr int PER = 8;
+    for (uint64_t b0 = (uint64_t) idLo + (uint64_t) blockIdx.x * (256 * PER); b0 < idHi; b0 += (uint64_t) gridDim.x * (256 * PER)) {
+        if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
+        __syncthreads();
+        int cls[PER]; uint32_t rank[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint64_t id = b0 + (uint64_t) j * 256 + threadIdx.x;
+            cls[j] = -1; rank[j] = 0;
+            if (id < idHi) {
+                const uint32_t L = len[id], nw = L >= k ? L - k + 1 : 0u;
+                cls[j] = nw > hugeWindows ? 2 : (nw > longWindows ? 1 : 0);
+                rank[j] = atomicAdd(&sCnt[cls[j]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) sBase[threadIdx.x] = sCnt[threadIdx.x] ? atomicAdd(threadIdx.x == 0 ? waveCount : (threadIdx.x == 1 ? longCount : hugeCount), sCnt[threadIdx.x]) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; j++)
+            if (cls[j] >= 0) (cls[j] == 0 ? waveList : (cls[j] == 1 ? longList : hugeList))[sBase[cls[j]] + rank[j]] = (uint32_t) (b0 + (uint64_t) j * 256 + threadIdx.x);
+        __syncthreads();
+    }
+}
+
 // The same, restated for the instruction mix (round 3).  The PMC pass over the kernel above (profiles/r03_pmc) showed it bound by
 // SCALAR issue — 1.3 M scalar against 0.67 M vector instructions per wavefront: per residue a chain of divergent branches (first
 // window or not, word boundary, X, the four-way switch of the pending stores, the probe loop), each paid in exec-mask bookkeeping —
@@ -2710,6 +2741,12 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             ca.base = (uint32_t) ea.powers[1]; ca.base7 = (uint32_t) ea.powers[7]; ca.slotBias = slotBias; ca.seed = ea.seed; ca.kstats = dKStats.as<unsigned long long>();
             hipLaunchKernelGGL(extractCachedKernel, dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("CACHED", 32))), dim3(64), 0, st, ca);
         }
+    }
+    else if (nMine && tier0 && tuneInt("CLASSIFY", 1) == 1) {                   // PLASSHIP_TUNE_CLASSIFY=2: the 16-scores tier takes every id itself
+        hipLaunchKernelGGL(classifyWindowsKernel, dim3(std::min<uint32_t>((nMine + 2047) / 2048, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, (const uint32_t *) db->d_len.as<uint32_t>(), sLo, sHi, (uint32_t) k,
+                           TIER0_WINDOWS, 64u * 16u, dWaveList.as<uint32_t>(), dWaveCount.as<uint32_t>(), dLongList.as<uint32_t>(), dLongCount.as<uint32_t>(), dOvIds.as<uint32_t>(), dOvCnt.as<uint32_t>());
+        ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
+        twoLists = true;
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
