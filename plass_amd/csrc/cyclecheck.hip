@@ -76,6 +76,7 @@ struct CycTabArgs {
     uint32_t *split;
     uint32_t *hist; uint64_t histStride;          // per workgroup: 2 * (longest sequence of the tier / 3) + 2 bins
     uint32_t *fallList; uint32_t *fallCount;      // sequences whose table overflowed (never seen; the HBM kernel below takes them)
+    uint32_t forcePasses;                         // tests only (PLASSHIP_TUNE_CYC_PASSES): too few passes, so that long contigs DO overflow
 };
 template <int THREADS, int SLOTS, int STAGE>      // STAGE: longest sequence whose letter codes are staged in LDS (0: read from HBM)
 __global__ __launch_bounds__(THREADS) void cycleTableKernel(CycTabArgs a) {
@@ -97,7 +98,7 @@ __global__ __launch_bounds__(THREADS) void cycleTableKernel(CycTabArgs a) {
         // positions by class (kmerClass): front [1, third + 1], middle [third + 2, 2 third + 1], back [2 third + 2, nk - 1]; position 0 is
         // "back" too, but its diagonals are <= 0 and never counted
         const uint32_t fLo = 1, fHi = min(third + 1, nk - 1), mLo = third + 2, mHi = min(2 * third + 1, nk - 1), bLo = 2 * third + 2, bHi = nk - 1;
-        const uint32_t passes = (third + 2 + SLOTS / 2 - 1) / (SLOTS / 2);          // load <= 0.5 per pass on average
+        const uint32_t passes = a.forcePasses ? a.forcePasses : (third + 2 + SLOTS / 2 - 1) / (SLOTS / 2);          // load <= 0.5 per pass on average
         if (STAGE) for (uint32_t i = tid; i < L; i += THREADS) sNum[i] = sMap[(unsigned char) seq[i]];
         if (tid == 0) { sHits = 0; sFirst = 0xFFFFFFFFu; sOver = 0; }
         __syncthreads();
@@ -354,6 +355,7 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
         CycTabArgs ta; memset(&ta, 0, sizeof(ta));
         ta.s = sv; ta.map = dMap.as<unsigned char>(); ta.split = dSplit.as<uint32_t>();
         ta.fallList = dLists.as<uint32_t>() + 4 * (size_t) N + cnt[4]; ta.fallCount = dFall.as<uint32_t>();
+        ta.forcePasses = (uint32_t) tuneInt("CYC_PASSES", 0);
         for (int t = 0; t < 4; t++) {
             if (!cnt[t]) continue;
             ta.list = dLists.as<uint32_t>() + (size_t) t * N; ta.nList = cnt[t]; ta.hist = dHist.as<uint32_t>() + histOff[t]; ta.histStride = stride[t];

@@ -304,14 +304,11 @@ def test_golden_cyclecheck(ctx, golden, tmp_path):
         assert_same_db(f"{c}/{name}_cycle", tmp_path / name, f"cyclecheck {name}")
 
 
-def test_cyclecheck_vs_oracle(ctx, oracle_bin, tmp_path):
-    """reads + random circular / linear / repetitive contigs of all kernel tiers against the oracle"""
-    from plass_amd import synth
-    rng = np.random.default_rng(23)
+def _cyclecheck_cases(rng, n_random, long_ones):
     B = "ACGT"
     rnd = lambda n: "".join(B[i] for i in rng.integers(0, 4, n))
     seqs = []
-    for _ in range(120):
+    for _ in range(n_random):
         n = int(rng.integers(40, 60000) if rng.random() < 0.3 else rng.integers(40, 3000))
         g = rnd(n)
         kind = int(rng.integers(0, 5))
@@ -326,13 +323,21 @@ def test_cyclecheck_vs_oracle(ctx, oracle_bin, tmp_path):
             u = rnd(int(rng.integers(5, 200))); seqs.append((u * (n // len(u) + 1))[:n])
         else:
             seqs.append(g[:n // 2] + "N" * int(rng.integers(1, 50)) + g[:n // 2])
-    # round 4: contigs that need several passes over the LDS table (a phase of a 130 kb contig holds 43 k k-mers, the table 4 k per
-    # pass), and two beyond 2^18 letters (position and k-mer no longer share a 64-bit entry: the HBM-table kernel)
-    g = rnd(130000); seqs.append(g + g[:40000])
-    seqs.append(rnd(150000))
-    g = rnd(90000); seqs.append(g[:45000] + "N" * 7 + g[:45000] + g[45000:])
-    g = rnd(200000); seqs.append(g + g[:75000])
-    seqs.append(rnd(270000))
+    if long_ones:
+        # round 4: contigs that need several passes over the LDS table (a phase of a 130 kb contig holds 43 k k-mers, the table 4 k per
+        # pass), and two beyond 2^18 letters (position and k-mer no longer share a 64-bit entry: the HBM-table kernel)
+        g = rnd(130000); seqs.append(g + g[:40000])
+        seqs.append(rnd(150000))
+        g = rnd(90000); seqs.append(g[:45000] + "N" * 7 + g[:45000] + g[45000:])
+        g = rnd(200000); seqs.append(g + g[:75000])
+        seqs.append(rnd(270000))
+    return seqs
+
+
+def test_cyclecheck_vs_oracle(ctx, oracle_bin, tmp_path):
+    """reads + random circular / linear / repetitive contigs of all kernel tiers against the oracle"""
+    from plass_amd import synth
+    seqs = _cyclecheck_cases(np.random.default_rng(23), 120, True)
     data, off, elen, key = synth.nucleotide_read_db(3000, seed=9)
     synth.write_db(str(tmp_path / "reads"), data, off, elen, key, 1)
     _, er = read_db(tmp_path / "reads")
@@ -348,6 +353,22 @@ def test_cyclecheck_vs_oracle(ctx, oracle_bin, tmp_path):
         n_cyc = st.n_cyclic
         assert st.n_block >= 7 and st.n_wave_large > 20
     assert n_cyc > 20
+
+
+def test_cyclecheck_table_overflow_falls_back(ctx, oracle_bin, tmp_path, monkeypatch):
+    """a contig whose k-mers do not fit the LDS table of a pass is handed to the HBM-table kernel: forced here by allowing the workgroup
+    tier ONE pass whatever the length (PLASSHIP_TUNE_CYC_PASSES=1), so every contig beyond ~12 kb overflows; results as the oracle's"""
+    seqs = _cyclecheck_cases(np.random.default_rng(31), 60, True)
+    _write_fasta_like_db(tmp_path / "seq", seqs, dbtype=1)
+    db = ctx.read_seqdb(tmp_path / "seq")
+    run_oracle(oracle_bin, ["cyclecheck", tmp_path / "seq", tmp_path / "o", "--max-seq-len", "300000", "--chop-cycle", 1])
+    cyc, st0 = ctx.cyclecheck(db, max_seq_len=300000, chop_cycle=True)
+    monkeypatch.setenv("PLASSHIP_TUNE_CYC_PASSES", "1")
+    cyc, st = ctx.cyclecheck(db, max_seq_len=300000, chop_cycle=True)
+    monkeypatch.delenv("PLASSHIP_TUNE_CYC_PASSES")
+    cyc.write(tmp_path / "g")
+    assert_same_db(tmp_path / "o", tmp_path / "g", "cyclecheck with overflowing tables")
+    assert st.n_block > st0.n_block + 5 and st.n_cyclic == st0.n_cyclic          # the fall-backs are counted with the last tier
 
 
 def test_golden_findassemblystart(ctx, golden, tmp_path):
