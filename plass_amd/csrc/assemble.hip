@@ -1874,6 +1874,8 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         PH_CHECK(hipEventRecord(ctx->ev[3], st));
         for (int e = 4; e <= 7; e++) PH_CHECK(hipEventRecord(ctx->ev[e], st));
     } else {
+    // (round 4: the protein tiers' lists in work classes like the nucleotide list changed nothing — 82.2 against 81.0 ms for the stage: the
+    //  tiers already group the queries by queue size, and id order keeps a wavefront's alignment records adjacent; profiles/r04_ab_knobs.txt)
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     // wavefronts per SIMD of the register-queue kernels (PLASSHIP_TUNE_ASM16 / ASM64): the grid is what the CUs hold at once
     const int w16 = tuneInt("ASM16", 5), w64 = tuneInt("ASM64", 4);      // round 3 (after the copy tails went word-wise): 16.6 ms at 5 wavefronts, 17.0 at 6, 18.0 at 4
