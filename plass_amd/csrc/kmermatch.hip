@@ -906,7 +906,16 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         if (pwH * 2 >= (1ull << 32)) fast = false;
         sa.topLo = (uint32_t) (pwH / sa.base); sa.topHi = (uint32_t) ea.powers[KF - HF - 1]; sa.baseH = (uint32_t) pwH;
         const dim3 shortGrid(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", nMine > 20000000u ? 72 : 18)));
-        if (fast && sa.base < (1u << 8) && sa.topLo < (1u << 24) && sa.topHi < (1u << 24)) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, true>), shortGrid, dim3(64), 0, st, sa);
+        // Resident wavefronts (round 4): every working lane has one partly written 128-byte line of records open; at the 18 wavefronts per CU
+        // the kernel's own LDS allows, those are 4.7 MB per XCD against 4 MB of L2 — lines leave the L2 half written and the kernel moves
+        // 71 GB for 35 GB of records (profiles/r03_pmc_hbm_traffic.txt).  Unused dynamic LDS caps the residency: 8 KB more per wavefront
+        // (10 per CU) took 34.6 -> 29.9 ms off iteration 0 and 28.4 -> 24.2 off iteration 1; with 16 KB (6 per CU) iteration 0, where
+        // every lane works, fell to 26.4 ms but the later iterations, where most lanes only queue their sequence, rose by 4-6 ms
+        // (profiles/r04_ab_knobs.txt, call 18).  PLASSHIP_TUNE_SHORT_PAD_KB overrides (1 = none).
+        const bool allWork = (int64_t) db->maxEntryLen - 2 - k + 1 <= (int64_t) par->kmers_per_seq - 1;      // no sequence long enough to be queued for the wave kernels
+        const int padKb = tuneInt("SHORT_PAD_KB", allWork ? 16 : 8);
+        const size_t padLds = padKb > 1 ? (size_t) padKb << 10 : 0;
+        if (fast && sa.base < (1u << 8) && sa.topLo < (1u << 24) && sa.topHi < (1u << 24)) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, true>), shortGrid, dim3(64), padLds, st, sa);
         else if (fast) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, false>), shortGrid, dim3(64), 0, st, sa);
         else hipLaunchKernelGGL((extractShortKernel<LONG>), shortGrid, dim3(64), 0, st, sa);   // 18 wavefronts fit a CU; on large sets twice that evens out the tail (50 M reads: 35.7 -> 34.4 ms)
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
