@@ -884,14 +884,21 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
             uint32_t lo = 0, hi = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, nOut = 0;
             uint64_t seqHash = 0;
             int lastX = -1;
-            uint32_t wordNext = 0;
-            if (Lw) __builtin_memcpy(&wordNext, base, 4);                                   // the buffer is padded past its end
-            for (uint32_t i = 0; i < Lmax; i += 4) {
-                // the four residues of the NEXT step are requested before this step's are used: the load is the head of the step's
-                // chain of dependent round trips (residues -> letter codes in LDS -> tag set in LDS -> store)
-                const uint32_t word = wordNext;
-                wordNext = 0;
-                if (i + 4 < Lw) __builtin_memcpy(&wordNext, base + i + 4, 4);
+            // sixteen residues per load (round 4: four per load fetched every 128-byte line of residues four to five times — the lanes of
+            // the resident wavefronts keep more lines open than the L1 and L2 hold — 23 GB read for 4 GB of residues); the NEXT sixteen
+            // are requested before this round's are used: the load is the head of a chain of dependent round trips (residues -> letter
+            // codes in LDS -> tag set in LDS -> store)
+            uint4 bufNext = make_uint4(0, 0, 0, 0);
+            if (Lw) __builtin_memcpy(&bufNext, base, 16);                                   // the buffer is padded past its end
+            for (uint32_t i0 = 0; i0 < Lmax; i0 += 16) {
+                const uint4 buf = bufNext;
+                bufNext = make_uint4(0, 0, 0, 0);
+                if (i0 + 16 < Lw) __builtin_memcpy(&bufNext, base + i0 + 16, 16);
+#pragma unroll
+              for (int step = 0; step < 4; step++) {
+                const uint32_t i = i0 + 4u * (uint32_t) step;
+                if (i >= Lmax) break;                                                        // wave-uniform
+                const uint32_t word = step == 0 ? buf.x : (step == 1 ? buf.y : (step == 2 ? buf.z : buf.w));
                 const uint32_t cw = (uint32_t) sMap[word & 0xFFu] | ((uint32_t) sMap[(word >> 8) & 0xFFu] << 8) |
                                     ((uint32_t) sMap[(word >> 16) & 0xFFu] << 16) | ((uint32_t) sMap[word >> 24] << 24);
                 const uint32_t f[4] = {f0, f1, f2, f3};
@@ -933,6 +940,7 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
                     }
                 }
                 f0 = f1; f1 = f2; f2 = f3; f3 = cw;
+              }
             }
             if (work && !toWave) {
                 R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
