@@ -26,6 +26,7 @@
 #include "device_utils.hpp"
 #include "host_util.hpp"
 #include "linepart.hpp"
+#include "xxh64_u64.hpp"
 #include <algorithm>
 #include <memory>
 #include <type_traits>

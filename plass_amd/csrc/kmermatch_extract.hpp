@@ -4,18 +4,7 @@
 // Kernels: boundsKernel, extractKernel (the wave-per-sequence tiers), extractShortKernel / extractShortFastKernel (thread per sequence), classifyWindowsKernel, extractCachedKernel (selected-window cache).
 #pragma once
 
-// ---- XXH64 of one little-endian u64 (xxhash 0.8.0, call site kmermatcher.cpp:33-38) ---------------------
-__host__ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
-__host__ __device__ __forceinline__ uint64_t xxh64U64(uint64_t v, uint64_t seed) {
-    const uint64_t P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL,
-                   P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
-    uint64_t h = seed + P5 + 8;
-    uint64_t k1 = rotl64(v * P2, 31) * P1;
-    h ^= k1;
-    h = rotl64(h, 27) * P1 + P4;
-    h ^= h >> 33; h *= P2; h ^= h >> 29; h *= P3; h ^= h >> 32;
-    return h;
-}
+// (XXH64 of one u64 and the windows' 16-bit score: xxh64_u64.hpp, included by kmermatch.hip)
 // 2-bit alphabet A0 C1 T2 G3, complement = code ^ 2 (Util.cpp:601-638)
 __device__ __forceinline__ uint64_t revComplementDev(uint64_t kmer, int k) {
     uint64_t x = kmer ^ 0xAAAAAAAAAAAAAAAAULL;                         // complement every 2-bit letter
@@ -356,7 +345,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                     if (p < nWin) {
                         uint64_t kmer; uint32_t pos;
                         if (phaseSplit & 32) sc[j] = p;
-                        else if (windowKmer(p, kmer, pos)) sc[j] = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
+                        else if (windowKmer(p, kmer, pos)) sc[j] = xxh64Score16(NUCL ? (kmer & ~BIT63) : kmer, a.seed);
                     }
                     n += (uint32_t) __popcll(__ballot(sc[j] != 0xFFFFFFFFu));
                 }
@@ -453,7 +442,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                         else if (resident) valid = kmerFromCodes<NUCL>([&](int i) { return sCodeAll[p + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                         else valid = kmerFromCodes<NUCL>([&](int i) { return sCode[lane + i]; }, k, (unsigned char) a.xCode, a.powers, L, p, kmer, pos);
                     }
-                    if (valid) score = (uint32_t) (xxh64U64(NUCL ? (kmer & ~BIT63) : kmer, a.seed) & 0xFFFFu);
+                    if (valid) score = xxh64Score16(NUCL ? (kmer & ~BIT63) : kmer, a.seed);
                     if (useCache) {
                         if (p < RES_L) sScore[p] = (unsigned short) score;
                         const unsigned long long vm = __ballot(valid);

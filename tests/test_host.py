@@ -201,3 +201,30 @@ def test_committed_headline_digests_are_complete():
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_chain_digests.json")))
     digs = g.get("seq_digests") or g.get("digests")
     assert digs and len(digs) == 12 and len(set(digs)) == 12 and all(len(d) == 16 for d in digs)
+
+
+def test_window_score_is_the_low_16_bits_of_xxh64(tmp_path):
+    """plass_amd/csrc/xxh64_u64.hpp: the extraction kernels take a window's 16-bit score from xxh64Score16, which skips the parts of the
+    last 64-bit multiplication the low 16 bits do not depend on — compiled here with g++ against xxh64U64, the oracle's restatement of
+    XXH64 and the reference's known answers (oracle.kat_xxh64)"""
+    import subprocess, ctypes
+    src = tmp_path / "t.cpp"
+    src.write_text('#include "xxh64_u64.hpp"\n#include <cstdio>\n#include <random>\n'
+                   'extern "C" unsigned long long full(unsigned long long v, unsigned long long s) { return plasship::xxh64U64(v, s); }\n'
+                   'extern "C" unsigned score(unsigned long long v, unsigned long long s) { return plasship::xxh64Score16(v, s); }\n'
+                   'extern "C" long sweep(long n) { std::mt19937_64 g(7); long bad = 0; for (long i = 0; i < n; i++) { unsigned long long v = g(), s = (i & 3) ? (g() & 0xFF) : g();'
+                   ' if (i % 5 == 0) v &= 0xFFFFFFFFFFFFFULL; bad += plasship::xxh64Score16(v, s) != (unsigned) (plasship::xxh64U64(v, s) & 0xFFFF); } return bad; }\n')
+    so = tmp_path / "t.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "plass_amd", "csrc"), str(src), "-o", str(so)])
+    lib = ctypes.CDLL(str(so))
+    lib.full.restype = ctypes.c_ulonglong; lib.full.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong]
+    lib.score.restype = ctypes.c_uint; lib.score.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong]
+    lib.sweep.restype = ctypes.c_long; lib.sweep.argtypes = [ctypes.c_long]
+    assert lib.sweep(20000000) == 0
+    import __graft_entry__ as g
+    g.oracle_bin()                                          # builds oracle/build/ if it is missing
+    ora = ctypes.CDLL(os.path.join(ROOT, "oracle", "build", "liboracle.so"))
+    ora.oracle_xxh64_u64.restype = ctypes.c_ulonglong; ora.oracle_xxh64_u64.argtypes = [ctypes.c_ulonglong, ctypes.c_ulonglong]
+    for v, s in ((0, 0), (1, 67), (0xFFFFFFFFFFFFFFFF, 68), (3899999999999999, 70), (123456789012345, 2 ** 63 + 5)):
+        assert lib.full(v, s) == ora.oracle_xxh64_u64(v, s) and lib.score(v, s) == (ora.oracle_xxh64_u64(v, s) & 0xFFFF)
+    assert lib.full(12345, 67) == 11599637584503786452      # SURVEY.md Appendix B
