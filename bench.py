@@ -138,8 +138,9 @@ def stage_table(kst, rst, ast, nucl_queue=False):
     t["kmermatcher_stage"] = (kst.ms_extract + kst.ms_sort1 + kst.ms_group + kst.ms_sort2 + kst.ms_reduce,
                               kst.residues + 4 * s * Nk + 4 * s * Nm + 12 * Nc, False, 1)
     if nucl_queue:
-        # nuclassembleresults / guidedassembleresults: the heap-replay queue kernels (one thread per query up to 256 hits, one wavefront
-        # per query beyond, re-runs of the queries that met an unknown comparator tuple) are timed as ONE interval (assemble.hip)
+        # nuclassembleresults / guidedassembleresults: the heap-replay queue kernels (one lane per queue up to 256 hits — copies and
+        # re-scored overlaps by the whole wavefront —, one wavefront per query beyond, re-runs of the queries that met an unknown
+        # comparator tuple) are timed as ONE interval (assemble.hip)
         t["assembleNuclKernel(+assembleNuclThreadKernel, all passes)"] = (ast.ms_tier_kernel[0], 32 * ast.tier_alignments[0] + 2 * ast.tier_query_residues[0] + 2 * ast.tier_rescored_residues[0], True, 1)
     else:
         for i, (name, single) in enumerate((("assembleGroupKernel<16>", True), ("assembleGroupKernel<32>+<64>", False), ("assembleBigKernel", True))):

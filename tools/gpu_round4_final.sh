@@ -32,6 +32,10 @@ cd $R
 python tools/rocpd_traffic.py $O/pmc5_FETCH_SIZE/pmc_results.db $O/pmc5_WRITE_SIZE/pmc_results.db 30 profiles/r04_pmc_traffic_c5.json 20 "python bench.py --config c5 --steps 10 --warmup 0 --no-cpu-baseline" > $O/pmc_hbm_traffic_c5.txt 2>&1
 cp profiles/r04_pmc_traffic_c5.json $O/pmc_traffic_c5.json
 timeout 900 python bench.py --config c5 > $O/bench_c5.log 2> $O/bench_c5.err; tail -c 300 $O/bench_c5.log; echo
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace -d $R/$O/prof5 -o c5 -- python $R/bench.py --config c5 --steps 10 --warmup 0 --no-cpu-baseline --no-verify > $R/$O/bench_c5_rocprof.log 2> $R/$O/bench_c5_rocprof.err
+cd $R
+python tools/rocpd_summary.py $O/prof5/c5_results.db > $O/kernel_stats_c5.txt 2>&1
 timeout 300 python bench.py --config c2 --no-wall > $O/bench_c2.log 2>/dev/null
 # sharded orchestration in a 1-rank native-RCCL group against the single-GPU path, 12.5 M reads
 timeout 400 python bench.py --pairs 6250000 --steps 12 --warmup 0 --no-cpu-baseline --no-wall --no-verify > $O/bench_12M_single.log 2>/dev/null
