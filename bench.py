@@ -465,6 +465,13 @@ def main():
         if gold and gold.get("pairs") == wl["read_pairs"] and mode != "partitions":
             verify["reference"] = "tests/golden/%s_chain_digests.json" % args.config
             verify["match"] = digests == gold["digests"][:len(digests)]
+    # ---- CPU baseline + the drop-in command line on the same sample.  BEFORE the wall-clock leg below: that leg's child process takes and
+    # returns 270 GB of HBM, and for seconds afterwards every process that allocates device memory waits for the driver to scrub it — the
+    # nine short `plass-hip` invocations of this leg then measure that (round 4's first evidence run: 4.8 s instead of 1.3 s;
+    # tools/cli_dropin_probe.py, profiles/r04_calls/call21_cli_dropin_probe.log) ----
+    cpu_line = None
+    if rank == 0 and world == 1 and comm is None and native is None and not args.no_cpu_baseline:
+        cpu_line = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, min(chain, 3))
     # ---- wall clock to final contigs (the metric's second half): the fragment DB goes to disk, then the fused C++ driver
     # (`plass-hip assemble-chain`: the loop of data/assemble.sh:85-156 incl. findassemblystart, DBs chained in HBM) runs as its own
     # process from DB files on disk to the final assembly DB on disk.  This process gives its HBM back first.
@@ -504,10 +511,7 @@ def main():
     if rank == 0:
         line["verify"] = verify
         line["wall_to_contigs"] = wall
-        if world == 1 and comm is None and native is None and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, min(chain, 3))
-        else:
-            line["cpu_baseline"] = None
+        line["cpu_baseline"] = cpu_line
     if native is not None:
         native.destroy()
     if dist is not None:
