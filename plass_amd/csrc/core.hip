@@ -3,6 +3,7 @@
 //   (mm/commons/DBReader.cpp:150-215,548-589; DBReader.h:185-213) and DBWriter for sequence DBs.
 #include "common.hpp"
 #include "host_util.hpp"
+#include "device_utils.hpp"
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -360,6 +361,30 @@ int stagedCopyToHost(plasship_ctx *ctx, void *hDst, const void *dSrc, uint64_t b
 using namespace plasship;
 
 // ---- sequence DB ---------------------------------------------------------------------------------
+// Bytes the kernels can take: the scoring kernels index their substitution tables with the residue BYTES ((a << 7) | b over
+// 123 rows) and blank columns with byte 0, so an entry must consist of bytes 1..122 and end in "\n\0" — what every DB the reference
+// writes looks like (letters, '*', the terminators).  One pass over the uploaded data: bytes above 122, NUL bytes, entries without the
+// final NUL.  counts[0] = bytes > 122, counts[1] = NUL bytes (must be one per entry), counts[2] = entries whose last byte is not NUL.
+namespace plasship {
+__global__ __launch_bounds__(256) void validateBytesKernel(const uint4 *__restrict__ data, uint64_t nWords, const uint64_t *__restrict__ off, uint64_t n, unsigned long long *__restrict__ counts) {
+    unsigned long long hi = 0, zero = 0, bad = 0;
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < nWords; i += (uint64_t) gridDim.x * 256) {
+        const uint4 w = data[i];
+        const uint32_t v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = v[j];
+            hi += (unsigned) __popc((((x & 0x7F7F7F7Fu) + 0x05050505u) | x) & 0x80808080u);          // a byte >= 123 (0x7B): +5 carries into bit 7, or bit 7 is set
+            zero += (unsigned) __popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu));        // exact zero-byte test
+        }
+    }
+    const char *bytes = reinterpret_cast<const char *>(data);
+    for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t) gridDim.x * 256) bad += bytes[off[i + 1] - 1] != 0;
+    hi = waveReduceSumU64(hi); zero = waveReduceSumU64(zero); bad = waveReduceSumU64(bad);
+    if ((threadIdx.x & 63) == 0) { if (hi) atomicAdd(&counts[0], hi); if (zero) atomicAdd(&counts[1], zero); if (bad) atomicAdd(&counts[2], bad); }
+}
+}  // namespace plasship
+
 extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t data_bytes, const uint64_t *off,
                                      const uint32_t *elen, const uint32_t *key, size_t n, int dbtype,
                                      plasship_seqdb **out) {
@@ -464,7 +489,24 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         int rc = stagedCopyToDevice(ctx, db->d_len.p, hlen.data(), n * 4); if (rc) return rc;
         rc = stagedCopyToDevice(ctx, db->d_key.p, db->h_key.data(), n * 4); if (rc) return rc;
     }
+    // the bytes: 1..122 inside the entries, one NUL per entry, at its end (the 64 bytes of padding behind the data are NUL: subtracted)
+    unsigned long long bc[3] = {0, 0, 0};
+    if (n) {
+        DevBuf dBC;
+        if (dBC.alloc(24) != hipSuccess) { setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+        PH_CHECK(hipMemsetAsync(dBC.p, 0, 24, ctx->stream));
+        const uint64_t nWords = (total + 15) / 16;                  // the last word may reach into the padding
+        hipLaunchKernelGGL(validateBytesKernel, dim3((unsigned) std::min<uint64_t>((nWords + 255) / 256, (uint64_t) ctx->numCU * 16)), dim3(256), 0, ctx->stream,
+                           (const uint4 *) db->d_data.p, nWords, (const uint64_t *) db->d_off.as<uint64_t>(), (uint64_t) n, dBC.as<unsigned long long>());
+        PH_CHECK(hipMemcpyAsync(bc, dBC.p, 24, hipMemcpyDeviceToHost, ctx->stream));
+    }
     PH_CHECK(plasship::streamSync(ctx->stream));
+    const unsigned long long padZeros = (16 - total % 16) % 16;
+    if (bc[0]) { setError("plasship_seqdb_upload: " + std::to_string(bc[0]) + " byte(s) above 'z' (122) in the sequence data: not a sequence DB the kernels' score tables can index"); return PLASSHIP_ERR_ARG; }
+    if (bc[2] || bc[1] != (unsigned long long) n + padZeros) {
+        setError("plasship_seqdb_upload: every entry must end in \"\\n\\0\" and hold no other NUL byte (" + std::to_string(bc[2]) + " entries without the final NUL, " +
+                 std::to_string((long long) bc[1] - (long long) padZeros) + " NUL bytes in " + std::to_string(n) + " entries)"); return PLASSHIP_ERR_ARG;
+    }
     *out = holder.release();
     return PLASSHIP_OK;
 }

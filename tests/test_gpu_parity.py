@@ -561,6 +561,26 @@ def _write_fasta_like_db(path, seqs, dbtype=0, keys=None):
     return data, off, elen, key
 
 
+def test_upload_refuses_bytes_the_score_tables_cannot_index(ctx, tmp_path):
+    """the scoring kernels index their tables with the residue bytes and blank columns with byte 0 — a DB with a byte above
+    'z' or a NUL inside an entry is refused at upload (the reference maps every byte through aa2num; such a DB is not one it writes)"""
+    import plass_amd
+    from plass_amd import synth
+    good = ["MKVLAAGIVGLLLAQWERTYHGFDSAPMKVLAAGI", "ACDEFGHIKLMNPQRSTVWYacdefxz*", "MK"]
+    data, off, elen, key = _write_fasta_like_db(tmp_path / "ok", good)
+    db = ctx.read_seqdb(tmp_path / "ok"); assert db.info()["n"] == 3; db.free()
+    for name, pos, byte, what in (("high", 5, 0xC3, "above 'z'"), ("brace", 40, 123, "above 'z'"), ("nul", 7, 0, "NUL")):
+        d = np.frombuffer(bytes(data), dtype=np.uint8).copy(); d[pos] = byte
+        synth.write_db(str(tmp_path / name), d, off, elen, key, 0)
+        with pytest.raises(plass_amd.PlasshipError) as ei:
+            ctx.read_seqdb(tmp_path / name)
+        assert what in str(ei.value)
+    d = np.frombuffer(bytes(data), dtype=np.uint8).copy(); d[int(off[0] + elen[0] - 1)] = ord("A")          # first entry without its final NUL
+    synth.write_db(str(tmp_path / "noterm"), d, off, elen, key, 0)
+    with pytest.raises(plass_amd.PlasshipError):
+        ctx.read_seqdb(tmp_path / "noterm")
+
+
 def test_adversarial_inputs_vs_oracle(ctx, oracle_bin, tmp_path):
     """ragged and hostile inputs: sequences shorter than k, X / '*' residues, low-complexity repeats (repeated
     k-mers, many ties in the hash threshold bin), exact duplicates, one contig above 32 767 residues (switches the
