@@ -22,6 +22,7 @@
 // replays libstdc++'s heap operations (assembleNuclKernel).
 #include "common.hpp"
 #include "device_utils.hpp"
+#include "posterior_class.hpp"
 #include "host_util.hpp"
 #include <algorithm>
 #include <memory>
@@ -407,38 +408,15 @@ __device__ __forceinline__ uint32_t ambHash(uint32_t a1, uint32_t b1, uint32_t a
 // posterior class of one (alpha, beta) tuple the memo does not hold yet: 0 (p < 0.45), 1 (p > 0.55), 2 (between), or -1 when the
 // decision sits on a threshold and the host table lacks the tuple (the query is then re-run).  Kept out of line: it is rare
 // (the memo absorbs it) and its double-precision lgamma / exp / log would otherwise dictate the register budget of the callers.
-// lgamma of a positive integer: log((n - 1)!) from the exact product below 16, Stirling's series above (truncation < 2e-14)
-__device__ __forceinline__ double lgammaInt(unsigned n) {
-    if (n < 16) { double f = 1.0; for (unsigned i = 2; i < n; i++) f *= (double) i; return log(f); }
-    const double x = (double) n, r = 1.0 / x, r2 = r * r;
-    return (x - 0.5) * log(x) - x + 0.91893853320467274178 +
-           r * (1.0 / 12.0 - r2 * (1.0 / 360.0 - r2 * (1.0 / 1260.0 - r2 * (1.0 / 1680.0 - r2 * (1.0 / 1188.0)))));
-}
-// Round 4: the reference evaluates p = sum_{i < alpha2} exp(log_r_i + log_c) with four lgamma and, per term, one exp and five log in
-// double (nuclassembleresult.cpp:36-58).  Only the CLASS of p is used, and a p within AMB_EPS of a threshold is decided by the host's
-// libm anyway (below), so the device may take any route that is accurate to well below AMB_EPS: the terms are t_0 = exp(log_c),
-// t_{i+1} = t_i (alpha1 + i)(beta2 + i) / ((i + 1)(i + alpha1 + beta1 + beta2)) — one division per term instead of six
-// transcendentals (rescaled when they grow: the sequence rises, then falls) — and the arguments of lgamma are integers.  The contigs
-// of the late nucleotide iterations of configs[4] overlap in thousands of columns with dozens of mismatches: such tuples miss the
-// memo (CMP_LEN, CMP_MM), and the heap of a query with 200 hits asks for thousands of them — 707 -> see profiles/r04_ab_knobs.txt.
+// (the value of p and the width of the band around the thresholds: posterior_class.hpp, plain C++ as well — tests/test_host.py compares it
+// with the reference's formula under glibc on the host)
 __device__ __attribute__((noinline)) int nuclPosteriorClassDev(unsigned alpha1, unsigned beta1, unsigned alpha2, unsigned beta2, const AsmArgs *ap) {
-    const double log_c = (lgammaInt(beta1 + beta2) + lgammaInt(alpha1 + beta1)) - (lgammaInt(alpha1 + beta1 + beta2) + lgammaInt(beta1));
-    double t = 1.0, sum = 0.0, logScale = 0.0;
-    const double S = (double) alpha1 + (double) beta1 + (double) beta2;
-    for (unsigned idx = 0; idx < alpha2; idx++) {
-        sum += t;
-        const double i = (double) idx;
-        t *= (((double) alpha1 + i) * ((double) beta2 + i)) / ((i + 1.0) * (i + S));
-        if (t > 1e200) { t *= 1e-200; sum *= 1e-200; logScale += 460.51701859880913680; }      // 200 ln 10
-    }
-    const double p = sum > 0.0 ? exp(log_c + logScale + log(sum)) : 0.0;
+    const double p = nuclPosteriorP(alpha1, beta1, alpha2, beta2);
     int cls = (p < 0.45) ? 0 : ((p > 0.55) ? 1 : 2);
     // The reference's decision is glibc's rounding of p whenever p sits on a threshold (zero mismatches on both sides and
     // overlap lengths 9 : 11 give exactly 0.45).  Device and host libm agree to ~1e-15; inside a 1e-9 band the class is
     // taken from the host-evaluated table instead.
-    // (log_c is a difference of numbers of the size of the overlap lengths times their logarithm: its rounding error, here and in
-    // the host's lgamma, grows with them — the band does too)
-    const double AMB_EPS = 1e-9 + 1e-13 * (S + (double) alpha2);
+    const double AMB_EPS = nuclPosteriorBand(alpha1, beta1, alpha2, beta2);
     if (fabs(p - 0.45) < AMB_EPS || fabs(p - 0.55) < AMB_EPS) {
         const AsmArgs &a = *ap;
         if (a.ambMask) {

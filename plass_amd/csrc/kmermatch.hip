@@ -906,7 +906,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         uint64_t pwH = 1; for (int i = 0; i < HF; i++) pwH *= sa.base;
         if (pwH * 2 >= (1ull << 32)) fast = false;
         sa.topLo = (uint32_t) (pwH / sa.base); sa.topHi = (uint32_t) ea.powers[KF - HF - 1]; sa.baseH = (uint32_t) pwH;
-        const dim3 shortGrid(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", nMine > 20000000u ? 72 : 18)));
+        const dim3 shortGrid(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", nMine > 20000000u ? 144 : 18)));
         // Resident wavefronts (round 4): every working lane has one partly written 128-byte line of records open; at the 18 wavefronts per CU
         // the kernel's own LDS allows, those are 4.7 MB per XCD against 4 MB of L2 — lines leave the L2 half written and the kernel moves
         // 71 GB for 35 GB of records (profiles/r03_pmc_hbm_traffic.txt).  Unused dynamic LDS caps the residency: 8 KB more per wavefront
@@ -918,7 +918,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         const size_t padLds = padKb > 1 ? (size_t) padKb << 10 : 0;
         if (fast && sa.base < (1u << 8) && sa.topLo < (1u << 24) && sa.topHi < (1u << 24)) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, true>), shortGrid, dim3(64), padLds, st, sa);
         else if (fast) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, false>), shortGrid, dim3(64), 0, st, sa);
-        else hipLaunchKernelGGL((extractShortKernel<LONG>), shortGrid, dim3(64), 0, st, sa);   // 18 wavefronts fit a CU; on large sets twice that evens out the tail (50 M reads: 35.7 -> 34.4 ms)
+        else hipLaunchKernelGGL((extractShortKernel<LONG>), shortGrid, dim3(64), 0, st, sa);   // 18 wavefronts fit a CU; on large sets a finer grid evens out the tail (50 M reads, round 3: 35.7 -> 34.4 ms at 72 per CU; round 4, after the residency cap: another 0.3-1.1 ms per iteration at 144, nothing more at 288 / 576)
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
         if (cacheReuse) {
             CachedArgs ca; memset(&ca, 0, sizeof(ca));

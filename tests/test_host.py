@@ -228,3 +228,52 @@ def test_window_score_is_the_low_16_bits_of_xxh64(tmp_path):
     for v, s in ((0, 0), (1, 67), (0xFFFFFFFFFFFFFFFF, 68), (3899999999999999, 70), (123456789012345, 2 ** 63 + 5)):
         assert lib.full(v, s) == ora.oracle_xxh64_u64(v, s) and lib.score(v, s) == (ora.oracle_xxh64_u64(v, s) & 0xFFFF)
     assert lib.full(12345, 67) == 11599637584503786452
+
+
+def test_posterior_class_route_agrees_with_the_reference_formula(tmp_path):
+    """plass_amd/csrc/posterior_class.hpp: the nucleotide comparator's posterior p from term ratios and an integer lgamma (what the kernels
+    evaluate) against the reference's formula — four lgamma, exp and log per term (src/assembler/nuclassembleresult.cpp:36-58, restated
+    below) — under the host's libm, on overlap tuples from reads (30 columns) to contigs (260 000 columns): the difference must stay
+    well inside the band within which the kernels leave the decision to the host-evaluated table, so outside the band both give one class."""
+    import subprocess, ctypes
+    src = tmp_path / "p.cpp"
+    src.write_text(r'''
+#include "posterior_class.hpp"
+#include <cstdio>
+#include <random>
+#include <algorithm>
+static double pRef(unsigned alpha1, unsigned beta1, unsigned alpha2, unsigned beta2) {
+    const double log_c = (lgamma((double) (beta1 + beta2)) + lgamma((double) (alpha1 + beta1))) - (lgamma((double) (alpha1 + beta1 + beta2)) + lgamma((double) beta1));
+    double log_r = 0.0, p = 0.0;
+    for (size_t idx = 0; idx < alpha2; idx++) {
+        p += exp(log_r + log_c);
+        log_r = log((double) (alpha1 + idx)) + log((double) (beta2 + idx)) - (log((double) (idx + 1)) + log((double) (idx + alpha1 + beta1 + beta2))) + log_r;
+    }
+    return p;
+}
+extern "C" double sweep(long n, long *classDiff) {
+    std::mt19937_64 g(5);
+    double worst = 0; *classDiff = 0;
+    for (long it = 0; it < n; it++) {
+        const unsigned maxL = (it % 4 == 0) ? 260000 : ((it % 4 == 1) ? 20000 : ((it % 4 == 2) ? 600 : 40));
+        const unsigned l1 = 1 + g() % maxL, l2 = (g() % 3 == 0) ? 1 + g() % maxL : (unsigned) std::max<long>(1, (long) l1 + (long) (g() % 41) - 20);
+        const double e1 = (g() % 1000) / 1000.0 * 0.1, e2 = (g() % 3) ? e1 * (0.5 + (g() % 1000) / 1000.0) : (g() % 1000) / 1000.0 * 0.1;
+        const unsigned m1 = std::min<unsigned>(l1, (unsigned) (l1 * e1)), m2 = std::min<unsigned>(l2, (unsigned) (l2 * e2));
+        const unsigned a1 = m1 + 1, b1 = l1 - m1 + 1, a2 = m2 + 1, b2 = l2 - m2 + 1;
+        const double a = plasship::nuclPosteriorP(a1, b1, a2, b2), b = pRef(a1, b1, a2, b2), band = plasship::nuclPosteriorBand(a1, b1, a2, b2);
+        worst = std::max(worst, std::fabs(a - b) / band);
+        const bool inBand = std::fabs(a - 0.45) < band || std::fabs(a - 0.55) < band;
+        const int ca = a < 0.45 ? 0 : (a > 0.55 ? 1 : 2), cb = b < 0.45 ? 0 : (b > 0.55 ? 1 : 2);
+        if (!inBand && ca != cb) (*classDiff)++;
+    }
+    return worst;
+}
+''')
+    so = tmp_path / "p.so"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I", os.path.join(ROOT, "plass_amd", "csrc"), str(src), "-o", str(so)])
+    lib = ctypes.CDLL(str(so))
+    lib.sweep.restype = ctypes.c_double; lib.sweep.argtypes = [ctypes.c_long, ctypes.POINTER(ctypes.c_long)]
+    diff = ctypes.c_long(0)
+    worst = lib.sweep(60000, ctypes.byref(diff))
+    assert diff.value == 0, "a class differs outside the band"
+    assert worst < 0.25, "the two routes differ by %.2f of the band" % worst
