@@ -100,20 +100,25 @@ def build_workload(ctx, cfg, pairs=None, min_genomes=0):
                   "generate_reads_s": round(t1 - t0, 3), "extractorfs_translatenucs_concatdbs_s": round(t2 - t1, 3)}
 
 
-def one_iteration(ctx, db, it):
+def one_iteration(ctx, db, it, xstat=None):
+    """xstat (sharded runs): callable returning the communicator's cumulative (bytes sent, seconds, calls) — sampled around every module so
+    that the N > 1 line can say which module's exchanges cost what"""
     import plass_amd
     par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=hash_shift(it),
                                     include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
-    t0 = time.perf_counter(); s0 = ctx.host_syncs()
+    xs = (lambda: tuple(xstat())) if xstat else (lambda: (0, 0.0, 0))
+    t0 = time.perf_counter(); s0 = ctx.host_syncs(); x0 = xs()
     cands, kst = ctx.kmermatcher(db, par)
-    t1 = time.perf_counter(); s1 = ctx.host_syncs()
+    t1 = time.perf_counter(); s1 = ctx.host_syncs(); x1 = xs()
     alns, rst = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5))
-    t2 = time.perf_counter(); s2 = ctx.host_syncs()
+    t2 = time.perf_counter(); s2 = ctx.host_syncs(); x2 = xs()
     out, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
-    t3 = time.perf_counter(); s3 = ctx.host_syncs()
+    t3 = time.perf_counter(); s3 = ctx.host_syncs(); x3 = xs()
     alns.free(); cands.free()
-    # wall: ms per module, then the number of times the host waited for the stream inside each module
-    return out, kst, rst, ast, ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s1 - s0, s2 - s1, s3 - s2)
+    xd = tuple(tuple(b[i] - a[i] for i in range(3)) for a, b in ((x0, x1), (x1, x2), (x2, x3)))
+    # wall: ms per module, then the number of times the host waited for the stream inside each module, then (sharded runs) the
+    # communicator's (bytes sent, seconds, calls) inside each module
+    return out, kst, rst, ast, ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, s1 - s0, s2 - s1, s3 - s2, xd)
 
 
 def stage_table(kst, rst, ast, nucl_queue=False):
@@ -339,6 +344,8 @@ def main():
             dist.barrier()
         ctx.sync(); torch.cuda.synchronize()
 
+    xstat = (lambda: native.stats()) if native is not None else ((lambda: (comm.bytes_moved, comm.seconds, comm.calls)) if comm is not None else None)
+
     def run(n_steps, record):
         db, rows, total = db0, [], 0
         for s in range(n_steps):
@@ -348,7 +355,7 @@ def main():
             ts = time.perf_counter()
             if VERBOSE and rank == 0:
                 i = db.info(); print("step %d iteration %d: %d sequences, %d residues, longest entry %d" % (s, it, i["n"], i["residues"], i["max_entry_len"]), file=sys.stderr, flush=True)
-            out, kst, rst, ast, wall = one_iteration(ctx, db, it)
+            out, kst, rst, ast, wall = one_iteration(ctx, db, it, xstat)
             if VERBOSE and rank == 0:
                 print("   N_k=%d N_m=%d N_c=%d cached=%d extract %.1f (short %.1f wave %.1f) | scored=%d accepted=%d | aln=%d extended=%d rescored=%d db +%.2f GB / copy %.2f GB asm %.1f | wall ms %s" % (
                     kst.n_kmer_records, kst.n_grouped, kst.n_candidates, kst.n_cached_sequences, kst.ms_extract, kst.ms_extract_short_kernel, kst.ms_extract_wave_kernel,
@@ -440,6 +447,16 @@ def main():
             nb, nsec, ncalls = native.stats()
             line["exchange"] = {"communicator": "native RCCL (plasship_rccl, ncclSend/ncclRecv groups on the context stream)", "device_bytes_sent_per_step_rank0": nb / max(steps, 1),
                                 "collective_calls_per_step": ncalls / max(steps, 1), "host_ms_in_collectives_per_step_rank0": nsec * 1e3 / max(steps, 1)}
+        if "exchange" in line:
+            # which module's exchanges: kmermatcher = exchange 1 (k-mer lines to their bucket's owner), exchange 2 (aggregated
+            # triples to their representative's owner), the run heads, status rounds; rescorediagonal = none; assembleresults = the all-gather of
+            # the extended sequences
+            per = {}
+            for mi, name in enumerate(("kmermatcher", "rescorediagonal", "assembleresults")):
+                tot = [sum(r[5][6][mi][f] for r in rows) for f in range(3)]
+                per[name] = {"device_bytes_sent_per_step_rank0": tot[0] / max(len(rows), 1), "host_ms_in_collectives_per_step_rank0": tot[1] * 1e3 / max(len(rows), 1),
+                             "collective_calls_per_step": tot[2] / max(len(rows), 1)}
+            line["exchange"]["per_module"] = per
     if db is not db0:
         db.free()
     # ---- untimed verification: one more traversal of the chain, digest of every iteration's output DB (include/plasship.h:
