@@ -284,10 +284,19 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
             int bStart = -1, bEnd = -1, bDiag = 0, bIds = 0; unsigned bScore = 0, bDiagLen = 0, bDist = 0;
             const unsigned d16 = hit.diag16 & 0xFFFFu;
             const unsigned nNeg = 1 + tLen / 32768, nPos = 1 + qLen / 65536;
-            for (unsigned c = 0; c < nNeg + nPos; c++) {
-                const int real = c < nNeg ? (int) (d16 - (c + 1) * 65536u) : (int) ((c - nNeg) * 65536u + d16);
+            // Every lane walks ITS OWN wraps that meet the sequences, in the same order as before (round 4, last GPU calls: SQ_THREAD_CYCLES_VALU
+            // showed 16 of 64 lanes active per vector instruction of this kernel — with one loop over the wrap index for all lanes, the
+            // lanes whose diagonal is the negative wrap scored in the first round and those with the positive wrap in the second, each
+            // round with about half the wavefront masked; a pair of sequences below 32 768 residues has exactly one such wrap)
+            const unsigned nWrap = nNeg + nPos;
+            auto wrapDiag = [&](unsigned c) -> int { return c < nNeg ? (int) (d16 - (c + 1) * 65536u) : (int) ((c - nNeg) * 65536u + d16); };
+            auto nextWrap = [&](unsigned c) -> unsigned {
+                for (; c < nWrap; c++) { const int real = wrapDiag(c); const unsigned dist = (unsigned) abs(real); if (real >= 0 ? dist < qLen : dist < tLen) break; }
+                return c;
+            };
+            for (unsigned c = nextWrap(0); c < nWrap; c = nextWrap(c + 1)) {
+                const int real = wrapDiag(c);
                 const unsigned dist = (unsigned) abs(real);
-                if (!(real >= 0 ? dist < qLen : dist < tLen)) continue;
                 DiagScore s = isReverse ? scoreDiagonal<true, G>(q, qLen, t, tLen, real, smat, sComp, sl) : scoreDiagonal<false, G>(q, qLen, t, tLen, real, smat, sComp, sl);
                 if (s.score > bScore) { bScore = s.score; bStart = s.first; bEnd = s.last; bDiag = real; bDiagLen = s.diagLen; bDist = dist; bIds = s.idCnt; }
             }
