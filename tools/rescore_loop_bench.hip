@@ -1,7 +1,8 @@
 // Stand-alone check + microbenchmark of the thread-per-pair scoring loop of rescorediagonal (plass_amd/csrc/rescore.hip, scoreDiagonal<false, 1>)
-// — development tool, written at the end of round 4 and NOT yet run (the round's GPU budget was spent): the SQ counters say the rescoring
-// kernel is bound by vector issue (profiles/r03_pmc, profiles/r04_pmc_c5, profiles/r04_pmc_lanes_per_kernel.txt), its loop costs 85 vector
-// instructions per 16 columns, and this file holds the variant to try first.
+// — development tool (end of round 4): the SQ counters say the rescoring kernel is bound by vector issue (profiles/r03_pmc, profiles/r04_pmc_c5,
+// profiles/r04_pmc_lanes_per_kernel.txt) and its loop costs 85 vector instructions per 16 columns; this file compares the loop with a cheaper variant.
+// Result on the MI355X (profiles/r04_rescore_loop_bench.log): both run at ~600 G columns/s on random pairs — memory bound; the loop is not where
+// the product kernel's instructions go.
 //   build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/rescore_loop_bench.hip -o tools/rescore_loop_bench
 //   run:   tools/rescore_loop_bench [pairs (default 2^22)] [mean overlap (default 115)]
 // Both kernels score the same synthetic pairs (random protein letters, overlaps of random length at random places of one buffer, so
