@@ -11,6 +11,7 @@
 // (another substitution matrix, spaced k-mers, masking, automatic k …) fail loudly like Debug(Debug::ERROR) + EXIT(EXIT_FAILURE).
 #include "../../include/plasship.h"
 #include <chrono>
+#include <cstdarg>
 #include <climits>
 #include <cstdio>
 #include <cstdlib>
@@ -61,7 +62,26 @@ struct Flags {
     std::set<std::string> seen;
 };
 
-static int fail(const char *what) { fprintf(stdout, "%s: %s\n", what, plasship_last_error()); return EXIT_FAILURE; }
+// Exit codes beyond EXIT_SUCCESS / EXIT_FAILURE: a request that is well-formed for the REFERENCE module but lies
+// outside what the GPU path implements (--rescore-mode 0, --wrapped-scoring 1, masking, spaced k-mers, automatic -k, a module that is not
+// part of the hot path, PLASSHIP_ERR_UNSUPPORTED from the library) ends with EXIT_UNSUPPORTED before anything is written, so that a
+// wrapper can hand exactly that call to the reference binary: `linclust` at the end of `penguin guided_nuclassemble` calls
+// `rescorediagonal --rescore-mode 0 --wrapped-scoring 1` (lib/mmseqs/data/workflow/linclust.sh:30) through the same $MMSEQS.
+// EXIT_DRYRUN_ACCEPTED: with PLASSHIP_CLI_DRYRUN=1 the command line is parsed and validated, nothing is read or computed (no GPU needed) —
+// what tools/workflow_dropin_check.sh uses to exercise the routing of every call the unmodified workflow scripts make.
+enum { EXIT_UNSUPPORTED = 95, EXIT_DRYRUN_ACCEPTED = 96 };
+static int g_lastRc = 0;
+static inline int K(int rc) { g_lastRc = rc; return rc; }
+static int unsupported(const char *fmt, ...) {
+    va_list ap; va_start(ap, fmt); vfprintf(stdout, fmt, ap); va_end(ap);
+    fprintf(stdout, "plass-hip: outside the GPU hot path, exit code %d (nothing was written)\n", (int) EXIT_UNSUPPORTED);
+    return EXIT_UNSUPPORTED;
+}
+static int fail(const char *what) {
+    fprintf(stdout, "%s: %s\n", what, plasship_last_error());
+    if (g_lastRc == PLASSHIP_ERR_UNSUPPORTED) { fprintf(stdout, "plass-hip: outside the GPU hot path, exit code %d (nothing was written)\n", (int) EXIT_UNSUPPORTED); return EXIT_UNSUPPORTED; }
+    return EXIT_FAILURE;
+}
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // which flags a module owns (its parameter vector in the reference)
@@ -120,8 +140,7 @@ int main(int argc, char **argv) {
     const std::string mod = argv[1];
     const auto mf = moduleFlags().find(mod);
     if (mf == moduleFlags().end()) {
-        fprintf(stdout, "plass-hip: module \"%s\" is not part of the GPU hot path (use the reference binary for it)\n", mod.c_str());
-        return EXIT_FAILURE;
+        return unsupported("plass-hip: module \"%s\" is not part of the GPU hot path (use the reference binary for it)\n", mod.c_str());
     }
     Flags f; std::vector<std::string> pos;
     if (mod == "kmermatcher") { f.covThr = 0.8f; f.alph = 13; f.kps = 0; }                    // setLinearFilterDefault
@@ -207,61 +226,67 @@ int main(int argc, char **argv) {
             const bool okA = multiParam(v, "aa", aa), okN = multiParam(v, "nucl", nu);
             if ((okA && baseName(aa) != "blosum62.out" && v.find(':') != std::string::npos) || (okN && baseName(nu) != "nucleotide.out" && v.find(':') != std::string::npos) ||
                 (v.find(':') == std::string::npos && baseName(v) != "blosum62.out" && baseName(v) != "nucleotide.out")) {
-                fprintf(stdout, "plass-hip: --sub-mat %s is not supported (built for blosum62.out / nucleotide.out)\n", v.c_str()); return EXIT_FAILURE;
+                return unsupported("plass-hip: --sub-mat %s is not supported (built for blosum62.out / nucleotide.out)\n", v.c_str());
             }
         }
         else if (a == "--spaced-kmer-mode" || a == "--mask" || a == "--mask-lower-case" || a == "--compressed" || a == "--create-lookup" || a == "--id-offset") {
-            if (atoi(v.c_str()) != 0) { fprintf(stdout, "%s %s is not supported by plass-hip\n", a.c_str(), v.c_str()); return EXIT_FAILURE; }
+            if (atoi(v.c_str()) != 0) return unsupported("%s %s is not supported by plass-hip\n", a.c_str(), v.c_str());
         }
-        else if (a == "--adjust-kmer-len") { int x = 0; if (!setBool(x)) return EXIT_FAILURE; if (x) { fprintf(stdout, "--adjust-kmer-len is not supported by plass-hip\n"); return EXIT_FAILURE; } }
-        else if (a == "--spaced-kmer-pattern") { if (!v.empty()) { fprintf(stdout, "--spaced-kmer-pattern is not supported by plass-hip\n"); return EXIT_FAILURE; } }
+        else if (a == "--adjust-kmer-len") { int x = 0; if (!setBool(x)) return EXIT_FAILURE; if (x) return unsupported("--adjust-kmer-len is not supported by plass-hip\n"); }
+        else if (a == "--spaced-kmer-pattern") { if (!v.empty()) return unsupported("--spaced-kmer-pattern is not supported by plass-hip\n"); }
         // --threads, -v, --db-load-mode, --split-memory-limit: no influence on the result
     }
-    if (f.wrapped || f.filterHits || f.sortResults) { fprintf(stdout, "--wrapped-scoring/--filter-hits/--sort-results are not supported by plass-hip\n"); return EXIT_FAILURE; }
+    if (f.wrapped || f.filterHits || f.sortResults) return unsupported("--wrapped-scoring/--filter-hits/--sort-results are not supported by plass-hip\n");
     if (mod == "kmermatcher") {
         // the module's own defaults for these two are "choose automatically" (k = 0: from the DB size, kmermatcher.cpp:607-613;
         // --kmer-per-seq 0): not reproduced — every workflow passes them
-        if (f.k <= 0 || f.kps <= 0) { fprintf(stdout, "plass-hip kmermatcher: -k and --kmer-per-seq must be given (the automatic choice of the reference is not implemented)\n"); return EXIT_FAILURE; }
+        if (f.k <= 0 || f.kps <= 0) return unsupported("plass-hip kmermatcher: -k and --kmer-per-seq must be given (the automatic choice of the reference is not implemented)\n");
         // the reference's module default is spaced k-mers and masking ON unless told otherwise; the workflows run with both off
         // (setLinearFilterDefault turns them off for kmermatcher itself)
     }
+    if (mod == "rescorediagonal" && f.rescoreMode != 3)
+        return unsupported("plass-hip rescorediagonal: --rescore-mode %d is not part of the GPU path (the assembly workflows use mode 3)\n", f.rescoreMode);
+    if (getenv("PLASSHIP_CLI_DRYRUN") && atoi(getenv("PLASSHIP_CLI_DRYRUN")) != 0) {
+        fprintf(stdout, "plass-hip dry run: %s accepted (%zu positional arguments, %zu flags); nothing read or computed\n", mod.c_str(), pos.size(), f.seen.size());
+        return EXIT_DRYRUN_ACCEPTED;
+    }
     plasship_ctx *ctx = nullptr;
-    if (plasship_ctx_create(-1, &ctx)) return fail("plass-hip");
+    if (K(plasship_ctx_create(-1, &ctx))) return fail("plass-hip");
     const double t0 = now();
     int rc = EXIT_SUCCESS;
     if (mod == "kmermatcher") {
         if (pos.size() != 2) { fprintf(stdout, "kmermatcher <i:sequenceDB> <o:prefDB>\n"); return EXIT_FAILURE; }
         plasship_seqdb *db = nullptr; plasship_cands *c = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("kmermatcher");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &db))) return fail("kmermatcher");
         int dbtype = 0; plasship_seqdb_info(db, nullptr, nullptr, nullptr, &dbtype, nullptr);
         plasship_kmermatch_params p; memset(&p, 0, sizeof(p));
         p.kmer_size = f.k; p.alphabet_size = f.alph; p.kmers_per_seq = f.kps; p.kmers_per_seq_scale = (dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES) ? f.scaleNucl : f.scaleAA;
         p.hash_shift = f.hashShift; p.include_only_extendable = f.onlyExt; p.ignore_multi_kmer = f.ignoreMulti; p.cov_mode = f.covMode; p.cov_thr = f.covThr;
         plasship_kmermatch_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_kmermatch(ctx, db, &p, &c, &st)) return fail("kmermatcher");
+        if (K(plasship_kmermatch(ctx, db, &p, &c, &st))) return fail("kmermatcher");
         fprintf(stdout, "k-mer records: %llu grouped: %llu candidates: %llu | kernels ms: extract %.3f partition %.3f group %.3f sort %.3f reduce %.3f\n",
                 (unsigned long long) st.n_kmer_records, (unsigned long long) st.n_grouped, (unsigned long long) st.n_candidates,
                 st.ms_extract, st.ms_sort1, st.ms_group, st.ms_sort2, st.ms_reduce);
-        if (plasship_cands_write(ctx, c, db, pos[1].c_str())) return fail("kmermatcher");
+        if (K(plasship_cands_write(ctx, c, db, pos[1].c_str()))) return fail("kmermatcher");
         plasship_cands_free(ctx, c); plasship_seqdb_free(ctx, db);
     } else if (mod == "rescorediagonal") {
         if (pos.size() != 4) { fprintf(stdout, "rescorediagonal <i:queryDB> <i:targetDB> <i:prefDB> <o:alnDB>\n"); return EXIT_FAILURE; }
         plasship_seqdb *q = nullptr, *t = nullptr; plasship_cands *c = nullptr; plasship_alns *al = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &q)) return fail("rescorediagonal");
-        if (pos[1] == pos[0]) t = q; else if (plasship_seqdb_read(ctx, pos[1].c_str(), &t)) return fail("rescorediagonal");
-        if (plasship_cands_read(ctx, q, t, pos[2].c_str(), &c)) return fail("rescorediagonal");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &q))) return fail("rescorediagonal");
+        if (pos[1] == pos[0]) t = q; else if (K(plasship_seqdb_read(ctx, pos[1].c_str(), &t))) return fail("rescorediagonal");
+        if (K(plasship_cands_read(ctx, q, t, pos[2].c_str(), &c))) return fail("rescorediagonal");
         plasship_rescore_params p; memset(&p, 0, sizeof(p));
         p.rescore_mode = f.rescoreMode; p.eval_thr = f.evalThr; p.seq_id_thr = f.seqIdThr; p.cov_mode = f.covMode; p.cov_thr = f.covThr;
         p.min_aln_len = f.minAlnLen; p.seq_id_mode = f.seqIdMode; p.add_backtrace = f.addBt; p.include_identity = f.addSelf;
         plasship_rescore_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_rescore(ctx, q, t, c, &p, &al, &st)) return fail("rescorediagonal");
+        if (K(plasship_rescore(ctx, q, t, c, &p, &al, &st))) return fail("rescorediagonal");
         fprintf(stdout, "scored: %llu accepted: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_scored, (unsigned long long) st.n_accepted, st.ms_kernel);
-        if (plasship_alns_write(ctx, al, pos[3].c_str())) return fail("rescorediagonal");
+        if (K(plasship_alns_write(ctx, al, pos[3].c_str()))) return fail("rescorediagonal");
         plasship_alns_free(ctx, al); plasship_cands_free(ctx, c); if (t != q) plasship_seqdb_free(ctx, t); plasship_seqdb_free(ctx, q);
     } else if (mod == "assembleresults" || mod == "nuclassembleresults") {
         if (pos.size() != 3) { fprintf(stdout, "%s <i:sequenceDB> <i:alnResult> <o:reprSeqDB>\n", mod.c_str()); return EXIT_FAILURE; }
         plasship_seqdb *db = nullptr, *o = nullptr; plasship_alns *al = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("assembleresults");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &db))) return fail("assembleresults");
         // the library picks the variant from the DB type (protein -> assembleresults, nucleotide -> nuclassembleresults);
         // the module name has to agree, the reference's assembleresults on nucleotides uses another comparator
         int dbtype = -1; plasship_seqdb_info(db, nullptr, nullptr, nullptr, &dbtype, nullptr);
@@ -269,83 +294,83 @@ int main(int argc, char **argv) {
             fprintf(stdout, "plass-hip: %s needs a %s sequence DB\n", mod.c_str(), mod == "nuclassembleresults" ? "nucleotide" : "protein");
             return EXIT_FAILURE;
         }
-        if (plasship_alns_read(ctx, db, pos[1].c_str(), &al)) return fail("assembleresults");
+        if (K(plasship_alns_read(ctx, db, pos[1].c_str(), &al))) return fail("assembleresults");
         plasship_assemble_params p; memset(&p, 0, sizeof(p));
         p.seq_id_thr = f.seqIdThr; p.max_seq_len = f.maxSeqLen; p.keep_target = f.keepTarget; p.rescore_mode = f.rescoreMode;
         plasship_assemble_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_assemble(ctx, db, al, &p, &o, &st)) return fail("assembleresults");
+        if (K(plasship_assemble(ctx, db, al, &p, &o, &st))) return fail("assembleresults");
         fprintf(stdout, "extended: %llu rescored: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_extended, (unsigned long long) st.n_rescored, st.ms_kernel);
-        if (plasship_seqdb_write(ctx, o, pos[2].c_str())) return fail("assembleresults");
+        if (K(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("assembleresults");
         plasship_seqdb_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, db);
     } else if (mod == "guidedassembleresults") {
         if (pos.size() != 5) { fprintf(stdout, "guidedassembleresults <i:nuclSequenceDB> <i:aaSequenceDB> <i:nuclAlnResult> <o:nuclAssembly> <o:aaAssembly>\n"); return EXIT_FAILURE; }
         plasship_seqdb *nu = nullptr, *aa = nullptr, *on = nullptr, *oa = nullptr; plasship_alns *al = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &nu) || plasship_seqdb_read(ctx, pos[1].c_str(), &aa)) return fail("guidedassembleresults");
-        if (plasship_alns_read(ctx, nu, pos[2].c_str(), &al)) return fail("guidedassembleresults");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &nu)) || K(plasship_seqdb_read(ctx, pos[1].c_str(), &aa))) return fail("guidedassembleresults");
+        if (K(plasship_alns_read(ctx, nu, pos[2].c_str(), &al))) return fail("guidedassembleresults");
         plasship_assemble_params p; memset(&p, 0, sizeof(p));
         p.seq_id_thr = f.seqIdThr; p.max_seq_len = f.maxSeqLen; p.keep_target = f.keepTarget; p.rescore_mode = f.rescoreMode;
         plasship_assemble_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_guided_assemble(ctx, nu, aa, al, &p, &on, &oa, &st)) return fail("guidedassembleresults");
+        if (K(plasship_guided_assemble(ctx, nu, aa, al, &p, &on, &oa, &st))) return fail("guidedassembleresults");
         fprintf(stdout, "extended: %llu rescored: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_extended, (unsigned long long) st.n_rescored, st.ms_kernel);
-        if (plasship_seqdb_write(ctx, on, pos[3].c_str()) || plasship_seqdb_write(ctx, oa, pos[4].c_str())) return fail("guidedassembleresults");
+        if (K(plasship_seqdb_write(ctx, on, pos[3].c_str())) || K(plasship_seqdb_write(ctx, oa, pos[4].c_str()))) return fail("guidedassembleresults");
         plasship_seqdb_free(ctx, on); plasship_seqdb_free(ctx, oa); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, aa); plasship_seqdb_free(ctx, nu);
     } else if (mod == "proteinaln2nucl") {
         if (pos.size() != 6) { fprintf(stdout, "proteinaln2nucl <i:queryNuclDB> <i:targetNuclDB> <i:queryAaDB> <i:targetAaDB> <i:alnDB> <o:alnDB>\n"); return EXIT_FAILURE; }
         if ((pos[0] == pos[1]) != (pos[2] == pos[3])) { fprintf(stdout, "Either query database == target database for nucleotide and amino acid or != for both\n"); return EXIT_FAILURE; }
         if (pos[0] != pos[1]) { fprintf(stdout, "plass-hip: proteinaln2nucl with separate query and target DBs is not supported (the assembly workflows use one DB)\n"); return EXIT_FAILURE; }
         plasship_seqdb *nu = nullptr, *aa = nullptr; plasship_alns *al = nullptr, *o = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &nu) || plasship_seqdb_read(ctx, pos[2].c_str(), &aa)) return fail("proteinaln2nucl");
-        if (plasship_alns_read(ctx, aa, pos[4].c_str(), &al)) return fail("proteinaln2nucl");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &nu)) || K(plasship_seqdb_read(ctx, pos[2].c_str(), &aa))) return fail("proteinaln2nucl");
+        if (K(plasship_alns_read(ctx, aa, pos[4].c_str(), &al))) return fail("proteinaln2nucl");
         plasship_aln2nucl_params p; p.gap_open = f.gapOpenNucl; p.gap_extend = f.gapExtendNucl;
         plasship_aln2nucl_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_aln2nucl(ctx, nu, nu, aa, aa, al, &p, &o, &st)) return fail("proteinaln2nucl");
+        if (K(plasship_aln2nucl(ctx, nu, nu, aa, aa, al, &p, &o, &st))) return fail("proteinaln2nucl");
         fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
-        if (plasship_alns_write(ctx, o, pos[5].c_str())) return fail("proteinaln2nucl");
+        if (K(plasship_alns_write(ctx, o, pos[5].c_str()))) return fail("proteinaln2nucl");
         plasship_alns_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, aa); plasship_seqdb_free(ctx, nu);
     } else if (mod == "findassemblystart") {
         if (pos.size() != 3) { fprintf(stdout, "findassemblystart <i:sequenceDB> <i:alnDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
         plasship_seqdb *db = nullptr, *o = nullptr; plasship_alns *al = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("findassemblystart");
-        if (plasship_alns_read(ctx, db, pos[1].c_str(), &al)) return fail("findassemblystart");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &db))) return fail("findassemblystart");
+        if (K(plasship_alns_read(ctx, db, pos[1].c_str(), &al))) return fail("findassemblystart");
         plasship_findstart_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_find_assembly_start(ctx, db, al, &o, &st)) return fail("findassemblystart");
+        if (K(plasship_find_assembly_start(ctx, db, al, &o, &st))) return fail("findassemblystart");
         fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
-        if (plasship_seqdb_write(ctx, o, pos[2].c_str())) return fail("findassemblystart");
+        if (K(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("findassemblystart");
         plasship_seqdb_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, db);
     } else if (mod == "cyclecheck") {
         if (pos.size() != 2) { fprintf(stdout, "cyclecheck <i:sequenceDB> <o:sequenceDBcycle>\n"); return EXIT_FAILURE; }
         plasship_seqdb *db = nullptr, *o = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("cyclecheck");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &db))) return fail("cyclecheck");
         plasship_cyclecheck_params p; p.max_seq_len = f.maxSeqLen; p.chop_cycle = f.chopCycle;
         plasship_cyclecheck_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_cyclecheck(ctx, db, &p, &o, nullptr, &st)) return fail("cyclecheck");
+        if (K(plasship_cyclecheck(ctx, db, &p, &o, nullptr, &st))) return fail("cyclecheck");
         fprintf(stdout, "circular: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_cyclic, st.ms_kernel);
-        if (plasship_seqdb_write(ctx, o, pos[1].c_str())) return fail("cyclecheck");
+        if (K(plasship_seqdb_write(ctx, o, pos[1].c_str()))) return fail("cyclecheck");
         plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
     } else if (mod == "extractorfs") {
         // writes <out> and <out>_h like the reference (extractorfs.cpp:28-32)
         if (pos.size() != 2) { fprintf(stdout, "extractorfs <i:sequenceDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
         plasship_seqdb *db = nullptr, *o = nullptr; plasship_orfhdr *h = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("extractorfs");
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &db))) return fail("extractorfs");
         plasship_orf_params p; memset(&p, 0, sizeof(p));
         p.min_length = f.orfMin; p.max_length = f.orfMax; p.max_gaps = f.orfGaps; p.contig_start_mode = f.contigStart; p.contig_end_mode = f.contigEnd;
         p.orf_start_mode = f.orfStart; p.forward_frames = f.fwdFrames; p.reverse_frames = f.revFrames; p.translation_table = f.translationTable;
         p.translate = f.translate; p.use_all_table_starts = f.allStarts; p.max_seq_len = f.maxSeqLen;
         plasship_orf_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_extract_orfs(ctx, db, &p, &o, &h, &st)) return fail("extractorfs");
+        if (K(plasship_extract_orfs(ctx, db, &p, &o, &h, &st))) return fail("extractorfs");
         fprintf(stdout, "orfs: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_out, st.ms_kernel);
-        if (plasship_seqdb_write(ctx, o, pos[1].c_str()) || plasship_orfhdr_write(ctx, h, (pos[1] + "_h").c_str())) return fail("extractorfs");
+        if (K(plasship_seqdb_write(ctx, o, pos[1].c_str())) || K(plasship_orfhdr_write(ctx, h, (pos[1] + "_h").c_str()))) return fail("extractorfs");
         plasship_orfhdr_free(ctx, h); plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
     } else if (mod == "translatenucs") {
         if (pos.size() != 2) { fprintf(stdout, "translatenucs <i:sequenceDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
         plasship_seqdb *db = nullptr, *o = nullptr; plasship_orfhdr *h = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &db)) return fail("translatenucs");
-        if (f.addOrfStop && plasship_orfhdr_read(ctx, (pos[0] + "_h").c_str(), &h)) return fail("translatenucs");      // translatenucs.cpp:29-34
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &db))) return fail("translatenucs");
+        if (f.addOrfStop && K(plasship_orfhdr_read(ctx, (pos[0] + "_h").c_str(), &h))) return fail("translatenucs");      // translatenucs.cpp:29-34
         plasship_translate_params p; p.translation_table = f.translationTable; p.add_orf_stop = f.addOrfStop; p.max_seq_len = f.maxSeqLen;
         plasship_orf_stats st; memset(&st, 0, sizeof(st));
-        if (plasship_translate_nucs(ctx, db, h, &p, &o, &st)) return fail("translatenucs");
+        if (K(plasship_translate_nucs(ctx, db, h, &p, &o, &st))) return fail("translatenucs");
         fprintf(stdout, "translated: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_out, st.ms_kernel);
-        if (plasship_seqdb_write(ctx, o, pos[1].c_str())) return fail("translatenucs");
+        if (K(plasship_seqdb_write(ctx, o, pos[1].c_str()))) return fail("translatenucs");
         plasship_orfhdr_free(ctx, h); plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
     } else if (mod == "concatdbs") {
         if (pos.size() != 3) { fprintf(stdout, "concatdbs <i:DB> <i:DB> <o:DB>\n"); return EXIT_FAILURE; }
@@ -355,15 +380,15 @@ int main(int argc, char **argv) {
         { std::string tp = pos[0] + ".dbtype"; FILE *ft = fopen(tp.c_str(), "rb"); unsigned ty = 0; if (ft && fread(&ty, 4, 1, ft) == 1) dbtype = (int) (ty & 0x3FFFFFFFu); if (ft) fclose(ft); }
         if (dbtype == PLASSHIP_DBTYPE_AMINO_ACIDS || dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES) {
             plasship_seqdb *a = nullptr, *b = nullptr, *o = nullptr;
-            if (plasship_seqdb_read(ctx, pos[0].c_str(), &a) || plasship_seqdb_read(ctx, pos[1].c_str(), &b)) return fail("concatdbs");
-            if (plasship_seqdb_concat(ctx, a, b, &o)) return fail("concatdbs");
-            if (plasship_seqdb_write(ctx, o, pos[2].c_str())) return fail("concatdbs");
+            if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &a)) || K(plasship_seqdb_read(ctx, pos[1].c_str(), &b))) return fail("concatdbs");
+            if (K(plasship_seqdb_concat(ctx, a, b, &o))) return fail("concatdbs");
+            if (K(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("concatdbs");
             plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, b); plasship_seqdb_free(ctx, a);
         } else if (dbtype == 12) {
             plasship_orfhdr *a = nullptr, *b = nullptr, *o = nullptr;
-            if (plasship_orfhdr_read(ctx, pos[0].c_str(), &a) || plasship_orfhdr_read(ctx, pos[1].c_str(), &b)) return fail("concatdbs");
-            if (plasship_orfhdr_concat(ctx, a, b, &o)) return fail("concatdbs");
-            if (plasship_orfhdr_write(ctx, o, pos[2].c_str())) return fail("concatdbs");
+            if (K(plasship_orfhdr_read(ctx, pos[0].c_str(), &a)) || K(plasship_orfhdr_read(ctx, pos[1].c_str(), &b))) return fail("concatdbs");
+            if (K(plasship_orfhdr_concat(ctx, a, b, &o))) return fail("concatdbs");
+            if (K(plasship_orfhdr_write(ctx, o, pos[2].c_str()))) return fail("concatdbs");
             plasship_orfhdr_free(ctx, o); plasship_orfhdr_free(ctx, b); plasship_orfhdr_free(ctx, a);
         } else { fprintf(stdout, "plass-hip concatdbs: database type %d is not supported (sequence DBs and ORF header DBs only)\n", dbtype); return EXIT_FAILURE; }
     } else if (chain) {
@@ -377,7 +402,7 @@ int main(int argc, char **argv) {
         // every exit path below joins the writer first (a joinable std::thread that goes out of scope terminates the process, and an
         // intermediate DB must not be left half written behind an ordinary error message: ADVICE r3)
         struct JoinOnExit { std::thread &t; ~JoinOnExit() { if (t.joinable()) t.join(); } } joinOnExit{writer};
-        if (!f.writeIntermediate.empty() && plasship_ctx_create(-1, &wctx)) return fail(mod.c_str());
+        if (!f.writeIntermediate.empty() && K(plasship_ctx_create(-1, &wctx))) return fail(mod.c_str());
         auto joinWriter = [&]() { if (writer.joinable()) writer.join(); return writerRc; };
         auto writeAsync = [&](const plasship_seqdb *d, const std::string &name) {
             if (!wctx) return;
@@ -391,7 +416,7 @@ int main(int argc, char **argv) {
         // a multi-GB input: the library takes its device arena (seconds of hipMalloc) while this thread reads and parses the DB files
         { struct stat stIn; if (stat(pos[0].c_str(), &stIn) == 0 && stIn.st_size >= ((off_t) 1 << 30)) (void) plasship_ctx_reserve_async(ctx); }
         plasship_seqdb *in = nullptr;
-        if (plasship_seqdb_read(ctx, pos[0].c_str(), &in)) return fail(mod.c_str());
+        if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &in))) return fail(mod.c_str());
         const double tRead = now();
         int dbtype = -1; plasship_seqdb_info(in, nullptr, nullptr, nullptr, &dbtype, nullptr);
         auto orfPar = [&](bool start) {       // the two extractorfs passes (Assembler.cpp:116-130, GuidedNuclassembler.cpp:133-145)
@@ -406,14 +431,14 @@ int main(int argc, char **argv) {
             if (dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES) { fprintf(stdout, "%s: the input must be a nucleotide read DB\n", mod.c_str()); return EXIT_FAILURE; }
             plasship_seqdb *ol = nullptr, *os = nullptr; plasship_orfhdr *hl = nullptr, *hs = nullptr; plasship_orf_stats ost;
             const plasship_orf_params pl = orfPar(false), ps = orfPar(true);
-            if (plasship_extract_orfs(ctx, in, &pl, &ol, &hl, &ost) || plasship_extract_orfs(ctx, in, &ps, &os, &hs, &ost)) return fail(mod.c_str());
+            if (K(plasship_extract_orfs(ctx, in, &pl, &ol, &hl, &ost)) || K(plasship_extract_orfs(ctx, in, &ps, &os, &hs, &ost))) return fail(mod.c_str());
             if (gd) {      // concatdbs of ORFs and headers, then one translatenucs (data/guidedNuclAssemble.sh:56-75)
                 plasship_seqdb *nu = nullptr; plasship_orfhdr *hh = nullptr;
-                if (plasship_seqdb_concat(ctx, ol, os, &nu) || plasship_orfhdr_concat(ctx, hl, hs, &hh) || plasship_translate_nucs(ctx, nu, hh, &tp, &aa, &ost)) return fail(mod.c_str());
+                if (K(plasship_seqdb_concat(ctx, ol, os, &nu)) || K(plasship_orfhdr_concat(ctx, hl, hs, &hh)) || K(plasship_translate_nucs(ctx, nu, hh, &tp, &aa, &ost))) return fail(mod.c_str());
                 plasship_orfhdr_free(ctx, hh); db = nu;
             } else {       // translatenucs x2, then concatdbs (data/assemble.sh:41-77)
                 plasship_seqdb *al = nullptr, *as = nullptr;
-                if (plasship_translate_nucs(ctx, ol, hl, &tp, &al, &ost) || plasship_translate_nucs(ctx, os, hs, &tp, &as, &ost) || plasship_seqdb_concat(ctx, al, as, &db)) return fail(mod.c_str());
+                if (K(plasship_translate_nucs(ctx, ol, hl, &tp, &al, &ost)) || K(plasship_translate_nucs(ctx, os, hs, &tp, &as, &ost)) || K(plasship_seqdb_concat(ctx, al, as, &db))) return fail(mod.c_str());
                 plasship_seqdb_free(ctx, al); plasship_seqdb_free(ctx, as);
             }
             plasship_orfhdr_free(ctx, hl); plasship_orfhdr_free(ctx, hs); plasship_seqdb_free(ctx, ol); plasship_seqdb_free(ctx, os); plasship_seqdb_free(ctx, in);
@@ -436,20 +461,20 @@ int main(int argc, char **argv) {
             if (prot) { hashShift += it % 2; kp.hash_shift = hashShift; kp.include_only_extendable = it > 0; } else { kp.hash_shift = f.hashShift; kp.include_only_extendable = 1; }
             plasship_seqdb *q = gd ? aa : db;
             plasship_cands *c = nullptr; plasship_alns *al = nullptr; plasship_kmermatch_stats ks; plasship_rescore_stats rs; plasship_assemble_stats as;
-            if (plasship_kmermatch(ctx, q, &kp, &c, &ks) || plasship_rescore(ctx, q, q, c, &rp, &al, &rs)) return fail(mod.c_str());
+            if (K(plasship_kmermatch(ctx, q, &kp, &c, &ks)) || K(plasship_rescore(ctx, q, q, c, &rp, &al, &rs))) return fail(mod.c_str());
             if (prot && it == 0) {         // data/assemble.sh:110-141: findassemblystart, then k-mer matching and re-scoring again on the corrected sequences
                 plasship_seqdb *corr = nullptr; plasship_findstart_stats fs;
-                if (plasship_find_assembly_start(ctx, db, al, &corr, &fs)) return fail(mod.c_str());
+                if (K(plasship_find_assembly_start(ctx, db, al, &corr, &fs))) return fail(mod.c_str());
                 plasship_alns_free(ctx, al); plasship_cands_free(ctx, c); plasship_seqdb_free(ctx, db); db = corr; q = db;
-                if (plasship_kmermatch(ctx, q, &kp, &c, &ks) || plasship_rescore(ctx, q, q, c, &rp, &al, &rs)) return fail(mod.c_str());
+                if (K(plasship_kmermatch(ctx, q, &kp, &c, &ks)) || K(plasship_rescore(ctx, q, q, c, &rp, &al, &rs))) return fail(mod.c_str());
             }
             overlaps += ks.n_candidates; kernelMs += ks.ms_extract + ks.ms_sort1 + ks.ms_group + ks.ms_sort2 + ks.ms_reduce + rs.ms_kernel;
             plasship_seqdb *next = nullptr, *nextAa = nullptr;
             if (gd) {
                 plasship_alns *na = nullptr; plasship_aln2nucl_params np; np.gap_open = f.gapOpenNucl; np.gap_extend = f.gapExtendNucl; plasship_aln2nucl_stats ns;
-                if (plasship_aln2nucl(ctx, db, db, aa, aa, al, &np, &na, &ns) || plasship_guided_assemble(ctx, db, aa, na, &ap, &next, &nextAa, &as)) return fail(mod.c_str());
+                if (K(plasship_aln2nucl(ctx, db, db, aa, aa, al, &np, &na, &ns)) || K(plasship_guided_assemble(ctx, db, aa, na, &ap, &next, &nextAa, &as))) return fail(mod.c_str());
                 plasship_alns_free(ctx, na);
-            } else if (plasship_assemble(ctx, db, al, &ap, &next, &as)) return fail(mod.c_str());
+            } else if (K(plasship_assemble(ctx, db, al, &ap, &next, &as))) return fail(mod.c_str());
             kernelMs += as.ms_kernel;
             plasship_alns_free(ctx, al); plasship_cands_free(ctx, c);
             if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), writerErr.c_str()); return EXIT_FAILURE; }   // the writer read `db`
@@ -457,8 +482,8 @@ int main(int argc, char **argv) {
             db = next; aa = nextAa;
             if (nuc) {     // data/nuclassemble.sh:19-61,132: circular contigs leave the loop, the rest goes on
                 plasship_seqdb *cyc = nullptr, *rest = nullptr; plasship_cyclecheck_params cp; cp.max_seq_len = f.maxSeqLen; cp.chop_cycle = f.chopCycle; plasship_cyclecheck_stats cs;
-                if (plasship_cyclecheck(ctx, db, &cp, &cyc, &rest, &cs)) return fail(mod.c_str());
-                if (cs.n_cyclic && plasship_seqdb_write(ctx, cyc, (pos[1] + "_cycle_" + std::to_string(it)).c_str())) return fail(mod.c_str());
+                if (K(plasship_cyclecheck(ctx, db, &cp, &cyc, &rest, &cs))) return fail(mod.c_str());
+                if (cs.n_cyclic && K(plasship_seqdb_write(ctx, cyc, (pos[1] + "_cycle_" + std::to_string(it)).c_str()))) return fail(mod.c_str());
                 plasship_seqdb_free(ctx, cyc); plasship_seqdb_free(ctx, db); db = rest;
             }
             fprintf(stdout, "iteration %d: candidates %llu verified %llu extended %llu (%.3f s since the DB was read)\n", it, (unsigned long long) ks.n_candidates, (unsigned long long) rs.n_accepted, (unsigned long long) as.n_extended, now() - tPrep);
@@ -466,7 +491,7 @@ int main(int argc, char **argv) {
         }
         const double tLoop = now();
         if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), writerErr.c_str()); return EXIT_FAILURE; }
-        if (plasship_seqdb_write(ctx, db, pos[1].c_str()) || (gd && plasship_seqdb_write(ctx, aa, pos[2].c_str()))) return fail(mod.c_str());
+        if (K(plasship_seqdb_write(ctx, db, pos[1].c_str())) || (gd && K(plasship_seqdb_write(ctx, aa, pos[2].c_str())))) return fail(mod.c_str());
         const double tEnd = now();
         fprintf(stdout, "chain: %d iterations, %llu candidate overlaps | read %.3fs preprocessing %.3fs iterations %.3fs (kernels %.3fs) write %.3fs\n", f.numIterations, overlaps,
                 tRead - t0, tPrep - tRead, tLoop - tPrep, kernelMs * 1e-3, tEnd - tLoop);

@@ -1,0 +1,165 @@
+"""DEEP chains against the CPU oracle (run with `-m gpu`): the regime the headline number is measured in — late
+iterations of long chains — pinned on digests the CPU oracle computed in the build container for the same synthetic reads
+(tests/golden/deep_chains.json, made by tests/golden/make_deep_chains.py):
+
+  c2_exact  BASELINE.json configs[1] AS STATED: 1 M reads (500 000 pairs, seed 1), the six iterations of `plass assemble
+            --num-iterations 6` including iteration 0's findassemblystart pass (data/assemble.sh:85-156)
+  c3_deep   2 M reads of the configs[2] community model, all TWELVE iterations of the default chain (hash shifts 67, 68, 68, 69, ...:
+            the selected-window cache alternates with re-seeded iterations, the DB heap alternates between append and full copy, contigs
+            reach thousands of residues and queues exceed 64 alignments)
+  c5_deep   2 M reads of the configs[4] model: six iterations of the nucleotide chain with cyclecheck --chop-cycle, four of the
+            protein-guided chain
+
+Every pref / aln / seq DB of every iteration is compared (`plass_oracle dbsum`: an order-independent digest of (key, length, bytes)
+over all entries; sequence DBs through the device digest, which is the same function).  The oracle tool is the checker; nothing of it
+runs in the product path."""
+import json
+import os
+
+import pytest
+
+from test_gpu_large_nucl import check_db, check_file
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden", "deep_chains.json")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return json.load(open(GOLD))
+
+
+@pytest.fixture()
+def ctx():
+    import plass_amd
+    c = plass_amd.Context(0)
+    yield c
+    c.close()
+
+
+def _reads(ctx, g):
+    import bench
+    sp = bench.synth_params(g["config"], g["pairs"])
+    for k, v in g["synth"].items():                          # the fixture was made for exactly these generator parameters
+        assert getattr(sp, k) == pytest.approx(v), k
+    reads, sst = ctx.synth_read_pairs(sp)
+    check_db(reads, g["reads"], "synthetic reads (GPU generator against the CPU generator)")
+    return reads, sst
+
+
+def _protein_chain(ctx, g, tmp_path, check_lists_from=0):
+    """the chain of data/assemble.sh on the device, every DB against the oracle's digests; returns per-iteration statistics"""
+    import bench
+    import plass_amd
+    reads, sst = _reads(ctx, g)
+    db = ctx.plass_fragments(reads)
+    reads.free()
+    check_db(db, g["fragments"], "extractorfs + translatenucs + concatdbs")
+    rs = plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5)
+    stats = []
+    for it, want in enumerate(g["iterations"]):
+        par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=bench.hash_shift(it),
+                                        include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
+        cands, kst = ctx.kmermatcher(db, par)
+        alns, rst = ctx.rescorediagonal(db, db, cands, rs)
+        if it == 0 and g["findassemblystart"]:
+            cands.write(tmp_path / "pref"); check_file(tmp_path / "pref", want["pref_uncorrected"], "kmermatcher before findassemblystart")
+            alns.write(tmp_path / "aln"); check_file(tmp_path / "aln", want["aln_uncorrected"], "rescorediagonal before findassemblystart")
+            corr, _ = ctx.findassemblystart(db, alns)
+            cands.free(); alns.free(); db.free()
+            check_db(corr, want["corrected"], "findassemblystart")
+            db = corr
+            cands, kst = ctx.kmermatcher(db, par)
+            alns, rst = ctx.rescorediagonal(db, db, cands, rs)
+        if it >= check_lists_from:
+            cands.write(tmp_path / "pref"); check_file(tmp_path / "pref", want["pref"], "kmermatcher, iteration %d" % it)
+            alns.write(tmp_path / "aln"); check_file(tmp_path / "aln", want["aln"], "rescorediagonal, iteration %d" % it)
+        cands.free()
+        out, ast = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
+        alns.free(); db.free()
+        check_db(out, want["seq"], "assembleresults, iteration %d" % it)
+        stats.append((kst, rst, ast, out.info()))
+        db = out
+    db.free()
+    return sst, stats
+
+
+@pytest.mark.timeout(1200)
+def test_configs1_as_stated_six_iterations_with_findassemblystart(ctx, gold, tmp_path):
+    g = gold["c2_exact"]
+    assert (g["config"], 2 * g["pairs"], g["iters"], g["findassemblystart"]) == ("c2", 1000000, 6, True)
+    assert len(g["iterations"]) == 6
+    _protein_chain(ctx, g, tmp_path)
+
+
+@pytest.mark.timeout(1800)
+def test_twelve_iterations_of_the_headline_community(ctx, gold, tmp_path):
+    g = gold["c3_deep"]
+    assert g["config"] == "c3" and 2 * g["pairs"] >= 2000000 and len(g["iterations"]) == 12
+    sst, stats = _protein_chain(ctx, g, tmp_path)
+    assert sst.max_coverage > 3 * sst.mean_coverage          # skewed like the headline workload
+    # the regime this fixture exists for: contigs of thousands of residues, the selected-window cache on even iterations, and the
+    # extension tier for queues of more than 64 alignments
+    assert stats[-1][3]["max_entry_len"] > 2000
+    assert all(k.n_cached_sequences > 0 for k, _, _, _ in stats[2::2]), "the selected-window cache did not serve the same-seed iterations"
+    assert all(k.n_cached_sequences == 0 for k, _, _, _ in stats[1::2]), "a re-seeded iteration took windows from the cache"
+    assert sum(a.tier_alignments[2] for _, _, a, _ in stats) > 0, "no query held more than 64 alignments: assembleBigKernel did not run"
+    assert any(a.db_appended_bytes > 0 for _, _, a, _ in stats) and any(a.db_copied_bytes > 0 for _, _, a, _ in stats), \
+        "the DB heap did not alternate between append and full copy"
+
+
+@pytest.mark.timeout(1800)
+def test_six_nucleotide_iterations_with_cyclecheck(ctx, gold, tmp_path):
+    from test_gpu_parity import km_params, nucl_as_params
+    import plass_amd
+    g = gold["c5_deep"]
+    assert 2 * g["pairs"] >= 2000000 and len(g["nucl"]) >= 6
+    db, _ = _reads(ctx, g)
+    longest = 0
+    for it, want in enumerate(g["nucl"]):
+        cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+        cands.write(tmp_path / "pref"); check_file(tmp_path / "pref", want["pref"], "kmermatcher -k 22, iteration %d" % it)
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+        cands.free()
+        alns.write(tmp_path / "aln"); check_file(tmp_path / "aln", want["aln"], "rescorediagonal (nucleotide), iteration %d" % it)
+        out, _ = ctx.assembleresults(db, alns, nucl_as_params())
+        alns.free(); db.free()
+        check_db(out, want["assembly"], "nuclassembleresults, iteration %d" % it)
+        cyc, rest, cst = ctx.cyclecheck(out, max_seq_len=200000, chop_cycle=True, with_rest=True)
+        assert cst.n_cyclic == want["n_cyclic"]
+        check_db(cyc, want["cycle"], "cyclecheck, iteration %d" % it)
+        check_db(rest, want["rest"], "non-circular rest, iteration %d" % it)
+        longest = max(longest, rest.info()["max_entry_len"])
+        cyc.free(); out.free()
+        db = rest
+    db.free()
+    assert longest > 5000                                    # contigs, not reads: the long-sequence tiers ran
+
+
+@pytest.mark.timeout(1800)
+def test_four_guided_iterations(ctx, gold, tmp_path):
+    from test_gpu_parity import gd_km_params, gd_rs_params
+    g = gold["c5_deep"]
+    assert len(g["guided"]) >= 4
+    reads, _ = _reads(ctx, g)
+    nu, aa = ctx.penguin_guided_inputs(reads)
+    reads.free()
+    check_db(nu, g["guided_input"]["nucl"], "extractorfs x2 + concatdbs")
+    check_db(aa, g["guided_input"]["aa"], "translatenucs --add-orf-stop of the concatenated ORFs")
+    for it, want in enumerate(g["guided"]):
+        cands, _ = ctx.kmermatcher(aa, gd_km_params())
+        cands.write(tmp_path / "pref"); check_file(tmp_path / "pref", want["pref"], "kmermatcher (guided), iteration %d" % it)
+        alns, _ = ctx.rescorediagonal(aa, aa, cands, gd_rs_params())
+        cands.free()
+        alns.write(tmp_path / "aln"); check_file(tmp_path / "aln", want["aln"], "rescorediagonal -a 1 (guided), iteration %d" % it)
+        naln, _ = ctx.proteinaln2nucl(nu, aa, alns)
+        alns.free()
+        naln.write(tmp_path / "aln_nucl"); check_file(tmp_path / "aln_nucl", want["aln_nucl"], "proteinaln2nucl, iteration %d" % it)
+        nu2, aa2, _ = ctx.guidedassembleresults(nu, aa, naln)
+        naln.free(); nu.free(); aa.free()
+        check_db(nu2, want["nucl"], "guidedassembleresults (nucleotide ORFs), iteration %d" % it)
+        check_db(aa2, want["aa"], "guidedassembleresults (protein twins), iteration %d" % it)
+        nu, aa = nu2, aa2
+    nu.free(); aa.free()

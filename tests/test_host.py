@@ -2,6 +2,7 @@
 without a device, and the synthetic generator is deterministic."""
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -277,3 +278,42 @@ extern "C" double sweep(long n, long *classDiff) {
     worst = lib.sweep(60000, ctypes.byref(diff))
     assert diff.value == 0, "a class differs outside the band"
     assert worst < 0.25, "the two routes differ by %.2f of the band" % worst
+
+
+def test_cli_exit_codes_separate_unsupported_from_failed():
+    """plass-hip's exit-code contract (no GPU needed with PLASSHIP_CLI_DRYRUN=1): 95 = the call is well-formed
+    for the reference but outside the GPU path (the wrapper hands it to the reference binary: linclust's rescorediagonal at the end of
+    `penguin guided_nuclassemble`, lib/mmseqs/data/workflow/linclust.sh:30), 96 = accepted in a dry run, 1 = a malformed call"""
+    exe = os.path.join(ROOT, "plass_amd", "plass-hip")
+    env = dict(os.environ, PLASSHIP_CLI_DRYRUN="1")
+    def rc(*args):
+        return subprocess.run([exe] + list(args), env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).returncode
+    assert rc("rescorediagonal", "q", "t", "p", "o", "--rescore-mode", "0", "--wrapped-scoring", "1", "-e", "0.001", "--min-seq-id", "0.9") == 95
+    assert rc("rescorediagonal", "q", "t", "p", "o", "--rescore-mode", "3", "--filter-hits", "1") == 95
+    assert rc("kmermatcher", "s", "p", "--kmer-per-seq", "21", "--mask", "1", "-k", "14") == 95
+    assert rc("kmermatcher", "s", "p", "--kmer-per-seq", "21") == 95                         # automatic k
+    assert rc("linclust", "a", "b", "c") == 95 and rc("clust", "a", "b", "c") == 95         # not hot-path modules
+    assert rc("rescorediagonal", "q", "t", "p", "o", "--rescore-mode", "3", "-e", "1e-5", "--min-seq-id", "0.9", "-c", "0", "--threads", "4") == 96
+    assert rc("kmermatcher", "s", "p", "-k", "22", "--kmer-per-seq", "60", "--alph-size", "nucl:5,aa:13", "--spaced-kmer-mode", "0", "--mask", "0",
+              "--sub-mat", "nucl:nucleotide.out,aa:blosum62.out", "--cov-mode", "1", "-c", "0.99", "--min-seq-id", "0.97") == 96
+    assert rc("kmermatcher", "s", "p", "-k", "14", "--kmer-per-seq", "60", "--no-such-flag", "1") == 1
+    assert rc("concatdbs", "a", "b", "c", "--preserve-keys") == 96
+
+
+def test_wrapper_routes_by_exit_code(tmp_path):
+    """plass_amd/plass-gpu-wrapper: hot-path modules go to plass-hip, exit 95 and every other module go to the reference binary, which is
+    exec'ed under the WRAPPER's name (the reference exports MMSEQS = argv[0], Application.cpp:198)"""
+    ref = tmp_path / "ref"
+    ref.write_text("#!/bin/bash\necho \"REF argv0=$0 args=$*\"\n")
+    ref.chmod(0o755)
+    w = os.path.join(ROOT, "plass_amd", "plass-gpu-wrapper")
+    log = tmp_path / "log"
+    env = dict(os.environ, PLASSHIP_CLI_DRYRUN="1", PLASS_REF_BIN=str(ref), PLASS_WRAPPER_LOG=str(log))
+    out = subprocess.run([w, "rescorediagonal", "a", "a", "p", "o", "--rescore-mode", "0", "--wrapped-scoring", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0 and "REF argv0=" in out.stdout and "args=rescorediagonal a a p o --rescore-mode 0" in out.stdout
+    out = subprocess.run([w, "createdb", "x", "y"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert "args=createdb x y" in out.stdout
+    out = subprocess.run([w, "kmermatcher", "s", "p", "-k", "14", "--kmer-per-seq", "60", "--bogus", "1"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 1 and "REF" not in out.stdout and "Unrecognized parameter" in out.stdout
+    lines = log.read_text().splitlines()
+    assert lines[0].startswith("reference  <- plass-hip exit 95") and "not a hot-path module" in lines[1] and lines[2].startswith("GPU path   exit 1")
