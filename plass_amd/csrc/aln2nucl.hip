@@ -29,6 +29,7 @@ __global__ __launch_bounds__(256) void aln2nuclKernel(A2NArgs a) {
     __syncthreads();
     for (uint64_t i = (uint64_t) blockIdx.x * 256 + threadIdx.x; i < a.n; i += (uint64_t) gridDim.x * 256) {
         AlnRec r = a.in[i];
+        if (!r.accepted) { a.out[i] = r; continue; }                // a hole of a sparse list stays a hole (common.hpp: plasship_alns)
         const char *nq = a.qn.data + a.qn.off[r.query], *nt = a.tn.data + a.tn.off[r.target];
         const bool qStartCodon = a.qa.data[a.qa.off[r.query]] == '*', tStartCodon = a.ta.data[a.ta.off[r.target]] == '*';
         if ((qStartCodon && r.qStart == 0) || (tStartCodon && r.dbStart == 0)) { a.err[0] = 1u; continue; }     // :103-106,123-126
@@ -92,20 +93,27 @@ extern "C" int plasship_aln2nucl(plasship_ctx *ctx, const plasship_seqdb *q_nucl
     if (differ) { setError("plasship_aln2nucl: nucleotide and protein DB have different keys"); return PLASSHIP_ERR_ARG; }
     std::unique_ptr<plasship_alns> holder(new plasship_alns());      // released to the caller on success only
     plasship_alns *o = holder.get();
-    o->nQueries = al->nQueries; o->nLines = al->nLines; o->nucl = true; o->addBacktrace = true; o->dbResidues = t_nucl->residues;
+    o->nQueries = al->nQueries; o->nLines = al->nLines; o->nSlots = al->nSlots; o->sparse = al->sparse; o->nucl = true; o->addBacktrace = true; o->dbResidues = t_nucl->residues;
     o->gappedOpen = par->gap_open; o->gappedExtend = par->gap_extend; o->qdb = q_nucl; o->tdb = t_nucl;
     DevBuf dMat, dErr;
-    if (o->d_qoff.alloc((al->nQueries + 1) * 8) != hipSuccess || o->d_recs.alloc(std::max<uint64_t>(al->nLines, 1) * sizeof(AlnRec)) != hipSuccess ||
+    if (o->d_qoff.alloc((al->nQueries + 1) * 8) != hipSuccess || o->d_recs.alloc(std::max<uint64_t>(al->nSlots, 1) * sizeof(AlnRec)) != hipSuccess ||
         dMat.alloc(123 * 123) != hipSuccess || dErr.alloc(8) != hipSuccess) { setError("plasship_aln2nucl: out of device memory"); return PLASSHIP_ERR_DEVICE; }
     PH_CHECK(hipMemcpyAsync(o->d_qoff.p, al->d_qoff.p, (al->nQueries + 1) * 8, hipMemcpyDeviceToDevice, st));
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(true), 123 * 123, hipMemcpyHostToDevice, st));
     PH_CHECK(hipMemsetAsync(dErr.p, 0, 8, st));
+    // The walk over 3 * alnLen nucleotide columns runs past the end of an entry when a protein twin is longer than its ORF / 3, like the
+    // reference's — into the entry that follows in the DB FILE.  A DB whose rewritten entries live in a shared heap (common.hpp: SeqHeap)
+    // is laid out like its file first (round 5: tests/test_gpu_deep.py::test_four_guided_iterations).
+    std::unique_ptr<plasship_seqdb> qPacked, tPacked;
+    if (!q_nucl->contiguous) { rc = packedCopyOf(ctx, q_nucl, qPacked); if (rc) return rc; }
+    if (t_nucl != q_nucl && !t_nucl->contiguous) { rc = packedCopyOf(ctx, t_nucl, tPacked); if (rc) return rc; }
+    const plasship_seqdb *qn = qPacked ? qPacked.get() : q_nucl, *tn = (t_nucl == q_nucl) ? qn : (tPacked ? tPacked.get() : t_nucl);
     A2NArgs a; memset(&a, 0, sizeof(a));
-    a.qn = q_nucl->view(); a.tn = t_nucl->view(); a.qa = q_aa->view(); a.ta = t_aa->view();
-    a.in = al->d_recs.as<AlnRec>(); a.out = o->d_recs.as<AlnRec>(); a.n = al->nLines; a.mat = dMat.as<signed char>();
+    a.qn = qn->view(); a.tn = tn->view(); a.qa = q_aa->view(); a.ta = t_aa->view();
+    a.in = al->d_recs.as<AlnRec>(); a.out = o->d_recs.as<AlnRec>(); a.n = al->nSlots; a.mat = dMat.as<signed char>();
     a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.err = dErr.as<uint32_t>();
     PH_CHECK(hipEventRecord(ctx->ev[0], st));
-    if (al->nLines) hipLaunchKernelGGL(aln2nuclKernel, dim3((unsigned) std::min<uint64_t>((al->nLines + 255) / 256, (uint64_t) ctx->numCU * 16)), dim3(256), 0, st, a);
+    if (al->nSlots) hipLaunchKernelGGL(aln2nuclKernel, dim3((unsigned) std::min<uint64_t>((al->nSlots + 255) / 256, (uint64_t) ctx->numCU * 16)), dim3(256), 0, st, a);
     PH_CHECK(hipEventRecord(ctx->ev[1], st));
     uint32_t herr[2] = {0, 0};
     PH_COPY_SYNC(st, herr, dErr.p, 8, hipMemcpyDeviceToHost);

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void assembleBigKernel(AsmArgs a) {
             x.seqId = (float) ((double) ids / ((double) alnLen + 0.5));
             x.score = (int) (scorePerCol * 100);
             x.qStart = r.qStart; x.qEnd = r.qEnd; x.qLen = (uint32_t) r.qLen; x.dbStart = r.dbStart; x.dbEnd = r.dbEnd; x.dbLen = (uint32_t) r.dbLen;
-            x.state = 0; x.pad = 0;
+            x.state = r.accepted ? 0u : 2u; x.pad = 0;                                    // a hole of a sparse list was never queued
             it[i] = x;
         }
         // the query starts in the middle of its arena slice
@@ -568,7 +568,7 @@ __global__ __launch_bounds__(64) void assembleNuclKernel(AsmArgs a) {
                 x.dbStart = (int) (x.dbLen - (unsigned) x.dbEnd - 1);
                 x.dbEnd = (int) (x.dbLen - dbs - 1);
             }
-            x.state = (GUIDED && x.seqId < a.seqIdThr) ? 2u : 0u;     // guided: re-evaluated on the nucleotide level, never queued
+            x.state = (!r.accepted || (GUIDED && x.seqId < a.seqIdThr)) ? 2u : 0u;     // a hole of a sparse list; guided: re-evaluated on the nucleotide level, never queued
             it[i] = x;
         }
         __syncthreads();
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(NT_BLOCK, 4) void assembleNuclThreadKernel(AsmArgs 
                 x.dbStart = (int) (x.dbLen - (unsigned) x.dbEnd - 1);
                 x.dbEnd = (int) (x.dbLen - dbs - 1);
             }
-            x.state = (GUIDED && x.seqId < a.seqIdThr) ? 2u : 0u;
+            x.state = (!r.accepted || (GUIDED && x.seqId < a.seqIdThr)) ? 2u : 0u;
             it[i] = x;
             if (x.state == 0) heapPush(hp, nHeap, i, it, cmp);
         }
@@ -1071,8 +1071,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             xQStart = r.qStart; xQEnd = r.qEnd; xQLen = (uint32_t) r.qLen; xDbStart = r.dbStart; xDbEnd = r.dbEnd; xDbLen = (uint32_t) r.dbLen;
             // the self alignment is popped and discarded without any effect (selectFragmentToExtend: isNotIdentity):
             // it never enters the register queue
-            xState = (xTarget == id) ? 2u : 0u;
-            xTOff = seqOff(a.s, xTarget); xTLen = seqLen(a.s, xTarget);      // fetched up front: one memory round trip less per pop
+            xState = (xTarget == id || !r.accepted) ? 2u : 0u;                 // (nor does a hole of a sparse list)
+            if (xState == 0) { xTOff = seqOff(a.s, xTarget); xTLen = seqLen(a.s, xTarget); }      // fetched up front: one memory round trip less per pop
         }
         // tie-break of CompareResultByScore (smaller key wins) as a rank among the group's targets
         const uint32_t tRank = groupRank<G>(xTarget);
@@ -1224,7 +1224,7 @@ __global__ __launch_bounds__(256) void arenaSumKernel(const AlnRec *__restrict__
         const AlnRec r = recs[i];
         const uint32_t id = r.query;
         uint32_t add = 0, addAa = 0; bool can = false;
-        if (r.target != id) {
+        if (r.target != id && r.accepted) {                                              // (a hole of a sparse list counts for nothing)
             add = (uint32_t) r.dbLen; addAa = (uint32_t) r.dbLen / 3 + 2;               // guided: a twin fragment is at most dbLen/3 + 1 residues
             // exact pre-screen: the first extension of a query is decided by coordinates the alignment already
             // carries (selectFragmentToExtend + the two geometry tests, assembleresult.cpp:40-57,211-263); if no
@@ -1534,12 +1534,17 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
 // mode 1: a packed copy in an exact buffer (packedCopyOf)
 static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                              const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                             const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent, int mode) {
+                             const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent, int mode, bool noAppend = false) {
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const SeqView sv = db->view();
     const bool useHeaps = mode == 0 && tuneInt("DBHEAP", 1) == 1;
-    const bool mayAppend = useHeaps && db->heap != nullptr;
+    // noAppend (the protein-guided path, round 5): the DB is written back to back in key order — the layout of the DB file.  The
+    // reference's proteinaln2nucl and guidedassembleresults read PAST the end of an entry when a protein twin and its ORF / 3 differ in
+    // length, i.e. into the entry that FOLLOWS in the data file; behind an entry appended to a shared heap lies
+    // whatever was appended next.  tests/test_gpu_deep.py::test_four_guided_iterations (round 5) found the difference in the third
+    // guided iteration, the first one whose input DB had appended entries: 3 bytes of one alignment DB in 382 MB.
+    const bool mayAppend = useHeaps && db->heap != nullptr && !noAppend;
     DevBuf dOutBytes, dKeep, dOutOff, dKeepPos, dMaxLen, dAppBytes, dAppOff;
     if (dOutBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dKeep.alloc(((size_t) N + 1) * 4) != hipSuccess || dOutOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
         dKeepPos.alloc(((size_t) N + 2) * 8) != hipSuccess || dMaxLen.alloc(4) != hipSuccess ||
@@ -1623,8 +1628,8 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
 }
 int plasship::buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                             const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                            const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent) {
-    return buildOutputDBImpl(ctx, db, dFlags, dNewLen, dNewStart, dArena, keepTarget, dTmp, tmpBytes, out, dExtra, hExtra, extraBytes, doneEvent, 0);
+                            const void *dExtra, void *hExtra, size_t extraBytes, hipEvent_t doneEvent, bool noAppend) {
+    return buildOutputDBImpl(ctx, db, dFlags, dNewLen, dNewStart, dArena, keepTarget, dTmp, tmpBytes, out, dExtra, hExtra, extraBytes, doneEvent, 0, noAppend);
 }
 int plasship::packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::unique_ptr<plasship_seqdb> &out) {
     const uint32_t N = (uint32_t) db->n;
@@ -1718,7 +1723,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
-    const uint64_t nLines = al->nLines;
+    const uint64_t nLines = al->nSlots;                     // record slots (a sparse list: holes included, common.hpp); al->nLines of them are alignments
     DevBuf dLeftCap, dBytes, dArenaOff, dTmp, dItems, dFlags, dNewLen, dNewStart, dMat, dStats, dArena;
     const size_t tmpBytes = exclusiveScanTmpBytes((size_t) N + 2);
     if (dLeftCap.alloc(((size_t) N + 1) * 4) != hipSuccess || dBytes.alloc(((size_t) N + 1) * 8) != hipSuccess || dArenaOff.alloc(((size_t) N + 2) * 8) != hipSuccess ||
@@ -1746,7 +1751,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     PH_CHECK(hipMemsetAsync(dQSum.p, 0, ((size_t) N + 1) * 8, st));
     PH_CHECK(hipMemsetAsync(dQCan.p, 0, ((size_t) N + 1) * 4, st));
     if (guided) PH_CHECK(hipMemsetAsync(dQSumAa.p, 0, ((size_t) N + 1) * 8, st));
-    if (al->nLines) hipLaunchKernelGGL(arenaSumKernel, dim3((unsigned) std::min<uint64_t>((al->nLines + 255) / 256, (uint64_t) ctx->numCU * 32)), dim3(256), 0, st, al->d_recs.as<AlnRec>(), (uint64_t) al->nLines,
+    if (nLines) hipLaunchKernelGGL(arenaSumKernel, dim3((unsigned) std::min<uint64_t>((nLines + 255) / 256, (uint64_t) ctx->numCU * 32)), dim3(256), 0, st, al->d_recs.as<AlnRec>(), (uint64_t) nLines,
                                        (uint64_t) par->max_seq_len, dQSum.as<unsigned long long>(), guided ? dQSumAa.as<unsigned long long>() : (unsigned long long *) nullptr, dQCan.as<uint32_t>(),
                                        (nucl && !guided) ? 1 : 0);
     if (N) hipLaunchKernelGGL(arenaSizeKernel, dim3(std::min<uint32_t>((N + 255) / 256, 8192)), dim3(256), 0, st, sv, al->d_qoff.as<uint64_t>(), (const unsigned long long *) dQSum.as<unsigned long long>(),
@@ -1782,8 +1787,12 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     a.mid32List = dMid32List.as<uint32_t>(); a.nMid32 = cnts[1];
     a.midList = dMidList.as<uint32_t>(); a.nMid = cnts[2];
     a.bigList = dBigList.as<uint32_t>(); a.nBig = cnts[3];
+    std::unique_ptr<plasship_seqdb> aaPacked;                // guided: the twins are read past their end like the reference does (buildOutputDBImpl, noAppend):
+    if (guided && !aaDb->contiguous) {                       // a twin DB that lives in a shared heap is laid out like its DB file first
+        const int rcP = packedCopyOf(ctx, aaDb, aaPacked); if (rcP) return rcP;
+    }
     if (guided) {
-        a.aa = aaDb->view(); a.aaArena = dAaArena.as<char>(); a.aaArenaOff = dAaArenaOff.as<uint64_t>(); a.aaLeftCap = dAaLeftCap.as<uint32_t>();
+        a.aa = (aaPacked ? aaPacked.get() : aaDb)->view(); a.aaArena = dAaArena.as<char>(); a.aaArenaOff = dAaArenaOff.as<uint64_t>(); a.aaLeftCap = dAaLeftCap.as<uint32_t>();
         a.aaNewLen = dAaNewLen.as<uint32_t>(); a.aaNewStart = dAaNewStart.as<uint64_t>();
     }
     DevBuf dHeap, dNeed, dRedo[2], dCnt;
@@ -1854,10 +1863,12 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     } else {
     // (round 4: the protein tiers' lists in work classes like the nucleotide list changed nothing — 82.2 against 81.0 ms for the stage: the
     //  tiers already group the queries by queue size, and id order keeps a wavefront's alignment records adjacent; profiles/r04_ab_knobs.txt)
-    PH_CHECK(hipEventRecord(ctx->ev[2], st));
     // wavefronts per SIMD of the register-queue kernels (PLASSHIP_TUNE_ASM16 / ASM64): the grid is what the CUs hold at once
     const int w16 = tuneInt("ASM16", 5), w64 = tuneInt("ASM64", 4);      // round 3 (after the copy tails went word-wise): 16.6 ms at 5 wavefronts, 17.0 at 6, 18.0 at 4
     const dim3 g16(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) w16)), g64(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) w64));
+    // (round 5: the four tiers — disjoint queries — launched side by side on four streams, so that one tier's tail of long queues lies under
+    //  the next tier: 88.8 against 82.7 ms for the stage; the tiers' wavefronts evict each other's lines.  profiles/r05_ab_knobs.txt)
+    PH_CHECK(hipEventRecord(ctx->ev[2], st));
     if (a.nSmall) {
         if (w16 == 6) hipLaunchKernelGGL((assembleGroupKernel<16, 6>), g16, dim3(256), 0, st, a);
         else if (w16 == 5) hipLaunchKernelGGL((assembleGroupKernel<16, 5>), g16, dim3(256), 0, st, a);
@@ -1889,11 +1900,12 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
         arenaP = dGathered.as<char>(); aaArenaP = dGatheredAa.as<char>();
     }
     int rcOut = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), arenaP, par->keep_target, dTmp.p, tmpBytes, &o,
-                              dStats.p, hs, 128, guided ? (hipEvent_t) nullptr : ctx->ev[1]);
+                              dStats.p, hs, 128, guided ? (hipEvent_t) nullptr : ctx->ev[1], guided);
     if (rcOut != PLASSHIP_OK) return rcOut;
     std::unique_ptr<plasship_seqdb> holdO(o), holdAa;              // released to the caller on success only
     if (guided) {
-        rcOut = buildOutputDB(ctx, aaDb, dFlags.as<uint32_t>(), dAaNewLen.as<uint32_t>(), dAaNewStart.as<uint64_t>(), aaArenaP, par->keep_target, dTmp.p, tmpBytes, &oAa);
+        rcOut = buildOutputDB(ctx, aaDb, dFlags.as<uint32_t>(), dAaNewLen.as<uint32_t>(), dAaNewStart.as<uint64_t>(), aaArenaP, par->keep_target, dTmp.p, tmpBytes, &oAa,
+                              nullptr, nullptr, 0, nullptr, true);
         if (rcOut != PLASSHIP_OK) return rcOut;
         holdAa.reset(oAa);
     }
@@ -1908,7 +1920,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
             stats->tier_alignments[t] = hs[3 + 3 * t]; stats->tier_query_residues[t] = hs[4 + 3 * t]; stats->tier_rescored_residues[t] = hs[5 + 3 * t];
         }
         stats->ms_assemble_kernel = sum;
-        stats->n_alignments = nLines; stats->rescored_residues = hs[2];
+        stats->n_alignments = al->nLines; stats->rescored_residues = hs[2];
         stats->db_appended_bytes = o->buildAppendedBytes; stats->db_copied_bytes = o->buildCopiedBytes;
     }
     *out = holdO.release();

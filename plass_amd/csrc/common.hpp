@@ -208,13 +208,20 @@ struct plasship_cands {
 
 struct plasship_alns {
     size_t nQueries = 0;
-    uint64_t nLines = 0;
+    uint64_t nLines = 0;           // ACCEPTED alignments (what plasship_alns_count reports, what a DB file holds)
+    // Round 5: a list made by plasship_rescore is SPARSE — one record slot per candidate pair, in the candidate list's own CSR, a rejected
+    // pair's record carrying accepted == 0 — because 95 % of the pairs of an assembly iteration are accepted: compacting the list moved
+    // 38 GB per iteration (8 ms at 50 M reads) to close 5 % of holes.  Every kernel that walks a query's records skips the holes (the
+    // extension kernels' queue fill, arenaSumKernel, findStartVoteKernel, aln2nuclKernel); the host paths (download, DB files) take a
+    // dense copy first (denseAlnsCopy, rescore.hip).  Lists read from DB files or made dense are not sparse: nSlots == nLines.
+    uint64_t nSlots = 0;           // records in d_recs (holes included)
+    bool sparse = false;
     bool nucl = false;
     bool addBacktrace = false;
     uint64_t dbResidues = 0;       // of the target DB (E-value area)
     int gappedOpen = 0, gappedExtend = 0;   // != 0: E-values of the gapped nucleotide evaluer (list made by plasship_aln2nucl)
     plasship::DevBuf d_qoff;       // uint64 [nQueries+1]
-    plasship::DevBuf d_recs;       // AlnRec [nLines]
+    plasship::DevBuf d_recs;       // AlnRec [nSlots]
     // DBs the list refers to (ids -> keys for text output); they must outlive this object
     const plasship_seqdb *qdb = nullptr, *tdb = nullptr;
 };
@@ -249,7 +256,7 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
 int packedCopyOf(plasship_ctx *ctx, const plasship_seqdb *db, std::unique_ptr<plasship_seqdb> &out);
 int buildOutputDB(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
                   const char *dArena, int keepTarget, void *dTmp, size_t tmpBytes, plasship_seqdb **out,
-                  const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr);
+                  const void *dExtra = nullptr, void *hExtra = nullptr, size_t extraBytes = 0, hipEvent_t doneEvent = nullptr, bool noAppend = false);
 // ---- host boundary (core.hip): bulk copies through the context's pinned double buffer, on the context stream ----
 // H2D of `total` bytes the caller produces chunk by chunk: produce(dst, byteOffset, bytes) fills a pinned chunk (consecutive chunks,
 // in order; it may use the host threads) while the previous chunk is in flight.  Returns after the last copy has completed.
@@ -266,4 +273,7 @@ int stagedCopyToDevice(plasship_ctx *ctx, void *dDst, const void *hSrc, uint64_t
 int stagedCopyToHost(plasship_ctx *ctx, void *hDst, const void *dSrc, uint64_t bytes);
 // sets *differ when two key arrays (device, n entries) are not identical
 int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, size_t n, bool *differ);
+// dense (hole-free) copy of an alignment list's CSR and records on the device (rescore.hip); for a list that is not sparse the buffers
+// stay empty and *qoff / *recs point at the list's own arrays
+int denseAlnsCopy(plasship_ctx *ctx, const plasship_alns *a, DevBuf &qoffBuf, DevBuf &recsBuf, const uint64_t **qoff, const AlnRec **recs);
 }

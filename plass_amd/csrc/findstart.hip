@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void findStartVoteKernel(SeqView s, const uint
         uint32_t votes = 1, stops = (posM > 0 && seq[posM - 1] == '*') ? 1u : 0u;
         for (uint64_t j = a0; j < a1; j++) {
             const AlnRec r = recs[j];
-            if (r.target == q) continue;
+            if (r.target == q || !r.accepted) continue;        // the self hit; a hole of a sparse list (common.hpp)
             votes++;
             if (r.qStart >= posM && posM <= r.qEnd) {
                 const int dbMPos = r.dbStart + (posM - r.qStart);
@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void findStartVoteKernel(SeqView s, const uint
             atomicMax(&addStop[q], posM);
             for (uint64_t j = a0; j < a1; j++) {
                 const AlnRec r = recs[j];
-                if (r.target == q) continue;
+                if (r.target == q || !r.accepted) continue;
                 if (r.qStart >= posM && posM <= r.qEnd) atomicMax(&addStop[r.target], r.dbStart + (posM - r.qStart));
             }
         }

@@ -181,9 +181,12 @@ extern "C" void plasship_alns_free(plasship_ctx *ctx, plasship_alns *a) {
 
 static int fetchAlns(plasship_ctx *ctx, const plasship_alns *a, std::vector<uint64_t> &qoff, std::vector<AlnRec> &recs) {
     qoff.resize(a->nQueries + 1); recs.resize(a->nLines);
+    // a list made by plasship_rescore is sparse (common.hpp: plasship_alns): the host sees a dense copy, made on the device
+    DevBuf dQoff, dRecs; const uint64_t *pq = nullptr; const AlnRec *pr = nullptr;
+    int rc = denseAlnsCopy(ctx, a, dQoff, dRecs, &pq, &pr); if (rc) return rc;
     PH_CHECK(plasship::streamSync(ctx->stream));
-    int rc = stagedCopyToHost(ctx, qoff.data(), a->d_qoff.p, (a->nQueries + 1) * 8); if (rc) return rc;
-    return stagedCopyToHost(ctx, recs.data(), a->d_recs.p, a->nLines * sizeof(AlnRec));
+    rc = stagedCopyToHost(ctx, qoff.data(), pq, (a->nQueries + 1) * 8); if (rc) return rc;
+    return stagedCopyToHost(ctx, recs.data(), pr, a->nLines * sizeof(AlnRec));
 }
 
 extern "C" int plasship_alns_download(plasship_ctx *ctx, const plasship_alns *a, plasship_aln_record *out) {
@@ -305,7 +308,7 @@ extern "C" int plasship_alns_read(plasship_ctx *ctx, const plasship_seqdb *db, c
     if (bad == 2) { setError("alignment line for a key that is not in the DB"); return PLASSHIP_ERR_ARG; }
     std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
     plasship_alns *a = holder.get();
-    a->nQueries = nQ; a->nLines = recs.size(); a->nucl = db->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES; a->dbResidues = db->residues;
+    a->nQueries = nQ; a->nLines = recs.size(); a->nSlots = recs.size(); a->nucl = db->dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES; a->dbResidues = db->residues;
     a->qdb = db; a->tdb = db;
     if (a->d_qoff.alloc((nQ + 1) * 8) != hipSuccess || a->d_recs.alloc(std::max<size_t>(recs.size(), 1) * sizeof(AlnRec)) != hipSuccess) {
         setError("plasship_alns_read: out of device memory"); return PLASSHIP_ERR_DEVICE;

@@ -201,6 +201,15 @@ static int buildLineLists(plasship_ctx *ctx, const uint32_t *dTags, uint64_t cap
     return PLASSHIP_OK;
 }
 
+// Sharded run, how the k-mer records reach the rank that owns their level-1 bucket:
+//   exchange (rounds 1-4): a rank extracts 1/W of the sequences and ships the level-1 lines of the other ranks' buckets (all-to-all);
+//   owner-filtered (round 5; the reference's own MPI scheme — every rank scans all sequences and keeps its hash range,
+//   kmermatcher.cpp:312,736-778): every rank extracts ALL sequences (the DB is replicated anyway) and level 1 drops what it does not
+//   own — no exchange 1 at all.  Extraction is not sharded then (75 of 350 ms per iteration at 50 M reads) but nothing crosses the
+//   links: by the cost model of DESIGN.md section 6 the better choice up to 4 ranks, where one xGMI link per pair carries the exchange.
+// PLASSHIP_TUNE_SHARD_EXTRACT: 1 = exchange, 2 = owner-filtered, unset = by the number of ranks.
+static bool shardOwnerFiltered(int W) { const int m = tuneInt("SHARD_EXTRACT", 0); return m == 2 || (m != 1 && W <= 4); }
+
 constexpr int KM_RETRY_EARLY_OVERFLOW_CHECK = -1000;     // internal: kmermatchImpl is to be called again, waiting for the extraction's overflow count
 // What the line path hands to the run reduction
 struct LinesOut { void *triples = nullptr; uint64_t nTriples = 0, Nk = 0, Nm = 0; std::vector<int64_t> stalePos; uint32_t staleT = 0; float msSort1 = 0, msGroup = 0, msSort2 = 0, msPart = 0; int nPart = 1;
@@ -350,13 +359,14 @@ static void moveBuf(DevBuf &dst, DevBuf &src) { dst.release(); dst.p = src.p; ds
 template <bool NUCL, bool LONG>
 static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_kmermatch_params *par, const LineGeo &geo, uint64_t total,
                           DevBuf &dA, DevBuf &dB, const DevBuf &dSlotOff, const DevBuf &dKStats, const ExtractArgs &ea, int keyBits, LinesOut &res,
-                          const uint32_t *dLateOverflow) {
+                          const uint32_t *dLateOverflow, bool filtered) {
     typedef Rec<LONG> R;
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
     const int numCU = ctx->numCU;
     const plasship_comm *cm = commOf(ctx);
     const int W = cm ? cm->world : 1, rk = cm ? cm->rank : 0;
+    const bool exch = cm && !filtered;                       // exchange 1 happens (see shardOwnerFiltered); otherwise the buffers are a single GPU's
     // stage boundaries are events read when the call is over (kmermatchImpl): nobody waits for the stream just to time a stage
     const int valueShift = std::max(0, keyBits - 11);         // VH_BINS = 2^11 monotone bins
     // ---- hash partition (replaces sort #1): level 1 over the slot array, level 2 over every level-1 bucket's line list ----
@@ -381,6 +391,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         a.in = dA.p; a.out = dB.p; a.tags = dTag1.as<uint32_t>(); a.totalLines = geo.totalLines; a.lastValidAll = geo.lastValid; a.pieceLines = geo.PL1; a.nb = geo.nb1;
         a.key.shift = geo.b1 ? 64 - geo.b1 : 63; a.key.rangeBits = 0; a.key.repBase = 0;
         a.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr; a.valueHist = dVHist.as<uint32_t>(); a.valueShift = valueShift;
+        if (cm && filtered) { a.keepLo = bLo; a.keepHi = bHi; }      // every rank has extracted everything: keep the records of the own buckets
         PH_CHECK(hipEventRecord(ctx->ev[8], st));
         const int rc = launchLinePart<NUCL, LONG, KEY_HASH, false, true>(ctx, a, geo.nP1); if (rc) return rc;
         PH_CHECK(hipEventRecord(ctx->ev[9], st));
@@ -390,7 +401,12 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     void *l1Recs = dB.p; const uint32_t *l1List = dList1.as<uint32_t>(); const uint32_t *l1Start = dStart1.as<uint32_t>() + bLo; uint64_t l1Lines = geo.cap1;
     const uint32_t *l1Tags = dTag1.as<uint32_t>();
     uint64_t NkAll = 0;
-    if (cm) {
+    if (cm && filtered && NUCL) {              // the globally smallest key (first-run quirk of the group kernel): every rank saw its own buckets' records
+        uint64_t mk = 0; PH_COPY_SYNC(st, &mk, dMinKey.p, 8, hipMemcpyDeviceToHost);
+        rc = commAllReduceMinU64(ctx, &mk, 1); if (rc) return rc;
+        PH_COPY_SYNC(st, dMinKey.p, &mk, 8, hipMemcpyHostToDevice);
+    }
+    if (exch) {
         // ---- exchange 1: the lines of every level-1 bucket to the bucket's owner ----
         std::vector<uint32_t> hStart1(geo.nb1 + 1);
         PH_COPY_SYNC(st, hStart1.data(), dStart1.p, ((size_t) geo.nb1 + 1) * 4, hipMemcpyDeviceToHost);
@@ -456,9 +472,9 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     DevBuf dL2;                                               // sharded run: level-2 output (a single GPU writes level 2 into dA)
     res.nPart = 1;
     if (geo.nb2) {
-        const uint64_t cap2 = cm ? l1Lines + (uint64_t) nbL * geo.nb2 : geo.cap2;
+        const uint64_t cap2 = exch ? l1Lines + (uint64_t) nbL * geo.nb2 : geo.cap2;
         void *l2Out = dA.p;
-        if (cm) { if (dL2.alloc(std::max<uint64_t>(cap2, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; } l2Out = dL2.p; }
+        if (exch) { if (dL2.alloc(std::max<uint64_t>(cap2, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the k-mer record arrays"); return PLASSHIP_ERR_DEVICE; } l2Out = dL2.p; }
         if (dTag2.alloc(std::max<uint64_t>(cap2, 1) * 4) != hipSuccess || dList2.alloc(std::max<uint64_t>(cap2, 1) * 4) != hipSuccess) { setError("kmermatch: out of device memory for the line lists"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(planListKernel, dim3(1), dim3(1024), 0, st, l1Start, nbL, geo.PL2, geo.nb2, dPieces2.as<LinePiece>(), dNP2.as<uint32_t>(),
                            dRegBeg.as<uint64_t>(), dRegEnd.as<uint64_t>(), dTot2.as<uint64_t>());
@@ -485,7 +501,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     // array); sharded run: the receive buffer when there are two levels, else a buffer of its own
     DevBuf dArena;
     void *arenaBuf;
-    if (cm) {
+    if (exch) {
         if (geo.nb2) arenaBuf = dRx.p;
         else { if (dArena.alloc(std::max<uint64_t>(finalCap, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; } arenaBuf = dArena.p; }
     } else arenaBuf = geo.nb2 ? dB.p : dA.p;
@@ -527,7 +543,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     for (uint32_t j = 0; j < gGrid; j++) NmLocal += hOutCnt[j];
     uint64_t Nm = NmLocal;
     const uint64_t NkLocal = ks[1] + ks[3];                  // records the extraction kernels of this rank wrote (sentinels excluded)
-    const uint64_t Nk = cm ? NkAll : NkLocal;                // ... and of the whole run
+    const uint64_t Nk = exch ? NkAll : NkLocal;              // ... and of the whole run (owner-filtered: every rank extracted everything)
     std::vector<uint64_t> hVHistG(hVHist.begin(), hVHist.end());
     if (cm) {
         // the stale-record check below is a property of the WHOLE run: N_m, the last (rep, target) run and the value histogram are
@@ -546,6 +562,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         PH_COPY_SYNC(st, hLastRun, dLastRun.p, 32, hipMemcpyDeviceToHost);
     }
     res.Nk = NkLocal;                                         // sharded run: the records THIS rank extracted (the ranks' sum is the run's N_k)
+    if (cm && filtered) { res.Nk = 0; for (uint32_t b = 0; b < VH_BINS; b++) res.Nk += hVHist[b]; }      // ... owner-filtered: the records it KEPT (level 1 counts each in its value histogram)
     res.Nm = NmLocal;
     PH_CHECK(hipEventRecord(ctx->ev[7], st));
     PH_TRACE(st, "kmermatch: group (line store)");
@@ -607,13 +624,13 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     // ---- sort #2: range partition of the grouped records by rep id over the line store + aggregation / sort per bucket ----
     PH_CHECK(hipEventRecord(ctx->ev[12], st));
     // the hash-bucketed records are dead now (the group kernel's arenas live in another buffer): free them for the rep side
-    if (cm) { dL2.release(); if (!geo.nb2) dRx.release(); }
+    if (exch) { dL2.release(); if (!geo.nb2) dRx.release(); }
     else (finalRecs == dA.p ? dA : dB).release();
     dTag1.release(); dList1.release(); dTag2.release(); dList2.release(); dRxList.release();
     std::vector<std::pair<uint64_t, uint64_t>> arenas(gGrid);                 // the arenas are dense segments: (first line, records)
     for (uint32_t j = 0; j < gGrid; j++) arenas[j] = std::make_pair(hArena[j] / RPL, hOutCnt[j]);
     DevBuf dTriples, dRepStart; uint64_t nTriples = 0;
-    auto arenasConsumed = [&]() { if (cm) { if (geo.nb2) dRx.release(); else dArena.release(); } else (arenaBuf == dA.p ? dA : dB).release(); };
+    auto arenasConsumed = [&]() { if (exch) { if (geo.nb2) dRx.release(); else dArena.release(); } else (arenaBuf == dA.p ? dA : dB).release(); };
     // (sharded nucleotide run: the triples leave for their owners with the rank word of their top member, see TripleX)
     if (NUCL && cm) rc = repSortLines<NUCL, LONG, false, NUCL>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, &dRepStart);
     else rc = repSortLines<NUCL, LONG, false>(ctx, arenaBuf, arenas, NmLocal, N, 0u, N, 0, arenasConsumed, dTriples, nTriples, cm ? &dRepStart : nullptr);
@@ -812,7 +829,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     if (exclusiveScanU32(st, dBound.as<uint32_t>(), dSlotOff.as<uint64_t>(), N, dScanTmp.p, scanTmpBytes)) { setError("kmermatch: scan failed"); return PLASSHIP_ERR_DEVICE; }
     uint64_t total = 0;
     uint32_t sLo = 0, sHi = N; uint64_t slotBias = 0, totalAll = 0;
-    if (cm) {
+    const bool filtered = cm && shardOwnerFiltered(W);       // every rank extracts all sequences and keeps its own buckets' records
+    if (cm && !filtered) {
         DevBuf dSplit; std::vector<uint64_t> hSplit(2 * (size_t) W + 2);
         if (dSplit.alloc(hSplit.size() * 8) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         hipLaunchKernelGGL(splitIdsKernel, dim3(1), dim3(256), 0, st, dSlotOff.as<uint64_t>(), N, W, dSplit.as<uint64_t>());
@@ -823,6 +841,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     } else {
     PH_CHECK(hipMemcpyAsync(&total, dSlotOff.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PH_CHECK(plasship::streamSync(st));
+    totalAll = total;
     }
     const uint32_t nMine = sHi - sLo;
 
@@ -832,7 +851,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     const LineGeo geo = lineGeometry(total, LONG, ctx->numCU, cm ? totalAll : 0, W);
     // single GPU: both buffers serve level 1 and level 2 (and the group kernel's arenas); sharded run: the slot array / level-1 output,
     // and the packed send buffer of exchange 1 (at most cap1 lines)
-    const uint64_t recCap = std::max<uint64_t>(total, (uint64_t) RPL * (cm ? geo.cap1 : std::max(geo.cap1, geo.cap2)));
+    const uint64_t recCap = std::max<uint64_t>(total, (uint64_t) RPL * ((cm && !filtered) ? geo.cap1 : std::max(geo.cap1, geo.cap2)));
     if (dA.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess || dB.alloc(std::max<uint64_t>(recCap, 1) * sizeof(R)) != hipSuccess) {
         setError("kmermatch: out of device memory for the k-mer record arrays (" + std::to_string(2 * recCap * sizeof(R)) + " bytes)"); return PLASSHIP_ERR_DEVICE;
     }
@@ -867,7 +886,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     // ---- selected-window cache (section 2c): which sequences keep last call's selection, and where this call's selection is kept ----
     plasship_ctx::KmCache &kc = ctx->kmCache;
     const bool fastIndex = !NUCL && k <= 14 && ea.powers[1] <= 16;      // kmerIndexCore
-    const bool cacheEligible = !NUCL && !LONG && !cm && fastIndex && k <= 16 && par->kmers_per_seq >= 1 && par->kmers_per_seq <= (int) KMC_POS + 1 && par->kmers_per_seq_scale == 0.0f &&
+    const bool cacheEligible = !NUCL && !LONG && (!cm || filtered) && fastIndex && k <= 16 && par->kmers_per_seq >= 1 && par->kmers_per_seq <= (int) KMC_POS + 1 && par->kmers_per_seq_scale == 0.0f &&
                                tuneInt("KMCACHE", 1) == 1;      // PLASSHIP_TUNE_KMCACHE=2 switches the cache off
     const bool cacheReuse = cacheEligible && kc.valid && kc.n == N && kc.gen == db->parentGen && db->d_changed.p && kc.k == k && kc.alph == par->alphabet_size &&
                             kc.kps == par->kmers_per_seq && kc.ignoreMulti == par->ignore_multi_kmer && kc.hashShift == par->hash_shift && !overflowCheckEarly;
@@ -954,6 +973,8 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         const uint32_t wide = std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU);
         // tiers 0 and 1 both queue into dOvIds
         if (twoLists) {
+            // (round 5: tiers 0 and 1 — disjoint lists — and the cached kernel side by side on three streams: extraction 81.7 against 81.2 ms
+            //  per iteration, nothing gained; profiles/r05_ab_knobs.txt)
             if (tuneInt("TIER0_WPE", 5) == 6) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 6>), dim3(wide), dim3(64), 0, st, ea);
             else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256>), dim3(wide), dim3(64), 0, st, ea);
             ExtractArgs e1 = ea; e1.waveList = dLongList.as<uint32_t>(); e1.waveCount = dLongCount.as<uint32_t>();
@@ -1015,7 +1036,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         int keyBitsL = 0;
         if (NUCL) keyBitsL = 2 * k; else { long double v = 1; for (int i = 0; i < k; i++) v *= (long double) (alph - 1); while (keyBitsL < 63 && (long double) (1ULL << keyBitsL) < v) keyBitsL++; }
         LinesOut lo;
-        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, (nMine && !overflowPossible) ? dLastCnt.as<uint32_t>() : nullptr);
+        int rcL = kmermatchLines<NUCL, LONG>(ctx, db, par, geo, total, dA, dB, dSlotOff, dKStats, ea, keyBitsL, lo, (nMine && !overflowPossible) ? dLastCnt.as<uint32_t>() : nullptr, filtered);
         if (rcL) return rcL;                                  // (KM_RETRY_EARLY_OVERFLOW_CHECK: the caller starts over)
         std::unique_ptr<plasship_cands> holderL; uint64_t NcL = 0; float msReduceL = 0;
         rcL = reduceToCandidates<NUCL, LONG>(ctx, db, lo.triples, lo.nTriples, lo.stalePos, lo.staleT, holderL, NcL, msReduceL, true);

@@ -104,6 +104,8 @@ struct LinePartArgs {
     int direct;                                  // records of lines that complete inside a tile go straight to HBM (see linePartKernel)
     unsigned long long *minKey;                  // optional (EXTRAS, NUCL): global minimum of (kmer | BIT63) (first-run quirk)
     uint32_t *valueHist; int valueShift;         // optional (EXTRAS)
+    uint32_t keepLo, keepHi;                     // (EXTRAS, keepHi != 0) owner-filtered extraction of a sharded run: records of the buckets outside
+                                                 // [keepLo, keepHi) are dropped here — another rank, which extracted the same sequences, keeps them
 };
 
 static inline size_t linePartLdsBytes(uint32_t nb, size_t recBytes, bool extras) {
@@ -171,6 +173,7 @@ __global__ __launch_bounds__(LP_BLOCK) void linePartKernel(LinePartArgs a) {
                 {
                     if (!isSentinel(rec[u])) {
                         const uint32_t b = lineBucket<NUCL, MODE>(a.key, rec[u].kmer, nb);
+                        if (EXTRAS && a.keepHi && (b < a.keepLo || b >= a.keepHi)) continue;
                         bk[u] = b; sq[u] = atomicAdd(&cnt[b], 1u); pending |= 1u << u;
                         if (EXTRAS) {
                             if (a.valueHist) atomicAdd(&vh[valueBin<NUCL>(rec[u].kmer, a.valueShift)], 1u);

@@ -32,8 +32,7 @@ struct RescoreArgs {
     const uint64_t *qoff;        // CSR over queries (only for nHits)
     const CandHit *hits;
     uint64_t nHits;
-    AlnRec *out;                 // [nHits]
-    uint32_t *accept;            // [nHits]
+    AlnRec *out;                 // [nHits]: the record of pair h in slot h, accepted or not (sparse list, common.hpp)
     const uint32_t *minScore;    // [maxQLen+1] minimum raw score passing -e for that query length
     uint32_t minScoreLen;
     const signed char *mat;      // 123*123 in global, staged to LDS
@@ -337,7 +336,6 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
         rec.accepted = accepted ? 1 : 0; rec.btKind = 1;        // ungapped: the backtrace is one run of alnLen 'M'
         if (sl == 0) {
             a.out[h] = rec;
-            a.accept[h] = accepted ? 1u : 0u;
             accLocal += accepted ? 1 : 0;
         }
     }
@@ -348,8 +346,10 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
     }
 }
 
-// four lanes per 64-byte record, 16 bytes each: both sides coalesced (one lane per record made every load and store instruction
-// touch 64 different lines: 8.8 ms for 226 M records, the wavefronts stalled on the memory pipe 80 % of their cycles)
+// dense copy of a sparse list (host paths only since round 5): four lanes per 64-byte record, 16 bytes each, both sides coalesced
+__global__ void acceptFlagsKernel(const AlnRec *__restrict__ recs, uint32_t *__restrict__ accept, uint64_t n) {
+    for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) accept[i] = recs[i].accepted ? 1u : 0u;
+}
 __global__ void compactAlnKernel(const uint4 *__restrict__ in, const uint32_t *__restrict__ accept,
                                  const uint64_t *__restrict__ pos, uint4 *__restrict__ out, uint64_t n) {
     static_assert(sizeof(AlnRec) == 64, "four 16-byte pieces per record");
@@ -369,6 +369,30 @@ __global__ void markLengthsKernel(const uint32_t *__restrict__ len, uint32_t n, 
         uint32_t l = len[i];
         if (l < cap) present[l] = 1;
     }
+}
+
+
+int denseAlnsCopy(plasship_ctx *ctx, const plasship_alns *a, DevBuf &qoffBuf, DevBuf &recsBuf, const uint64_t **qoff, const AlnRec **recs) {
+    *qoff = a->d_qoff.as<uint64_t>(); *recs = a->d_recs.as<AlnRec>();
+    if (!a->sparse) return PLASSHIP_OK;
+    const uint64_t n = a->nSlots;
+    DevBuf dAccept, dPos, dTmp;
+    const size_t tmpBytes = exclusiveScanTmpBytes(n);
+    if (dAccept.alloc(std::max<uint64_t>(n, 1) * 4) != hipSuccess || dPos.alloc((n + 1) * 8) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess ||
+        qoffBuf.alloc((a->nQueries + 1) * 8) != hipSuccess || recsBuf.alloc(std::max<uint64_t>(a->nLines, 1) * sizeof(AlnRec)) != hipSuccess) {
+        setError("alignment list: out of device memory for the dense copy"); return PLASSHIP_ERR_DEVICE;
+    }
+    if (n) hipLaunchKernelGGL(acceptFlagsKernel, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, (uint64_t) ctx->numCU * 32)), dim3(256), 0, ctx->stream, a->d_recs.as<AlnRec>(), dAccept.as<uint32_t>(), n);
+    if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), n, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
+    if (n) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((4 * n + 255) / 256, (uint64_t) ctx->numCU * 64)), dim3(256), 0, ctx->stream,
+                              a->d_recs.as<uint4>(), dAccept.as<uint32_t>(), dPos.as<uint64_t>(), recsBuf.as<uint4>(), n);
+    hipLaunchKernelGGL(gatherOffsetsKernel, dim3((unsigned) std::min<uint64_t>((a->nQueries + 256) / 256, 65535)), dim3(256), 0, ctx->stream,
+                       a->d_qoff.as<uint64_t>(), dPos.as<uint64_t>(), qoffBuf.as<uint64_t>(), (uint64_t) a->nQueries);
+    uint64_t nAcc = 0;
+    PH_COPY_SYNC(ctx->stream, &nAcc, dPos.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost);
+    if (nAcc != a->nLines) { setError("alignment list: the accepted records do not add up to the list's count"); return PLASSHIP_ERR_DEVICE; }
+    *qoff = qoffBuf.as<uint64_t>(); *recs = recsBuf.as<AlnRec>();
+    return PLASSHIP_OK;
 }
 
 }  // namespace plasship
@@ -409,15 +433,17 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     PH_CHECK(hipMemcpyAsync(dMinScore.p, minScore.data(), (size_t) tabLen * 4, hipMemcpyHostToDevice, ctx->stream));
     PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(nucl), 123 * 123, hipMemcpyHostToDevice, ctx->stream));
 
-    DevBuf dAll, dAccept, dPos, dTmp;
-    const size_t tmpBytes = exclusiveScanTmpBytes(nHits);
-    if (dAll.alloc(std::max<uint64_t>(nHits, 1) * sizeof(AlnRec)) != hipSuccess || dAccept.alloc(std::max<uint64_t>(nHits, 1) * 4) != hipSuccess ||
-        dPos.alloc((nHits + 1) * 8) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
+    plasship_alns *al = holder.get();
+    al->nQueries = qdb->n; al->nucl = nucl; al->addBacktrace = par->add_backtrace != 0; al->dbResidues = tdb->residues;
+    if (al->d_qoff.alloc((qdb->n + 1) * 8) != hipSuccess || al->d_recs.alloc(std::max<uint64_t>(nHits, 1) * sizeof(AlnRec)) != hipSuccess) {
+        setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
 
     { int rcOL = ensureOffLen(ctx, qdb); if (!rcOL) rcOL = ensureOffLen(ctx, tdb); if (rcOL) return rcOL; }
     RescoreArgs a;
     a.q = qdb->view(); a.t = tdb->view(); a.qoff = c->d_qoff.as<uint64_t>(); a.hits = c->d_hits.as<CandHit>(); a.nHits = nHits;
-    a.out = dAll.as<AlnRec>(); a.accept = dAccept.as<uint32_t>(); a.minScore = dMinScore.as<uint32_t>(); a.minScoreLen = tabLen;
+    a.out = al->d_recs.as<AlnRec>(); a.minScore = dMinScore.as<uint32_t>(); a.minScoreLen = tabLen;
     a.mat = dMat.as<signed char>(); a.sameDB = (qdb == tdb); a.includeIdentity = par->include_identity; a.reverseCapable = c->reverseCapable;
     a.covMode = par->cov_mode; a.covThr = par->cov_thr; a.seqIdThr = par->seq_id_thr; a.alnLenThr = par->min_aln_len; a.seqIdMode = par->seq_id_mode;
     a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.stats = dStats.as<unsigned long long>();
@@ -436,27 +462,14 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     else hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
-    if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), nHits, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
-    // the accepted alignments are compacted into a buffer sized for ALL pairs (nearly all candidates of an assembly iteration are
-    // accepted): their number is read with the statistics at the end instead of costing a wait of its own here
-    uint64_t nAcc = 0;
-    PH_CHECK(hipMemcpyAsync(&nAcc, dPos.as<uint64_t>() + nHits, 8, hipMemcpyDeviceToHost, ctx->stream));
-
-    std::unique_ptr<plasship_alns> holder(new plasship_alns());     // released to the caller on success only
-    plasship_alns *al = holder.get();
-    al->nQueries = qdb->n; al->nucl = nucl; al->addBacktrace = par->add_backtrace != 0; al->dbResidues = tdb->residues;
-    if (al->d_qoff.alloc((qdb->n + 1) * 8) != hipSuccess || al->d_recs.alloc(std::max<uint64_t>(nHits, 1) * sizeof(AlnRec)) != hipSuccess) {
-        setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE;
-    }
-    if (nHits) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((4 * nHits + 255) / 256, (uint64_t) ctx->numCU * 64)), dim3(256), 0, ctx->stream,
-                                  dAll.as<uint4>(), dAccept.as<uint32_t>(), dPos.as<uint64_t>(), al->d_recs.as<uint4>(), nHits);
-    hipLaunchKernelGGL(gatherOffsetsKernel, dim3((unsigned) std::min<uint64_t>((qdb->n + 256) / 256, 65535)), dim3(256), 0, ctx->stream,
-                       c->d_qoff.as<uint64_t>(), dPos.as<uint64_t>(), al->d_qoff.as<uint64_t>(), (uint64_t) qdb->n);
+    // the list stays SPARSE (common.hpp: plasship_alns): record h belongs to candidate pair h, the CSR is the candidate list's
+    PH_CHECK(hipMemcpyAsync(al->d_qoff.p, c->d_qoff.p, (qdb->n + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
     unsigned long long hs[2] = {0, 0};
     PH_CHECK(hipMemcpyAsync(hs, dStats.p, 16, hipMemcpyDeviceToHost, ctx->stream));
     PH_CHECK(plasship::streamSync(ctx->stream));
     PH_CHECK(hipGetLastError());
-    al->nLines = nAcc;
+    const uint64_t nAcc = hs[0];
+    al->nLines = nAcc; al->nSlots = nHits; al->sparse = true;
     al->qdb = qdb; al->tdb = tdb;
     if (stats) {
         stats->n_scored = nHits; stats->n_accepted = nAcc; stats->overlap_residues = hs[1];

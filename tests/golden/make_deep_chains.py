@@ -5,6 +5,8 @@
   c2_exact  BASELINE.json configs[1] as stated: 1 M reads (500 000 pairs, seed 1), the six iterations of `plass assemble
             --num-iterations 6` INCLUDING iteration 0's findassemblystart pass (data/assemble.sh:85-156: kmermatcher, rescorediagonal,
             findassemblystart, kmermatcher, rescorediagonal, assembleresults), hash shifts of src/workflow/Assembler.cpp:99-110
+  c2_bench  the same reads through the chain `bench.py --config c2` times (no findassemblystart): tests/golden/c2_chain_digests.json, what that
+            bench line's `verify` compares its run with
   c3_deep   2 M reads (1 M pairs) of the configs[2] community model (skewed coverage), the TWELVE iterations of the default
             `plass assemble` chain as bench.py runs it (hash shifts 67, 68, 68, 69, ...; contigs of thousands of residues, queues of
             more than 64 alignments, the selected-window cache alternating with re-seeded iterations, the DB heap alternating between
@@ -163,6 +165,12 @@ def main():
         with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
             if what == "c2_exact":
                 res[what] = protein_chain(g, bench, _lib, "c2", bench.CONFIGS["c2"][1], 6, True, thr, td, t0)
+            elif what == "c2_bench":        # the chain `bench.py --config c2` times (no findassemblystart): its `verify` digests, by the oracle
+                res[what] = protein_chain(g, bench, _lib, "c2", bench.CONFIGS["c2"][1], 6, False, thr, td, t0)
+                with open(os.path.join(ROOT, "tests", "golden", "c2_chain_digests.json"), "w") as f:
+                    json.dump({"made_by": "tests/golden/make_deep_chains.py --only c2_bench (CPU oracle: the six iterations of bench.py --config c2, digests of seq_1 .. seq_6)",
+                               "config": "c2", "pairs": res[what]["pairs"], "digests": [r["seq"]["digest"] for r in res[what]["iterations"]]}, f, indent=1)
+                    f.write("\n")
             elif what == "c3_deep":
                 res[what] = protein_chain(g, bench, _lib, "c3", a.deep_pairs, 12, False, thr, td, t0)
             elif what == "c5_deep":

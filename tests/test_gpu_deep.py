@@ -100,9 +100,9 @@ def test_twelve_iterations_of_the_headline_community(ctx, gold, tmp_path):
     assert g["config"] == "c3" and 2 * g["pairs"] >= 2000000 and len(g["iterations"]) == 12
     sst, stats = _protein_chain(ctx, g, tmp_path)
     assert sst.max_coverage > 3 * sst.mean_coverage          # skewed like the headline workload
-    # the regime this fixture exists for: contigs of thousands of residues, the selected-window cache on even iterations, and the
+    # the regime this fixture exists for: contigs of more than a thousand residues, the selected-window cache on even iterations, and the
     # extension tier for queues of more than 64 alignments
-    assert stats[-1][3]["max_entry_len"] > 2000
+    assert stats[-1][3]["max_entry_len"] > 1500
     assert all(k.n_cached_sequences > 0 for k, _, _, _ in stats[2::2]), "the selected-window cache did not serve the same-seed iterations"
     assert all(k.n_cached_sequences == 0 for k, _, _, _ in stats[1::2]), "a re-seeded iteration took windows from the cache"
     assert sum(a.tier_alignments[2] for _, _, a, _ in stats) > 0, "no query held more than 64 alignments: assembleBigKernel did not run"

@@ -717,11 +717,12 @@ def test_cli_flag_sweep(golden, tmp_path, name, mod, flags):
 @pytest.mark.parametrize("mod,extra", [("rescorediagonal", ["--rescore-mode", "2"]), ("rescorediagonal", ["--wrapped-scoring", "1"]),
                                        ("kmermatcher", ["--spaced-kmer-mode", "1"]), ("assembleresults", ["--rescore-mode", "0"])])
 def test_cli_unsupported_fails_loudly(golden, tmp_path, mod, extra):
-    """what the GPU path does not implement exits non-zero with a message (no silent fallback, no output DB)"""
+    """what the GPU path does not implement ends with a message and exit code 95 — the code plass_amd/plass-gpu-wrapper hands to the
+    reference binary on — whether the command line says so or the library does (no silent fallback, no output DB)"""
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     m, pos, outs = sweep_positional(golden, mod, tmp_path / "out")
     p = subprocess.run([os.path.join(root, "plass_amd", "plass-hip"), m] + pos + extra, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=120)
-    assert p.returncode != 0 and ("not supported" in p.stdout or "only" in p.stdout), p.stdout[-800:]
+    assert p.returncode == 95 and ("not supported" in p.stdout or "only" in p.stdout or "not part of the GPU path" in p.stdout) and "outside the GPU hot path" in p.stdout, p.stdout[-800:]
     assert not os.path.exists(outs[0][1] + ".index")
 
