@@ -1353,33 +1353,40 @@ __global__ void outLenKernel(SeqView s, const uint32_t *__restrict__ flags, cons
 // where they are, a rewritten one (flag 0x20: extended, cut, chopped) is copied from the arena to heapBase + appOff[id] behind
 // everything the heap held.  G lanes per entry; what moves per iteration is the rewritten 10-20 % of the sequences instead of
 // 2 x all residues (writeOutKernel below: 15 ms per iteration at 50 M reads, the same again on every rank of a sharded run).
-template <int G>
+// Round 5: ONE THREAD per entry for the index (coalesced: rounds 4's eight lanes per entry read every index word eight times over and moved
+// 14.6 + 5.4 GB per launch for ~3 GB of rewritten entries), then the wavefront copies the rewritten entries of its 64 ids one after the other
+// with all 64 lanes, 8 bytes per lane and step (a rewritten entry is a contig of a few hundred residues: one to three steps).
 __global__ __launch_bounds__(256) void appendOutKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen,
-                                                       const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
+                                                       const uint64_t *__restrict__ newStart, const char *arena,
                                                        const uint64_t *__restrict__ appOff, uint64_t heapBase, const uint32_t *__restrict__ keep,
                                                        const uint64_t *__restrict__ keepPos, const uint32_t *__restrict__ inKey,
-                                                       char *__restrict__ heap, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey,
+                                                       char *heap, uint64_t *__restrict__ outOffArr, uint32_t *__restrict__ outLen, uint32_t *__restrict__ outKey,
                                                        unsigned char *__restrict__ changedOut) {
-    const int gl = threadIdx.x & (G - 1);
-    constexpr int groupsPerBlock = 256 / G;
-    for (uint32_t id = blockIdx.x * groupsPerBlock + (threadIdx.x / G); id < s.n; id += gridDim.x * groupsPerBlock) {
-        if (!keep[id]) continue;
-        const uint32_t f = flags[id];
-        const bool ext = (f & 0x20u) != 0;
-        uint64_t o; uint32_t L;
-        if (ext) {
-            L = newLen[id]; o = heapBase + appOff[id];
-            const char *src = arena + newStart[id]; char *dst = heap + o;
-            for (unsigned p = 8u * (unsigned) gl; p < L; p += 8u * G) {
-                const uint64_t x = loadU64Unaligned(src + p);                            // buffers are padded past their ends
-                if (p + 8 <= L) storeU64Unaligned(dst + p, x); else storeTail(dst + p, x, L - p);
-            }
-            if (gl == 0) { dst[L] = '\n'; dst[L + 1] = '\0'; }
-        } else { L = s.len[id]; o = s.off[id]; }
-        if (gl == 0) {
+    // (arena and heap are NOT restrict: cyclecheck and findassemblystart pass the heap itself as the arena — disjoint ranges of one buffer)
+    const int lane = laneId();
+    for (uint32_t id0 = (blockIdx.x * 256 + (threadIdx.x & ~63u)); id0 < s.n; id0 += gridDim.x * 256) {
+        const uint32_t id = id0 + (uint32_t) lane;
+        bool ext = false; uint32_t L = 0; uint64_t srcOff = 0, o = 0;
+        if (id < s.n && keep[id]) {
+            ext = (flags[id] & 0x20u) != 0;
+            if (ext) { L = newLen[id]; o = heapBase + appOff[id]; srcOff = newStart[id]; }
+            else { L = s.len[id]; o = s.off[id]; }
             const uint64_t j = keepPos[id];
             outOffArr[j] = o; outLen[j] = L; outKey[j] = inKey[id];
             if (changedOut) changedOut[j] = ext ? 1 : 0;
+        }
+        unsigned long long m = __ballot(ext);
+        while (m) {
+            const int src = __ffsll((long long) m) - 1;
+            m &= m - 1;
+            const uint32_t cl = (uint32_t) __shfl((int) L, src, 64);
+            const uint64_t co = (uint64_t) __shfl((unsigned long long) o, src, 64), cs = (uint64_t) __shfl((unsigned long long) srcOff, src, 64);
+            const char *from = arena + cs; char *dst = heap + co;
+            for (unsigned p = 8u * (unsigned) lane; p < cl; p += 512u) {
+                const uint64_t x = loadU64Unaligned(from + p);                           // buffers are padded past their ends
+                if (p + 8 <= cl) storeU64Unaligned(dst + p, x); else storeTail(dst + p, x, cl - p);
+            }
+            if (lane == 0) { dst[cl] = '\n'; dst[cl + 1] = '\0'; }
         }
     }
 }
@@ -1529,7 +1536,7 @@ static int ambTableInsert(plasship_ctx *ctx, const uint32_t *tuples, uint32_t n)
 
 // builds one output DB (extended entries from the arena + carried-over entries of `db`), entries in key order.
 // mode 0: the DB shares `db`'s heap when it has one with room (appendOutKernel: only the rewritten entries move); else its entries are
-//         written back to back into a NEW heap with room for the iterations to come (as much again as the data, at most PLASSHIP_TUNE_DBHEAP_GB = 8 GB;
+//         written back to back into a NEW heap with room for the iterations to come (as much again as the data, at most PLASSHIP_TUNE_DBHEAP_GB = 16 GB;
 //         PLASSHIP_TUNE_DBHEAP=2: no heaps, every DB in an exact buffer of its own as in rounds 1-3)
 // mode 1: a packed copy in an exact buffer (packedCopyOf)
 static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const uint32_t *dFlags, const uint32_t *dNewLen, const uint64_t *dNewStart,
@@ -1573,16 +1580,17 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
         o->ancestorGen = db->gen;
         if (outN == N) o->parentGen = db->gen;
     }
-    // room in the shared heap?  (the reservation is atomic: two DBs derived from one parent get disjoint ranges; a reservation that
-    // does not fit is simply left unused — the heap is about to be replaced anyway)
+    // room in the shared heap?  (the reservation is atomic: two DBs derived from one parent get disjoint ranges)
     bool append = false; uint64_t heapBase = 0;
-    if (mayAppend) {
-        heapBase = db->heap->used.fetch_add(appTotal);
-        append = heapBase + appTotal + 64 <= db->heap->buf.bytes;
+    if (mayAppend) {                                          // (the reservation commits only if it fits: a DB that does not fit leaves the heap's room to its siblings)
+        uint64_t cur = db->heap->used.load();
+        while (cur + appTotal + 64 <= db->heap->buf.bytes) {
+            if (db->heap->used.compare_exchange_weak(cur, cur + appTotal)) { heapBase = cur; append = true; break; }
+        }
     }
     if (append) {
         o->heap = db->heap; o->contiguous = false;
-        if (N) hipLaunchKernelGGL((appendOutKernel<8>), dim3(std::min<uint32_t>((N + 31) / 32, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16))), dim3(256), 0, st, sv, dFlags, dNewLen, dNewStart, dArena,
+        if (N) hipLaunchKernelGGL(appendOutKernel, dim3(std::min<uint32_t>((N + 255) / 256, (uint32_t) ctx->numCU * (uint32_t) tuneInt("WRITEOUT", 16))), dim3(256), 0, st, sv, dFlags, dNewLen, dNewStart, dArena,
                                   (const uint64_t *) dAppOff.as<uint64_t>(), heapBase, (const uint32_t *) dKeep.as<uint32_t>(), (const uint64_t *) dKeepPos.as<uint64_t>(), (const uint32_t *) db->d_key.as<uint32_t>(),
                                   db->heap->buf.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
     } else {
@@ -1590,8 +1598,8 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
         if (useHeaps) {
             o->heap = std::make_shared<SeqHeap>();
             // room for the entries the next iterations rewrite (25-35 % of the data per iteration at 50 M reads): as much again as the
-            // data, but no more than PLASSHIP_TUNE_DBHEAP_GB (default 8) — kmermatcher's record arrays need 170 of the 288 GB there
-            const uint64_t cap = outBytes + std::min<uint64_t>(outBytes, (uint64_t) tuneInt("DBHEAP_GB", 8) << 30) + 4096;
+            // data, but no more than PLASSHIP_TUNE_DBHEAP_GB (default 16; round 4: 8 — the sparse alignment lists of round 5 freed 14 GB) — kmermatcher's record arrays need 170 of the 288 GB there
+            const uint64_t cap = outBytes + std::min<uint64_t>(outBytes, (uint64_t) tuneInt("DBHEAP_GB", 16) << 30) + 4096;
             if (o->heap->buf.allocLong(cap) == hipSuccess) { o->heap->used = outBytes; dst = o->heap->buf.as<char>(); }
             else o->heap.reset();                             // no room for the slack: an exact buffer will do
         }

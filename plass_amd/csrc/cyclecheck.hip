@@ -409,7 +409,8 @@ extern "C" int plasship_cyclecheck(plasship_ctx *ctx, const plasship_seqdb *db, 
     // the circular sequences (whole or cut) ...
     plasship_seqdb *oc = nullptr, *orest = nullptr;
     if (N) hipLaunchKernelGGL(cycleFlagsKernel, dim3(gridN), dim3(256), 0, st, sv, dSplit.as<uint32_t>(), par->chop_cycle ? 1 : 0, 0, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>());
-    int rc = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), sv.data, 0, dTmp.p, tmpBytes, &oc, nullptr, nullptr, 0, ctx->ev[1]);
+    int rc = buildOutputDB(ctx, db, dFlags.as<uint32_t>(), dNewLen.as<uint32_t>(), dNewStart.as<uint64_t>(), sv.data, 0, dTmp.p, tmpBytes, &oc, nullptr, nullptr, 0, ctx->ev[1],
+                           true);      // (noAppend: the cycle DB is written out and freed at once — its entries do not belong in the chain's long-lived heap)
     if (rc != PLASSHIP_OK) return rc;
     std::unique_ptr<plasship_seqdb> holdC(oc);
     oc->dbtype = PLASSHIP_DBTYPE_NUCLEOTIDES;

@@ -194,10 +194,11 @@ static int launchLinePart(plasship_ctx *ctx, const LinePartArgs &a, uint64_t nPi
 static int buildLineLists(plasship_ctx *ctx, const uint32_t *dTags, uint64_t capLines, uint32_t nb, uint32_t *dCount, uint32_t *dStart, uint32_t *dCursor, uint32_t *dList) {
     hipStream_t st = ctx->stream;
     PH_CHECK(hipMemsetAsync(dCount, 0, (size_t) nb * 4, st));
-    const unsigned g = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>((capLines + TS_CHUNK - 1) / TS_CHUNK, (uint64_t) ctx->numCU * 8));
+    const unsigned g = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>((capLines + 4095) / 4096, (uint64_t) ctx->numCU * 8));
+    const unsigned gs = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>((capLines + TS_CHUNK - 1) / TS_CHUNK, (uint64_t) ctx->numCU * 2));
     hipLaunchKernelGGL(tagHistKernel, dim3(g), dim3(256), 0, st, dTags, capLines, nb, dCount);
     hipLaunchKernelGGL(tagScanKernel, dim3(1), dim3(1024), 0, st, (const uint32_t *) dCount, nb, dStart, dCursor);
-    hipLaunchKernelGGL(tagScatterKernel, dim3(g), dim3(256), 0, st, dTags, capLines, nb, dCursor, dList);
+    hipLaunchKernelGGL(tagScatterKernel, dim3(gs), dim3(TS_BLOCK), 0, st, dTags, capLines, nb, dCursor, dList);
     return PLASSHIP_OK;
 }
 

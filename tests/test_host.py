@@ -317,3 +317,28 @@ def test_wrapper_routes_by_exit_code(tmp_path):
     assert out.returncode == 1 and "REF" not in out.stdout and "Unrecognized parameter" in out.stdout
     lines = log.read_text().splitlines()
     assert lines[0].startswith("reference  <- plass-hip exit 95") and "not a hot-path module" in lines[1] and lines[2].startswith("GPU path   exit 1")
+
+
+def test_deep_chain_fixtures_are_complete():
+    """tests/golden/deep_chains.json (CPU oracle only, tests/golden/make_deep_chains.py): configs[1] as stated with its six iterations and the
+    findassemblystart pass, twelve iterations of the community chain, six nucleotide and four guided iterations — every DB with entries, bytes
+    and digest; tests/golden/c2_chain_digests.json (bench.py --config c2's `verify`) is the oracle's chain without findassemblystart"""
+    import json
+    d = json.load(open(os.path.join(ROOT, "tests", "golden", "deep_chains.json")))
+    assert "CPU oracle only" in d["made_by"]
+    c2, c3, c5 = d["c2_exact"], d["c3_deep"], d["c5_deep"]
+    assert (c2["pairs"], c2["iters"], c2["findassemblystart"], len(c2["iterations"])) == (500000, 6, True, 6)
+    assert all(k in c2["iterations"][0] for k in ("pref_uncorrected", "aln_uncorrected", "corrected", "pref", "aln", "seq"))
+    assert c3["config"] == "c3" and 2 * c3["pairs"] >= 2000000 and len(c3["iterations"]) == 12 and not c3["findassemblystart"]
+    assert len(c5["nucl"]) == 6 and len(c5["guided"]) == 4 and 2 * c5["pairs"] >= 2000000
+    for rows, keys in ((c2["iterations"], ("pref", "aln", "seq")), (c3["iterations"], ("pref", "aln", "seq")), (c5["nucl"], ("pref", "aln", "assembly", "cycle", "rest")),
+                       (c5["guided"], ("pref", "aln", "aln_nucl", "nucl", "aa"))):
+        for r in rows:
+            for k in keys:
+                assert r[k]["entries"] > 0 and r[k]["bytes"] >= 0 and re.fullmatch(r"[0-9a-f]{16}", r[k]["digest"]), (k, r[k])
+    # residues grow along the chains (the chains were really chained)
+    seqb = [r["seq"]["bytes"] for r in c3["iterations"]]
+    assert seqb == sorted(seqb) and seqb[-1] > 2 * seqb[0]
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "c2_chain_digests.json")))
+    assert "CPU oracle" in g["made_by"] and g["pairs"] == 500000 and g["digests"] == [r["seq"]["digest"] for r in d["c2_bench"]["iterations"]]
+    assert g["digests"][0] != c2["iterations"][0]["seq"]["digest"]      # findassemblystart changes iteration 0 already
