@@ -335,7 +335,7 @@ def test_deep_chain_fixtures_are_complete():
                        (c5["guided"], ("pref", "aln", "aln_nucl", "nucl", "aa"))):
         for r in rows:
             for k in keys:
-                assert r[k]["entries"] > 0 and r[k]["bytes"] >= 0 and re.fullmatch(r"[0-9a-f]{16}", r[k]["digest"]), (k, r[k])
+                assert (r[k]["entries"] > 0 or k == "cycle") and r[k]["bytes"] >= 0 and re.fullmatch(r"[0-9a-f]{16}", r[k]["digest"]), (k, r[k])   # (no circular contig in this community)
     # residues grow along the chains (the chains were really chained)
     seqb = [r["seq"]["bytes"] for r in c3["iterations"]]
     assert seqb == sorted(seqb) and seqb[-1] > 2 * seqb[0]
