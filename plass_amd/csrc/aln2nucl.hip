@@ -104,6 +104,7 @@ extern "C" int plasship_aln2nucl(plasship_ctx *ctx, const plasship_seqdb *q_nucl
     // The walk over 3 * alnLen nucleotide columns runs past the end of an entry when a protein twin is longer than its ORF / 3, like the
     // reference's — into the entry that follows in the DB FILE.  A DB whose rewritten entries live in a shared heap (common.hpp: SeqHeap)
     // is laid out like its file first (round 5: tests/test_gpu_deep.py::test_four_guided_iterations).
+    rc = finishSelfAlns(ctx, al); if (rc) return rc;         // every protein alignment is converted, the identity pairs included
     std::unique_ptr<plasship_seqdb> qPacked, tPacked;
     if (!q_nucl->contiguous) { rc = packedCopyOf(ctx, q_nucl, qPacked); if (rc) return rc; }
     if (t_nucl != q_nucl && !t_nucl->contiguous) { rc = packedCopyOf(ctx, t_nucl, tPacked); if (rc) return rc; }

@@ -1731,6 +1731,9 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     PH_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint32_t N = (uint32_t) db->n;
+    // nuclassembleresults / guidedassembleresults rank a query's alignment with itself among the others (it enters the heap like any hit);
+    // assembleresults pops and discards it (assembleresult.cpp:203-209): only the former need the identity pairs scored (common.hpp: selfPending)
+    if (nucl) { const int rcS = finishSelfAlns(ctx, al); if (rcS) return rcS; }
     const uint64_t nLines = al->nSlots;                     // record slots (a sparse list: holes included, common.hpp); al->nLines of them are alignments
     DevBuf dLeftCap, dBytes, dArenaOff, dTmp, dItems, dFlags, dNewLen, dNewStart, dMat, dStats, dArena;
     const size_t tmpBytes = exclusiveScanTmpBytes((size_t) N + 2);
@@ -1795,6 +1798,10 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     a.mid32List = dMid32List.as<uint32_t>(); a.nMid32 = cnts[1];
     a.midList = dMidList.as<uint32_t>(); a.nMid = cnts[2];
     a.bigList = dBigList.as<uint32_t>(); a.nBig = cnts[3];
+    // assembleBigKernel keeps the self hit in its HBM-resident queue (its rank decides what is left queued when the length cap ends the pop
+    // loop, assembleresult.cpp:259-263,285): the identity pairs of ITS queries are scored now (common.hpp: selfPending); the register-queue
+    // kernels never queue the self hit
+    if (!nucl && a.nBig) { const int rcS = finishSelfAlns(ctx, al, dBigList.as<uint32_t>(), a.nBig); if (rcS) return rcS; }
     std::unique_ptr<plasship_seqdb> aaPacked;                // guided: the twins are read past their end like the reference does (buildOutputDBImpl, noAppend):
     if (guided && !aaDb->contiguous) {                       // a twin DB that lives in a shared heap is laid out like its DB file first
         const int rcP = packedCopyOf(ctx, aaDb, aaPacked); if (rcP) return rcP;

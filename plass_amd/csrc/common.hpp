@@ -111,8 +111,10 @@ struct AlnRec {
     int32_t reversed;
     int32_t accepted;
     int32_t fromText;
-    int32_t btKind;            // backtrace of the record: 0 unknown / none, 1 one run of alnLen 'M' (ungapped), 2 anything else
+    int32_t btKind;            // backtrace of the record: 0 unknown / none, 1 one run of alnLen 'M' (ungapped), 2 anything else,
+                               // ALN_SELF_PENDING: an identity pair not scored yet (plasship_alns::selfPending)
 };
+constexpr int32_t ALN_SELF_PENDING = 3;
 
 }  // namespace plasship
 
@@ -216,6 +218,17 @@ struct plasship_alns {
     // dense copy first (denseAlnsCopy, rescore.hip).  Lists read from DB files or made dense are not sparse: nSlots == nLines.
     uint64_t nSlots = 0;           // records in d_recs (holes included)
     bool sparse = false;
+    // Round 5, LAZY SELF HITS: every query's alignment with itself (a third of the pairs, and in the late iterations of an assembly — contigs of
+    // thousands of residues against themselves — most of the columns rescorediagonal scores: the stage grew 20 -> 60 ms over the twelve
+    // iterations at 50 M reads while the candidate pairs fell) is accepted whatever it scores, and assembleresults pops and discards it
+    // (assembleresult.cpp:203-209, isNotIdentity), findassemblystart skips it.  plasship_rescore therefore leaves the identity pairs as STUBS
+    // (accepted = 1, btKind = ALN_SELF_PENDING, the candidate's score / diagonal stashed in rawScore / qStart) and the first consumer that
+    // READS a self record — DB files, downloads, proteinaln2nucl, the nucleotide and guided extension (whose comparator ranks the self hit
+    // with the others) — has them scored then, by the same kernels (finishSelfAlns, rescore.hip): every record any reader sees is the
+    // record rounds 1-4 made.  selfPending is the list's state, not its value: mutable, set back by finishSelfAlns.
+    mutable bool selfPending = false;
+    plasship_rescore_params rsPar = {};      // what finishSelfAlns scores with
+    bool rsSameDB = false; int rsReverseCapable = 0;
     bool nucl = false;
     bool addBacktrace = false;
     uint64_t dbResidues = 0;       // of the target DB (E-value area)
@@ -276,4 +289,7 @@ int deviceKeysDiffer(plasship_ctx *ctx, const uint32_t *a, const uint32_t *b, si
 // dense (hole-free) copy of an alignment list's CSR and records on the device (rescore.hip); for a list that is not sparse the buffers
 // stay empty and *qoff / *recs point at the list's own arrays
 int denseAlnsCopy(plasship_ctx *ctx, const plasship_alns *a, DevBuf &qoffBuf, DevBuf &recsBuf, const uint64_t **qoff, const AlnRec **recs);
+// scores the identity pairs plasship_rescore left as stubs (plasship_alns::selfPending); no-op for a list that has none
+// (dQueryList: only the stubs of these nQueryList queries — ids on the device)
+int finishSelfAlns(plasship_ctx *ctx, const plasship_alns *a, const uint32_t *dQueryList = nullptr, uint32_t nQueryList = 0);
 }

@@ -183,7 +183,8 @@ static int fetchAlns(plasship_ctx *ctx, const plasship_alns *a, std::vector<uint
     qoff.resize(a->nQueries + 1); recs.resize(a->nLines);
     // a list made by plasship_rescore is sparse (common.hpp: plasship_alns): the host sees a dense copy, made on the device
     DevBuf dQoff, dRecs; const uint64_t *pq = nullptr; const AlnRec *pr = nullptr;
-    int rc = denseAlnsCopy(ctx, a, dQoff, dRecs, &pq, &pr); if (rc) return rc;
+    int rc = finishSelfAlns(ctx, a); if (rc) return rc;          // (identity pairs left as stubs are scored now: the host reads every record)
+    rc = denseAlnsCopy(ctx, a, dQoff, dRecs, &pq, &pr); if (rc) return rc;
     PH_CHECK(plasship::streamSync(ctx->stream));
     rc = stagedCopyToHost(ctx, qoff.data(), pq, (a->nQueries + 1) * 8); if (rc) return rc;
     return stagedCopyToHost(ctx, recs.data(), pr, a->nLines * sizeof(AlnRec));

@@ -43,6 +43,12 @@ struct RescoreArgs {
     unsigned long long *stats;   // [0] accepted, [1] overlap residues
     unsigned long long *longList, *longCount;   // hit indices queued for the 16-lane kernel
     uint32_t shortMax;           // min(qLen, tLen) up to which the thread-per-pair kernel scores a pair itself
+    // lazy self hits (common.hpp: plasship_alns::selfPending).  mode 0: the pairs of a candidate list, identity pairs left as stubs when
+    // lazySelf; mode 1 (finishSelfAlns): the record slots of an alignment list, only the stubs are scored (hits == nullptr: the pair is rebuilt
+    // from its stub); mode 2: the same for the stubs of the queries of `queryList` only (the extension kernel for queues beyond 64 alignments
+    // keeps the self hit in its HBM-resident queue: assembleBigKernel)
+    int mode, lazySelf;
+    const uint32_t *queryList; uint32_t nQueryList;
 };
 
 __device__ __forceinline__ bool canBeCoveredDev(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -229,7 +235,8 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
     const int sl = threadIdx.x & (G - 1);
     const uint64_t stride = (uint64_t) gridDim.x * groupsPerBlock;
     unsigned long long accLocal = 0, ovLocal = 0;
-    const uint64_t nWork = (G == 1) ? a.nHits : (uint64_t) *a.longCount;
+    const uint64_t nWork = (G == 1) ? (a.mode == 2 ? (uint64_t) a.nQueryList : a.nHits) : (uint64_t) *a.longCount;
+    const bool finish = a.mode != 0;                     // (wave-uniform)
     // G == 1: the candidate of the next round and its sequences' offsets / lengths are requested while the current pair is scored
     // (a pair is a chain of dependent round trips: candidate -> offsets and lengths -> residues; two of them leave the chain)
     struct Meta { uint64_t qOff, tOff; uint32_t qLen, tLen; };
@@ -238,14 +245,26 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
     uint64_t w = (uint64_t) blockIdx.x * groupsPerBlock + (threadIdx.x / G);
     CandHit hitNext; Meta metaNext; CandHit hitAfter;
     memset(&hitNext, 0, sizeof(hitNext)); memset(&hitAfter, 0, sizeof(hitAfter)); memset(&metaNext, 0, sizeof(metaNext));
-    if (G == 1) {
+    if (G == 1 && !finish) {
         if (w < nWork) { hitNext = a.hits[w]; metaNext = loadMeta(hitNext); }
         if (w + stride < nWork) hitAfter = a.hits[w + stride];
     }
     for (; w < nWork; w += stride) {
-        const uint64_t h = (G == 1) ? w : a.longList[w];
+        uint64_t h = (G == 1) ? w : a.longList[w];
         CandHit hit; Meta me;
-        if (G == 1) {
+        if (G == 1 && a.mode == 2) {                          // the stub among the record slots of query queryList[w]
+            const uint32_t qq = a.queryList[w];
+            uint64_t j = a.qoff[qq]; const uint64_t j1 = a.qoff[qq + 1];
+            while (j < j1 && a.out[j].btKind != ALN_SELF_PENDING) j++;
+            if (j == j1) continue;
+            h = j;
+        }
+        if (finish) {                                         // the pair behind a stub: score and diagonal of the candidate were stashed in it
+            const AlnRec stub = a.out[h];
+            if (stub.btKind != ALN_SELF_PENDING) continue;
+            hit.query = stub.query; hit.target = stub.target; hit.prefScore = stub.rawScore; hit.diag16 = (uint32_t) stub.qStart;
+            me = loadMeta(hit);
+        } else if (G == 1) {
             hit = hitNext; me = metaNext;
             hitNext = hitAfter;
             if (w + stride < nWork) metaNext = loadMeta(hitNext);
@@ -256,6 +275,15 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
         const unsigned qLen = me.qLen;
         const char *t = a.t.data + me.tOff;
         const unsigned tLen = me.tLen;
+        if (G == 1 && !finish && a.lazySelf && qid == tid && (a.includeIdentity || a.sameDB)) {
+            // an identity pair: accepted whatever it scores, read by few consumers — left as a stub for finishSelfAlns (common.hpp)
+            AlnRec stub; memset(&stub, 0, sizeof(stub));
+            stub.query = qid; stub.target = tid; stub.rawScore = hit.prefScore; stub.qStart = (int32_t) hit.diag16; stub.qLen = (int) qLen; stub.dbLen = (int) tLen;
+            stub.accepted = 1; stub.btKind = ALN_SELF_PENDING;
+            a.out[h] = stub;
+            accLocal += 1;
+            continue;
+        }
         if (G == 1) {                                         // long overlap: 16 lanes will score it (one atomic per wavefront, not per pair)
             // (round 4: sending every SELF hit — a third of the list, and the lane the others wait for — to the 16-lane kernel as well
             //  doubled the stage, 45 -> 89 ms: its per-pair epilogue on 16 lanes costs more than the waiting; profiles/r04_ab_knobs.txt)
@@ -395,6 +423,45 @@ int denseAlnsCopy(plasship_ctx *ctx, const plasship_alns *a, DevBuf &qoffBuf, De
     return PLASSHIP_OK;
 }
 
+// The identity pairs plasship_rescore left as stubs (common.hpp: plasship_alns::selfPending), scored by the same kernels with the list's own
+// parameters.  An identity pair is accepted whatever it scores and its sequence identity does not depend on the E-value gate
+// (rescorediagonal.cpp:262-297), so the per-length minimum-score table of plasship_rescore is not needed here (an empty table: "no E-value").
+int finishSelfAlns(plasship_ctx *ctx, const plasship_alns *al, const uint32_t *dQueryList, uint32_t nQueryList) {
+    if (!al->selfPending) return PLASSHIP_OK;
+    if (!al->qdb || !al->tdb) { setError("alignment list: the DBs it was made from are gone (they must outlive the list)"); return PLASSHIP_ERR_ARG; }
+    const bool nucl = al->nucl;
+    const uint64_t n = al->nSlots;
+    DevBuf dMat, dStats, dLongList, dLongCount;
+    if (dMat.alloc(123 * 123) != hipSuccess || dStats.alloc(16) != hipSuccess || dLongList.alloc(((uint64_t) al->nQueries + 1) * 8) != hipSuccess || dLongCount.alloc(8) != hipSuccess) {
+        setError("alignment list: out of device memory"); return PLASSHIP_ERR_DEVICE;
+    }
+    PH_CHECK(hipMemsetAsync(dStats.p, 0, 16, ctx->stream));
+    PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 8, ctx->stream));
+    PH_CHECK(hipMemcpyAsync(dMat.p, asciiSubMat(nucl), 123 * 123, hipMemcpyHostToDevice, ctx->stream));
+    { int rcOL = ensureOffLen(ctx, al->qdb); if (!rcOL) rcOL = ensureOffLen(ctx, al->tdb); if (rcOL) return rcOL; }
+    HostEvaluer ev(nucl, al->dbResidues);
+    const plasship_rescore_params &par = al->rsPar;
+    RescoreArgs a; memset(&a, 0, sizeof(a));
+    a.q = al->qdb->view(); a.t = al->tdb->view(); a.qoff = al->d_qoff.as<uint64_t>(); a.hits = nullptr; a.nHits = n;
+    a.out = al->d_recs.as<AlnRec>(); a.minScore = nullptr; a.minScoreLen = 0;
+    a.mat = dMat.as<signed char>(); a.sameDB = al->rsSameDB; a.includeIdentity = par.include_identity; a.reverseCapable = al->rsReverseCapable;
+    a.covMode = par.cov_mode; a.covThr = par.cov_thr; a.seqIdThr = par.seq_id_thr; a.alnLenThr = par.min_aln_len; a.seqIdMode = par.seq_id_mode;
+    a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.stats = dStats.as<unsigned long long>();
+    a.longList = dLongList.as<unsigned long long>(); a.longCount = dLongCount.as<unsigned long long>();
+    a.shortMax = (uint32_t) tuneInt("RESCORE_SHORT", (int) RS_SHORT_MAX);
+    a.mode = dQueryList ? 2 : 1; a.lazySelf = 0; a.queryList = dQueryList; a.nQueryList = nQueryList;
+    const uint64_t work = dQueryList ? (uint64_t) nQueryList : n;
+    if (work) {
+        const unsigned grid = (unsigned) std::min<uint64_t>((work + 255) / 256 + 1, (uint64_t) ctx->numCU * 32);
+        hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);
+    }
+    PH_CHECK(plasship::streamSync(ctx->stream));          // (the local buffers above are released with the function: their kernels must be through)
+    PH_CHECK(hipGetLastError());
+    if (!dQueryList) al->selfPending = false;
+    return PLASSHIP_OK;
+}
+
 }  // namespace plasship
 using namespace plasship;
 
@@ -452,6 +519,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     PH_CHECK(hipMemsetAsync(dLongCount.p, 0, 8, ctx->stream));
     a.longList = dLongList.as<unsigned long long>(); a.longCount = dLongCount.as<unsigned long long>();
     a.shortMax = (uint32_t) tuneInt("RESCORE_SHORT", (int) RS_SHORT_MAX);
+    a.mode = 0; a.lazySelf = tuneInt("LAZY_SELF", 1) == 1 ? 1 : 0;      // PLASSHIP_TUNE_LAZY_SELF=2: every identity pair scored here (rounds 1-4)
     const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * (uint64_t) tuneInt("RESCORE", nHits > 50000000ull ? 32 : 12));   // large lists: smaller shares per workgroup even out the tail (37.8 -> 35.9 ms at 250 M pairs)
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
     static const int wpe = tuneInt("RESCORE_WPE", 5);       // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight)
@@ -471,6 +539,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     const uint64_t nAcc = hs[0];
     al->nLines = nAcc; al->nSlots = nHits; al->sparse = true;
     al->qdb = qdb; al->tdb = tdb;
+    al->selfPending = a.lazySelf != 0; al->rsPar = *par; al->rsSameDB = (qdb == tdb); al->rsReverseCapable = c->reverseCapable;
     if (stats) {
         stats->n_scored = nHits; stats->n_accepted = nAcc; stats->overlap_residues = hs[1];
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;
