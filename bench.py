@@ -174,7 +174,7 @@ KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extr
                   # (MODE 0 = the hash partition of the k-mer records; the MODE 1 instantiations are the rep sort's range partitions: VERDICT r4 weak #10)
                   "partitionKernel(k-mer records)": "linePartKernel<(true|false), (true|false), 0, .*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel",
                   "assembleNuclKernel(+assembleNuclThreadKernel, all passes)": "assembleNucl(Thread)?Kernel<"}
-PMC_FILES = {"c3": "r04_pmc_traffic.json", "c5": "r04_pmc_traffic_c5.json"}
+PMC_FILES = {"c3": "r05_pmc_traffic.json", "c5": "r05_pmc_traffic_c5.json"}
 
 
 def stored_traffic(kernel, launches_per_step, cfg="c3"):
@@ -196,6 +196,38 @@ def stored_traffic(kernel, launches_per_step, cfg="c3"):
     tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for name, r in rows.get("kernels", {}).items() if re.search(pat, name))
     steps = rows.get("steps", 0)
     return (tot / steps / max(launches_per_step, 1e-9), rows.get("source", "")) if tot and steps else (None, "the stored profile has no row for " + kernel)
+
+
+# the cost model of a sharded iteration, so that a SCALE record can be read against it phase by phase.
+# Inputs measured on ONE MI355X at 50 M reads (profiles/r05_bench_driver_cmd.log): ms per iteration of the single-GPU path by module, the part
+# of kmermatcher that is NOT sharded when every rank extracts all sequences (owner-filtered extraction, the default up to 4 ranks), the
+# 1-rank overhead of the sharded orchestration (12.5 M reads: the owner's merge of the exchanged triples, packing the extended sequences);
+# link: one xGMI link per GPU pair, 76 GB/s per direction assumed.
+MODEL_50M = {"kmermatcher_ms": 217.0, "extraction_ms": 75.0, "rescore_ms": 35.0, "assemble_ms": 78.0, "other_ms": 0.0,
+             "shard_overhead": 0.09, "level1_line_bytes": 63e9, "triple_bytes": 5e9, "extended_bytes": 3.5e9, "link_GBs": 76.0, "host_rounds_ms": 2.0}
+
+
+def scaling_model(world, reads, measured_module_wall=None):
+    """predicted ms per iteration of the sharded run at `world` ranks for both ways the k-mer records reach their owner, scaled linearly
+    with the reads from the 50 M-read figures; `measured_module_wall_ms` = this run's [kmermatcher, rescorediagonal, assembleresults]"""
+    m = MODEL_50M
+    f = reads / 50e6
+    W = max(world, 1)
+    ov = 1.0 + m["shard_overhead"]
+    t2 = (m["triple_bytes"] + m["extended_bytes"]) * f / (W * W * m["link_GBs"] * 1e9) * 1e3 * (W - 1) if W > 1 else 0.0
+    filt_km = m["extraction_ms"] * f + (m["kmermatcher_ms"] - m["extraction_ms"]) * f * ov / W
+    exch_km = m["kmermatcher_ms"] * f * ov / W + (m["level1_line_bytes"] * f / (W * W * m["link_GBs"] * 1e9) * 1e3 if W > 1 else 0.0)
+    rest = (m["rescore_ms"] + m["assemble_ms"] * ov) * f / W + t2 + (m["host_rounds_ms"] if W > 1 else 0.0)
+    single = (m["kmermatcher_ms"] + m["rescore_ms"] + m["assemble_ms"]) * f
+    out = {"inputs": m, "single_gpu_ms": round(single, 1),
+           "owner_filtered": {"kmermatcher_ms": round(filt_km, 1), "total_ms": round(filt_km + rest, 1), "speedup": round(single / (filt_km + rest), 2)},
+           "exchange": {"kmermatcher_ms": round(exch_km, 1), "total_ms": round(exch_km + rest, 1), "speedup": round(single / (exch_km + rest), 2)},
+           "library_default": "owner_filtered" if W <= 4 else "exchange",
+           "note": "kmermatch.hip shardOwnerFiltered: owner-filtered extraction up to 4 ranks (nothing crosses the links for the k-mer records; extraction is "
+                   "replicated), the all-to-all of level-1 lines beyond (PLASSHIP_TUNE_SHARD_EXTRACT=1 / 2 forces one)"}
+    if measured_module_wall:
+        out["measured_module_wall_ms"] = [round(x, 1) for x in measured_module_wall]
+    return out
 
 
 def furthest_below(tot, n_steps, cfg):
@@ -476,6 +508,7 @@ def main():
                 per[name] = {"device_bytes_sent_per_step_rank0": xt[0] / max(len(rows), 1), "host_ms_in_collectives_per_step_rank0": xt[1] * 1e3 / max(len(rows), 1),
                              "collective_calls_per_step": xt[2] / max(len(rows), 1)}
             line["exchange"]["per_module"] = per
+            line["exchange"]["model"] = scaling_model(world, wl["reads"], line["roofline"]["module_wall_ms_per_step"] if line.get("roofline") else None)
     if db is not db0:
         db.free()
     # ---- untimed verification: one more traversal of the chain, digest of every iteration's output DB (include/plasship.h:

@@ -1072,7 +1072,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             // the self alignment is popped and discarded without any effect (selectFragmentToExtend: isNotIdentity):
             // it never enters the register queue
             xState = (xTarget == id || !r.accepted) ? 2u : 0u;                 // (nor does a hole of a sparse list)
-            if (xState == 0) { xTOff = seqOff(a.s, xTarget); xTLen = seqLen(a.s, xTarget); }      // fetched up front: one memory round trip less per pop
+            // offset / length of the target, fetched up front (one memory round trip less per pop) — for the hits that can take one of the
+            // two extension branches at all: the geometry tests below read them for nobody else, and a re-scored hit came through a branch
+            // (round 5: a random 128-byte line of metadata per hit that is popped and dropped in its first round)
+            const bool branchType = ((xDbStart == 0 && xDbEnd != (int) xDbLen - 1) || (xQStart == 0 && xQEnd != (int) xQLen - 1)) && !(xDbStart == 0 && xQStart == 0);
+            if (xState == 0 && branchType) { xTOff = seqOff(a.s, xTarget); xTLen = seqLen(a.s, xTarget); }
         }
         // tie-break of CompareResultByScore (smaller key wins) as a rank among the group's targets
         const uint32_t tRank = groupRank<G>(xTarget);
