@@ -131,9 +131,13 @@ template <int G> __device__ __forceinline__ void scoreColumnsG(const char *q, co
     for (unsigned p = p0; p < len; p += 8u * G) {
         if (p != p0) { qw = loadU64Unaligned(q + p); tw = loadU64Unaligned(t + p); }
         const int lo = (int) first - (int) p, hi = (int) last - (int) p;       // columns [lo, hi] of this word are scored
-        const uint64_t m = byteRangeMask(lo, hi + 1);
-        ids += zeroBytes(qw ^ tw, byteRangeMask(lo, hi));                       // [qStart, qEnd): the last aligned column is not counted
-        const uint64_t qv = qw & m, tv = tw & m;
+        uint64_t qv = qw, tv = tw;
+        if (lo <= 0 && hi >= 8) ids += zeroBytes(qw ^ tw, ~0ULL);               // an interior word: all eight columns scored and counted (round 5: the two
+        else {                                                                  // range masks cost as much as the eight lookups)
+            const uint64_t m = byteRangeMask(lo, hi + 1);
+            ids += zeroBytes(qw ^ tw, byteRangeMask(lo, hi));                   // [qStart, qEnd): the last aligned column is not counted
+            qv = qw & m; tv = tw & m;
+        }
 #pragma unroll
         for (unsigned j = 0; j < 8; j++) {
             const unsigned a = (unsigned) (qv >> (8 * j)) & 0xFFu, b = (unsigned) (tv >> (8 * j)) & 0xFFu;
@@ -157,9 +161,13 @@ __device__ __forceinline__ void scoreColumnsSerial(const char *q, const char *t,
 #pragma unroll
         for (unsigned k = 0; k < 4; k++) {
             const int lo = (int) first - (int) (p + 8 * k), hi = (int) last - (int) (p + 8 * k);
-            const uint64_t m = byteRangeMask(lo, hi + 1);
-            ids += zeroBytes(qw[k] ^ tw[k], byteRangeMask(lo, hi));
-            const uint64_t qv = qw[k] & m, tv = tw[k] & m;
+            uint64_t qv = qw[k], tv = tw[k];
+            if (lo <= 0 && hi >= 8) ids += zeroBytes(qw[k] ^ tw[k], ~0ULL);     // an interior word (see scoreColumnsG)
+            else {
+                const uint64_t m = byteRangeMask(lo, hi + 1);
+                ids += zeroBytes(qw[k] ^ tw[k], byteRangeMask(lo, hi));
+                qv = qw[k] & m; tv = tw[k] & m;
+            }
 #pragma unroll
             for (unsigned j = 0; j < 8; j++) {
                 const unsigned a = (unsigned) (qv >> (8 * j)) & 0xFFu, b = (unsigned) (tv >> (8 * j)) & 0xFFu;
