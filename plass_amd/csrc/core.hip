@@ -115,9 +115,16 @@ static hipError_t poolMallocRaw(void **p, size_t n, bool longLived) {
             if (hit) g_poolHits++;
             else {
                 // a new slab: modest while the process is small, most of the remaining HBM once it is not
+                // (round 5: ONE slab of most of the HBM per process — a process that already has it grows in modest steps instead of taking 88 % of
+                //  what is left again and again — and never the last 1.5 GB: the HIP runtime allocates the kernels' scratch there on demand.
+                //  A pytest process that had run the 50 M-read tests held 99.97 % of the HBM, and the child process of a later test died in a
+                //  kernel launch with "out of resources, available free memory 94 MB"; profiles/r05_calls/)
                 size_t fr = 0, tt = 0; (void) hipMemGetInfo(&fr, &tt);
-                const size_t most = (size_t) ((double) fr * poolFraction());
-                const bool bigJob = dp.total >= ((size_t) 8 << 30) || n >= ((size_t) 4 << 30);
+                const size_t keepFree = (size_t) 3 << 29;
+                const size_t most = std::min<size_t>((size_t) ((double) fr * poolFraction()), fr > keepFree ? fr - keepFree : 0);
+                bool haveBigSlab = false;
+                for (const auto &sl : dp.slabs) if (sl.base && sl.size >= ((size_t) 16 << 30)) haveBigSlab = true;
+                const bool bigJob = !haveBigSlab && (dp.total >= ((size_t) 8 << 30) || n >= ((size_t) 4 << 30));
                 slabBytes = bigJob ? most : std::min<size_t>(std::max<size_t>(2 * n, (size_t) 1 << 30), most);
                 if (slabBytes < n || fails) slabBytes = n;                  // last resort: exactly what is asked for
                 slabBytes = (slabBytes + MB2 - 1) / MB2 * MB2;
