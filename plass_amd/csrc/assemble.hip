@@ -50,6 +50,7 @@ struct AsmArgs {
     const signed char *mat;
     double lambda, logK, ln2;
     float seqIdThr; uint64_t maxSeqLen; int rescoreMode;
+    uint32_t ownLaneMin;                        // wide register queues: at least this many deferred hits of a round are re-scored each by its own lane, fewer one after the other by the whole group
     unsigned long long *stats;                  // [0] extended, [1] rescored hits, [2] rescored overlap residues
     uint32_t *bigList; uint32_t nBig;   // queries with more than 64 alignments (HBM-resident queue)
     uint32_t *midList; uint32_t nMid;   // 33..64 alignments: one wavefront per query
@@ -1162,7 +1163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
             const char *qs = buf + curStart;
             unsigned long long deferred = groupBallot<G>(xState == 1);
             if (deferred) waveMemSync();
-            if (G >= 32) {
+            if (G >= 32 && (uint32_t) __popcll(deferred) >= a.ownLaneMin) {
                 // wide queues: every deferred lane re-scores its own hit (8 residues per step), all hits of the round in
                 // parallel and without cross-lane traffic; with a dozen or more deferred hits this beats taking them one
                 // after the other with the whole group (most of whose lanes idle on a 50-150 residue overlap)
@@ -1805,6 +1806,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     a.s = sv; a.qoff = al->d_qoff.as<uint64_t>(); a.recs = al->d_recs.as<AlnRec>(); a.items = dItems.as<Item>(); a.arenaOff = dArenaOff.as<uint64_t>();
     a.leftCap = dLeftCap.as<uint32_t>(); a.arena = dArena.as<char>(); a.flags = dFlags.as<uint32_t>(); a.newLen = dNewLen.as<uint32_t>(); a.newStart = dNewStart.as<uint64_t>();
     a.mat = dMat.as<signed char>(); a.lambda = ev.g[0]; a.logK = ev.logK; a.ln2 = ev.ln2; a.seqIdThr = par->seq_id_thr; a.maxSeqLen = par->max_seq_len; a.rescoreMode = par->rescore_mode;
+    a.ownLaneMin = (uint32_t) tuneInt("ASM_OWN", 6);      // swept 1 / 3 / 6 / 12 / never: 30.4 / 28.4 / 27.9 / 29.9 / 40.3 ms for the two wide tiers (profiles/r05_ab_knobs.txt, call 11)
     a.stats = dStats.as<unsigned long long>();
     a.smallList = dSmallList.as<uint32_t>(); a.nSmall = cnts[0];
     a.mid32List = dMid32List.as<uint32_t>(); a.nMid32 = cnts[1];
@@ -1903,7 +1905,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    if (a.nMid32) hipLaunchKernelGGL((assembleGroupKernel<32, 5>), dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * 5u)), dim3(256), 0, st, a);
+    if (a.nMid32) hipLaunchKernelGGL((assembleGroupKernel<32, 5>), dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * 5u)), dim3(256), 0, st, a);      // (4 wavefronts per SIMD: 28.3 against 28.0 ms)
     if (a.nMid) {
         if (w64 == 5) hipLaunchKernelGGL((assembleGroupKernel<64, 5>), g64, dim3(256), 0, st, a);
         else if (w64 == 4) hipLaunchKernelGGL((assembleGroupKernel<64, 4>), g64, dim3(256), 0, st, a);

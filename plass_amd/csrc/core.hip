@@ -44,6 +44,10 @@ int g_ctxCount = 0;
 // plasship_ctx_reserve_async: the arena's big slab is being allocated by a background thread; an allocation that finds no range waits
 std::mutex g_reserveMu; std::condition_variable g_reserveCv; int g_reserving = 0;
 thread_local bool tl_isReserver = false;
+// A process that ends while the reservation thread is still inside hipMalloc (a CLI failure right after plasship_ctx_reserve_async: ADVICE r4):
+// this object is constructed after — so destroyed before — the mutexes, the condition variable and the pools above, and before the HIP
+// runtime's own exit handlers (registered earlier, when the library's dependency was loaded); its destructor waits for the thread.
+struct ReserveJoin { ~ReserveJoin() { std::unique_lock<std::mutex> lk(g_reserveMu); g_reserveCv.wait(lk, [] { return g_reserving == 0; }); } } g_reserveJoin;
 size_t g_poolHits = 0, g_poolMisses = 0; double g_poolMissMs = 0, g_poolMissBytes = 0;
 
 // best fit over all free ranges of the device (a few hundred at most)

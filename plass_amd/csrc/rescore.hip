@@ -8,7 +8,7 @@
 //   alignment/DistanceCalculator.h:204-220  mode 3 end-to-end score, '*' trimmed at either end
 //   alignment/rescorediagonal.cpp:251-297   alnLen, coordinates, identity count, seqId, coverage
 //
-// Kernel design: ONE THREAD per candidate pair whenever the shorter sequence has at most 512 residues (rescoreKernel<1>: a read
+// Kernel design: ONE THREAD per candidate pair whenever the shorter sequence has at most 768 residues (rescoreKernel<1>: a read
 // overlap is 30-150 columns; a wavefront per pair would idle most lanes and pay two reductions per pair), 16 lanes per pair on a
 // list of the rest (rescoreKernel<16>, 8 residues per lane and step).  The 123x123 ASCII-indexed score table
 // (SubstitutionMatrix.h:56-73; 15 KB) lives in LDS; a thread streams 16 residues of both sequences per round trip (unaligned
@@ -88,7 +88,7 @@ __device__ __forceinline__ char nuclRevCompChar(char c) {
 constexpr int RS_BLOCK = 256;
 // lanes per candidate pair: G = 1 (one thread per pair: short read overlaps, ~6 wave-instructions per pair)
 // or G = 16 (long overlaps, queued by the first kernel)
-constexpr uint32_t RS_SHORT_MAX = 512;   // min(qLen, tLen) handled by one thread
+constexpr uint32_t RS_SHORT_MAX = 768;   // min(qLen, tLen) handled by one thread (round 5: 512 -> 768 once the identity pairs were gone: 31.2 -> 30.7 ms; 256: 46, 2048: 30.9)
 
 template <int G> __device__ __forceinline__ int groupReduceSumG(int v) {
 #pragma unroll
@@ -453,7 +453,7 @@ int finishSelfAlns(plasship_ctx *ctx, const plasship_alns *al, const uint32_t *d
     const uint64_t work = dQueryList ? (uint64_t) nQueryList : n;
     if (work) {
         const unsigned grid = (unsigned) std::min<uint64_t>((work + 255) / 256 + 1, (uint64_t) ctx->numCU * 32);
-        hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+        hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
         hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);
     }
     PH_CHECK(plasship::streamSync(ctx->stream));          // (the local buffers above are released with the function: their kernels must be through)
@@ -522,12 +522,14 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     a.mode = 0; a.lazySelf = tuneInt("LAZY_SELF", 1) == 1 ? 1 : 0;      // PLASSHIP_TUNE_LAZY_SELF=2: every identity pair scored here (rounds 1-4)
     const unsigned grid = (unsigned) std::min<uint64_t>((nHits + 255) / 256 + 1, (uint64_t) ctx->numCU * (uint64_t) tuneInt("RESCORE", nHits > 50000000ull ? 32 : 12));   // large lists: smaller shares per workgroup even out the tail (37.8 -> 35.9 ms at 250 M pairs)
     PH_CHECK(hipEventRecord(ctx->ev[0], ctx->stream));
-    static const int wpe = tuneInt("RESCORE_WPE", 5);       // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight)
+    // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight).  Round 5: 4 — with the stub and finishing paths
+    // the kernel spills 88 bytes per lane at 5 (96 VGPRs) and nothing at 4 (125): 35.5 -> 31.2 ms per iteration at 50 M reads; 3: 33.2, 6: 43.9
+    // (profiles/r05_ab_knobs.txt, calls 12-13)
+    static const int wpe = tuneInt("RESCORE_WPE", 4);
     // (16 or 8 lanes per pair for EVERY pair, and a second thread-per-pair pass for the overlaps of 128-512 columns, were both
     // slower — 76 / 53 ms and 83 ms against 45 ms per iteration at 50 M reads: profiles/r03_ab_knobs.txt)
-    if (wpe == 4) hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-    else if (wpe == 6) hipLaunchKernelGGL((rescoreKernel<1, 6>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    if (wpe == 5) hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     // the list stays SPARSE (common.hpp: plasship_alns): record h belongs to candidate pair h, the CSR is the candidate list's
