@@ -203,8 +203,8 @@ def stored_traffic(kernel, launches_per_step, cfg="c3"):
 # of kmermatcher that is NOT sharded when every rank extracts all sequences (owner-filtered extraction, the default up to 4 ranks), the
 # 1-rank overhead of the sharded orchestration (12.5 M reads: the owner's merge of the exchanged triples, packing the extended sequences);
 # link: one xGMI link per GPU pair, 76 GB/s per direction assumed.
-MODEL_50M = {"kmermatcher_ms": 217.0, "extraction_ms": 75.0, "rescore_ms": 35.0, "assemble_ms": 78.0, "other_ms": 0.0,
-             "shard_overhead": 0.09, "level1_line_bytes": 63e9, "triple_bytes": 5e9, "extended_bytes": 3.5e9, "link_GBs": 76.0, "host_rounds_ms": 2.0}
+MODEL_50M = {"kmermatcher_ms": 213.0, "extraction_ms": 75.0, "rescore_ms": 30.0, "assemble_ms": 75.0, "other_ms": 0.0,
+             "shard_overhead": 0.10, "level1_line_bytes": 63e9, "triple_bytes": 5e9, "extended_bytes": 3.5e9, "link_GBs": 76.0, "host_rounds_ms": 2.0}
 
 
 def scaling_model(world, reads, measured_module_wall=None):
