@@ -342,3 +342,20 @@ def test_deep_chain_fixtures_are_complete():
     g = json.load(open(os.path.join(ROOT, "tests", "golden", "c2_chain_digests.json")))
     assert "CPU oracle" in g["made_by"] and g["pairs"] == 500000 and g["digests"] == [r["seq"]["digest"] for r in d["c2_bench"]["iterations"]]
     assert g["digests"][0] != c2["iterations"][0]["seq"]["digest"]      # findassemblystart changes iteration 0 already
+
+
+def test_scaling_model_and_furthest_below_of_the_bench_line():
+    """bench.py: the cost model the N > 1 line prints (owner-filtered extraction up to 4 ranks, the exchange of level-1
+    lines beyond) and the `roofline.furthest_below` selection"""
+    import bench
+    m1, m2, m4, m8 = (bench.scaling_model(w, 50e6) for w in (1, 2, 4, 8))
+    assert m1["library_default"] == m2["library_default"] == m4["library_default"] == "owner_filtered" and m8["library_default"] == "exchange"
+    assert m2["owner_filtered"]["total_ms"] < m2["exchange"]["total_ms"]            # one link per pair: replicated extraction beats moving every record
+    assert m8["exchange"]["total_ms"] < m8["owner_filtered"]["total_ms"]            # seven links per GPU: the all-to-all wins
+    assert 1.0 < m2["owner_filtered"]["speedup"] < m4["owner_filtered"]["speedup"] < m8["exchange"]["speedup"] < 8.0
+    assert bench.scaling_model(4, 25e6)["single_gpu_ms"] == pytest.approx(m4["single_gpu_ms"] / 2, rel=1e-3)      # linear in the reads
+    # furthest_below: the single kernel with the lowest fraction of the HBM peak by algorithmic bytes among those above 2 % of the step
+    tot = {"kmermatcher_stage": [200.0, 280e9, False, 1], "rescore_stage": [30.0, 45e9, False, 1], "assemble_stage": [70.0, 51e9, False, 1],
+           "fast": [50.0, 200e9, True, 1], "slow": [20.0, 5e9, True, 1], "tiny": [1.0, 1e6, True, 1], "stage_not_single": [90.0, 1e9, False, 1]}
+    fb = bench.furthest_below(tot, 1, "no-such-config")
+    assert fb["kernel"] == "slow" and fb["frac"] == pytest.approx(5e9 / 20e-3 / 1e9 / bench.HBM_PEAK_GBS) and fb["traffic_ratio"] is None
