@@ -10,6 +10,7 @@ with the fixture:
             incl. findassemblystart in iteration 0
   c2_bench  the same reads through the chain `bench.py --config c2` times (no findassemblystart)
   c3_deep   2 M reads of the configs[2] community, twelve iterations
+  large_chain, large_nucl  the round-2/3 fixtures of tests/test_gpu_large.py / test_gpu_large_nucl.py (12.5 M / 5 M reads), oracle-made like the deep ones
   c5_headline  (only on request: hours) the workload of `bench.py --config c5`: 20 M reads, 5 nucleotide + 5 guided iterations — against
             tests/golden/c5_chain_digests.json (GPU-made)
   c3_headline  (only on request: hours) THE BENCH LINE'S WORKLOAD: 50 M reads, twelve iterations — against tests/golden/c3_chain_digests.json, the
@@ -117,7 +118,7 @@ def protein(g, bench, _lib, fx, q, td):
               "--max-seq-len", "65535", "--hash-shift", str(bench.hash_shift(it)), "--include-only-extendable", "1" if it else "0"]
         km += fx.get("km_extra", [])
         ref(PLASS, ["kmermatcher", s, p] + km, q); ref(PLASS, ["rescorediagonal", s, s, p, al] + RS, q)
-        if it == 0 and fx["findassemblystart"]:
+        if it == 0 and fx.get("findassemblystart"):
             check(p, want["pref_uncorrected"], "it 0: kmermatcher before findassemblystart"); check(al, want["aln_uncorrected"], "it 0: rescorediagonal before findassemblystart")
             ref(PLASS, ["findassemblystart", s, al, P("corrected")], q)
             check(P("corrected"), want["corrected"], "it 0: findassemblystart")
@@ -231,6 +232,10 @@ def main():
         with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
             if what in ("c2_exact", "c3_deep", "c2_bench"):
                 protein(g, bench, _lib, fx[what], q, td)
+            elif what == "large_chain":            # tests/golden/large_chain.json (12.5 M reads, three iterations: tests/test_gpu_large.py), oracle-made as well
+                protein(g, bench, _lib, json.load(open(os.path.join(ROOT, "tests", "golden", "large_chain.json"))), q, td)
+            elif what == "large_nucl":             # tests/golden/large_nucl.json (5 M reads, three nucleotide + two guided iterations: tests/test_gpu_large_nucl.py)
+                nucl_and_guided(g, bench, _lib, T, json.load(open(os.path.join(ROOT, "tests", "golden", "large_nucl.json"))), q, td)
             elif what == "c3_headline":
                 # the workload of the bench line itself: 50 M reads, twelve iterations.  tests/golden/c3_chain_digests.json holds what the GPU path
                 # produced (what `verify` in bench.py compares every run with); here the reference computes the same chain on the CPU.
