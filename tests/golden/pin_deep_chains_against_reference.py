@@ -10,7 +10,8 @@ with the fixture:
             incl. findassemblystart in iteration 0
   c2_bench  the same reads through the chain `bench.py --config c2` times (no findassemblystart)
   c3_deep   2 M reads of the configs[2] community, twelve iterations
-  large_chain, large_nucl  the round-2/3 fixtures of tests/test_gpu_large.py / test_gpu_large_nucl.py (12.5 M / 5 M reads), oracle-made like the deep ones
+  large_chain, large_nucl, big_offsets  the round-2..4 fixtures of tests/test_gpu_large.py / test_gpu_large_nucl.py (12.5 M / 5 M reads; sequence data
+            beyond 2^32 bytes), oracle-made like the deep ones
   c5_headline  (only on request: hours) the workload of `bench.py --config c5`: 20 M reads, 5 nucleotide + 5 guided iterations — against
             tests/golden/c5_chain_digests.json (GPU-made)
   c3_headline  (only on request: hours) THE BENCH LINE'S WORKLOAD: 50 M reads, twelve iterations — against tests/golden/c3_chain_digests.json, the
@@ -108,7 +109,19 @@ def protein(g, bench, _lib, fx, q, td):
         rm(P("nucl_" + name), P("nucl_" + name + "_h"))
     ref(PLASS, ["concatdbs", P("aa_long"), P("aa_start"), P("seq_0")], q)
     rm(P("reads"), P("reads_h"), P("aa_long"), P("aa_start"), P("aa_long_h"), P("aa_start_h"))
-    check(P("seq_0"), fx["fragments"], "extractorfs x2 + translatenucs x2 + concatdbs")
+    if fx.get("filler"):
+        # tests/golden/big_offsets.json: 4.48 GB of filler sequences in front of the fragments, so every live byte offset exceeds 2^32
+        from make_big_offsets import write_filler_db
+        check(P("seq_0"), fx["live"], "extractorfs x2 + translatenucs x2 + concatdbs (the live fragments)")
+        for sfx in ("", ".index", ".dbtype"):
+            os.rename(P("seq_0") + sfx, P("live") + sfx)
+        write_filler_db(P("filler"), fx["filler"]["n"], fx["filler"]["length"], fx["filler"]["seed"])
+        check(P("filler"), fx["filler_db"], "filler DB (numpy generator)")
+        ref(PLASS, ["concatdbs", P("filler"), P("live"), P("seq_0")], q)
+        rm(P("filler"), P("live"))
+        check(P("seq_0"), fx["db"], "concatdbs filler live: the DB beyond 2^32 bytes")
+    else:
+        check(P("seq_0"), fx["fragments"], "extractorfs x2 + translatenucs x2 + concatdbs")
     t_it = time.time()
     RS = ["--rescore-mode", "3", "-e", "1e-05", "-c", "0", "-a", "0", "--cov-mode", "0", "--min-seq-id", "0.9", "--min-aln-len", "0", "--seq-id-mode", "0", "--sort-results", "0"]
     AS = ["--min-seq-id", "0.9", "--max-seq-len", "65535", "--keep-target", "1", "--rescore-mode", "3"]
@@ -234,6 +247,8 @@ def main():
                 protein(g, bench, _lib, fx[what], q, td)
             elif what == "large_chain":            # tests/golden/large_chain.json (12.5 M reads, three iterations: tests/test_gpu_large.py), oracle-made as well
                 protein(g, bench, _lib, json.load(open(os.path.join(ROOT, "tests", "golden", "large_chain.json"))), q, td)
+            elif what == "big_offsets":            # tests/golden/big_offsets.json (sequence data beyond 2^32 bytes, three iterations)
+                protein(g, bench, _lib, json.load(open(os.path.join(ROOT, "tests", "golden", "big_offsets.json"))), q, td)
             elif what == "large_nucl":             # tests/golden/large_nucl.json (5 M reads, three nucleotide + two guided iterations: tests/test_gpu_large_nucl.py)
                 nucl_and_guided(g, bench, _lib, T, json.load(open(os.path.join(ROOT, "tests", "golden", "large_nucl.json"))), q, td)
             elif what == "c3_headline":
