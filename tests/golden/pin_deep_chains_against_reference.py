@@ -102,7 +102,7 @@ def protein(g, bench, _lib, fx, q, td):
     P = lambda n: os.path.join(td, n)
     sp = bench.synth_params(fx["config"], fx["pairs"])
     synth(g, sp, P("reads")); write_header_db(P("reads"), P("reads_h"))
-    check(P("reads"), fx["reads"], "synthetic reads")
+    check(P("reads"), fx.get("reads"), "synthetic reads")
     for name, par in (("long", _lib.PLASS_ORFS_LONG), ("start", _lib.PLASS_ORFS_START)):
         ref(PLASS, ["extractorfs", P("reads"), P("nucl_" + name)] + orf_flags(par), Q1)
         ref(PLASS, ["translatenucs", P("nucl_" + name), P("aa_" + name), "--add-orf-stop", "1"], Q1)
@@ -149,7 +149,7 @@ def nucl_and_guided(g, bench, _lib, T, fx, q, td):
     P = lambda n: os.path.join(td, n)
     sp = bench.synth_params("c5", fx["pairs"])
     synth(g, sp, P("reads")); write_header_db(P("reads"), P("reads_h"))
-    check(P("reads"), fx["reads"], "synthetic reads")
+    check(P("reads"), fx.get("reads"), "synthetic reads")
     src = P("reads")
     t_it = time.time()
     for it, want in enumerate(fx["nucl"]):
