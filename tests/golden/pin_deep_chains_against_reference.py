@@ -12,6 +12,8 @@ with the fixture:
   c3_deep   2 M reads of the configs[2] community, twelve iterations
   large_chain, large_nucl, big_offsets  the round-2..4 fixtures of tests/test_gpu_large.py / test_gpu_large_nucl.py (12.5 M / 5 M reads; sequence data
             beyond 2^32 bytes), oracle-made like the deep ones
+  record_chain  (only on request: hours) WRITES tests/golden/reference_chain.json: twelve iterations on 25 M reads of the configs[2] community by the
+            reference alone — a fixture with no oracle in its chain of trust (tests/test_gpu_deep.py::test_reference_made_chain)
   c5_headline  (only on request: hours) the workload of `bench.py --config c5`: 20 M reads, 5 nucleotide + 5 guided iterations — against
             tests/golden/c5_chain_digests.json (GPU-made)
   c3_headline  (only on request: hours, and only meaningful on a host with > 100 GB of memory) THE BENCH LINE'S WORKLOAD: 50 M reads, twelve iterations —
@@ -49,6 +51,7 @@ Q1 = ["--threads", "1", "-v", "1"]
 
 
 T_REF = {}
+SPLIT_SEEN = False
 
 
 def ref(binary, args, q):
@@ -62,6 +65,8 @@ def ref(binary, args, q):
         out = subprocess.run([binary] + [str(a) for a in args] + q[:2] + ["-v", "3"], check=True, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True).stdout
         parts = [l for l in out.splitlines() if l.startswith("Process file into")]
         if parts:
+            global SPLIT_SEEN
+            SPLIT_SEEN = True
             print("         (NOTE: the reference's kmermatcher split its work — '%s' — the result of a split run differs from the unsplit one)" % parts[0].strip(), flush=True)
     else:
         subprocess.run([binary] + [str(a) for a in args] + q, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.STDOUT)
@@ -81,11 +86,18 @@ def same(path, want):
     return all(got[k] == want[k] for k in ("entries", "bytes", "digest") if k in want)
 
 
+RECORD = False                                            # --record-chain: the reference's digests are written down instead of compared
+
+
 def check(path, want, what):
     global N_OK, N_BAD
     if want is None:                                          # no fixture for this DB (headline chain: only the sequence DBs have one)
         return
     got = db_sums(path)
+    if RECORD:
+        want.update(got)
+        print("%-8s %-58s entries %9d bytes %11d digest %s" % ("RECORD", what, got["entries"], got["bytes"], got["digest"]), flush=True)
+        return
     ok = all(got[k] == want[k] for k in ("entries", "bytes", "digest") if k in want)
     N_OK += ok; N_BAD += (not ok)
     print("%-8s %-58s entries %9d bytes %11d digest %s%s" % ("MATCH" if ok else "DIFFERS", what, got["entries"], got["bytes"], got["digest"],
@@ -142,7 +154,11 @@ def protein(g, bench, _lib, fx, q, td):
         km = ["--alph-size", "13", "--kmer-per-seq", "60", "--kmer-per-seq-scale", "nucl:0.200,aa:0.000", "-k", "14", "-c", "0", "--cov-mode", "0", "--ignore-multi-kmer", "1",
               "--max-seq-len", "65535", "--hash-shift", str(bench.hash_shift(it)), "--include-only-extendable", "1" if it else "0"]
         km += fx.get("km_extra", [])
-        ref(PLASS, ["kmermatcher", s, p] + km, q); ref(PLASS, ["rescorediagonal", s, s, p, al] + RS, q)
+        ref(PLASS, ["kmermatcher", s, p] + km, q)
+        if SPLIT_SEEN and fx.get("stop_on_split"):
+            print("         (iteration %d: the records no longer fit this host's memory in one part; the chain is not followed further)" % it, flush=True)
+            break
+        ref(PLASS, ["rescorediagonal", s, s, p, al] + RS, q)
         if it == 0 and fx.get("findassemblystart"):
             check(p, want["pref_uncorrected"], "it 0: kmermatcher before findassemblystart"); check(al, want["aln_uncorrected"], "it 0: rescorediagonal before findassemblystart")
             ref(PLASS, ["findassemblystart", s, al, P("corrected")], q)
@@ -244,6 +260,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="c2_exact,c3_deep,c5_deep")
     ap.add_argument("--threads", type=int, default=8)
+    ap.add_argument("--record-pairs", type=int, default=12500000, help="read pairs of the record_chain section")
     ap.add_argument("--split-memory-limit", default="0", help="of the headline sections' kmermatcher calls (0 = the reference's default: 90 %% of the host's memory)")
     a = ap.parse_args()
     import bench, __graft_entry__ as g
@@ -258,6 +275,24 @@ def main():
         with tempfile.TemporaryDirectory(dir=os.environ.get("TMPDIR", "/tmp")) as td:
             if what in ("c2_exact", "c3_deep", "c2_bench"):
                 protein(g, bench, _lib, fx[what], q, td)
+            elif what == "record_chain":
+                # A fixture made by the REFERENCE ALONE (no oracle in the chain of trust): tests/golden/reference_chain.json — the twelve iterations of the
+                # default protein chain on --record-pairs read pairs of the configs[2] community, as large as the reference runs UNSPLIT on this host.
+                from make_deep_chains import synth_dict
+                global RECORD
+                RECORD = True
+                sp = bench.synth_params("c3", a.record_pairs)
+                rec = {"made_by": "tests/golden/pin_deep_chains_against_reference.py --only record_chain (the UNMODIFIED reference: plass kmermatcher / rescorediagonal / "
+                                  "assembleresults, 8 threads, unsplit; digests by plass_oracle dbsum)",
+                       "config": "c3", "pairs": a.record_pairs, "iters": 12, "findassemblystart": False, "synth": synth_dict(sp), "reads": {}, "fragments": {},
+                       "iterations": [{"pref": {}, "aln": {}, "seq": {}} for _ in range(12)]}
+                protein(g, bench, _lib, rec, q, td)
+                RECORD = False
+                assert not SPLIT_SEEN, "the reference split its kmermatcher: this is not the result the fixture is meant to hold"
+                rec["reference_seconds"] = {k: round(v, 1) for k, v in T_REF.items()}
+                with open(os.path.join(ROOT, "tests", "golden", "reference_chain.json"), "w") as f:
+                    json.dump(rec, f, indent=1)
+                    f.write("\n")
             elif what == "large_chain":            # tests/golden/large_chain.json (12.5 M reads, three iterations: tests/test_gpu_large.py), oracle-made as well
                 protein(g, bench, _lib, json.load(open(os.path.join(ROOT, "tests", "golden", "large_chain.json"))), q, td)
             elif what == "big_offsets":            # tests/golden/big_offsets.json (sequence data beyond 2^32 bytes, three iterations)
@@ -268,7 +303,7 @@ def main():
                 # the workload of the bench line itself: 50 M reads, twelve iterations.  tests/golden/c3_chain_digests.json holds what the GPU path
                 # produced (what `verify` in bench.py compares every run with); here the reference computes the same chain on the CPU.
                 h = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_chain_digests.json")))
-                protein(g, bench, _lib, {"config": h["config"], "pairs": h["pairs"], "findassemblystart": False, "reads": None, "fragments": {"entries": h["fragments"]},
+                protein(g, bench, _lib, {"config": h["config"], "pairs": h["pairs"], "findassemblystart": False, "reads": None, "fragments": {"entries": h["fragments"]}, "stop_on_split": True,
                                          "km_extra": ["--split-memory-limit", a.split_memory_limit],      # 5.3 G k-mer records = 85 GB: unsplit only on a host with > 100 GB
                                          "iterations": [{"seq": {"digest": d}} for d in h["digests"]]}, q, td)
             elif what == "c5_headline":
