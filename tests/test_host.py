@@ -387,6 +387,26 @@ def test_deep_chain_fixtures_carry_the_reference_pin():
     assert sum(len(v) for v in sect.values()) == 134
 
 
+def test_bench_workload_digests_carry_the_reference_pin():
+    """tests/golden/c5_chain_digests.json (what `bench.py --config c5` verifies every run against; made by the GPU path) is identical to what the
+    unmodified reference computes for the same 20 M reads: profiles/r05_headline_pin_reference.txt must show every one of the ten committed digests
+    as a MATCH of the reference's run, and no difference"""
+    import json
+    h = json.load(open(os.path.join(ROOT, "tests", "golden", "c5_chain_digests.json")))
+    rec = open(os.path.join(ROOT, "profiles", "r05_headline_pin_reference.txt")).read()
+    body = rec.split("---- c5_headline ----")[1]
+    got = dict((m[0], m[1]) for m in re.findall(r"^MATCH +(.*?) +entries +\d+ bytes +\d+ digest ([0-9a-f]{16})$", body, re.M))
+    assert not re.search(r"^DIFFERS", body, re.M) and "NOTE: the reference's kmermatcher split" not in body
+    gd = [d.split("+") for d in h["digests"] if "+" in d]
+    nu = [d for d in h["digests"] if "+" not in d]
+    assert len(gd) == 5 and len(nu) == 5 and len(got) == 15
+    for it, (a, b) in enumerate(gd):
+        assert got["guided it %d: nucl" % it] == a and got["guided it %d: aa" % it] == b
+    for it, d in enumerate(nu):
+        assert got["nucleotide it %d: rest" % it] == d
+    assert re.search(r"^DBs compared: 15, identical to the reference's: 15, differing: 0$", body, re.M)
+
+
 def test_scaling_model_and_furthest_below_of_the_bench_line():
     """bench.py: the cost model the N > 1 line prints (owner-filtered extraction up to 4 ranks, the exchange of level-1
     lines beyond) and the `roofline.furthest_below` selection"""
