@@ -388,7 +388,17 @@ def test_deep_chain_fixtures_carry_the_reference_pin():
             for k in ("pref", "aln", "aln_nucl", "nucl", "aa"):
                 want(name, "guided it %d: %s" % (it, k), r[k])
         assert len(sect[name]) == 3 + 5 * len(f["nucl"]) + 5 * len(f["guided"])
-    assert sum(len(v) for v in sect.values()) == 134 + 11 + 28
+    # sequence data beyond 2^32 bytes (big_offsets.json)
+    f = G("big_offsets.json")
+    body = rec.split("---- big_offsets ----")[1].split("\n(big_offsets done")[0]
+    sect["big_offsets"] = re.findall(r"^MATCH +(.*?) +entries +(\d+) bytes +(\d+) digest ([0-9a-f]{16})$", body, re.M)
+    assert not re.search(r"^DIFFERS", body, re.M)
+    want("big_offsets", "extractorfs x2 + translatenucs x2 + concatdbs (the live fragments)", f["live"]); want("big_offsets", "filler DB (numpy generator)", f["filler_db"])
+    want("big_offsets", "concatdbs filler live: the DB beyond 2^32 bytes", f["db"])
+    for it, r in enumerate(f["iterations"]):
+        want("big_offsets", "it %d: kmermatcher" % it, r["pref"]); want("big_offsets", "it %d: rescorediagonal" % it, r["aln"]); want("big_offsets", "it %d: assembleresults" % it, r["seq"])
+    assert f["db"]["bytes"] > 1 << 32 and len(sect["big_offsets"]) == 12
+    assert sum(len(v) for v in sect.values()) == 134 + 11 + 28 + 12
 
 
 def test_bench_workload_digests_carry_the_reference_pin():
