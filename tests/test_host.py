@@ -408,7 +408,7 @@ def test_bench_workload_digests_carry_the_reference_pin():
     import json
     h = json.load(open(os.path.join(ROOT, "tests", "golden", "c5_chain_digests.json")))
     rec = open(os.path.join(ROOT, "profiles", "r05_headline_pin_reference.txt")).read()
-    body = rec.split("---- c5_headline ----")[1]
+    body = rec.split("---- c5_headline ----")[1].split("---- c3_headline ----")[0]
     got = dict((m[0], m[1]) for m in re.findall(r"^MATCH +(.*?) +entries +\d+ bytes +\d+ digest ([0-9a-f]{16})$", body, re.M))
     assert not re.search(r"^DIFFERS", body, re.M) and "NOTE: the reference's kmermatcher split" not in body
     gd = [d.split("+") for d in h["digests"] if "+" in d]
@@ -418,7 +418,19 @@ def test_bench_workload_digests_carry_the_reference_pin():
         assert got["guided it %d: nucl" % it] == a and got["guided it %d: aa" % it] == b
     for it, d in enumerate(nu):
         assert got["nucleotide it %d: rest" % it] == d
-    assert re.search(r"^DBs compared: 15, identical to the reference's: 15, differing: 0$", body, re.M)
+    assert re.search(r"^DBs compared: 15, identical to the reference's: 15, differing: 0$", body.split("---- c3_headline ----")[0], re.M)
+    # THE BENCH LINE'S WORKLOAD (50 M reads): tests/golden/c3_chain_digests.json, GPU-made; the reference follows the chain unsplit through iteration 5 on
+    # the 62 GB build container — every digest it produced must be the committed one, and the record must say where and why it stopped
+    h = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_chain_digests.json")))
+    body = rec.split("---- c3_headline ----")[1]
+    got = re.findall(r"^MATCH +it (\d+): assembleresults +entries +(\d+) bytes +\d+ digest ([0-9a-f]{16})$", body, re.M)
+    assert not re.search(r"^DIFFERS", body, re.M) and len(got) >= 6
+    for it, n, dg in got:
+        assert int(n) == h["fragments"] and dg == h["digests"][int(it)]
+    assert [int(it) for it, _, _ in got] == list(range(len(got)))
+    assert re.search(r"^MATCH +extractorfs x2 \+ translatenucs x2 \+ concatdbs +entries +%d " % h["fragments"], body, re.M)
+    first_split = body.index("NOTE: the reference's kmermatcher split")
+    assert all(body.index("it %s: assembleresults" % it) < first_split for it, _, _ in got)      # nothing after the split is claimed
 
 
 def test_scaling_model_and_furthest_below_of_the_bench_line():
