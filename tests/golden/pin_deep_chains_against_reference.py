@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """BUILD CONTAINER ONLY (needs the survey-time build of the unmodified reference, REF_BUILD = /tmp/plass-build: tests/golden/make_golden.sh).
 
-Pins tests/golden/deep_chains.json — the CPU oracle's digests of DEEP chains, which tests/test_gpu_deep.py holds the GPU path to — against the
-REFERENCE ITSELF: the same synthetic reads (`plass_oracle synthreads`), the same module calls in the same order, made by the unmodified
+Pins the fixtures that were NOT written by the reference — tests/golden/deep_chains.json and the older large fixtures (CPU oracle), and the digests of
+the bench workloads (GPU path) — against the REFERENCE ITSELF: the same synthetic reads (`plass_oracle synthreads`), the same module calls in the same order, made by the unmodified
 `plass` / `penguin` binaries (8 threads), every DB digested with `plass_oracle dbsum` (order-independent over (key, length, bytes)) and compared
 with the fixture:
 
@@ -12,13 +12,15 @@ with the fixture:
   c3_deep   2 M reads of the configs[2] community, twelve iterations
   large_chain, large_nucl, big_offsets  the round-2..4 fixtures of tests/test_gpu_large.py / test_gpu_large_nucl.py (12.5 M / 5 M reads; sequence data
             beyond 2^32 bytes), oracle-made like the deep ones
-  record_chain  (only on request: hours) WRITES tests/golden/reference_chain.json: twelve iterations on 25 M reads of the configs[2] community by the
-            reference alone — a fixture with no oracle in its chain of trust (tests/test_gpu_deep.py::test_reference_made_chain)
+  record_chain  (only on request: hours) WRITES tests/golden/reference_chain.json: twelve iterations on --record-pairs read pairs of the configs[2] community
+            by the reference alone — a fixture with no oracle in its chain of trust.  (Not run / not committed in round 5: no GPU time was left to run
+            a test against it.)
   c5_headline  (only on request: hours) the workload of `bench.py --config c5`: 20 M reads, 5 nucleotide + 5 guided iterations — against
-            tests/golden/c5_chain_digests.json (GPU-made)
-  c3_headline  (only on request: hours, and only meaningful on a host with > 100 GB of memory) THE BENCH LINE'S WORKLOAD: 50 M reads, twelve iterations —
-            against tests/golden/c3_chain_digests.json, the digests the GPU path produced and bench.py's `verify` holds every run to.  On the 62 GB
-            build container the reference's kmermatcher splits (85 GB of records), and a split run is a different computation (see ref()).
+            tests/golden/c5_chain_digests.json (GPU-made).  Output: profiles/r05_headline_pin_reference.txt
+  c3_headline  (only on request: hours) THE BENCH LINE'S WORKLOAD: 50 M reads, twelve iterations — against tests/golden/c3_chain_digests.json, the digests
+            the GPU path produced and bench.py's `verify` holds every run to.  The chain is followed as long as the reference's kmermatcher runs in ONE
+            part: on the 62 GB build container through iteration 5 (58 GB of records); iteration 6 splits, and a split run is a different computation
+            (see ref()).  A host with > 100 GB carries it through all twelve.  Output: profiles/r05_headline_pin_reference.txt
   c5_deep   2 M reads of the configs[4] model: six nucleotide iterations with cyclecheck --chop-cycle 1 + the rest DB (data/nuclassemble.sh),
             four protein-guided iterations (data/guidedNuclAssemble.sh)
 
