@@ -419,18 +419,20 @@ def test_bench_workload_digests_carry_the_reference_pin():
     for it, d in enumerate(nu):
         assert got["nucleotide it %d: rest" % it] == d
     assert re.search(r"^DBs compared: 15, identical to the reference's: 15, differing: 0$", body.split("---- c3_headline ----")[0], re.M)
-    # THE BENCH LINE'S WORKLOAD (50 M reads): tests/golden/c3_chain_digests.json, GPU-made; the reference follows the chain unsplit through iteration 5 on
-    # the 62 GB build container — every digest it produced must be the committed one, and the record must say where and why it stopped
+    # THE BENCH LINE'S WORKLOAD (50 M reads): tests/golden/c3_chain_digests.json, GPU-made; the reference follows the whole chain UNSPLIT
+    # (--split-memory-limit 64G on the 62 GB build container) — all twelve digests it produced must be the committed ones
     h = json.load(open(os.path.join(ROOT, "tests", "golden", "c3_chain_digests.json")))
-    body = rec.split("---- c3_headline ----")[1]
+    body = rec.split("---- c3_headline ----")[1].split("# ---- the first run")[0]
     got = re.findall(r"^MATCH +it (\d+): assembleresults +entries +(\d+) bytes +\d+ digest ([0-9a-f]{16})$", body, re.M)
-    assert not re.search(r"^DIFFERS", body, re.M) and len(got) >= 6
+    assert not re.search(r"^DIFFERS", body, re.M) and "NOTE: the reference's kmermatcher split" not in body
+    assert [int(it) for it, _, _ in got] == list(range(12)) and len(h["digests"]) == 12
     for it, n, dg in got:
         assert int(n) == h["fragments"] and dg == h["digests"][int(it)]
-    assert [int(it) for it, _, _ in got] == list(range(len(got)))
     assert re.search(r"^MATCH +extractorfs x2 \+ translatenucs x2 \+ concatdbs +entries +%d " % h["fragments"], body, re.M)
-    first_split = body.index("NOTE: the reference's kmermatcher split")
-    assert all(body.index("it %s: assembleresults" % it) < first_split for it, _, _ in got)      # nothing after the split is claimed
+    assert re.search(r"^DBs compared: 13, identical to the reference's: 13, differing: 0$", body, re.M)
+    # the first run (default memory limit) stopped where the reference began to split, and claims nothing beyond
+    first = rec.split("# ---- the first run")[1]
+    assert first.index("it 5: assembleresults") < first.index("NOTE: the reference's kmermatcher split") and "it 6: assembleresults" not in first
 
 
 def test_scaling_model_and_furthest_below_of_the_bench_line():
