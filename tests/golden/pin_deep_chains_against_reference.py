@@ -19,8 +19,8 @@ with the fixture:
             tests/golden/c5_chain_digests.json (GPU-made).  Output: profiles/r05_headline_pin_reference.txt
   c3_headline  (only on request: hours) THE BENCH LINE'S WORKLOAD: 50 M reads, twelve iterations — against tests/golden/c3_chain_digests.json, the digests
             the GPU path produced and bench.py's `verify` holds every run to.  The chain is followed as long as the reference's kmermatcher runs in ONE
-            part: on the 62 GB build container through iteration 5 (58 GB of records); iteration 6 splits, and a split run is a different computation
-            (see ref()).  A host with > 100 GB carries it through all twelve.  Output: profiles/r05_headline_pin_reference.txt
+            part (a split run is a different computation, see ref()): with the default limit on the 62 GB build container through iteration 5; with
+            `--split-memory-limit 64G` through all twelve (62.8 GB of records in iteration 11: just fits).  Output: profiles/r05_headline_pin_reference.txt
   c5_deep   2 M reads of the configs[4] model: six nucleotide iterations with cyclecheck --chop-cycle 1 + the rest DB (data/nuclassemble.sh),
             four protein-guided iterations (data/guidedNuclAssemble.sh)
 
