@@ -534,6 +534,9 @@ def main():
         if gold and gold.get("pairs") == wl["read_pairs"] and mode != "partitions":
             verify["reference"] = "tests/golden/%s_chain_digests.json" % args.config
             verify["match"] = digests == gold["digests"][:len(digests)]
+            # (round 5: those digests are what the UNMODIFIED REFERENCE computes for this workload — c3: all twelve iterations of the 50 M-read chain,
+            # c2: the oracle's digests, themselves pinned against the reference; profiles/r05_headline_pin_reference.txt, r05_deep_pin_reference.txt)
+            verify["reference_is"] = "identical to the unmodified reference binaries' run of this workload (profiles/r05_headline_pin_reference.txt, profiles/r05_deep_pin_reference.txt)"
     # ---- CPU baseline + the drop-in command line on the same sample.  BEFORE the wall-clock leg below: that leg's child process takes and
     # returns 270 GB of HBM, and for seconds afterwards every process that allocates device memory waits for the driver to scrub it — the
     # nine short `plass-hip` invocations of this leg then measure that (round 4's first evidence run: 4.8 s instead of 1.3 s;
@@ -679,8 +682,8 @@ def main_c5(args):
     ctx.sync(); torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     # ---- untimed verification: one more traversal, digest of every step's output DB(s) against the committed digests of this workload
-    # (tests/golden/c5_chain_digests.json — the GPU path's own output, a regression pin; the same chains are checked against the CPU
-    # oracle at 5 M reads by tests/test_gpu_large_nucl.py) ----
+    # (tests/golden/c5_chain_digests.json — written down from the GPU path's output in round 4; round 5: identical to the unmodified reference's
+    # run of the same 20 M reads, profiles/r05_headline_pin_reference.txt) ----
     verify = None
     if not args.no_verify:
         digests = []
@@ -693,6 +696,7 @@ def main_c5(args):
         if gold and gold.get("pairs") == sp.n_pairs:
             verify["reference"] = "tests/golden/c5_chain_digests.json"
             verify["match"] = digests == gold["digests"][:len(digests)]
+            verify["reference_is"] = "identical to the unmodified reference binaries' run of this workload (profiles/r05_headline_pin_reference.txt)"
     tot = {}
     for (_, _, k, r, a, extra, kind) in rows:
         tab = stage_table(k, r, a, nucl_queue=True)
