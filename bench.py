@@ -25,7 +25,7 @@ Also on the JSON line:
   iterations   — one row per timed step: chain iteration, ms, N_k / N_m / N_c, stage times
   roofline     — dominant kernel of the timed run: algorithmic bytes (SURVEY.md section 8d) / its HIP-event time, per launch;
                  `traffic` = HBM bytes per launch of that kernel from the stored rocprofv3 PMC pass of the same command
-                 (profiles/r02_pmc_traffic.json), null if that file has no row for it
+                 (PMC_FILES below: the newest profiles/rNN_pmc_traffic.json taken from these sources), null if that file has no row for it
   cpu_baseline — the CPU oracle (a port of the reference's algorithm, oracle/) on a bounded sample of the same community
                  model on this host's cores (rank 0, N = 1), plus the I/O-inclusive rate of the drop-in command line
                  (plass-hip: DB files in, DB files out) on the same sample
@@ -174,24 +174,32 @@ KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extr
                   # (MODE 0 = the hash partition of the k-mer records; the MODE 1 instantiations are the rep sort's range partitions: VERDICT r4 weak #10)
                   "partitionKernel(k-mer records)": "linePartKernel<(true|false), (true|false), 0, .*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel",
                   "assembleNuclKernel(+assembleNuclThreadKernel, all passes)": "assembleNucl(Thread)?Kernel<"}
-PMC_FILES = {"c3": "r05_pmc_traffic.json", "c5": "r05_pmc_traffic_c5.json"}
+ROUND = "r06"                          # prefix of the profiles/ files this round's evidence run writes (tools/gpu_round6_final.sh)
+KERNEL_STATS_FILE = "profiles/%s_kernel_stats_driver_cmd.txt" % ROUND
+# stored PMC passes, newest first: the first one whose recorded source hash equals this build's is quoted (stored_traffic)
+PMC_FILES = {"c3": ["%s_pmc_traffic.json" % ROUND, "r05_pmc_traffic.json"], "c5": ["%s_pmc_traffic_c5.json" % ROUND, "r05_pmc_traffic_c5.json"]}
 
 
 def stored_traffic(kernel, launches_per_step, cfg="c3"):
     """(HBM bytes per launch of `kernel` — all its instantiations together — from the stored PMC passes of the driver's command, note).
-    profiles/r04_pmc_traffic[_c5].json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes, FETCH_SIZE doubled as
+    profiles/rNN_pmc_traffic[_c5].json (PMC_FILES): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in two separate passes, FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for gfx950; the file records the hash of the sources it was measured on and is refused for any
     other code.  A stored figure, not measured in this run: PMC collection serialises the kernels."""
-    name = PMC_FILES.get(cfg)
-    if name is None:
+    names = PMC_FILES.get(cfg)
+    if not names:
         return None, "no PMC pass is stored for --config %s" % cfg
-    f = os.path.join(ROOT, "profiles", name)
-    try:
-        rows = json.load(open(f))
-    except (OSError, ValueError):
-        return None, "no stored PMC profile (profiles/%s)" % name
-    if rows.get("source_sha") != source_sha():
-        return None, "profiles/%s was taken from other sources (%s, this build %s): not quoted" % (name, rows.get("source_sha"), source_sha())
+    rows, why = None, "no stored PMC profile (profiles/%s)" % names[0]
+    for name in names:
+        try:
+            cand = json.load(open(os.path.join(ROOT, "profiles", name)))
+        except (OSError, ValueError):
+            continue
+        if cand.get("source_sha") == source_sha():
+            rows = cand
+            break
+        why = "profiles/%s was taken from other sources (%s, this build %s): not quoted" % (name, cand.get("source_sha"), source_sha())
+    if rows is None:
+        return None, why
     pat = KERNEL_SYMBOLS.get(kernel, re.escape(re.sub(r"[<(].*", "", kernel)) + "[<(]")
     tot = sum(r["hbm_bytes_per_launch"] * r["launches"] for name, r in rows.get("kernels", {}).items() if re.search(pat, name))
     steps = rows.get("steps", 0)
@@ -457,7 +465,7 @@ def main():
                                  "frac": (tot[key][1] / (tot[key][0] * 1e-3) / 1e9 / HBM_PEAK_GBS) if tot[key][0] > 0 else 0.0}
             roof = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                     "kernel_note": "`%s` = every instantiation of that kernel template launched in a step, timed together with HIP events on the library's stream "
-                                   "(rocprofv3 lists the instantiations as separate symbols: profiles/r03_kernel_stats_driver_cmd.txt)" % dom,
+                                   "(rocprofv3 lists the instantiations as separate symbols: %s)" % (dom, KERNEL_STATS_FILE),
                     "traffic": traffic, "traffic_note": traffic_note, "rescore_stage": stage("rescore_stage"), "assemble_stage": stage("assemble_stage"), "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg, "launches_per_step": tot[dom][3] / len(stats),
                     "stage_ms_per_step": {k: round(v[0] / len(stats), 4) for k, v in tot.items()},
                     "kmermatcher_stage": {"algorithmic_bytes_per_step": km[1] / len(stats), "ms_per_step": km[0] / len(stats),

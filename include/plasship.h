@@ -190,11 +190,17 @@ typedef struct plasship_rescore_params {
 typedef struct plasship_rescore_stats {
     uint64_t n_scored;    /* candidate pairs scored (incl. the self hit of every query)          */
     uint64_t n_accepted;  /* alignment lines kept                                                */
-    uint64_t overlap_residues; /* Σ diagonal overlap length over scored pairs                    */
+    uint64_t overlap_residues; /* Σ diagonal overlap length over the pairs scored BY THIS CALL: the identity pairs it leaves
+                                * as stubs (below) are not in it                                 */
     float ms_kernel;
 } plasship_rescore_stats;
 
-/* qdb == tdb (same handle) is the plass case (sameQTDB, rescorediagonal.cpp:59-69) */
+/* qdb == tdb (same handle) is the plass case (sameQTDB, rescorediagonal.cpp:59-69).
+ * LIFETIME AND THREADING of the list this returns: every query's alignment with itself is left as an unscored stub and scored by the
+ * first plasship_* call that READS a self record (plasship_alns_write / _download / _count of a dense copy, plasship_aln2nucl, the
+ * nucleotide and guided extension).  Until then the list refers to qdb and tdb and to this call's parameters: both DBs must outlive
+ * the list (they must anyway: ids become keys when the list is written), and the first such reader MODIFIES the list's records in
+ * place — one context / one thread at a time may use a list made by plasship_rescore. */
 int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, const plasship_seqdb *tdb,
                      const plasship_cands *c, const plasship_rescore_params *par, plasship_alns **out,
                      plasship_rescore_stats *stats);
@@ -341,6 +347,9 @@ int plasship_translate_nucs(plasship_ctx *ctx, const plasship_seqdb *orfs, const
                             plasship_seqdb **out_aa, plasship_orf_stats *stats);
 /* concatdbs <A> <B> <out> without --preserve-keys: keys of A kept, entry i of B (in key order) gets key max(keyA) + 1 + i */
 int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a, const plasship_seqdb *b, plasship_seqdb **out);
+/* concatdbs <A> <B> <out> --preserve-keys (mm/commons/DBConcat.cpp:113-118 with preserveKeysB = true; data/nuclassemble.sh:41,145): the union of
+ * the two DBs, every entry under its own key.  preserve_keys_b == 0: plasship_seqdb_concat.  A key that occurs in both DBs: PLASSHIP_ERR_UNSUPPORTED. */
+int plasship_seqdb_concat_keys(plasship_ctx *ctx, const plasship_seqdb *a, const plasship_seqdb *b, int preserve_keys_b, plasship_seqdb **out);
 int plasship_orfhdr_concat(plasship_ctx *ctx, const plasship_orfhdr *a, const plasship_orfhdr *b, plasship_orfhdr **out);
 int plasship_orfhdr_read(plasship_ctx *ctx, const char *db_path, plasship_orfhdr **out);
 int plasship_orfhdr_write(plasship_ctx *ctx, const plasship_orfhdr *h, const char *db_path);

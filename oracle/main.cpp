@@ -13,7 +13,7 @@
 //   plass_oracle dbsum <DB>…   entries, data bytes and an order-independent digest (sum over entries of a 64-bit hash of key, length and
 //       bytes) of each DB: the large parity tests compare DBs of hundreds of megabytes through it, whatever the order of the entries in the
 //       data file
-//   plass_oracle extractorfs <seqDB> <outDB> [flags] | translatenucs <nuclDB> <outAaDB> [--add-orf-stop 1] | concatdbs <dbA> <dbB> <outDB>
+//   plass_oracle extractorfs <seqDB> <outDB> [flags] | translatenucs <nuclDB> <outAaDB> [--add-orf-stop 1] | concatdbs <dbA> <dbB> <outDB> [--preserve-keys 1]
 #include "oracle.hpp"
 #include "../plass_amd/csrc/synth_core.hpp"   // the read model of include/plasship_synth.h (measurement infrastructure shared with the GPU generator)
 #include <chrono>
@@ -40,6 +40,7 @@ static bool multiParam(const std::string &v, const char *which, std::string &out
 }
 
 static oracle::OrfParams orfPar;    // extractorfs / translatenucs flags
+static bool preserveKeys = false;   // concatdbs --preserve-keys 1
 static bool chopCycle = false;      // --chop-cycle (cyclecheck; setCycleCheckDefaults: off unless the workflow passes it)
 static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<std::string> &pos) {
     for (int i = from; i < argc; i++) {
@@ -69,6 +70,7 @@ static int parseFlags(int argc, char **argv, int from, Params &par, std::vector<
             else if (a == "--max-seq-len") par.maxSeqLen = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--keep-target") par.keepTarget = atoi(v.c_str()) != 0;
             else if (a == "--chop-cycle") chopCycle = atoi(v.c_str()) != 0;
+            else if (a == "--preserve-keys") preserveKeys = atoi(v.c_str()) != 0;
             else if (a == "--min-length") orfPar.orfMinLength = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--max-length") orfPar.orfMaxLength = (size_t) strtoull(v.c_str(), nullptr, 10);
             else if (a == "--max-gaps") orfPar.orfMaxGaps = (size_t) strtoull(v.c_str(), nullptr, 10);
@@ -250,7 +252,7 @@ int main(int argc, char **argv) {
         if (pos.size() != 3) { fprintf(stderr, "concatdbs <dbA> <dbB> <outDB>\n"); return 1; }
         DB a, b, o;
         if (!readDB(pos[0], a, err) || !readDB(pos[1], b, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
-        if (!concatdbs(a, b, o, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        if (!concatdbs(a, b, o, err, preserveKeys)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
         if (!writeDB(pos[2], o, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; }
     } else { fprintf(stderr, "unknown module %s\n", mod.c_str()); return 1; }
     return 0;

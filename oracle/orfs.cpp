@@ -236,8 +236,15 @@ bool translatenucs(const DB &seqDb, const DB *hdrDb, const OrfParams &op, DB &ou
 // offset), and entry id of B becomes key id + max(keyA) + 1 (DBConcat.cpp:113-118).  For a B whose data lies in key order that is
 // "B renumbered behind A in key order"; translatenucs run on several threads leaves its data in thread order, and B's new keys then
 // follow the FILE (tests/golden/concat_noncanonical.tar.gz: written by the reference with 8 threads).
-bool concatdbs(const DB &a, const DB &b, DB &out, std::string &) {
+// --preserve-keys (preserveKeysB, DBConcat.cpp:113-118): B's entries keep their keys as well — the union of the two DBs.
+bool concatdbs(const DB &a, const DB &b, DB &out, std::string &, bool preserveKeysB) {
     out = DB(); out.dbtype = a.dbtype;
+    if (preserveKeysB) {
+        for (size_t i = 0; i < a.size(); i++) out.add(a.key[i], a.entry(i), a.elen[i] - 1);
+        for (size_t i = 0; i < b.size(); i++) out.add(b.key[i], b.entry(i), b.elen[i] - 1);
+        out.sortByKey();
+        return true;
+    }
     unsigned maxKeyA = 0;
     for (size_t i = 0; i < a.size(); i++) { out.add(a.key[i], a.entry(i), a.elen[i] - 1); maxKeyA = std::max(maxKeyA, a.key[i]); }
     maxKeyA++;

@@ -144,6 +144,7 @@ SYMBOLS = [
     ("plasship_extract_orfs", C.c_int, [P, P, C.POINTER(_OrfParams), C.POINTER(P), C.POINTER(P), C.POINTER(OrfStats)]),
     ("plasship_translate_nucs", C.c_int, [P, P, P, C.POINTER(_TranslateParams), C.POINTER(P), C.POINTER(OrfStats)]),
     ("plasship_seqdb_concat", C.c_int, [P, P, P, C.POINTER(P)]),
+    ("plasship_seqdb_concat_keys", C.c_int, [P, P, P, C.c_int, C.POINTER(P)]),
     ("plasship_orfhdr_concat", C.c_int, [P, P, P, C.POINTER(P)]),
     ("plasship_orfhdr_read", C.c_int, [P, C.c_char_p, C.POINTER(P)]),
     ("plasship_orfhdr_write", C.c_int, [P, P, C.c_char_p]),
@@ -402,9 +403,12 @@ class Context:
         _check(self.lib.plasship_translate_nucs(self.h, orfs.h, hdr.h if hdr is not None else None, C.byref(cp), C.byref(h), C.byref(st)), "plasship_translate_nucs")
         return SeqDB(self, h), st
 
-    def concatdbs(self, a, b):
-        """reference module concatdbs (keys of A kept, B renumbered behind them); sequence DBs or header DBs"""
+    def concatdbs(self, a, b, preserve_keys=False):
+        """reference module concatdbs (keys of A kept, B renumbered behind them; preserve_keys: B's kept as well — the union); sequence DBs or header DBs"""
         h = P()
+        if preserve_keys:
+            _check(self.lib.plasship_seqdb_concat_keys(self.h, a.h, b.h, 1, C.byref(h)), "plasship_seqdb_concat_keys")
+            return SeqDB(self, h)
         if isinstance(a, OrfHeaders):
             _check(self.lib.plasship_orfhdr_concat(self.h, a.h, b.h, C.byref(h)), "plasship_orfhdr_concat")
             return OrfHeaders(self, h)

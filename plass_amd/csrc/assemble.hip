@@ -1608,7 +1608,7 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
                                   db->heap->buf.as<char>(), o->d_off.as<uint64_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), o->d_changed.as<unsigned char>());
     } else {
         char *dst = nullptr;
-        if (useHeaps) {
+        if (useHeaps && !noAppend) {                           // (noAppend: nobody will ever append behind this DB — an exact buffer, no slack: ADVICE r5)
             o->heap = std::make_shared<SeqHeap>();
             // room for the entries the next iterations rewrite (25-35 % of the data per iteration at 50 M reads): as much again as the
             // data, but no more than PLASSHIP_TUNE_DBHEAP_GB (default 16; round 4: 8 — the sparse alignment lists of round 5 freed 14 GB) — kmermatcher's record arrays need 170 of the 288 GB there

@@ -71,7 +71,9 @@ struct Flags {
 // what tools/workflow_dropin_check.sh uses to exercise the routing of every call the unmodified workflow scripts make.
 enum { EXIT_UNSUPPORTED = 95, EXIT_DRYRUN_ACCEPTED = 96 };
 static int g_lastRc = 0;
+static bool g_wrote = false;             // an output DB of this call exists on disk (a completed *_write): exit code 95 would make a wrapper re-run the call over it
 static inline int K(int rc) { g_lastRc = rc; return rc; }
+static inline int KW(int rc) { g_lastRc = rc; if (rc == 0) g_wrote = true; return rc; }      // K() for the calls that write a DB
 static int unsupported(const char *fmt, ...) {
     va_list ap; va_start(ap, fmt); vfprintf(stdout, fmt, ap); va_end(ap);
     fprintf(stdout, "plass-hip: outside the GPU hot path, exit code %d (nothing was written)\n", (int) EXIT_UNSUPPORTED);
@@ -79,7 +81,10 @@ static int unsupported(const char *fmt, ...) {
 }
 static int fail(const char *what) {
     fprintf(stdout, "%s: %s\n", what, plasship_last_error());
-    if (g_lastRc == PLASSHIP_ERR_UNSUPPORTED) { fprintf(stdout, "plass-hip: outside the GPU hot path, exit code %d (nothing was written)\n", (int) EXIT_UNSUPPORTED); return EXIT_UNSUPPORTED; }
+    if (g_lastRc == PLASSHIP_ERR_UNSUPPORTED && !g_wrote) { fprintf(stdout, "plass-hip: outside the GPU hot path, exit code %d (nothing was written)\n", (int) EXIT_UNSUPPORTED); return EXIT_UNSUPPORTED; }
+    // (an "unsupported" that arrives after an output DB of this call was written is an ordinary failure: the files stay as they are and no wrapper
+    //  should run the reference over them — ADVICE r5)
+    if (g_lastRc == PLASSHIP_ERR_UNSUPPORTED) fprintf(stdout, "plass-hip: part of the output was already written; exit code %d, not %d\n", (int) EXIT_FAILURE, (int) EXIT_UNSUPPORTED);
     return EXIT_FAILURE;
 }
 static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
@@ -246,6 +251,25 @@ int main(int argc, char **argv) {
     }
     if (mod == "rescorediagonal" && f.rescoreMode != 3)
         return unsupported("plass-hip rescorediagonal: --rescore-mode %d is not part of the GPU path (the assembly workflows use mode 3)\n", f.rescoreMode);
+    // Requests that are valid for the reference and lie outside the GPU path are all refused HERE, before the dry-run exit and before anything is
+    // read or written (data/nuclassemble.sh:41,145 calls `concatdbs ... --preserve-keys` whenever circular contigs exist; with exit
+    // code 1 the wrapper ended the workflow instead of handing the call to the reference, and the dry run reported it as accepted)
+    if (mod == "concatdbs") {
+        if (f.takeLarger) return unsupported("plass-hip concatdbs: --take-larger-entry is not part of the GPU path\n");
+        if (pos.size() == 3) {      // sequence DBs, or the header DBs of ORF DBs (dbtype 12: data/assemble.sh:75); a DB that is not there yet cannot be probed (dry run on names only)
+            const std::string tp = pos[0] + ".dbtype"; FILE *ft = fopen(tp.c_str(), "rb"); unsigned ty = 0;
+            if (ft) {
+                const bool got = fread(&ty, 4, 1, ft) == 1; fclose(ft);
+                const int dbtype = got ? (int) (ty & 0x3FFFFFFFu) : -1;
+                if (got && dbtype != PLASSHIP_DBTYPE_AMINO_ACIDS && dbtype != PLASSHIP_DBTYPE_NUCLEOTIDES && dbtype != 12)
+                    return unsupported("plass-hip concatdbs: database type %d is not part of the GPU path (sequence DBs and ORF header DBs only)\n", dbtype);
+                if (got && dbtype == 12 && f.preserveKeys) return unsupported("plass-hip concatdbs: --preserve-keys on a header DB is not part of the GPU path\n");
+            }
+        }
+    }
+    if (mod == "proteinaln2nucl" && pos.size() == 6 && (pos[0] == pos[1]) != (pos[2] == pos[3])) { fprintf(stdout, "Either query database == target database for nucleotide and amino acid or != for both\n"); return EXIT_FAILURE; }
+    if (mod == "proteinaln2nucl" && pos.size() == 6 && pos[0] != pos[1])
+        return unsupported("plass-hip proteinaln2nucl: separate query and target DBs are not part of the GPU path (the assembly workflows use one DB)\n");
     if (getenv("PLASSHIP_CLI_DRYRUN") && atoi(getenv("PLASSHIP_CLI_DRYRUN")) != 0) {
         fprintf(stdout, "plass-hip dry run: %s accepted (%zu positional arguments, %zu flags); nothing read or computed\n", mod.c_str(), pos.size(), f.seen.size());
         return EXIT_DRYRUN_ACCEPTED;
@@ -267,7 +291,7 @@ int main(int argc, char **argv) {
         fprintf(stdout, "k-mer records: %llu grouped: %llu candidates: %llu | kernels ms: extract %.3f partition %.3f group %.3f sort %.3f reduce %.3f\n",
                 (unsigned long long) st.n_kmer_records, (unsigned long long) st.n_grouped, (unsigned long long) st.n_candidates,
                 st.ms_extract, st.ms_sort1, st.ms_group, st.ms_sort2, st.ms_reduce);
-        if (K(plasship_cands_write(ctx, c, db, pos[1].c_str()))) return fail("kmermatcher");
+        if (KW(plasship_cands_write(ctx, c, db, pos[1].c_str()))) return fail("kmermatcher");
         plasship_cands_free(ctx, c); plasship_seqdb_free(ctx, db);
     } else if (mod == "rescorediagonal") {
         if (pos.size() != 4) { fprintf(stdout, "rescorediagonal <i:queryDB> <i:targetDB> <i:prefDB> <o:alnDB>\n"); return EXIT_FAILURE; }
@@ -281,7 +305,7 @@ int main(int argc, char **argv) {
         plasship_rescore_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_rescore(ctx, q, t, c, &p, &al, &st))) return fail("rescorediagonal");
         fprintf(stdout, "scored: %llu accepted: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_scored, (unsigned long long) st.n_accepted, st.ms_kernel);
-        if (K(plasship_alns_write(ctx, al, pos[3].c_str()))) return fail("rescorediagonal");
+        if (KW(plasship_alns_write(ctx, al, pos[3].c_str()))) return fail("rescorediagonal");
         plasship_alns_free(ctx, al); plasship_cands_free(ctx, c); if (t != q) plasship_seqdb_free(ctx, t); plasship_seqdb_free(ctx, q);
     } else if (mod == "assembleresults" || mod == "nuclassembleresults") {
         if (pos.size() != 3) { fprintf(stdout, "%s <i:sequenceDB> <i:alnResult> <o:reprSeqDB>\n", mod.c_str()); return EXIT_FAILURE; }
@@ -300,7 +324,7 @@ int main(int argc, char **argv) {
         plasship_assemble_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_assemble(ctx, db, al, &p, &o, &st))) return fail("assembleresults");
         fprintf(stdout, "extended: %llu rescored: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_extended, (unsigned long long) st.n_rescored, st.ms_kernel);
-        if (K(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("assembleresults");
+        if (KW(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("assembleresults");
         plasship_seqdb_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, db);
     } else if (mod == "guidedassembleresults") {
         if (pos.size() != 5) { fprintf(stdout, "guidedassembleresults <i:nuclSequenceDB> <i:aaSequenceDB> <i:nuclAlnResult> <o:nuclAssembly> <o:aaAssembly>\n"); return EXIT_FAILURE; }
@@ -312,12 +336,10 @@ int main(int argc, char **argv) {
         plasship_assemble_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_guided_assemble(ctx, nu, aa, al, &p, &on, &oa, &st))) return fail("guidedassembleresults");
         fprintf(stdout, "extended: %llu rescored: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_extended, (unsigned long long) st.n_rescored, st.ms_kernel);
-        if (K(plasship_seqdb_write(ctx, on, pos[3].c_str())) || K(plasship_seqdb_write(ctx, oa, pos[4].c_str()))) return fail("guidedassembleresults");
+        if (KW(plasship_seqdb_write(ctx, on, pos[3].c_str())) || KW(plasship_seqdb_write(ctx, oa, pos[4].c_str()))) return fail("guidedassembleresults");
         plasship_seqdb_free(ctx, on); plasship_seqdb_free(ctx, oa); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, aa); plasship_seqdb_free(ctx, nu);
     } else if (mod == "proteinaln2nucl") {
         if (pos.size() != 6) { fprintf(stdout, "proteinaln2nucl <i:queryNuclDB> <i:targetNuclDB> <i:queryAaDB> <i:targetAaDB> <i:alnDB> <o:alnDB>\n"); return EXIT_FAILURE; }
-        if ((pos[0] == pos[1]) != (pos[2] == pos[3])) { fprintf(stdout, "Either query database == target database for nucleotide and amino acid or != for both\n"); return EXIT_FAILURE; }
-        if (pos[0] != pos[1]) { fprintf(stdout, "plass-hip: proteinaln2nucl with separate query and target DBs is not supported (the assembly workflows use one DB)\n"); return EXIT_FAILURE; }
         plasship_seqdb *nu = nullptr, *aa = nullptr; plasship_alns *al = nullptr, *o = nullptr;
         if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &nu)) || K(plasship_seqdb_read(ctx, pos[2].c_str(), &aa))) return fail("proteinaln2nucl");
         if (K(plasship_alns_read(ctx, aa, pos[4].c_str(), &al))) return fail("proteinaln2nucl");
@@ -325,7 +347,7 @@ int main(int argc, char **argv) {
         plasship_aln2nucl_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_aln2nucl(ctx, nu, nu, aa, aa, al, &p, &o, &st))) return fail("proteinaln2nucl");
         fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
-        if (K(plasship_alns_write(ctx, o, pos[5].c_str()))) return fail("proteinaln2nucl");
+        if (KW(plasship_alns_write(ctx, o, pos[5].c_str()))) return fail("proteinaln2nucl");
         plasship_alns_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, aa); plasship_seqdb_free(ctx, nu);
     } else if (mod == "findassemblystart") {
         if (pos.size() != 3) { fprintf(stdout, "findassemblystart <i:sequenceDB> <i:alnDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
@@ -335,7 +357,7 @@ int main(int argc, char **argv) {
         plasship_findstart_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_find_assembly_start(ctx, db, al, &o, &st))) return fail("findassemblystart");
         fprintf(stdout, "alignments: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_alignments, st.ms_kernel);
-        if (K(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("findassemblystart");
+        if (KW(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("findassemblystart");
         plasship_seqdb_free(ctx, o); plasship_alns_free(ctx, al); plasship_seqdb_free(ctx, db);
     } else if (mod == "cyclecheck") {
         if (pos.size() != 2) { fprintf(stdout, "cyclecheck <i:sequenceDB> <o:sequenceDBcycle>\n"); return EXIT_FAILURE; }
@@ -345,7 +367,7 @@ int main(int argc, char **argv) {
         plasship_cyclecheck_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_cyclecheck(ctx, db, &p, &o, nullptr, &st))) return fail("cyclecheck");
         fprintf(stdout, "circular: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_cyclic, st.ms_kernel);
-        if (K(plasship_seqdb_write(ctx, o, pos[1].c_str()))) return fail("cyclecheck");
+        if (KW(plasship_seqdb_write(ctx, o, pos[1].c_str()))) return fail("cyclecheck");
         plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
     } else if (mod == "extractorfs") {
         // writes <out> and <out>_h like the reference (extractorfs.cpp:28-32)
@@ -359,7 +381,7 @@ int main(int argc, char **argv) {
         plasship_orf_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_extract_orfs(ctx, db, &p, &o, &h, &st))) return fail("extractorfs");
         fprintf(stdout, "orfs: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_out, st.ms_kernel);
-        if (K(plasship_seqdb_write(ctx, o, pos[1].c_str())) || K(plasship_orfhdr_write(ctx, h, (pos[1] + "_h").c_str()))) return fail("extractorfs");
+        if (KW(plasship_seqdb_write(ctx, o, pos[1].c_str())) || KW(plasship_orfhdr_write(ctx, h, (pos[1] + "_h").c_str()))) return fail("extractorfs");
         plasship_orfhdr_free(ctx, h); plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
     } else if (mod == "translatenucs") {
         if (pos.size() != 2) { fprintf(stdout, "translatenucs <i:sequenceDB> <o:sequenceDB>\n"); return EXIT_FAILURE; }
@@ -370,27 +392,26 @@ int main(int argc, char **argv) {
         plasship_orf_stats st; memset(&st, 0, sizeof(st));
         if (K(plasship_translate_nucs(ctx, db, h, &p, &o, &st))) return fail("translatenucs");
         fprintf(stdout, "translated: %llu | kernel ms: %.3f\n", (unsigned long long) st.n_out, st.ms_kernel);
-        if (K(plasship_seqdb_write(ctx, o, pos[1].c_str()))) return fail("translatenucs");
+        if (KW(plasship_seqdb_write(ctx, o, pos[1].c_str()))) return fail("translatenucs");
         plasship_orfhdr_free(ctx, h); plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, db);
     } else if (mod == "concatdbs") {
         if (pos.size() != 3) { fprintf(stdout, "concatdbs <i:DB> <i:DB> <o:DB>\n"); return EXIT_FAILURE; }
-        if (f.preserveKeys || f.takeLarger) { fprintf(stdout, "plass-hip concatdbs: --preserve-keys / --take-larger-entry are not supported\n"); return EXIT_FAILURE; }
         // sequence DBs, or the header DBs of ORF DBs (dbtype 12: data/assemble.sh:75)
         int dbtype = -1;
         { std::string tp = pos[0] + ".dbtype"; FILE *ft = fopen(tp.c_str(), "rb"); unsigned ty = 0; if (ft && fread(&ty, 4, 1, ft) == 1) dbtype = (int) (ty & 0x3FFFFFFFu); if (ft) fclose(ft); }
         if (dbtype == PLASSHIP_DBTYPE_AMINO_ACIDS || dbtype == PLASSHIP_DBTYPE_NUCLEOTIDES) {
             plasship_seqdb *a = nullptr, *b = nullptr, *o = nullptr;
             if (K(plasship_seqdb_read(ctx, pos[0].c_str(), &a)) || K(plasship_seqdb_read(ctx, pos[1].c_str(), &b))) return fail("concatdbs");
-            if (K(plasship_seqdb_concat(ctx, a, b, &o))) return fail("concatdbs");
-            if (K(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("concatdbs");
+            if (K(plasship_seqdb_concat_keys(ctx, a, b, f.preserveKeys, &o))) return fail("concatdbs");
+            if (KW(plasship_seqdb_write(ctx, o, pos[2].c_str()))) return fail("concatdbs");
             plasship_seqdb_free(ctx, o); plasship_seqdb_free(ctx, b); plasship_seqdb_free(ctx, a);
         } else if (dbtype == 12) {
             plasship_orfhdr *a = nullptr, *b = nullptr, *o = nullptr;
             if (K(plasship_orfhdr_read(ctx, pos[0].c_str(), &a)) || K(plasship_orfhdr_read(ctx, pos[1].c_str(), &b))) return fail("concatdbs");
             if (K(plasship_orfhdr_concat(ctx, a, b, &o))) return fail("concatdbs");
-            if (K(plasship_orfhdr_write(ctx, o, pos[2].c_str()))) return fail("concatdbs");
+            if (KW(plasship_orfhdr_write(ctx, o, pos[2].c_str()))) return fail("concatdbs");
             plasship_orfhdr_free(ctx, o); plasship_orfhdr_free(ctx, b); plasship_orfhdr_free(ctx, a);
-        } else { fprintf(stdout, "plass-hip concatdbs: database type %d is not supported (sequence DBs and ORF header DBs only)\n", dbtype); return EXIT_FAILURE; }
+        } else { fprintf(stdout, "plass-hip concatdbs: cannot read the database type of %s\n", pos[0].c_str()); return EXIT_FAILURE; }      // (other types were refused above)
     } else if (chain) {
         // ---- fused drivers: the iteration loop of a workflow script with every DB of the loop resident in HBM; only the first DB is
         //      read from disk and only the last one written (plus, with --write-intermediate DIR, every iteration's assembly by a host
@@ -483,7 +504,7 @@ int main(int argc, char **argv) {
             if (nuc) {     // data/nuclassemble.sh:19-61,132: circular contigs leave the loop, the rest goes on
                 plasship_seqdb *cyc = nullptr, *rest = nullptr; plasship_cyclecheck_params cp; cp.max_seq_len = f.maxSeqLen; cp.chop_cycle = f.chopCycle; plasship_cyclecheck_stats cs;
                 if (K(plasship_cyclecheck(ctx, db, &cp, &cyc, &rest, &cs))) return fail(mod.c_str());
-                if (cs.n_cyclic && K(plasship_seqdb_write(ctx, cyc, (pos[1] + "_cycle_" + std::to_string(it)).c_str()))) return fail(mod.c_str());
+                if (cs.n_cyclic && KW(plasship_seqdb_write(ctx, cyc, (pos[1] + "_cycle_" + std::to_string(it)).c_str()))) return fail(mod.c_str());
                 plasship_seqdb_free(ctx, cyc); plasship_seqdb_free(ctx, db); db = rest;
             }
             fprintf(stdout, "iteration %d: candidates %llu verified %llu extended %llu (%.3f s since the DB was read)\n", it, (unsigned long long) ks.n_candidates, (unsigned long long) rs.n_accepted, (unsigned long long) as.n_extended, now() - tPrep);
@@ -491,7 +512,7 @@ int main(int argc, char **argv) {
         }
         const double tLoop = now();
         if (joinWriter()) { fprintf(stdout, "%s: writing an intermediate DB failed: %s\n", mod.c_str(), writerErr.c_str()); return EXIT_FAILURE; }
-        if (K(plasship_seqdb_write(ctx, db, pos[1].c_str())) || (gd && K(plasship_seqdb_write(ctx, aa, pos[2].c_str())))) return fail(mod.c_str());
+        if (KW(plasship_seqdb_write(ctx, db, pos[1].c_str())) || (gd && KW(plasship_seqdb_write(ctx, aa, pos[2].c_str())))) return fail(mod.c_str());
         const double tEnd = now();
         fprintf(stdout, "chain: %d iterations, %llu candidate overlaps | read %.3fs preprocessing %.3fs iterations %.3fs (kernels %.3fs) write %.3fs\n", f.numIterations, overlaps,
                 tRead - t0, tPrep - tRead, tLoop - tPrep, kernelMs * 1e-3, tEnd - tLoop);

@@ -144,7 +144,7 @@ struct plasship_ctx {
     // of the <= 60 selected k-mers} of the LAST plasship_kmermatch call on this context; the next call re-uses the line of every
     // sequence its DB inherited unchanged from that call's DB when the selection parameters (hash seed included) are the same
     struct KmCache {
-        plasship::DevBuf lines; uint64_t n = 0, gen = 0; bool valid = false;
+        plasship::DevBuf lines; uint64_t n = 0, gen = 0; bool valid = false, seenEligible = false;      // seenEligible: an earlier call on this context could have used lines (they are allocated from the second such call on, or for a derived DB)
         int k = 0, alph = 0, kps = 0, ignoreMulti = 0, hashShift = 0;
     } kmCache;
     // cyclecheck.hip: generation of the last "rest" DB plasship_cyclecheck made on this context (every entry of it is known not to be

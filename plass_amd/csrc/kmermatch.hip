@@ -894,7 +894,12 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     kc.valid = false;                                         // (set again when this call has succeeded)
     DevBuf dCachedList, dCachedCount;
     unsigned long long cacheLinesPtr = 0;                    // -> kstats[4] (see ExtractArgs)
-    if (cacheEligible && N) {
+    // The lines are only worth their N x 128 bytes (11 GB at 88 M sequences) when a later call can use them: a DB that was DERIVED from another
+    // one (a chained iteration), or a context that has made an eligible call before (a single `plass-hip kmermatcher` call on a DB
+    // read from files paid for them in memory and in 128-byte stores per long sequence for nothing)
+    const bool cacheWanted = cacheEligible && N && (cacheReuse || db->parentGen != 0 || db->ancestorGen != 0 || kc.seenEligible || tuneInt("KMCACHE_EAGER", 0) == 1);
+    if (cacheEligible) kc.seenEligible = true;
+    if (cacheWanted) {
         if (kc.lines.bytes < (size_t) N * KMC_LINE) { kc.lines.release(); if (kc.lines.allocLong((size_t) N * KMC_LINE) != hipSuccess) { setError("kmermatch: out of device memory for the selected-window cache"); return PLASSHIP_ERR_DEVICE; } }
         cacheLinesPtr = (unsigned long long) (uintptr_t) kc.lines.p;
         if (cacheReuse) {
@@ -1060,7 +1065,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             stats->ms_extract = msExtract; stats->ms_sort1 = lo.msSort1; stats->ms_group = lo.msGroup; stats->ms_sort2 = lo.msSort2; stats->ms_reduce = msReduceL;
             stats->n_scratch_sequences = nOv; stats->n_restarts = overflowCheckEarly ? 1u : 0u;
         }
-        if (cacheEligible && N) {     // the lines now describe THIS DB (the wave kernels rewrote what changed, the rest was kept)
+        if (cacheWanted) {     // the lines now describe THIS DB (the wave kernels rewrote what changed, the rest was kept)
             kc.valid = true; kc.n = N; kc.gen = db->gen; kc.k = k; kc.alph = par->alphabet_size; kc.kps = par->kmers_per_seq; kc.ignoreMulti = par->ignore_multi_kmer; kc.hashShift = par->hash_shift;
         }
         *out = holderL.release();

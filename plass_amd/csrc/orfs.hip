@@ -530,6 +530,69 @@ extern "C" int plasship_seqdb_concat(plasship_ctx *ctx, const plasship_seqdb *a,
     *out = o.release();
     return PLASSHIP_OK;
 }
+// concatdbs <A> <B> <out> --preserve-keys (DBConcat.cpp:113-118 with preserveKeysB; data/nuclassemble.sh:41,145: the circular contigs taken out
+// by cyclecheck rejoin the linear ones under their own keys): the union of the two DBs, every entry under its own key.  A handle holds its entries
+// in key order, so the result is the MERGE of the two key-sorted lists — rank of A's entry i = i + |{keys of B < keyA[i]}|, of B's entry j =
+// j + |{keys of A <= keyB[j]}| (a binary search per entry) — and the bytes are gathered into that order, back to back like the DB file.
+// A key held by both DBs (the reference then writes two entries under one key, which no reader of its own resolves) is refused.
+__global__ void mergeRankKernel(const uint32_t *__restrict__ keyA, const uint32_t *__restrict__ lenA, uint32_t nA, const uint32_t *__restrict__ keyB, const uint32_t *__restrict__ lenB, uint32_t nB,
+                                uint32_t *__restrict__ rankA, uint32_t *__restrict__ rankB, uint32_t *__restrict__ len, uint32_t *__restrict__ key, uint64_t *__restrict__ bytes, uint32_t *__restrict__ dup) {
+    for (uint32_t t = blockIdx.x * blockDim.x + threadIdx.x; t < nA + nB; t += gridDim.x * blockDim.x) {
+        const bool fromA = t < nA; const uint32_t i = fromA ? t : t - nA;
+        const uint32_t k = fromA ? keyA[i] : keyB[i];
+        const uint32_t *o = fromA ? keyB : keyA; uint32_t lo = 0, hi = fromA ? nB : nA;
+        while (lo < hi) { const uint32_t mid = lo + (hi - lo) / 2; if (fromA ? (o[mid] < k) : (o[mid] <= k)) lo = mid + 1; else hi = mid; }
+        if (!fromA && lo > 0 && o[lo - 1] == k) atomicOr(dup, 1u);
+        const uint32_t r = i + lo, l = fromA ? lenA[i] : lenB[i];
+        (fromA ? rankA : rankB)[i] = r; len[r] = l; key[r] = k; bytes[r] = (uint64_t) l + 2;
+    }
+}
+__global__ __launch_bounds__(256) void mergeCopyKernel(const char *__restrict__ src, const uint64_t *__restrict__ offS, const uint32_t *__restrict__ lenS, const uint32_t *__restrict__ rank, uint32_t n,
+                                                       const uint64_t *__restrict__ newOff, char *__restrict__ data) {
+    const int G = 16, gl = threadIdx.x & (G - 1);
+    for (uint32_t j = blockIdx.x * (256 / G) + threadIdx.x / G; j < n; j += gridDim.x * (256 / G)) {
+        const uint32_t r = rank[j], el = lenS[j] + 2; const uint64_t d = newOff[r], s = offS[j];
+        for (uint32_t i = gl; i < el; i += G) data[d + i] = src[s + i];
+    }
+}
+extern "C" int plasship_seqdb_concat_keys(plasship_ctx *ctx, const plasship_seqdb *a, const plasship_seqdb *b, int preserve_keys_b, plasship_seqdb **out) {
+    if (!preserve_keys_b) return plasship_seqdb_concat(ctx, a, b, out);
+    if (!ctx || !a || !b || !out) { setError("plasship_seqdb_concat_keys: bad argument"); return PLASSHIP_ERR_ARG; }
+    PH_ENTER(ctx);
+    hipStream_t st = ctx->stream;
+    const uint64_t nn = (uint64_t) a->n + b->n;
+    if (nn >= 0xFFFFFFFFull) { setError("plasship_seqdb_concat_keys: too many sequences"); return PLASSHIP_ERR_UNSUPPORTED; }
+    if (a->dbtype != b->dbtype) { setError("plasship_seqdb_concat_keys: the DB types differ"); return PLASSHIP_ERR_ARG; }
+    std::unique_ptr<plasship_seqdb> packedA, packedB;
+    if (!a->contiguous) { const int rcP = packedCopyOf(ctx, a, packedA); if (rcP) return rcP; a = packedA.get(); }
+    if (!b->contiguous) { const int rcP = packedCopyOf(ctx, b, packedB); if (rcP) return rcP; b = packedB.get(); }
+    const uint64_t dataBytes = a->dataBytes + b->dataBytes;
+    std::unique_ptr<plasship_seqdb> o(new plasship_seqdb());
+    DevBuf dRankA, dRankB, dBytes, dDup, dTmp; const size_t tmpBytes = exclusiveScanTmpBytes(nn + 2);
+    if (o->d_data.allocLong(dataBytes + 64) != hipSuccess || o->d_off.allocLong((nn + 1) * 8) != hipSuccess || o->d_len.allocLong((nn + 1) * 4) != hipSuccess ||
+        o->d_key.allocLong((nn + 1) * 4) != hipSuccess || dRankA.alloc(((uint64_t) a->n + 1) * 4) != hipSuccess || dRankB.alloc(((uint64_t) b->n + 1) * 4) != hipSuccess ||
+        dBytes.alloc((nn + 1) * 8) != hipSuccess || dDup.alloc(4) != hipSuccess || dTmp.alloc(tmpBytes) != hipSuccess) { setError("plasship_seqdb_concat_keys: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+    PH_CHECK(hipMemsetAsync(dDup.p, 0, 4, st));
+    PH_CHECK(hipMemsetAsync((char *) o->d_data.p + dataBytes, 0, 64, st));
+    if (nn) {
+        hipLaunchKernelGGL(mergeRankKernel, dim3(gridOf(nn, ctx->numCU)), dim3(256), 0, st, a->d_key.as<uint32_t>(), a->d_len.as<uint32_t>(), (uint32_t) a->n, b->d_key.as<uint32_t>(), b->d_len.as<uint32_t>(), (uint32_t) b->n,
+                           dRankA.as<uint32_t>(), dRankB.as<uint32_t>(), o->d_len.as<uint32_t>(), o->d_key.as<uint32_t>(), dBytes.as<uint64_t>(), dDup.as<uint32_t>());
+        if (exclusiveScanU64(st, dBytes.as<uint64_t>(), o->d_off.as<uint64_t>(), nn, dTmp.p, tmpBytes)) { setError("plasship_seqdb_concat_keys: scan failed"); return PLASSHIP_ERR_DEVICE; }
+        // (the scan leaves its total at [nn]: o->d_off is the finished index)
+        if (a->n) hipLaunchKernelGGL(mergeCopyKernel, dim3(gridOf((a->n + 15) / 16, ctx->numCU)), dim3(256), 0, st, a->dataPtr(), a->d_off.as<uint64_t>(), a->d_len.as<uint32_t>(), (const uint32_t *) dRankA.as<uint32_t>(), (uint32_t) a->n,
+                                     (const uint64_t *) o->d_off.as<uint64_t>(), o->d_data.as<char>());
+        if (b->n) hipLaunchKernelGGL(mergeCopyKernel, dim3(gridOf((b->n + 15) / 16, ctx->numCU)), dim3(256), 0, st, b->dataPtr(), b->d_off.as<uint64_t>(), b->d_len.as<uint32_t>(), (const uint32_t *) dRankB.as<uint32_t>(), (uint32_t) b->n,
+                                     (const uint64_t *) o->d_off.as<uint64_t>(), o->d_data.as<char>());
+    } else PH_CHECK(hipMemsetAsync(o->d_off.p, 0, 8, st));
+    uint32_t dup = 0;
+    PH_COPY_SYNC(st, &dup, dDup.p, 4, hipMemcpyDeviceToHost);
+    PH_CHECK(hipGetLastError());
+    if (dup) { setError("plasship_seqdb_concat_keys: a key occurs in both DBs (the reference writes two entries under one key then; not reproduced)"); return PLASSHIP_ERR_UNSUPPORTED; }
+    o->dbtype = a->dbtype; o->n = (size_t) nn; o->dataBytes = dataBytes; o->residues = a->residues + b->residues;
+    o->maxEntryLen = std::max(a->maxEntryLen, b->maxEntryLen); o->hostIndexValid = false;
+    *out = o.release();
+    return PLASSHIP_OK;
+}
 extern "C" int plasship_orfhdr_concat(plasship_ctx *ctx, const plasship_orfhdr *a, const plasship_orfhdr *b, plasship_orfhdr **out) {
     if (!ctx || !a || !b || !out) { setError("plasship_orfhdr_concat: bad argument"); return PLASSHIP_ERR_ARG; }
     PH_ENTER(ctx);

@@ -411,7 +411,7 @@ int denseAlnsCopy(plasship_ctx *ctx, const plasship_alns *a, DevBuf &qoffBuf, De
         setError("alignment list: out of device memory for the dense copy"); return PLASSHIP_ERR_DEVICE;
     }
     if (n) hipLaunchKernelGGL(acceptFlagsKernel, dim3((unsigned) std::min<uint64_t>((n + 255) / 256, (uint64_t) ctx->numCU * 32)), dim3(256), 0, ctx->stream, a->d_recs.as<AlnRec>(), dAccept.as<uint32_t>(), n);
-    if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), n, dTmp.p, tmpBytes)) { setError("scan failed"); return PLASSHIP_ERR_DEVICE; }
+    if (exclusiveScanU32(ctx->stream, dAccept.as<uint32_t>(), dPos.as<uint64_t>(), n, dTmp.p, tmpBytes)) { (void) plasship::streamSync(ctx->stream); setError("scan failed"); return PLASSHIP_ERR_DEVICE; }   // (the local buffers go with the function: their kernel must be through)
     if (n) hipLaunchKernelGGL(compactAlnKernel, dim3((unsigned) std::min<uint64_t>((4 * n + 255) / 256, (uint64_t) ctx->numCU * 64)), dim3(256), 0, ctx->stream,
                               a->d_recs.as<uint4>(), dAccept.as<uint32_t>(), dPos.as<uint64_t>(), recsBuf.as<uint4>(), n);
     hipLaunchKernelGGL(gatherOffsetsKernel, dim3((unsigned) std::min<uint64_t>((a->nQueries + 256) / 256, 65535)), dim3(256), 0, ctx->stream,
@@ -525,7 +525,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight).  Round 5: 4 — with the stub and finishing paths
     // the kernel spills 88 bytes per lane at 5 (96 VGPRs) and nothing at 4 (125): 35.5 -> 31.2 ms per iteration at 50 M reads; 3: 33.2, 6: 43.9
     // (profiles/r05_ab_knobs.txt, calls 12-13)
-    static const int wpe = tuneInt("RESCORE_WPE", 4);
+    static const int wpe = [] { const int v = tuneInt("RESCORE_WPE", 4); if (v != 4 && v != 5) fprintf(stderr, "[plasship] PLASSHIP_TUNE_RESCORE_WPE=%d: only 4 and 5 are built, using 4\n", v); return v; }();
     // (16 or 8 lanes per pair for EVERY pair, and a second thread-per-pair pass for the overlaps of 128-512 columns, were both
     // slower — 76 / 53 ms and 83 ms against 45 ms per iteration at 50 M reads: profiles/r03_ab_knobs.txt)
     if (wpe == 5) hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
@@ -541,7 +541,9 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     const uint64_t nAcc = hs[0];
     al->nLines = nAcc; al->nSlots = nHits; al->sparse = true;
     al->qdb = qdb; al->tdb = tdb;
-    al->selfPending = a.lazySelf != 0; al->rsPar = *par; al->rsSameDB = (qdb == tdb); al->rsReverseCapable = c->reverseCapable;
+    // (stubs exist only where an identity pair can: the same DB on both sides, or --add-self-matches — ADVICE r5: a list without any made every
+    //  later consumer walk all its slots once)
+    al->selfPending = a.lazySelf != 0 && (a.sameDB || a.includeIdentity); al->rsPar = *par; al->rsSameDB = (qdb == tdb); al->rsReverseCapable = c->reverseCapable;
     if (stats) {
         stats->n_scored = nHits; stats->n_accepted = nAcc; stats->overlap_residues = hs[1];
         float ms = 0; (void) hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]); stats->ms_kernel = ms;

@@ -26,7 +26,7 @@ def oracle_bin():
 def golden(tmp_path_factory):
     """golden DBs written by the unmodified reference (tests/golden/make_golden.sh)"""
     d = tmp_path_factory.mktemp("golden")
-    for name in ("example_aa.tar.gz", "example_aa_sweep.tar.gz", "example_nucl.tar.gz", "example_guided.tar.gz", "long_nucl.tar.gz", "adversarial.tar.gz", "stale_scan_cases.tar.gz", "findstart.tar.gz", "cyclecheck.tar.gz", "orfs.tar.gz", "concat_noncanonical.tar.gz", "strand_ties.tar.gz"):
+    for name in ("example_aa.tar.gz", "example_aa_sweep.tar.gz", "example_nucl.tar.gz", "example_guided.tar.gz", "long_nucl.tar.gz", "adversarial.tar.gz", "stale_scan_cases.tar.gz", "findstart.tar.gz", "cyclecheck.tar.gz", "orfs.tar.gz", "concat_noncanonical.tar.gz", "strand_ties.tar.gz", "concat_preserve.tar.gz"):
         with tarfile.open(os.path.join(ROOT, "tests", "golden", name)) as t:
             t.extractall(d)
     return str(d)

@@ -176,3 +176,26 @@ def test_concatdbs_header_db_follows_the_file_order_too(ctx, golden, tmp_path):
     a = ctx.read_seqdb(f"{c}/A"); b = ctx.read_seqdb(f"{c}/B")
     out = ctx.concatdbs(a, b); out.write(tmp_path / "n")
     assert_same_db(f"{c}/C", tmp_path / "n", "concatdbs of the nucleotide ORF DBs")
+
+
+def test_concatdbs_preserve_keys(ctx, golden, tmp_path):
+    """`concatdbs --preserve-keys` (DBConcat.cpp:113-118; data/nuclassemble.sh:41,145): circular contigs rejoin the linear ones under their own
+    keys.  Inputs are index subsets over larger data files (the workflow's `_noneCycle` DB); reference-written DBs
+    (tests/golden/make_concat_preserve.sh), through the C-ABI and through `plass-hip concatdbs ... --preserve-keys` as the script calls it"""
+    c = os.path.join(golden, "concat_preserve")
+    a, b, rest = ctx.read_seqdb(f"{c}/cycA"), ctx.read_seqdb(f"{c}/cycB"), ctx.read_seqdb(f"{c}/noneCycle")
+    call = ctx.concatdbs(a, b, preserve_keys=True); call.write(tmp_path / "cycle_all")
+    assert_same_db(f"{c}/cycle_all", tmp_path / "cycle_all", "concatdbs cycA cycB --preserve-keys")
+    merged = ctx.concatdbs(rest, call, preserve_keys=True); merged.write(tmp_path / "merged")
+    assert_same_db(f"{c}/merged", tmp_path / "merged", "concatdbs noneCycle cycle_all --preserve-keys")
+    # the order of the arguments does not matter for a union
+    ctx.concatdbs(call, rest, preserve_keys=True).write(tmp_path / "merged2")
+    assert_same_db(f"{c}/merged", tmp_path / "merged2", "concatdbs cycle_all noneCycle --preserve-keys")
+    # a key held by both DBs is refused (the reference writes two entries under one key)
+    with pytest.raises(Exception):
+        ctx.concatdbs(call, a, preserve_keys=True)
+    hip = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "plass_amd", "plass-hip")
+    p = subprocess.run([hip, "concatdbs", f"{c}/noneCycle", f"{c}/cycle_all", str(tmp_path / "cli"), "--preserve-keys"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert p.returncode == 0, p.stdout
+    assert_same_db(f"{c}/merged", tmp_path / "cli", "plass-hip concatdbs --preserve-keys")
+

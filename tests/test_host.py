@@ -178,7 +178,7 @@ def test_stored_traffic_is_quoted_only_for_the_sources_it_was_measured_on(tmp_pa
     stale silently)."""
     import json
     import bench
-    f = os.path.join(ROOT, "profiles", bench.PMC_FILES["c3"])
+    f = next(os.path.join(ROOT, "profiles", n) for n in bench.PMC_FILES["c3"] if os.path.exists(os.path.join(ROOT, "profiles", n)))      # newest stored pass
     rows = json.load(open(f))
     assert rows["steps"] > 0 and rows["kernels"] and "--steps 20 --warmup 5" in rows["source"]
     # for the sources the file was measured on the figure is quoted ...
@@ -297,7 +297,20 @@ def test_cli_exit_codes_separate_unsupported_from_failed():
     assert rc("kmermatcher", "s", "p", "-k", "22", "--kmer-per-seq", "60", "--alph-size", "nucl:5,aa:13", "--spaced-kmer-mode", "0", "--mask", "0",
               "--sub-mat", "nucl:nucleotide.out,aa:blosum62.out", "--cov-mode", "1", "-c", "0.99", "--min-seq-id", "0.97") == 96
     assert rc("kmermatcher", "s", "p", "-k", "14", "--kmer-per-seq", "60", "--no-such-flag", "1") == 1
-    assert rc("concatdbs", "a", "b", "c", "--preserve-keys") == 96
+    assert rc("concatdbs", "a", "b", "c", "--preserve-keys") == 96                           # implemented since round 6 (sequence DBs)
+    # valid for the reference, outside the GPU path: refused with 95 BEFORE the dry-run exit (they used to end with 1 after it)
+    assert rc("concatdbs", "a", "b", "c", "--take-larger-entry") == 95
+    assert rc("proteinaln2nucl", "qn", "tn", "qa", "ta", "aln", "out") == 95                 # separate query / target DBs
+    assert rc("proteinaln2nucl", "n", "n", "a", "a", "aln", "out") == 96
+    assert rc("proteinaln2nucl", "n", "n", "qa", "ta", "aln", "out") == 1                    # malformed for the reference as well
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        for name, ty in (("aln", 5), ("hdr", 12), ("seq", 1)):
+            open(os.path.join(td, name + ".dbtype"), "wb").write(ty.to_bytes(4, "little"))
+        P = lambda n: os.path.join(td, n)
+        assert rc("concatdbs", P("aln"), P("aln"), P("o")) == 95                             # an alignment DB: the probe of <A>.dbtype sits before the dry-run exit
+        assert rc("concatdbs", P("hdr"), P("hdr"), P("o")) == 96 and rc("concatdbs", P("seq"), P("seq"), P("o"), "--preserve-keys") == 96
+        assert rc("concatdbs", P("hdr"), P("hdr"), P("o"), "--preserve-keys") == 95
 
 
 def test_wrapper_routes_by_exit_code(tmp_path):
@@ -317,6 +330,12 @@ def test_wrapper_routes_by_exit_code(tmp_path):
     assert out.returncode == 1 and "REF" not in out.stdout and "Unrecognized parameter" in out.stdout
     lines = log.read_text().splitlines()
     assert lines[0].startswith("reference  <- plass-hip exit 95") and "not a hot-path module" in lines[1] and lines[2].startswith("GPU path   exit 1")
+    # NOT a dry run: a request that is valid for the reference and outside the GPU path reaches the reference — plass-hip refuses
+    # it before it creates a context, so this needs no GPU either
+    env2 = {k: v for k, v in env.items() if k != "PLASSHIP_CLI_DRYRUN"}
+    out = subprocess.run([w, "concatdbs", "a", "b", "c", "--take-larger-entry"], env=env2, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert out.returncode == 0 and "args=concatdbs a b c --take-larger-entry" in out.stdout
+    assert log.read_text().splitlines()[3].startswith("reference  <- plass-hip exit 95")
 
 
 def test_deep_chain_fixtures_are_complete():

@@ -256,3 +256,15 @@ def test_oracle_concatdbs_follows_the_data_file_order(oracle_bin, golden, tmp_pa
     assert_same_db(os.path.join(c, "Cs_h"), tmp_path / "hs", "concatdbs of a header DB in shuffled file order")
     run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "A"), os.path.join(c, "B"), tmp_path / "n"])
     assert_same_db(os.path.join(c, "C"), tmp_path / "n", "concatdbs of the nucleotide ORF DBs")
+
+
+def test_oracle_concatdbs_preserve_keys(oracle_bin, golden, tmp_path):
+    """`concatdbs --preserve-keys` as data/nuclassemble.sh:41,145 calls it (DBConcat.cpp:113-118 with preserveKeysB): the union of two DBs with
+    disjoint keys, inputs that are index subsets over a larger data file like the workflow's `_noneCycle` DB; reference-written
+    (tests/golden/make_concat_preserve.sh)"""
+    c = os.path.join(golden, "concat_preserve")
+    run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "cycA"), os.path.join(c, "cycB"), tmp_path / "cycle_all", "--preserve-keys", "1"])
+    assert_same_db(os.path.join(c, "cycle_all"), tmp_path / "cycle_all", "concatdbs cycA cycB --preserve-keys")
+    run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "noneCycle"), tmp_path / "cycle_all", tmp_path / "merged", "--preserve-keys", "1"])
+    assert_same_db(os.path.join(c, "merged"), tmp_path / "merged", "concatdbs noneCycle cycle_all --preserve-keys")
+
