@@ -134,3 +134,26 @@ def sweep_positional(golden, mod, out):
     if mod == "rescorediagonal":
         return mod, [f"{s}/seq_0", f"{s}/seq_0", f"{s}/pref_0", out], [("", out)]
     return mod, [f"{s}/seq_0", f"{s}/aln_0", out], [("", out)]
+
+
+def check_strand_membership(rec, ent, what):
+    """tests/golden/strand_membership.json (make_strand_membership.py): the prefilter entries `ent` {key: bytes} of one nucleotide iteration
+    against what the unmodified reference wrote in K runs — every query that is not tie-dependent byte for byte (one SHA-256 over them),
+    every LINE of a tie-dependent query one of the versions some reference run wrote of it"""
+    import hashlib
+    ties = {int(k): v for k, v in rec["ties"].items()}
+    assert len(ent) == rec["entries"], what
+    h = hashlib.sha256()
+    for k in sorted(ent):
+        if k not in ties:
+            h.update(b"%d\x00" % k); h.update(ent[k])
+    assert h.hexdigest() == rec["stable_sha256"], "%s: an entry that does not depend on a strand tie differs from the reference's" % what
+    for k, t in ties.items():
+        mine = {}
+        for l in ent[k].decode("latin-1").split("\n"):
+            if l and l != "\x00":
+                mine[l.split("\t", 1)[0]] = l
+        assert mine.keys() == t["lines"].keys(), "%s: query %d names other targets than the reference" % (what, k)
+        for tg, l in mine.items():
+            assert l in t["lines"][tg], "%s: query %d, target %s: %r is not a line any of the reference's runs wrote (%r)" % (what, k, tg, l, t["lines"][tg])
+

@@ -27,20 +27,34 @@ def dbsum(path):
 def check(path, want, what):
     got = dbsum(path)
     for k in ("entries", "bytes", "digest"):
-        assert got[k] == want[k], "%s: %s differs from the CPU oracle's (got %s, expected %s)" % (what, k, got[k], want[k])
+        assert got[k] == want[k], "%s: %s differs from the fixture's (got %s, expected %s)" % (what, k, got[k], want[k])
     for suffix in ("", ".index", ".dbtype"):
         if os.path.exists(str(path) + suffix):
             os.remove(str(path) + suffix)
 
 
 def test_large_chain_against_oracle_checksums(tmp_path):
+    run_protein_chain(json.load(open(GOLD)), tmp_path, min_reads=5000000)
+
+
+def test_reference_only_chain(tmp_path):
+    """VERDICT r5 missing #5: a large fixture with NO oracle in its chain of trust.  tests/golden/reference_chain.json was written by the
+    unmodified reference alone (tests/golden/pin_deep_chains_against_reference.py --only record_chain, profiles/r06_record_chain_reference.txt):
+    5 M reads of the configs[2] community -> 8.8 M protein fragments -> all twelve iterations of the default chain, every `pref`, `aln` and `seq`
+    DB digested.  The GPU path regenerates the reads and must reproduce every sequence DB (digest computed in HBM) and, for iterations 0, 6 and
+    11 (a fresh seed, a cached same-seed iteration, the last), the prefilter and alignment DBs through their files."""
+    gold = json.load(open(os.path.join(HERE, "golden", "reference_chain.json")))
+    assert "UNMODIFIED reference alone" in gold["made_by"] and len(gold["iterations"]) == 12
+    run_protein_chain(gold, tmp_path, min_reads=5000000, files_for=(0, 6, 11))
+
+
+def run_protein_chain(gold, tmp_path, min_reads, files_for=None):
     import bench
     import plass_amd
-    gold = json.load(open(GOLD))
     sp = bench.synth_params(gold["config"], gold["pairs"])
     for k, v in gold["synth"].items():                       # the fixture was made for exactly these generator parameters
         assert getattr(sp, k) == pytest.approx(v), k
-    assert 2 * gold["pairs"] >= 5000000
+    assert 2 * gold["pairs"] >= min_reads
     ctx = plass_amd.Context(0)
     try:
         reads, sst = ctx.synth_read_pairs(sp)
@@ -55,18 +69,22 @@ def test_large_chain_against_oracle_checksums(tmp_path):
         for it, want in enumerate(gold["iterations"]):
             par = plass_amd.KmermatchParams(k=14, alph_size=13, kmer_per_seq=60, kmer_per_seq_scale=0.0, hash_shift=bench.hash_shift(it),
                                             include_only_extendable=(it > 0), ignore_multi_kmer=True, cov_mode=0, c=0.0)
+            files = files_for is None or it in files_for
             cands, _ = ctx.kmermatcher(db, par)
-            cands.write(tmp_path / "pref")
-            check(tmp_path / "pref", want["pref"], "kmermatcher, iteration %d" % it)
+            if files:
+                cands.write(tmp_path / "pref")
+                check(tmp_path / "pref", want["pref"], "kmermatcher, iteration %d" % it)
             alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.9, e=1e-5))
             cands.free()
-            alns.write(tmp_path / "aln")
-            check(tmp_path / "aln", want["aln"], "rescorediagonal, iteration %d" % it)
+            if files:
+                alns.write(tmp_path / "aln")
+                check(tmp_path / "aln", want["aln"], "rescorediagonal, iteration %d" % it)
             out, _ = ctx.assembleresults(db, alns, plass_amd.AssembleParams(min_seq_id=0.9, max_seq_len=65535, keep_target=True))
             alns.free(); db.free()
-            out.write(tmp_path / "seq")
             assert out.digest() == (want["seq"]["digest"], want["seq"]["bytes"]), "device digest of seq_%d" % (it + 1)
-            check(tmp_path / "seq", want["seq"], "assembleresults, iteration %d" % it)
+            if files:
+                out.write(tmp_path / "seq")
+                check(tmp_path / "seq", want["seq"], "assembleresults, iteration %d" % it)
             db = out
         db.free()
     finally:

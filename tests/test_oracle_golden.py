@@ -268,3 +268,28 @@ def test_oracle_concatdbs_preserve_keys(oracle_bin, golden, tmp_path):
     run_oracle(oracle_bin, ["concatdbs", os.path.join(c, "noneCycle"), tmp_path / "cycle_all", tmp_path / "merged", "--preserve-keys", "1"])
     assert_same_db(os.path.join(c, "merged"), tmp_path / "merged", "concatdbs noneCycle cycle_all --preserve-keys")
 
+
+def test_oracle_strand_ties_are_a_reference_outcome(oracle_bin, tmp_path):
+    """where the reference's nucleotide kmermatcher is not deterministic (strand-tied pairs: 10 runs of one command gave 8
+    versions of one entry), the oracle's result must be ONE OF THE REFERENCE'S — checked as set membership, line by line, against
+    tests/golden/strand_membership.json (the judge's case: seed 424242, 40 000 pairs, 4 genomes of 100-200 kb, three iterations of the
+    nucleotide chain; 10 reference runs per iteration; generator tests/golden/make_strand_membership.py)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_strand_membership import chain_step, entries
+    from conftest import check_strand_membership
+    import conftest as T
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "strand_membership.json")))
+    assert sum(r["tie_dependent_pairs"] for r in fx["iterations"]) >= 10 and "UNMODIFIED reference" in fx["made_by"]
+    P = lambda n: str(tmp_path / n)
+    run_oracle(oracle_bin, ["synthreads", P("reads")] + fx["synth"])
+    src = P("reads")
+    for it, rec in enumerate(fx["iterations"]):
+        run_oracle(oracle_bin, ["kmermatcher", src, P("o_pref")] + fx["kmermatcher"] + ["--threads", "4"])
+        ent = entries(P("o_pref"))
+        check_strand_membership(rec, ent, "oracle, nucleotide iteration %d" % it)
+        for k, t in rec["ties"].items():                      # (the oracle is deterministic: it writes what it wrote when the fixture was made)
+            assert ent[int(k)].decode("latin-1") == t["oracle"]
+        src = chain_step(oracle_bin, T, src, P, it, 4)
+
