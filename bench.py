@@ -170,7 +170,7 @@ def source_sha():
 
 
 # rocprofv3 names of the kernels behind a row of the stage table (all instantiations of a template are one row)
-KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShort(Fast)?Kernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescore(Refill)?Kernel<",
+KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShort(Fast)?Kernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
                   # (MODE 0 = the hash partition of the k-mer records; the MODE 1 instantiations are the rep sort's range partitions: VERDICT r4 weak #10)
                   "partitionKernel(k-mer records)": "linePartKernel<(true|false), (true|false), 0, .*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel",
                   "assembleNuclKernel(+assembleNuclThreadKernel, all passes)": "assembleNucl(Thread)?Kernel<"}

@@ -374,267 +374,13 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
     }
 }
 
-// =====================================================================================================
-// Round 6: the same pairs on a PERSISTENT wavefront whose lanes REFILL.  rescoreKernel<1> above walks its pairs in
-// lock-step — every lane takes a pair, the wavefront scores until the LONGEST of the 64 is through, then all 64 run the epilogue:
-// 21.7 of 64 lanes active per vector instruction at 50 M reads (profiles/r05_pmc_lanes_per_kernel.txt), because a read overlap is 2-10
-// steps of 16 columns and one contig-contig pair per wavefront is 30-48.  Here the pair loop is decoupled from the column loop:
-//   * the wave-uniform loop body is ONE 16-column step for every lane that has a diagonal open (the step of scoreDiagonal<REV, 1>,
-//     unchanged: blanked columns, one zero-byte test for the identities, the next 16 residues requested before these are scored);
-//   * a lane whose pair is through WAITS (masked) until `T` lanes of the wavefront are out of work — then those lanes run the epilogue
-//     together (bit score, identity, coverage, the 64-byte record) and draw new pairs, while the lanes still scoring keep their state in
-//     registers and go on with the next step: a long pair never holds more than its own lane, and the epilogue — a third of the kernel's
-//     instructions — runs at >= T of 64 lanes instead of whenever one lane is through.  T = 32 by default (PLASSHIP_TUNE_RESCORE_T);
-//   * pairs come from a device-wide cursor in chunks of 1024 per wavefront (no static shares: the long pairs of a few deep queries no
-//     longer make one workgroup the tail of the launch); candidate and packed (offset, length) words of a lane's NEXT pair are requested
-//     when it draws the current one, so a refill waits for one round trip (the first residues), like the lock-step kernel;
-//   * identity pairs (stubs), long pairs (queued for the 16-lane kernel) and pairs that score nothing (coverage gate, no wrap meets the
-//     sequences) are finished inside the refill, which runs a second round for the lanes that drew one.
-// Per pair the arithmetic is the lock-step kernel's, statement for statement: tests compare the alignment DBs byte for byte with the
-// reference's; PLASSHIP_TUNE_RESCORE_REFILL=2 selects the lock-step kernel (the A/B of profiles/r06_ab_knobs.txt).
-// =====================================================================================================
-constexpr uint32_t RF_CHUNK = 1024;
-// A pair is scored here only when both sequences are shorter than 32 768 residues: then at most ONE wrap of the 16-bit diagonal meets
-// the sequences (the negative wrap d - 65536 needs d > 32 768 > qLen, the positive one d < qLen), so the lane carries no wrap index and
-// no "best so far" — the first version kept both, with the geometry and both sequences' offsets, and spilled 112 registers at four
-// wavefronts per SIMD.  Pairs with a longer sequence go to the 16-lane kernel with the long overlaps (it walks every wrap).
-constexpr uint32_t RF_MAXLEN = 32768;
-template <bool REVCAP, int WPE>
-__global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rescoreRefillKernel(RescoreArgs a, unsigned long long *cursor, uint32_t T) {
-    __shared__ signed char smat[123 * 128];
-    __shared__ unsigned char sComp[256];
-    for (int i = threadIdx.x; i < 123 * 128; i += RS_BLOCK) smat[i] = (i & 127) < 123 ? a.mat[(i >> 7) * 123 + (i & 127)] : (signed char) 0;
-    for (int i = threadIdx.x; i < 256; i += RS_BLOCK) sComp[i] = i ? (unsigned char) nuclRevCompChar((char) i) : (unsigned char) 0;
-    __syncthreads();
-    if (threadIdx.x == 0) smat[0] = 0;      // blanked columns look up [0][0]; no residue is byte 0
-    __syncthreads();
-    const int lane = laneId();
-    const unsigned long long ltMask = (1ULL << lane) - 1ULL;
-    const uint64_t nWork = a.nHits;
-    enum { IDLE = 0, SCORING = 1, DONE = 2 };
-    // wave-uniform: the chunk this wavefront draws from
-    uint64_t next = 0, end = 0; bool srcDry = false;
-    // per lane: the pair being scored ...
-    int status = IDLE;
-    uint64_t curH = 0; uint32_t qid = 0, tid = 0, qLen = 0, tLen = 0; int real = 0;      // real: the diagonal (the one wrap that meets the sequences)
-    bool isReverse = false, hasDiag = false, firstStar = false;
-    // ... the pair drawn ahead (candidate + the packed (offset, length) words of its sequences) ...
-    bool nxtValid = false; uint64_t nxtH = 0, nxtQv = 0, nxtTv = 0; CandHit nxtHit;
-    memset(&nxtHit, 0, sizeof(nxtHit));
-    // ... and the open diagonal: byte offsets of column 0 in the DBs' data (reverse strand: qPos = offset of the query ENTRY, column 0 = stored
-    // residue qLen - 1 - qo), columns [0, last], the next 16 residues of both sequences
-    uint64_t qPos = 0, tPos = 0;
-    unsigned qo = 0, last = 0, p = 0, ends = 0; int sc = 0, ids = 0;
-    uint32_t qn[4] = {0, 0, 0, 0}, tn[4] = {0, 0, 0, 0};
-    uint32_t accLocal = 0, ovLocal = 0;   // (per lane: at most a few 10^5 pairs of < 2^15 columns)
-
-    // the 16 query residues of columns [pp, pp + 16) (reverse strand: the stored bytes that END at the mirrored position, byte-reversed; near the
-    // start of the sequence byte by byte, never reading before the buffer) — scoreDiagonal's fetchQ
-    auto fetchQ = [&](unsigned pp, uint32_t *w) {
-        if (!REVCAP || !isReverse) __builtin_memcpy(w, a.q.data + qPos + pp, 16);
-        else {
-            const char *q = a.q.data + qPos;
-            const unsigned rem = qLen - (qo + pp);
-            if (rem >= 16) {
-                uint32_t v[4]; __builtin_memcpy(v, q + (qLen - 1 - (qo + pp)) - 15, 16);
-                w[0] = __builtin_bswap32(v[3]); w[1] = __builtin_bswap32(v[2]); w[2] = __builtin_bswap32(v[1]); w[3] = __builtin_bswap32(v[0]);
-            } else {
-                uint64_t lo = 0, hi = 0;
-                for (unsigned j = rem; j-- > 0;) { hi = (hi << 8) | (lo >> 56); lo = (lo << 8) | (uint64_t) (unsigned char) q[qLen - 1 - (qo + pp + j)]; }
-                w[0] = (uint32_t) lo; w[1] = (uint32_t) (lo >> 32); w[2] = (uint32_t) hi; w[3] = (uint32_t) (hi >> 32);
-            }
-        }
-    };
-
-    for (;;) {
-        const unsigned long long mScoring = __ballot(status == SCORING);
-        const unsigned long long mOut = __ballot(status == DONE || (status == IDLE && (nxtValid || !srcDry || next < end)));
-        if (!mScoring && !mOut) break;
-        if (mOut && (!mScoring || (uint32_t) __popcll(mOut) >= T)) {
-            // ---- the lanes out of work: epilogue (rescorediagonal.cpp:251-314, the lock-step kernel's), then refill ----
-            if (status == DONE) {
-                const bool isIdentity = (qid == tid) && (a.includeIdentity || a.sameDB);
-                AlnRec rec; memset(&rec, 0, sizeof(rec));
-                rec.query = qid; rec.target = tid;
-                bool accepted = false;
-                if (canBeCoveredDev(a.covThr, a.covMode, (float) qLen, (float) tLen)) {
-                    // the wrap's result if it scored > 0 (computeUngappedAlignment keeps a strictly better one), else the defaults of LocalAlignment()
-                    const unsigned score = hasDiag ? (unsigned) max(sc, 0) : 0u;
-                    const bool have = score > 0;
-                    const int bStart = have ? (firstStar ? 1 : 0) : -1, bEnd = have ? (int) last : -1, bDiag = have ? real : 0;
-                    const unsigned bDist = (unsigned) abs(bDiag);
-                    if (have) ovLocal += bDiag >= 0 ? min(tLen, qLen - bDist) : min(tLen - bDist, qLen);
-                    const int distance = (int) score;
-                    const int bitScore = (int) (fma(a.lambda, (double) distance, -a.logK) / a.ln2 + 0.5);
-                    const int alnLen = (bEnd - bStart) + 1;
-                    int qS, qE, dS, dE;
-                    if (bDiag >= 0) { qS = bStart + (int) bDist; qE = bEnd + (int) bDist; dS = bStart; dE = bEnd; }
-                    else { qS = bStart; qE = bEnd; dS = bStart + (int) bDist; dE = bEnd + (int) bDist; }
-                    const uint32_t ms = (qLen < a.minScoreLen) ? a.minScore[qLen] : 0xFFFFFFFFu;
-                    const bool hasEvalue = (uint32_t) distance >= ms;
-                    int idCnt = have ? ids : 0;
-                    if (bStart < 0) idCnt = isIdentity ? 1 : 0;
-                    float seqId = 0.0f;
-                    if (hasEvalue || isIdentity) {
-                        switch (a.seqIdMode) {                                                     // Util.cpp:588-598
-                            case 0: seqId = (float) idCnt / (float) alnLen; break;
-                            case 1: seqId = (float) idCnt / (float) min((int) qLen, (int) tLen); break;
-                            case 2: seqId = (float) idCnt / (float) max((int) qLen, (int) tLen); break;
-                            default: seqId = 0.0f;
-                        }
-                    }
-                    const float queryCov = computeCovDev((unsigned) qS, (unsigned) qE, qLen);
-                    const float targetCov = computeCovDev((unsigned) dS, (unsigned) dE, tLen);
-                    if (isReverse) { qS = (int) qLen - qS - 1; qE = (int) qLen - qE - 1; }
-                    const bool hasCov = hasCoverageDev(a.covThr, a.covMode, queryCov, targetCov);
-                    const bool hasSeqId = (double) seqId >= (double) (a.seqIdThr - FLT_EPSILON);
-                    const bool hasAlnLen = alnLen >= a.alnLenThr;
-                    accepted = isIdentity || (hasAlnLen && hasCov && hasSeqId && hasEvalue);
-                    rec.bitScore = bitScore; rec.rawScore = distance; rec.seqId = seqId;
-                    rec.qStart = qS; rec.qEnd = qE; rec.qLen = (int) qLen; rec.dbStart = dS; rec.dbEnd = dE; rec.dbLen = (int) tLen;
-                    rec.alnLen = alnLen; rec.reversed = isReverse ? 1 : 0;
-                }
-                rec.accepted = accepted ? 1 : 0; rec.btKind = 1;
-                a.out[curH] = rec;
-                accLocal += accepted ? 1u : 0u;
-                status = IDLE;
-            }
-            // two rounds: a lane that draws a pair with nothing to score here (an identity pair, a long one) draws again
-#pragma unroll 1
-            for (int round = 0; round < 2; round++) {
-                const bool wantDraw = status == IDLE;                     // (a lane that takes its drawn-ahead pair, and a lane that has none yet)
-                if (!__ballot(wantDraw)) break;
-                const bool take = wantDraw && nxtValid;
-                const CandHit hit = nxtHit; const uint64_t h = nxtH, qv = nxtQv, tv = nxtTv;
-                nxtValid = nxtValid && !take;
-                // draw ahead: one index per wanting lane from the wavefront's chunk, a new chunk from the device-wide cursor when it is used up
-                {
-                    bool got = false;
-                    for (;;) {
-                        const unsigned long long m = __ballot(wantDraw && !got);
-                        if (!m) break;
-                        const uint64_t avail = end - next;
-                        const uint32_t cnt = (uint32_t) __popcll(m), rank = (uint32_t) __popcll(m & ltMask);
-                        if (wantDraw && !got && (uint64_t) rank < avail) { nxtH = next + rank; got = true; }
-                        next += std::min<uint64_t>((uint64_t) cnt, avail);
-                        if ((uint64_t) cnt <= avail || srcDry) break;
-                        const int leader = __ffsll((long long) __ballot(wantDraw && !got)) - 1;
-                        unsigned long long base = 0;
-                        if (lane == leader) base = atomicAdd(cursor, (unsigned long long) RF_CHUNK);
-                        base = __shfl(base, leader, 64);
-                        if (base >= nWork) { srcDry = true; break; }
-                        next = base; end = std::min<uint64_t>(base + RF_CHUNK, nWork);
-                    }
-                    if (got) { nxtHit = a.hits[nxtH]; nxtQv = a.q.offLen[nxtHit.query]; nxtTv = a.t.offLen[nxtHit.target]; nxtValid = true; }
-                }
-                if (take) {
-                    curH = h; qid = hit.query; tid = hit.target;
-                    qLen = (uint32_t) qv & 0xFFFFFFu; tLen = (uint32_t) tv & 0xFFFFFFu;
-                    if (a.lazySelf && qid == tid && (a.includeIdentity || a.sameDB)) {
-                        // an identity pair: accepted whatever it scores — left as a stub for finishSelfAlns (common.hpp)
-                        AlnRec stub; memset(&stub, 0, sizeof(stub));
-                        stub.query = qid; stub.target = tid; stub.rawScore = hit.prefScore; stub.qStart = (int32_t) hit.diag16; stub.qLen = (int) qLen; stub.dbLen = (int) tLen;
-                        stub.accepted = 1; stub.btKind = ALN_SELF_PENDING;
-                        a.out[h] = stub;
-                        accLocal += 1;
-                    } else if (min(qLen, tLen) > a.shortMax || max(qLen, tLen) >= RF_MAXLEN) {
-                        // long overlap, or a sequence long enough for several wraps: queued for the 16-lane kernel (one atomic per group of lanes
-                        // that found one in this round)
-                        const unsigned long long m = __ballot(true);
-                        const int leader = __ffsll((long long) m) - 1;
-                        unsigned long long basePos = 0;
-                        if (lane == leader) basePos = atomicAdd(a.longCount, (unsigned long long) __popcll(m));
-                        basePos = __shfl(basePos, leader, 64);
-                        a.longList[basePos + (unsigned long long) __popcll(m & ltMask)] = h;
-                    } else {
-                        isReverse = a.reverseCapable && hit.prefScore < 0;
-                        // the wrap that meets the sequences (DistanceCalculator.h:93-175): d - 65536 if its distance lies inside the target, d if inside the query
-                        const unsigned d16 = hit.diag16 & 0xFFFFu;
-                        const bool neg = 65536u - d16 < tLen, pos = d16 < qLen;
-                        real = neg ? (int) d16 - 65536 : (int) d16;
-                        const unsigned dist = (unsigned) abs(real);
-                        unsigned to = 0, len = 0;
-                        if (neg) { qo = 0; to = dist; len = min(tLen - dist, qLen); } else if (pos) { qo = dist; to = 0; len = min(tLen, qLen - dist); }
-                        // (a diagonal without a column — an empty sequence — scores nothing: scoreDiagonal's `len == 0`)
-                        hasDiag = len > 0 && canBeCoveredDev(a.covThr, a.covMode, (float) qLen, (float) tLen);
-                        status = DONE;                                        // (nothing to score: the record with the defaults, written with the next epilogues)
-                        if (hasDiag) {
-                            tPos = (tv >> 24) + to;
-                            qPos = (REVCAP && isReverse) ? (qv >> 24) : (qv >> 24) + qo;
-                            __builtin_memcpy(tn, a.t.data + tPos, 16); fetchQ(0, qn);
-                            const unsigned char te = (unsigned char) a.t.data[tPos + len - 1];
-                            const unsigned char qe = (unsigned char) ((REVCAP && isReverse) ? a.q.data[qPos + (qLen - 1 - (qo + len - 1))] : a.q.data[qPos + len - 1]);
-                            ends = (unsigned) te | ((unsigned) qe << 8);
-                            last = len - 1; p = 0; sc = 0; ids = 0;
-                            status = SCORING;
-                        }
-                    }
-                }
-            }
-            continue;
-        }
-        // ---- one step of 16 columns for every lane with an open diagonal (the loop body of scoreDiagonal<REV, 1>) ----
-        if (status == SCORING) {
-            if (p == 0) {
-                const char t0 = (char) (tn[0] & 0xFFu), te = (char) (ends & 0xFFu);
-                const char q0 = (REVCAP && isReverse) ? (char) sComp[qn[0] & 0xFFu] : (char) (qn[0] & 0xFFu);
-                const char qe = (REVCAP && isReverse) ? (char) sComp[(ends >> 8) & 0xFFu] : (char) ((ends >> 8) & 0xFFu);
-                firstStar = (q0 == '*' || t0 == '*');
-                if (last > 0 && (qe == '*' || te == '*')) last--;
-            }
-            uint32_t qw[4], tw[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) { qw[k] = qn[k]; tw[k] = tn[k]; }
-            if (p + 16u <= last) { __builtin_memcpy(tn, a.t.data + tPos + p + 16, 16); fetchQ(p + 16, qn); }
-            const unsigned n = min(16u, last - p + 1);
-            const unsigned skip = (p == 0 && firstStar) ? 1u : 0u;   // column 0 of the overlap is not scored when it holds a '*'
-            const unsigned blanks = (16u - n) + skip;
-            if (blanks) {
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int nb = (int) n - 4 * k;
-                    uint32_t m = nb >= 4 ? 0xFFFFFFFFu : (nb <= 0 ? 0u : ((1u << (8 * nb)) - 1u));
-                    if (k == 0 && skip) m &= 0xFFFFFF00u;
-                    qw[k] &= m; tw[k] &= m;
-                }
-            }
-            if (REVCAP) {
-                const bool rev = isReverse;
-#pragma unroll
-                for (unsigned j = 0; j < 16; j++) {
-                    unsigned x = (qw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                    if (rev) x = (unsigned) sComp[x];
-                    const unsigned y = (tw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                    sc += (int) smat[(x << 7) | y];
-                    ids += ((x & ~0x20u) == (y & ~0x20u)) ? 1 : 0;
-                }
-                ids -= (int) blanks;
-            } else {
-                int z = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t x = (qw[k] ^ tw[k]) & 0xDFDFDFDFu;
-                    z += __popc(~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu));
-                }
-                ids += z - (int) blanks;
-#pragma unroll
-                for (unsigned j = 0; j < 16; j++) {
-                    const unsigned x = (qw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                    const unsigned y = (tw[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-                    sc += (int) smat[(x << 7) | y];
-                }
-            }
-            p += 16u;
-            if (p > last) status = DONE;
-        }
-    }
-    unsigned long long accW = waveReduceSumU64((unsigned long long) accLocal), ovW = waveReduceSumU64((unsigned long long) ovLocal);
-    if (lane == 0) {
-        if (accW) atomicAdd(&a.stats[0], accW);
-        if (ovW) atomicAdd(&a.stats[1], ovW);
-    }
-}
-
+// (Round 6, VERDICT r5 item 2: a PERSISTENT wavefront whose lanes refill — one 16-column step per loop trip for every lane with an open
+//  diagonal, the lanes that are through waiting until T of them run the epilogue together and draw new pairs from a device-wide cursor — was
+//  built, byte-identical on every test, and measured against this kernel on the 12 iterations of the 50 M-read chain
+//  (profiles/r06_calls/call1_rescore_refill_sweep.txt): 36.3 ms at T = 32, 33.4 at 48, 32.1 at 64, 42.7 at 16, against 30.8 ms for the
+//  lock-step kernel.  The time grows linearly with the number of refill events per 64 pairs (~2.4 ms each) while the stepping part does not
+//  shrink with the fuller lanes: the kernel is bound by the round trips a pair consists of, not by vector issue — a refill exposes one per
+//  event for T pairs where the lock-step kernel exposes one per 64 — and the lanes-per-instruction figure does not measure that.  Removed.)
 // dense copy of a sparse list (host paths only since round 5): four lanes per 64-byte record, 16 bytes each, both sides coalesced
 __global__ void acceptFlagsKernel(const AlnRec *__restrict__ recs, uint32_t *__restrict__ accept, uint64_t n) {
     for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) accept[i] = recs[i].accepted ? 1u : 0u;
@@ -789,22 +535,7 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     static const int wpe = [] { const int v = tuneInt("RESCORE_WPE", 4); if (v != 4 && v != 5) fprintf(stderr, "[plasship] PLASSHIP_TUNE_RESCORE_WPE=%d: only 4 and 5 are built, using 4\n", v); return v; }();
     // (16 or 8 lanes per pair for EVERY pair, and a second thread-per-pair pass for the overlaps of 128-512 columns, were both
     // slower — 76 / 53 ms and 83 ms against 45 ms per iteration at 50 M reads: profiles/r03_ab_knobs.txt)
-    // round 6: the persistent lane-refill kernel (above); PLASSHIP_TUNE_RESCORE_REFILL=2: the lock-step kernel of rounds 1-5
-    const bool refill = tuneInt("RESCORE_REFILL", 1) == 1 && qdb->d_offLen.p && tdb->d_offLen.p;
-    DevBuf dCursor;
-    if (refill) {
-        if (dCursor.alloc(8) != hipSuccess) { setError("plasship_rescore: out of device memory"); return PLASSHIP_ERR_DEVICE; }
-        PH_CHECK(hipMemsetAsync(dCursor.p, 0, 8, ctx->stream));
-        const uint32_t T = (uint32_t) std::min(64, std::max(1, tuneInt("RESCORE_T", 32)));
-        // one resident set of wavefronts: WPE per SIMD, four SIMDs per CU, four wavefronts per workgroup
-        const int rwpe = tuneInt("RESCORE_REFILL_WPE", 4);
-        const unsigned rgrid = (unsigned) std::max<uint64_t>(1, std::min<uint64_t>((nHits + RF_CHUNK - 1) / RF_CHUNK, (uint64_t) ctx->numCU * (uint64_t) (rwpe == 5 ? 5 : (rwpe == 3 ? 3 : 4))));
-        if (c->reverseCapable) hipLaunchKernelGGL((rescoreRefillKernel<true, 4>), dim3(rgrid), dim3(RS_BLOCK), 0, ctx->stream, a, dCursor.as<unsigned long long>(), T);
-        else if (rwpe == 5) hipLaunchKernelGGL((rescoreRefillKernel<false, 5>), dim3(rgrid), dim3(RS_BLOCK), 0, ctx->stream, a, dCursor.as<unsigned long long>(), T);
-        else if (rwpe == 3) hipLaunchKernelGGL((rescoreRefillKernel<false, 3>), dim3(rgrid), dim3(RS_BLOCK), 0, ctx->stream, a, dCursor.as<unsigned long long>(), T);
-        else hipLaunchKernelGGL((rescoreRefillKernel<false, 4>), dim3(rgrid), dim3(RS_BLOCK), 0, ctx->stream, a, dCursor.as<unsigned long long>(), T);
-    }
-    else if (wpe == 5) hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    if (wpe == 5) hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
     else hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));

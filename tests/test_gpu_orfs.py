@@ -182,6 +182,7 @@ def test_concatdbs_preserve_keys(ctx, golden, tmp_path):
     """`concatdbs --preserve-keys` (DBConcat.cpp:113-118; data/nuclassemble.sh:41,145): circular contigs rejoin the linear ones under their own
     keys.  Inputs are index subsets over larger data files (the workflow's `_noneCycle` DB); reference-written DBs
     (tests/golden/make_concat_preserve.sh), through the C-ABI and through `plass-hip concatdbs ... --preserve-keys` as the script calls it"""
+    import subprocess
     c = os.path.join(golden, "concat_preserve")
     a, b, rest = ctx.read_seqdb(f"{c}/cycA"), ctx.read_seqdb(f"{c}/cycB"), ctx.read_seqdb(f"{c}/noneCycle")
     call = ctx.concatdbs(a, b, preserve_keys=True); call.write(tmp_path / "cycle_all")
