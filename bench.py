@@ -255,6 +255,31 @@ def furthest_below(tot, n_steps, cfg):
     return worst
 
 
+# The unmodified reference on the WHOLE bench workloads, measured in the build container (8 threads of a Xeon at 2.1 GHz; it cannot travel to the
+# GPU box): seconds inside its kmermatcher / rescorediagonal / assembleresults (c3: twelve iterations on 50 M reads, kmermatcher unsplit) and inside
+# the ten PenguiN steps of c5 (20 M reads) — the runs whose results are the digests `verify` compares with (profiles/r05_headline_pin_reference.txt).
+REFERENCE_FULL_WORKLOAD = {
+    "c3": {"seconds": 8420.0, "seconds_by_module": {"kmermatcher": 3879.0, "rescorediagonal": 2596.0, "assembleresults": 1945.0}, "threads": 8, "cpu": "Xeon 2.1 GHz (build container)",
+           "candidate_overlaps": 2.40e9, "overlaps_per_s": 2.40e9 / 8420.0, "iterations": 12, "reads": 50000000, "source": "profiles/r05_headline_pin_reference.txt",
+           "note": "the unmodified `plass` binary, AVX2, 8 OpenMP threads, kmermatcher in one part (--split-memory-limit 64G); its seq_1 .. seq_12 are tests/golden/c3_chain_digests.json"},
+    "c5": {"seconds": 4126.0, "threads": 8, "cpu": "Xeon 2.1 GHz (build container)", "overlaps_per_s": 0.16e6, "iterations": 10, "reads": 20000000,
+           "source": "profiles/r05_headline_pin_reference.txt", "note": "the unmodified `penguin` binary: 5 guided iterations (2 156 s) + 5 nucleotide iterations with cyclecheck (1 970 s)"},
+    # round 6, 6 threads: the reference-only fixture tests/golden/reference_chain.json (5 M reads, twelve iterations; profiles/r06_record_chain_reference.txt)
+    "c3_5M_reads": {"seconds": 746.6, "seconds_by_module": {"kmermatcher": 454.5, "rescorediagonal": 141.0, "assembleresults": 151.1}, "threads": 6, "cpu": "Xeon 2.1 GHz (build container)",
+                    "iterations": 12, "reads": 5000000, "source": "profiles/r06_record_chain_reference.txt"},
+}
+
+
+def host_cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(ctx, cfg, sample_pairs, iters):
     """(1) the CPU oracle — a port of the reference algorithm with OpenMP over the loops the reference threads — on a bounded
     sample of the same community model (same generator, same coverage), module compute time only;
@@ -264,8 +289,8 @@ def cpu_baseline(ctx, cfg, sample_pairs, iters):
     if not os.path.exists(g.oracle_bin()):
         subprocess.check_call(["make", "-j", "4"], cwd=os.path.join(ROOT, "oracle"))
     threads = max(1, min(len(os.sched_getaffinity(0)), 64))
-    if sample_pairs <= 0:                                    # ~10-30 s of CPU work whatever the core count
-        sample_pairs = 40000 if threads < 8 else 120000
+    if sample_pairs <= 0:                                    # ~10-30 s of CPU work whatever the core count (the GPU box has 64+ cores: 1 M pairs there — VERDICT r5 item 8)
+        sample_pairs = 40000 if threads < 8 else (120000 if threads < 32 else 1000000)
     db, desc = build_workload(ctx, cfg, sample_pairs, min_genomes=5)      # >= 5 genomes with log-normal abundances: skewed like the GPU workload
     thr = ["--threads", str(threads)]
     tot_t, tot_c, cli_t, cli_c = 0.0, 0, 0.0, 0
@@ -294,7 +319,8 @@ def cpu_baseline(ctx, cfg, sample_pairs, iters):
             tot_c += int(re.search(r"N_c=(\d+)", e1).group(1))
             for e in (e1, e2, e3):                           # "oracle <module>: …, 1.234 s" (other lines may follow: a profiler attached to the child)
                 tot_t += float(re.search(r"^oracle \w+:.*?([0-9.]+) s\s*$", e, re.M).group(1))
-    res = {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
+    res = {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port", "cpu": host_cpu_model(), "seconds": round(tot_t, 2),
+           "reference_full_workload": REFERENCE_FULL_WORKLOAD.get(cfg),
            "sample": "%d read pairs of the same community model at the same mean coverage, skewed (%d genomes, log-normal abundances sigma 1; %d protein fragments), iterations 0..%d of the chain, "
                      "oracle module compute time (no DB I/O), %d OpenMP threads (grouping and result writing are single-threaded, as in the reference)"
                      % (desc["read_pairs"], desc["genomes"], desc["protein_fragments"], iters - 1, threads),
@@ -351,6 +377,8 @@ def main():
     dev = torch.device("cuda", local)
     comm = None; native = None
     sharded_error = None
+    comm_timeout = float(os.environ.get("PLASS_BENCH_COMM_TIMEOUT", "240"))
+    setup_s = {}
     # the preprocessing is not sharded: every rank builds the identical DB from the seed (before a communicator is installed)
     db0, wl = build_workload(ctx, args.config, pairs if mode != "partitions" else max(1000, pairs // world))
     if mode == "sharded":
@@ -360,7 +388,7 @@ def main():
             try:                     # rank 0 makes the id, torch.distributed carries it (control plane only)
                 box = [rccl_unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0, device=dev)
-                native = RcclComm(ctx, rank, world, box[0])
+                native = bounded(lambda: RcclComm(ctx, rank, world, box[0]), comm_timeout, "creating the native RCCL communicator (ncclCommInitRank)", rank)
             except Exception as e:
                 comm_error = "%s: %s" % (type(e).__name__, e)
             ok = torch.tensor([0 if comm_error else 1], dtype=torch.int64, device=dev)
@@ -374,7 +402,14 @@ def main():
             comm = TorchComm(dist, dev)
             comm.install(ctx)
         try:
-            sharded_preflight(ctx, dist, dev)
+            t_pre = time.perf_counter()
+            bounded(lambda: sharded_preflight(ctx, dist, dev), comm_timeout, "the sharded preflight iteration (first exchanges over the links, %s communicator)" % ("native RCCL" if native is not None else "torch.distributed"), rank)
+            setup_s["preflight_s"] = round(time.perf_counter() - t_pre, 3)      # (the links' first use, RCCL's channel set-up: outside the timed steps)
+        except TimeoutError as e:
+            # a collective that never completes leaves this context's stream blocked: nothing can be salvaged in this process.  Say which rank and
+            # which phase, and end the job with an error instead of hanging until somebody's outer limit (the peers time out in the same phase)
+            print(json.dumps({"error": str(e), "rank": rank, "world": world}), file=sys.stderr, flush=True)
+            os._exit(86)
         except Exception as e:       # e.g. a collective this RCCL / torch build lacks: say so and fall back
             if args.mode == "sharded":
                 raise
@@ -516,6 +551,7 @@ def main():
                 per[name] = {"device_bytes_sent_per_step_rank0": xt[0] / max(len(rows), 1), "host_ms_in_collectives_per_step_rank0": xt[1] * 1e3 / max(len(rows), 1),
                              "collective_calls_per_step": xt[2] / max(len(rows), 1)}
             line["exchange"]["per_module"] = per
+            line["exchange"]["setup"] = setup_s                  # one-off set-up that happened BEFORE the timed steps (the preflight iteration = the links' first use)
             line["exchange"]["model"] = scaling_model(world, wl["reads"], line["roofline"]["module_wall_ms_per_step"] if line.get("roofline") else None)
     if db is not db0:
         db.free()
@@ -551,7 +587,8 @@ def main():
     # tools/cli_dropin_probe.py, profiles/r04_calls/call21_cli_dropin_probe.log) ----
     cpu_line = None
     if rank == 0 and world == 1 and comm is None and native is None and not args.no_cpu_baseline:
-        cpu_line = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, min(chain, 3))
+        # (64 host cores and more: 1 M pairs through ALL iterations of the chain, about a minute; fewer: three iterations of a smaller sample)
+        cpu_line = cpu_baseline(ctx, args.config, args.cpu_sample_pairs, chain if len(os.sched_getaffinity(0)) >= 32 else min(chain, 3))
     # ---- wall clock to final contigs (the metric's second half): the fragment DB goes to disk, then the fused C++ driver
     # (`plass-hip assemble-chain`: the loop of data/assemble.sh:85-156 incl. findassemblystart, DBs chained in HBM) runs as its own
     # process from DB files on disk to the final assembly DB on disk.  This process gives its HBM back first.
@@ -734,7 +771,8 @@ def main_c5(args):
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_note": traffic_note, "ms_per_launch": ms_avg, "algorithmic_bytes_per_launch": bytes_avg,
                          "stage_ms_per_step": {k: round(v[0] / len(rows), 4) for k, v in tot.items()},
-                         "kmermatcher_stage": stage("kmermatcher_stage"), "rescore_stage": stage("rescore_stage"), "assemble_stage": stage("assemble_stage")}}
+                         "kmermatcher_stage": stage("kmermatcher_stage"), "rescore_stage": stage("rescore_stage"), "assemble_stage": stage("assemble_stage"),
+                         "furthest_below": furthest_below(tot, len(rows), "c5")}}
     for key in ("nu", "aa", "db"):
         x = st.get(key)
         if x is not None and x is not reads and x is not nu0 and x is not aa0:
@@ -792,9 +830,32 @@ def cpu_baseline_c5(sample_pairs):
             nu, aa = P("nu%d" % it), P("aa%d" % it)
             timed(["kmermatcher", aa, P("p")] + T.GD_KM); timed(["rescorediagonal", aa, aa, P("p"), P("a")] + T.GD_RS)
             timed(["proteinaln2nucl", nu, nu, aa, aa, P("a"), P("an")] + T.GD_P2N); timed(["guidedassembleresults", nu, aa, P("an"), P("nu%d" % (it + 1)), P("aa%d" % (it + 1))] + T.GD_AS[:6])
-    return {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port",
+    return {"value": tot_c / tot_t, "unit": "overlaps/s", "cores": threads, "kind": "port", "cpu": host_cpu_model(), "seconds": round(tot_t, 2),
+            "reference_full_workload": REFERENCE_FULL_WORKLOAD["c5"],
             "sample": "%d read pairs of the c5 community model at the same mean coverage, skewed (%d genomes, sigma 1): 2 nucleotide iterations (incl. cyclecheck) and 2 protein-guided "
                       "iterations (incl. proteinaln2nucl), oracle module compute time (no DB I/O), %d OpenMP threads" % (sp.n_pairs, sp.n_genomes, threads)}
+
+
+def bounded(fn, seconds, what, rank):
+    """runs fn() on a helper thread and waits at most `seconds` for it: the first sharded run on hardware nobody has touched must not be able to hang the
+    job without a word.  A timeout raises with the rank and the phase in the message; the helper thread is left behind."""
+    import threading
+    box = {}
+
+    def work():
+        try:
+            box["r"] = fn()
+        except BaseException as e:                               # noqa: B902 (carried to the caller's thread)
+            box["e"] = e
+    th = threading.Thread(target=work, daemon=True)
+    th.start(); th.join(seconds if seconds > 0 else None)
+    if th.is_alive():
+        msg = "rank %d: %s did not finish within %.0f s (PLASS_BENCH_COMM_TIMEOUT); NCCL_DEBUG=INFO shows RCCL's view of the links" % (rank, what, seconds)
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+        raise TimeoutError(msg)
+    if "e" in box:
+        raise box["e"]
+    return box.get("r")
 
 
 def sharded_preflight(ctx, dist, device):

@@ -62,6 +62,7 @@ int commAllgatherHost(plasship_ctx *ctx, const void *send, void *recv, uint64_t 
     PH_CHECK(plasship::streamSync(ctx->stream));
     if (ctx->debugFailCollective >= 0 && ctx->debugFailCollective-- == 0) { setError("sharded run: injected rank-local failure (plasship_ctx_debug_fail_collective)"); return PLASSHIP_ERR_DEVICE; }
     { const int rc = commStatus(ctx, 0); if (rc) return rc; }
+    watchCollective("host all-gather");
     if (cm->allgather_host(cm->user, send, recv, bytesPerRank) != 0) { setError("sharded run: the caller's allgather_host failed"); return PLASSHIP_ERR_DEVICE; }
     return PLASSHIP_OK;
 }
@@ -105,6 +106,7 @@ int commAlltoallvRecords(plasship_ctx *ctx, const void *dSend, const uint64_t *s
     rc = commAgreeOk(ctx, recv.alloc(std::max<uint64_t>(tot + slackRecords, 1) * recordBytes) == hipSuccess, "sharded run: out of device memory for the receive buffer");
     if (rc) return rc;
     if (!cm->stream_ordered) PH_CHECK(plasship::streamSync(ctx->stream));
+    watchCollective("all-to-all(v) of device records");
     if (cm->alltoallv_dev(cm->user, dSend, sendBytes.data(), recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's alltoallv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     *recvTotal = tot;
     if (allTotal) { uint64_t a = 0; for (uint64_t c : all) a += c; *allTotal = a; }
@@ -129,6 +131,7 @@ int commAllgathervBytesKnown(plasship_ctx *ctx, const void *dSend, uint64_t send
     const int rcA = commAgreeOk(ctx, recv.alloc(tot + 64) == hipSuccess, "sharded run: out of device memory for the gather buffer");
     if (rcA) return rcA;
     if (!cm->stream_ordered) PH_CHECK(plasship::streamSync(ctx->stream));
+    watchCollective("all-gather(v) of device bytes");
     if (cm->allgatherv_dev(cm->user, dSend, sendBytes, recv.p, recvBytes.data()) != 0) { setError("sharded run: the caller's allgatherv_dev failed"); return PLASSHIP_ERR_DEVICE; }
     return PLASSHIP_OK;
 }

@@ -6,7 +6,9 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
 
 namespace {
 using namespace plasship;
@@ -151,8 +153,35 @@ extern "C" int plasship_rccl_comm_create(plasship_ctx *ctx, int rank, int world,
     std::unique_ptr<plasship_rccl_comm> c(new plasship_rccl_comm());
     c->ctx = ctx; c->rank = rank; c->world = world;
     UniqueId uid; memcpy(&uid, id, PLASSHIP_RCCL_ID_BYTES);
-    const int e = r.CommInitRank(&c->comm, world, uid, rank);
-    if (e != 0) { setError(std::string("RCCL: ncclCommInitRank: ") + r.GetErrorString(e)); return PLASSHIP_ERR_DEVICE; }
+    // ncclCommInitRank is a rendezvous of all ranks: on hardware nobody has run this on yet it is the first place a sharded job can wait for
+    // ever (a rank that never arrives, a fabric RCCL cannot bring up).  It runs on a helper thread with a deadline (PLASSHIP_COMM_TIMEOUT_S,
+    // default 300, 0 = none); past it the call fails with the rank in the message and the caller can choose another communicator
+    // (bench.py --comm auto: torch.distributed).  The helper thread is left behind in that case — RCCL offers no way to cancel the call.
+    struct InitBox { std::mutex mu; std::condition_variable cv; bool done = false; int e = 0; Comm comm = nullptr; };
+    auto box = std::make_shared<InitBox>();
+    const int dev = ctx->device;
+    std::thread th([box, &r, world, uid, rank, dev]() {
+        (void) hipSetDevice(dev);
+        Comm cm = nullptr;
+        const int e = r.CommInitRank(&cm, world, uid, rank);
+        std::lock_guard<std::mutex> g(box->mu); box->e = e; box->comm = cm; box->done = true; box->cv.notify_all();
+    });
+    {
+        const char *te = getenv("PLASSHIP_COMM_TIMEOUT_S"); const double limit = te ? atof(te) : 300.0;
+        std::unique_lock<std::mutex> lk(box->mu);
+        const bool ok = limit <= 0.0 ? (box->cv.wait(lk, [&] { return box->done; }), true) : box->cv.wait_for(lk, std::chrono::duration<double>(limit), [&] { return box->done; });
+        if (!ok) {
+            lk.unlock(); th.detach();
+            setError("RCCL: rank " + std::to_string(rank) + " of " + std::to_string(world) + ": ncclCommInitRank did not return within " + std::to_string((int) limit) +
+                     " s (PLASSHIP_COMM_TIMEOUT_S) - not every rank reached the rendezvous, or RCCL cannot bring the links up (NCCL_DEBUG=INFO)");
+            fprintf(stderr, "[plasship] %s\n", plasship_last_error());
+            return PLASSHIP_ERR_PEER;
+        }
+    }
+    th.join();
+    c->comm = box->comm;
+    const int e = box->e;
+    if (e != 0) { setError(std::string("RCCL: rank ") + std::to_string(rank) + ": ncclCommInitRank: " + r.GetErrorString(e)); return PLASSHIP_ERR_DEVICE; }
     plasship_comm pc; memset(&pc, 0, sizeof(pc));
     pc.rank = rank; pc.world = world; pc.user = c.get();
     pc.allgather_host = cbAllgatherHost; pc.alltoallv_dev = cbAlltoallv; pc.allgatherv_dev = cbAllgatherv;

@@ -63,10 +63,17 @@ bool traceOn();
 hipError_t poolMalloc(void **p, size_t n, bool longLived = false);
 // every C-ABI entry that allocates calls this first (PH_ENTER): the stream the calling thread's allocations belong to
 void poolEnter(hipStream_t stream);
+// sharded run (round 6): which rank the calling thread's context is, so that a wait for the stream that never ends — a collective a peer
+// never joined, a link that is down: what the FIRST run on real xGMI links can meet — becomes an error with the rank and the last
+// collective in it instead of a hang (core.hip: streamSync polls with a deadline when a communicator of more than one rank is installed;
+// PLASSHIP_COMM_TIMEOUT_S, default 300, 0 = wait for ever).  watchCollective names what was enqueued last.
+void watchEnter(const plasship_ctx *ctx);
+void watchCollective(const char *what);
 #define PH_ENTER(ctx)                                                                    \
     do {                                                                                 \
         PH_CHECK(hipSetDevice((ctx)->device));                                           \
         plasship::poolEnter((ctx)->stream);                                              \
+        plasship::watchEnter(ctx);                                                       \
     } while (0)
 void poolFree(void *p);
 void poolTrim();

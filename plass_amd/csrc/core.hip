@@ -201,9 +201,43 @@ int tuneInt(const char *name, int dflt) {
 bool traceOn() { static const bool v = getenv("PLASSHIP_TRACE") != nullptr; return v; }
 void setError(const std::string &msg) { g_err = msg; }
 static std::atomic<unsigned long long> g_hostSyncs(0);
-hipError_t streamSync(hipStream_t st) { g_hostSyncs++; return hipStreamSynchronize(st); }
+// ---- a wait that can end (sharded runs): see common.hpp, watchEnter ----
+thread_local int tl_watchRank = -1, tl_watchWorld = 1;
+thread_local const char *tl_watchLast = "none yet";
+thread_local unsigned long long tl_watchCount = 0;
+thread_local std::string tl_watchMsg;
+void watchEnter(const plasship_ctx *ctx) {
+    if (ctx && ctx->hasComm && ctx->comm.world > 1) { tl_watchRank = ctx->comm.rank; tl_watchWorld = ctx->comm.world; }
+    else { tl_watchRank = -1; tl_watchWorld = 1; }
+    tl_watchMsg.clear();
+}
+void watchCollective(const char *what) { tl_watchLast = what; tl_watchCount++; }
+static double commTimeoutSeconds() { static const double v = [] { const char *e = getenv("PLASSHIP_COMM_TIMEOUT_S"); return e ? atof(e) : 300.0; }(); return v; }
+hipError_t streamSync(hipStream_t st) {
+    g_hostSyncs++;
+    const double limit = tl_watchWorld > 1 ? commTimeoutSeconds() : 0.0;
+    if (limit <= 0.0) return hipStreamSynchronize(st);
+    // poll: a few hundred queries back to back (a kernel chain that is nearly through), then short sleeps
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0;; spins++) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+        if (spins < 512) continue;
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > limit) {
+            tl_watchMsg = "sharded run, rank " + std::to_string(tl_watchRank) + " of " + std::to_string(tl_watchWorld) + ": the stream did not drain within " + std::to_string((int) limit) +
+                          " s (PLASSHIP_COMM_TIMEOUT_S); last collective enqueued: " + tl_watchLast + " (#" + std::to_string(tl_watchCount) + " on this thread) - a peer that left the call, "
+                          "or a link that is down (NCCL_DEBUG=INFO shows RCCL's view)";
+            fprintf(stderr, "[plasship] %s\n", tl_watchMsg.c_str());
+            return hipErrorNotReady;
+        }
+        std::this_thread::sleep_for(std::chrono::microseconds(el < 0.01 ? 20 : 200));
+    }
+}
 std::string hipErrStr(hipError_t e, const char *what, const char *file, int line) {
-    return std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
+    const std::string std_ = std::string("HIP error ") + hipGetErrorString(e) + " in " + what + " at " + file + ":" + std::to_string(line);
+    if (!tl_watchMsg.empty()) { const std::string m = tl_watchMsg + " [" + std_ + "]"; tl_watchMsg.clear(); return m; }
+    return std_;
 }
 __global__ void keysDifferKernel(const uint32_t *__restrict__ a, const uint32_t *__restrict__ b, uint32_t n, uint32_t *__restrict__ flag) {
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) if (a[i] != b[i]) *flag = 1u;
@@ -416,6 +450,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         if (!ok) sortedA = false;
     });
     const bool sorted = sortedA;
+    const double tu0 = ioNow();
     if (!sorted) std::stable_sort(perm.begin(), perm.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
     std::unique_ptr<plasship_seqdb> holder(new plasship_seqdb());   // released to the caller on success only
     plasship_seqdb *db = holder.get();
@@ -462,6 +497,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         db->d_len.allocLong((n + 1) * 4) != hipSuccess || db->d_key.allocLong((n + 1) * 4) != hipSuccess) {
         setError("plasship_seqdb_upload: out of device memory"); return PLASSHIP_ERR_DEVICE;
     }
+    const double tu1 = ioNow();
     PH_CHECK(hipMemsetAsync((char *) db->d_data.p + total, 0, 64, ctx->stream));     // the padding only; the entries are copied below
     // entries packed into id order, chunk by chunk, straight into the pinned staging buffers (an entry may straddle two chunks)
     {
@@ -479,6 +515,7 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         });
         if (rc) return rc;
     }
+    const double tu2 = ioNow();
     // file order != key order (a DB several writer threads left behind): remember every entry's rank in the data file
     {
         bool fileSorted = true;
@@ -512,6 +549,8 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
         PH_CHECK(hipMemcpyAsync(bc, dBC.p, 24, hipMemcpyDeviceToHost, ctx->stream));
     }
     PH_CHECK(plasship::streamSync(ctx->stream));
+    if (ioTimingOn()) fprintf(stderr, "[plasship io] seqdb_upload: %zu entries, %.2f GB: host index arrays + device allocation (waits for the arena) %.3f s, packed upload %.3f s, index upload + validation %.3f s\n",
+                              n, (double) total / 1e9, tu1 - tu0, tu2 - tu1, ioNow() - tu2);
     const unsigned long long padZeros = (16 - total % 16) % 16;
     if (bc[0]) { setError("plasship_seqdb_upload: " + std::to_string(bc[0]) + " byte(s) above 'z' (122) in the sequence data: not a sequence DB the kernels' score tables can index"); return PLASSHIP_ERR_ARG; }
     if (bc[2] || bc[1] != (unsigned long long) n + padZeros) {
@@ -525,8 +564,12 @@ extern "C" int plasship_seqdb_upload(plasship_ctx *ctx, const char *data, size_t
 extern "C" int plasship_seqdb_read(plasship_ctx *ctx, const char *db_path, plasship_seqdb **out) {
     if (!ctx || !db_path || !out) { setError("plasship_seqdb_read: bad argument"); return PLASSHIP_ERR_ARG; }
     HostDB h; std::string err;
+    const double t0 = ioNow();
     if (!readDBFiles(db_path, h, err)) { setError(err); return PLASSHIP_ERR_IO; }
-    return plasship_seqdb_upload(ctx, h.data.data(), h.data.size(), h.off.data(), h.elen.data(), h.key.data(), h.key.size(), h.dbtype, out);
+    const double t1 = ioNow();
+    const int rc = plasship_seqdb_upload(ctx, h.data.data(), h.data.size(), h.off.data(), h.elen.data(), h.key.data(), h.key.size(), h.dbtype, out);
+    if (ioTimingOn()) fprintf(stderr, "[plasship io] seqdb_read %s: files %.3f s, index arrays + upload + validation %.3f s\n", db_path, t1 - t0, ioNow() - t1);
+    return rc;
 }
 
 static int ensureHostIndex(plasship_ctx *ctx, plasship_seqdb *db) {
@@ -585,6 +628,7 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
     // the device layout is the file layout (entries "SEQ\n\0" back to back in key order): the data file is the device buffer, streamed
     // through the pinned staging buffers while the previous chunk is being written; the index is formatted on the host threads
     std::string err; DBFileWriter w;
+    const double tw0 = ioNow();
     if (!w.open(db_path, db->dbtype, err)) { setError(err); return PLASSHIP_ERR_IO; }
     std::atomic<bool> packed(true);
     parallelRanges(db->n, [&](int, size_t b, size_t e) {
@@ -594,7 +638,10 @@ extern "C" int plasship_seqdb_write(plasship_ctx *ctx, const plasship_seqdb *cdb
         rc = stagedDownload(ctx, db->dataPtr(), db->dataBytes, [&](const char *src, uint64_t, uint64_t nb) { w.data(src, (size_t) nb); return !w.failed; });
         if (rc == PLASSHIP_ERR_IO) setError(std::string("error while writing ") + db_path);
         if (rc) return rc;
+        const double tw1 = ioNow();
         w.index(db->h_key.data(), db->h_elen.data(), db->n);
+        if (ioTimingOn()) fprintf(stderr, "[plasship io] seqdb_write %s: data %.2f GB in %.3f s (%.2f GB/s), index of %zu entries %.3f s\n", db_path, (double) db->dataBytes / 1e9, tw1 - tw0,
+                                  (double) db->dataBytes / 1e9 / std::max(tw1 - tw0, 1e-9), db->n, ioNow() - tw1);
     } else {                                                  // a DB with gaps between its entries (none of the producers here makes one)
         HostBytes data;
         if (!data.alloc(db->dataBytes)) { setError("plasship_seqdb_write: out of host memory"); return PLASSHIP_ERR_IO; }

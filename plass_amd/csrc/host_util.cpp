@@ -1,5 +1,6 @@
 // Host-side helpers of the product (see host_util.hpp).  Product code: independent of oracle/.
 #include "host_util.hpp"
+#include <chrono>
 #include "tables_data.h"
 #include <algorithm>
 #include <cmath>
@@ -74,8 +75,12 @@ static bool readInto(const std::string &p, char *dst, uint64_t n) {
 
 // DB layout: NAME or NAME.0..NAME.k data (offsets global over the concatenation, FileUtil.cpp:336-352),
 // NAME.index "key\toffset\tlength\n", NAME.dbtype int32 LE (bit 31 = compressed, unsupported here).
+// PLASSHIP_IO_TIMING=1: the phases of reading / writing a DB on stderr (tools/chain_wall_probe.py)
+bool ioTimingOn() { static const bool v = getenv("PLASSHIP_IO_TIMING") != nullptr; return v; }
+double ioNow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 bool readDBFiles(const std::string &path, HostDB &db, std::string &err) {
     db = HostDB();
+    const double tio0 = ioNow();
     std::string t;
     if (!readSmallFile(path + ".dbtype", t) || t.size() < 4) { err = "cannot read " + path + ".dbtype"; return false; }
     uint32_t ty; memcpy(&ty, t.data(), 4);
@@ -93,8 +98,10 @@ bool readDBFiles(const std::string &path, HostDB &db, std::string &err) {
     }
     if (!db.data.alloc((size_t) total)) { err = "out of host memory reading " + path; return false; }
     { uint64_t o = 0; for (auto &f : files) { if (!readInto(f.first, db.data.data() + o, f.second)) { err = "cannot read " + f.first; return false; } o += f.second; } }
+    const double tio1 = ioNow();
     uint64_t idxBytes = 0; HostBytes idx;
     if (!fileSize(path + ".index", idxBytes) || !idx.alloc((size_t) idxBytes) || !readInto(path + ".index", idx.data(), idxBytes)) { err = "cannot read " + path + ".index"; return false; }
+    const double tio2 = ioNow();
     // parse on all threads: a range of bytes handles the lines that START in it
     const char *base = idx.data(); const size_t nb = idx.size();
     const int maxT = hostThreads();
@@ -129,6 +136,8 @@ bool readDBFiles(const std::string &path, HostDB &db, std::string &err) {
             if (!pt.key.empty()) { memcpy(&db.key[at[t]], pt.key.data(), pt.key.size() * 4); memcpy(&db.off[at[t]], pt.off.data(), pt.off.size() * 8); memcpy(&db.elen[at[t]], pt.elen.data(), pt.elen.size() * 4); }
         }
     }, nullptr, 1);
+    if (ioTimingOn()) fprintf(stderr, "[plasship io] read %s: data %.2f GB in %.3f s (%.2f GB/s), index %.2f GB in %.3f s, parse %zu lines %.3f s (%d host threads)\n", path.c_str(),
+                              (double) total / 1e9, tio1 - tio0, (double) total / 1e9 / std::max(tio1 - tio0, 1e-9), (double) idxBytes / 1e9, tio2 - tio1, lines, ioNow() - tio2, maxT);
     return true;
 }
 

@@ -41,6 +41,8 @@ struct HostDB {
 // NAME or NAME.0 .. NAME.k (the unmerged per-thread files of the reference's DBWriter; offsets run over their concatenation),
 // NAME.index, NAME.dbtype.  The data is read with pread() on all host threads, the index is parsed on all host threads.
 bool readDBFiles(const std::string &path, HostDB &db, std::string &err);
+bool ioTimingOn();      // PLASSHIP_IO_TIMING=1: phase timings of the host boundary on stderr
+double ioNow();
 
 // Writer of NAME, NAME.index, NAME.dbtype.  Everything goes to "<file>.tmp.<pid>" first; close() checks every write and renames
 // the three files into place, so a reader never sees a half-written DB and a failed write never leaves one behind under NAME.

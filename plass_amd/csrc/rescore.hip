@@ -222,8 +222,11 @@ __device__ __forceinline__ DiagScore scoreDiagonal(const char *__restrict__ q, u
     return r;
 }
 
-template <int G, int WPE>
+// MODE (round 6): RescoreArgs::mode as a compile-time constant — the launch over a candidate list (0) does not carry the registers of the
+// stub-finishing paths (1, 2) through its loop
+template <int G, int WPE, int MODE = -1>
 __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void rescoreKernel(RescoreArgs a) {
+    const int mode = MODE >= 0 ? MODE : a.mode;
     __shared__ signed char smat[123 * 128];              // row stride 128: the index of a column is (a << 7) | b
     __shared__ unsigned char sComp[256];                 // reverse-strand hits: complement of a stored letter (getRevFragment's mapping)
     for (int i = threadIdx.x; i < 123 * 128; i += RS_BLOCK) smat[i] = (i & 127) < 123 ? a.mat[(i >> 7) * 123 + (i & 127)] : (signed char) 0;
@@ -235,8 +238,8 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
     const int sl = threadIdx.x & (G - 1);
     const uint64_t stride = (uint64_t) gridDim.x * groupsPerBlock;
     unsigned long long accLocal = 0, ovLocal = 0;
-    const uint64_t nWork = (G == 1) ? (a.mode == 2 ? (uint64_t) a.nQueryList : a.nHits) : (uint64_t) *a.longCount;
-    const bool finish = a.mode != 0;                     // (wave-uniform)
+    const uint64_t nWork = (G == 1) ? (mode == 2 ? (uint64_t) a.nQueryList : a.nHits) : (uint64_t) *a.longCount;
+    const bool finish = mode != 0;                     // (wave-uniform)
     // G == 1: the candidate of the next round and its sequences' offsets / lengths are requested while the current pair is scored
     // (a pair is a chain of dependent round trips: candidate -> offsets and lengths -> residues; two of them leave the chain)
     struct Meta { uint64_t qOff, tOff; uint32_t qLen, tLen; };
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(RS_BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, W
     for (; w < nWork; w += stride) {
         uint64_t h = (G == 1) ? w : a.longList[w];
         CandHit hit; Meta me;
-        if (G == 1 && a.mode == 2) {                          // the stub among the record slots of query queryList[w]
+        if (G == 1 && mode == 2) {                          // the stub among the record slots of query queryList[w]
             const uint32_t qq = a.queryList[w];
             uint64_t j = a.qoff[qq]; const uint64_t j1 = a.qoff[qq + 1];
             while (j < j1 && a.out[j].btKind != ALN_SELF_PENDING) j++;
@@ -532,11 +535,12 @@ extern "C" int plasship_rescore(plasship_ctx *ctx, const plasship_seqdb *qdb, co
     // wavefronts per SIMD of the thread-per-pair kernel (registers against chains in flight).  Round 5: 4 — with the stub and finishing paths
     // the kernel spills 88 bytes per lane at 5 (96 VGPRs) and nothing at 4 (125): 35.5 -> 31.2 ms per iteration at 50 M reads; 3: 33.2, 6: 43.9
     // (profiles/r05_ab_knobs.txt, calls 12-13)
-    static const int wpe = [] { const int v = tuneInt("RESCORE_WPE", 4); if (v != 4 && v != 5) fprintf(stderr, "[plasship] PLASSHIP_TUNE_RESCORE_WPE=%d: only 4 and 5 are built, using 4\n", v); return v; }();
+    static const int wpe = [] { const int v = tuneInt("RESCORE_WPE", 4); if (v < 4 || v > 6) fprintf(stderr, "[plasship] PLASSHIP_TUNE_RESCORE_WPE=%d: only 4, 5 and 6 are built, using 4\n", v); return v; }();
     // (16 or 8 lanes per pair for EVERY pair, and a second thread-per-pair pass for the overlaps of 128-512 columns, were both
     // slower — 76 / 53 ms and 83 ms against 45 ms per iteration at 50 M reads: profiles/r03_ab_knobs.txt)
-    if (wpe == 5) hipLaunchKernelGGL((rescoreKernel<1, 5>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((rescoreKernel<1, 4>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    if (wpe == 5) hipLaunchKernelGGL((rescoreKernel<1, 5, 0>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    else if (wpe == 6) hipLaunchKernelGGL((rescoreKernel<1, 6, 0>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((rescoreKernel<1, 4, 0>), dim3(grid), dim3(RS_BLOCK), 0, ctx->stream, a);
     hipLaunchKernelGGL((rescoreKernel<16, 6>), dim3((unsigned) ctx->numCU * 8), dim3(RS_BLOCK), 0, ctx->stream, a);     // long overlaps (count read on the device)
     PH_CHECK(hipEventRecord(ctx->ev[1], ctx->stream));
     // the list stays SPARSE (common.hpp: plasship_alns): record h belongs to candidate pair h, the CSR is the candidate list's

@@ -11,7 +11,7 @@ db, wl = bench.build_workload(ctx, "c3", pairs)
 td = tempfile.mkdtemp(prefix="plass_wall_probe_")
 db.write(os.path.join(td, "frag")); db.free(); ctx.close()
 for extra in ({}, {}):
-    env = dict(g.child_env()); env["PLASSHIP_POOL_STATS"] = "1"; env.update(extra)
+    env = dict(g.child_env()); env["PLASSHIP_POOL_STATS"] = "1"; env["PLASSHIP_IO_TIMING"] = "1"; env.update(extra)
     t0 = time.perf_counter()
     p = subprocess.run([os.path.join(ROOT, "plass_amd", "plass-hip"), "assemble-chain", os.path.join(td, "frag"), os.path.join(td, "out"), "--num-iterations", "12"],
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
