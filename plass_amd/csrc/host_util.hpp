@@ -1,6 +1,7 @@
 // Host-side helpers of the product: DB files, text formats, E-value arithmetic.
 // Format contracts: SURVEY.md §8b; text formats QueryMatcher.h:114-126, Matcher.cpp:323-370.
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -50,7 +51,7 @@ double ioNow();
 //               all host threads
 //   small DBs:  add(key, bytes) per entry
 struct DBFileWriter {
-    FILE *fd = nullptr, *fi = nullptr; std::string path, tmpSuffix; uint64_t off = 0, dataPos = 0; int dbtype = 0; bool failed = false, open_ = false;
+    FILE *fd = nullptr, *fi = nullptr; std::string path, tmpSuffix; uint64_t off = 0, dataPos = 0; int dbtype = 0; std::atomic<bool> failed{false}; bool open_ = false;   // failed: data() and index() may run on two threads (plasship_seqdb_write)
     std::string ibuf;
     DBFileWriter() {}
     DBFileWriter(const DBFileWriter &) = delete; DBFileWriter &operator=(const DBFileWriter &) = delete;

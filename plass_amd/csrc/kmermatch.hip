@@ -516,7 +516,6 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
     ga.nBuckets = nBuckets; ga.bucketsPerBlock = bpb; ga.outCount = dOutCnt.as<uint64_t>();
     PH_CHECK(hipMemsetAsync(dMaxRT.p, 0, 8, st));
     ga.maxRepTarget = dMaxRT.as<unsigned long long>();
-    ga.doubleHash = tuneInt("GROUP_PROBE", 1) == 2 ? 1u : 0u;      // PLASSHIP_TUNE_GROUP_PROBE=2: double hashing in the group kernel's table (A/B, round 6)
     ga.includeOnlyExtendable = par->include_only_extendable; ga.covMode = par->cov_mode; ga.covThr = par->cov_thr; ga.minKey = NUCL ? dMinKey.as<unsigned long long>() : nullptr;
     // positions per bucket (sentinel padding included) decide the workgroup shape of the 16-byte-record kernel
     const uint64_t avgPos = finalCap * RPL / std::max<uint32_t>(nBuckets, 1);

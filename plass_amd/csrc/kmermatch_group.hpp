@@ -20,7 +20,6 @@ struct GroupArgs {
     int includeOnlyExtendable, covMode; float covThr;
     const unsigned long long *minKey;   // NUCL: K of the globally first run
     unsigned long long *maxRepTarget;   // max over emitted records of (rep << 32 | member): the last run of sort #2
-    uint32_t doubleHash;                // groupLinesKernel: probe step from the hash (odd, so every slot is reached) instead of 1 — see there
 };
 
 __device__ __forceinline__ bool canBeCoveredK(float covThr, int covMode, float q, float t) {   // Util.cpp:533-550
@@ -250,9 +249,8 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
             if (!isSentinel(r) && !(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
                 uint32_t slot = (uint32_t) (hh >> 32) & (HT - 1);
-                // (round 6) double hashing: with a step of 1 the 2 000-3 000 distinct k-mers of a 50 M-read bucket cluster in the 4 096 slots and a
-                // wavefront probes until its unluckiest lane has found a free one; an odd step taken from other bits of the hash breaks the clusters
-                const uint32_t step = a.doubleHash ? (((uint32_t) (hh >> 17) | 1u) & (HT - 1)) : 1u;
+                // (round 6: double hashing — an odd step from other bits of the hash instead of 1 — changed nothing, 38.7 -> 38.3 ms at 50 M reads: the
+                //  table is loaded to a third, probing is not where the time is; profiles/r06_ab_knobs.txt, call 3)
                 full = true;
                 for (uint32_t probe = 0; probe < HT; probe++) {
                     const unsigned long long prev = atomicCAS(&hKey[slot], ~0ULL, K);
@@ -265,7 +263,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                         full = false;
                         break;
                     }
-                    slot = (slot + step) & (HT - 1);
+                    slot = (slot + 1) & (HT - 1);
                 }
             }
             const unsigned long long cm = __ballot(claimed);
@@ -280,8 +278,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
                 const uint64_t hh = K * 0xD6E8FEB86659FD93ULL;
                 if (!(nSub > 1 && (uint32_t) ((hh >> 40) % nSub) != sub)) {
                     uint32_t slot = (uint32_t) (hh >> 32) & (HT - 1);
-                    const uint32_t step = a.doubleHash ? (((uint32_t) (hh >> 17) | 1u) & (HT - 1)) : 1u;
-                    while (hKey[slot] != K) slot = (slot + step) & (HT - 1);
+                    while (hKey[slot] != K) slot = (slot + 1) & (HT - 1);
                     if ((hMulti[slot >> 5] >> (slot & 31)) & 1u) {
                         const unsigned long long best = hBest[slot];
                         const uint32_t repId = (uint32_t) (best >> 16);
