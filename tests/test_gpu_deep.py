@@ -163,3 +163,39 @@ def test_four_guided_iterations(ctx, gold, tmp_path):
         check_db(aa2, want["aa"], "guidedassembleresults (protein twins), iteration %d" % it)
         nu, aa = nu2, aa2
     nu.free(); aa.free()
+
+
+def test_circular_replicons_chop_cycle_at_depth(ctx, tmp_path):
+    """VERDICT r5 item 5c / missing #4: `cyclecheck --chop-cycle 1` firing at DEPTH on the GPU path — small circular replicons whose contigs close
+    in iterations 3-6 (503 circular contigs in all) — every DB of seven nucleotide iterations against tests/golden/circular_chain.json (oracle-made,
+    every module output compared with the unmodified reference's: profiles/r06_circular_chain_pin.txt)."""
+    import json
+    import sys
+    import plass_amd
+    from test_gpu_parity import km_params, nucl_as_params
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from make_circular_chain import write_reads
+    fx = json.load(open(os.path.join(HERE, "golden", "circular_chain.json")))
+    write_reads(str(tmp_path / "reads"))
+    db = ctx.read_seqdb(tmp_path / "reads")
+    check_db(db, fx["reads"], "reads (numpy generator)")
+    total = 0
+    for it, want in enumerate(fx["iterations"]):
+        cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+        cands.write(tmp_path / "pref"); check_file(tmp_path / "pref", want["pref"], "kmermatcher -k 22, iteration %d" % it)
+        alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
+        cands.free()
+        alns.write(tmp_path / "aln"); check_file(tmp_path / "aln", want["aln"], "rescorediagonal, iteration %d" % it)
+        out, _ = ctx.assembleresults(db, alns, nucl_as_params())
+        alns.free(); db.free()
+        check_db(out, want["assembly"], "nuclassembleresults, iteration %d" % it)
+        cyc, rest, cst = ctx.cyclecheck(out, max_seq_len=200000, chop_cycle=True, with_rest=True)
+        assert cst.n_cyclic == want["n_cyclic"]
+        total += cst.n_cyclic
+        check_db(cyc, want["cycle"], "cyclecheck --chop-cycle 1, iteration %d" % it)
+        check_db(rest, want["rest"], "non-circular rest, iteration %d" % it)
+        cyc.free(); out.free()
+        db = rest
+    db.free()
+    assert total > 400
+

@@ -293,3 +293,32 @@ def test_oracle_strand_ties_are_a_reference_outcome(oracle_bin, tmp_path):
             assert ent[int(k)].decode("latin-1") == t["oracle"]
         src = chain_step(oracle_bin, T, src, P, it, 4)
 
+
+def test_oracle_circular_chain(oracle_bin, tmp_path):
+    """`cyclecheck --chop-cycle 1` AT DEPTH.  A community with small circular replicons (tests/golden/make_circular_chain.py:
+    numpy reads that wrap around the origin, seed in the fixture); contigs grow around the replicons until their ends overlap and cyclecheck takes
+    them out in iterations 3-6 (9 / 94 / 167 / 233 contigs).  Every DB of the seven iterations equals tests/golden/circular_chain.json, whose
+    every module output was compared with the unmodified reference's on the same inputs (28 of 28: profiles/r06_circular_chain_pin.txt)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_circular_chain import write_reads
+    from make_large_nucl import db_sums, rest_db
+    import conftest as T
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "circular_chain.json")))
+    assert "unmodified reference" in fx["made_by"] and sum(r["n_cyclic"] for r in fx["iterations"][3:]) > 100
+    P = lambda n: str(tmp_path / n)
+    write_reads(P("reads"))
+    assert db_sums(P("reads")) == fx["reads"]
+    src = P("reads")
+    km = T.NUCL_KM + ["--max-seq-len", "200000"]
+    for it, want in enumerate(fx["iterations"]):
+        run_oracle(oracle_bin, ["kmermatcher", src, P("pref")] + km + ["--threads", "4"])
+        run_oracle(oracle_bin, ["rescorediagonal", src, src, P("pref"), P("aln")] + T.NUCL_RS + ["--threads", "4"])
+        run_oracle(oracle_bin, ["nuclassembleresults", src, P("aln"), P("assembly_%d" % it)] + T.NUCL_AS + ["--threads", "4"])
+        run_oracle(oracle_bin, ["cyclecheck", P("assembly_%d" % it), P("cycle_%d" % it), "--max-seq-len", "200000", "--chop-cycle", "1"])
+        assert rest_db(P("assembly_%d" % it), P("cycle_%d" % it), P("rest_%d" % it)) == want["n_cyclic"]
+        for name, path in (("pref", P("pref")), ("aln", P("aln")), ("assembly", P("assembly_%d" % it)), ("cycle", P("cycle_%d" % it)), ("rest", P("rest_%d" % it))):
+            assert db_sums(path) == want[name], "iteration %d: %s" % (it, name)
+        src = P("rest_%d" % it)
+
