@@ -1894,7 +1894,8 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     //  tiers already group the queries by queue size, and id order keeps a wavefront's alignment records adjacent; profiles/r04_ab_knobs.txt)
     // wavefronts per SIMD of the register-queue kernels (PLASSHIP_TUNE_ASM16 / ASM64): the grid is what the CUs hold at once
     const int w16 = tuneInt("ASM16", 5), w64 = tuneInt("ASM64", 4);      // round 3 (after the copy tails went word-wise): 16.6 ms at 5 wavefronts, 17.0 at 6, 18.0 at 4
-    const dim3 g16(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) w16)), g64(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) w64));
+    const uint32_t gx = (uint32_t) std::max(1, tuneInt("ASM_GRIDX", 1));      // grid = gx x what the CUs hold at once (round 6 A/B: finer shares against the tail)
+    const dim3 g16(std::min<uint32_t>((a.nSmall + 15) / 16, (uint32_t) ctx->numCU * (uint32_t) w16 * gx)), g64(std::min<uint32_t>((a.nMid + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) w64 * gx));
     // (round 5: the four tiers — disjoint queries — launched side by side on four streams, so that one tier's tail of long queues lies under
     //  the next tier: 88.8 against 82.7 ms for the stage; the tiers' wavefronts evict each other's lines.  profiles/r05_ab_knobs.txt)
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
@@ -1905,7 +1906,7 @@ static int assembleImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plass
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    if (a.nMid32) hipLaunchKernelGGL((assembleGroupKernel<32, 5>), dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * 5u)), dim3(256), 0, st, a);      // (4 wavefronts per SIMD: 28.3 against 28.0 ms)
+    if (a.nMid32) hipLaunchKernelGGL((assembleGroupKernel<32, 5>), dim3(std::min<uint32_t>((a.nMid32 + 7) / 8, (uint32_t) ctx->numCU * 5u * gx)), dim3(256), 0, st, a);      // (4 wavefronts per SIMD: 28.3 against 28.0 ms)
     if (a.nMid) {
         if (w64 == 5) hipLaunchKernelGGL((assembleGroupKernel<64, 5>), g64, dim3(256), 0, st, a);
         else if (w64 == 4) hipLaunchKernelGGL((assembleGroupKernel<64, 4>), g64, dim3(256), 0, st, a);

@@ -961,7 +961,11 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
-    static const int waveBlocksPerCU = [] { const char *e = getenv("PLASSHIP_EXTRACT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 32; }();     // 32 one-wavefront workgroups per CU: measured best of 12..64 on the 1 M-read set
+    // one-wavefront workgroups per CU of the register tiers' grids.  32 was measured best of 12..64 on the 1 M-read set; on the 50 M-read chain
+    // (round 6, profiles/r06_ab_knobs.txt call 7) a CU holds 20 / 16 of them at once and a grid of 32 leaves a second, 60 %-filled round: 40: 57.5 ms
+    // for the wave tiers per iteration, 64: 55.8, 96: 54.5, 128: 54.1, 192: 53.7, 256: 53.7, 512: 54.7 against 58.1 at 32 -> 192 for large sets
+    static const int waveBlocksEnv = [] { const char *e = getenv("PLASSHIP_EXTRACT_BLOCKS_PER_CU"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int waveBlocksPerCU = waveBlocksEnv ? waveBlocksEnv : (nMine > 5000000u ? 192 : 32);
     // launch chain, each tier queueing what it cannot hold for the next: (1) register front end, up to 1024 windows (every read,
     // most contigs); (2) the same with 48 scores per lane, up to 3072 windows (proteins longer than that are rare) and, for
     // nucleotides, up to 1024 candidates; (3) three-pass path with codes and scores of up to 8160 residues resident in LDS;
@@ -992,12 +996,12 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         //  scaling: 512 candidates instead of 1 024 halve its LDS and let eight instead of four wavefronts work per CU; a candidate set
         //  that does not fit is queued for the next tier like any other overflow)
         constexpr int CAP48 = NUCL ? 512 : 128;
-        if (NUCL && tuneInt("NUCL_CAP48", 1) == 1) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP48, false, 48, 992, NUCL ? 2 : 0>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * 8u)), dim3(64), 0, st, e2);
-        else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 4u : 16u))), dim3(64), 0, st, e2);
+        if (NUCL && tuneInt("NUCL_CAP48", 1) == 1) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP48, false, 48, 992, NUCL ? 2 : 0>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("TIER2", 8))), dim3(64), 0, st, e2);
+        else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 48, 992>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("TIER2", NUCL ? 4 : 16))), dim3(64), 0, st, e2);
         PH_CHECK(hipMemsetAsync(dOvCnt.p, 0, 4, st));            // tier 2 has consumed the first queue: it becomes tier 3's output queue
         ExtractArgs e3 = ea; e3.waveList = dOv2Ids.as<uint32_t>(); e3.waveCount = dOv2Cnt.as<uint32_t>();
         e3.overflowIds = dOvIds.as<uint32_t>(); e3.overflowCount = dOvCnt.as<uint32_t>();
-        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (NUCL ? 2u : 5u))), dim3(64), 0, st, e3);
+        hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP2, false, 0, 8160>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("TIER3", NUCL ? 2 : 5))), dim3(64), 0, st, e3);
     }
     // what the last stage could not hold either (candidate sets beyond LDS)
     DevBuf &dLastIds = *lastIds, &dLastCnt = *lastCnt;
