@@ -1404,6 +1404,14 @@ __global__ __launch_bounds__(256) void appendOutKernel(SeqView s, const uint32_t
     }
 }
 
+// origin of every entry of an output DB in the anchor DB of kmermatcher's position cache (plasship_seqdb::d_origin; round 6): a carried-over
+// entry keeps the id its source had there (the source's own id when the source IS the anchor), a rewritten entry has none
+__global__ __launch_bounds__(256) void originOutKernel(uint32_t n, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ keep, const uint64_t *__restrict__ keepPos,
+                                                       const uint32_t *__restrict__ srcOrigin, uint32_t *__restrict__ outOrigin) {
+    for (uint32_t id = blockIdx.x * 256 + threadIdx.x; id < n; id += gridDim.x * 256)
+        if (keep[id]) outOrigin[keepPos[id]] = (flags[id] & 0x20u) ? 0xFFFFFFFFu : (srcOrigin ? srcOrigin[id] : id);
+}
+
 template <int G, int U>
 __global__ __launch_bounds__(256) void writeOutKernel(SeqView s, const uint32_t *__restrict__ flags, const uint32_t *__restrict__ newLen,
                                                       const uint64_t *__restrict__ newStart, const char *__restrict__ arena,
@@ -1592,6 +1600,17 @@ static int buildOutputDBImpl(plasship_ctx *ctx, const plasship_seqdb *db, const 
         if (o->d_changed.allocLong((size_t) outN) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         o->ancestorGen = db->gen;
         if (outN == N) o->parentGen = db->gen;
+    }
+    // ... and, when `db` is the anchor of kmermatcher's position cache or descends from it, the id every carried-over entry had in the anchor
+    if (outN && mode == 0 && ctx->kmPosCache.valid && ctx->kmPosCache.gen != 0) {
+        const uint64_t anchor = ctx->kmPosCache.gen;
+        const bool isAnchor = db->gen == anchor, descends = !isAnchor && db->originGen == anchor && db->d_origin.p != nullptr;
+        if (isAnchor || descends) {
+            if (o->d_origin.allocLong((size_t) outN * 4) != hipSuccess) { setError("plasship_assemble: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            o->originGen = anchor;
+            hipLaunchKernelGGL(originOutKernel, dim3(std::min<uint32_t>((N + 255) / 256, 4096)), dim3(256), 0, st, N, dFlags, (const uint32_t *) dKeep.as<uint32_t>(), (const uint64_t *) dKeepPos.as<uint64_t>(),
+                               descends ? (const uint32_t *) db->d_origin.as<uint32_t>() : (const uint32_t *) nullptr, o->d_origin.as<uint32_t>());
+        }
     }
     // room in the shared heap?  (the reservation is atomic: two DBs derived from one parent get disjoint ranges)
     bool append = false; uint64_t heapBase = 0;

@@ -154,6 +154,15 @@ struct plasship_ctx {
         plasship::DevBuf lines; uint64_t n = 0, gen = 0; bool valid = false, seenEligible = false;      // seenEligible: an earlier call on this context could have used lines (they are allocated from the second such call on, or for a derived DB)
         int k = 0, alph = 0, kps = 0, ignoreMulti = 0, hashShift = 0;
     } kmCache;
+    // kmermatcher's position cache of nucleotide runs (kmermatch_extract.hpp section 2d): per record slot of the LAST nucleotide
+    // plasship_kmermatch call on this context the window position it selected (the identity slot: the count), that call's slot offsets
+    // and identity hashes.  `gen` (that call's DB) is the ANCHOR: every DB buildOutputDB derives from it, directly or through other derived
+    // DBs, carries per entry the id it had in the anchor (plasship_seqdb::d_origin) — entries may be dropped on the way.
+    struct KmPosCache {
+        plasship::DevBuf pos, slotOff, idHash; uint64_t n = 0, gen = 0; bool valid = false, seen = false, lng = false;
+        int k = 0, kps = 0, ignoreMulti = 0, hashShift = 0; float scale = 0;
+    } kmPosCache;
+    uint64_t kmermatchCalls = 0;       // plasship_kmermatch calls this context has seen (a second call suggests a chain: the caches are written from then on)
     // cyclecheck.hip: generation of the last "rest" DB plasship_cyclecheck made on this context (every entry of it is known not to be
     // circular at that --max-seq-len); a later call on a DB that descends from it checks only the entries rewritten since
     uint64_t cycKnownGen = 0, cycKnownMaxLen = 0;
@@ -176,6 +185,10 @@ struct plasship_seqdb {
     // entry with d_changed == 0 is byte for byte an entry of the DB with that generation, under whatever id (cyclecheck.hip).
     uint64_t gen = plasship::newDbGeneration(), parentGen = 0, ancestorGen = 0;
     plasship::DevBuf d_changed;
+    // `originGen` != 0: d_origin[i] = the id entry i had in the DB of that generation (the anchor of kmermatcher's position cache,
+    // plasship_ctx::kmPosCache), 0xFFFFFFFF if its bytes are not an entry of that DB; survives dropped entries and chains of derivations
+    uint64_t originGen = 0;
+    plasship::DevBuf d_origin;
     size_t n = 0;
     uint64_t dataBytes = 0, residues = 0;
     uint32_t maxEntryLen = 0;

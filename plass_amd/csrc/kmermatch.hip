@@ -907,7 +907,27 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             PH_CHECK(hipMemsetAsync(dCachedCount.p, 0, 4, st));
         }
     } else kc.lines.release();
-    PH_CHECK(hipMemcpyAsync(dKStats.as<unsigned long long>() + 4, &cacheLinesPtr, 8, hipMemcpyHostToDevice, st));
+    // ---- position cache of nucleotide runs (kmermatch_extract.hpp section 2d) ----
+    typedef typename std::conditional<LONG, uint32_t, unsigned short>::type PosT;
+    plasship_ctx::KmPosCache &pc = ctx->kmPosCache;
+    const bool posEligible = NUCL && !cm && N && tier0 && tuneInt("CLASSIFY", 1) == 1 && tuneInt("KMCACHE", 1) == 1;      // PLASSHIP_TUNE_KMCACHE=2 switches it off
+    const bool posReuse = posEligible && pc.valid && pc.gen != 0 && db->originGen == pc.gen && db->d_origin.p && pc.lng == LONG && pc.k == k && pc.kps == par->kmers_per_seq &&
+                          pc.scale == par->kmers_per_seq_scale && pc.ignoreMulti == par->ignore_multi_kmer && pc.hashShift == par->hash_shift;
+    // (like the lines of section 2c, the positions are only written when a later call can use them: a derived DB, or a context that has run kmermatcher before)
+    const bool posWanted = posEligible && (posReuse || db->parentGen != 0 || db->ancestorGen != 0 || db->originGen != 0 || pc.seen || ctx->kmermatchCalls > 0 || tuneInt("KMCACHE_EAGER", 0) == 1);
+    if (posEligible) pc.seen = true;
+    ctx->kmermatchCalls++;
+    DevBuf dPosNew, dIdHashNew;
+    unsigned long long cachePtrs[3] = {cacheLinesPtr, 0, 0};
+    if (posWanted) {
+        if (dPosNew.allocLong((size_t) (total + 1) * sizeof(PosT)) != hipSuccess || dIdHashNew.allocLong(((size_t) N + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory for the position cache"); return PLASSHIP_ERR_DEVICE; }
+        cachePtrs[1] = (unsigned long long) (uintptr_t) dPosNew.p; cachePtrs[2] = (unsigned long long) (uintptr_t) dIdHashNew.p;
+        if (posReuse) {
+            if (dCachedList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCachedCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
+            PH_CHECK(hipMemsetAsync(dCachedCount.p, 0, 4, st));
+        }
+    }
+    PH_CHECK(hipMemcpyAsync(dKStats.as<unsigned long long>() + 4, cachePtrs, 24, hipMemcpyHostToDevice, st));      // (cachePtrs lives until the function's last wait)
     PH_CHECK(hipEventRecord(ctx->ev[2], st));
     bool twoLists = false;
     if (!NUCL && k <= 16 && nMine) {
@@ -955,9 +975,19 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     }
     else if (nMine && tier0 && tuneInt("CLASSIFY", 1) == 1) {                   // PLASSHIP_TUNE_CLASSIFY=2: the 16-scores tier takes every id itself
         hipLaunchKernelGGL(classifyWindowsKernel, dim3(std::min<uint32_t>((nMine + 2047) / 2048, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, (const uint32_t *) db->d_len.as<uint32_t>(), sLo, sHi, (uint32_t) k,
-                           TIER0_WINDOWS, 64u * 16u, dWaveList.as<uint32_t>(), dWaveCount.as<uint32_t>(), dLongList.as<uint32_t>(), dLongCount.as<uint32_t>(), dOvIds.as<uint32_t>(), dOvCnt.as<uint32_t>());
+                           TIER0_WINDOWS, 64u * 16u, dWaveList.as<uint32_t>(), dWaveCount.as<uint32_t>(), dLongList.as<uint32_t>(), dLongCount.as<uint32_t>(), dOvIds.as<uint32_t>(), dOvCnt.as<uint32_t>(),
+                           posReuse ? (const uint32_t *) db->d_origin.as<uint32_t>() : (const uint32_t *) nullptr, dCachedList.as<uint32_t>(), dCachedCount.as<uint32_t>());
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();
         twoLists = true;
+        if constexpr (NUCL) {
+            if (posReuse) {      // entries the position cache describes: their records rebuilt from the cached window positions
+                CachedPosArgs<LONG> ca; memset(&ca, 0, sizeof(ca));
+                ca.s = ea.s; ca.slotOff = ea.slotOff; ca.arr = ea.arr; ca.map = ea.map; ca.posOld = pc.pos.p; ca.slotOffOld = pc.slotOff.as<uint64_t>();
+                ca.idHashOld = pc.idHash.as<unsigned long long>(); ca.origin = db->d_origin.as<uint32_t>(); ca.posNew = dPosNew.p; ca.idHashNew = dIdHashNew.as<unsigned long long>();
+                ca.list = dCachedList.as<uint32_t>(); ca.count = dCachedCount.as<uint32_t>(); ca.k = k; ca.seed = ea.seed; ca.kstats = dKStats.as<unsigned long long>();
+                hipLaunchKernelGGL((extractCachedPosKernel<LONG>), dim3(std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) tuneInt("CACHEDPOS", 32))), dim3(64), 0, st, ca);
+            }
+        }
     }
     PH_CHECK(hipEventRecord(ctx->ev[3], st));
     PH_CHECK(hipEventRecord(ctx->ev[4], st));
@@ -1061,7 +1091,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             stats->ms_extract_short_kernel = ms; stats->ms_extract_wave_kernel = ms2; stats->ms_extract_kernel = ms + ms2;
             stats->ms_part_scatter = lo.msPart; stats->n_part_scatter = lo.nPart;
             unsigned long long ks[4] = {0, 0, 0, 0}; uint32_t nCachedSeqs = 0;
-            if (cacheReuse) PH_CHECK(hipMemcpyAsync(&nCachedSeqs, dCachedCount.p, 4, hipMemcpyDeviceToHost, st));
+            if (cacheReuse || posReuse) PH_CHECK(hipMemcpyAsync(&nCachedSeqs, dCachedCount.p, 4, hipMemcpyDeviceToHost, st));
             PH_COPY_SYNC(st, ks, dKStats.p, 32, hipMemcpyDeviceToHost);
             stats->n_cached_sequences = nCachedSeqs; stats->reserved0 = 0;
             stats->short_residues = ks[0]; stats->short_records = ks[1]; stats->wave_residues = ks[2]; stats->wave_records = ks[3];
@@ -1071,6 +1101,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         }
         if (cacheWanted) {     // the lines now describe THIS DB (the wave kernels rewrote what changed, the rest was kept)
             kc.valid = true; kc.n = N; kc.gen = db->gen; kc.k = k; kc.alph = par->alphabet_size; kc.kps = par->kmers_per_seq; kc.ignoreMulti = par->ignore_multi_kmer; kc.hashShift = par->hash_shift;
+        }
+        if (posWanted) {       // the positions now describe THIS DB: it becomes the anchor the derived DBs' d_origin refers to
+            if (pc.slotOff.allocLong(((size_t) N + 2) * 8) != hipSuccess) { pc.valid = false; setError("kmermatch: out of device memory for the position cache"); return PLASSHIP_ERR_DEVICE; }
+            PH_CHECK(hipMemcpyAsync(pc.slotOff.p, dSlotOff.p, ((size_t) N + 1) * 8, hipMemcpyDeviceToDevice, st));
+            PH_CHECK(plasship::streamSync(st));
+            std::swap(pc.pos.p, dPosNew.p); std::swap(pc.pos.bytes, dPosNew.bytes); std::swap(pc.idHash.p, dIdHashNew.p); std::swap(pc.idHash.bytes, dIdHashNew.bytes);
+            pc.valid = true; pc.n = N; pc.gen = db->gen; pc.lng = LONG; pc.k = k; pc.kps = par->kmers_per_seq; pc.scale = par->kmers_per_seq_scale;
+            pc.ignoreMulti = par->ignore_multi_kmer; pc.hashShift = par->hash_shift;
         }
         *out = holderL.release();
         return PLASSHIP_OK;
@@ -1089,7 +1127,8 @@ extern "C" int plasship_kmermatch(plasship_ctx *ctx, const plasship_seqdb *db, c
     // kmermatcher.cpp:797-802: KmerPosition<short> unless a sequence is too long for it.  (Nucleotide k > 23: the 16-byte grouped
     // record has no room for the k-mer the strand rule needs — embedOrd — so such a run takes the 24-byte layout, whose arithmetic
     // is the same on sequences that short.)
-    const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX) || (nucl && par->kmer_size > 23);
+    // (PLASSHIP_TUNE_FORCE_LONG=1: the 24-byte layout whatever the lengths — the tests run the short chains through the long kernels with it)
+    const bool lng = !(db->maxEntryLen < (uint32_t) SHRT_MAX) || (nucl && par->kmer_size > 23) || tuneInt("FORCE_LONG", 0) == 1;
     int rc = KM_RETRY_EARLY_OVERFLOW_CHECK;
     for (int attempt = 0; attempt < 2 && rc == KM_RETRY_EARLY_OVERFLOW_CHECK; attempt++) {
         const bool early = attempt > 0;

@@ -56,7 +56,8 @@ struct ExtractArgs {
     // One more input travels OUTSIDE this struct — the tuned tiers are at the edge of their register budgets (round 4: a block of code
     // that filled an overflowing sequence's slots with sentinels cost the 4-scores tier 40 bytes of scratch per lane and 8-13 ms per
     // iteration; that fill is a kernel of its own now, fillOverflowSlotsKernel):
-    //   kstats[4] = address of the selected-window cache lines (section 2c; 0 = no cache), fetched per sequence where it is used.
+    //   kstats[4] = address of the selected-window cache lines (section 2c; 0 = no cache), fetched per sequence where it is used;
+    //   kstats[5] / kstats[6] = position cache of nucleotide runs (section 2d; 0 = none): window position per record slot, identity hash per id.
 };
 
 __device__ __forceinline__ bool candLess(const Cand &a, const Cand &b, bool nucl) {
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     __shared__ unsigned long long sValid[RESL / 64 + 2];             // per-tile validity masks
     __shared__ unsigned short sKmcPos[64];                           // positions of the ordered path's selection, for the cache line (section 2c)
     typedef Rec<LONG> R;
+    typedef typename std::conditional<LONG, uint32_t, unsigned short>::type PosT;      // one entry of the position cache (section 2d)
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
     const int k = a.k;
@@ -552,6 +554,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 arr[slot] = r;
             }
             for (uint32_t i = 1 + C + lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[slot + i] = r; }
+            if constexpr (NUCL) {      // position cache (section 2d): window positions of the records just written, their count in the identity record's place
+                if (!FALLBACK_NOSTATS(a)) {
+                    PosT *pa = reinterpret_cast<PosT *>(a.kstats[5]);
+                    if (pa) {
+                        for (uint32_t i = lane; i < C; i += 64) { const Cand cd = cand[i]; pa[slot + 1 + i] = (PosT) ((cd.kmer & BIT63) ? cd.pos : (L - cd.pos - (uint32_t) k)); }
+                        if (lane == 0) { pa[slot] = (PosT) C; reinterpret_cast<unsigned long long *>(a.kstats[6])[id] = seqHash; }
+                    }
+                }
+            }
             if (!LONG && !FALLBACK_NOSTATS(a)) {
                 unsigned char *cl = reinterpret_cast<unsigned char *>(a.kstats[4]);
                 if (cl) {
@@ -599,6 +610,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         }
         // ---- selection walk (kmermatcher.cpp:274-347) as prefix counts over the sorted candidates ----
         uint32_t binCarry = 0, selCarry = 0;
+        PosT *posCache = nullptr;                                      // (section 2d)
+        if constexpr (NUCL) { if (!FALLBACK_NOSTATS(a)) posCache = reinterpret_cast<PosT *>(a.kstats[5]); }
         for (uint32_t c0 = 0; c0 < C; c0 += 64) {
             const uint32_t i = c0 + lane;
             Cand cd; cd.kmer = 0; cd.pos = 0; cd.score = 0x80000000u;
@@ -616,10 +629,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
                 if constexpr (LONG) r.pad = 0;
                 arr[slot + 1 + selRank] = r;
                 if (selRank < 64u) sKmcPos[selRank] = (unsigned short) cd.pos;       // (for the selected-window cache line below)
+                if constexpr (NUCL) { if (posCache) posCache[slot + 1 + selRank] = (PosT) ((cd.kmer & BIT63) ? cd.pos : (L - cd.pos - (uint32_t) k)); }
             }
             binCarry += (uint32_t) __popcll(mb); selCarry += (uint32_t) __popcll(ms);
         }
         const uint32_t numSel = (uint32_t) min((size_t) selCarry, considered);
+        if constexpr (NUCL) { if (posCache && lane == 0) { posCache[slot] = (PosT) numSel; reinterpret_cast<unsigned long long *>(a.kstats[6])[id] = seqHash; } }
         if (!LONG && !FALLBACK_NOSTATS(a)) {
             unsigned char *cl = reinterpret_cast<unsigned char *>(a.kstats[4]);
             if (cl) {
@@ -779,13 +794,15 @@ __global__ __launch_bounds__(64) void extractShortKernel(ShortArgs a) {
 
 // Nucleotide DBs (and protein k > 16) have no thread-per-sequence kernel in front of the wave kernels; this one only sorts the ids into the
 // tiers' lists by window count (round 4: until then the 16-scores tier walked every sequence itself, reads of 130 windows included).
+// (round 6, section 2d: `origin` != nullptr — ids whose bytes are those of a sequence the position cache describes go to a fourth list)
 __global__ __launch_bounds__(256) void classifyWindowsKernel(const uint32_t *__restrict__ len, uint32_t idLo, uint32_t idHi, uint32_t k, uint32_t longWindows, uint32_t hugeWindows,
                                                              uint32_t *__restrict__ waveList, uint32_t *__restrict__ waveCount, uint32_t *__restrict__ longList, uint32_t *__restrict__ longCount,
-                                                             uint32_t *__restrict__ hugeList, uint32_t *__restrict__ hugeCount) {
-    __shared__ uint32_t sCnt[3], sBase[3];
+                                                             uint32_t *__restrict__ hugeList, uint32_t *__restrict__ hugeCount,
+                                                             const uint32_t *__restrict__ origin, uint32_t *__restrict__ cachedList, uint32_t *__restrict__ cachedCount) {
+    __shared__ uint32_t sCnt[4], sBase[4];
     constexpr int PER = 8;
     for (uint64_t b0 = (uint64_t) idLo + (uint64_t) blockIdx.x * (256 * PER); b0 < idHi; b0 += (uint64_t) gridDim.x * (256 * PER)) {
-        if (threadIdx.x < 3) sCnt[threadIdx.x] = 0;
+        if (threadIdx.x < 4) sCnt[threadIdx.x] = 0;
         __syncthreads();
         int cls[PER]; uint32_t rank[PER];
 #pragma unroll
@@ -795,15 +812,16 @@ __global__ __launch_bounds__(256) void classifyWindowsKernel(const uint32_t *__r
             if (id < idHi) {
                 const uint32_t L = len[id], nw = L >= k ? L - k + 1 : 0u;
                 cls[j] = nw > hugeWindows ? 2 : (nw > longWindows ? 1 : 0);
+                if (origin && origin[id] != 0xFFFFFFFFu) cls[j] = 3;
                 rank[j] = atomicAdd(&sCnt[cls[j]], 1u);
             }
         }
         __syncthreads();
-        if (threadIdx.x < 3) sBase[threadIdx.x] = sCnt[threadIdx.x] ? atomicAdd(threadIdx.x == 0 ? waveCount : (threadIdx.x == 1 ? longCount : hugeCount), sCnt[threadIdx.x]) : 0u;
+        if (threadIdx.x < 4) sBase[threadIdx.x] = sCnt[threadIdx.x] ? atomicAdd(threadIdx.x == 0 ? waveCount : (threadIdx.x == 1 ? longCount : (threadIdx.x == 2 ? hugeCount : cachedCount)), sCnt[threadIdx.x]) : 0u;
         __syncthreads();
 #pragma unroll
         for (int j = 0; j < PER; j++)
-            if (cls[j] >= 0) (cls[j] == 0 ? waveList : (cls[j] == 1 ? longList : hugeList))[sBase[cls[j]] + rank[j]] = (uint32_t) (b0 + (uint64_t) j * 256 + threadIdx.x);
+            if (cls[j] >= 0) (cls[j] == 0 ? waveList : (cls[j] == 1 ? longList : (cls[j] == 2 ? hugeList : cachedList)))[sBase[cls[j]] + rank[j]] = (uint32_t) (b0 + (uint64_t) j * 256 + threadIdx.x);
         __syncthreads();
     }
 }
@@ -1022,6 +1040,95 @@ __global__ __launch_bounds__(64) void extractCachedKernel(CachedArgs a) {
         if (lane == 63) { R r; r.kmer = xxh64U64(cur.idh, a.seed); r.id = cur.id; r.len = (uint16_t) cur.L; r.pos = 0; arr[cur.slot] = r; }     // identity record (kmermatcher.cpp:241-249)
         for (uint32_t i = 1 + n + (uint32_t) lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[cur.slot + i] = r; }
         stRes += cur.L; stRec += 1 + n;
+    }
+    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
+}
+
+// =====================================================================================================
+// 2d. the position cache of nucleotide runs (round 6).  PenguiN's nucleotide chains never change the hash seed (Nuclassembler.cpp:24,
+//     GuidedNuclassembler.cpp:25: --hash-shift stays what it is), and an iteration rewrites a minority of the sequences, so from the
+//     second call on most sequences are byte for byte what they were when kmermatcher last selected their windows.  The selection is
+//     variable-length there (--kmer-per-seq-scale 0.1: 59 + 0.1 L windows) and nuclassembleresults / cyclecheck DROP entries, so the
+//     128-byte lines of section 2c do not fit; instead the extraction kernels leave, beside the record array, ONE WINDOW POSITION PER
+//     RECORD SLOT (u16, u32 in the long layout; the slot of the identity record holds the count) and the identity hash per id, and the
+//     DBs derived from the DB of that call carry, per entry, the id it had there (plasship_seqdb::d_origin, 0xFFFFFFFF = rewritten —
+//     buildOutputDB, assemble.hip).  The next call with the same selection parameters rebuilds the records of every such entry here:
+//     canonical k-mer and strand from the bytes at the cached positions, nothing hashed, nothing selected.  Same records in the same
+//     slots as the full kernels write (the nucleotide chain tests pass through here from their third call on; PLASSHIP_TUNE_KMCACHE=2
+//     switches it off).
+// =====================================================================================================
+template <bool LONG>
+struct CachedPosArgs {
+    SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map;
+    const void *posOld; const uint64_t *slotOffOld; const unsigned long long *idHashOld; const uint32_t *origin;
+    void *posNew; unsigned long long *idHashNew;
+    const uint32_t *list, *count; int k; uint64_t seed; unsigned long long *kstats;
+};
+template <bool LONG>
+__global__ __launch_bounds__(64) void extractCachedPosKernel(CachedPosArgs<LONG> a) {
+    __shared__ unsigned char sMap[256];
+    typedef Rec<LONG> R;
+    typedef typename std::conditional<LONG, uint32_t, unsigned short>::type PosT;
+    R *arr = reinterpret_cast<R *>(a.arr);
+    const PosT *posOld = reinterpret_cast<const PosT *>(a.posOld);
+    PosT *posNew = reinterpret_cast<PosT *>(a.posNew);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
+    __syncthreads();
+    const int k = a.k;
+    const uint32_t nWork = *a.count;
+    unsigned long long stRes = 0, stRec = 0;
+    // the chain of a sequence: list entry -> origin, index entry, slot range -> old slot range -> count, positions -> bytes -> records.
+    // Metadata of sequence w + grid is in flight while sequence w is written.
+    struct Meta { uint32_t id, L, cnt; uint64_t off, slot, slot1, so; unsigned long long idh; };
+    auto loadMeta = [&](uint32_t id) {
+        Meta m; m.id = id; m.L = a.s.len[id]; m.off = a.s.off[id]; m.slot = a.slotOff[id]; m.slot1 = a.slotOff[id + 1];
+        const uint32_t src = a.origin[id];
+        m.so = a.slotOffOld[src]; m.idh = a.idHashOld[src]; m.cnt = (uint32_t) posOld[m.so];
+        return m;
+    };
+    Meta nxt; nxt.id = 0; nxt.L = 0; nxt.cnt = 0; nxt.off = 0; nxt.slot = 0; nxt.slot1 = 0; nxt.so = 0; nxt.idh = 0;
+    if (blockIdx.x < nWork) nxt = loadMeta(a.list[blockIdx.x]);
+    for (uint32_t w = blockIdx.x; w < nWork; w += gridDim.x) {
+        const Meta cur = nxt;
+        if (w + gridDim.x < nWork) nxt = loadMeta(a.list[w + gridDim.x]);
+        const char *base = a.s.data + cur.off;
+        const uint32_t bound = (uint32_t) (cur.slot1 - cur.slot), L = cur.L;
+        for (uint32_t i = lane; i < cur.cnt; i += 64) {
+            const uint32_t p = (uint32_t) posOld[cur.so + 1 + i];
+            // the k <= 31 letters of the window as codes (0..3, X = 4), eight per word; the entry is "SEQ\n\0" in a padded buffer
+            uint64_t x = 0, f = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (8 * j < k) {
+                    uint64_t raw; __builtin_memcpy(&raw, base + p + 8 * j, 8);
+                    uint64_t v = 0;
+#pragma unroll
+                    for (int b = 0; b < 8; b++) v |= (uint64_t) sMap[(raw >> (8 * b)) & 0xFF] << (8 * b);
+                    const int nb = k - 8 * j;
+                    if (nb < 8) v &= (1ULL << (8 * nb)) - 1ULL;
+                    x |= v;
+                    const int sh = 2 * (k - 8 * (j + 1));
+                    const uint64_t g = pack2x8(v);
+                    f |= (sh >= 0) ? (g << sh) : (g >> (-sh));
+                }
+            }
+            (void) x;                                                  // (a cached window held no X and was no palindrome when it was selected)
+            const uint64_t rc = revComplementDev(f, k);
+            const bool pickRev = rc < f;
+            R r; r.kmer = pickRev ? rc : (f | BIT63); r.id = cur.id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) (pickRev ? (L - p - (uint32_t) k) : p);
+            if constexpr (LONG) r.pad = 0;
+            arr[cur.slot + 1 + i] = r;
+            posNew[cur.slot + 1 + i] = (PosT) p;
+        }
+        if (lane == 63) {
+            R r; r.kmer = xxh64U64(cur.idh, a.seed); r.id = cur.id; r.len = (decltype(r.len)) L; r.pos = 0;
+            if constexpr (LONG) r.pad = 0;
+            arr[cur.slot] = r;
+            posNew[cur.slot] = (PosT) cur.cnt; a.idHashNew[cur.id] = cur.idh;
+        }
+        for (uint32_t i = 1 + cur.cnt + (uint32_t) lane; i < bound; i += 64) { R r; memset(&r, 0xFF, sizeof(R)); arr[cur.slot + i] = r; }
+        stRes += L; stRec += 1 + cur.cnt;
     }
     if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
 }

@@ -118,8 +118,11 @@ def test_six_nucleotide_iterations_with_cyclecheck(ctx, gold, tmp_path):
     assert 2 * g["pairs"] >= 2000000 and len(g["nucl"]) >= 6
     db, _ = _reads(ctx, g)
     longest = 0
+    cached = []
     for it, want in enumerate(g["nucl"]):
-        cands, _ = ctx.kmermatcher(db, km_params(it, nucl=True))
+        n_db = db.info()["n"]
+        cands, kst = ctx.kmermatcher(db, km_params(it, nucl=True))
+        cached.append((kst.n_cached_sequences, n_db))
         cands.write(tmp_path / "pref"); check_file(tmp_path / "pref", want["pref"], "kmermatcher -k 22, iteration %d" % it)
         alns, _ = ctx.rescorediagonal(db, db, cands, plass_amd.RescoreParams(min_seq_id=0.99))
         cands.free()
@@ -136,6 +139,18 @@ def test_six_nucleotide_iterations_with_cyclecheck(ctx, gold, tmp_path):
         db = rest
     db.free()
     assert longest > 5000                                    # contigs, not reads: the long-sequence tiers ran
+    # round 6: PenguiN never changes the hash seed, so from the second or third call on every entry the chain carried over unchanged
+    # — through nuclassembleresults' dropped targets and cyclecheck's dropped circular contigs — takes its windows from the position cache
+    if os.environ.get("PLASSHIP_TUNE_KMCACHE", "1") != "2":
+        # (the first call of a fresh context writes no positions — nothing says a chain follows — so the second call may still hash everything)
+        assert cached[0][0] == 0 and all(c > n // 4 for c, n in cached[2:]), cached
+
+
+def test_six_nucleotide_iterations_in_the_long_record_layout(ctx, gold, tmp_path, monkeypatch):
+    """the same chain with kmermatcher forced into its 24-byte record layout (what a DB with an entry of 32 767 residues or more takes): the long
+    instantiations of the extraction tiers and of the position cache's kernel (u32 positions) against the same reference-pinned DBs"""
+    monkeypatch.setenv("PLASSHIP_TUNE_FORCE_LONG", "1")
+    test_six_nucleotide_iterations_with_cyclecheck(ctx, gold, tmp_path)
 
 
 @pytest.mark.timeout(1800)
