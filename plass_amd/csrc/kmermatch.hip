@@ -1011,12 +1011,43 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         if (dOv2Ids.alloc(((size_t) N + 1) * 4) != hipSuccess || dOv2Cnt.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
         PH_CHECK(hipMemsetAsync(dOv2Cnt.p, 0, 4, st));
         const uint32_t wide = std::min<uint32_t>(nMine, (uint32_t) ctx->numCU * (uint32_t) waveBlocksPerCU);
+        // (round 6) four sequences per wavefront for the sequences of the 4-scores tier (kmermatch_extract.hpp section 2e): the thread-per-sequence kernel's
+        // list sorted into four lists by window count, one launch per list; what a launch cannot finish (surplus in the threshold bin, a possible
+        // repeat) is queued for the 4-scores tier, which reads that queue instead of the list
+        ExtractArgs e0 = ea;
+        DevBuf dRowLists, dRowCounts, dRowFall, dRowFallCnt;
+        const bool rowTier = !NUCL && !LONG && twoLists && ea.waveList == dWaveList.as<uint32_t>() && fastIndex && k <= 14 && par->kmers_per_seq >= 1 && par->kmers_per_seq <= (int) KMC_POS + 1 &&
+                             par->kmers_per_seq_scale == 0.0f && tuneInt("ROWTIER", 1) == 1;      // PLASSHIP_TUNE_ROWTIER=2: the 4-scores tier takes the whole list
+        if (rowTier) {
+            const uint32_t rs = N + 1;
+            if (dRowLists.alloc((size_t) 4 * rs * 4) != hipSuccess || dRowCounts.alloc(16) != hipSuccess || dRowFall.alloc((size_t) rs * 4) != hipSuccess || dRowFallCnt.alloc(4) != hipSuccess) {
+                setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE;
+            }
+            PH_CHECK(hipMemsetAsync(dRowCounts.p, 0, 16, st));
+            PH_CHECK(hipMemsetAsync(dRowFallCnt.p, 0, 4, st));
+            hipLaunchKernelGGL(binWaveListKernel, dim3(std::min<uint32_t>((nMine + 2047) / 2048, (uint32_t) ctx->numCU * 8)), dim3(256), 0, st, (const uint32_t *) dWaveList.as<uint32_t>(), (const uint32_t *) dWaveCount.as<uint32_t>(),
+                               (const uint32_t *) db->d_len.as<uint32_t>(), (uint32_t) k, 96u, 128u, 192u, dRowLists.as<uint32_t>(), rs, dRowCounts.as<uint32_t>());
+            RowArgs ra; memset(&ra, 0, sizeof(ra));
+            ra.s = ea.s; ra.slotOff = ea.slotOff; ra.arr = ea.arr; ra.map = ea.map; ra.fallList = dRowFall.as<uint32_t>(); ra.fallCount = dRowFallCnt.as<uint32_t>();
+            ra.k = k; ra.xCode = ea.xCode; ra.kps = ea.kps; ra.ignoreMulti = ea.ignoreMulti; ra.seed = ea.seed; ra.base = (uint32_t) ea.powers[1]; ra.base7 = (uint32_t) ea.powers[7];
+            ra.slotBias = slotBias; ra.kstats = dKStats.as<unsigned long long>();
+            const dim3 rowGrid(std::min<uint32_t>((nMine + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ROWGRID", 64)));
+            const bool w5 = tuneInt("ROW_WPE", 4) == 5;
+            for (int b = 0; b < 4; b++) {
+                ra.list = dRowLists.as<uint32_t>() + (size_t) b * rs; ra.count = dRowCounts.as<uint32_t>() + b;
+                if (b == 0) { if (w5) hipLaunchKernelGGL((extractRowKernel<6, 5>), rowGrid, dim3(64), 0, st, ra); else hipLaunchKernelGGL((extractRowKernel<6, 4>), rowGrid, dim3(64), 0, st, ra); }
+                else if (b == 1) { if (w5) hipLaunchKernelGGL((extractRowKernel<8, 5>), rowGrid, dim3(64), 0, st, ra); else hipLaunchKernelGGL((extractRowKernel<8, 4>), rowGrid, dim3(64), 0, st, ra); }
+                else if (b == 2) hipLaunchKernelGGL((extractRowKernel<12, 4>), rowGrid, dim3(64), 0, st, ra);
+                else hipLaunchKernelGGL((extractRowKernel<16, 4>), rowGrid, dim3(64), 0, st, ra);
+            }
+            e0.waveList = dRowFall.as<uint32_t>(); e0.waveCount = dRowFallCnt.as<uint32_t>();
+        }
         // tiers 0 and 1 both queue into dOvIds
         if (twoLists) {
             // (round 5: tiers 0 and 1 — disjoint lists — and the cached kernel side by side on three streams: extraction 81.7 against 81.2 ms
             //  per iteration, nothing gained; profiles/r05_ab_knobs.txt)
-            if (tuneInt("TIER0_WPE", 5) == 6) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 6>), dim3(wide), dim3(64), 0, st, ea);
-            else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256>), dim3(wide), dim3(64), 0, st, ea);
+            if (tuneInt("TIER0_WPE", 5) == 6) hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256, 6>), dim3(wide), dim3(64), 0, st, e0);
+            else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 4, 256>), dim3(wide), dim3(64), 0, st, e0);
             ExtractArgs e1 = ea; e1.waveList = dLongList.as<uint32_t>(); e1.waveCount = dLongCount.as<uint32_t>();
             hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, e1);
         } else hipLaunchKernelGGL((extractKernel<NUCL, LONG, CAP, false, 16, 992>), dim3(wide), dim3(64), 0, st, ea);

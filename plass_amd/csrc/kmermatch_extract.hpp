@@ -1045,6 +1045,266 @@ __global__ __launch_bounds__(64) void extractCachedKernel(CachedArgs a) {
 }
 
 // =====================================================================================================
+// 2e. FOUR SEQUENCES PER WAVEFRONT (round 6).  The wave-per-sequence tiers pay their control — staging, the
+//     identity hash, the 16 steps of the threshold bisection, the candidate list, the repeat check, the stores — once per
+//     wavefront and sequence, and half of what they issue is scalar bookkeeping for ONE sequence (SQ_INSTS_SALU ~ SQ_INSTS_VALU,
+//     profiles/r05_pmc_lanes_per_kernel.txt).  Here a ROW of 16 lanes owns a sequence of up to 16 * REGS windows: window p is
+//     lane p % 16's register p / 16, every count is a per-lane count plus a row reduction on the DPP path (no ballots, no
+//     scalar loop per sequence), and one instruction stream drives four sequences.  Only the common outcome is finished here —
+//     the threshold bin holds no surplus and no selected k-mer repeats: the reference then selects exactly the windows at or
+//     below the threshold, in an order that does not matter (see the fast path of extractKernel) — everything else (surplus in
+//     the threshold bin, a possible repeat, a sequence too long for the instantiation) is queued for the 4-scores tier, which
+//     then owns the slot range.  Lists by window count (binWaveListKernel) keep the four sequences of a wavefront alike.
+//     Protein runs with k <= 14, alphabet base <= 16, no length scaling, --kmer-per-seq <= 60 (the Plass workflow);
+//     PLASSHIP_TUNE_ROWTIER=2 switches it off.
+// =====================================================================================================
+struct RowArgs {
+    SeqView s; const uint64_t *slotOff; void *arr; const unsigned char *map;
+    const uint32_t *list, *count;             // ids of this launch (count on the device)
+    uint32_t *fallList, *fallCount;           // what this kernel leaves to the 4-scores tier
+    int k, xCode, kps, ignoreMulti; uint64_t seed; uint32_t base, base7; uint64_t slotBias;
+    unsigned long long *kstats;               // [2] residues, [3] records (the wave tiers' counters); [4] selected-window cache lines
+};
+constexpr uint64_t rowPowU64(uint64_t b, unsigned e) { uint64_t r = 1; while (e) { if (e & 1u) r *= b; b *= b; e >>= 1; } return r; }      // modulo 2^64
+constexpr uint64_t rowInv31() { uint64_t x = 31; for (int i = 0; i < 6; i++) x *= 2ull - 31ull * x; return x; }      // Newton: 31 * 31 = 1 modulo 8, every step doubles the correct bits
+static_assert(rowInv31() * 31ull == 1ull, "inverse of 31 modulo 2^64");
+__device__ __forceinline__ uint32_t rowExclusiveScan16(uint32_t v) {      // exclusive prefix sum inside each row of 16 lanes
+    uint32_t x = v;
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xF, 0xF, true);      // row_shr:1, lanes without a source add 0
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xF, 0xF, true);
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x114, 0xF, 0xF, true);
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x118, 0xF, 0xF, true);
+    return x - v;
+}
+__device__ __forceinline__ unsigned long long rowSum16U64(unsigned long long v) {
+    v += dppMov64<0xB1>(v); v += dppMov64<0x4E>(v); v += dppMov64<0x141>(v); v += dppMov64<0x140>(v);
+    return v;
+}
+// the ids of a list sorted into four lists by window count (<= w0, <= w1, <= w2, the rest): the rows of a wavefront share their loop bounds
+__global__ __launch_bounds__(256) void binWaveListKernel(const uint32_t *__restrict__ list, const uint32_t *__restrict__ count, const uint32_t *__restrict__ len, uint32_t k,
+                                                         uint32_t w0, uint32_t w1, uint32_t w2, uint32_t *__restrict__ out, uint32_t outStride, uint32_t *__restrict__ outCount) {
+    __shared__ uint32_t sCnt[4], sBase[4];
+    const uint32_t n = *count;
+    constexpr int PER = 8;
+    for (uint64_t b0 = (uint64_t) blockIdx.x * (256 * PER); b0 < n; b0 += (uint64_t) gridDim.x * (256 * PER)) {
+        if (threadIdx.x < 4) sCnt[threadIdx.x] = 0;
+        __syncthreads();
+        int cls[PER]; uint32_t rank[PER], ids[PER];
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const uint64_t i = b0 + (uint64_t) j * 256 + threadIdx.x;
+            cls[j] = -1; rank[j] = 0; ids[j] = 0;
+            if (i < n) {
+                ids[j] = list[i];
+                const uint32_t L = len[ids[j]], nw = L >= k ? L - k + 1 : 0u;
+                cls[j] = nw <= w0 ? 0 : (nw <= w1 ? 1 : (nw <= w2 ? 2 : 3));
+                rank[j] = atomicAdd(&sCnt[cls[j]], 1u);
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 4) sBase[threadIdx.x] = sCnt[threadIdx.x] ? atomicAdd(&outCount[threadIdx.x], sCnt[threadIdx.x]) : 0u;
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < PER; j++) if (cls[j] >= 0) out[(size_t) cls[j] * outStride + sBase[cls[j]] + rank[j]] = ids[j];
+        __syncthreads();
+    }
+}
+
+template <int REGS, int WPE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE))) void extractRowKernel(RowArgs a) {
+    constexpr uint32_t MAXWIN = 16u * REGS, MAXL = MAXWIN + 13u;           // k <= 14
+    constexpr uint32_t ROWB = (MAXL + 31u + 15u) & ~15u;                    // staged codes of a row, X padding included
+    constexpr bool TWO = MAXL > 256u;                                       // a second 16-byte chunk per lane
+    constexpr uint32_t NPOW = MAXL + 17u;
+    __shared__ unsigned char sMap[256];
+    __shared__ __attribute__((aligned(16))) unsigned char sCode[4][ROWB];
+    __shared__ unsigned long long sPow[NPOW];                               // 31^(x - 15) modulo 2^64 (31 is odd: the inverse exists)
+    __shared__ unsigned short sSel[4][64];                                  // window positions of the selection, row by row
+    __shared__ __attribute__((aligned(16))) uint32_t sSet[4][128];          // repeat check: 32-bit tags of the selected k-mers
+    typedef Rec<false> R;
+    R *arr = reinterpret_cast<R *>(a.arr);
+    const int lane = threadIdx.x, row = lane >> 4, sub = lane & 15;
+    const int k = a.k;
+    if (blockIdx.x * 4u >= *a.count) return;                               // (a list shorter than the grid: nothing to set up)
+    for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
+    {
+        // 31^(lane - 15) by the bits of the lane (compile-time squares), then steps of 31^64: a block's set-up is a dozen multiplications
+        // (a first version walked 31^lane up one factor at a time — 63 dependent 64-bit products per block, and the launch preferred small grids)
+        constexpr uint64_t inv31 = rowInv31(), c0 = rowPowU64(inv31, 15), p64 = rowPowU64(31ull, 64);
+        uint64_t m = c0;
+#pragma unroll
+        for (int b = 0; b < 6; b++) if ((lane >> b) & 1) m *= rowPowU64(31ull, 1u << b);
+        for (uint32_t x = lane; x < NPOW; x += 64) { sPow[x] = m; m *= p64; }
+    }
+    __syncthreads();
+    const uint32_t nWork = *a.count;
+    const uint32_t stride = gridDim.x * 4u;
+    const uint32_t xC = (uint32_t) a.xCode;
+    const uint32_t considerRaw = (uint32_t) (a.kps - 1);                    // kmermatcher.cpp:223 with --kmer-per-seq-scale 0
+    unsigned long long stRes = 0, stRec = 0;
+    struct Meta { uint32_t id, L; uint64_t off, slot, slot1; };
+    auto loadMeta = [&](uint32_t w) {
+        Meta m; m.id = 0xFFFFFFFFu; m.L = 0; m.off = 0; m.slot = 0; m.slot1 = 0;
+        if (w < nWork) { m.id = a.list[w]; m.L = a.s.len[m.id]; m.off = a.s.off[m.id]; m.slot = a.slotOff[m.id] - a.slotBias; m.slot1 = a.slotOff[m.id + 1] - a.slotBias; }
+        return m;
+    };
+    auto loadRaw = [&](const Meta &m, uint32_t at) { uint4 v = make_uint4(0, 0, 0, 0); if (at < m.L) __builtin_memcpy(&v, a.s.data + m.off + at, 16); return v; };      // (buffers are padded past their ends)
+    uint32_t w = blockIdx.x * 4u + (uint32_t) row;
+    auto loadId = [&](uint32_t ww) { return ww < nWork ? a.list[ww] : 0xFFFFFFFFu; };
+    auto metaOf = [&](uint32_t id) {
+        Meta m; m.id = id; m.L = 0; m.off = 0; m.slot = 0; m.slot1 = 0;
+        if (id != 0xFFFFFFFFu) { m.L = a.s.len[id]; m.off = a.s.off[id]; m.slot = a.slotOff[id] - a.slotBias; m.slot1 = a.slotOff[id + 1] - a.slotBias; }
+        return m;
+    };
+    Meta mNext = loadMeta(w); uint32_t id2 = loadId(w + stride);
+    uint4 rawN0 = loadRaw(mNext, (uint32_t) sub * 16u);
+    for (uint32_t w0 = blockIdx.x * 4u; w0 < nWork; w0 += stride, w += stride) {
+        const Meta cur = mNext; const uint4 raw0 = rawN0;
+        uint4 raw1 = make_uint4(0, 0, 0, 0);
+        if (TWO) raw1 = loadRaw(cur, 256u + (uint32_t) sub * 16u);         // (the last 13 residues of the longest sequences: requested here, used behind the first chunk)
+        mNext = metaOf(id2);
+        rawN0 = loadRaw(mNext, (uint32_t) sub * 16u);
+        id2 = loadId(w + 2u * stride);
+        const bool active = cur.id != 0xFFFFFFFFu;
+        const uint32_t L = cur.L, id = cur.id;
+        const uint32_t nWin = (L >= (uint32_t) k) ? L - (uint32_t) k + 1u : 0u;
+        const bool tooLong = active && nWin > MAXWIN;                       // (the lists are binned: does not happen)
+        const uint32_t nWinU = (uint32_t) __builtin_amdgcn_readfirstlane((int) waveMaxU32((active && !tooLong) ? nWin : 0u));
+        // ---- letter codes of the row's sequence into LDS (16 per lane and chunk), the chunk's part of the identity hash on the way ----
+        unsigned long long hAcc = 0;
+        auto stageChunk = [&](const uint4 &raw, uint32_t c) {
+            const uint32_t r[4] = {raw.x, raw.y, raw.z, raw.w};
+            uint32_t cw[4];
+#pragma unroll
+            for (int d = 0; d < 4; d++)
+                cw[d] = (uint32_t) sMap[r[d] & 0xFFu] | ((uint32_t) sMap[(r[d] >> 8) & 0xFFu] << 8) | ((uint32_t) sMap[(r[d] >> 16) & 0xFFu] << 16) | ((uint32_t) sMap[r[d] >> 24] << 24);
+            if (16u * c < ROWB) *reinterpret_cast<uint4 *>(&sCode[row][16u * c]) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+            // identity hash (Util::hash, Util.h:337-345: sum code[p] * 31^(L-1-p)): the chunk's 16 codes as four base-31 quads, the quads
+            // joined by 31^4; codes at and behind L count as 0, so a partial chunk is its sum times 31^(16-m) — undone by the NEGATIVE
+            // exponent of the chunk's power 31^(L - 16 (c + 1))
+            const int m = (int) L - (int) (16u * c);
+            if (m > 0 && !tooLong) {
+                uint32_t q[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const int nb = m - 4 * d;
+                    const uint32_t z = nb >= 4 ? cw[d] : (nb <= 0 ? 0u : (cw[d] & ((1u << (8 * nb)) - 1u)));
+                    q[d] = __umul24(__umul24(__umul24(z & 0xFFu, 31u) + ((z >> 8) & 0xFFu), 31u) + ((z >> 16) & 0xFFu), 31u) + (z >> 24);
+                }
+                constexpr unsigned long long K4 = 923521ull;                 // 31^4
+                const unsigned long long H = (((unsigned long long) q[0] * K4 + q[1]) * K4 + q[2]) * K4 + q[3];
+                hAcc += H * sPow[(uint32_t) ((int) L - 16 * (int) (c + 1) + 15)];
+            }
+        };
+        stageChunk(raw0, (uint32_t) sub);
+        if (TWO) stageChunk(raw1, 16u + (uint32_t) sub);
+        if (active && !tooLong) for (uint32_t i = (uint32_t) sub; i < 31u; i += 16u) sCode[row][L + i] = (unsigned char) xC;      // X behind the sequence: every window read stays defined
+        for (uint32_t i = (uint32_t) sub * 4u; i < 128u; i += 64u) *reinterpret_cast<uint4 *>(&sSet[row][i]) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+        const unsigned long long seqHash = rowSum16U64(hAcc);
+        // ---- one score per window, in registers ----
+        uint32_t sc[REGS];
+        uint32_t nLane = 0;
+#pragma unroll
+        for (int j = 0; j < REGS; j++) {
+            sc[j] = 0xFFFFFFFFu;
+            if ((uint32_t) j * 16u < nWinU) {
+                // (every lane hashes — a window behind the row's last one reads stale codes inside the row's buffer and is discarded: the rows of a
+                //  wavefront differ in length, and a branch per row and window costs more than the masked lanes it saves)
+                const uint32_t p = (uint32_t) j * 16u + (uint32_t) sub;
+                uint64_t kmer;
+                const bool v = kmerIndexFastAligned(sCode[row], p, k, xC, a.base, a.base7, kmer);
+                const uint32_t h = xxh64Score16(kmer, a.seed);
+                const bool use = v && p < nWin && !tooLong;
+                sc[j] = use ? h : 0xFFFFFFFFu; nLane += use ? 1u : 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);      // one window's hash at a time: the temporaries of interleaved windows cost a wavefront per SIMD
+        }
+        const uint32_t n = (uint32_t) rowSum16((int) nLane);
+        const uint32_t considered = min(considerRaw, n);
+        // ---- the reference's walk over 65 536 score bins (kmermatcher.cpp:224-239) as a bisection: every count a per-lane count + a row sum ----
+        uint32_t t = 0;
+#pragma unroll 1
+        for (int bit = 15; bit >= 0; bit--) {
+            const uint32_t tr = t | (1u << bit);
+            uint32_t c = 0;
+#pragma unroll
+            for (int j = 0; j < REGS; j++) if ((uint32_t) j * 16u < nWinU) c += (sc[j] < tr) ? 1u : 0u;
+            if ((uint32_t) rowSum16((int) c) < considered) t = tr;
+        }
+        if (n <= considered) t = 0xFFFFu;                                   // every valid window is selected
+        uint32_t selMask = 0;
+#pragma unroll
+        for (int j = 0; j < REGS; j++) if ((uint32_t) j * 16u < nWinU) selMask |= (sc[j] <= t) ? (1u << j) : 0u;
+        const uint32_t cLane = (uint32_t) __popc(selMask);
+        const uint32_t C = (uint32_t) rowSum16((int) cLane);
+        bool ok = active && !tooLong && C == considered;                    // no surplus in the threshold bin
+        // ---- the selected windows' positions, row by row (any order: see the fast path of extractKernel) ----
+        {
+            uint32_t at = rowExclusiveScan16(cLane);
+            if (ok) {
+#pragma unroll
+                for (int j = 0; j < REGS; j++) if ((selMask >> j) & 1u) { sSel[row][at] = (unsigned short) ((uint32_t) j * 16u + (uint32_t) sub); at++; }
+            }
+        }
+        __syncthreads();
+        const uint64_t slot = cur.slot;
+        const uint32_t bound = (uint32_t) (cur.slot1 - cur.slot);
+        bool rep = false;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t r = (uint32_t) sub + 16u * (uint32_t) i;
+            if (ok && r < C) {
+                const uint32_t p = sSel[row][r];
+                uint64_t kmer; (void) kmerIndexFastAligned(sCode[row], p, k, xC, a.base, a.base7, kmer);
+                if (a.ignoreMulti) {      // equal k-mers have equal tags: a tag met twice sends the sequence to the tier that compares k-mers
+                    const uint64_t hx = kmer * 0x9E3779B97F4A7C15ULL;
+                    const uint32_t tag = (uint32_t) (hx >> 32) | 1u;
+                    uint32_t sl = (uint32_t) (hx >> 20) & 127u;
+                    for (;;) {
+                        const uint32_t prev = atomicCAS(&sSet[row][sl], 0u, tag);
+                        if (prev == 0u) break;
+                        if (prev == tag) { rep = true; break; }
+                        sl = (sl + 1u) & 127u;
+                    }
+                }
+                R rec; rec.kmer = kmer; rec.id = id; rec.len = (uint16_t) L; rec.pos = (int16_t) p;
+                arr[slot + 1 + r] = rec;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (rowSum16(rep ? 1 : 0) != 0) ok = false;
+        if (ok) {
+            if (sub == 15) { R rec; rec.kmer = xxh64U64(seqHash, a.seed); rec.id = id; rec.len = (uint16_t) L; rec.pos = 0; arr[slot] = rec; }      // identity record (kmermatcher.cpp:241-249)
+            for (uint32_t i = 1u + C + (uint32_t) sub; i < bound; i += 16u) { R rec; memset(&rec, 0xFF, sizeof(R)); arr[slot + i] = rec; }
+            unsigned char *cl = reinterpret_cast<unsigned char *>(a.kstats[4]);
+            if (cl) {       // selected-window cache (section 2c): the same line the wave tiers' fast path leaves
+                unsigned short *ln = reinterpret_cast<unsigned short *>(cl + (size_t) id * KMC_LINE);
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const uint32_t r = (uint32_t) sub + 16u * (uint32_t) i; if (r < KMC_POS) ln[4 + r] = (r < C) ? sSel[row][r] : (unsigned short) 0xFFFFu; }
+                if (sub == 0) *reinterpret_cast<unsigned long long *>(ln) = seqHash;
+                if (sub == 15) ln[KMC_FLAGS] = (unsigned short) KMC_CLEAN;
+            }
+            if (sub == 0) { stRes += L; stRec += 1 + C; }
+        }
+        // ---- what is left to the 4-scores tier: one atomic per wavefront ----
+        {
+            const bool fall = active && !ok && sub == 0;
+            const unsigned long long fm = __ballot(fall);
+            if (fm) {
+                uint32_t basePos = 0;
+                if (lane == 0) basePos = atomicAdd(a.fallCount, (uint32_t) __popcll(fm));
+                basePos = __shfl(basePos, 0, 64);
+                if (fall) a.fallList[basePos + (uint32_t) __popcll(fm & ((1ULL << lane) - 1ULL))] = id;
+            }
+        }
+        __syncthreads();
+    }
+    stRes = waveReduceSumU64(stRes); stRec = waveReduceSumU64(stRec);
+    if (lane == 0 && a.kstats) { atomicAdd(&a.kstats[2], stRes); atomicAdd(&a.kstats[3], stRec); }
+}
+
+// =====================================================================================================
 // 2d. the position cache of nucleotide runs (round 6).  PenguiN's nucleotide chains never change the hash seed (Nuclassembler.cpp:24,
 //     GuidedNuclassembler.cpp:25: --hash-shift stays what it is), and an iteration rewrites a minority of the sequences, so from the
 //     second call on most sequences are byte for byte what they were when kmermatcher last selected their windows.  The selection is
