@@ -1031,7 +1031,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
             ra.s = ea.s; ra.slotOff = ea.slotOff; ra.arr = ea.arr; ra.map = ea.map; ra.fallList = dRowFall.as<uint32_t>(); ra.fallCount = dRowFallCnt.as<uint32_t>();
             ra.k = k; ra.xCode = ea.xCode; ra.kps = ea.kps; ra.ignoreMulti = ea.ignoreMulti; ra.seed = ea.seed; ra.base = (uint32_t) ea.powers[1]; ra.base7 = (uint32_t) ea.powers[7];
             ra.slotBias = slotBias; ra.kstats = dKStats.as<unsigned long long>();
-            const dim3 rowGrid(std::min<uint32_t>((nMine + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ROWGRID", 64)));
+            const dim3 rowGrid(std::min<uint32_t>((nMine + 3) / 4, (uint32_t) ctx->numCU * (uint32_t) tuneInt("ROWGRID", 32)));
             const bool w5 = tuneInt("ROW_WPE", 4) == 5;
             for (int b = 0; b < 4; b++) {
                 ra.list = dRowLists.as<uint32_t>() + (size_t) b * rs; ra.count = dRowCounts.as<uint32_t>() + b;

@@ -226,6 +226,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
     const int k = a.k;
+    // (round 6: a block behind the end of its list leaves before the set-up below — 63 dependent 64-bit products for 31^lane; the grids are
+    //  192 blocks per CU and the lists of the later tiers, and of the 4-scores tier behind the row kernels, are often shorter than that)
+    if (blockIdx.x >= (FALLBACK ? a.nIds : (a.waveList ? *a.waveCount : (a.idHi - a.idLo)))) return;
     for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
     __syncthreads();
     const bool fastIdx = !NUCL && k <= 14 && a.powers[1] <= 16;      // see kmerIndexFast
