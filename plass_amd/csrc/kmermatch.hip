@@ -961,7 +961,14 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         const bool allWork = (int64_t) db->maxEntryLen - 2 - k + 1 <= (int64_t) par->kmers_per_seq - 1;      // no sequence long enough to be queued for the wave kernels
         const int padKb = tuneInt("SHORT_PAD_KB", allWork ? 16 : 8);
         const size_t padLds = padKb > 1 ? (size_t) padKb << 10 : 0;
-        if (fast && sa.base < (1u << 8) && sa.topLo < (1u << 24) && sa.topHi < (1u << 24)) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, true>), shortGrid, dim3(64), padLds, st, sa);
+        // records through LDS (extractShortFastKernel<..., STAGE>; 1: on, no residency pad; 3: on, with the pad; 2: off): measured at 50 M reads (profiles/r06_ab_knobs.txt,
+        // call 15) it takes 2.8 ms off iteration 0, where every lane works (30.5 -> 27.7 ms), and costs 1.5-2 ms in the later iterations, where a third of
+        // the lanes only queue their sequence and the flushes' barriers are paid for fewer records -> on exactly when no sequence can be queued
+        const int stageMode = LONG ? 0 : tuneInt("SHORT_STAGE", allWork ? 1 : 2);
+        if (fast && sa.base < (1u << 8) && sa.topLo < (1u << 24) && sa.topHi < (1u << 24) && (stageMode == 1 || stageMode == 3)) {
+            if constexpr (!LONG) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, true, true>), shortGrid, dim3(64), stageMode == 3 ? padLds : 0, st, sa);
+        }
+        else if (fast && sa.base < (1u << 8) && sa.topLo < (1u << 24) && sa.topHi < (1u << 24)) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, true>), shortGrid, dim3(64), padLds, st, sa);
         else if (fast) hipLaunchKernelGGL((extractShortFastKernel<LONG, KF, false>), shortGrid, dim3(64), 0, st, sa);
         else hipLaunchKernelGGL((extractShortKernel<LONG>), shortGrid, dim3(64), 0, st, sa);   // 18 wavefronts fit a CU; on large sets a finer grid evens out the tail (50 M reads, round 3: 35.7 -> 34.4 ms at 72 per CU; round 4, after the residency cap: another 0.3-1.1 ms per iteration at 144, nothing more at 288 / 576)
         ea.waveList = dWaveList.as<uint32_t>(); ea.waveCount = dWaveCount.as<uint32_t>();

@@ -850,13 +850,21 @@ __device__ __forceinline__ uint32_t waveMaxU32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t) __shfl_xor((int) v, o, 64));
     return v;
 }
-template <bool LONG, int K, bool MUL24>
+// STAGE (round 6): a lane's records go to LDS first — eight per lane, rows swizzled so that both the lanes' own 16-byte stores and the cooperative
+// reads are conflict-free — and every eight residues the wavefront writes them out TOGETHER: eight lanes per source lane, i.e. up to 128 contiguous
+// bytes per source instead of one 16-byte piece per lane and window into 64 different lines (the kernel was bound by those pieces: 44 GB of
+// write traffic for 28 GB of records at 2.2-2.6 TB/s, with resident wavefronts capped so that the half-written lines stay in the L2).
+template <bool LONG, int K, bool MUL24, bool STAGE = false>
 __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
+    static_assert(!(STAGE && LONG), "the staging rows hold 16-byte records");
     constexpr int H = K / 2;
     static_assert(K <= 16 && 16 - K + H + 3 <= 15, "the digits that leave the halves are read from the 16-byte FIFO before this iteration's codes enter it");
     __shared__ unsigned char sMap[256];
     __shared__ __attribute__((aligned(16))) unsigned short sSet[64 * 64];    // per-lane open-addressing set of tags, as above
     typedef Rec<LONG> R;
+    __shared__ __attribute__((aligned(16))) R sStage[STAGE ? 8 * 64 : 1];     // record k of lane l since the last flush: [k * 64 + ((l + 8 k) & 63)]
+    __shared__ unsigned long long sDst[STAGE ? 64 : 1];
+    __shared__ uint32_t sCnt[STAGE ? 64 : 1];
     R *arr = reinterpret_cast<R *>(a.arr);
     const int lane = threadIdx.x;
     for (int i = lane; i < 256; i += 64) sMap[i] = a.map[i];
@@ -892,6 +900,21 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
             }
             const uint32_t Lw = work ? L : 0u;                 // a lane without work has no residue inside
             uint32_t lo = 0, hi = 0, f0 = 0, f1 = 0, f2 = 0, f3 = 0, nOut = 0;
+            uint32_t nFlushed = 0;                             // STAGE: records of this lane already written out
+            auto flush = [&]() {
+                const uint32_t cnt = (work && !toWave) ? nOut - nFlushed : 0u;
+                if (__ballot(cnt != 0u)) {
+                    sDst[STAGE ? lane : 0] = slot + 1 + nFlushed; sCnt[STAGE ? lane : 0] = cnt;
+                    __syncthreads();
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; r8++) {
+                        const int sl = r8 * 8 + (lane >> 3), j = lane & 7;
+                        if ((uint32_t) j < sCnt[STAGE ? sl : 0]) arr[sDst[STAGE ? sl : 0] + (uint32_t) j] = sStage[STAGE ? (j * 64 + ((sl + 8 * j) & 63)) : 0];
+                    }
+                    __syncthreads();
+                }
+                nFlushed = nOut;
+            };
             uint64_t seqHash = 0;
             int lastX = -1;
             // sixteen residues per load (round 4: four per load fetched every 128-byte line of residues four to five times — the lanes of
@@ -945,13 +968,16 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
                         }
                         R r; r.kmer = (uint64_t) lo + (uint64_t) hi * (uint64_t) baseH; r.id = id; r.len = (decltype(r.len)) L; r.pos = (decltype(r.pos)) p;
                         if constexpr (LONG) r.pad = 0;
-                        arr[slot + 1 + nOut] = r;
+                        if constexpr (STAGE) { const uint32_t pi = nOut - nFlushed; sStage[pi * 64u + (((uint32_t) lane + 8u * pi) & 63u)] = r; }
+                        else arr[slot + 1 + nOut] = r;
                         nOut++;
                     }
                 }
                 f0 = f1; f1 = f2; f2 = f3; f3 = cw;
+                if constexpr (STAGE) { if (step & 1) flush(); }      // eight residues: at most eight records per lane
               }
             }
+            if constexpr (STAGE) flush();
             if (work && !toWave) {
                 R r; r.kmer = xxh64U64(seqHash, a.seed); r.id = id; r.len = (decltype(r.len)) L; r.pos = 0;
                 if constexpr (LONG) r.pad = 0;
