@@ -170,7 +170,7 @@ def source_sha():
 
 
 # rocprofv3 names of the kernels behind a row of the stage table (all instantiations of a template are one row)
-KERNEL_SYMBOLS = {"extractKernel": "extractKernel<", "extractShortKernel": "extractShort(Fast)?Kernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
+KERNEL_SYMBOLS = {"extractKernel": "(extractKernel<|extractRowKernel<|binWaveListKernel)", "extractShortKernel": "extractShort(Fast)?Kernel<", "groupKernel": "group(Lines)?Kernel<", "rescoreKernel": "rescoreKernel<",
                   # (MODE 0 = the hash partition of the k-mer records; the MODE 1 instantiations are the rep sort's range partitions: VERDICT r4 weak #10)
                   "partitionKernel(k-mer records)": "linePartKernel<(true|false), (true|false), 0, .*\\(plasship::LinePartArgs\\)", "assembleGroupKernel<16>": "assembleGroupKernel<16", "assembleBigKernel": "assembleBigKernel",
                   "assembleNuclKernel(+assembleNuclThreadKernel, all passes)": "assembleNucl(Thread)?Kernel<"}
@@ -207,11 +207,12 @@ def stored_traffic(kernel, launches_per_step, cfg="c3"):
 
 
 # the cost model of a sharded iteration, so that a SCALE record can be read against it phase by phase.
-# Inputs measured on ONE MI355X at 50 M reads (profiles/r05_bench_driver_cmd.log): ms per iteration of the single-GPU path by module, the part
+# Inputs measured on ONE MI355X at 50 M reads (profiles/r06_bench_driver_cmd.log): ms per iteration of the single-GPU path by module, the part
 # of kmermatcher that is NOT sharded when every rank extracts all sequences (owner-filtered extraction, the default up to 4 ranks), the
 # 1-rank overhead of the sharded orchestration (12.5 M reads: the owner's merge of the exchanged triples, packing the extended sequences);
 # link: one xGMI link per GPU pair, 76 GB/s per direction assumed.
-MODEL_50M = {"kmermatcher_ms": 213.0, "extraction_ms": 75.0, "rescore_ms": 30.0, "assemble_ms": 75.0, "other_ms": 0.0,
+# (round 6: the module times of profiles/r06_bench_driver_cmd.log — kmermatcher 203 of which extraction 63.5, rescorediagonal 29, assembleresults 76.5)
+MODEL_50M = {"kmermatcher_ms": 203.0, "extraction_ms": 63.5, "rescore_ms": 29.0, "assemble_ms": 76.5, "other_ms": 0.0,
              "shard_overhead": 0.10, "level1_line_bytes": 63e9, "triple_bytes": 5e9, "extended_bytes": 3.5e9, "link_GBs": 76.0, "host_rounds_ms": 2.0}
 
 
