@@ -911,16 +911,18 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
     typedef typename std::conditional<LONG, uint32_t, unsigned short>::type PosT;
     plasship_ctx::KmPosCache &pc = ctx->kmPosCache;
     const bool posEligible = NUCL && !cm && N && tier0 && tuneInt("CLASSIFY", 1) == 1 && tuneInt("KMCACHE", 1) == 1;      // PLASSHIP_TUNE_KMCACHE=2 switches it off
-    const bool posReuse = posEligible && pc.valid && pc.gen != 0 && db->originGen == pc.gen && db->d_origin.p && pc.lng == LONG && pc.k == k && pc.kps == par->kmers_per_seq &&
+    bool posReuse = posEligible && pc.valid && pc.gen != 0 && db->originGen == pc.gen && db->d_origin.p && pc.lng == LONG && pc.k == k && pc.kps == par->kmers_per_seq &&
                           pc.scale == par->kmers_per_seq_scale && pc.ignoreMulti == par->ignore_multi_kmer && pc.hashShift == par->hash_shift;
     // (like the lines of section 2c, the positions are only written when a later call can use them: a derived DB, or a context that has run kmermatcher before)
-    const bool posWanted = posEligible && (posReuse || db->parentGen != 0 || db->ancestorGen != 0 || db->originGen != 0 || pc.seen || ctx->kmermatchCalls > 0 || tuneInt("KMCACHE_EAGER", 0) == 1);
+    bool posWanted = posEligible && (posReuse || db->parentGen != 0 || db->ancestorGen != 0 || db->originGen != 0 || pc.seen || ctx->kmermatchCalls > 0 || tuneInt("KMCACHE_EAGER", 0) == 1);
     if (posEligible) pc.seen = true;
     ctx->kmermatchCalls++;
     DevBuf dPosNew, dIdHashNew;
     unsigned long long cachePtrs[3] = {cacheLinesPtr, 0, 0};
+    if (posWanted && (dPosNew.allocLong((size_t) (total + 1) * sizeof(PosT)) != hipSuccess || dIdHashNew.allocLong(((size_t) N + 1) * 8) != hipSuccess)) {
+        dPosNew.release(); dIdHashNew.release(); posWanted = posReuse = false;      // no room for the positions: the call works without them (and the next one hashes everything)
+    }
     if (posWanted) {
-        if (dPosNew.allocLong((size_t) (total + 1) * sizeof(PosT)) != hipSuccess || dIdHashNew.allocLong(((size_t) N + 1) * 8) != hipSuccess) { setError("kmermatch: out of device memory for the position cache"); return PLASSHIP_ERR_DEVICE; }
         cachePtrs[1] = (unsigned long long) (uintptr_t) dPosNew.p; cachePtrs[2] = (unsigned long long) (uintptr_t) dIdHashNew.p;
         if (posReuse) {
             if (dCachedList.alloc(((size_t) N + 1) * 4) != hipSuccess || dCachedCount.alloc(4) != hipSuccess) { setError("kmermatch: out of device memory"); return PLASSHIP_ERR_DEVICE; }
@@ -1024,7 +1026,9 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         ExtractArgs e0 = ea;
         DevBuf dRowLists, dRowCounts, dRowFall, dRowFallCnt;
         const bool rowTier = !NUCL && !LONG && twoLists && ea.waveList == dWaveList.as<uint32_t>() && fastIndex && k <= 14 && par->kmers_per_seq >= 1 && par->kmers_per_seq <= (int) KMC_POS + 1 &&
-                             par->kmers_per_seq_scale == 0.0f && tuneInt("ROWTIER", 1) == 1;      // PLASSHIP_TUNE_ROWTIER=2: the 4-scores tier takes the whole list
+                             par->kmers_per_seq_scale == 0.0f && (tuneInt("ROWTIER", nMine > 4000000u ? 1 : 2) & 1) == 1;      // PLASSHIP_TUNE_ROWTIER=2: the 4-scores tier takes the whole list; 3: rows whatever the size
+        // (large sets only: at 1 M reads the five extra launches in a row — each a chain of dependent round trips with the chip a tenth full — cost the
+        //  wave tiers 0.35 ms per iteration, 1.64 -> 1.99 ms; at 12.5 M reads the rows win 1.9 ms, at 50 M 5.8: profiles/r06_ab_knobs.txt)
         if (rowTier) {
             const uint32_t rs = N + 1;
             if (dRowLists.alloc((size_t) 4 * rs * 4) != hipSuccess || dRowCounts.alloc(16) != hipSuccess || dRowFall.alloc((size_t) rs * 4) != hipSuccess || dRowFallCnt.alloc(4) != hipSuccess) {

@@ -111,6 +111,15 @@ def test_twelve_iterations_of_the_headline_community(ctx, gold, tmp_path):
 
 
 @pytest.mark.timeout(1800)
+def test_twelve_iterations_through_the_row_kernels(ctx, gold, tmp_path, monkeypatch):
+    """round 6: the four-sequences-per-wavefront extraction kernels (kmermatch_extract.hpp section 2e) are used from 4 M sequences on; here they are
+    forced on the 2 M-read chain (every 49-256-window sequence of twelve iterations through them, the rare outcomes through their fall-back queue)
+    against the same reference-pinned DBs; the 12.5 M- and 50 M-read tests (tests/test_gpu_large.py) take them by default"""
+    monkeypatch.setenv("PLASSHIP_TUNE_ROWTIER", "3")
+    test_twelve_iterations_of_the_headline_community(ctx, gold, tmp_path)
+
+
+@pytest.mark.timeout(1800)
 def test_six_nucleotide_iterations_with_cyclecheck(ctx, gold, tmp_path):
     from test_gpu_parity import km_params, nucl_as_params
     import plass_amd

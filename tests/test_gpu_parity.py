@@ -48,6 +48,14 @@ def test_golden_aa_modules(ctx, golden, tmp_path, it):
     assert_same_db(f"{s}/seq_{it + 1}", tmp_path / "seq", "assembleresults")
 
 
+def test_golden_aa_modules_through_the_row_kernels(ctx, golden, tmp_path, monkeypatch):
+    """the reference-written golden DBs of the bundled example with the four-sequences-per-wavefront extraction kernels forced (round 6; by default
+    they take sets of 4 M sequences and more)"""
+    monkeypatch.setenv("PLASSHIP_TUNE_ROWTIER", "3")
+    for it in (0, 1, 2):
+        test_golden_aa_modules(ctx, golden, tmp_path, it)
+
+
 def test_golden_aa_chained_on_device(ctx, golden, tmp_path):
     """three iterations without touching disk in between: the contigs must equal the reference's"""
     import plass_amd
@@ -649,6 +657,17 @@ def test_protein_repeats_overflow_the_candidate_set(ctx, oracle_bin, tmp_path):
             scratch += st.n_scratch_sequences; restarts += st.n_restarts
             cands.free()
     assert scratch > 0 and restarts > 0, "no sequence overflowed the candidate set: the test does not reach the path it is for"
+
+
+def test_adversarial_inputs_through_the_row_kernels(ctx, golden, oracle_bin, tmp_path, monkeypatch):
+    """X runs, repeats, threshold ties and overfull candidate sets with the row kernels forced (round 6): what they cannot finish must reach the wave
+    tiers through their fall-back queue with the same records as before"""
+    monkeypatch.setenv("PLASSHIP_TUNE_ROWTIER", "3")
+    for ext in (False, True):
+        test_golden_adversarial_inputs(ctx, golden, tmp_path, ext)
+    test_adversarial_inputs_vs_oracle(ctx, oracle_bin, tmp_path)
+    test_protein_repeats_overflow_the_candidate_set(ctx, oracle_bin, tmp_path)
+    test_synthetic_three_iterations_vs_oracle(ctx, oracle_bin, tmp_path)
 
 
 def test_empty_and_singleton_db(ctx, oracle_bin, tmp_path):
