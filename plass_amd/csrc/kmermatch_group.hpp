@@ -202,8 +202,13 @@ __global__ __launch_bounds__(GR_BLOCK) void groupKernel(GroupArgs a) {
 // 2^20 buckets two partition levels can make with ~4000 positions each, which 512 threads and 4096 slots take in one go (a
 // bucket beyond the registers would be read from HBM once per phase and sub-pass).  "At least two members" is one bit per slot.
 constexpr int GL_RMAX = 8;
-template <bool NUCL, int BLOCK, uint32_t HT, int WPE>
+// LAHEAD (round 6): the fetch of a bucket is two dependent round trips (line list entry, then the record), and the counters say the
+// wavefronts are parked two thirds of their cycles (SQ_WAIT_ANY 65 %, LDS pipe 10 %).  A second set of record registers does not fit (126 of 128 VGPRs:
+// profiles/r06_ab_knobs.txt), but the LIST ENTRIES of the next bucket do — one load per thread at the start of a bucket, parked in LDS behind its first
+// phase — so that the record loads at the bucket's end start from LDS: one round trip on the critical path instead of two.
+template <bool NUCL, int BLOCK, uint32_t HT, int WPE, bool LAHEAD = false>
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) void groupLinesKernel(GroupArgs a) {
+    __shared__ uint32_t sList[LAHEAD ? GL_RMAX * BLOCK / RPL : 1];
     typedef Rec<false> R;
     constexpr uint32_t MAXKEYS = HT / 4 * 3;                 // distinct k-mers per sub-pass before splitting further
     __shared__ unsigned long long hKey[HT];
@@ -225,19 +230,26 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
     // of the previous bucket are dead — behind its last phase, ahead of the barriers that close it and of the table reset
     R rg[GL_RMAX];
     uint32_t nNext = 0, lbNext = 0;
-    auto fetch = [&](uint32_t b) {
+    auto fetch = [&](uint32_t b, bool fromLds) {
         nNext = (b < bEnd) ? a.lineCnt[b] * RPL : 0u; lbNext = (b < bEnd) ? a.lineBeg[b] : 0u;
         if (nNext && nNext <= (uint32_t) GL_RMAX * BLOCK) {
 #pragma unroll
-            for (int j = 0; j < GL_RMAX; j++) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nNext) ? in[(uint64_t) a.list[lbNext + i / RPL] * RPL + (i % RPL)] : none; }
+            for (int j = 0; j < GL_RMAX; j++) {
+                const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x;
+                const uint32_t le = (LAHEAD && fromLds) ? sList[LAHEAD ? i / RPL : 0] : a.list[lbNext + i / RPL];
+                rg[j] = (i < nNext) ? in[(uint64_t) le * RPL + (i % RPL)] : none;
+            }
         }
     };
     uint32_t par = 0;                                // which cursor the current sub-pass uses (workgroup-uniform)
-    fetch(bBegin);
+    fetch(bBegin, false);
     for (uint32_t b = bBegin; b < bEnd; b++) {
         const uint32_t n = nNext;                    // record positions of the bucket (padding sentinels included)
         const uint32_t lb = lbNext;
-        if (n == 0) { fetch(b + 1); continue; }
+        if (n == 0) { fetch(b + 1, false); continue; }
+        // (LAHEAD) the next bucket's list entries: requested here, stored to LDS behind this bucket's first phase
+        uint32_t leAhead = 0; bool aheadStored = false;
+        if (LAHEAD && b + 1 < bEnd) { const uint32_t nl = a.lineCnt[b + 1]; if (threadIdx.x < nl && nl <= (uint32_t) GL_RMAX * BLOCK / RPL) leAhead = a.list[a.lineBeg[b + 1] + threadIdx.x]; }
         auto recAt = [&](uint32_t i) -> R { return in[(uint64_t) a.list[lb + i / RPL] * RPL + (i % RPL)]; };
         const bool inRegs = n <= (uint32_t) GL_RMAX * BLOCK;
         bool fetched = false;
@@ -330,13 +342,27 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
 #pragma unroll
                     for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseA(rg[j], nSub, sub);
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseA(i < n ? recAt(i) : none, nSub, sub); }
+                if (LAHEAD && !aheadStored) { if (threadIdx.x < GL_RMAX * BLOCK / RPL) sList[LAHEAD ? threadIdx.x : 0] = leAhead; aheadStored = true; }
                 __syncthreads();
                 if (sFlag[1] || sFlag[0] > MAXKEYS) { redo = true; __syncthreads(); break; }
+                if (inRegs && LAHEAD && sub + 1 == nSub) {
+                    // last sub-pass: a record register is dead once its phase C is through — the next bucket's record takes it at once (list entries from
+                    // LDS), so the loads of registers 0..6 travel under the rest of this phase instead of starting behind it
+                    const uint32_t nN = (b + 1 < bEnd) ? a.lineCnt[b + 1] * RPL : 0u, lbN = (b + 1 < bEnd) ? a.lineBeg[b + 1] : 0u;
+                    const bool nextRegs = nN && nN <= (uint32_t) GL_RMAX * BLOCK;
+#pragma unroll
+                    for (int j = 0; j < GL_RMAX; j++) {
+                        if ((uint32_t) j * BLOCK < n) phaseC(rg[j], nSub, sub);
+                        if (nextRegs) { const uint32_t i = (uint32_t) j * BLOCK + threadIdx.x; rg[j] = (i < nN) ? in[(uint64_t) sList[LAHEAD ? i / RPL : 0] * RPL + (i % RPL)] : none; }
+                    }
+                    nNext = nN; lbNext = lbN; fetched = true;
+                } else {
                 if (inRegs) {
 #pragma unroll
                     for (int j = 0; j < GL_RMAX; j++) if ((uint32_t) j * BLOCK < n) phaseC(rg[j], nSub, sub);
                 } else for (uint32_t i0 = 0; i0 < n; i0 += BLOCK) { const uint32_t i = i0 + threadIdx.x; phaseC(i < n ? recAt(i) : none, nSub, sub); }
-                if (sub + 1 == nSub) { fetch(b + 1); fetched = true; }     // last sub-pass: nothing reads this bucket's registers again
+                if (sub + 1 == nSub) { fetch(b + 1, true); fetched = true; }     // last sub-pass: nothing reads this bucket's registers again
+                }
                 __syncthreads();
                 written += sCursor[par];
                 par ^= 1u;
@@ -346,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(WPE, WPE)
             written = writtenAtBucketStart;
             __syncthreads();
         }
-        if (!fetched) fetch(b + 1);                  // (cannot happen: the last sub-pass always completes; kept for the invariant)
+        if (!fetched) fetch(b + 1, false);           // (cannot happen: the last sub-pass always completes; kept for the invariant)
     }
     if (a.maxRepTarget) {
 #pragma unroll
