@@ -1058,13 +1058,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
     const uint32_t groupsTotal = gridDim.x * (256 / G);
     const uint32_t nWork = (G == 64) ? a.nMid : ((G == 32) ? a.nMid32 : a.nSmall);
     unsigned long long nExt = 0, nResc = 0, nRescRes = 0, nAln = 0, nQRes = 0;
-    for (uint32_t w = blockIdx.x * (256 / G) + threadIdx.x / G; w < nWork; w += groupsTotal) {
-        const uint32_t id = (G == 64) ? a.midList[w] : ((G == 32) ? a.mid32List[w] : a.smallList[w]);   // work lists: arenaSizeKernel
-        const uint64_t h0 = a.qoff[id], h1 = a.qoff[id + 1];
+    // Round 6: a query starts with a chain of dependent round trips — work list entry -> CSR offsets, arena offset, packed (offset, length), left capacity ->
+    // alignment records -> the targets' metadata -> bytes — and the counters show the wavefronts parked 57-72 % of their cycles.  The first two links travel
+    // ahead: the list entry two items ahead in every lane (one register), and the five per-query words of the next item ONE WORD PER LANE (lanes 0..4 of the
+    // group, two registers; ten registers per lane went to scratch and cost more than the look-ahead saved: profiles/r06_ab_knobs.txt, call 21), handed round
+    // with shuffles when the item's turn comes.
+    const uint32_t *workList = (G == 64) ? a.midList : ((G == 32) ? a.mid32List : a.smallList);      // work lists: arenaSizeKernel
+    auto loadWord = [&](uint32_t pid) -> uint64_t {
+        uint64_t v = 0;
+        if (pid != 0xFFFFFFFFu) {
+            if (gl == 0) v = a.qoff[pid]; else if (gl == 1) v = a.qoff[pid + 1]; else if (gl == 2) v = a.arenaOff[pid]; else if (gl == 3) v = a.s.offLen[pid]; else if (gl == 4) v = a.leftCap[pid];
+        }
+        return v;
+    };
+    uint32_t w = blockIdx.x * (256 / G) + threadIdx.x / G;
+    uint32_t idNext = (w < nWork) ? workList[w] : 0xFFFFFFFFu;
+    uint64_t wordNext = loadWord(idNext);
+    uint32_t idAhead = (w + groupsTotal < nWork) ? workList[w + groupsTotal] : 0xFFFFFFFFu;
+    for (; w < nWork; w += groupsTotal) {
+        const uint32_t id = idNext;
+        const uint64_t h0 = __shfl(wordNext, 0, G), h1 = __shfl(wordNext, 1, G), aoff = __shfl(wordNext, 2, G), qOffLen = __shfl(wordNext, 3, G), qLeftCap = __shfl(wordNext, 4, G);
+        idNext = idAhead; wordNext = loadWord(idNext);
+        idAhead = (w + 2u * groupsTotal < nWork) ? workList[w + 2u * groupsTotal] : 0xFFFFFFFFu;
         const uint32_t h = (uint32_t) (h1 - h0);
-        const uint64_t aoff = a.arenaOff[id];
-        const char *orig = a.s.data + seqOff(a.s, id);
-        unsigned querySeqLen = seqLen(a.s, id);
+        const char *orig = a.s.data + (qOffLen >> 24);
+        unsigned querySeqLen = (unsigned) ((uint32_t) qOffLen & 0xFFFFFFu);
         if (gl == 0) { nAln += h; nQRes += querySeqLen; }
         // ---- queue fill (assembleresult.cpp:161-189): lane i owns alignment i ----
         uint32_t xTarget = 0xFFFFFFFFu, xAlnLen = 0, xQLen = 0, xDbLen = 0, xState = 2, xTLen = 0; uint64_t xTOff = 0;
@@ -1090,7 +1108,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
         // tie-break of CompareResultByScore (smaller key wins) as a rank among the group's targets
         const uint32_t tRank = groupRank<G>(xTarget);
         char *buf = a.arena + aoff;
-        uint64_t curStart = a.leftCap[id];
+        uint64_t curStart = qLeftCap;
         copyBytesG<G>(buf + curStart, orig, querySeqLen, gl);
         uint64_t curLen = querySeqLen;
         bool couldExtend = false;
