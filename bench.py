@@ -211,8 +211,8 @@ def stored_traffic(kernel, launches_per_step, cfg="c3"):
 # of kmermatcher that is NOT sharded when every rank extracts all sequences (owner-filtered extraction, the default up to 4 ranks), the
 # 1-rank overhead of the sharded orchestration (12.5 M reads: the owner's merge of the exchanged triples, packing the extended sequences);
 # link: one xGMI link per GPU pair, 76 GB/s per direction assumed.
-# (round 6: the module times of profiles/r06_bench_driver_cmd.log — kmermatcher 203 of which extraction 63.5, rescorediagonal 29, assembleresults 76.5)
-MODEL_50M = {"kmermatcher_ms": 203.0, "extraction_ms": 63.5, "rescore_ms": 29.0, "assemble_ms": 76.5, "other_ms": 0.0,
+# (round 6: the module times of profiles/r06_bench_driver_cmd.log — kmermatcher 193.6 of which extraction 63.5, rescorediagonal 28.6, assembleresults 75.0)
+MODEL_50M = {"kmermatcher_ms": 193.6, "extraction_ms": 63.5, "rescore_ms": 28.6, "assemble_ms": 75.0, "other_ms": 0.0,
              "shard_overhead": 0.10, "level1_line_bytes": 63e9, "triple_bytes": 5e9, "extended_bytes": 3.5e9, "link_GBs": 76.0, "host_rounds_ms": 2.0}
 
 
