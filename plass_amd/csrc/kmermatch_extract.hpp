@@ -875,13 +875,34 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
     const bool multi = a.ignoreMulti != 0;
     auto digitMul = [&](uint32_t d, uint32_t pw) -> uint32_t { return MUL24 ? __umul24(d, pw) : d * pw; };
     unsigned long long stRes = 0, stRec = 0;
-    for (uint32_t b0 = a.idLo + blockIdx.x * 64; b0 < a.idHi; b0 += gridDim.x * 64) {
+    // Round 6: the ids of a block's rounds are arithmetic, so the index words of the round after next (length, offset, slot range) and the first sixteen
+    // residues of the next round's sequences are requested while the current round is worked on: a round used to START with three dependent round trips
+    // (length -> offset and slots -> residues), and the counters showed the wavefronts parked 57 % of their cycles (profiles/r06_calls/call13_pmc_b.txt).
+    struct Ahead { uint32_t L; uint64_t off, slot, slot1; };
+    auto loadAhead = [&](uint64_t idw) { Ahead m; m.L = 0; m.off = 0; m.slot = 0; m.slot1 = 0; if (idw < (uint64_t) a.idHi) { m.L = a.s.len[idw]; m.off = a.s.off[idw]; m.slot = a.slotOff[idw]; m.slot1 = a.slotOff[idw + 1]; } return m; };
+    auto isShort = [&](uint32_t Lx) { const uint32_t nw = (Lx >= (uint32_t) K) ? (Lx - K + 1) : 0; const size_t cr = (size_t) ((float) (a.kps - 1) + (a.scale * (float) Lx)); return !(Lx > SHORT_MAXL || (size_t) nw > cr || (multi && nw > 48)); };
+    auto firstBytes = [&](const Ahead &m, uint64_t idw) { uint4 v = make_uint4(0, 0, 0, 0); if (idw < (uint64_t) a.idHi && m.L && isShort(m.L)) __builtin_memcpy(&v, a.s.data + m.off, 16); return v; };      // (the buffer is padded past its end)
+    // (not with STAGE — iteration 0, every lane working, the kernel at its write bandwidth: measured 27.7 -> 32.7 ms with the look-ahead, call 23 — there the
+    //  words of a round are requested together at its start, one round trip ahead of the residues)
+    constexpr bool AHEAD = !STAGE;
+    const uint64_t strideIds = (uint64_t) gridDim.x * 64;
+    uint64_t bw = (uint64_t) a.idLo + (uint64_t) blockIdx.x * 64;
+    Ahead mCur = {0, 0, 0, 0}, mNext = {0, 0, 0, 0};
+    uint4 bytesCur = make_uint4(0, 0, 0, 0);
+    if (AHEAD) { mCur = loadAhead(bw + lane); mNext = loadAhead(bw + strideIds + lane); bytesCur = firstBytes(mCur, bw + lane); }
+    for (uint32_t b0 = a.idLo + blockIdx.x * 64; b0 < a.idHi; b0 += gridDim.x * 64, bw += strideIds) {
         const uint32_t id = b0 + lane;
         const bool active = id < a.idHi;
+        Ahead cur; uint4 curBytes;
+        if (AHEAD) {
+            cur = mCur; curBytes = bytesCur;
+            mCur = mNext; bytesCur = firstBytes(mCur, bw + strideIds + lane);
+            mNext = loadAhead(bw + 2 * strideIds + lane);
+        } else { cur = loadAhead(bw + lane); curBytes = firstBytes(cur, bw + lane); }
         bool toWave = false, lenWave = false;
         uint32_t L = 0;
         if (active) {
-            L = a.s.len[id];
+            L = cur.L;
             const uint32_t nWin = (L >= (uint32_t) K) ? (L - K + 1) : 0;
             const size_t consideredRaw = (size_t) ((float) (a.kps - 1) + (a.scale * (float) L));
             // (more than 48 windows would overfill the 64-slot tag set: the kernel above hands such a sequence over at its 49th
@@ -894,8 +915,8 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
             const char *base = a.s.data;
             uint64_t slot = 0; uint32_t bound = 0;
             if (work) {
-                base += a.s.off[id];
-                slot = a.slotOff[id] - a.slotBias; bound = (uint32_t) (a.slotOff[id + 1] - a.slotOff[id]);
+                base += cur.off;
+                slot = cur.slot - a.slotBias; bound = (uint32_t) (cur.slot1 - cur.slot);
                 if (multi) { uint4 z = make_uint4(0, 0, 0, 0); uint4 *q = reinterpret_cast<uint4 *>(mySet); for (int i = 0; i < 8; i++) q[i] = z; }
             }
             const uint32_t Lw = work ? L : 0u;                 // a lane without work has no residue inside
@@ -921,8 +942,7 @@ __global__ __launch_bounds__(64) void extractShortFastKernel(ShortArgs a) {
             // the resident wavefronts keep more lines open than the L1 and L2 hold — 23 GB read for 4 GB of residues); the NEXT sixteen
             // are requested before this round's are used: the load is the head of a chain of dependent round trips (residues -> letter
             // codes in LDS -> tag set in LDS -> store)
-            uint4 bufNext = make_uint4(0, 0, 0, 0);
-            if (Lw) __builtin_memcpy(&bufNext, base, 16);                                   // the buffer is padded past its end
+            uint4 bufNext = Lw ? curBytes : make_uint4(0, 0, 0, 0);                        // (requested a round ago)
             for (uint32_t i0 = 0; i0 < Lmax; i0 += 16) {
                 const uint4 buf = bufNext;
                 bufNext = make_uint4(0, 0, 0, 0);
