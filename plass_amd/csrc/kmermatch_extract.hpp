@@ -313,9 +313,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(WPE ? WPE : 
         }
         if (useRegs) {
             // ---- codes to LDS (padded with X so that every window read stays inside the staged bytes) ----
-            for (uint32_t i = lane; i < L + 31; i += 64) {
-                const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < 192) ? cb2 : ((i < 256) ? cb3 : ((i < L) ? base[i] : (char) 0))));      // first 256 bytes were prefetched
-                sCodeAll[i] = (i < L) ? sMap[(unsigned char) ch] : (unsigned char) a.xCode;
+            // Round 6: what lies behind the 256 prefetched bytes is fetched SIXTEEN bytes per lane, all loads of a sequence in flight together.  (Until
+            // then the loop below went on byte by byte — 64 bytes per load instruction, each load waited for before the next was issued: up to 13
+            // dependent round trips for a 1 000-residue sequence, 45 in the 48-scores tier; the counters showed the tiers parked 50-60 % of their cycles.)
+            {
+                const uint32_t head = min(L + 31u, 256u);
+                for (uint32_t i = lane; i < head; i += 64) {
+                    const char ch = (i < 64) ? cb0 : ((i < 128) ? cb1 : ((i < 192) ? cb2 : cb3));      // the first 256 bytes were prefetched
+                    sCodeAll[i] = (i < L) ? sMap[(unsigned char) ch] : (unsigned char) a.xCode;
+                }
+                if (L + 31u > 256u) {
+                    constexpr int NCH = (int) ((CODES - 256u + 1023u) / 1024u);
+                    uint4 wv[NCH];
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) { const uint32_t p = 256u + 1024u * (uint32_t) c + 16u * (uint32_t) lane; wv[c] = make_uint4(0, 0, 0, 0); if (p < L) __builtin_memcpy(&wv[c], base + p, 16); }      // (buffers are padded past their ends)
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) {
+                        const uint32_t p = 256u + 1024u * (uint32_t) c + 16u * (uint32_t) lane;
+                        if (p < L + 31u && p + 16u <= CODES) {
+                            const uint32_t r4[4] = {wv[c].x, wv[c].y, wv[c].z, wv[c].w};
+                            uint32_t cw[4];
+#pragma unroll
+                            for (int d = 0; d < 4; d++) {
+                                uint32_t v = 0;
+#pragma unroll
+                                for (int b = 0; b < 4; b++) { const uint32_t q = p + 4u * (uint32_t) d + (uint32_t) b; v |= (uint32_t) ((q < L) ? sMap[(r4[d] >> (8 * b)) & 0xFFu] : (unsigned char) a.xCode) << (8 * b); }
+                                cw[d] = v;
+                            }
+                            *reinterpret_cast<uint4 *>(&sCodeAll[p]) = make_uint4(cw[0], cw[1], cw[2], cw[3]);
+                        }
+                    }
+                }
             }
             __syncthreads();
             // identity hash (Util::hash, Util.h:337-345: h = h*31 + code, i.e. sum code[p] * 31^(L-1-p) modulo 2^64): lane l owns the
