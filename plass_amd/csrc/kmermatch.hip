@@ -506,7 +506,7 @@ static int kmermatchLines(plasship_ctx *ctx, const plasship_seqdb *db, const pla
         if (geo.nb2) arenaBuf = dRx.p;
         else { if (dArena.alloc(std::max<uint64_t>(finalCap, 1) * RPL * sizeof(R)) != hipSuccess) { setError("kmermatch: out of device memory for the grouped records"); return PLASSHIP_ERR_DEVICE; } arenaBuf = dArena.p; }
     } else arenaBuf = geo.nb2 ? dB.p : dA.p;
-    const uint32_t gBlocks = std::max<uint32_t>(1, std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 6)));
+    const uint32_t gBlocks = std::max<uint32_t>(1, std::min<uint32_t>(nBuckets, (uint32_t) numCU * (uint32_t) tuneInt("GROUP", 24)));      // (6 until round 6; with the look-ahead 24 measures 1 ms better at 50 M reads — smaller arenas for the rep sort: profiles/r06_ab_knobs.txt, call 26)
     const uint32_t bpb = (std::max<uint32_t>(nBuckets, 1) + gBlocks - 1) / gBlocks;
     const uint32_t gGrid = (std::max<uint32_t>(nBuckets, 1) + bpb - 1) / bpb;
     DevBuf dOutCnt, dArenaStart, dMaxRT, dLastRun;
@@ -955,7 +955,7 @@ int kmermatchImpl(plasship_ctx *ctx, const plasship_seqdb *db, const plasship_km
         uint64_t pwH = 1; for (int i = 0; i < HF; i++) pwH *= sa.base;
         if (pwH * 2 >= (1ull << 32)) fast = false;
         sa.topLo = (uint32_t) (pwH / sa.base); sa.topHi = (uint32_t) ea.powers[KF - HF - 1]; sa.baseH = (uint32_t) pwH;
-        const dim3 shortGrid(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", nMine > 20000000u ? 144 : 18)));
+        const dim3 shortGrid(std::min<uint32_t>((nMine + 63) / 64, (uint32_t) ctx->numCU * (uint32_t) tuneInt("SHORT", nMine > 20000000u ? 288 : 18)));
         // Resident wavefronts (round 4): every working lane has one partly written 128-byte line of records open; at the 18 wavefronts per CU
         // the kernel's own LDS allows, those are 4.7 MB per XCD against 4 MB of L2 — lines leave the L2 half written and the kernel moves
         // 71 GB for 35 GB of records (profiles/r03_pmc_hbm_traffic.txt).  Unused dynamic LDS caps the residency: 8 KB more per wavefront
