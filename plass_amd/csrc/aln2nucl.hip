@@ -44,8 +44,18 @@ __global__ __launch_bounds__(256) void aln2nuclKernel(A2NArgs a) {
         const char *q = nq + r.qStart, *t = nt + r.dbStart;
         const int n3 = cnt * 3;
         int ids = 0, score = 0;
-        for (int p = 0; p < n3; p += 8) {
-            uint64_t qw, tw; __builtin_memcpy(&qw, q + p, 8); __builtin_memcpy(&tw, t + p, 8);     // buffers are padded past their ends
+        // (round 6: sixteen columns per load and the NEXT sixteen requested before these are scored — the walk was a chain of one dependent round trip
+        //  per eight columns, 15 of them for a 40-residue protein alignment)
+        uint64_t qn2[2], tn2[2];
+        __builtin_memcpy(qn2, q, 16); __builtin_memcpy(tn2, t, 16);                                  // buffers are padded past their ends
+        for (int p0 = 0; p0 < n3; p0 += 16) {
+            const uint64_t q2[2] = {qn2[0], qn2[1]}, t2[2] = {tn2[0], tn2[1]};
+            if (p0 + 16 < n3) { __builtin_memcpy(qn2, q + p0 + 16, 16); __builtin_memcpy(tn2, t + p0 + 16, 16); }
+#pragma unroll
+          for (int h = 0; h < 2; h++) {
+            const int p = p0 + 8 * h;
+            if (p >= n3) break;
+            uint64_t qw = q2[h], tw = t2[h];
             const int m = min(8, n3 - p);
             // columns behind the end are blanked (byte 0 in both words) and their lookups of entry [0][0] taken off again: eight
             // unconditional lookups per step that go out together.  ([0][0] itself is a legitimate entry here: like the reference,
@@ -60,6 +70,7 @@ __global__ __launch_bounds__(256) void aln2nuclKernel(A2NArgs a) {
                 score += (int) smat[a * 123 + b];
             }
             score -= (8 - m) * (int) smat[0];
+          }
         }
         r.rawScore = score;
         r.bitScore = (int) (fma(a.lambda, (double) score, -a.logK) / a.ln2);      // implicit double -> int in the reference: truncation

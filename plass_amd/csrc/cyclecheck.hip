@@ -81,7 +81,7 @@ struct CycTabArgs {
 template <int THREADS, int SLOTS, int STAGE>      // STAGE: longest sequence whose letter codes are staged in LDS (0: read from HBM)
 __global__ __launch_bounds__(THREADS) void cycleTableKernel(CycTabArgs a) {
     __shared__ unsigned char sMap[256];
-    __shared__ unsigned char sNum[STAGE ? STAGE + 8 : 8];
+    __shared__ __attribute__((aligned(16))) unsigned char sNum[STAGE ? STAGE + 32 : 16];
     __shared__ unsigned long long sTab[SLOTS];
     __shared__ uint32_t sHits, sFirst, sOver;
     const uint32_t tid = threadIdx.x;
@@ -90,16 +90,42 @@ __global__ __launch_bounds__(THREADS) void cycleTableKernel(CycTabArgs a) {
     for (uint32_t i = tid; i < 256; i += THREADS) sMap[i] = a.map[i];
     __syncthreads();
     uint32_t *hist = a.hist + (uint64_t) blockIdx.x * a.histStride;
+    // Round 6: a sequence used to start with list entry -> length, offset -> its letters BYTE BY BYTE (one 64- or 256-byte load instruction per trip of the
+    // staging loop, each waited for: 6 / 24 / 48 dependent loads in the three staged tiers).  Now the list entry travels two sequences ahead, length and
+    // offset one ahead, and the letters are fetched 16 bytes per thread with all loads of a sequence in flight together.
+    uint32_t idNext = blockIdx.x < a.nList ? a.list[blockIdx.x] : 0u;
+    uint32_t idAhead = blockIdx.x + gridDim.x < a.nList ? a.list[blockIdx.x + gridDim.x] : 0u;
+    uint32_t LNext = blockIdx.x < a.nList ? a.s.len[idNext] : 0u; uint64_t offNext = blockIdx.x < a.nList ? a.s.off[idNext] : 0ull;
     for (uint32_t w = blockIdx.x; w < a.nList; w += gridDim.x) {
-        const uint32_t id = a.list[w];
-        const uint32_t L = a.s.len[id];
-        const char *seq = a.s.data + a.s.off[id];
+        const uint32_t id = idNext;
+        const uint32_t L = LNext;
+        const char *seq = a.s.data + offNext;
+        idNext = idAhead;
+        if (w + gridDim.x < a.nList) { LNext = a.s.len[idNext]; offNext = a.s.off[idNext]; }
+        idAhead = (w + 2 * gridDim.x < a.nList) ? a.list[w + 2 * gridDim.x] : 0u;
         const uint32_t third = L / 3, nk = L - CC_K + 1, nBins = 2 * third + 1;
         // positions by class (kmerClass): front [1, third + 1], middle [third + 2, 2 third + 1], back [2 third + 2, nk - 1]; position 0 is
         // "back" too, but its diagonals are <= 0 and never counted
         const uint32_t fLo = 1, fHi = min(third + 1, nk - 1), mLo = third + 2, mHi = min(2 * third + 1, nk - 1), bLo = 2 * third + 2, bHi = nk - 1;
         const uint32_t passes = a.forcePasses ? a.forcePasses : (third + 2 + SLOTS / 2 - 1) / (SLOTS / 2);          // load <= 0.5 per pass on average
-        if (STAGE) for (uint32_t i = tid; i < L; i += THREADS) sNum[i] = sMap[(unsigned char) seq[i]];
+        if (STAGE) {
+            constexpr int NCH = STAGE ? (STAGE + 16 * THREADS - 1) / (16 * THREADS) : 1;
+            uint4 wv[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { const uint32_t p = 16u * ((uint32_t) c * THREADS + tid); wv[c] = make_uint4(0, 0, 0, 0); if (p < L) __builtin_memcpy(&wv[c], seq + p, 16); }      // (buffers are padded past their ends)
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                const uint32_t p = 16u * ((uint32_t) c * THREADS + tid);
+                if (p < L) {
+                    const uint32_t r4[4] = {wv[c].x, wv[c].y, wv[c].z, wv[c].w};
+                    uint32_t cw[4];
+#pragma unroll
+                    for (int d = 0; d < 4; d++)
+                        cw[d] = (uint32_t) sMap[r4[d] & 0xFFu] | ((uint32_t) sMap[(r4[d] >> 8) & 0xFFu] << 8) | ((uint32_t) sMap[(r4[d] >> 16) & 0xFFu] << 16) | ((uint32_t) sMap[r4[d] >> 24] << 24);
+                    *reinterpret_cast<uint4 *>(&sNum[p]) = make_uint4(cw[0], cw[1], cw[2], cw[3]);      // (codes behind L are never read)
+                }
+            }
+        }
         if (tid == 0) { sHits = 0; sFirst = 0xFFFFFFFFu; sOver = 0; }
         __syncthreads();
         auto code = [&](uint32_t i) -> unsigned long long { return STAGE ? (unsigned long long) sNum[i] : (unsigned long long) sMap[(unsigned char) seq[i]]; };
