@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6, GPU call 36: position cache kernel, two records per lane with both windows in flight; grid 64 per CU
+# round 6, GPU call 35: the position cache's kernel with every link of its chain a sequence earlier than the next (list entry 4 ahead ... positions 1 ahead)
 cd "$GRAFT_REPO_ROOT" || exit 1
 O=gpurun_out/r06_call35; mkdir -p $O
 export PYTHONUNBUFFERED=1
@@ -10,4 +10,5 @@ d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); s=d['roofline']['
 print('c5 %-40s %.1f verify %s | ext %.1f+%.1f km %.1f' % (sys.argv[1], d['ms_per_step'], d['verify'].get('match'), s['extractShortKernel'], s['extractKernel'], s['kmermatcher_stage']))
 print('      extraction per step: ' + ' '.join('%.1f' % r.get('extract_ms', -1) for r in d['iterations']))" "$*" | tee -a $O/sweep.txt; }
 run5 X=0
+run5 PLASSHIP_TUNE_CACHEDPOS=64
 run5 PLASSHIP_TUNE_KMCACHE=2
